@@ -1,0 +1,116 @@
+"""ctypes binding of the C ABI (include/alfalfa_amd.h) -- the same stub a cgo/JNI/N-API binding would write.
+
+The library is built in-tree by alfalfa_amd.build (hipcc, gfx950).  There is no Python or CPU
+implementation behind these calls: if the library is missing or has no GPU to run on, they raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+AA_OK = 0
+ERR_NAMES = {-1: "Invalid", -2: "Unsupported", -3: "LogicError", -4: "OutOfRange", -5: "HipError",
+             -6: "NoDevice", -7: "BadArgument"}
+
+AA_MB_HAS_NONZERO, AA_MB_HAS_Y2, AA_MB_INTER, AA_MB_SKIP, AA_MB_LF_SKIP_INNER = 1, 2, 4, 8, 16
+
+MB_INFO_DTYPE = np.dtype([("y_mode", "u1"), ("uv_mode", "u1"), ("ref_frame", "u1"), ("segment_id", "u1"),
+                          ("flags", "u1"), ("lf_level", "u1"), ("split_partition", "u1"), ("reserved", "u1"),
+                          ("nz_mask", "<u4"), ("coeff_index", "<u4"), ("u", "u1", (64,))])
+assert MB_INFO_DTYPE.itemsize == 80
+
+
+class FrameHeader(C.Structure):
+    _fields_ = [(n, C.c_uint8) for n in (
+        "key_frame", "show_frame", "loop_filter_level", "sharpness_level", "num_dct_partitions",
+        "segmentation_enabled", "filter_adjustments_enabled", "refresh_last", "refresh_golden",
+        "refresh_alternate", "copy_buffer_to_golden", "copy_buffer_to_alternate", "sign_bias_golden",
+        "sign_bias_alternate", "q_index", "has_intra_mb")] + [
+        ("mb_width", C.c_uint16), ("mb_height", C.c_uint16), ("width", C.c_uint16), ("height", C.c_uint16),
+        ("quant", (C.c_uint16 * 6) * 4), ("num_macroblocks", C.c_uint32), ("num_coeff_blocks", C.c_uint32),
+        ("num_intra_mbs", C.c_uint32), ("compressed_size", C.c_uint32)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "quant"}
+        d["quant"] = [[self.quant[s][k] for k in range(6)] for s in range(4)]
+        return d
+
+
+class KernelStats(C.Structure):
+    _fields_ = [("recon_inter_ms", C.c_double), ("recon_intra_ms", C.c_double), ("loopfilter_ms", C.c_double),
+                ("recon_inter_launches", C.c_uint64), ("recon_intra_launches", C.c_uint64),
+                ("loopfilter_launches", C.c_uint64), ("macroblocks", C.c_uint64)]
+
+
+class AlfalfaError(RuntimeError):
+    """Mirrors the reference's exception types (exception.hh:76-98) by name in `.kind`."""
+
+    def __init__(self, code, message):
+        super().__init__("%s: %s" % (ERR_NAMES.get(code, str(code)), message))
+        self.code, self.kind, self.message = code, ERR_NAMES.get(code, str(code)), message
+
+
+# every entry point declared in include/alfalfa_amd.h: (name, restype, argtypes)
+_P = C.c_void_p
+_U8P = C.POINTER(C.c_uint8)
+SYMBOLS = [
+    ("aa_last_error", C.c_char_p, []), ("aa_abi_version", C.c_int, []), ("aa_device_count", C.c_int, []),
+    ("aa_parser_create", C.c_int, [C.c_uint16, C.c_uint16, C.POINTER(_P)]), ("aa_parser_destroy", None, [_P]),
+    ("aa_parser_parse", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(FrameHeader), _P, _P]),
+    ("aa_parser_get_probs", C.c_int, [_P, _U8P]),
+    ("aa_parser_get_segmentation", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int8), C.POINTER(C.c_int8), _U8P]),
+    ("aa_parser_get_filter_adjustments", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int8), C.POINTER(C.c_int8)]),
+    ("aa_ctx_create", C.c_int, [C.c_int, C.POINTER(_P)]), ("aa_ctx_destroy", None, [_P]), ("aa_ctx_sync", C.c_int, [_P]),
+    ("aa_ctx_compute_stream", _P, [_P]), ("aa_ctx_copy_stream", _P, [_P]),
+    ("aa_stream_create", C.c_int, [_P, C.c_uint16, C.c_uint16, C.POINTER(_P)]), ("aa_stream_destroy", None, [_P]),
+    ("aa_stream_parse", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(FrameHeader)]),
+    ("aa_stream_upload", C.c_int, [_P]),
+    ("aa_decode_batch", C.c_int, [_P, C.POINTER(_P), C.c_int, C.POINTER(C.c_int)]),
+    ("aa_stream_decode", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("aa_stream_frame_count", C.c_int, [_P]), ("aa_stream_release_before", C.c_int, [_P, C.c_int]),
+    ("aa_stream_rewind", C.c_int, [_P]),
+    ("aa_stream_download", C.c_int, [_P, C.c_int, _P, _P, _P]),
+    ("aa_stream_raster_device", C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    ("aa_stream_references", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("aa_stream_import_reference", C.c_int, [_P, _P, _P, _P]),
+    ("aa_stream_import_reference_host", C.c_int, [_P, _P, _P, _P]),
+    ("aa_raster_geometry", None, [C.c_uint16, C.c_uint16, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("aa_ctx_profile", C.c_int, [_P, C.c_int]), ("aa_ctx_kernel_stats", C.c_int, [_P, C.POINTER(KernelStats), C.c_int]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load (building if stale) the native library.  Raises if it cannot be built or loaded: no fallback."""
+    global _lib
+    if _lib is None:
+        path = _build.LIB
+        if _build.stale():
+            if os.path.exists(_build.HIPCC):
+                _build.build()
+            elif not os.path.exists(path):
+                raise RuntimeError("libalfalfa_amd.so is missing and hipcc is not available: there is no CPU fallback")
+        L = C.CDLL(path)
+        for name, restype, argtypes in SYMBOLS:
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = restype, argtypes
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != AA_OK:
+        raise AlfalfaError(rc, lib().aa_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return lib().aa_device_count()
+
+
+def raster_geometry(width, height):
+    pw, ph = C.c_uint32(), C.c_uint32()
+    lib().aa_raster_geometry(width, height, C.byref(pw), C.byref(ph))
+    return pw.value, ph.value

@@ -1,0 +1,36 @@
+// Records the HIP kernels read, as laid out in HBM.  Shared by runtime.cpp (host) and kernels.hip (device).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/alfalfa_amd.h"
+
+// One decoded-frame job, resident in HBM (one per (stream, frame)); built by the host when the frame is
+// parsed: raster slots are assigned then (References bookkeeping = Frame::copy_to, frame.cc:271-307), so a
+// job is self-contained and can be (re)played without touching the host.
+struct aa_dev_frame {
+  uint8_t * cur[3];            // output raster planes Y,U,V (padded, stride = padded width; raster.hh:54-56)
+  const uint8_t * ref[4][3];   // [1] last, [2] golden, [3] altref planes ([0] unused)
+  const aa_mb_info * mbs;      // mb_width*mb_height records
+  const int16_t * coeffs;      // compact 16-coefficient blocks
+  uint16_t quant[4][6];        // per segment {y_dc,y_ac,y2_dc,y2_ac,uv_dc,uv_ac}
+  uint16_t mbw, mbh;
+  uint8_t key_frame;
+  uint8_t loop_filter_level;   // header value (0: no filtering at all)
+  uint8_t sharpness;
+  uint8_t has_intra;
+  uint32_t pad;
+};
+
+#define AA_MAX_BATCH 120       // frames per launch: kernel argument = 120 pointers (960 B) passed by value
+
+struct aa_frame_list {
+  const aa_dev_frame * f[AA_MAX_BATCH];
+};
+
+// kernels.hip launchers (plain C++ signatures so runtime.cpp needs no HIP kernel syntax)
+struct aa_launch_timing;
+namespace aa {
+int launch_recon_inter( const aa_frame_list & list, int n, unsigned max_mbs, void * stream );
+int launch_recon_intra_diagonal( const aa_frame_list & list, int n, int diagonal, int row_lo, int rows, void * stream );
+int launch_loopfilter_diagonal( const aa_frame_list & list, int n, int diagonal, int row_lo, int rows, void * stream );
+}

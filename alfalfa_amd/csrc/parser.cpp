@@ -1,0 +1,521 @@
+// Host-side VP8 frame parser (see parser.hh for the reference functions it replaces).
+#include "parser.hh"
+
+#include <cstring>
+
+#include "bool_reader.hh"
+#include "vp8_tables.h"
+
+namespace aa {
+
+namespace {
+
+enum MbMode : uint8_t { DC_PRED, V_PRED, H_PRED, TM_PRED, B_PRED, NEARESTMV, NEARMV, ZEROMV, NEWMV, SPLITMV };
+enum BMode : uint8_t { B_DC_PRED, B_TM_PRED, B_VE_PRED, B_HE_PRED, B_LD_PRED, B_RD_PRED, B_VR_PRED, B_VL_PRED,
+                       B_HD_PRED, B_HU_PRED, LEFT4X4, ABOVE4X4, ZERO4X4, NEW4X4 };
+enum RefFrame : uint8_t { CURRENT_FRAME, LAST_FRAME, GOLDEN_FRAME, ALTREF_FRAME };
+enum BlockType { Y_AFTER_Y2 = 0, Y2 = 1, UV = 2, Y_WITHOUT_Y2 = 3 };   // block.hh:46
+
+// RFC 6386 trees as in modemv_data.cc:162-281
+constexpr int8_t kKfYModeTree[8] = { -B_PRED, 2, 4, 6, -DC_PRED, -V_PRED, -H_PRED, -TM_PRED };
+constexpr int8_t kYModeTree[8] = { -DC_PRED, 2, 4, 6, -V_PRED, -H_PRED, -TM_PRED, -B_PRED };
+constexpr int8_t kUvModeTree[6] = { -DC_PRED, 2, -V_PRED, 4, -H_PRED, -TM_PRED };
+constexpr int8_t kBModeTree[18] = { -B_DC_PRED, 2, -B_TM_PRED, 4, -B_VE_PRED, 6, 8, 12, -B_HE_PRED, 10,
+                                    -B_RD_PRED, -B_VR_PRED, -B_LD_PRED, 14, -B_VL_PRED, 16, -B_HD_PRED, -B_HU_PRED };
+constexpr int8_t kSmallMvTree[14] = { 2, 8, 4, 6, -0, -1, -2, -3, 10, 12, -4, -5, -6, -7 };
+constexpr int8_t kMvRefTree[8] = { -ZEROMV, 2, -NEARESTMV, 4, -NEARMV, 6, -NEWMV, -SPLITMV };
+constexpr int8_t kSubMvRefTree[6] = { -LEFT4X4, 2, -ABOVE4X4, 4, -ZERO4X4, -NEW4X4 };
+constexpr int8_t kSplitMvTree[6] = { -3, 2, -2, 4, -0, -1 };
+constexpr int8_t kSegmentIdTree[6] = { 2, 4, -0, -1, -2, -3 };
+
+constexpr uint8_t kZigzag[16] = { 0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15 };
+constexpr uint8_t kBand[16] = { 0, 1, 2, 3, 6, 4, 5, 6, 6, 6, 6, 6, 6, 6, 6, 7 };
+
+// mv_partitions (modemv_data.cc:245-276): partition index of each raster-order sub-block
+constexpr uint8_t kSplitLayout[4][16] = { { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1 },
+                                          { 0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1, 1 },
+                                          { 0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3 },
+                                          { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15 } };
+constexpr uint8_t kSplitFirst[4][16] = { { 0, 8 }, { 0, 2 }, { 0, 2, 8, 10 }, { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15 } };
+constexpr uint8_t kSplitCount[4] = { 2, 2, 4, 16 };
+
+struct Mv { int16_t x = 0, y = 0; bool zero() const { return x == 0 && y == 0; } bool operator==( const Mv & o ) const { return x == o.x && y == o.y; } };
+
+inline int clamp( int v, int lo, int hi ) { return v < lo ? lo : ( v > hi ? hi : v ); }
+
+// MotionVector::read_component, macroblock.cc:198-229
+int16_t read_mv_component( BoolReader & bd, const uint8_t * p )
+{
+  enum { MV_IS_SHORT, SIGN, SHORT, BITS = SHORT + 8 - 1, MV_LONG_BITS = 10 };
+  int x = 0;
+  if ( bd.get( p[MV_IS_SHORT] ) ) {
+    for ( int i = 0; i < 3; i++ ) x += bd.get( p[BITS + i] ) << i;
+    for ( int i = MV_LONG_BITS - 1; i > 3; i-- ) x += bd.get( p[BITS + i] ) << i;
+    if ( !( x & 0xFFF0 ) || bd.get( p[BITS + 3] ) ) x += 8;
+  } else {
+    x = bd.tree( kSmallMvTree, p + SHORT );
+  }
+  x <<= 1;
+  if ( x && bd.get( p[SIGN] ) ) x = -x;
+  return static_cast<int16_t>( x );
+}
+
+Mv read_mv( BoolReader & bd, const ProbTables & pt )
+{
+  Mv m;
+  m.y = read_mv_component( bd, pt.mv[0] );   // row first (macroblock.cc:283-287)
+  m.x = read_mv_component( bd, pt.mv[1] );
+  return m;
+}
+
+// Scorer::clamp, macroblock.cc:183-195
+Mv clamp_mv( Mv m, unsigned col, unsigned row, unsigned mbw, unsigned mbh )
+{
+  const int to_left = clamp( -( static_cast<int>( col * 16 ) << 3 ) - 128, -32768, 32767 );
+  const int to_right = clamp( ( static_cast<int>( ( mbw - 1 - col ) * 16 ) << 3 ) + 128, -32768, 32767 );
+  const int to_top = clamp( -( static_cast<int>( row * 16 ) << 3 ) - 128, -32768, 32767 );
+  const int to_bottom = clamp( ( static_cast<int>( ( mbh - 1 - row ) * 16 ) << 3 ) + 128, -32768, 32767 );
+  m.x = static_cast<int16_t>( clamp( m.x, to_left, to_right ) );
+  m.y = static_cast<int16_t>( clamp( m.y, to_top, to_bottom ) );
+  return m;
+}
+
+// Block::parse_tokens, tokens.cc:50-135.  Returns true iff a non-zero token was decoded (Q1).
+// `out` must be 16 zeroed int16 (de-zigzagged positions are written).
+inline bool parse_block( BoolReader & bd, const uint8_t ( *probs )[3][11], int first, int ctx, int16_t * out )
+{
+  static constexpr uint8_t kCat3[3] = { 173, 148, 140 };
+  static constexpr uint8_t kCat4[4] = { 176, 155, 140, 135 };
+  static constexpr uint8_t kCat5[5] = { 180, 157, 141, 134, 130 };
+  static constexpr uint8_t kCat6[11] = { 254, 254, 243, 230, 196, 177, 153, 140, 133, 130, 129 };
+  bool nonzero = false;
+  int index = first;
+  const uint8_t * p = probs[kBand[index]][ctx];
+  if ( !bd.get( p[0] ) ) return false;   // immediate EOB
+  for ( ;; ) {
+    // here: "not EOB" has been established for position `index`
+    while ( !bd.get( p[1] ) ) {           // ZERO token: no EOB check for the next position
+      if ( ++index == 16 ) return nonzero;
+      p = probs[kBand[index]][0];
+    }
+    nonzero = true;
+    int value;
+    int next_ctx;
+    if ( !bd.get( p[2] ) ) { value = 1; next_ctx = 1; }
+    else {
+      next_ctx = 2;
+      if ( !bd.get( p[3] ) ) {
+        if ( !bd.get( p[4] ) ) value = 2;
+        else value = 3 + bd.get( p[5] );
+      } else if ( !bd.get( p[6] ) ) {
+        if ( !bd.get( p[7] ) ) value = 5 + bd.get( 159 );
+        else { value = 7 + 2 * bd.get( 165 ); value += bd.get( 145 ); }
+      } else {
+        const uint8_t * cp; int n, base;
+        if ( !bd.get( p[8] ) ) {
+          if ( !bd.get( p[9] ) ) { cp = kCat3; n = 3; base = 11; } else { cp = kCat4; n = 4; base = 19; }
+        } else {
+          if ( !bd.get( p[10] ) ) { cp = kCat5; n = 5; base = 35; } else { cp = kCat6; n = 11; base = 67; }
+        }
+        int inc = 0;
+        for ( int i = 0; i < n; i++ ) inc = ( inc << 1 ) + bd.get( cp[i] );
+        value = base + inc;
+      }
+    }
+    if ( bd.get( 128 ) ) value = -value;
+    out[kZigzag[index]] = static_cast<int16_t>( value );
+    if ( ++index == 16 ) return true;
+    p = probs[kBand[index]][next_ctx];
+    if ( !bd.get( p[0] ) ) return true;   // EOB
+  }
+}
+
+struct Quantizer { uint16_t f[6]; };   // {y_dc, y_ac, y2_dc, y2_ac, uv_dc, uv_ac}
+
+inline int clamp_q( int q ) { return q < 0 ? 0 : ( q > 127 ? 127 : q ); }
+
+// Quantizer::Quantizer, quantization.cc:83-93
+Quantizer make_quantizer( int y_ac_qi, const int delta[5] /* y_dc, y2_dc, y2_ac, uv_dc, uv_ac */ )
+{
+  Quantizer q;
+  q.f[1] = k_ac_qlookup[clamp_q( y_ac_qi )];
+  q.f[0] = k_dc_qlookup[clamp_q( y_ac_qi + delta[0] )];
+  q.f[2] = static_cast<uint16_t>( k_dc_qlookup[clamp_q( y_ac_qi + delta[1] )] * 2 );
+  q.f[3] = static_cast<uint16_t>( k_ac_qlookup[clamp_q( y_ac_qi + delta[2] )] * 155 / 100 );
+  q.f[4] = k_dc_qlookup[clamp_q( y_ac_qi + delta[3] )];
+  q.f[5] = k_ac_qlookup[clamp_q( y_ac_qi + delta[4] )];
+  if ( q.f[3] < 8 ) q.f[3] = 8;
+  if ( q.f[4] > 132 ) q.f[4] = 132;
+  return q;
+}
+
+} // namespace
+
+void ProbTables::set_defaults()
+{
+  std::memcpy( coeff, k_default_coeff_probs, sizeof coeff );
+  std::memcpy( y_mode, k_default_y_mode_probs, sizeof y_mode );
+  std::memcpy( uv_mode, k_default_uv_mode_probs, sizeof uv_mode );
+  std::memcpy( mv, k_default_mv_probs, sizeof mv );
+}
+
+Parser::Parser( uint16_t width, uint16_t height )
+  : width_( width ), height_( height ), mbw_( ( width + 15u ) / 16u ), mbh_( ( height + 15u ) / 16u ),
+    above_nz_( static_cast<size_t>( mbw_ ) * 9 ), flipped_( static_cast<size_t>( mbw_ ) * mbh_ )
+{
+  probs_.set_defaults();
+  seg_.map.assign( static_cast<size_t>( mbw_ ) * mbh_, 3 );
+}
+
+void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa_mb_info * mbs, int16_t * coeff_out )
+{
+  // ---- frame tag + partition split: uncompressed_chunk.cc:34-130 ----
+  if ( size < 3 ) throw ParseError( AA_ERR_INVALID, "invalid bitstream: VP8 frame truncated" );
+  const uint32_t tag = data[0] | ( data[1] << 8 ) | ( static_cast<uint32_t>( data[2] ) << 16 );
+  const bool key = !( tag & 1 );
+  const unsigned version = ( tag >> 1 ) & 7;
+  const bool show = ( tag >> 4 ) & 1;
+  const uint32_t first_len = ( tag >> 5 ) & 0x7FFFF;
+  bool experimental = false;
+  if ( version == 4 || version == 6 ) experimental = true;
+  else if ( version != 0 ) throw ParseError( AA_ERR_UNSUPPORTED, "unsupported bitstream: VP8 version of " + std::to_string( version ) );
+  const uint32_t first_off = key ? 10 : 3;
+  if ( size <= static_cast<size_t>( first_off ) + first_len )
+    throw ParseError( AA_ERR_INVALID, "invalid bitstream: invalid VP8 first partition length" );
+  if ( key ) {
+    if ( data[3] != 0x9d || data[4] != 0x01 || data[5] != 0x2a )
+      throw ParseError( AA_ERR_INVALID, "invalid bitstream: did not find key-frame start code" );
+    const unsigned fw = ( data[6] | ( data[7] << 8 ) ) & 0x3FFF, hscale = data[7] >> 6;
+    const unsigned fh = ( data[8] | ( data[9] << 8 ) ) & 0x3FFF, vscale = data[9] >> 6;
+    if ( fw != width_ || fh != height_ || hscale || vscale )
+      throw ParseError( AA_ERR_UNSUPPORTED, "unsupported bitstream: VP8 upscaling not supported" );
+    if ( experimental ) throw ParseError( AA_ERR_INVALID, "invalid bitstream: experimental key frame" );   // decoder_state.hh:81-83
+  } else if ( experimental ) {
+    throw ParseError( AA_ERR_UNSUPPORTED, "unsupported bitstream: experimental" );                         // decoder.cc:131-133
+  }
+  const uint8_t * rest = data + first_off + first_len;
+  const size_t rest_len = size - first_off - first_len;
+
+  BoolReader bd( data + first_off, first_len );
+
+  // ---- frame header: frame_header.hh:194-295 ----
+  std::memset( &hdr, 0, sizeof hdr );
+  hdr.key_frame = key; hdr.show_frame = show;
+  hdr.mb_width = static_cast<uint16_t>( mbw_ ); hdr.mb_height = static_cast<uint16_t>( mbh_ );
+  hdr.width = width_; hdr.height = height_;
+  hdr.num_macroblocks = mbw_ * mbh_;
+  hdr.compressed_size = static_cast<uint32_t>( size );
+
+  bool color_space = false, clamping_type = false;
+  if ( key ) { color_space = bd.flag(); clamping_type = bd.flag(); }
+
+  // Flagged<UpdateSegmentation>
+  const bool seg_enabled = bd.flag();
+  bool seg_update_map = false, seg_update_data = false, seg_abs = false;
+  int seg_quant[4] = { 0, 0, 0, 0 }, seg_lf[4] = { 0, 0, 0, 0 };
+  uint8_t seg_tree_probs[3] = { 255, 255, 255 };
+  if ( seg_enabled ) {
+    seg_update_map = bd.flag();
+    seg_update_data = bd.flag();
+    if ( seg_update_data ) {
+      seg_abs = bd.flag();
+      for ( int i = 0; i < 4; i++ ) seg_quant[i] = bd.flag() ? bd.signed_literal( 7 ) : 0;
+      for ( int i = 0; i < 4; i++ ) seg_lf[i] = bd.flag() ? bd.signed_literal( 6 ) : 0;
+    }
+    if ( seg_update_map ) for ( int i = 0; i < 3; i++ ) seg_tree_probs[i] = bd.flag() ? static_cast<uint8_t>( bd.literal( 8 ) ) : 255;
+  }
+  const bool filter_type = bd.flag();
+  hdr.loop_filter_level = static_cast<uint8_t>( bd.literal( 6 ) );
+  hdr.sharpness_level = static_cast<uint8_t>( bd.literal( 3 ) );
+  // Flagged<Flagged<ModeRefLFDeltaUpdate>>
+  const bool lf_adj_enabled = bd.flag();
+  bool lf_delta_update = false;
+  int ref_delta[4] = { 0, 0, 0, 0 }, mode_delta[4] = { 0, 0, 0, 0 };
+  if ( lf_adj_enabled ) {
+    lf_delta_update = bd.flag();
+    if ( lf_delta_update ) {
+      for ( int i = 0; i < 4; i++ ) ref_delta[i] = bd.flag() ? bd.signed_literal( 6 ) : 0;
+      for ( int i = 0; i < 4; i++ ) mode_delta[i] = bd.flag() ? bd.signed_literal( 6 ) : 0;
+    }
+  }
+  const int log2_parts = bd.literal( 2 );
+  hdr.num_dct_partitions = static_cast<uint8_t>( 1 << log2_parts );
+  const int y_ac_qi = bd.literal( 7 );
+  hdr.q_index = static_cast<uint8_t>( y_ac_qi );
+  int qdelta[5];   // y_dc, y2_dc, y2_ac, uv_dc, uv_ac (bitstream order, frame_header.hh:40-44)
+  for ( int i = 0; i < 5; i++ ) qdelta[i] = bd.flag() ? bd.signed_literal( 4 ) : 0;
+
+  bool refresh_entropy;
+  bool sign_bias_golden = false, sign_bias_alt = false;
+  if ( key ) {
+    refresh_entropy = bd.flag();
+    hdr.refresh_last = hdr.refresh_golden = hdr.refresh_alternate = 1;
+  } else {
+    hdr.refresh_golden = static_cast<uint8_t>( bd.flag() );
+    hdr.refresh_alternate = static_cast<uint8_t>( bd.flag() );
+    hdr.copy_buffer_to_golden = hdr.refresh_golden ? 0 : static_cast<uint8_t>( bd.literal( 2 ) );
+    hdr.copy_buffer_to_alternate = hdr.refresh_alternate ? 0 : static_cast<uint8_t>( bd.literal( 2 ) );
+    sign_bias_golden = bd.flag(); sign_bias_alt = bd.flag();
+    refresh_entropy = bd.flag();
+    hdr.refresh_last = static_cast<uint8_t>( bd.flag() );
+  }
+  hdr.sign_bias_golden = sign_bias_golden; hdr.sign_bias_alternate = sign_bias_alt;
+
+  // ---- state transition: decoder_state.hh:72-167 ----
+  ProbTables fp;            // this frame's tables
+  if ( key ) fp.set_defaults();   // key frames reset the persistent state (decoder.cc:234-240), applied below once the header is valid
+  else fp = probs_;
+  for ( int i = 0; i < 4; i++ ) for ( int j = 0; j < 8; j++ ) for ( int k = 0; k < 3; k++ ) for ( int l = 0; l < 11; l++ )
+    if ( bd.get( k_coeff_update_probs[( ( i * 8 + j ) * 3 + k ) * 11 + l] ) ) fp.coeff[i][j][k][l] = static_cast<uint8_t>( bd.literal( 8 ) );
+  const bool skip_enabled = bd.flag();
+  const int prob_skip = skip_enabled ? bd.literal( 8 ) : 0;
+  int prob_inter = 0, prob_last = 0, prob_golden = 0;
+  if ( !key ) {
+    prob_inter = bd.literal( 8 ); prob_last = bd.literal( 8 ); prob_golden = bd.literal( 8 );
+    if ( bd.flag() ) for ( int i = 0; i < 4; i++ ) fp.y_mode[i] = static_cast<uint8_t>( bd.literal( 8 ) );
+    if ( bd.flag() ) for ( int i = 0; i < 3; i++ ) fp.uv_mode[i] = static_cast<uint8_t>( bd.literal( 8 ) );
+    for ( int i = 0; i < 2; i++ ) for ( int j = 0; j < 19; j++ )
+      if ( bd.get( k_mv_update_probs[i * 19 + j] ) ) { const int x = bd.literal( 7 ); fp.mv[i][j] = static_cast<uint8_t>( x ? x << 1 : 1 ); }
+  }
+  if ( color_space || clamping_type ) throw ParseError( AA_ERR_UNSUPPORTED, "unsupported bitstream: VP8 color_space and clamping_type bits" );
+  if ( filter_type ) throw ParseError( AA_ERR_UNSUPPORTED, "unsupported bitstream: VP8 'simple' in-loop deblocking filter" );
+
+  if ( key ) {
+    probs_.set_defaults();
+    seg_.enabled = seg_enabled; seg_.absolute = false;
+    std::memset( seg_.quant, 0, 4 ); std::memset( seg_.lf, 0, 4 );
+    if ( seg_enabled ) std::memset( seg_.map.data(), 3, seg_.map.size() );     // Segmentation ctor: map(width, height, 3)
+    fadj_.enabled = lf_adj_enabled; std::memset( fadj_.ref, 0, 4 ); std::memset( fadj_.mode, 0, 4 );
+  } else {
+    if ( lf_adj_enabled ) { if ( !fadj_.enabled ) { fadj_.enabled = true; std::memset( fadj_.ref, 0, 4 ); std::memset( fadj_.mode, 0, 4 ); } }
+    else fadj_.enabled = false;
+    if ( seg_enabled ) {
+      if ( !seg_.enabled ) {
+        seg_.enabled = true; seg_.absolute = false; std::memset( seg_.quant, 0, 4 ); std::memset( seg_.lf, 0, 4 );
+        std::memset( seg_.map.data(), 3, seg_.map.size() );
+      }
+    } else seg_.enabled = false;
+  }
+  if ( refresh_entropy ) probs_ = fp;
+  if ( lf_adj_enabled && lf_delta_update )
+    for ( int i = 0; i < 4; i++ ) { fadj_.ref[i] = static_cast<int8_t>( ref_delta[i] ); fadj_.mode[i] = static_cast<int8_t>( mode_delta[i] ); }
+  if ( seg_enabled && seg_update_data ) {
+    seg_.absolute = seg_abs;
+    for ( int i = 0; i < 4; i++ ) { seg_.quant[i] = static_cast<int8_t>( seg_quant[i] ); seg_.lf[i] = static_cast<int8_t>( seg_lf[i] ); }
+  }
+  hdr.segmentation_enabled = seg_.enabled; hdr.filter_adjustments_enabled = fadj_.enabled;
+
+  // ---- per-frame constants for the device ----
+  for ( int s = 0; s < 4; s++ ) {
+    int qi = y_ac_qi;
+    if ( seg_.enabled ) qi = static_cast<uint8_t>( seg_.quant[s] + ( seg_.absolute ? 0 : y_ac_qi ) );   // Q2: wraps as uint8 before clamp
+    const Quantizer q = make_quantizer( qi, qdelta );
+    std::memcpy( hdr.quant[s], q.f, sizeof q.f );
+  }
+  int seg_level[4];
+  for ( int s = 0; s < 4; s++ )
+    seg_level[s] = seg_.enabled ? seg_.lf[s] + ( seg_.absolute ? 0 : hdr.loop_filter_level ) : hdr.loop_filter_level;   // Q3: unclamped
+
+  // ---- DCT partitions: uncompressed_chunk.cc:132-155 ----
+  const int nparts = hdr.num_dct_partitions;
+  BoolReader parts[8];
+  {
+    if ( rest_len < static_cast<size_t>( 3 * ( nparts - 1 ) ) ) throw ParseError( AA_ERR_OUT_OF_RANGE, "attempted to read past end of chunk" );
+    const uint8_t * p = rest + 3 * ( nparts - 1 );
+    size_t left = rest_len - 3 * ( nparts - 1 );
+    for ( int i = 0; i < nparts; i++ ) {
+      size_t len = left;
+      if ( i < nparts - 1 ) {
+        len = rest[3 * i] | ( rest[3 * i + 1] << 8 ) | ( static_cast<size_t>( rest[3 * i + 2] ) << 16 );
+        if ( len > left ) throw ParseError( AA_ERR_OUT_OF_RANGE, "attempted to read past end of chunk" );
+      }
+      parts[i].reset( p, len ); p += len; left -= len;
+    }
+  }
+
+  // ---- macroblock headers + tokens ----
+  std::memset( above_nz_.data(), 0, above_nz_.size() );
+  uint32_t coeff_blocks = 0, intra_mbs = 0;
+  const unsigned mbw = mbw_, mbh = mbh_;
+
+  for ( unsigned row = 0; row < mbh; row++ ) {
+    uint8_t left_nz[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    BoolReader & tok = parts[row % nparts];
+    for ( unsigned col = 0; col < mbw; col++ ) {
+      const unsigned mi = row * mbw + col;
+      aa_mb_info & mb = mbs[mi];
+      std::memset( &mb, 0, sizeof mb );
+
+      // Macroblock ctor: segment id, skip flag, inter/intra + reference (macroblock.cc:43-71, 458-465)
+      if ( seg_enabled && seg_update_map ) seg_.map[mi] = static_cast<uint8_t>( bd.tree( kSegmentIdTree, seg_tree_probs ) );
+      mb.segment_id = seg_.enabled ? seg_.map[mi] : 0;
+      const bool skip = skip_enabled ? bd.get( prob_skip ) : false;
+      bool inter = false;
+      if ( !key ) {
+        inter = bd.get( prob_inter );
+        if ( inter ) {
+          mb.ref_frame = LAST_FRAME;
+          if ( bd.get( prob_last ) ) mb.ref_frame = bd.get( prob_golden ) ? ALTREF_FRAME : GOLDEN_FRAME;
+          flipped_[mi] = ( mb.ref_frame == GOLDEN_FRAME && sign_bias_golden ) || ( mb.ref_frame == ALTREF_FRAME && sign_bias_alt );
+        }
+      }
+
+      if ( !inter ) {
+        // ---- intra modes: macroblock.cc:84-111 (key) / 354-376 (inter frame) ----
+        intra_mbs++;
+        mb.y_mode = static_cast<uint8_t>( key ? bd.tree( kKfYModeTree, k_kf_y_mode_probs ) : bd.tree( kYModeTree, fp.y_mode ) );
+        if ( mb.y_mode == B_PRED ) {
+          for ( int b = 0; b < 16; b++ ) {
+            if ( key ) {
+              int above_mode = B_DC_PRED, left_mode = B_DC_PRED;
+              if ( b >= 4 ) above_mode = mb.u.b_mode[b - 4];
+              else if ( row > 0 ) above_mode = mbs[mi - mbw].u.b_mode[b + 12];
+              if ( b & 3 ) left_mode = mb.u.b_mode[b - 1];
+              else if ( col > 0 ) left_mode = mbs[mi - 1].u.b_mode[b + 3];
+              mb.u.b_mode[b] = static_cast<uint8_t>( bd.tree( kBModeTree, k_kf_b_mode_probs + ( above_mode * 10 + left_mode ) * 9 ) );
+            } else {
+              mb.u.b_mode[b] = static_cast<uint8_t>( bd.tree( kBModeTree, k_b_mode_probs ) );
+            }
+          }
+        } else {
+          static constexpr uint8_t kImplied[4] = { B_DC_PRED, B_VE_PRED, B_HE_PRED, B_TM_PRED };   // macroblock.hh:134-143
+          std::memset( mb.u.b_mode, kImplied[mb.y_mode], 16 );
+        }
+        mb.uv_mode = static_cast<uint8_t>( key ? bd.tree( kUvModeTree, k_kf_uv_mode_probs ) : bd.tree( kUvModeTree, fp.uv_mode ) );
+      } else {
+        // ---- inter modes: census (scorer.hh, macroblock.cc:143-181,301-312) then mode / MVs (:377-455) ----
+        mb.flags |= AA_MB_INTER;
+        uint8_t score[4] = { 0, 0, 0, 0 };
+        Mv cand[4];
+        int idx = 0, split_score = 0;
+        const bool my_flip = flipped_[mi];
+        auto consider = [&]( unsigned ni, int weight ) {
+          const aa_mb_info & nb = mbs[ni];
+          if ( !( nb.flags & AA_MB_INTER ) ) return;
+          Mv mv; mv.x = nb.u.mv[15][0]; mv.y = nb.u.mv[15][1];
+          if ( static_cast<bool>( flipped_[ni] ) != my_flip ) { mv.x = static_cast<int16_t>( -mv.x ); mv.y = static_cast<int16_t>( -mv.y ); }
+          if ( mv.zero() ) score[0] += weight;
+          else {
+            if ( !( mv == cand[idx] ) ) cand[++idx] = mv;
+            score[idx] += weight;
+          }
+          if ( nb.y_mode == SPLITMV ) split_score += weight;
+        };
+        if ( row > 0 ) consider( mi - mbw, 2 );
+        if ( col > 0 ) consider( mi - 1, 2 );
+        if ( row > 0 && col > 0 ) consider( mi - mbw - 1, 1 );
+        if ( score[3] && cand[idx] == cand[1] ) score[1] += score[3];                       // Q8
+        if ( score[2] > score[1] ) { std::swap( score[1], score[2] ); std::swap( cand[1], cand[2] ); }
+        if ( score[1] >= score[0] ) cand[0] = cand[1];
+        const uint8_t mode_probs[4] = { k_mv_counts_to_probs[score[0] * 4 + 0], k_mv_counts_to_probs[score[1] * 4 + 1],
+                                        k_mv_counts_to_probs[score[2] * 4 + 2], k_mv_counts_to_probs[split_score * 4 + 3] };
+        mb.y_mode = static_cast<uint8_t>( bd.tree( kMvRefTree, mode_probs ) );
+        Mv base;
+        switch ( mb.y_mode ) {
+        case NEARESTMV: base = clamp_mv( cand[1], col, row, mbw, mbh ); break;
+        case NEARMV: base = clamp_mv( cand[2], col, row, mbw, mbh ); break;
+        case ZEROMV: break;
+        case NEWMV: {
+          const Mv delta = read_mv( bd, fp );
+          const Mv best = clamp_mv( cand[0], col, row, mbw, mbh );
+          base.x = static_cast<int16_t>( delta.x + best.x ); base.y = static_cast<int16_t>( delta.y + best.y );
+          break; }
+        case SPLITMV: {
+          mb.split_partition = static_cast<uint8_t>( bd.tree( kSplitMvTree, k_split_mv_probs ) );
+          const Mv best = clamp_mv( cand[0], col, row, mbw, mbh );
+          const uint8_t * layout = kSplitLayout[mb.split_partition];
+          for ( int part = 0; part < kSplitCount[mb.split_partition]; part++ ) {
+            const int b = kSplitFirst[mb.split_partition][part];
+            // YBlock::read_subblock_inter_prediction, macroblock.cc:231-281
+            Mv lmv, amv;
+            if ( b & 3 ) { lmv.x = mb.u.mv[b - 1][0]; lmv.y = mb.u.mv[b - 1][1]; }
+            else if ( col > 0 && ( mbs[mi - 1].flags & AA_MB_INTER ) ) { lmv.x = mbs[mi - 1].u.mv[b + 3][0]; lmv.y = mbs[mi - 1].u.mv[b + 3][1]; }
+            if ( b >= 4 ) { amv.x = mb.u.mv[b - 4][0]; amv.y = mb.u.mv[b - 4][1]; }
+            else if ( row > 0 && ( mbs[mi - mbw].flags & AA_MB_INTER ) ) { amv.x = mbs[mi - mbw].u.mv[b + 12][0]; amv.y = mbs[mi - mbw].u.mv[b + 12][1]; }
+            int ctx = 0;
+            if ( lmv == amv ) ctx = lmv.zero() ? 4 : 3;
+            else if ( amv.zero() ) ctx = 2;
+            else if ( lmv.zero() ) ctx = 1;
+            Mv m;
+            switch ( bd.tree( kSubMvRefTree, k_submv_ref_probs + ctx * 3 ) ) {
+            case LEFT4X4: m = lmv; break;
+            case ABOVE4X4: m = amv; break;
+            case ZERO4X4: break;
+            case NEW4X4: { const Mv d = read_mv( bd, fp ); m.x = static_cast<int16_t>( d.x + best.x ); m.y = static_cast<int16_t>( d.y + best.y ); break; }
+            }
+            for ( int k = 0; k < 16; k++ ) if ( layout[k] == part ) { mb.u.mv[k][0] = m.x; mb.u.mv[k][1] = m.y; }
+          }
+          break; }
+        default: throw ParseError( AA_ERR_LOGIC, "logic error" );
+        }
+        if ( mb.y_mode != SPLITMV ) for ( int k = 0; k < 16; k++ ) { mb.u.mv[k][0] = base.x; mb.u.mv[k][1] = base.y; }
+      }
+
+      const bool has_y2 = !( mb.y_mode == B_PRED || mb.y_mode == SPLITMV );
+      if ( has_y2 ) mb.flags |= AA_MB_HAS_Y2;
+      if ( skip ) mb.flags |= AA_MB_SKIP;
+
+      // ---- tokens: Macroblock::parse_tokens (macroblock.cc:475-502); storage order = nz_mask bit order ----
+      uint8_t * anz = &above_nz_[static_cast<size_t>( col ) * 9];
+      mb.coeff_index = coeff_blocks;
+      bool any = false;
+      if ( skip ) {
+        std::memset( anz, 0, 8 ); std::memset( left_nz, 0, 8 );
+        if ( has_y2 ) { anz[8] = 0; left_nz[8] = 0; }   // a non-coded Y2 leaves the chain untouched (frame.cc:255-269)
+      } else {
+        int16_t y2_block[16];
+        bool y2_nz = false;
+        if ( has_y2 ) {
+          std::memset( y2_block, 0, sizeof y2_block );
+          y2_nz = parse_block( tok, fp.coeff[Y2], 0, anz[8] + left_nz[8], y2_block );
+          anz[8] = left_nz[8] = y2_nz;
+        }
+        const int ytype = has_y2 ? Y_AFTER_Y2 : Y_WITHOUT_Y2;
+        const int yfirst = has_y2 ? 1 : 0;
+        uint32_t mask = 0;
+        for ( int b = 0; b < 16; b++ ) {
+          int16_t * slot = coeff_out + static_cast<size_t>( coeff_blocks ) * 16;
+          std::memset( slot, 0, 32 );
+          const int bx = b & 3, by = b >> 2;
+          const bool nz = parse_block( tok, fp.coeff[ytype], yfirst, anz[bx] + left_nz[by], slot );
+          anz[bx] = left_nz[by] = nz;
+          if ( nz ) { mask |= 1u << b; coeff_blocks++; }
+        }
+        for ( int pl = 0; pl < 2; pl++ ) for ( int b = 0; b < 4; b++ ) {
+          int16_t * slot = coeff_out + static_cast<size_t>( coeff_blocks ) * 16;
+          std::memset( slot, 0, 32 );
+          uint8_t & a = anz[4 + pl * 2 + ( b & 1 )]; uint8_t & l = left_nz[4 + pl * 2 + ( b >> 1 )];
+          const bool nz = parse_block( tok, fp.coeff[UV], 0, a + l, slot );
+          a = l = nz;
+          if ( nz ) { mask |= 1u << ( 16 + pl * 4 + b ); coeff_blocks++; }
+        }
+        if ( y2_nz ) {
+          std::memcpy( coeff_out + static_cast<size_t>( coeff_blocks ) * 16, y2_block, 32 );
+          mask |= 1u << 24; coeff_blocks++;
+        }
+        mb.nz_mask = mask;
+        any = mask != 0;
+      }
+      if ( any ) mb.flags |= AA_MB_HAS_NONZERO;
+      if ( has_y2 && !any ) mb.flags |= AA_MB_LF_SKIP_INNER;
+
+      // ---- per-MB loop filter level: frame.cc:144-166, macroblock.cc:611-623, loopfilter.cc:59-79 ----
+      if ( hdr.loop_filter_level ) {
+        int level = seg_level[mb.segment_id];
+        if ( fadj_.enabled ) {
+          level += fadj_.ref[mb.ref_frame];
+          if ( mb.ref_frame == CURRENT_FRAME ) level += ( mb.y_mode == B_PRED ) ? fadj_.mode[0] : 0;
+          else if ( mb.y_mode == ZEROMV ) level += fadj_.mode[1];
+          else if ( mb.y_mode == SPLITMV ) level += fadj_.mode[3];
+          else level += fadj_.mode[2];
+        }
+        mb.lf_level = static_cast<uint8_t>( level <= 0 ? 0 : ( level > 63 ? 63 : level ) );
+      }
+    }
+  }
+  hdr.num_coeff_blocks = coeff_blocks;
+  hdr.num_intra_mbs = intra_mbs;
+  hdr.has_intra_mb = intra_mbs != 0;
+}
+
+} // namespace aa

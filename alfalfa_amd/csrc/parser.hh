@@ -1,0 +1,77 @@
+// Host-side VP8 frame parser: compressed frame -> aa_frame_header + aa_mb_info[] + compact coefficient blocks.
+//
+// Implements, from the algorithm, what the reference does in
+//   UncompressedChunk (uncompressed_chunk.cc:34-155), DecoderState::parse_and_apply<F> (decoder_state.hh:72-167),
+//   Frame::parse_macroblock_headers / parse_tokens (frame.cc:95-137), Macroblock ctor + decode_prediction_modes
+//   (macroblock.cc:43-111,342-456), Block::parse_tokens (tokens.cc:50-135), plus the per-frame constants the device
+//   needs (quantisers frame.cc:185-206 / quantization.cc:83-93, per-MB loop-filter level frame.cc:144-166 /
+//   macroblock.cc:611-623 / loopfilter.cc:59-79).
+// It does NOT build the reference's object graph (TwoD<Macroblock>, Optional contexts): records go straight into
+// caller-provided (normally pinned) arrays in the layout the kernels read.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/alfalfa_amd.h"
+
+namespace aa {
+
+struct ProbTables {            // ProbabilityTables, decoder.hh:57-92
+  uint8_t coeff[4][8][3][11];
+  uint8_t y_mode[4];
+  uint8_t uv_mode[3];
+  uint8_t mv[2][19];
+  void set_defaults();
+};
+
+struct SegmentationState {     // Optional<Segmentation>, decoder.hh:151-188
+  bool enabled = false;
+  bool absolute = false;
+  int8_t quant[4] = { 0, 0, 0, 0 };
+  int8_t lf[4] = { 0, 0, 0, 0 };
+  std::vector<uint8_t> map;    // mb_width * mb_height
+};
+
+struct FilterAdjustState {     // Optional<FilterAdjustments>, decoder.hh:94-121
+  bool enabled = false;
+  int8_t ref[4] = { 0, 0, 0, 0 };
+  int8_t mode[4] = { 0, 0, 0, 0 };
+};
+
+class ParseError
+{
+public:
+  aa_status code;
+  std::string message;
+  ParseError( aa_status c, std::string m ) : code( c ), message( std::move( m ) ) {}
+};
+
+class Parser
+{
+public:
+  Parser( uint16_t width, uint16_t height );
+
+  // Throws ParseError.  mb_out: mb_width*mb_height records.  coeff_out: worst case 25*16 int16 per MB.
+  void parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa_mb_info * mb_out, int16_t * coeff_out );
+
+  uint16_t width() const { return width_; }
+  uint16_t height() const { return height_; }
+  unsigned mb_width() const { return mbw_; }
+  unsigned mb_height() const { return mbh_; }
+
+  const ProbTables & probs() const { return probs_; }
+  const SegmentationState & segmentation() const { return seg_; }
+  const FilterAdjustState & filter_adjustments() const { return fadj_; }
+
+private:
+  uint16_t width_, height_;
+  unsigned mbw_, mbh_;
+  ProbTables probs_;
+  SegmentationState seg_;
+  FilterAdjustState fadj_;
+  std::vector<uint8_t> above_nz_;   // per MB column: 4 Y, 2 U, 2 V, 1 Y2
+  std::vector<uint8_t> flipped_;    // per MB: motion_vectors_flipped_ (macroblock.cc:464-465)
+};
+
+} // namespace aa

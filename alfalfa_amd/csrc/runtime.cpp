@@ -1,0 +1,555 @@
+// Device runtime behind the C ABI (include/alfalfa_amd.h): HIP context, per-stream frame store (pinned host
+// arena mirrored 1:1 in HBM), raster slots with the reference's References bookkeeping, batched launches.
+//
+// Memory plan (MI355X: 288 GB HBM3E per GPU):
+//   * every parsed frame's records (aa_dev_frame + aa_mb_info[] + compact coefficient blocks) are appended to a
+//     per-stream arena: a pinned host chunk and a device chunk with IDENTICAL offsets, so an upload is one large
+//     hipMemcpyAsync of the not-yet-uploaded byte range on the copy stream (side stream, event-ordered);
+//   * rasters are slots of 3 tightly packed padded planes (VP8Raster, raster.hh:54-56); slots are assigned when a
+//     frame is PARSED by replaying Frame::copy_to (frame.cc:271-307) on slot ids, so each job is self-contained
+//     and device execution never consults the host;
+//   * decode = k_recon_inter (1 launch) + k_recon_intra / k_loopfilter (one launch per 2:1 anti-diagonal).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/alfalfa_amd.h"
+#include "device_types.h"
+#include "parser.hh"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+aa_status fail( aa_status code, const std::string & msg ) { g_last_error = msg; return code; }
+aa_status hip_fail( hipError_t e, const char * what )
+{
+  return fail( e == hipErrorNoDevice || e == hipErrorInvalidDevice ? AA_ERR_NO_DEVICE : AA_ERR_HIP,
+               std::string( what ) + ": " + hipGetErrorString( e ) );
+}
+#define HIP_TRY( expr ) do { hipError_t e__ = ( expr ); if ( e__ != hipSuccess ) return hip_fail( e__, #expr ); } while ( 0 )
+
+constexpr size_t kChunkBytes = size_t( 64 ) << 20;
+constexpr size_t kAlign = 256;
+inline size_t align_up( size_t v, size_t a = kAlign ) { return ( v + a - 1 ) / a * a; }
+
+struct Chunk {
+  uint8_t * host = nullptr;   // pinned
+  uint8_t * dev = nullptr;
+  size_t capacity = 0, used = 0, uploaded = 0;
+};
+
+struct Slot {
+  uint8_t * dev = nullptr;
+  int refs = 0;               // References + frame handles holding this raster
+};
+
+struct FrameRec {
+  aa_frame_header hdr;
+  aa_dev_frame * host_job = nullptr;       // in pinned chunk
+  const aa_dev_frame * dev_job = nullptr;  // same offset in device chunk
+  int out_slot = -1;
+  int ref_after[3] = { -1, -1, -1 };       // References (last, golden, alt) after this frame, as frame indices
+  std::vector<uint8_t> intra_diagonals;    // [d] != 0: diagonal d holds an intra MB
+  bool handle_held = true;
+};
+
+} // namespace
+
+struct aa_parser { aa::Parser impl; aa_parser( uint16_t w, uint16_t h ) : impl( w, h ) {} };
+
+struct aa_ctx {
+  int device = 0;
+  hipStream_t compute = nullptr, copy = nullptr;
+  hipEvent_t upload_done = nullptr;
+  bool profile = false;
+  aa_kernel_stats stats {};
+  struct Timed { hipEvent_t a, b; int kind; };
+  std::vector<Timed> pending;
+  std::vector<hipEvent_t> free_events;
+};
+
+struct aa_stream {
+  aa_ctx * ctx;
+  aa::Parser parser;
+  uint32_t pw, ph;
+  size_t plane_bytes[3], slot_bytes;
+  std::vector<Chunk> chunks;
+  std::vector<Slot> slots;
+  std::vector<FrameRec> frames;
+  int cur_ref_slot[3];     // slot ids of last/golden/alt at PARSE time
+  int cur_ref_frame[3];    // frame indices (for aa_stream_references)
+  int next_submit = 0;     // device half progress
+  aa_stream( aa_ctx * c, uint16_t w, uint16_t h ) : ctx( c ), parser( w, h ) {}
+};
+
+namespace {
+
+aa_status set_device( aa_ctx * ctx ) { HIP_TRY( hipSetDevice( ctx->device ) ); return AA_OK; }
+
+aa_status alloc_slot( aa_stream * s, int * out )
+{
+  for ( size_t i = 0; i < s->slots.size(); i++ ) if ( s->slots[i].refs == 0 ) { *out = static_cast<int>( i ); return AA_OK; }
+  Slot sl;
+  HIP_TRY( hipMalloc( reinterpret_cast<void **>( &sl.dev ), s->slot_bytes ) );
+  s->slots.push_back( sl );
+  *out = static_cast<int>( s->slots.size() - 1 );
+  return AA_OK;
+}
+void retain( aa_stream * s, int slot ) { if ( slot >= 0 ) s->slots[slot].refs++; }
+void release( aa_stream * s, int slot ) { if ( slot >= 0 ) s->slots[slot].refs--; }
+void set_ref( aa_stream * s, int which, int slot, int frame )
+{
+  retain( s, slot ); release( s, s->cur_ref_slot[which] );
+  s->cur_ref_slot[which] = slot; s->cur_ref_frame[which] = frame;
+}
+
+aa_status reserve( aa_stream * s, size_t bytes, Chunk ** out )
+{
+  if ( s->chunks.empty() || s->chunks.back().used + bytes > s->chunks.back().capacity ) {
+    Chunk c;
+    c.capacity = std::max( kChunkBytes, align_up( bytes ) );
+    HIP_TRY( hipHostMalloc( reinterpret_cast<void **>( &c.host ), c.capacity, hipHostMallocDefault ) );
+    hipError_t e = hipMalloc( reinterpret_cast<void **>( &c.dev ), c.capacity );
+    if ( e != hipSuccess ) { (void) hipHostFree( c.host ); return hip_fail( e, "hipMalloc(frame store chunk)" ); }
+    s->chunks.push_back( c );
+  }
+  *out = &s->chunks.back();
+  return AA_OK;
+}
+
+hipEvent_t get_event( aa_ctx * ctx )
+{
+  if ( !ctx->free_events.empty() ) { hipEvent_t e = ctx->free_events.back(); ctx->free_events.pop_back(); return e; }
+  hipEvent_t e = nullptr; (void) hipEventCreate( &e ); return e;
+}
+void drain_profile( aa_ctx * ctx )
+{
+  for ( auto & t : ctx->pending ) {
+    float ms = 0;
+    if ( hipEventSynchronize( t.b ) == hipSuccess && hipEventElapsedTime( &ms, t.a, t.b ) == hipSuccess ) {
+      if ( t.kind == 0 ) { ctx->stats.recon_inter_ms += ms; ctx->stats.recon_inter_launches++; }
+      else if ( t.kind == 1 ) { ctx->stats.recon_intra_ms += ms; ctx->stats.recon_intra_launches++; }
+      else { ctx->stats.loopfilter_ms += ms; ctx->stats.loopfilter_launches++; }
+    }
+    ctx->free_events.push_back( t.a ); ctx->free_events.push_back( t.b );
+  }
+  ctx->pending.clear();
+}
+
+struct LaunchTimer {
+  aa_ctx * ctx; int kind; hipEvent_t a = nullptr;
+  LaunchTimer( aa_ctx * c, int k ) : ctx( c ), kind( k ) { if ( ctx->profile ) { a = get_event( ctx ); (void) hipEventRecord( a, ctx->compute ); } }
+  ~LaunchTimer() { if ( ctx->profile ) { hipEvent_t b = get_event( ctx ); (void) hipEventRecord( b, ctx->compute ); ctx->pending.push_back( { a, b, kind } ); if ( ctx->pending.size() >= 8192 ) drain_profile( ctx ); } }
+};
+
+} // namespace
+
+extern "C" {
+
+const char * aa_last_error( void ) { return g_last_error.c_str(); }
+int aa_abi_version( void ) { return AA_ABI_VERSION; }
+int aa_device_count( void ) { int n = 0; if ( hipGetDeviceCount( &n ) != hipSuccess ) return 0; return n; }
+
+void aa_raster_geometry( uint16_t width, uint16_t height, uint32_t * pw, uint32_t * ph )
+{
+  if ( pw ) *pw = 16u * ( ( width + 15u ) / 16u );
+  if ( ph ) *ph = 16u * ( ( height + 15u ) / 16u );
+}
+
+/* ---------------- parser ---------------- */
+aa_status aa_parser_create( uint16_t width, uint16_t height, aa_parser ** out )
+{
+  if ( !out || !width || !height ) return fail( AA_ERR_ARGUMENT, "aa_parser_create: bad argument" );
+  *out = new ( std::nothrow ) aa_parser( width, height );
+  return *out ? AA_OK : fail( AA_ERR_ARGUMENT, "out of memory" );
+}
+void aa_parser_destroy( aa_parser * p ) { delete p; }
+
+aa_status aa_parser_parse( aa_parser * p, const uint8_t * data, size_t size, aa_frame_header * hdr, aa_mb_info * mb, int16_t * coeff )
+{
+  if ( !p || !data || !hdr || !mb || !coeff ) return fail( AA_ERR_ARGUMENT, "aa_parser_parse: null argument" );
+  try { p->impl.parse( data, size, *hdr, mb, coeff ); }
+  catch ( const aa::ParseError & e ) { return fail( e.code, e.message ); }
+  return AA_OK;
+}
+static void export_probs( const aa::Parser & ps, uint8_t * out )
+{
+  const aa::ProbTables & t = ps.probs();
+  std::memcpy( out, t.coeff, 1056 ); std::memcpy( out + 1056, t.y_mode, 4 );
+  std::memcpy( out + 1060, t.uv_mode, 3 ); std::memcpy( out + 1063, t.mv, 38 );
+}
+aa_status aa_parser_get_probs( const aa_parser * p, uint8_t probs[1101] )
+{
+  if ( !p || !probs ) return fail( AA_ERR_ARGUMENT, "null argument" );
+  export_probs( p->impl, probs ); return AA_OK;
+}
+aa_status aa_parser_get_segmentation( const aa_parser * p, int * enabled, int * absolute, int8_t quant[4], int8_t lf[4], uint8_t * map )
+{
+  if ( !p ) return fail( AA_ERR_ARGUMENT, "null argument" );
+  const aa::SegmentationState & s = p->impl.segmentation();
+  if ( enabled ) *enabled = s.enabled;
+  if ( absolute ) *absolute = s.absolute;
+  if ( quant ) std::memcpy( quant, s.quant, 4 );
+  if ( lf ) std::memcpy( lf, s.lf, 4 );
+  if ( map ) std::memcpy( map, s.map.data(), s.map.size() );
+  return AA_OK;
+}
+aa_status aa_parser_get_filter_adjustments( const aa_parser * p, int * enabled, int8_t ref[4], int8_t mode[4] )
+{
+  if ( !p ) return fail( AA_ERR_ARGUMENT, "null argument" );
+  const aa::FilterAdjustState & f = p->impl.filter_adjustments();
+  if ( enabled ) *enabled = f.enabled;
+  if ( ref ) std::memcpy( ref, f.ref, 4 );
+  if ( mode ) std::memcpy( mode, f.mode, 4 );
+  return AA_OK;
+}
+
+/* ---------------- context ---------------- */
+aa_status aa_ctx_create( int device, aa_ctx ** out )
+{
+  if ( !out ) return fail( AA_ERR_ARGUMENT, "aa_ctx_create: null out" );
+  int n = 0;
+  hipError_t e = hipGetDeviceCount( &n );
+  if ( e != hipSuccess || n == 0 )
+    return fail( AA_ERR_NO_DEVICE, "no HIP device visible: the decode path has no CPU fallback" );
+  if ( device < 0 || device >= n ) return fail( AA_ERR_ARGUMENT, "device index out of range" );
+  std::unique_ptr<aa_ctx> ctx( new aa_ctx );
+  ctx->device = device;
+  HIP_TRY( hipSetDevice( device ) );
+  HIP_TRY( hipStreamCreateWithFlags( &ctx->compute, hipStreamNonBlocking ) );
+  HIP_TRY( hipStreamCreateWithFlags( &ctx->copy, hipStreamNonBlocking ) );
+  HIP_TRY( hipEventCreateWithFlags( &ctx->upload_done, hipEventDisableTiming ) );
+  *out = ctx.release();
+  return AA_OK;
+}
+void aa_ctx_destroy( aa_ctx * ctx )
+{
+  if ( !ctx ) return;
+  (void) hipSetDevice( ctx->device );
+  (void) hipStreamSynchronize( ctx->compute ); (void) hipStreamSynchronize( ctx->copy );
+  drain_profile( ctx );
+  for ( auto e : ctx->free_events ) (void) hipEventDestroy( e );
+  (void) hipEventDestroy( ctx->upload_done );
+  (void) hipStreamDestroy( ctx->compute ); (void) hipStreamDestroy( ctx->copy );
+  delete ctx;
+}
+aa_status aa_ctx_sync( aa_ctx * ctx )
+{
+  if ( !ctx ) return fail( AA_ERR_ARGUMENT, "null ctx" );
+  HIP_TRY( hipStreamSynchronize( ctx->copy ) );
+  HIP_TRY( hipStreamSynchronize( ctx->compute ) );
+  return AA_OK;
+}
+void * aa_ctx_compute_stream( aa_ctx * ctx ) { return ctx ? ctx->compute : nullptr; }
+void * aa_ctx_copy_stream( aa_ctx * ctx ) { return ctx ? ctx->copy : nullptr; }
+aa_status aa_ctx_profile( aa_ctx * ctx, int enable )
+{
+  if ( !ctx ) return fail( AA_ERR_ARGUMENT, "null ctx" );
+  if ( !enable ) { (void) hipStreamSynchronize( ctx->compute ); drain_profile( ctx ); }
+  ctx->profile = enable != 0;
+  return AA_OK;
+}
+aa_status aa_ctx_kernel_stats( aa_ctx * ctx, aa_kernel_stats * out, int reset )
+{
+  if ( !ctx || !out ) return fail( AA_ERR_ARGUMENT, "null argument" );
+  HIP_TRY( hipStreamSynchronize( ctx->compute ) );
+  drain_profile( ctx );
+  *out = ctx->stats;
+  if ( reset ) ctx->stats = aa_kernel_stats {};
+  return AA_OK;
+}
+
+/* ---------------- stream ---------------- */
+aa_status aa_stream_create( aa_ctx * ctx, uint16_t width, uint16_t height, aa_stream ** out )
+{
+  if ( !ctx || !out || !width || !height ) return fail( AA_ERR_ARGUMENT, "aa_stream_create: bad argument" );
+  if ( aa_status st = set_device( ctx ) ) return st;
+  std::unique_ptr<aa_stream> s( new aa_stream( ctx, width, height ) );
+  aa_raster_geometry( width, height, &s->pw, &s->ph );
+  s->plane_bytes[0] = size_t( s->pw ) * s->ph;
+  s->plane_bytes[1] = s->plane_bytes[2] = size_t( s->pw / 2 ) * ( s->ph / 2 );
+  s->slot_bytes = align_up( s->plane_bytes[0] + 2 * s->plane_bytes[1] );
+  // References(width, height): all three references alias one (blank) raster (decoder.cc:161-169)
+  int slot;
+  if ( aa_status st = alloc_slot( s.get(), &slot ) ) return st;
+  HIP_TRY( hipMemsetAsync( s->slots[slot].dev, 0, s->slot_bytes, ctx->compute ) );
+  for ( int i = 0; i < 3; i++ ) { s->cur_ref_slot[i] = -1; s->cur_ref_frame[i] = -1; }
+  for ( int i = 0; i < 3; i++ ) set_ref( s.get(), i, slot, -1 );
+  *out = s.release();
+  return AA_OK;
+}
+void aa_stream_destroy( aa_stream * s )
+{
+  if ( !s ) return;
+  (void) hipSetDevice( s->ctx->device );
+  (void) hipStreamSynchronize( s->ctx->compute ); (void) hipStreamSynchronize( s->ctx->copy );
+  for ( auto & c : s->chunks ) { (void) hipHostFree( c.host ); (void) hipFree( c.dev ); }
+  for ( auto & sl : s->slots ) (void) hipFree( sl.dev );
+  delete s;
+}
+
+static uint8_t * slot_plane( aa_stream * s, int slot, int plane )
+{
+  uint8_t * p = s->slots[slot].dev;
+  if ( plane >= 1 ) p += s->plane_bytes[0];
+  if ( plane >= 2 ) p += s->plane_bytes[1];
+  return p;
+}
+
+aa_status aa_stream_parse( aa_stream * s, const uint8_t * data, size_t size, int * frame_index, aa_frame_header * hdr_out )
+{
+  if ( !s || !data ) return fail( AA_ERR_ARGUMENT, "aa_stream_parse: null argument" );
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  const size_t nmb = size_t( s->parser.mb_width() ) * s->parser.mb_height();
+  const size_t job_bytes = align_up( sizeof( aa_dev_frame ) );
+  const size_t mb_bytes = align_up( nmb * sizeof( aa_mb_info ) );
+  const size_t worst = job_bytes + mb_bytes + align_up( nmb * 25 * 32 );
+  Chunk * c;
+  if ( aa_status st = reserve( s, worst, &c ) ) return st;
+  const size_t off = c->used;
+  aa_dev_frame * job = reinterpret_cast<aa_dev_frame *>( c->host + off );
+  aa_mb_info * mbs = reinterpret_cast<aa_mb_info *>( c->host + off + job_bytes );
+  int16_t * coeffs = reinterpret_cast<int16_t *>( c->host + off + job_bytes + mb_bytes );
+
+  FrameRec rec;
+  try { s->parser.parse( data, size, rec.hdr, mbs, coeffs ); }
+  catch ( const aa::ParseError & e ) { return fail( e.code, e.message ); }
+  const aa_frame_header & h = rec.hdr;
+  c->used = off + job_bytes + mb_bytes + align_up( size_t( h.num_coeff_blocks ) * 32 );   // commit what was used
+
+  // which 2:1 anti-diagonals hold intra MBs (launch schedule of k_recon_intra)
+  const int mbw = h.mb_width, mbh = h.mb_height;
+  rec.intra_diagonals.assign( mbw + 2 * ( mbh - 1 ), 0 );
+  if ( h.has_intra_mb )
+    for ( int r = 0; r < mbh; r++ ) for ( int col = 0; col < mbw; col++ )
+      if ( !( mbs[r * mbw + col].flags & AA_MB_INTER ) ) rec.intra_diagonals[col + 2 * r] = 1;
+
+  // raster slots: output + the References this frame predicts from; then Frame::copy_to on slot ids
+  int out_slot;
+  if ( aa_status st = alloc_slot( s, &out_slot ) ) return st;
+  retain( s, out_slot );   // the frame's own handle (RasterHandle returned to the caller)
+  rec.out_slot = out_slot;
+  std::memset( job, 0, sizeof *job );
+  for ( int p = 0; p < 3; p++ ) job->cur[p] = slot_plane( s, out_slot, p );
+  for ( int r = 0; r < 3; r++ ) for ( int p = 0; p < 3; p++ ) job->ref[r + 1][p] = slot_plane( s, s->cur_ref_slot[r], p );
+  job->mbs = reinterpret_cast<const aa_mb_info *>( c->dev + off + job_bytes );
+  job->coeffs = reinterpret_cast<const int16_t *>( c->dev + off + job_bytes + mb_bytes );
+  std::memcpy( job->quant, h.quant, sizeof job->quant );
+  job->mbw = h.mb_width; job->mbh = h.mb_height;
+  job->key_frame = h.key_frame; job->loop_filter_level = h.loop_filter_level;
+  job->sharpness = h.sharpness_level; job->has_intra = h.has_intra_mb;
+  rec.host_job = job;
+  rec.dev_job = reinterpret_cast<const aa_dev_frame *>( c->dev + off );
+
+  const int fi = static_cast<int>( s->frames.size() );
+  enum { LAST = 0, GOLDEN = 1, ALT = 2 };
+  if ( h.key_frame ) { for ( int i = 0; i < 3; i++ ) set_ref( s, i, out_slot, fi ); }
+  else {
+    if ( h.copy_buffer_to_alternate == 1 ) set_ref( s, ALT, s->cur_ref_slot[LAST], s->cur_ref_frame[LAST] );
+    else if ( h.copy_buffer_to_alternate == 2 ) set_ref( s, ALT, s->cur_ref_slot[GOLDEN], s->cur_ref_frame[GOLDEN] );
+    if ( h.copy_buffer_to_golden == 1 ) set_ref( s, GOLDEN, s->cur_ref_slot[LAST], s->cur_ref_frame[LAST] );
+    else if ( h.copy_buffer_to_golden == 2 ) set_ref( s, GOLDEN, s->cur_ref_slot[ALT], s->cur_ref_frame[ALT] );
+    if ( h.refresh_golden ) set_ref( s, GOLDEN, out_slot, fi );
+    if ( h.refresh_alternate ) set_ref( s, ALT, out_slot, fi );
+    if ( h.refresh_last ) set_ref( s, LAST, out_slot, fi );
+  }
+  for ( int i = 0; i < 3; i++ ) rec.ref_after[i] = s->cur_ref_frame[i];
+  s->frames.push_back( std::move( rec ) );
+  if ( frame_index ) *frame_index = fi;
+  if ( hdr_out ) *hdr_out = h;
+  return AA_OK;
+}
+
+aa_status aa_stream_upload( aa_stream * s )
+{
+  if ( !s ) return fail( AA_ERR_ARGUMENT, "null stream" );
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  bool any = false;
+  for ( auto & c : s->chunks ) {
+    if ( c.uploaded < c.used ) {
+      HIP_TRY( hipMemcpyAsync( c.dev + c.uploaded, c.host + c.uploaded, c.used - c.uploaded, hipMemcpyHostToDevice, s->ctx->copy ) );
+      c.uploaded = c.used; any = true;
+    }
+  }
+  if ( any ) {
+    HIP_TRY( hipEventRecord( s->ctx->upload_done, s->ctx->copy ) );
+    HIP_TRY( hipStreamWaitEvent( s->ctx->compute, s->ctx->upload_done, 0 ) );
+  }
+  return AA_OK;
+}
+
+aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, const int * frame_index )
+{
+  if ( !ctx || !streams || !frame_index || n <= 0 ) return fail( AA_ERR_ARGUMENT, "aa_decode_batch: bad argument" );
+  if ( aa_status st = set_device( ctx ) ) return st;
+  std::vector<const aa_dev_frame *> inter_jobs, intra_jobs, lf_jobs;
+  std::vector<const FrameRec *> intra_recs;
+  unsigned max_mbs = 0; int max_mbw = 0, max_mbh = 0;
+  uint64_t total_mbs = 0;
+  for ( int i = 0; i < n; i++ ) {
+    aa_stream * s = streams[i];
+    if ( !s || s->ctx != ctx ) return fail( AA_ERR_ARGUMENT, "aa_decode_batch: stream belongs to another context" );
+    const int fi = frame_index[i];
+    if ( fi < 0 || fi >= static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_ARGUMENT, "aa_decode_batch: frame index out of range" );
+    if ( fi != s->next_submit ) return fail( AA_ERR_LOGIC, "aa_decode_batch: frames of a stream must be submitted in order" );
+  }
+  for ( int i = 0; i < n; i++ ) if ( aa_status st = aa_stream_upload( streams[i] ) ) return st;
+  for ( int i = 0; i < n; i++ ) {
+    aa_stream * s = streams[i];
+    const FrameRec & r = s->frames[frame_index[i]];
+    const aa_frame_header & h = r.hdr;
+    if ( h.num_intra_mbs < h.num_macroblocks ) inter_jobs.push_back( r.dev_job );
+    if ( h.has_intra_mb ) { intra_jobs.push_back( r.dev_job ); intra_recs.push_back( &r ); }
+    if ( h.loop_filter_level ) lf_jobs.push_back( r.dev_job );
+    max_mbs = std::max<unsigned>( max_mbs, h.num_macroblocks );
+    max_mbw = std::max<int>( max_mbw, h.mb_width ); max_mbh = std::max<int>( max_mbh, h.mb_height );
+    total_mbs += h.num_macroblocks;
+    s->next_submit++;
+  }
+  ctx->stats.macroblocks += total_mbs;
+
+  auto for_each_list = [&]( const std::vector<const aa_dev_frame *> & jobs, auto && fn ) -> int {
+    for ( size_t base = 0; base < jobs.size(); base += AA_MAX_BATCH ) {
+      aa_frame_list list;
+      const int cnt = static_cast<int>( std::min<size_t>( AA_MAX_BATCH, jobs.size() - base ) );
+      for ( int k = 0; k < cnt; k++ ) list.f[k] = jobs[base + k];
+      for ( int k = cnt; k < AA_MAX_BATCH; k++ ) list.f[k] = nullptr;
+      if ( int e = fn( list, cnt ) ) return e;
+    }
+    return 0;
+  };
+  auto check = [&]( int e, const char * what ) -> aa_status {
+    if ( e ) return hip_fail( static_cast<hipError_t>( e ), what );
+    return AA_OK;
+  };
+
+  // 1. every inter-coded macroblock of the batch, one launch
+  if ( !inter_jobs.empty() ) {
+    const int e = for_each_list( inter_jobs, [&]( const aa_frame_list & l, int cnt ) {
+      LaunchTimer t( ctx, 0 ); return aa::launch_recon_inter( l, cnt, max_mbs, ctx->compute ); } );
+    if ( aa_status st = check( e, "k_recon_inter" ) ) return st;
+  }
+  const int ndiag = max_mbw + 2 * ( max_mbh - 1 );
+  // 2. intra macroblocks, 2:1 anti-diagonal order (left, above-left, above, above-right are final)
+  if ( !intra_jobs.empty() ) {
+    for ( int d = 0; d < ndiag; d++ ) {
+      bool needed = false;
+      for ( const FrameRec * r : intra_recs ) if ( d < static_cast<int>( r->intra_diagonals.size() ) && r->intra_diagonals[d] ) { needed = true; break; }
+      if ( !needed ) continue;
+      const int row_lo = std::max( 0, ( d - ( max_mbw - 1 ) + 1 ) / 2 ), row_hi = std::min( max_mbh - 1, d / 2 );
+      if ( row_hi < row_lo ) continue;
+      const int e = for_each_list( intra_jobs, [&]( const aa_frame_list & l, int cnt ) {
+        LaunchTimer t( ctx, 1 ); return aa::launch_recon_intra_diagonal( l, cnt, d, row_lo, row_hi - row_lo + 1, ctx->compute ); } );
+      if ( aa_status st = check( e, "k_recon_intra" ) ) return st;
+    }
+  }
+  // 3. loop filter over the fully reconstructed frames, same diagonal order (loopfilter.cc:133-154 dependencies)
+  if ( !lf_jobs.empty() ) {
+    for ( int d = 0; d < ndiag; d++ ) {
+      const int row_lo = std::max( 0, ( d - ( max_mbw - 1 ) + 1 ) / 2 ), row_hi = std::min( max_mbh - 1, d / 2 );
+      if ( row_hi < row_lo ) continue;
+      const int e = for_each_list( lf_jobs, [&]( const aa_frame_list & l, int cnt ) {
+        LaunchTimer t( ctx, 2 ); return aa::launch_loopfilter_diagonal( l, cnt, d, row_lo, row_hi - row_lo + 1, ctx->compute ); } );
+      if ( aa_status st = check( e, "k_loopfilter" ) ) return st;
+    }
+  }
+  return AA_OK;
+}
+
+aa_status aa_stream_decode( aa_stream * s, const uint8_t * data, size_t size, int * frame_index, int * shown )
+{
+  int fi = -1; aa_frame_header h;
+  if ( aa_status st = aa_stream_parse( s, data, size, &fi, &h ) ) return st;
+  aa_stream * one[1] = { s };
+  if ( aa_status st = aa_decode_batch( s->ctx, one, 1, &fi ) ) return st;
+  if ( frame_index ) *frame_index = fi;
+  if ( shown ) *shown = h.show_frame;
+  return AA_OK;
+}
+
+int aa_stream_frame_count( const aa_stream * s ) { return s ? static_cast<int>( s->frames.size() ) : 0; }
+
+aa_status aa_stream_release_before( aa_stream * s, int first_kept )
+{
+  if ( !s ) return fail( AA_ERR_ARGUMENT, "null stream" );
+  const int n = std::min<int>( first_kept, static_cast<int>( s->frames.size() ) );
+  for ( int i = 0; i < n; i++ ) if ( s->frames[i].handle_held ) { s->frames[i].handle_held = false; release( s, s->frames[i].out_slot ); }
+  return AA_OK;
+}
+
+aa_status aa_stream_rewind( aa_stream * s )
+{
+  if ( !s ) return fail( AA_ERR_ARGUMENT, "null stream" );
+  for ( const auto & f : s->frames ) if ( !f.handle_held ) return fail( AA_ERR_LOGIC, "aa_stream_rewind: frames were released; slots may have been reused" );
+  s->next_submit = 0;
+  return AA_OK;
+}
+
+aa_status aa_stream_download( aa_stream * s, int fi, uint8_t * y, uint8_t * u, uint8_t * v )
+{
+  if ( !s || fi < 0 || fi >= static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_ARGUMENT, "aa_stream_download: bad frame index" );
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  const FrameRec & r = s->frames[fi];
+  if ( !r.handle_held ) return fail( AA_ERR_LOGIC, "aa_stream_download: frame was released" );
+  if ( fi >= s->next_submit ) return fail( AA_ERR_LOGIC, "aa_stream_download: frame not decoded yet" );
+  HIP_TRY( hipStreamSynchronize( s->ctx->compute ) );
+  uint8_t * dst[3] = { y, u, v };
+  for ( int p = 0; p < 3; p++ ) if ( dst[p] ) HIP_TRY( hipMemcpy( dst[p], slot_plane( s, r.out_slot, p ), s->plane_bytes[p], hipMemcpyDeviceToHost ) );
+  return AA_OK;
+}
+
+aa_status aa_stream_raster_device( aa_stream * s, int fi, void ** y, void ** u, void ** v )
+{
+  if ( !s || fi < 0 || fi >= static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_ARGUMENT, "bad frame index" );
+  const FrameRec & r = s->frames[fi];
+  if ( y ) *y = slot_plane( s, r.out_slot, 0 );
+  if ( u ) *u = slot_plane( s, r.out_slot, 1 );
+  if ( v ) *v = slot_plane( s, r.out_slot, 2 );
+  return AA_OK;
+}
+
+aa_status aa_stream_references( const aa_stream * s, int * last, int * golden, int * alternate )
+{
+  if ( !s ) return fail( AA_ERR_ARGUMENT, "null stream" );
+  int r[3] = { -1, -1, -1 };
+  if ( s->next_submit > 0 ) std::memcpy( r, s->frames[s->next_submit - 1].ref_after, sizeof r );
+  if ( last ) *last = r[0];
+  if ( golden ) *golden = r[1];
+  if ( alternate ) *alternate = r[2];
+  return AA_OK;
+}
+
+static aa_status import_common( aa_stream * s, const void * const src[3], hipMemcpyKind kind )
+{
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  if ( s->next_submit != static_cast<int>( s->frames.size() ) )
+    return fail( AA_ERR_LOGIC, "import_reference: parsed frames are still waiting to be decoded" );
+  int slot;
+  if ( aa_status st = alloc_slot( s, &slot ) ) return st;
+  for ( int p = 0; p < 3; p++ )
+    HIP_TRY( hipMemcpyAsync( slot_plane( s, slot, p ), src[p], s->plane_bytes[p], kind, s->ctx->compute ) );
+  if ( kind == hipMemcpyHostToDevice ) HIP_TRY( hipStreamSynchronize( s->ctx->compute ) );
+  for ( int i = 0; i < 3; i++ ) set_ref( s, i, slot, -1 );
+  return AA_OK;
+}
+aa_status aa_stream_import_reference( aa_stream * s, const void * y, const void * u, const void * v )
+{
+  if ( !s || !y || !u || !v ) return fail( AA_ERR_ARGUMENT, "null argument" );
+  const void * src[3] = { y, u, v };
+  return import_common( s, src, hipMemcpyDeviceToDevice );
+}
+aa_status aa_stream_import_reference_host( aa_stream * s, const uint8_t * y, const uint8_t * u, const uint8_t * v )
+{
+  if ( !s || !y || !u || !v ) return fail( AA_ERR_ARGUMENT, "null argument" );
+  const void * src[3] = { y, u, v };
+  return import_common( s, src, hipMemcpyHostToDevice );
+}
+
+} // extern "C"

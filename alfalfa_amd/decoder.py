@@ -1,0 +1,214 @@
+"""Python mirror of the reference's decoder surface for THIS path, over the C ABI.
+
+Names follow the reference: Parser ~ DecoderState::parse_and_apply (decoder_state.hh:72-167),
+Decoder ~ Decoder (decoder.hh:244-300: decode_frame / get_frame_output / parse_and_decode_frame /
+get_references), FilePlayer ~ FilePlayer (player.hh:66-97: advance / eof), DecodeBatch = N
+independent streams decoded in lockstep (ExCamera chunks / GOPs, one batch per GPU).
+"""
+import ctypes as C
+import struct
+
+import numpy as np
+
+from . import capi
+from .capi import AlfalfaError, FrameHeader, MB_INFO_DTYPE  # noqa: F401
+
+
+class Parser:
+    """Host-only bitstream parser with the reference's persistent DecoderState."""
+
+    def __init__(self, width, height):
+        self.L = capi.lib()
+        self.h = C.c_void_p()
+        capi.check(self.L.aa_parser_create(width, height, C.byref(self.h)))
+        self.width, self.height = width, height
+        self.mbw, self.mbh = (width + 15) // 16, (height + 15) // 16
+        n = self.mbw * self.mbh
+        self._mb = np.zeros(n, dtype=MB_INFO_DTYPE)
+        self._coeff = np.zeros(n * 25 * 16, dtype=np.int16)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.aa_parser_destroy(self.h); self.h = None
+
+    def parse(self, frame_bytes):
+        """-> (header dict, mb_info structured array [mbh, mbw], coefficient blocks [n, 16])."""
+        hdr = FrameHeader()
+        capi.check(self.L.aa_parser_parse(self.h, frame_bytes, len(frame_bytes), C.byref(hdr),
+                                          self._mb.ctypes.data_as(C.c_void_p), self._coeff.ctypes.data_as(C.c_void_p)))
+        h = hdr.as_dict()
+        return h, self._mb.copy().reshape(self.mbh, self.mbw), self._coeff[:h["num_coeff_blocks"] * 16].copy().reshape(-1, 16)
+
+    def probs(self):
+        out = (C.c_uint8 * 1101)()
+        capi.check(self.L.aa_parser_get_probs(self.h, out))
+        return np.frombuffer(bytes(out), dtype=np.uint8)
+
+    def segmentation(self):
+        en, ab = C.c_int(), C.c_int()
+        q, lf = (C.c_int8 * 4)(), (C.c_int8 * 4)()
+        m = np.zeros(self.mbw * self.mbh, dtype=np.uint8)
+        capi.check(self.L.aa_parser_get_segmentation(self.h, C.byref(en), C.byref(ab), q, lf, m.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return {"enabled": bool(en.value), "absolute": bool(ab.value), "quant": list(q), "lf": list(lf), "map": m.reshape(self.mbh, self.mbw)}
+
+    def filter_adjustments(self):
+        en = C.c_int(); r, m = (C.c_int8 * 4)(), (C.c_int8 * 4)()
+        capi.check(self.L.aa_parser_get_filter_adjustments(self.h, C.byref(en), r, m))
+        return {"enabled": bool(en.value), "ref": list(r), "mode": list(m)}
+
+
+class Context:
+    """One HIP device: compute + copy streams.  One per process in multi-GPU runs."""
+
+    def __init__(self, device=0):
+        self.L = capi.lib()
+        self.h = C.c_void_p()
+        capi.check(self.L.aa_ctx_create(device, C.byref(self.h)))
+        self.device = device
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.aa_ctx_destroy(self.h); self.h = None
+
+    def sync(self):
+        capi.check(self.L.aa_ctx_sync(self.h))
+
+    def profile(self, enable):
+        capi.check(self.L.aa_ctx_profile(self.h, int(enable)))
+
+    def kernel_stats(self, reset=False):
+        st = capi.KernelStats()
+        capi.check(self.L.aa_ctx_kernel_stats(self.h, C.byref(st), int(reset)))
+        return {n: getattr(st, n) for n, _ in capi.KernelStats._fields_}
+
+    def compute_stream(self):
+        return self.L.aa_ctx_compute_stream(self.h)
+
+    def decode_batch(self, decoders, frame_indices):
+        n = len(decoders)
+        arr = (C.c_void_p * n)(*[d.h for d in decoders])
+        idx = (C.c_int * n)(*frame_indices)
+        capi.check(self.L.aa_decode_batch(self.h, arr, n, idx))
+
+
+class Decoder:
+    """Decoder(width, height) of the reference, rasters resident in HBM."""
+
+    def __init__(self, ctx, width, height):
+        self.ctx, self.L = ctx, capi.lib()
+        self.h = C.c_void_p()
+        capi.check(self.L.aa_stream_create(ctx.h, width, height, C.byref(self.h)))
+        self.width, self.height = width, height
+        self.padded_width, self.padded_height = capi.raster_geometry(width, height)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.aa_stream_destroy(self.h); self.h = None
+
+    # -- two-step form: parse_frame + decode_frame (decoder.cc:89-118) --
+    def parse_frame(self, frame_bytes):
+        fi, hdr = C.c_int(), FrameHeader()
+        capi.check(self.L.aa_stream_parse(self.h, frame_bytes, len(frame_bytes), C.byref(fi), C.byref(hdr)))
+        return fi.value, hdr.as_dict()
+
+    def upload(self):
+        capi.check(self.L.aa_stream_upload(self.h))
+
+    def decode_frame(self, frame_index):
+        self.ctx.decode_batch([self], [frame_index])
+
+    # -- one-step form: get_frame_output (decoder.cc:125-135) -> (shown, frame index of the raster) --
+    def get_frame_output(self, frame_bytes):
+        fi, shown = C.c_int(), C.c_int()
+        capi.check(self.L.aa_stream_decode(self.h, frame_bytes, len(frame_bytes), C.byref(fi), C.byref(shown)))
+        return bool(shown.value), fi.value
+
+    def parse_and_decode_frame(self, frame_bytes):
+        shown, fi = self.get_frame_output(frame_bytes)
+        return fi if shown else None
+
+    def frame_count(self):
+        return self.L.aa_stream_frame_count(self.h)
+
+    def rewind(self):
+        capi.check(self.L.aa_stream_rewind(self.h))
+
+    def release_before(self, first_kept):
+        capi.check(self.L.aa_stream_release_before(self.h, first_kept))
+
+    def raster(self, frame_index):
+        """VP8Raster of a decoded frame as three padded numpy planes (lazy D2H, like RasterHandle::get())."""
+        pw, ph = self.padded_width, self.padded_height
+        y = np.empty((ph, pw), np.uint8); u = np.empty((ph // 2, pw // 2), np.uint8); v = np.empty((ph // 2, pw // 2), np.uint8)
+        capi.check(self.L.aa_stream_download(self.h, frame_index, y.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
+        return y, u, v
+
+    def raster_bytes(self, frame_index):
+        return b"".join(p.tobytes() for p in self.raster(frame_index))
+
+    def display_bytes(self, frame_index):
+        """BaseRaster::dump (raster.cc:85-114): display rectangle as planar I420."""
+        y, u, v = self.raster(frame_index)
+        w, h = self.width, self.height
+        return y[:h, :w].tobytes() + u[:(h + 1) // 2, :(w + 1) // 2].tobytes() + v[:(h + 1) // 2, :(w + 1) // 2].tobytes()
+
+    def raster_device_pointers(self, frame_index):
+        y, u, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        capi.check(self.L.aa_stream_raster_device(self.h, frame_index, C.byref(y), C.byref(u), C.byref(v)))
+        return y.value, u.value, v.value
+
+    def get_references(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        capi.check(self.L.aa_stream_references(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"last": a.value, "golden": b.value, "alternative": c.value}
+
+    def import_reference_device(self, y_ptr, u_ptr, v_ptr):
+        capi.check(self.L.aa_stream_import_reference(self.h, C.c_void_p(y_ptr), C.c_void_p(u_ptr), C.c_void_p(v_ptr)))
+
+    def import_reference_host(self, y, u, v):
+        y, u, v = (np.ascontiguousarray(p, dtype=np.uint8) for p in (y, u, v))
+        capi.check(self.L.aa_stream_import_reference_host(self.h, y.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
+
+
+def read_ivf(path_or_bytes):
+    """IVF container (util/ivf.cc:36-82): -> (width, height, [frame bytes])."""
+    data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
+    if data[:4] != b"DKIF":
+        raise AlfalfaError(-1, "invalid bitstream: missing IVF file header")
+    if struct.unpack_from("<H", data, 4)[0] != 0:
+        raise AlfalfaError(-2, "unsupported bitstream: not an IVF version 0 file")
+    hdr_len = struct.unpack_from("<H", data, 6)[0]
+    if hdr_len != 32:
+        raise AlfalfaError(-2, "unsupported bitstream: unsupported IVF header length")
+    width, height = struct.unpack_from("<HH", data, 12)
+    nframes = struct.unpack_from("<I", data, 24)[0]
+    frames, pos = [], hdr_len
+    for _ in range(nframes):
+        if pos + 12 > len(data):
+            raise AlfalfaError(-1, "invalid bitstream: IVF file truncated")
+        n = struct.unpack_from("<I", data, pos)[0]
+        if pos + 12 + n > len(data):
+            raise AlfalfaError(-1, "invalid bitstream: IVF file truncated")
+        frames.append(bytes(data[pos + 12:pos + 12 + n])); pos += 12 + n
+    return width, height, frames
+
+
+class FilePlayer:
+    """FilePlayer (player.cc:85-144): starts at the first key frame; advance() returns the next SHOWN raster."""
+
+    def __init__(self, ctx, path_or_bytes):
+        self.width, self.height, self.frames = read_ivf(path_or_bytes)
+        self.decoder = Decoder(ctx, self.width, self.height)
+        self.frame_no = 0
+        while self.frame_no < len(self.frames) and (self.frames[self.frame_no][0] & 1):
+            self.frame_no += 1
+
+    def eof(self):
+        return self.frame_no == len(self.frames)
+
+    def advance(self):
+        while not self.eof():
+            fi = self.decoder.parse_and_decode_frame(self.frames[self.frame_no]); self.frame_no += 1
+            if fi is not None:
+                return fi
+        raise AlfalfaError(-2, "unsupported bitstream: hidden frames at end of file")

@@ -1,0 +1,187 @@
+/* alfalfa_amd.h -- C ABI of the MI355X-native VP8 decode hot path (drop-in for excamera/alfalfa src/decoder).
+ *
+ * The reference has no FFI layer: its seam is the C++ class API Decoder / DecoderState / References /
+ * RasterHandle / VP8Raster (decoder.hh:123-300, raster_handle.hh:77-123, vp8_raster.hh:53-316).  This
+ * header is the plain-C boundary underneath our C++ mirror of those classes (include/alfalfa_amd/ C++ headers)
+ * and underneath any other binding (ctypes in alfalfa_amd/capi.py).  Plain pointers
+ * and sizes only; every function returns an aa_status and never throws.  No torch types.
+ *
+ * Pipeline (reference call stack SURVEY.md 3.1):
+ *   host   aa_parser_*      decompress_frame + parse_frame  (uncompressed_chunk.cc:34-155, decoder_state.hh:72-167,
+ *                           frame.cc:95-137, macroblock.cc:43-502, tokens.cc:50-135) -> macroblock records + coefficient blocks
+ *   device aa_stream_*      decode_frame: Frame::decode + Frame::loopfilter + Frame::copy_to (decoder.cc:101-118,
+ *                           frame.cc:139-307) as HIP kernels over device-resident rasters
+ *   batch  aa_decode_batch  one pass of the hot path over frame f_i of N independent streams (ExCamera chunks / GOPs)
+ *
+ * There is NO CPU fallback for the device half: without a HIP device every aa_ctx_* / aa_stream_* call fails
+ * with AA_ERR_NO_DEVICE.  The parser half is host code by design (serial BoolDecoder) and runs anywhere.
+ */
+#ifndef ALFALFA_AMD_H
+#define ALFALFA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AA_ABI_VERSION 1
+
+typedef enum aa_status {
+  AA_OK = 0,
+  AA_ERR_INVALID = -1,      /* reference: Invalid("invalid bitstream: ...")       exception.hh:76-82  */
+  AA_ERR_UNSUPPORTED = -2,  /* reference: Unsupported("unsupported bitstream: ...") exception.hh:84-90 */
+  AA_ERR_LOGIC = -3,        /* reference: LogicError                                exception.hh:92-98  */
+  AA_ERR_OUT_OF_RANGE = -4, /* reference: std::out_of_range from Chunk bounds       chunk.hh:54-59     */
+  AA_ERR_HIP = -5,          /* HIP runtime failure (message has hipGetErrorString)                      */
+  AA_ERR_NO_DEVICE = -6,    /* no HIP device / kernels missing: the device path NEVER falls back to CPU */
+  AA_ERR_ARGUMENT = -7
+} aa_status;
+
+/* Message of the last failing call on this thread ("" if none). */
+const char * aa_last_error( void );
+int aa_abi_version( void );
+/* Number of visible HIP devices (0 when there is none; never fails). */
+int aa_device_count( void );
+
+/* ------------------------------------------------------------------------------------------------
+ * Parsed-frame records (what Appendix B of SURVEY.md says the device needs).  Layout is ABI.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Per-macroblock record, 80 bytes.  Modes use the reference's enums (modemv_data.hh:37-49). */
+typedef struct aa_mb_info {
+  uint8_t y_mode;        /* mbmode: DC_PRED,V_PRED,H_PRED,TM_PRED,B_PRED,NEARESTMV,NEARMV,ZEROMV,NEWMV,SPLITMV */
+  uint8_t uv_mode;       /* DC_PRED..TM_PRED (intra MBs) */
+  uint8_t ref_frame;     /* reference_frame: 0 CURRENT (intra), 1 LAST, 2 GOLDEN, 3 ALTREF */
+  uint8_t segment_id;    /* 0..3 (persistent map value; 0 when segmentation is off) */
+  uint8_t flags;         /* AA_MB_* */
+  uint8_t lf_level;      /* final loop-filter level of this MB, 0 = not filtered, else 1..63
+                            (segment + ref + mode adjustments applied, loopfilter.cc:43-79, macroblock.cc:611-623) */
+  uint8_t split_partition; /* SPLITMV partition id (mv_partitions index) */
+  uint8_t reserved;
+  uint32_t nz_mask;      /* bit b set: block b has stored coefficients. b: 0..15 Y (raster), 16..19 U, 20..23 V, 24 Y2 */
+  uint32_t coeff_index;  /* index (in 16-coefficient blocks) of this MB's first stored block in the frame's coefficient array */
+  union {
+    uint8_t b_mode[16];  /* B_PRED: bmode of each 4x4 (intra MBs) */
+    int16_t mv[16][2];   /* inter MBs: {x, y} of each Y sub-block, quarter-pel (all equal unless SPLITMV) */
+  } u;
+} aa_mb_info;
+
+#define AA_MB_HAS_NONZERO 1u   /* Macroblock::has_nonzero_: residual path runs (macroblock.cc:531,547,579,593) */
+#define AA_MB_HAS_Y2 2u        /* Y2 coded: mode is neither B_PRED nor SPLITMV (block.hh:183-190) */
+#define AA_MB_INTER 4u         /* inter_coded() */
+#define AA_MB_SKIP 8u          /* mb_skip_coeff */
+#define AA_MB_LF_SKIP_INNER 16u /* loop filter skips sub-block edges: Y2 coded && !has_nonzero (macroblock.cc:607) */
+
+/* Per-frame constants. */
+typedef struct aa_frame_header {
+  uint8_t key_frame, show_frame;
+  uint8_t loop_filter_level;   /* header value; 0 => Frame::loopfilter is skipped entirely (frame.cc:143) */
+  uint8_t sharpness_level;
+  uint8_t num_dct_partitions;
+  uint8_t segmentation_enabled, filter_adjustments_enabled;
+  uint8_t refresh_last, refresh_golden, refresh_alternate;  /* key frames: all 1 */
+  uint8_t copy_buffer_to_golden, copy_buffer_to_alternate;  /* 0 none, 1 last, 2 the other (frame.cc:278-292) */
+  uint8_t sign_bias_golden, sign_bias_alternate;
+  uint8_t q_index;
+  uint8_t has_intra_mb;        /* any intra MB in this frame (always 1 for key frames) */
+  uint16_t mb_width, mb_height;
+  uint16_t width, height;      /* display size */
+  /* dequantisation factors per segment (index 0 used when segmentation is off; all 4 filled):
+     {y_dc, y_ac, y2_dc, y2_ac, uv_dc, uv_ac}  quantization.cc:83-93, frame.cc:185-206 */
+  uint16_t quant[4][6];
+  uint32_t num_macroblocks;
+  uint32_t num_coeff_blocks;   /* stored 16-coefficient blocks (32 bytes each) */
+  uint32_t num_intra_mbs;
+  uint32_t compressed_size;
+} aa_frame_header;
+
+/* ------------------------------------------------------------------------------------------------
+ * Host parser: the reference's DecoderState + parse_frame (decoder_state.hh:72-167).  Host only.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct aa_parser aa_parser;
+
+aa_status aa_parser_create( uint16_t width, uint16_t height, aa_parser ** out );
+void aa_parser_destroy( aa_parser * p );
+
+/* Parse one compressed frame (Chunk = {data,size}, chunk.hh:38-73) and apply it to the persistent state.
+ * mb_out must hold mb_width*mb_height records; coeff_out must hold 25*16*mb_width*mb_height int16 (worst case).
+ * On error the persistent state is left as the reference leaves it (it may already be modified). */
+aa_status aa_parser_parse( aa_parser * p, const uint8_t * data, size_t size,
+                           aa_frame_header * hdr_out, aa_mb_info * mb_out, int16_t * coeff_out );
+
+/* Persistent state (DecoderState, decoder.hh:190-225), flat export for tests / serialisation:
+ * probs[1101] = 1056 coefficient, 4 y-mode, 3 uv-mode, 38 mv probabilities. */
+aa_status aa_parser_get_probs( const aa_parser * p, uint8_t probs[1101] );
+/* segmentation: enabled, absolute, quant[4], lf[4]; map (mb_width*mb_height bytes) may be NULL */
+aa_status aa_parser_get_segmentation( const aa_parser * p, int * enabled, int * absolute, int8_t quant[4], int8_t lf[4], uint8_t * map );
+aa_status aa_parser_get_filter_adjustments( const aa_parser * p, int * enabled, int8_t ref[4], int8_t mode[4] );
+
+/* ------------------------------------------------------------------------------------------------
+ * Device context: one per GPU (one process per GPU in multi-GPU runs).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct aa_ctx aa_ctx;
+typedef struct aa_stream aa_stream;
+
+aa_status aa_ctx_create( int device, aa_ctx ** out );
+void aa_ctx_destroy( aa_ctx * ctx );
+aa_status aa_ctx_sync( aa_ctx * ctx );               /* waits for copy + compute streams */
+/* hipStream_t handles as opaque pointers (to order foreign work, e.g. an RCCL broadcast, against ours) */
+void * aa_ctx_compute_stream( aa_ctx * ctx );
+void * aa_ctx_copy_stream( aa_ctx * ctx );
+
+/* ------------------------------------------------------------------------------------------------
+ * Stream decoder: the reference's Decoder (decoder.hh:244-300) with device-resident References.
+ * Frames are appended in bitstream order; rasters live in HBM and are fetched on demand.
+ * ---------------------------------------------------------------------------------------------- */
+aa_status aa_stream_create( aa_ctx * ctx, uint16_t width, uint16_t height, aa_stream ** out );
+void aa_stream_destroy( aa_stream * s );
+
+/* Host half: parse frame into pinned staging (no GPU work). Returns the frame's index in *frame_index. */
+aa_status aa_stream_parse( aa_stream * s, const uint8_t * data, size_t size, int * frame_index, aa_frame_header * hdr_out );
+/* hipMemcpyAsync (copy stream) of every parsed, not yet uploaded frame's records into HBM. */
+aa_status aa_stream_upload( aa_stream * s );
+/* Device half for frame `frame_index` of each of n streams (all on the same ctx): reconstruct, loop-filter,
+ * update references.  Frames of one stream must be submitted in order.  Asynchronous. */
+aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, const int * frame_index );
+/* Convenience = parse + upload + decode_batch(n=1): Decoder::get_frame_output (decoder.cc:125-135). */
+aa_status aa_stream_decode( aa_stream * s, const uint8_t * data, size_t size, int * frame_index, int * shown );
+
+/* Number of frames appended so far; drop host+device records of frames < first_kept (rasters stay while referenced). */
+int aa_stream_frame_count( const aa_stream * s );
+aa_status aa_stream_release_before( aa_stream * s, int first_kept );
+/* Forget all frames but keep decoder state? No: rewind the DEVICE half to frame 0 so the same resident
+ * records can be decoded again (used by bench.py's steps; parser state is untouched). */
+aa_status aa_stream_rewind( aa_stream * s );
+
+/* Output raster of a decoded frame (VP8Raster: three padded planes, stride = padded width, raster.hh:54-56).
+ * Synchronises with the compute stream, then D2H.  Any pointer may be NULL. */
+aa_status aa_stream_download( aa_stream * s, int frame_index, uint8_t * y, uint8_t * u, uint8_t * v );
+/* Device pointers of a frame's planes (valid while the frame's raster is alive). */
+aa_status aa_stream_raster_device( aa_stream * s, int frame_index, void ** y, void ** u, void ** v );
+/* References::last/golden/alternative after the most recently SUBMITTED frame: frame indices (-1 = initial blank). */
+aa_status aa_stream_references( const aa_stream * s, int * last, int * golden, int * alternate );
+/* Replace all three references by a raster given as device planes (e.g. received by an RCCL broadcast over xGMI):
+ * the entry-state hand-off of xc-decode-bundle (decoder.cc:171-175, References(EncoderStateDeserializer&)). */
+aa_status aa_stream_import_reference( aa_stream * s, const void * y_dev, const void * u_dev, const void * v_dev );
+/* Same from host planes. */
+aa_status aa_stream_import_reference_host( aa_stream * s, const uint8_t * y, const uint8_t * u, const uint8_t * v );
+
+/* Padded plane geometry for a display size (VP8Raster ctor, prediction.cc:94-97). */
+void aa_raster_geometry( uint16_t width, uint16_t height, uint32_t * padded_width, uint32_t * padded_height );
+
+/* Per-kernel timing of the device half, measured with HIP events on the compute stream.
+ * enable=1 brackets every kernel launch with events (serialises nothing beyond event records). */
+typedef struct aa_kernel_stats {
+  double recon_inter_ms, recon_intra_ms, loopfilter_ms;      /* summed launch durations */
+  uint64_t recon_inter_launches, recon_intra_launches, loopfilter_launches;
+  uint64_t macroblocks;                                      /* MBs processed by decode_batch calls */
+} aa_kernel_stats;
+aa_status aa_ctx_profile( aa_ctx * ctx, int enable );
+aa_status aa_ctx_kernel_stats( aa_ctx * ctx, aa_kernel_stats * out, int reset );
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALFALFA_AMD_H */
