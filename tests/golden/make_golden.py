@@ -22,16 +22,31 @@ CASES = [("qcif_q30",        176, 144,  6,  7, "low",   30, "best",  -1, -1, Fal
          ("w200_q40_lf63s7", 208, 112,  8, 33, "high",  40, "rt",    63,  7, False)]
 
 
+# synthetic feature streams (tools/vp8_synth.py): SPLITMV, golden/altref + sign bias, segmentation, 1..8 partitions,
+# loop-filter deltas, hidden frames, probability updates, far-out MVs, odd sizes -- things the reference encoder never emits
+#             name              w    h   seed frames
+SYNTH_CASES = [("synth_96x80_s1",   96,  80,  1, 8), ("synth_175x143_s3", 175, 143, 3, 6), ("synth_33x17_s7", 33, 17, 7, 10),
+               ("synth_200x48_s11", 200, 48, 11, 8), ("synth_64x64_s20", 64, 64, 20, 8)]
+
+
 def run(*cmd):
     subprocess.run(list(cmd), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
 def main():
+    import vp8_synth
     out = {}
     with tempfile.TemporaryDirectory() as td:
-        for name, w, h, n, seed, ent, qi, quality, lf, sharp, allkey in CASES:
+        for case in CASES + SYNTH_CASES:
+            if len(case) == 5:
+                name, w, h, seed, n = case
+                lf, allkey = -1, None
+            else:
+                name, w, h, n, seed, ent, qi, quality, lf, sharp, allkey = case
             ivf = os.path.join(td, name + ".ivf")
-            if allkey:
+            if allkey is None:
+                vo.write_ivf(ivf, w, h, vp8_synth.feature_stream(w, h, seed, n).frames)
+            elif allkey:
                 frames = []
                 for k, planes in enumerate(make_y4m.synth_frames(w, h, n, seed, ent)):
                     y4m = os.path.join(td, "one.y4m")

@@ -61,3 +61,18 @@ def test_batched_lockstep_equals_single_stream(gpu_ctx):
         gpu_ctx.decode_batch(decs, [f] * len(decs))
     for d, n in zip(decs, streams):
         assert sha256(d.raster_bytes(3)) == GOLDEN[n]["raster_sha256"][3]
+
+
+@pytest.mark.parametrize("seed", list(range(200, 224)))
+def test_hip_matches_oracle_on_synthetic_feature_streams(gpu_ctx, seed):
+    """SPLITMV / golden+altref / segmentation / multi-partition / LF deltas / hidden frames / far MVs / odd sizes."""
+    import vp8_synth
+    sizes = [(96, 80), (33, 17), (64, 64), (175, 143), (16, 16), (200, 48), (320, 176), (48, 256)]
+    w, h = sizes[seed % len(sizes)]
+    st = vp8_synth.feature_stream(w, h, seed, 8)
+    dec, ora = aa.Decoder(gpu_ctx, w, h), vo.OracleDecoder(w, h)
+    for i, fr in enumerate(st.frames):
+        shown, fi = dec.get_frame_output(fr)
+        assert ora.decode(fr) == shown
+        got, want = dec.raster_bytes(fi), ora.raster_bytes()
+        assert got == want, "seed %d frame %d (%s): %s" % (seed, i, ora.frame_info(), first_diff(got, want, dec.padded_width, dec.padded_height))
