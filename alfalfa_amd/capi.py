@@ -62,6 +62,11 @@ SYMBOLS = [
     ("aa_parser_get_probs", C.c_int, [_P, _U8P]),
     ("aa_parser_get_segmentation", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int8), C.POINTER(C.c_int8), _U8P]),
     ("aa_parser_get_filter_adjustments", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int8), C.POINTER(C.c_int8)]),
+    ("aa_parser_state_size", C.c_size_t, [_P]), ("aa_parser_export_state", C.c_int, [_P, _P, C.c_size_t]),
+    ("aa_parser_import_state", C.c_int, [_P, C.c_char_p, C.c_size_t]),
+    ("aa_stream_state_size", C.c_size_t, [_P]), ("aa_stream_export_state", C.c_int, [_P, _P, C.c_size_t]),
+    ("aa_stream_import_state", C.c_int, [_P, C.c_char_p, C.c_size_t]),
+    ("aa_stream_export_raster", C.c_int, [_P, C.c_int, _P, _P, _P]),
     ("aa_ctx_create", C.c_int, [C.c_int, C.POINTER(_P)]), ("aa_ctx_destroy", None, [_P]), ("aa_ctx_sync", C.c_int, [_P]),
     ("aa_ctx_compute_stream", _P, [_P]), ("aa_ctx_copy_stream", _P, [_P]),
     ("aa_stream_create", C.c_int, [_P, C.c_uint16, C.c_uint16, C.POINTER(_P)]), ("aa_stream_destroy", None, [_P]),

@@ -167,6 +167,34 @@ Parser::Parser( uint16_t width, uint16_t height )
   seg_.map.assign( static_cast<size_t>( mbw_ ) * mbh_, 3 );
 }
 
+size_t Parser::state_size() const { return 4 + 6 + 1101 + 10 + 9 + seg_.map.size(); }
+
+void Parser::export_state( uint8_t * out ) const
+{
+  std::memcpy( out, "AAST", 4 ); out += 4;
+  const uint16_t hdr[3] = { 1, width_, height_ };
+  std::memcpy( out, hdr, 6 ); out += 6;
+  std::memcpy( out, probs_.coeff, 1056 ); std::memcpy( out + 1056, probs_.y_mode, 4 );
+  std::memcpy( out + 1060, probs_.uv_mode, 3 ); std::memcpy( out + 1063, probs_.mv, 38 ); out += 1101;
+  out[0] = seg_.enabled; out[1] = seg_.absolute; std::memcpy( out + 2, seg_.quant, 4 ); std::memcpy( out + 6, seg_.lf, 4 ); out += 10;
+  out[0] = fadj_.enabled; std::memcpy( out + 1, fadj_.ref, 4 ); std::memcpy( out + 5, fadj_.mode, 4 ); out += 9;
+  std::memcpy( out, seg_.map.data(), seg_.map.size() );
+}
+
+void Parser::import_state( const uint8_t * in, size_t size )
+{
+  uint16_t hdr[3];
+  if ( size != state_size() || std::memcmp( in, "AAST", 4 ) != 0 ) throw ParseError( AA_ERR_ARGUMENT, "import_state: not a decoder-state blob of this geometry" );
+  std::memcpy( hdr, in + 4, 6 );
+  if ( hdr[0] != 1 || hdr[1] != width_ || hdr[2] != height_ ) throw ParseError( AA_ERR_ARGUMENT, "import_state: version or frame size mismatch" );
+  in += 10;
+  std::memcpy( probs_.coeff, in, 1056 ); std::memcpy( probs_.y_mode, in + 1056, 4 );
+  std::memcpy( probs_.uv_mode, in + 1060, 3 ); std::memcpy( probs_.mv, in + 1063, 38 ); in += 1101;
+  seg_.enabled = in[0]; seg_.absolute = in[1]; std::memcpy( seg_.quant, in + 2, 4 ); std::memcpy( seg_.lf, in + 6, 4 ); in += 10;
+  fadj_.enabled = in[0]; std::memcpy( fadj_.ref, in + 1, 4 ); std::memcpy( fadj_.mode, in + 5, 4 ); in += 9;
+  std::memcpy( seg_.map.data(), in, seg_.map.size() );
+}
+
 void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa_mb_info * mbs, int16_t * coeff_out )
 {
   // ---- frame tag + partition split: uncompressed_chunk.cc:34-130 ----

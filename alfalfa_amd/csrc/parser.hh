@@ -60,6 +60,13 @@ public:
   unsigned mb_width() const { return mbw_; }
   unsigned mb_height() const { return mbh_; }
 
+  // DecoderState as a flat blob (the hand-off `Decoder( DecoderState, References )` needs, decoder.cc:43-46):
+  // "AAST" u16 version, u16 width, u16 height, probs[1101], seg{enabled,absolute,quant[4],lf[4]}, fadj{enabled,ref[4],mode[4]},
+  // segmentation map[mb_width*mb_height]
+  size_t state_size() const;
+  void export_state( uint8_t * out ) const;
+  void import_state( const uint8_t * in, size_t size );   // throws ParseError(AA_ERR_ARGUMENT) on a foreign / mismatching blob
+
   const ProbTables & probs() const { return probs_; }
   const SegmentationState & segmentation() const { return seg_; }
   const FilterAdjustState & filter_adjustments() const { return fadj_; }

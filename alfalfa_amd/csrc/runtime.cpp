@@ -211,6 +211,23 @@ aa_status aa_parser_get_filter_adjustments( const aa_parser * p, int * enabled, 
   return AA_OK;
 }
 
+static aa_status export_state_common( const aa::Parser & ps, uint8_t * buf, size_t capacity )
+{
+  if ( !buf || capacity < ps.state_size() ) return fail( AA_ERR_ARGUMENT, "export_state: buffer too small" );
+  ps.export_state( buf ); return AA_OK;
+}
+static aa_status import_state_common( aa::Parser & ps, const uint8_t * buf, size_t size )
+{
+  if ( !buf ) return fail( AA_ERR_ARGUMENT, "import_state: null buffer" );
+  try { ps.import_state( buf, size ); } catch ( const aa::ParseError & e ) { return fail( e.code, e.message ); }
+  return AA_OK;
+}
+size_t aa_parser_state_size( const aa_parser * p ) { return p ? p->impl.state_size() : 0; }
+aa_status aa_parser_export_state( const aa_parser * p, uint8_t * buf, size_t capacity )
+{ return p ? export_state_common( p->impl, buf, capacity ) : fail( AA_ERR_ARGUMENT, "null parser" ); }
+aa_status aa_parser_import_state( aa_parser * p, const uint8_t * buf, size_t size )
+{ return p ? import_state_common( p->impl, buf, size ) : fail( AA_ERR_ARGUMENT, "null parser" ); }
+
 /* ---------------- context ---------------- */
 aa_status aa_ctx_create( int device, aa_ctx ** out )
 {
@@ -525,6 +542,22 @@ aa_status aa_stream_references( const aa_stream * s, int * last, int * golden, i
   if ( alternate ) *alternate = r[2];
   return AA_OK;
 }
+
+aa_status aa_stream_export_raster( aa_stream * s, int fi, void * y, void * u, void * v )
+{
+  if ( !s || fi < 0 || fi >= static_cast<int>( s->frames.size() ) || !y || !u || !v ) return fail( AA_ERR_ARGUMENT, "aa_stream_export_raster: bad argument" );
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  if ( fi >= s->next_submit ) return fail( AA_ERR_LOGIC, "aa_stream_export_raster: frame not decoded yet" );
+  void * dst[3] = { y, u, v };
+  for ( int p = 0; p < 3; p++ )
+    HIP_TRY( hipMemcpyAsync( dst[p], slot_plane( s, s->frames[fi].out_slot, p ), s->plane_bytes[p], hipMemcpyDeviceToDevice, s->ctx->compute ) );
+  return AA_OK;
+}
+size_t aa_stream_state_size( const aa_stream * s ) { return s ? s->parser.state_size() : 0; }
+aa_status aa_stream_export_state( const aa_stream * s, uint8_t * buf, size_t capacity )
+{ return s ? export_state_common( s->parser, buf, capacity ) : fail( AA_ERR_ARGUMENT, "null stream" ); }
+aa_status aa_stream_import_state( aa_stream * s, const uint8_t * buf, size_t size )
+{ return s ? import_state_common( s->parser, buf, size ) : fail( AA_ERR_ARGUMENT, "null stream" ); }
 
 static aa_status import_common( aa_stream * s, const void * const src[3], hipMemcpyKind kind )
 {

@@ -39,6 +39,16 @@ class Parser:
         h = hdr.as_dict()
         return h, self._mb.copy().reshape(self.mbh, self.mbw), self._coeff[:h["num_coeff_blocks"] * 16].copy().reshape(-1, 16)
 
+    def export_state(self):
+        """DecoderState as bytes (host half of the entry-state hand-off, decoder.cc:43-46)."""
+        n = self.L.aa_parser_state_size(self.h)
+        buf = (C.c_uint8 * n)()
+        capi.check(self.L.aa_parser_export_state(self.h, buf, n))
+        return bytes(buf)
+
+    def import_state(self, blob):
+        capi.check(self.L.aa_parser_import_state(self.h, blob, len(blob)))
+
     def probs(self):
         out = (C.c_uint8 * 1101)()
         capi.check(self.L.aa_parser_get_probs(self.h, out))
@@ -161,6 +171,23 @@ class Decoder:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         capi.check(self.L.aa_stream_references(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return {"last": a.value, "golden": b.value, "alternative": c.value}
+
+    def export_state(self):
+        n = self.L.aa_stream_state_size(self.h)
+        buf = (C.c_uint8 * n)()
+        capi.check(self.L.aa_stream_export_state(self.h, buf, n))
+        return bytes(buf)
+
+    def import_state(self, blob):
+        capi.check(self.L.aa_stream_import_state(self.h, blob, len(blob)))
+
+    def plane_sizes(self):
+        pw, ph = self.padded_width, self.padded_height
+        return pw * ph, (pw // 2) * (ph // 2), (pw // 2) * (ph // 2)
+
+    def export_raster_device(self, frame_index, y_ptr, u_ptr, v_ptr):
+        """D2D copy of a decoded raster into caller-owned device planes (async on the compute stream)."""
+        capi.check(self.L.aa_stream_export_raster(self.h, frame_index, C.c_void_p(y_ptr), C.c_void_p(u_ptr), C.c_void_p(v_ptr)))
 
     def import_reference_device(self, y_ptr, u_ptr, v_ptr):
         capi.check(self.L.aa_stream_import_reference(self.h, C.c_void_p(y_ptr), C.c_void_p(u_ptr), C.c_void_p(v_ptr)))

@@ -118,6 +118,12 @@ aa_status aa_parser_get_probs( const aa_parser * p, uint8_t probs[1101] );
 aa_status aa_parser_get_segmentation( const aa_parser * p, int * enabled, int * absolute, int8_t quant[4], int8_t lf[4], uint8_t * map );
 aa_status aa_parser_get_filter_adjustments( const aa_parser * p, int * enabled, int8_t ref[4], int8_t mode[4] );
 
+/* DecoderState as one flat blob: the host half of the entry-state hand-off `Decoder( DecoderState, References )`
+ * (decoder.cc:43-46; the device half is aa_stream_import_reference).  Size depends only on the frame size. */
+size_t aa_parser_state_size( const aa_parser * p );
+aa_status aa_parser_export_state( const aa_parser * p, uint8_t * buf, size_t capacity );
+aa_status aa_parser_import_state( aa_parser * p, const uint8_t * buf, size_t size );
+
 /* ------------------------------------------------------------------------------------------------
  * Device context: one per GPU (one process per GPU in multi-GPU runs).
  * ---------------------------------------------------------------------------------------------- */
@@ -167,6 +173,14 @@ aa_status aa_stream_references( const aa_stream * s, int * last, int * golden, i
 aa_status aa_stream_import_reference( aa_stream * s, const void * y_dev, const void * u_dev, const void * v_dev );
 /* Same from host planes. */
 aa_status aa_stream_import_reference_host( aa_stream * s, const uint8_t * y, const uint8_t * u, const uint8_t * v );
+
+/* Copy a decoded frame's raster into caller-owned DEVICE planes (e.g. a torch tensor used as RCCL send buffer);
+ * asynchronous on the compute stream. */
+aa_status aa_stream_export_raster( aa_stream * s, int frame_index, void * y_dev, void * u_dev, void * v_dev );
+/* The stream's DecoderState (its parser), same blob as aa_parser_export_state / aa_parser_import_state. */
+size_t aa_stream_state_size( const aa_stream * s );
+aa_status aa_stream_export_state( const aa_stream * s, uint8_t * buf, size_t capacity );
+aa_status aa_stream_import_state( aa_stream * s, const uint8_t * buf, size_t size );
 
 /* Padded plane geometry for a display size (VP8Raster ctor, prediction.cc:94-97). */
 void aa_raster_geometry( uint16_t width, uint16_t height, uint32_t * padded_width, uint32_t * padded_height );
