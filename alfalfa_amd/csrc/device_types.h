@@ -12,6 +12,7 @@ struct aa_dev_frame {
   const uint8_t * ref[4][3];   // [1] last, [2] golden, [3] altref planes ([0] unused)
   const aa_mb_info * mbs;      // mb_width*mb_height records
   const int16_t * coeffs;      // compact 16-coefficient blocks
+  const unsigned long long * intra_rows;   // per MB row: ceil(mbw/64) words, bit c set = MB (c,row) is intra
   uint16_t quant[4][6];        // per segment {y_dc,y_ac,y2_dc,y2_ac,uv_dc,uv_ac}
   uint16_t mbw, mbh;
   uint8_t key_frame;
@@ -21,6 +22,16 @@ struct aa_dev_frame {
   uint32_t pad;
 };
 
+// In-launch ordering state of the row-pipelined kernels; zeroed (hipMemsetAsync) before every such launch.
+struct aa_sync_ws {
+  int error;                   // != 0: a bounded spin expired (sticky; reported as AA_ERR_HIP by the host).  NOT zeroed per launch.
+  int pad0[3];
+  int ticket;                  // next (frame,row) to hand out        -- zeroed from here on before every launch
+  int pad1[3];
+  int progress[1];             // [frame in launch][mbh_max]: macroblock columns of that row that are final
+};
+#define AA_SYNC_WS_ZERO_FROM 16   // byte offset of `ticket`
+
 #define AA_MAX_BATCH 120       // frames per launch: kernel argument = 120 pointers (960 B) passed by value
 
 struct aa_frame_list {
@@ -28,9 +39,10 @@ struct aa_frame_list {
 };
 
 // kernels.hip launchers (plain C++ signatures so runtime.cpp needs no HIP kernel syntax)
-struct aa_launch_timing;
 namespace aa {
 int launch_recon_inter( const aa_frame_list & list, int n, unsigned max_mbs, void * stream );
 int launch_recon_intra_diagonal( const aa_frame_list & list, int n, int diagonal, int row_lo, int rows, void * stream );
 int launch_loopfilter_diagonal( const aa_frame_list & list, int n, int diagonal, int row_lo, int rows, void * stream );
+int launch_recon_intra_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, void * stream );
+int launch_loopfilter_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, void * stream );
 }

@@ -227,11 +227,137 @@ __global__ __launch_bounds__( kLanes ) void k_recon_inter( const aa_frame_list l
   }
 }
 
+// ---- global accesses that other workgroups of the SAME launch consume / produced -----------------------------------
+// Row-pipelined kernels hand pixels from one workgroup to another inside a launch.  Per-XCD L2s are not coherent and a
+// CU's L1 is never refreshed by other CUs' stores, so (MI355X_MICROARCH.md "inter-workgroup visibility", valid form
+// "{sc1 stores and sc1 loads on both sides}") shared pixels are written with write-through agent-scope stores, the
+// producing wave drains them (s_waitcnt vmcnt(0)) before it publishes its progress word, and consumers read them with
+// agent-scope (L1-bypassing) loads after one relaxed poll of that word.  No fences.
+template <bool kShared>
+__device__ __forceinline__ void store_u32( uint8_t * p, uint32_t v )
+{
+  if ( kShared ) __hip_atomic_store( reinterpret_cast<uint32_t *>( p ), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  else *reinterpret_cast<uint32_t *>( p ) = v;
+}
+template <bool kShared>
+__device__ __forceinline__ uint32_t load_u32( const uint8_t * p )
+{
+  if ( kShared ) return __hip_atomic_load( reinterpret_cast<const uint32_t *>( p ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  return *reinterpret_cast<const uint32_t *>( p );
+}
+
 struct alignas( 16 ) IntraLds {
   ResidualLds r;
-  uint8_t y[17][24];     // [row+1][col+1]: row -1 = above (cols -1..19 incl. above-right), col -1 = left
-  uint8_t c[2][9][12];   // chroma: [plane][row+1][col+1]
+  alignas( 16 ) uint8_t y[17][24];    // [row+1][col+4]: row -1 = above (cols -4..19 incl. above-right), col -1 = left
+  alignas( 16 ) uint8_t c[2][9][12];  // chroma: [plane][row+1][col+4]
 };
+
+// One intra macroblock, whole wave: neighbours -> LDS, predict (+ residual), write.  Macroblock::reconstruct_intra
+// (macroblock.cc:523-551) with VP8Raster::Block<N>::predictors (prediction.cc:99-167).
+// kShared: neighbours may have been produced by another workgroup of this launch (row-pipelined schedule).
+template <bool kShared>
+__device__ void intra_macroblock( const aa_dev_frame & f, const aa_mb_info & mb, const int col, const int row, IntraLds & L, const int lane )
+{
+  const int pw = f.mbw * 16, cw = pw >> 1;
+  const bool has_res = mb.flags & AA_MB_HAS_NONZERO;
+  if ( has_res ) compute_residual( mb, f, L.r, lane );
+
+  const int x0 = col * 16, y0 = row * 16;
+  const uint8_t * Y = f.cur[0];
+  // above row as 6 dwords: x0-4 (corner in byte 3), x0..x0+15, x0+16 (above-right); left column: byte 3 of the dword at x0-4
+  if ( lane < 6 ) {
+    uint32_t v;
+    if ( y0 == 0 ) v = 0x7F7F7F7Fu;
+    else if ( lane == 0 ) v = x0 > 0 ? load_u32<kShared>( Y + static_cast<size_t>( y0 - 1 ) * pw + x0 - 4 ) : 0x81818181u;
+    else if ( lane <= 4 ) v = load_u32<kShared>( Y + static_cast<size_t>( y0 - 1 ) * pw + x0 + ( lane - 1 ) * 4 );
+    else if ( x0 + 16 >= pw ) v = 0x01010101u * ( load_u32<kShared>( Y + static_cast<size_t>( y0 - 1 ) * pw + pw - 4 ) >> 24 );   // replicate: prediction.cc:144-151
+    else v = load_u32<kShared>( Y + static_cast<size_t>( y0 - 1 ) * pw + x0 + 16 );
+    *reinterpret_cast<uint32_t *>( &L.y[0][lane * 4] ) = v;
+  } else if ( lane >= 32 && lane < 48 ) {
+    const int r = lane - 32;
+    L.y[r + 1][3] = x0 > 0 ? static_cast<uint8_t>( load_u32<kShared>( Y + static_cast<size_t>( y0 + r ) * pw + x0 - 4 ) >> 24 ) : 129;
+  }
+  {
+    const int cx0 = col * 8, cy0 = row * 8;
+    const int pl = lane >> 5, l = lane & 31;
+    const uint8_t * C = f.cur[1 + pl];
+    if ( l < 3 ) {
+      uint32_t v;
+      if ( cy0 == 0 ) v = 0x7F7F7F7Fu;
+      else if ( l == 0 ) v = cx0 > 0 ? load_u32<kShared>( C + static_cast<size_t>( cy0 - 1 ) * cw + cx0 - 4 ) : 0x81818181u;
+      else v = load_u32<kShared>( C + static_cast<size_t>( cy0 - 1 ) * cw + cx0 + ( l - 1 ) * 4 );
+      *reinterpret_cast<uint32_t *>( &L.c[pl][0][l * 4] ) = v;
+    } else if ( l >= 16 && l < 24 ) {
+      const int r = l - 16;
+      L.c[pl][r + 1][3] = cx0 > 0 ? static_cast<uint8_t>( load_u32<kShared>( C + static_cast<size_t>( cy0 + r ) * cw + cx0 - 4 ) >> 24 ) : 129;
+    }
+  }
+  __syncthreads();
+
+  // ---- chroma: U then V, 8x8 (prediction.cc:435-450) ----
+  if ( lane < 32 ) {
+    const int pl = lane >> 4, l = lane & 15;
+    const int r = l >> 1, c4 = ( l & 1 ) * 4;
+    int sa = 0, sl = 0;
+    for ( int i = 0; i < 8; i++ ) { sa += L.c[pl][0][i + 4]; sl += L.c[pl][i + 1][3]; }
+    const int dc = bigpred_dc( sa, sl, row > 0, col > 0, 3 );
+    const int corner = L.c[pl][0][3], left = L.c[pl][r + 1][3];
+    const int blk = 16 + pl * 4 + ( r >> 2 ) * 2 + ( c4 >> 2 );
+    uint32_t out = 0;
+    for ( int j = 0; j < 4; j++ ) {
+      int v = bigpred_pixel( mb.uv_mode, L.c[pl][0][c4 + j + 4], left, corner, dc );
+      if ( has_res ) v = clamp255( v + L.r.res[blk][( r & 3 ) * 4 + j] );
+      out |= static_cast<uint32_t>( v ) << ( 8 * j );
+    }
+    store_u32<kShared>( f.cur[1 + pl] + static_cast<size_t>( row * 8 + r ) * cw + col * 8 + c4, out );
+  }
+
+  // ---- luma ----
+  if ( mb.y_mode != B_PRED ) {
+    const int r = lane >> 2, c4 = ( lane & 3 ) * 4;
+    int sa = 0, sl = 0;
+    for ( int i = 0; i < 16; i++ ) { sa += L.y[0][i + 4]; sl += L.y[i + 1][3]; }
+    const int dc = bigpred_dc( sa, sl, row > 0, col > 0, 4 );
+    const int corner = L.y[0][3], left = L.y[r + 1][3];
+    const int blk = ( r >> 2 ) * 4 + ( c4 >> 2 );
+    uint32_t out = 0;
+    for ( int j = 0; j < 4; j++ ) {
+      int v = bigpred_pixel( mb.y_mode, L.y[0][c4 + j + 4], left, corner, dc );
+      if ( has_res ) v = clamp255( v + L.r.res[blk][( r & 3 ) * 4 + j] );
+      out |= static_cast<uint32_t>( v ) << ( 8 * j );
+    }
+    store_u32<kShared>( f.cur[0] + static_cast<size_t>( y0 + r ) * pw + x0 + c4, out );
+    __syncthreads();      // LDS is reused by the next macroblock of a row-pipelined workgroup
+    return;
+  }
+  // B_PRED: 16 sub-blocks in raster order, each predicted from already reconstructed pixels then + residual
+  // (macroblock.cc:541-544).  Lanes 0..15 own one pixel of the current sub-block.
+  for ( int b = 0; b < 16; b++ ) {
+    const int bx = b & 3, by = b >> 2;
+    int v = 0;
+    if ( lane < 16 ) {
+      uint8_t E[13];
+      const int ar = by * 4, ac = bx * 4 + 3;     // LDS index of (row -1, col -1) of this sub-block
+      for ( int i = 0; i < 4; i++ ) E[i] = L.y[ar + 4 - i][ac];
+      E[4] = L.y[ar][ac];
+      for ( int i = 0; i < 4; i++ ) E[5 + i] = L.y[ar][ac + 1 + i];
+      for ( int i = 0; i < 4; i++ ) E[9 + i] = ( bx == 3 ) ? L.y[0][20 + i] : L.y[ar][ac + 5 + i];   // prediction.cc:140-164
+      const int c = lane & 3, r = lane >> 2;
+      v = bpred_pixel( mb.u.b_mode[b], E, c, r );
+      if ( has_res ) v = clamp255( v + L.r.res[b][r * 4 + c] );
+    }
+    __syncthreads();
+    if ( lane < 16 ) L.y[by * 4 + ( lane >> 2 ) + 1][bx * 4 + ( lane & 3 ) + 4] = static_cast<uint8_t>( v );
+    __syncthreads();
+  }
+  {
+    const int r = lane >> 2, c4 = ( lane & 3 ) * 4;
+    uint32_t out = 0;
+    for ( int j = 0; j < 4; j++ ) out |= static_cast<uint32_t>( L.y[r + 1][c4 + j + 4] ) << ( 8 * j );
+    store_u32<kShared>( f.cur[0] + static_cast<size_t>( y0 + r ) * pw + x0 + c4, out );
+  }
+  __syncthreads();
+}
 
 // grid.x = position on the diagonal (row = row_lo + blockIdx.x, col = d - 2*row), grid.y = frame in batch
 __global__ __launch_bounds__( kLanes ) void k_recon_intra( const aa_frame_list list, const int diagonal, const int row_lo )
@@ -243,103 +369,68 @@ __global__ __launch_bounds__( kLanes ) void k_recon_intra( const aa_frame_list l
   if ( row >= f.mbh || col < 0 || col >= f.mbw ) return;
   const aa_mb_info & mb = f.mbs[row * f.mbw + col];
   if ( mb.flags & AA_MB_INTER ) return;
-  const int lane = threadIdx.x;
-  const int pw = f.mbw * 16, cw = pw >> 1;
-  const bool has_res = mb.flags & AA_MB_HAS_NONZERO;
-  if ( has_res ) compute_residual( mb, f, L.r, lane );
+  intra_macroblock<false>( f, mb, col, row, L, threadIdx.x );
+}
 
-  // ---- neighbours: VP8Raster::Block<N>::predictors (prediction.cc:99-167) ----
-  const int x0 = col * 16, y0 = row * 16;
-  const uint8_t * Y = f.cur[0];
-  if ( lane < 21 ) {                 // above row: corner, 16 above, 4 above-right
-    int v;
-    if ( y0 == 0 ) v = 127;
-    else if ( lane == 0 ) v = x0 > 0 ? Y[static_cast<size_t>( y0 - 1 ) * pw + x0 - 1] : 129;
-    else if ( lane <= 16 ) v = Y[static_cast<size_t>( y0 - 1 ) * pw + x0 + lane - 1];
-    else v = ( x0 + 16 >= pw ) ? Y[static_cast<size_t>( y0 - 1 ) * pw + pw - 1] : Y[static_cast<size_t>( y0 - 1 ) * pw + x0 + lane - 1];
-    L.y[0][lane] = static_cast<uint8_t>( v );
-  } else if ( lane >= 32 && lane < 48 ) {   // left column
-    const int r = lane - 32;
-    L.y[r + 1][0] = x0 > 0 ? Y[static_cast<size_t>( y0 + r ) * pw + x0 - 1] : 129;
-  }
-  {
-    const int cx0 = col * 8, cy0 = row * 8;
-    const int pl = lane >> 5, l = lane & 31;
-    const uint8_t * C = f.cur[1 + pl];
-    if ( l < 9 ) {
-      int v;
-      if ( cy0 == 0 ) v = 127;
-      else if ( l == 0 ) v = cx0 > 0 ? C[static_cast<size_t>( cy0 - 1 ) * cw + cx0 - 1] : 129;
-      else v = C[static_cast<size_t>( cy0 - 1 ) * cw + cx0 + l - 1];
-      L.c[pl][0][l] = static_cast<uint8_t>( v );
-    } else if ( l >= 16 && l < 24 ) {
-      const int r = l - 16;
-      L.c[pl][r + 1][0] = cx0 > 0 ? C[static_cast<size_t>( cy0 + r ) * cw + cx0 - 1] : 129;
-    }
-  }
+// ---- in-launch ordering for the row-pipelined kernels ------------------------------------------------------------
+// One workgroup (one wave) owns one macroblock row of one frame and walks it left to right; row r may work on column c
+// once row r-1 has finished column min(c+1, mbw-1) (left/above/above-right dependencies of intra prediction and of the
+// loop filter: the same 2:1 wavefront as the per-diagonal launches, without 254 kernel boundaries).
+// Deadlock freedom does not rely on residency or dispatch order: rows are handed out by an atomic TICKET in dependency
+// order, so the row a workgroup waits for is always held by a workgroup that is already running.  Every spin is
+// bounded; on expiry the kernel records an error code and carries on (the host reports AA_ERR_HIP, never a hang).
+__device__ __forceinline__ int take_ticket( aa_sync_ws * ws, int * slot, const int lane )
+{
+  if ( lane == 0 ) *slot = atomicAdd( &ws->ticket, 1 );
   __syncthreads();
+  return *slot;
+}
+__device__ __forceinline__ void publish_progress( int * progress, const int value, const int lane )
+{
+  asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );      // every store of this wave has been written through
+  if ( lane == 0 ) __hip_atomic_store( progress, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+}
+__device__ __forceinline__ void wait_progress( const int * progress, const int need, aa_sync_ws * ws )
+{
+  int spins = 0;
+  while ( __hip_atomic_load( progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) < need ) {
+    __builtin_amdgcn_s_sleep( 2 );
+    ++spins;
+    // watchdog: sticky error word; once any wait has expired every other wait gives up within 1024 polls
+    if ( ( spins & 1023 ) == 0 && __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
+    if ( spins > ( 1 << 21 ) ) { __hip_atomic_store( &ws->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); break; }
+  }
+}
 
-  // ---- chroma: U then V, 8x8 (prediction.cc:435-450) ----
-  if ( lane < 32 ) {
-    const int pl = lane >> 4, l = lane & 15;
-    const int r = l >> 1, c4 = ( l & 1 ) * 4;
-    int sa = 0, sl = 0;
-    for ( int i = 0; i < 8; i++ ) { sa += L.c[pl][0][i + 1]; sl += L.c[pl][i + 1][0]; }
-    const int dc = bigpred_dc( sa, sl, row > 0, col > 0, 3 );
-    const int corner = L.c[pl][0][0], left = L.c[pl][r + 1][0];
-    const int blk = 16 + pl * 4 + ( r >> 2 ) * 2 + ( c4 >> 2 );
-    uint32_t out = 0;
-    for ( int j = 0; j < 4; j++ ) {
-      int v = bigpred_pixel( mb.uv_mode, L.c[pl][0][c4 + j + 1], left, corner, dc );
-      if ( has_res ) v = clamp255( v + L.r.res[blk][( r & 3 ) * 4 + j] );
-      out |= static_cast<uint32_t>( v ) << ( 8 * j );
+// grid.x = n_frames * mbh_max workgroups; ticket t -> (frame t / mbh_max, row t % mbh_max)
+__global__ __launch_bounds__( kLanes ) void k_recon_intra_rows( const aa_frame_list list, const int n_frames, const int mbh_max, aa_sync_ws * ws )
+{
+  __shared__ IntraLds L;
+  __shared__ int s_ticket;
+  const int lane = threadIdx.x;
+  const int t = take_ticket( ws, &s_ticket, lane );
+  const int fi = t / mbh_max, row = t % mbh_max;
+  if ( fi >= n_frames ) return;
+  const aa_dev_frame & f = *list.f[fi];
+  if ( row >= f.mbh ) return;
+  int * progress = ws->progress + fi * mbh_max;
+  const int mbw = f.mbw;
+  if ( f.has_intra ) {
+    const int words = ( mbw + 63 ) >> 6;
+    const unsigned long long * mask = f.intra_rows + static_cast<size_t>( row ) * words;
+    for ( int w = 0; w < words; w++ ) {
+      unsigned long long m = mask[w];
+      while ( m ) {
+        const int col = w * 64 + __ffsll( static_cast<long long>( m ) ) - 1;
+        m &= m - 1;
+        // everything left of `col` in this row is final; then wait for the row above
+        publish_progress( &progress[row], col, lane );
+        if ( row > 0 ) wait_progress( &progress[row - 1], min( col + 2, mbw ), ws );
+        intra_macroblock<true>( f, f.mbs[row * mbw + col], col, row, L, lane );
+      }
     }
-    *reinterpret_cast<uint32_t *>( f.cur[1 + pl] + static_cast<size_t>( row * 8 + r ) * cw + col * 8 + c4 ) = out;
   }
-
-  // ---- luma ----
-  if ( mb.y_mode != B_PRED ) {
-    const int r = lane >> 2, c4 = ( lane & 3 ) * 4;
-    int sa = 0, sl = 0;
-    for ( int i = 0; i < 16; i++ ) { sa += L.y[0][i + 1]; sl += L.y[i + 1][0]; }
-    const int dc = bigpred_dc( sa, sl, row > 0, col > 0, 4 );
-    const int corner = L.y[0][0], left = L.y[r + 1][0];
-    const int blk = ( r >> 2 ) * 4 + ( c4 >> 2 );
-    uint32_t out = 0;
-    for ( int j = 0; j < 4; j++ ) {
-      int v = bigpred_pixel( mb.y_mode, L.y[0][c4 + j + 1], left, corner, dc );
-      if ( has_res ) v = clamp255( v + L.r.res[blk][( r & 3 ) * 4 + j] );
-      out |= static_cast<uint32_t>( v ) << ( 8 * j );
-    }
-    *reinterpret_cast<uint32_t *>( f.cur[0] + static_cast<size_t>( y0 + r ) * pw + x0 + c4 ) = out;
-    return;
-  }
-  // B_PRED: 16 sub-blocks in raster order, each predicted from already reconstructed pixels then + residual
-  // (macroblock.cc:541-544).  Lanes 0..15 own one pixel of the current sub-block.
-  for ( int b = 0; b < 16; b++ ) {
-    const int bx = b & 3, by = b >> 2;
-    int v = 0;
-    if ( lane < 16 ) {
-      uint8_t E[13];
-      const int ar = by * 4, ac = bx * 4;         // LDS index of (row -1, col -1) of this sub-block
-      for ( int i = 0; i < 4; i++ ) E[i] = L.y[ar + 4 - i][ac];
-      E[4] = L.y[ar][ac];
-      for ( int i = 0; i < 4; i++ ) E[5 + i] = L.y[ar][ac + 1 + i];
-      for ( int i = 0; i < 4; i++ ) E[9 + i] = ( bx == 3 ) ? L.y[0][17 + i] : L.y[ar][ac + 5 + i];   // prediction.cc:140-164
-      const int c = lane & 3, r = lane >> 2;
-      v = bpred_pixel( mb.u.b_mode[b], E, c, r );
-      if ( has_res ) v = clamp255( v + L.r.res[b][r * 4 + c] );
-    }
-    __syncthreads();
-    if ( lane < 16 ) L.y[by * 4 + ( lane >> 2 ) + 1][bx * 4 + ( lane & 3 ) + 1] = static_cast<uint8_t>( v );
-    __syncthreads();
-  }
-  {
-    const int r = lane >> 2, c4 = ( lane & 3 ) * 4;
-    uint32_t out = 0;
-    for ( int j = 0; j < 4; j++ ) out |= static_cast<uint32_t>( L.y[r + 1][c4 + j + 1] ) << ( 8 * j );
-    *reinterpret_cast<uint32_t *>( f.cur[0] + static_cast<size_t>( y0 + r ) * pw + x0 + c4 ) = out;
-  }
+  publish_progress( &progress[row], mbw, lane );
 }
 
 struct alignas( 16 ) LfLds {
@@ -362,10 +453,44 @@ __device__ __forceinline__ void lf_edge( uint8_t * p, const int s, const bool mb
   p[-2 * s] = static_cast<uint8_t>( p1 ); p[-s] = static_cast<uint8_t>( p0 ); p[0] = static_cast<uint8_t>( q0 ); p[s] = static_cast<uint8_t>( q1 );
 }
 
-// grid as k_recon_intra.  MB (col,row) filters its left MB edge, inner vertical edges, top MB edge, inner horizontal
-// edges (NormalLoopFilter::filter, loopfilter.cc:133-154) on an LDS copy of its 16x16 (+4 px left/above) region.
-// All MBs with col + 2*row == d are independent: their read/write footprints ([x0-4,x0+15] x [y0-4,y0+15]) are
-// disjoint and everything they read was finished by diagonals < d.
+// The eight dependent edge passes of NormalLoopFilter::filter (loopfilter.cc:133-154) on the LDS copy of one MB:
+// left MB edge, inner vertical edges, top MB edge, inner horizontal edges.  Lanes 0..15 luma line, 16..23 U, 24..31 V.
+__device__ void lf_passes( LfLds & L, const bool have_left, const bool have_top, const bool inner, const LfParams & P, const int lane )
+{
+  const bool is_y = lane < 16, is_c = lane >= 16 && lane < 32;
+  const int cl = ( lane - 16 ) & 7, cp = ( lane - 16 ) >> 3;
+  if ( have_left ) {
+    if ( is_y ) lf_edge( &L.y[4 + lane][4], 1, true, P );
+    else if ( is_c ) lf_edge( &L.c[cp][4 + cl][4], 1, true, P );
+  }
+  __syncthreads();
+  if ( inner ) {
+    if ( is_y ) lf_edge( &L.y[4 + lane][8], 1, false, P );
+    else if ( is_c ) lf_edge( &L.c[cp][4 + cl][8], 1, false, P );
+    __syncthreads();
+    if ( is_y ) lf_edge( &L.y[4 + lane][12], 1, false, P );
+    __syncthreads();
+    if ( is_y ) lf_edge( &L.y[4 + lane][16], 1, false, P );
+    __syncthreads();
+  }
+  if ( have_top ) {
+    if ( is_y ) lf_edge( &L.y[4][4 + lane], 20, true, P );
+    else if ( is_c ) lf_edge( &L.c[cp][4][4 + cl], 12, true, P );
+  }
+  __syncthreads();
+  if ( inner ) {
+    if ( is_y ) lf_edge( &L.y[8][4 + lane], 20, false, P );
+    else if ( is_c ) lf_edge( &L.c[cp][8][4 + cl], 12, false, P );
+    __syncthreads();
+    if ( is_y ) lf_edge( &L.y[12][4 + lane], 20, false, P );
+    __syncthreads();
+    if ( is_y ) lf_edge( &L.y[16][4 + lane], 20, false, P );
+    __syncthreads();
+  }
+}
+
+// grid as k_recon_intra.  All MBs with col + 2*row == d are independent: their read/write footprints
+// ([x0-4,x0+15] x [y0-4,y0+15]) are disjoint and everything they read was finished by diagonals < d.
 __global__ __launch_bounds__( kLanes ) void k_loopfilter( const aa_frame_list list, const int diagonal, const int row_lo )
 {
   __shared__ LfLds L;
@@ -380,7 +505,6 @@ __global__ __launch_bounds__( kLanes ) void k_loopfilter( const aa_frame_list li
   const int pw = f.mbw * 16, cw = pw >> 1;
   const int x0 = col * 16, y0 = row * 16, cx0 = col * 8, cy0 = row * 8;
   const LfParams P = lf_params( level, f.sharpness, f.key_frame );
-  const bool inner = !( mb.flags & AA_MB_LF_SKIP_INNER );
 
   // ---- stage: 20 rows x 5 dwords (Y), 2 x 12 rows x 3 dwords (U,V) ----
   uint8_t * Y = f.cur[0];
@@ -400,42 +524,7 @@ __global__ __launch_bounds__( kLanes ) void k_loopfilter( const aa_frame_list li
   }
   __syncthreads();
 
-  // lane roles inside a pass: 0..15 luma line, 16..23 U line, 24..31 V line
-  const bool is_y = lane < 16, is_c = lane >= 16 && lane < 32;
-  const int cl = ( lane - 16 ) & 7, cp = ( lane - 16 ) >> 3;
-
-  // 1: left macroblock edge (vertical edge at x0), if not the first column
-  if ( col > 0 ) {
-    if ( is_y ) lf_edge( &L.y[4 + lane][4], 1, true, P );
-    else if ( is_c ) lf_edge( &L.c[cp][4 + cl][4], 1, true, P );
-  }
-  __syncthreads();
-  // 2: inner vertical edges x0+4, +8, +12 (chroma: +4)
-  if ( inner ) {
-    if ( is_y ) lf_edge( &L.y[4 + lane][8], 1, false, P );
-    else if ( is_c ) lf_edge( &L.c[cp][4 + cl][8], 1, false, P );
-    __syncthreads();
-    if ( is_y ) lf_edge( &L.y[4 + lane][12], 1, false, P );
-    __syncthreads();
-    if ( is_y ) lf_edge( &L.y[4 + lane][16], 1, false, P );
-    __syncthreads();
-  }
-  // 3: top macroblock edge
-  if ( row > 0 ) {
-    if ( is_y ) lf_edge( &L.y[4][4 + lane], 20, true, P );
-    else if ( is_c ) lf_edge( &L.c[cp][4][4 + cl], 12, true, P );
-  }
-  __syncthreads();
-  // 4: inner horizontal edges
-  if ( inner ) {
-    if ( is_y ) lf_edge( &L.y[8][4 + lane], 20, false, P );
-    else if ( is_c ) lf_edge( &L.c[cp][8][4 + cl], 12, false, P );
-    __syncthreads();
-    if ( is_y ) lf_edge( &L.y[12][4 + lane], 20, false, P );
-    __syncthreads();
-    if ( is_y ) lf_edge( &L.y[16][4 + lane], 20, false, P );
-    __syncthreads();
-  }
+  lf_passes( L, col > 0, row > 0, !( mb.flags & AA_MB_LF_SKIP_INNER ), P, lane );
 
   // ---- write back what this MB may have modified: rows/cols -3..15 minus the untouched corner.
   // Dword stores over [-4,15] are safe: nothing else touches that footprint during this launch.
@@ -455,6 +544,111 @@ __global__ __launch_bounds__( kLanes ) void k_loopfilter( const aa_frame_list li
   }
 }
 
+// Row-pipelined loop filter: ticket -> (frame, MB row); the wave walks its row left to right.
+//   * per-MB loop-filter level/flags of the whole row are preloaded into LDS once;
+//   * the macroblock's own 16 rows were produced by earlier launches -> plain loads, PREFETCHED into registers while
+//     the previous macroblock is being filtered;
+//   * the 4 rows above belong to the previous MB row, filtered by another workgroup of this launch -> agent-scope
+//     loads after progress[row-1] >= min(col+2, mbw);
+//   * the 4 columns to the left are the wave's own previous macroblock -> carried over in LDS, never re-read;
+//   * every store is write-through; progress[row] = col+1 is published one step late, after the first poll for the
+//     next macroblock has returned (its s_waitcnt also drains the stores), so the drain overlaps the prefetch + poll.
+constexpr int kMaxMbw = 1024;     // 16383 px / 16
+
+__global__ __launch_bounds__( kLanes ) void k_loopfilter_rows( const aa_frame_list list, const int n_frames, const int mbh_max, aa_sync_ws * ws )
+{
+  __shared__ LfLds L;
+  __shared__ uint16_t s_info[kMaxMbw];     // lf_level | flags << 8
+  __shared__ int s_ticket;
+  const int lane = threadIdx.x;
+  const int t = take_ticket( ws, &s_ticket, lane );
+  const int fi = t / mbh_max, row = t % mbh_max;
+  if ( fi >= n_frames ) return;
+  const aa_dev_frame & f = *list.f[fi];
+  if ( row >= f.mbh || !f.loop_filter_level ) return;
+  int * progress = ws->progress + fi * mbh_max;
+  const int mbw = f.mbw, pw = mbw * 16, cw = pw >> 1;
+  const int y0 = row * 16, cy0 = row * 8;
+  uint8_t * Y = f.cur[0];
+  for ( int c = lane; c < mbw; c += kLanes ) {
+    const aa_mb_info & m = f.mbs[row * mbw + c];
+    s_info[c] = static_cast<uint16_t>( m.lf_level | ( m.flags << 8 ) );
+  }
+  __syncthreads();
+
+  // lane roles for the bulk transfers: luma 16 rows x 4 dwords = 64 lanes; chroma 2 planes x 8 rows x 2 dwords = 32 lanes
+  const int yr = 4 + ( lane >> 2 ), yd = 1 + ( lane & 3 );
+  const int cpl = ( lane >> 4 ) & 1, cr = 4 + ( ( lane >> 1 ) & 7 ), cd = 1 + ( lane & 1 );
+  const uint8_t * yrow = Y + static_cast<size_t>( y0 - 4 + yr ) * pw - 4 + yd * 4;
+  const uint8_t * crow = f.cur[1 + cpl] + static_cast<size_t>( cy0 - 4 + cr ) * cw - 4 + cd * 4;
+
+  bool carried = false;            // LDS columns -4..-1 hold the previous macroblock's filtered right edge
+  bool prefetched = false;
+  uint32_t pre_y = 0, pre_c = 0;
+  int pending = -1;                // progress value not yet published (its stores may still be in flight)
+  for ( int col = 0; col < mbw; col++ ) {
+    const int info = s_info[col];
+    const int level = info & 0xFF;
+    if ( level == 0 ) {
+      carried = false; prefetched = false;
+      publish_progress( &progress[row], col + 1, lane ); pending = -1;
+      continue;
+    }
+    const int x0 = col * 16, cx0 = col * 8;
+    if ( !prefetched ) {
+      pre_y = *reinterpret_cast<const uint32_t *>( yrow + x0 );
+      if ( lane < 32 ) pre_c = *reinterpret_cast<const uint32_t *>( crow + cx0 );
+    }
+    if ( !carried && col > 0 ) {   // left neighbour columns straight from memory (previous MB was not filtered)
+      if ( lane < 16 ) *reinterpret_cast<uint32_t *>( &L.y[4 + lane][0] ) = *reinterpret_cast<const uint32_t *>( Y + static_cast<size_t>( y0 + lane ) * pw + x0 - 4 );
+      else if ( lane < 32 ) { const int l = lane - 16; *reinterpret_cast<uint32_t *>( &L.c[l >> 3][4 + ( l & 7 )][0] ) = *reinterpret_cast<const uint32_t *>( f.cur[1 + ( l >> 3 )] + static_cast<size_t>( cy0 + ( l & 7 ) ) * cw + cx0 - 4 ); }
+    }
+    if ( row > 0 ) {
+      const int need = min( col + 2, mbw );
+      int seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      if ( pending >= 0 ) { publish_progress( &progress[row], pending, lane ); pending = -1; }
+      if ( seen < need ) wait_progress( &progress[row - 1], need, ws );
+      if ( lane < 16 ) {             // 4 rows x 4 dwords above the luma block
+        const int r = lane >> 2, d = 1 + ( lane & 3 );
+        *reinterpret_cast<uint32_t *>( &L.y[r][d * 4] ) = load_u32<true>( Y + static_cast<size_t>( y0 - 4 + r ) * pw + x0 - 4 + d * 4 );
+      } else if ( lane < 32 ) {      // 2 planes x 4 rows x 2 dwords above the chroma blocks
+        const int l = lane - 16, pl = l >> 3, r = ( l >> 1 ) & 3, d = 1 + ( l & 1 );
+        *reinterpret_cast<uint32_t *>( &L.c[pl][r][d * 4] ) = load_u32<true>( f.cur[1 + pl] + static_cast<size_t>( cy0 - 4 + r ) * cw + cx0 - 4 + d * 4 );
+      }
+    } else if ( pending >= 0 ) { publish_progress( &progress[row], pending, lane ); pending = -1; }
+    *reinterpret_cast<uint32_t *>( &L.y[yr][yd * 4] ) = pre_y;
+    if ( lane < 32 ) *reinterpret_cast<uint32_t *>( &L.c[cpl][cr][cd * 4] ) = pre_c;
+    __syncthreads();
+
+    lf_passes( L, col > 0, row > 0, !( ( info >> 8 ) & AA_MB_LF_SKIP_INNER ), lf_params( level, f.sharpness, f.key_frame ), lane );
+
+    // write-through stores: rows -3..-1 x cols 0..15 (previous MB row), rows 0..15 x cols -4..15
+    for ( int i = lane; i < 100; i += kLanes ) {
+      const int r = i / 5, d = i % 5;
+      if ( r == 0 || ( r < 4 && ( d == 0 || row == 0 ) ) || ( d == 0 && col == 0 ) ) continue;
+      store_u32<true>( Y + static_cast<size_t>( y0 - 4 + r ) * pw + x0 - 4 + d * 4, *reinterpret_cast<const uint32_t *>( &L.y[r][d * 4] ) );
+    }
+    for ( int i = lane; i < 72; i += kLanes ) {
+      const int pl = i / 36, e = i % 36, r = e / 3, d = e % 3;
+      if ( r == 0 || ( r < 4 && ( d == 0 || row == 0 ) ) || ( d == 0 && col == 0 ) ) continue;
+      store_u32<true>( f.cur[1 + pl] + static_cast<size_t>( cy0 - 4 + r ) * cw + cx0 - 4 + d * 4, *reinterpret_cast<const uint32_t *>( &L.c[pl][r][d * 4] ) );
+    }
+    pending = col + 1;
+    // prefetch the next macroblock's own rows while these stores drain
+    prefetched = col + 1 < mbw && ( s_info[col + 1] & 0xFF ) != 0;
+    if ( prefetched ) {
+      pre_y = *reinterpret_cast<const uint32_t *>( yrow + x0 + 16 );
+      if ( lane < 32 ) pre_c = *reinterpret_cast<const uint32_t *>( crow + cx0 + 8 );
+    }
+    // carry the filtered right edge (cols 12..15 / 4..7) over as the next macroblock's left neighbour columns
+    if ( lane < 16 ) *reinterpret_cast<uint32_t *>( &L.y[4 + lane][0] ) = *reinterpret_cast<const uint32_t *>( &L.y[4 + lane][16] );
+    else if ( lane < 32 ) { const int l = lane - 16; *reinterpret_cast<uint32_t *>( &L.c[l >> 3][4 + ( l & 7 )][0] ) = *reinterpret_cast<const uint32_t *>( &L.c[l >> 3][4 + ( l & 7 )][8] ); }
+    carried = true;
+    __syncthreads();
+  }
+  if ( pending >= 0 ) publish_progress( &progress[row], pending, lane );
+}
+
 } // namespace
 
 int launch_recon_inter( const aa_frame_list & list, int n, unsigned max_mbs, void * stream )
@@ -471,6 +665,16 @@ int launch_recon_intra_diagonal( const aa_frame_list & list, int n, int diagonal
 int launch_loopfilter_diagonal( const aa_frame_list & list, int n, int diagonal, int row_lo, int rows, void * stream )
 {
   hipLaunchKernelGGL( k_loopfilter, dim3( rows, n ), dim3( kLanes ), 0, static_cast<hipStream_t>( stream ), list, diagonal, row_lo );
+  return static_cast<int>( hipGetLastError() );
+}
+int launch_recon_intra_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, void * stream )
+{
+  hipLaunchKernelGGL( k_recon_intra_rows, dim3( n * mbh_max ), dim3( kLanes ), 0, static_cast<hipStream_t>( stream ), list, n, mbh_max, ws );
+  return static_cast<int>( hipGetLastError() );
+}
+int launch_loopfilter_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, void * stream )
+{
+  hipLaunchKernelGGL( k_loopfilter_rows, dim3( n * mbh_max ), dim3( kLanes ), 0, static_cast<hipStream_t>( stream ), list, n, mbh_max, ws );
   return static_cast<int>( hipGetLastError() );
 }
 

@@ -8,11 +8,14 @@
 //   * rasters are slots of 3 tightly packed padded planes (VP8Raster, raster.hh:54-56); slots are assigned when a
 //     frame is PARSED by replaying Frame::copy_to (frame.cc:271-307) on slot ids, so each job is self-contained
 //     and device execution never consults the host;
-//   * decode = k_recon_inter (1 launch) + k_recon_intra / k_loopfilter (one launch per 2:1 anti-diagonal).
+//   * decode = k_recon_inter + k_recon_intra_rows + k_loopfilter_rows: three launches per batch step (the two row-pipelined
+//     kernels order macroblock rows in-launch by ticket + progress words); ALFALFA_AMD_SCHEDULE=diagonal selects the
+//     launch-per-anti-diagonal schedule instead (kept for A/B measurement).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -69,6 +72,9 @@ struct aa_ctx {
   hipStream_t compute = nullptr, copy = nullptr;
   hipEvent_t upload_done = nullptr;
   bool profile = false;
+  int schedule = 0;            // 0: row-pipelined persistent kernels (default), 1: one launch per 2:1 anti-diagonal
+  aa_sync_ws * ws = nullptr;   // in-launch ordering state of the row-pipelined kernels
+  size_t ws_bytes = 0;
   aa_kernel_stats stats {};
   struct Timed { hipEvent_t a, b; int kind; };
   std::vector<Timed> pending;
@@ -243,6 +249,7 @@ aa_status aa_ctx_create( int device, aa_ctx ** out )
   HIP_TRY( hipStreamCreateWithFlags( &ctx->compute, hipStreamNonBlocking ) );
   HIP_TRY( hipStreamCreateWithFlags( &ctx->copy, hipStreamNonBlocking ) );
   HIP_TRY( hipEventCreateWithFlags( &ctx->upload_done, hipEventDisableTiming ) );
+  if ( const char * e = std::getenv( "ALFALFA_AMD_SCHEDULE" ) ) ctx->schedule = std::string( e ) == "diagonal" ? 1 : 0;
   *out = ctx.release();
   return AA_OK;
 }
@@ -254,14 +261,29 @@ void aa_ctx_destroy( aa_ctx * ctx )
   drain_profile( ctx );
   for ( auto e : ctx->free_events ) (void) hipEventDestroy( e );
   (void) hipEventDestroy( ctx->upload_done );
+  if ( ctx->ws ) (void) hipFree( ctx->ws );
   (void) hipStreamDestroy( ctx->compute ); (void) hipStreamDestroy( ctx->copy );
   delete ctx;
+}
+static aa_status check_watchdog( aa_ctx * ctx )
+{
+  if ( !ctx->ws ) return AA_OK;
+  int err = 0;
+  HIP_TRY( hipMemcpy( &err, &ctx->ws->error, sizeof err, hipMemcpyDeviceToHost ) );
+  if ( err ) return fail( AA_ERR_HIP, "row-pipelined kernel: a bounded wait for the macroblock row above expired (output is not valid)" );
+  return AA_OK;
 }
 aa_status aa_ctx_sync( aa_ctx * ctx )
 {
   if ( !ctx ) return fail( AA_ERR_ARGUMENT, "null ctx" );
   HIP_TRY( hipStreamSynchronize( ctx->copy ) );
   HIP_TRY( hipStreamSynchronize( ctx->compute ) );
+  return check_watchdog( ctx );
+}
+aa_status aa_ctx_set_schedule( aa_ctx * ctx, int schedule )
+{
+  if ( !ctx || ( schedule != AA_SCHEDULE_ROWS && schedule != AA_SCHEDULE_DIAGONAL ) ) return fail( AA_ERR_ARGUMENT, "aa_ctx_set_schedule: bad argument" );
+  ctx->schedule = schedule;
   return AA_OK;
 }
 void * aa_ctx_compute_stream( aa_ctx * ctx ) { return ctx ? ctx->compute : nullptr; }
@@ -327,26 +349,33 @@ aa_status aa_stream_parse( aa_stream * s, const uint8_t * data, size_t size, int
   const size_t nmb = size_t( s->parser.mb_width() ) * s->parser.mb_height();
   const size_t job_bytes = align_up( sizeof( aa_dev_frame ) );
   const size_t mb_bytes = align_up( nmb * sizeof( aa_mb_info ) );
-  const size_t worst = job_bytes + mb_bytes + align_up( nmb * 25 * 32 );
+  const size_t words_per_row = ( s->parser.mb_width() + 63 ) / 64;
+  const size_t rows_bytes = align_up( words_per_row * s->parser.mb_height() * sizeof( unsigned long long ) );
+  const size_t worst = job_bytes + mb_bytes + rows_bytes + align_up( nmb * 25 * 32 );
   Chunk * c;
   if ( aa_status st = reserve( s, worst, &c ) ) return st;
   const size_t off = c->used;
   aa_dev_frame * job = reinterpret_cast<aa_dev_frame *>( c->host + off );
   aa_mb_info * mbs = reinterpret_cast<aa_mb_info *>( c->host + off + job_bytes );
-  int16_t * coeffs = reinterpret_cast<int16_t *>( c->host + off + job_bytes + mb_bytes );
+  unsigned long long * intra_rows = reinterpret_cast<unsigned long long *>( c->host + off + job_bytes + mb_bytes );
+  int16_t * coeffs = reinterpret_cast<int16_t *>( c->host + off + job_bytes + mb_bytes + rows_bytes );
 
   FrameRec rec;
   try { s->parser.parse( data, size, rec.hdr, mbs, coeffs ); }
   catch ( const aa::ParseError & e ) { return fail( e.code, e.message ); }
   const aa_frame_header & h = rec.hdr;
-  c->used = off + job_bytes + mb_bytes + align_up( size_t( h.num_coeff_blocks ) * 32 );   // commit what was used
+  c->used = off + job_bytes + mb_bytes + rows_bytes + align_up( size_t( h.num_coeff_blocks ) * 32 );   // commit what was used
 
   // which 2:1 anti-diagonals hold intra MBs (launch schedule of k_recon_intra)
   const int mbw = h.mb_width, mbh = h.mb_height;
   rec.intra_diagonals.assign( mbw + 2 * ( mbh - 1 ), 0 );
+  std::memset( intra_rows, 0, words_per_row * mbh * sizeof( unsigned long long ) );
   if ( h.has_intra_mb )
     for ( int r = 0; r < mbh; r++ ) for ( int col = 0; col < mbw; col++ )
-      if ( !( mbs[r * mbw + col].flags & AA_MB_INTER ) ) rec.intra_diagonals[col + 2 * r] = 1;
+      if ( !( mbs[r * mbw + col].flags & AA_MB_INTER ) ) {
+        rec.intra_diagonals[col + 2 * r] = 1;
+        intra_rows[r * words_per_row + ( col >> 6 )] |= 1ull << ( col & 63 );
+      }
 
   // raster slots: output + the References this frame predicts from; then Frame::copy_to on slot ids
   int out_slot;
@@ -357,7 +386,8 @@ aa_status aa_stream_parse( aa_stream * s, const uint8_t * data, size_t size, int
   for ( int p = 0; p < 3; p++ ) job->cur[p] = slot_plane( s, out_slot, p );
   for ( int r = 0; r < 3; r++ ) for ( int p = 0; p < 3; p++ ) job->ref[r + 1][p] = slot_plane( s, s->cur_ref_slot[r], p );
   job->mbs = reinterpret_cast<const aa_mb_info *>( c->dev + off + job_bytes );
-  job->coeffs = reinterpret_cast<const int16_t *>( c->dev + off + job_bytes + mb_bytes );
+  job->intra_rows = reinterpret_cast<const unsigned long long *>( c->dev + off + job_bytes + mb_bytes );
+  job->coeffs = reinterpret_cast<const int16_t *>( c->dev + off + job_bytes + mb_bytes + rows_bytes );
   std::memcpy( job->quant, h.quant, sizeof job->quant );
   job->mbw = h.mb_width; job->mbh = h.mb_height;
   job->key_frame = h.key_frame; job->loop_filter_level = h.loop_filter_level;
@@ -454,6 +484,37 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
     if ( aa_status st = check( e, "k_recon_inter" ) ) return st;
   }
   const int ndiag = max_mbw + 2 * ( max_mbh - 1 );
+  if ( ctx->schedule == 0 ) {
+    // 2+3. row-pipelined kernels: one launch each; macroblock rows are ordered in-launch (ticket + progress words)
+    const size_t need = sizeof( aa_sync_ws ) + sizeof( int ) * size_t( AA_MAX_BATCH ) * max_mbh;
+    if ( need > ctx->ws_bytes ) {
+      HIP_TRY( hipStreamSynchronize( ctx->compute ) );
+      if ( ctx->ws ) (void) hipFree( ctx->ws );
+      ctx->ws = nullptr; ctx->ws_bytes = 0;
+      HIP_TRY( hipMalloc( reinterpret_cast<void **>( &ctx->ws ), need ) );
+      HIP_TRY( hipMemset( ctx->ws, 0, need ) );
+      ctx->ws_bytes = need;
+    }
+    auto rows_launch = [&]( const std::vector<const aa_dev_frame *> & jobs, int kind ) -> aa_status {
+      if ( jobs.empty() ) return AA_OK;
+      for ( size_t base = 0; base < jobs.size(); base += AA_MAX_BATCH ) {
+        aa_frame_list list;
+        const int cnt = static_cast<int>( std::min<size_t>( AA_MAX_BATCH, jobs.size() - base ) );
+        for ( int k = 0; k < AA_MAX_BATCH; k++ ) list.f[k] = k < cnt ? jobs[base + k] : nullptr;
+        HIP_TRY( hipMemsetAsync( reinterpret_cast<uint8_t *>( ctx->ws ) + AA_SYNC_WS_ZERO_FROM, 0,
+                                 sizeof( aa_sync_ws ) - AA_SYNC_WS_ZERO_FROM + sizeof( int ) * size_t( cnt ) * max_mbh, ctx->compute ) );
+        LaunchTimer t( ctx, kind );
+        const int e = kind == 1 ? aa::launch_recon_intra_rows( list, cnt, max_mbh, ctx->ws, ctx->compute )
+                                : aa::launch_loopfilter_rows( list, cnt, max_mbh, ctx->ws, ctx->compute );
+        if ( e ) return hip_fail( static_cast<hipError_t>( e ), kind == 1 ? "k_recon_intra_rows" : "k_loopfilter_rows" );
+      }
+      return AA_OK;
+    };
+    if ( aa_status st = rows_launch( intra_jobs, 1 ) ) return st;
+    if ( aa_status st = rows_launch( lf_jobs, 2 ) ) return st;
+    return AA_OK;
+  }
+  // ---- ALFALFA_AMD_SCHEDULE=diagonal: the kernel boundary is the inter-workgroup synchronisation ----
   // 2. intra macroblocks, 2:1 anti-diagonal order (left, above-left, above, above-right are final)
   if ( !intra_jobs.empty() ) {
     for ( int d = 0; d < ndiag; d++ ) {
@@ -517,6 +578,7 @@ aa_status aa_stream_download( aa_stream * s, int fi, uint8_t * y, uint8_t * u, u
   if ( !r.handle_held ) return fail( AA_ERR_LOGIC, "aa_stream_download: frame was released" );
   if ( fi >= s->next_submit ) return fail( AA_ERR_LOGIC, "aa_stream_download: frame not decoded yet" );
   HIP_TRY( hipStreamSynchronize( s->ctx->compute ) );
+  if ( aa_status st = check_watchdog( s->ctx ) ) return st;
   uint8_t * dst[3] = { y, u, v };
   for ( int p = 0; p < 3; p++ ) if ( dst[p] ) HIP_TRY( hipMemcpy( dst[p], slot_plane( s, r.out_slot, p ), s->plane_bytes[p], hipMemcpyDeviceToHost ) );
   return AA_OK;

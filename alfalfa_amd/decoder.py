@@ -83,6 +83,10 @@ class Context:
     def sync(self):
         capi.check(self.L.aa_ctx_sync(self.h))
 
+    def set_schedule(self, name):
+        """"rows" (default): row-pipelined persistent kernels; "diagonal": one launch per anti-diagonal."""
+        capi.check(self.L.aa_ctx_set_schedule(self.h, {"rows": 0, "diagonal": 1}[name]))
+
     def profile(self, enable):
         capi.check(self.L.aa_ctx_profile(self.h, int(enable)))
 

@@ -38,8 +38,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="1080p_inter_lf")
-    ap.add_argument("--streams", type=int, default=48, help="independent streams per GPU")
-    ap.add_argument("--frames", type=int, default=24, help="frames per stream")
+    ap.add_argument("--streams", type=int, default=96, help="independent streams per GPU")
+    ap.add_argument("--frames", type=int, default=12, help="frames per stream")
+    ap.add_argument("--schedule", default="rows", choices=["rows", "diagonal"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
@@ -51,9 +52,11 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("AA_BENCH_FORCE_DIST"):     # the env switch lets a 1-GPU box exercise the RCCL path
         import torch
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -72,6 +75,7 @@ def main():
     mbs_per_step = S * F * mbs_per_frame
 
     ctx = aa.Context(local_rank)
+    ctx.set_schedule(args.schedule)
     decs = [aa.Decoder(ctx, width, height) for _ in range(S)]
 
     # ---- multi-GPU only: one-shot entry-state hand-off (outside the timed region).  Rank 0 decodes the head (key frame)
@@ -238,7 +242,7 @@ def main():
                                    "parsed records resident in HBM" % (args.config, S, width, height, F, F - 1,
                                                                         workload.CONFIGS[args.config][3], workload.CONFIGS[args.config][4]),
                        "streams_per_gpu": S, "frames_per_stream": F, "macroblocks_per_step_per_gpu": mbs_per_step,
-                       "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective"},
+                       "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective", "schedule": args.schedule},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "host": {"parse_mb_per_s_per_core": round(mbs_per_step / sum(per_stream_parse_s), 1),
                      "parse_threads": nthreads, "parse_wall_s": round(t_parse_wall, 3),

@@ -133,6 +133,13 @@ typedef struct aa_stream aa_stream;
 aa_status aa_ctx_create( int device, aa_ctx ** out );
 void aa_ctx_destroy( aa_ctx * ctx );
 aa_status aa_ctx_sync( aa_ctx * ctx );               /* waits for copy + compute streams */
+/* Launch schedule of the dependency-ordered kernels (intra prediction, loop filter):
+ *   AA_SCHEDULE_ROWS (default)  row-pipelined persistent kernels, rows ordered in-launch by ticket + progress words
+ *   AA_SCHEDULE_DIAGONAL        one launch per 2:1 anti-diagonal (kernel boundary = synchronisation); for A/B runs
+ * Also selectable with the environment variable ALFALFA_AMD_SCHEDULE=rows|diagonal at context creation. */
+#define AA_SCHEDULE_ROWS 0
+#define AA_SCHEDULE_DIAGONAL 1
+aa_status aa_ctx_set_schedule( aa_ctx * ctx, int schedule );
 /* hipStream_t handles as opaque pointers (to order foreign work, e.g. an RCCL broadcast, against ours) */
 void * aa_ctx_compute_stream( aa_ctx * ctx );
 void * aa_ctx_copy_stream( aa_ctx * ctx );
