@@ -29,7 +29,7 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd = [HIPCC] + FLAGS + os.environ.get("AA_EXTRA_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -32,7 +32,7 @@ struct aa_sync_ws {
 };
 #define AA_SYNC_WS_ZERO_FROM 16   // byte offset of `ticket`
 
-#define AA_MAX_BATCH 120       // frames per launch: kernel argument = 120 pointers (960 B) passed by value
+#define AA_MAX_BATCH 256       // frames per launch: kernel argument = 256 pointers (2 KiB) passed by value
 
 struct aa_frame_list {
   const aa_dev_frame * f[AA_MAX_BATCH];
@@ -44,5 +44,5 @@ int launch_recon_inter( const aa_frame_list & list, int n, unsigned max_mbs, voi
 int launch_recon_intra_diagonal( const aa_frame_list & list, int n, int diagonal, int row_lo, int rows, void * stream );
 int launch_loopfilter_diagonal( const aa_frame_list & list, int n, int diagonal, int row_lo, int rows, void * stream );
 int launch_recon_intra_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, void * stream );
-int launch_loopfilter_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, void * stream );
+int launch_loopfilter_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, void * stream, bool pair_frames );
 }

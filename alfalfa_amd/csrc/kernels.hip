@@ -11,6 +11,8 @@
 // global byte once.  Batches of independent frames (streams / GOPs) fill the chip: grid.y = frame in batch.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "device_types.h"
 #include "vp8_math.hh"
 
@@ -22,9 +24,11 @@ constexpr int kLanes = 64;
 enum : int { DC_PRED, V_PRED, H_PRED, TM_PRED, B_PRED, NEARESTMV, NEARMV, ZEROMV, NEWMV, SPLITMV };
 
 struct alignas( 16 ) ResidualLds {
-  int16_t cf[25][16];    // dense, dequantised coefficients (block 24 = Y2)
+  union {
+    int16_t cf[25][16];  // dense, dequantised coefficients (block 24 = Y2); dead once the first IDCT pass has run
+    int16_t res[24][16]; // residual to add: block b, [row*4+col] -- written by the second pass over the same storage
+  };
   int16_t im[24][16];    // first-pass results (int16, Q5)
-  int16_t res[24][16];   // residual to add: block b, [row*4+col]
   uint8_t map[32];       // rank of stored block -> dense block id
 };
 
@@ -84,51 +88,57 @@ __device__ __forceinline__ void load_taps( int frac, int ( &t )[6] )
   for ( int i = 0; i < 6; i++ ) t[i] = sixtap_coeff( frac, i );
 }
 
-// Motion-compensated prediction of one NxN block into LDS `dst` (row-major, stride N).
-// VP8Raster::Block<N>::inter_predict (prediction.cc:655-674): every fetch is clamped to the padded plane, which
-// equals the interior ("unsafe") path when the footprint is inside and EdgeExtendedRaster::at otherwise.
-template <int N>
-__device__ void mc_block( const uint8_t * __restrict__ ref, const int pw, const int ph, const int x0, const int y0,
-                          const int mvx, const int mvy, uint8_t * win, uint8_t * im, uint8_t * dst, const int lane )
+// ---- six-tap motion compensation on packed bytes ------------------------------------------------------------------
+// One lane produces 4 adjacent outputs of a filter pass from 12 consecutive source bytes held in three dwords:
+// about 7 VALU instructions per output instead of ~25 for byte-at-a-time code.
+// 4 bytes starting at byte offset s (0..11) of the 16-byte string d0 d1 d2 0
+__device__ __forceinline__ uint32_t bytes_at( const uint32_t d0, const uint32_t d1, const uint32_t d2, const int s )
 {
-  const int sx = x0 + ( mvx >> 3 ), sy = y0 + ( mvy >> 3 );   // arithmetic shift (Q9)
-  const int mx = mvx & 7, my = mvy & 7;
-  if ( ( mx | my ) == 0 ) {
-    for ( int i = lane; i < N * N; i += kLanes ) {
-      const int r = i / N, c = i % N;
-      dst[i] = ref[static_cast<size_t>( clampi( sy + r, 0, ph - 1 ) ) * pw + clampi( sx + c, 0, pw - 1 )];
-    }
-    __syncthreads();
-    return;
+  const int q = s >> 2, sh = s & 3;
+  const uint32_t lo = q == 0 ? d0 : ( q == 1 ? d1 : d2 );
+  const uint32_t hi = q == 0 ? d1 : ( q == 1 ? d2 : 0u );
+  return __builtin_amdgcn_alignbyte( hi, lo, sh );
+}
+__device__ __forceinline__ void pack_taps( const int frac, uint32_t & t0123, uint32_t & t45 )
+{
+  t0123 = ( sixtap_coeff( frac, 0 ) & 0xFF ) | ( ( sixtap_coeff( frac, 1 ) & 0xFF ) << 8 ) | ( ( sixtap_coeff( frac, 2 ) & 0xFF ) << 16 )
+          | ( static_cast<uint32_t>( sixtap_coeff( frac, 3 ) & 0xFF ) << 24 );
+  t45 = ( sixtap_coeff( frac, 4 ) & 0xFF ) | ( ( sixtap_coeff( frac, 5 ) & 0xFF ) << 8 );
+}
+// outputs k = 0..3 take source bytes o+k .. o+k+5 (o = 0..3) of the 12-byte string d0 d1 d2; frac 0 = identity (its
+// centre tap 128 does not fit int8).  sum(taps) = 128, so sum t_i*p_i = sum t_i*(p_i - 128) + 16384: the pixels are
+// re-biased to signed bytes with one xor per dword and each output is two v_dot4_i32_i8 on taps packed as signed bytes.
+// NOTE: hipcc 7.2 folds a pair of `clamp255( x >> 7 )` into v_ashr_pk_u8_i32 and then assumes the upper 16 result bits
+// are zero; on gfx950 they are not (found with tools/_t6.hip on hardware) -- the empty asm keeps shift and clamp apart.
+__device__ __forceinline__ uint32_t sixtap_x4( uint32_t d0, uint32_t d1, uint32_t d2, const int o, const int frac, const uint32_t t0123, const uint32_t t45 )
+{
+  if ( frac == 0 ) return bytes_at( d0, d1, d2, o + 2 );
+  d0 ^= 0x80808080u; d1 ^= 0x80808080u; d2 ^= 0x80808080u;
+  uint32_t out = 0;
+#pragma unroll
+  for ( int k = 0; k < 4; k++ ) {
+    const int a = static_cast<int>( bytes_at( d0, d1, d2, o + k ) ), b = static_cast<int>( bytes_at( d0, d1, d2, o + k + 4 ) );
+    int v = __builtin_amdgcn_sdot4( a, static_cast<int>( t0123 ), __builtin_amdgcn_sdot4( b, static_cast<int>( t45 ), 16384 + 64, false ), false ) >> 7;
+    asm volatile( "" : "+v"( v ) );
+    out |= static_cast<uint32_t>( clamp255( v ) ) << ( 8 * k );
   }
-  constexpr int W = N + 5;
-  for ( int i = lane; i < W * W; i += kLanes ) {
-    const int r = i / W, c = i % W;
-    win[i] = ref[static_cast<size_t>( clampi( sy - 2 + r, 0, ph - 1 ) ) * pw + clampi( sx - 2 + c, 0, pw - 1 )];
-  }
-  int hf[6], vf[6];
-  load_taps( mx, hf ); load_taps( my, vf );
-  __syncthreads();
-  for ( int i = lane; i < W * N; i += kLanes ) {            // horizontal pass over N+5 rows, clamp to u8 (Q6)
-    const int r = i / N, c = i % N;
-    const uint8_t * p = win + r * W + c;
-    im[i] = static_cast<uint8_t>( sixtap( p[0], p[1], p[2], p[3], p[4], p[5], hf[0], hf[1], hf[2], hf[3], hf[4], hf[5] ) );
-  }
-  __syncthreads();
-  for ( int i = lane; i < N * N; i += kLanes ) {            // vertical pass
-    const int r = i / N, c = i % N;
-    const uint8_t * p = im + r * N + c;
-    dst[i] = static_cast<uint8_t>( sixtap( p[0], p[N], p[2 * N], p[3 * N], p[4 * N], p[5 * N], vf[0], vf[1], vf[2], vf[3], vf[4], vf[5] ) );
-  }
-  __syncthreads();
+  return out;
 }
 
-struct alignas( 16 ) InterLds {
+struct alignas( 16 ) InterLds {     // ~5 KB: 32 single-wave workgroups fit one CU (the kernel is latency bound: occupancy matters)
   ResidualLds r;
-  uint8_t win[24 * 81];      // reference windows: 21x21 / 13x13 (whole-MB) or 24 x 9x9 (SPLITMV)
-  uint8_t im[24 * 36];       // first-pass output
-  uint8_t pred[384];         // Y 16x16 | U 8x8 | V 8x8, each row-major
-  int16_t unit[24][4];       // SPLITMV: per 4x4 unit {sx-2, sy-2, mx, my}
+  alignas( 16 ) uint8_t pred[384];   // Y 16x16 | U 8x8 | V 8x8, each row-major
+  union {
+    struct {                         // SPLITMV: 24 units of 4x4, byte-at-a-time
+      uint8_t win[24 * 81];          // 9x9 reference windows
+      uint8_t im[24 * 36];           // first-pass output
+      int16_t unit[24][4];           // per unit {sx-2, sy-2, mx, my}
+    };
+    struct {                         // whole-MB vector: reference windows as dword rows, first-pass output stored
+      uint32_t wy[21][6], wc[2][13][4];   // TRANSPOSED (column-major) so that the vertical pass also reads 12
+      uint32_t ty[16][6], tc[2][8][4];    // consecutive bytes per lane
+    };
+  };
 };
 
 // grid.x = macroblock (XCD-aware order), grid.y = frame in batch
@@ -148,15 +158,82 @@ __global__ __launch_bounds__( kLanes ) void k_recon_inter( const aa_frame_list l
   const int col = mi % f.mbw, row = mi / f.mbw;
   const int pw = f.mbw * 16, ph = f.mbh * 16, cw = pw >> 1, ch = ph >> 1;
   const bool has_res = mb.flags & AA_MB_HAS_NONZERO;
+  const uint8_t * const * ref = f.ref[mb.ref_frame & 3];
+  const bool whole = mb.y_mode != SPLITMV;
+  // Y 16x16 with the MB vector, U/V 8x8 with the derived chroma vector (macroblock.cc:583-586)
+  const int mvx = mb.u.mv[0][0], mvy = mb.u.mv[0][1];
+  const int cmx = chroma_mv( 4 * mvx ), cmy = chroma_mv( 4 * mvy );
+  const int sxy = col * 16 + ( mvx >> 3 ) - 2, syy = row * 16 + ( mvy >> 3 ) - 2;     // window origins (Q9: arithmetic shift)
+  const int sxc = col * 8 + ( cmx >> 3 ) - 2, syc = row * 8 + ( cmy >> 3 ) - 2;
+  // aligned-dword staging when the windows lie inside the planes, else byte-wise coordinate clamping (EdgeExtendedRaster)
+  const int axy = sxy & ~3, axc = sxc & ~3;
+  const bool inside = whole && sxy >= 0 && syy >= 0 && axy + 24 <= pw && syy + 21 <= ph && sxc >= 0 && syc >= 0 && axc + 16 <= cw && syc + 13 <= ch;
+  // issue the reference-window loads before the residual work so that their latency overlaps it
+  uint32_t wreg[4] = { 0, 0, 0, 0 };
+  if ( inside ) {
+#pragma unroll
+    for ( int k = 0; k < 4; k++ ) {
+      const int i = lane + k * kLanes;
+      if ( i < 126 ) { const int r = i / 6, d = i % 6; wreg[k] = *reinterpret_cast<const uint32_t *>( ref[0] + static_cast<size_t>( syy + r ) * pw + axy + d * 4 ); }
+      else if ( i < 230 ) { const int j = i - 126, pl = j / 52, e = j % 52, r = e >> 2, d = e & 3;
+                            wreg[k] = *reinterpret_cast<const uint32_t *>( ref[1 + pl] + static_cast<size_t>( syc + r ) * cw + axc + d * 4 ); }
+    }
+  }
   if ( has_res ) compute_residual( mb, f, L.r, lane );
 
-  const uint8_t * const * ref = f.ref[mb.ref_frame & 3];
-  if ( mb.y_mode != SPLITMV ) {
-    const int mvx = mb.u.mv[0][0], mvy = mb.u.mv[0][1];
-    const int cmx = chroma_mv( 4 * mvx ), cmy = chroma_mv( 4 * mvy );
-    mc_block<16>( ref[0], pw, ph, col * 16, row * 16, mvx, mvy, L.win, L.im, L.pred, lane );
-    mc_block<8>( ref[1], cw, ch, col * 8, row * 8, cmx, cmy, L.win, L.im, L.pred + 256, lane );
-    mc_block<8>( ref[2], cw, ch, col * 8, row * 8, cmx, cmy, L.win, L.im, L.pred + 320, lane );
+  if ( whole ) {
+    int oy, oc;
+    if ( inside ) {
+      oy = sxy & 3; oc = sxc & 3;
+      uint32_t * flat = &L.wy[0][0];          // wy (126 dwords) is directly followed by wc (104 dwords)
+#pragma unroll
+      for ( int k = 0; k < 4; k++ ) { const int i = lane + k * kLanes; if ( i < 230 ) flat[i] = wreg[k]; }
+    } else {
+      oy = 0; oc = 0;
+      uint8_t * by = reinterpret_cast<uint8_t *>( &L.wy[0][0] );
+      for ( int i = lane; i < 21 * 24; i += kLanes ) {
+        const int r = i / 24, c = i % 24;
+        by[i] = ref[0][static_cast<size_t>( clampi( syy + r, 0, ph - 1 ) ) * pw + clampi( sxy + c, 0, pw - 1 )];
+      }
+      uint8_t * bc = reinterpret_cast<uint8_t *>( &L.wc[0][0][0] );
+      for ( int i = lane; i < 2 * 13 * 16; i += kLanes ) {
+        const int pl = i / 208, e = i % 208, r = e >> 4, c = e & 15;
+        bc[i] = ref[1 + pl][static_cast<size_t>( clampi( syc + r, 0, ch - 1 ) ) * cw + clampi( sxc + c, 0, cw - 1 )];
+      }
+    }
+    uint32_t hy0, hy1, vy0, vy1, hc0, hc1, vc0, vc1;
+    pack_taps( mvx & 7, hy0, hy1 ); pack_taps( mvy & 7, vy0, vy1 ); pack_taps( cmx & 7, hc0, hc1 ); pack_taps( cmy & 7, vc0, vc1 );
+    __syncthreads();
+    // horizontal pass over N+5 rows; result bytes go to the transposed buffers t[column][row]
+    for ( int t = lane; t < 84 + 52; t += kLanes ) {
+      if ( t < 84 ) {
+        const int r = t >> 2, g = t & 3;
+        const uint32_t o4 = sixtap_x4( L.wy[r][g], L.wy[r][g + 1], L.wy[r][g + 2], oy, mvx & 7, hy0, hy1 );
+        uint8_t * tb = reinterpret_cast<uint8_t *>( &L.ty[g * 4][0] ) + r;
+        tb[0] = static_cast<uint8_t>( o4 ); tb[24] = static_cast<uint8_t>( o4 >> 8 ); tb[48] = static_cast<uint8_t>( o4 >> 16 ); tb[72] = static_cast<uint8_t>( o4 >> 24 );
+      } else {
+        const int j = t - 84, pl = j / 26, e = j % 26, r = e >> 1, g = e & 1;
+        const uint32_t o4 = sixtap_x4( L.wc[pl][r][g], L.wc[pl][r][g + 1], L.wc[pl][r][g + 2], oc, cmx & 7, hc0, hc1 );
+        uint8_t * tb = reinterpret_cast<uint8_t *>( &L.tc[pl][g * 4][0] ) + r;
+        tb[0] = static_cast<uint8_t>( o4 ); tb[16] = static_cast<uint8_t>( o4 >> 8 ); tb[32] = static_cast<uint8_t>( o4 >> 16 ); tb[48] = static_cast<uint8_t>( o4 >> 24 );
+      }
+    }
+    __syncthreads();
+    // vertical pass: lane = (column c, row group i) -> rows 4i..4i+3 of column c
+    for ( int t = lane; t < 64 + 32; t += kLanes ) {
+      if ( t < 64 ) {
+        const int c = t >> 2, i = t & 3;
+        const uint32_t o4 = sixtap_x4( L.ty[c][i], L.ty[c][i + 1], L.ty[c][i + 2], 0, mvy & 7, vy0, vy1 );
+        uint8_t * pb = L.pred + ( i * 4 ) * 16 + c;
+        pb[0] = static_cast<uint8_t>( o4 ); pb[16] = static_cast<uint8_t>( o4 >> 8 ); pb[32] = static_cast<uint8_t>( o4 >> 16 ); pb[48] = static_cast<uint8_t>( o4 >> 24 );
+      } else {
+        const int j = t - 64, pl = j >> 4, c = ( j >> 1 ) & 7, i = j & 1;
+        const uint32_t o4 = sixtap_x4( L.tc[pl][c][i], L.tc[pl][c][i + 1], L.tc[pl][c][i + 2], 0, cmy & 7, vc0, vc1 );
+        uint8_t * pb = L.pred + 256 + pl * 64 + ( i * 4 ) * 8 + c;
+        pb[0] = static_cast<uint8_t>( o4 ); pb[8] = static_cast<uint8_t>( o4 >> 8 ); pb[16] = static_cast<uint8_t>( o4 >> 16 ); pb[24] = static_cast<uint8_t>( o4 >> 24 );
+      }
+    }
+    __syncthreads();
   } else {
     // 16 luma + 4+4 chroma 4x4 units, each with its own vector; all units go through both filter passes
     // (fraction 0 = identity taps, bit-identical to a copy).
@@ -390,7 +467,7 @@ __device__ __forceinline__ void publish_progress( int * progress, const int valu
   asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );      // every store of this wave has been written through
   if ( lane == 0 ) __hip_atomic_store( progress, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
 }
-__device__ __forceinline__ void wait_progress( const int * progress, const int need, aa_sync_ws * ws )
+__device__ __forceinline__ void wait_progress( const int * progress, const int need, aa_sync_ws * ws, const int code )
 {
   int spins = 0;
   while ( __hip_atomic_load( progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) < need ) {
@@ -398,7 +475,7 @@ __device__ __forceinline__ void wait_progress( const int * progress, const int n
     ++spins;
     // watchdog: sticky error word; once any wait has expired every other wait gives up within 1024 polls
     if ( ( spins & 1023 ) == 0 && __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
-    if ( spins > ( 1 << 21 ) ) { __hip_atomic_store( &ws->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); break; }
+    if ( spins > ( 1 << 21 ) ) { __hip_atomic_store( &ws->error, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); break; }
   }
 }
 
@@ -425,7 +502,7 @@ __global__ __launch_bounds__( kLanes ) void k_recon_intra_rows( const aa_frame_l
         m &= m - 1;
         // everything left of `col` in this row is final; then wait for the row above
         publish_progress( &progress[row], col, lane );
-        if ( row > 0 ) wait_progress( &progress[row - 1], min( col + 2, mbw ), ws );
+        if ( row > 0 ) wait_progress( &progress[row - 1], min( col + 2, mbw ), ws, 1 );
         intra_macroblock<true>( f, f.mbs[row * mbw + col], col, row, L, lane );
       }
     }
@@ -544,109 +621,206 @@ __global__ __launch_bounds__( kLanes ) void k_loopfilter( const aa_frame_list li
   }
 }
 
-// Row-pipelined loop filter: ticket -> (frame, MB row); the wave walks its row left to right.
-//   * per-MB loop-filter level/flags of the whole row are preloaded into LDS once;
-//   * the macroblock's own 16 rows were produced by earlier launches -> plain loads, PREFETCHED into registers while
-//     the previous macroblock is being filtered;
-//   * the 4 rows above belong to the previous MB row, filtered by another workgroup of this launch -> agent-scope
-//     loads after progress[row-1] >= min(col+2, mbw);
-//   * the 4 columns to the left are the wave's own previous macroblock -> carried over in LDS, never re-read;
-//   * every store is write-through; progress[row] = col+1 is published one step late, after the first poll for the
-//     next macroblock has returned (its s_waitcnt also drains the stores), so the drain overlaps the prefetch + poll.
 constexpr int kMaxMbw = 1024;     // 16383 px / 16
 
-__global__ __launch_bounds__( kLanes ) void k_loopfilter_rows( const aa_frame_list list, const int n_frames, const int mbh_max, aa_sync_ws * ws )
+// ---- row-pipelined loop filter ------------------------------------------------------------------------------------
+// The vertical-edge passes (left MB edge + inner vertical edges) of a macroblock touch only its own 16 pixel rows, so
+// they do not depend on the macroblock row above; only the horizontal-edge passes (top MB edge + inner horizontal
+// edges) do.  Splitting them takes half of the filter arithmetic off the cross-row critical path.
+__device__ void lf_passes_vertical( LfLds & L, const bool active, const bool have_left, const bool inner, const LfParams & P, const int hl )
 {
-  __shared__ LfLds L;
-  __shared__ uint16_t s_info[kMaxMbw];     // lf_level | flags << 8
+  const bool is_y = active && hl < 16, is_c = active && hl >= 16;
+  const int cl = ( hl - 16 ) & 7, cp = ( hl - 16 ) >> 3;
+  if ( have_left ) {
+    if ( is_y ) lf_edge( &L.y[4 + hl][4], 1, true, P );
+    else if ( is_c ) lf_edge( &L.c[cp][4 + cl][4], 1, true, P );
+  }
+  __syncthreads();
+  if ( is_y && inner ) lf_edge( &L.y[4 + hl][8], 1, false, P );
+  else if ( is_c && inner ) lf_edge( &L.c[cp][4 + cl][8], 1, false, P );
+  __syncthreads();
+  if ( is_y && inner ) lf_edge( &L.y[4 + hl][12], 1, false, P );
+  __syncthreads();
+  if ( is_y && inner ) lf_edge( &L.y[4 + hl][16], 1, false, P );
+  __syncthreads();
+}
+__device__ void lf_passes_horizontal( LfLds & L, const bool active, const bool have_top, const bool inner, const LfParams & P, const int hl )
+{
+  const bool is_y = active && hl < 16, is_c = active && hl >= 16;
+  const int cl = ( hl - 16 ) & 7, cp = ( hl - 16 ) >> 3;
+  if ( have_top ) {
+    if ( is_y ) lf_edge( &L.y[4][4 + hl], 20, true, P );
+    else if ( is_c ) lf_edge( &L.c[cp][4][4 + cl], 12, true, P );
+  }
+  __syncthreads();
+  if ( is_y && inner ) lf_edge( &L.y[8][4 + hl], 20, false, P );
+  else if ( is_c && inner ) lf_edge( &L.c[cp][8][4 + cl], 12, false, P );
+  __syncthreads();
+  if ( is_y && inner ) lf_edge( &L.y[12][4 + hl], 20, false, P );
+  __syncthreads();
+  if ( is_y && inner ) lf_edge( &L.y[16][4 + hl], 20, false, P );
+  __syncthreads();
+}
+
+// ticket -> (group of `fpw` frames, MB row).  fpw = 2: lanes 0..31 filter row `row` of frame 2g, lanes 32..63 the same
+// row of frame 2g+1 (same geometry, guaranteed by the host); fpw = 1: the upper half idles.  The edge passes keep only
+// 16 (luma) + 16 (chroma) lanes of a frame busy, so pairing frames doubles the work per issued instruction.
+// Per macroblock, per half:
+//   * level/flags of the whole row are preloaded into LDS once; the MB's own 16 rows (produced by earlier launches) are
+//     PREFETCHED with plain loads while the previous MB is filtered; the 4 columns to the left are the half's own
+//     previous MB, carried over in LDS;
+//   * vertical passes run first (no dependency on the row above); the poll of progress[row-1] is issued before them;
+//   * then wait for progress[row-1] >= min(col+2, mbw), fetch the 4 rows above with agent-scope loads (they were
+//     filtered by another workgroup of this launch), run the horizontal passes;
+//   * every store is write-through; progress[row] = col+1 is published one step late, once the stores have drained
+//     behind the next MB's prefetch (s_waitcnt vmcnt(0) after its first pass), so the drain is never waited for.
+__global__ __launch_bounds__( kLanes ) void k_loopfilter_rows( const aa_frame_list list, const int n_frames, const int mbh_max, aa_sync_ws * ws, const int fpw )
+{
+  __shared__ LfLds L2[2];
+  __shared__ uint16_t s_info[2][kMaxMbw];
   __shared__ int s_ticket;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, half = lane >> 5, hl = lane & 31;
   const int t = take_ticket( ws, &s_ticket, lane );
-  const int fi = t / mbh_max, row = t % mbh_max;
-  if ( fi >= n_frames ) return;
-  const aa_dev_frame & f = *list.f[fi];
-  if ( row >= f.mbh || !f.loop_filter_level ) return;
-  int * progress = ws->progress + fi * mbh_max;
-  const int mbw = f.mbw, pw = mbw * 16, cw = pw >> 1;
+  const int group = t / mbh_max, row = t % mbh_max;
+  if ( group * fpw >= n_frames ) return;
+  const aa_dev_frame & f0 = *list.f[group * fpw];
+  if ( row >= f0.mbh ) return;
+  const int fi = group * fpw + half;
+  const bool have = half < fpw && fi < n_frames;
+  const aa_dev_frame & f = *list.f[have ? fi : group * fpw];
+  const bool frame_on = have && f.loop_filter_level != 0;
+  if ( !__any( frame_on ) ) return;
+  LfLds & L = L2[half];
+  int * progress = ws->progress + ( have ? fi : group * fpw ) * mbh_max;
+  const int mbw = f0.mbw, pw = mbw * 16, cw = pw >> 1;
   const int y0 = row * 16, cy0 = row * 8;
-  uint8_t * Y = f.cur[0];
-  for ( int c = lane; c < mbw; c += kLanes ) {
-    const aa_mb_info & m = f.mbs[row * mbw + c];
-    s_info[c] = static_cast<uint16_t>( m.lf_level | ( m.flags << 8 ) );
+  uint8_t * const Y = f.cur[0];
+  uint8_t * const C0 = f.cur[1];
+  uint8_t * const C1 = f.cur[2];
+  const int sharp = f.sharpness; const bool key = f.key_frame;
+  for ( int c = hl; c < mbw; c += 32 ) {
+    int v = 0;
+    if ( frame_on ) { const aa_mb_info & m = f.mbs[row * mbw + c]; v = m.lf_level | ( m.flags << 8 ); }
+    s_info[half][c] = static_cast<uint16_t>( v );
   }
   __syncthreads();
 
-  // lane roles for the bulk transfers: luma 16 rows x 4 dwords = 64 lanes; chroma 2 planes x 8 rows x 2 dwords = 32 lanes
-  const int yr = 4 + ( lane >> 2 ), yd = 1 + ( lane & 3 );
-  const int cpl = ( lane >> 4 ) & 1, cr = 4 + ( ( lane >> 1 ) & 7 ), cd = 1 + ( lane & 1 );
-  const uint8_t * yrow = Y + static_cast<size_t>( y0 - 4 + yr ) * pw - 4 + yd * 4;
-  const uint8_t * crow = f.cur[1 + cpl] + static_cast<size_t>( cy0 - 4 + cr ) * cw - 4 + cd * 4;
+  // bulk-transfer roles inside a half: luma 64 dwords = 2 per lane, chroma 32 dwords = 1 per lane
+  const int yr0 = 4 + ( hl >> 2 ), yr1 = yr0 + 8, yd = 1 + ( hl & 3 );
+  const int cpl = hl >> 4, cr = 4 + ( ( hl >> 1 ) & 7 ), cd = 1 + ( hl & 1 );
+  const uint8_t * yrow0 = Y + static_cast<size_t>( y0 - 4 + yr0 ) * pw - 4 + yd * 4;
+  const uint8_t * yrow1 = yrow0 + static_cast<size_t>( 8 ) * pw;
+  const uint8_t * crow = ( cpl ? C1 : C0 ) + static_cast<size_t>( cy0 - 4 + cr ) * cw - 4 + cd * 4;
+  // store slots (which dword of the LDS tile this lane writes back, and where): 5 luma/chroma slots per lane,
+  // resolved once per row instead of per macroblock.  kind: 0 unused, 1 always, 2 only when col > 0 (left columns);
+  // +4: the dword lies in the bottom 4 pixel rows of this MB row, which the NEXT row's workgroup reads in this launch
+  // -> write-through (sc1) store.  Everything else is read by nobody before the launch ends -> plain (L2 write-back,
+  // the 8 macroblocks sharing a 128-B line combine there) store; measured: all-write-through moved 6x the algorithmic bytes.
+  uint8_t * st_ptr[5]; int st_lds[5]; int st_kind[5]; int st_step[5];
+  {
+    int k = 0;
+    for ( int i = hl; i < 100 && k < 5; i += 32 ) {            // luma: 20 rows x 5 dwords
+      const int r = i / 5, d = i % 5;
+      if ( r == 0 || ( r < 4 && ( d == 0 || row == 0 ) ) ) continue;
+      st_ptr[k] = Y + static_cast<ptrdiff_t>( y0 - 4 + r ) * pw - 4 + d * 4; st_lds[k] = r * 20 + d * 4; st_kind[k] = ( d == 0 ? 2 : 1 ) | ( r >= 16 ? 4 : 0 ); st_step[k] = 16; k++;
+    }
+    for ( int i = hl; i < 72 && k < 5; i += 32 ) {             // chroma: 2 planes x 12 rows x 3 dwords
+      const int pl = i / 36, e = i % 36, r = e / 3, d = e % 3;
+      if ( r == 0 || ( r < 4 && ( d == 0 || row == 0 ) ) ) continue;
+      st_ptr[k] = ( pl ? C1 : C0 ) + static_cast<ptrdiff_t>( cy0 - 4 + r ) * cw - 4 + d * 4; st_lds[k] = 400 + pl * 144 + r * 12 + d * 4; st_kind[k] = ( d == 0 ? 2 : 1 ) | ( r >= 8 ? 4 : 0 ); st_step[k] = 8; k++;
+    }
+    for ( ; k < 5; k++ ) { st_ptr[k] = Y; st_lds[k] = 0; st_kind[k] = 0; st_step[k] = 0; }
+  }
+  const uint8_t * const lds_base = &L.y[0][0];     // LfLds: y[20][20] (400 B) followed by c[2][12][12]
 
-  bool carried = false;            // LDS columns -4..-1 hold the previous macroblock's filtered right edge
-  bool prefetched = false;
-  uint32_t pre_y = 0, pre_c = 0;
-  int pending = -1;                // progress value not yet published (its stores may still be in flight)
+  bool carried = false, prefetched = false;
+  uint32_t pre_y0 = 0, pre_y1 = 0, pre_c = 0;
+  int pending = -1;
   for ( int col = 0; col < mbw; col++ ) {
-    const int info = s_info[col];
+    const int info = s_info[half][col];
     const int level = info & 0xFF;
-    if ( level == 0 ) {
+    const bool active = level != 0;
+    const int x0 = col * 16, cx0 = col * 8;
+    if ( !__any( active ) ) {           // neither frame filters this macroblock
       carried = false; prefetched = false;
-      publish_progress( &progress[row], col + 1, lane ); pending = -1;
+      asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+      if ( hl == 0 && frame_on ) __hip_atomic_store( &progress[row], col + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      pending = -1;
       continue;
     }
-    const int x0 = col * 16, cx0 = col * 8;
-    if ( !prefetched ) {
-      pre_y = *reinterpret_cast<const uint32_t *>( yrow + x0 );
-      if ( lane < 32 ) pre_c = *reinterpret_cast<const uint32_t *>( crow + cx0 );
+    if ( active && !prefetched ) {
+      pre_y0 = *reinterpret_cast<const uint32_t *>( yrow0 + x0 ); pre_y1 = *reinterpret_cast<const uint32_t *>( yrow1 + x0 );
+      pre_c = *reinterpret_cast<const uint32_t *>( crow + cx0 );
     }
-    if ( !carried && col > 0 ) {   // left neighbour columns straight from memory (previous MB was not filtered)
-      if ( lane < 16 ) *reinterpret_cast<uint32_t *>( &L.y[4 + lane][0] ) = *reinterpret_cast<const uint32_t *>( Y + static_cast<size_t>( y0 + lane ) * pw + x0 - 4 );
-      else if ( lane < 32 ) { const int l = lane - 16; *reinterpret_cast<uint32_t *>( &L.c[l >> 3][4 + ( l & 7 )][0] ) = *reinterpret_cast<const uint32_t *>( f.cur[1 + ( l >> 3 )] + static_cast<size_t>( cy0 + ( l & 7 ) ) * cw + cx0 - 4 ); }
+    if ( active && !carried && col > 0 ) {   // left neighbour columns straight from memory
+      if ( hl < 16 ) *reinterpret_cast<uint32_t *>( &L.y[4 + hl][0] ) = *reinterpret_cast<const uint32_t *>( Y + static_cast<size_t>( y0 + hl ) * pw + x0 - 4 );
+      else { const int l = hl - 16; *reinterpret_cast<uint32_t *>( &L.c[l >> 3][4 + ( l & 7 )][0] ) = *reinterpret_cast<const uint32_t *>( ( ( l >> 3 ) ? C1 : C0 ) + static_cast<size_t>( cy0 + ( l & 7 ) ) * cw + cx0 - 4 ); }
     }
-    if ( row > 0 ) {
-      const int need = min( col + 2, mbw );
-      int seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-      if ( pending >= 0 ) { publish_progress( &progress[row], pending, lane ); pending = -1; }
-      if ( seen < need ) wait_progress( &progress[row - 1], need, ws );
-      if ( lane < 16 ) {             // 4 rows x 4 dwords above the luma block
-        const int r = lane >> 2, d = 1 + ( lane & 3 );
-        *reinterpret_cast<uint32_t *>( &L.y[r][d * 4] ) = load_u32<true>( Y + static_cast<size_t>( y0 - 4 + r ) * pw + x0 - 4 + d * 4 );
-      } else if ( lane < 32 ) {      // 2 planes x 4 rows x 2 dwords above the chroma blocks
-        const int l = lane - 16, pl = l >> 3, r = ( l >> 1 ) & 3, d = 1 + ( l & 1 );
-        *reinterpret_cast<uint32_t *>( &L.c[pl][r][d * 4] ) = load_u32<true>( f.cur[1 + pl] + static_cast<size_t>( cy0 - 4 + r ) * cw + cx0 - 4 + d * 4 );
-      }
-    } else if ( pending >= 0 ) { publish_progress( &progress[row], pending, lane ); pending = -1; }
-    *reinterpret_cast<uint32_t *>( &L.y[yr][yd * 4] ) = pre_y;
-    if ( lane < 32 ) *reinterpret_cast<uint32_t *>( &L.c[cpl][cr][cd * 4] ) = pre_c;
+    if ( active ) {
+      *reinterpret_cast<uint32_t *>( &L.y[yr0][yd * 4] ) = pre_y0; *reinterpret_cast<uint32_t *>( &L.y[yr1][yd * 4] ) = pre_y1;
+      *reinterpret_cast<uint32_t *>( &L.c[cpl][cr][cd * 4] ) = pre_c;
+    }
+    // everything issued so far (previous MB's write-through stores included) has completed: publish the previous MB
+    asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+    if ( hl == 0 && pending >= 0 ) __hip_atomic_store( &progress[row], pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    pending = -1;
+    const int need = min( col + 2, mbw );
+    int seen = need;
+    if ( row > 0 && active ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );   // consumed after the vertical passes
     __syncthreads();
 
-    lf_passes( L, col > 0, row > 0, !( ( info >> 8 ) & AA_MB_LF_SKIP_INNER ), lf_params( level, f.sharpness, f.key_frame ), lane );
+    const LfParams P = lf_params( active ? level : 1, sharp, key );
+    const bool inner = !( ( info >> 8 ) & AA_MB_LF_SKIP_INNER );
+    lf_passes_vertical( L, active, col > 0, inner, P, hl );
 
-    // write-through stores: rows -3..-1 x cols 0..15 (previous MB row), rows 0..15 x cols -4..15
-    for ( int i = lane; i < 100; i += kLanes ) {
-      const int r = i / 5, d = i % 5;
-      if ( r == 0 || ( r < 4 && ( d == 0 || row == 0 ) ) || ( d == 0 && col == 0 ) ) continue;
-      store_u32<true>( Y + static_cast<size_t>( y0 - 4 + r ) * pw + x0 - 4 + d * 4, *reinterpret_cast<const uint32_t *>( &L.y[r][d * 4] ) );
+    if ( row > 0 ) {
+      int spins = 0;
+      while ( !__all( seen >= need ) ) {
+        __builtin_amdgcn_s_sleep( 1 );
+        if ( seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        ++spins;
+        if ( ( spins & 1023 ) == 0 && __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
+        if ( spins > ( 1 << 21 ) ) { __hip_atomic_store( &ws->error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); break; }
+      }
+      if ( active ) {
+        if ( hl < 16 ) {             // 4 rows x 4 dwords above the luma block
+          const int r = hl >> 2, d = 1 + ( hl & 3 );
+          *reinterpret_cast<uint32_t *>( &L.y[r][d * 4] ) = load_u32<true>( Y + static_cast<size_t>( y0 - 4 + r ) * pw + x0 - 4 + d * 4 );
+        } else {                     // 2 planes x 4 rows x 2 dwords above the chroma blocks
+          const int l = hl - 16, pl = l >> 3, r = ( l >> 1 ) & 3, d = 1 + ( l & 1 );
+          *reinterpret_cast<uint32_t *>( &L.c[pl][r][d * 4] ) = load_u32<true>( ( pl ? C1 : C0 ) + static_cast<size_t>( cy0 - 4 + r ) * cw + cx0 - 4 + d * 4 );
+        }
+      }
+      __syncthreads();
     }
-    for ( int i = lane; i < 72; i += kLanes ) {
-      const int pl = i / 36, e = i % 36, r = e / 3, d = e % 3;
-      if ( r == 0 || ( r < 4 && ( d == 0 || row == 0 ) ) || ( d == 0 && col == 0 ) ) continue;
-      store_u32<true>( f.cur[1 + pl] + static_cast<size_t>( cy0 - 4 + r ) * cw + cx0 - 4 + d * 4, *reinterpret_cast<const uint32_t *>( &L.c[pl][r][d * 4] ) );
+
+    lf_passes_horizontal( L, active, row > 0, inner, P, hl );
+
+    if ( active ) {   // write-through stores: rows -3..-1 x cols 0..15 (previous MB row), rows 0..15 x cols -4..15
+#pragma unroll
+      for ( int k = 0; k < 5; k++ )
+        if ( ( st_kind[k] & 1 ) || ( ( st_kind[k] & 2 ) && col > 0 ) ) {
+          const uint32_t v = *reinterpret_cast<const uint32_t *>( lds_base + st_lds[k] );
+          if ( st_kind[k] & 4 ) store_u32<true>( st_ptr[k] + col * st_step[k], v );
+          else store_u32<false>( st_ptr[k] + col * st_step[k], v );
+        }
     }
-    pending = col + 1;
+    if ( frame_on ) pending = col + 1;
     // prefetch the next macroblock's own rows while these stores drain
-    prefetched = col + 1 < mbw && ( s_info[col + 1] & 0xFF ) != 0;
+    prefetched = col + 1 < mbw && ( s_info[half][col + 1] & 0xFF ) != 0;
     if ( prefetched ) {
-      pre_y = *reinterpret_cast<const uint32_t *>( yrow + x0 + 16 );
-      if ( lane < 32 ) pre_c = *reinterpret_cast<const uint32_t *>( crow + cx0 + 8 );
+      pre_y0 = *reinterpret_cast<const uint32_t *>( yrow0 + x0 + 16 ); pre_y1 = *reinterpret_cast<const uint32_t *>( yrow1 + x0 + 16 );
+      pre_c = *reinterpret_cast<const uint32_t *>( crow + cx0 + 8 );
     }
-    // carry the filtered right edge (cols 12..15 / 4..7) over as the next macroblock's left neighbour columns
-    if ( lane < 16 ) *reinterpret_cast<uint32_t *>( &L.y[4 + lane][0] ) = *reinterpret_cast<const uint32_t *>( &L.y[4 + lane][16] );
-    else if ( lane < 32 ) { const int l = lane - 16; *reinterpret_cast<uint32_t *>( &L.c[l >> 3][4 + ( l & 7 )][0] ) = *reinterpret_cast<const uint32_t *>( &L.c[l >> 3][4 + ( l & 7 )][8] ); }
-    carried = true;
+    if ( active ) {                  // carry the filtered right edge over as the next macroblock's left neighbour columns
+      if ( hl < 16 ) *reinterpret_cast<uint32_t *>( &L.y[4 + hl][0] ) = *reinterpret_cast<const uint32_t *>( &L.y[4 + hl][16] );
+      else { const int l = hl - 16; *reinterpret_cast<uint32_t *>( &L.c[l >> 3][4 + ( l & 7 )][0] ) = *reinterpret_cast<const uint32_t *>( &L.c[l >> 3][4 + ( l & 7 )][8] ); }
+    }
+    carried = active;
     __syncthreads();
   }
-  if ( pending >= 0 ) publish_progress( &progress[row], pending, lane );
+  asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+  if ( hl == 0 && pending >= 0 ) __hip_atomic_store( &progress[row], pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
 }
 
 } // namespace
@@ -667,14 +841,22 @@ int launch_loopfilter_diagonal( const aa_frame_list & list, int n, int diagonal,
   hipLaunchKernelGGL( k_loopfilter, dim3( rows, n ), dim3( kLanes ), 0, static_cast<hipStream_t>( stream ), list, diagonal, row_lo );
   return static_cast<int>( hipGetLastError() );
 }
+// Test hook: ALFALFA_AMD_TEST_LDS_PAD=<bytes> adds dynamic LDS to the row-pipelined launches to force PARTIAL residency
+// (the ordering protocol must not depend on every workgroup being resident).
+static unsigned test_lds_pad()
+{
+  static const unsigned pad = [] { const char * e = std::getenv( "ALFALFA_AMD_TEST_LDS_PAD" ); return e ? static_cast<unsigned>( std::atoi( e ) ) : 0u; }();
+  return pad;
+}
 int launch_recon_intra_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, void * stream )
 {
-  hipLaunchKernelGGL( k_recon_intra_rows, dim3( n * mbh_max ), dim3( kLanes ), 0, static_cast<hipStream_t>( stream ), list, n, mbh_max, ws );
+  hipLaunchKernelGGL( k_recon_intra_rows, dim3( n * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n, mbh_max, ws );
   return static_cast<int>( hipGetLastError() );
 }
-int launch_loopfilter_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, void * stream )
+int launch_loopfilter_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, void * stream, bool pair_frames )
 {
-  hipLaunchKernelGGL( k_loopfilter_rows, dim3( n * mbh_max ), dim3( kLanes ), 0, static_cast<hipStream_t>( stream ), list, n, mbh_max, ws );
+  const int fpw = pair_frames ? 2 : 1;
+  hipLaunchKernelGGL( k_loopfilter_rows, dim3( ( ( n + fpw - 1 ) / fpw ) * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n, mbh_max, ws, fpw );
   return static_cast<int>( hipGetLastError() );
 }
 

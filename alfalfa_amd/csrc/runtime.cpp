@@ -71,6 +71,8 @@ struct aa_ctx {
   int device = 0;
   hipStream_t compute = nullptr, copy = nullptr;
   hipEvent_t upload_done = nullptr;
+  int live_streams = 0;        // aa_ctx_destroy is deferred until the last stream is gone (bindings may finalise in any order)
+  bool dying = false;
   bool profile = false;
   int schedule = 0;            // 0: row-pipelined persistent kernels (default), 1: one launch per 2:1 anti-diagonal
   aa_sync_ws * ws = nullptr;   // in-launch ordering state of the row-pipelined kernels
@@ -253,9 +255,15 @@ aa_status aa_ctx_create( int device, aa_ctx ** out )
   *out = ctx.release();
   return AA_OK;
 }
+static void ctx_free( aa_ctx * ctx );
 void aa_ctx_destroy( aa_ctx * ctx )
 {
   if ( !ctx ) return;
+  if ( ctx->live_streams > 0 ) { ctx->dying = true; return; }
+  ctx_free( ctx );
+}
+static void ctx_free( aa_ctx * ctx )
+{
   (void) hipSetDevice( ctx->device );
   (void) hipStreamSynchronize( ctx->compute ); (void) hipStreamSynchronize( ctx->copy );
   drain_profile( ctx );
@@ -270,7 +278,8 @@ static aa_status check_watchdog( aa_ctx * ctx )
   if ( !ctx->ws ) return AA_OK;
   int err = 0;
   HIP_TRY( hipMemcpy( &err, &ctx->ws->error, sizeof err, hipMemcpyDeviceToHost ) );
-  if ( err ) return fail( AA_ERR_HIP, "row-pipelined kernel: a bounded wait for the macroblock row above expired (output is not valid)" );
+  if ( err ) return fail( AA_ERR_HIP, std::string( "row-pipelined kernel " ) + ( err == 1 ? "k_recon_intra_rows" : "k_loopfilter_rows" )
+                                      + ": a bounded wait for the macroblock row above expired (output is not valid)" );
   return AA_OK;
 }
 aa_status aa_ctx_sync( aa_ctx * ctx )
@@ -321,6 +330,7 @@ aa_status aa_stream_create( aa_ctx * ctx, uint16_t width, uint16_t height, aa_st
   HIP_TRY( hipMemsetAsync( s->slots[slot].dev, 0, s->slot_bytes, ctx->compute ) );
   for ( int i = 0; i < 3; i++ ) { s->cur_ref_slot[i] = -1; s->cur_ref_frame[i] = -1; }
   for ( int i = 0; i < 3; i++ ) set_ref( s.get(), i, slot, -1 );
+  ctx->live_streams++;
   *out = s.release();
   return AA_OK;
 }
@@ -331,7 +341,9 @@ void aa_stream_destroy( aa_stream * s )
   (void) hipStreamSynchronize( s->ctx->compute ); (void) hipStreamSynchronize( s->ctx->copy );
   for ( auto & c : s->chunks ) { (void) hipHostFree( c.host ); (void) hipFree( c.dev ); }
   for ( auto & sl : s->slots ) (void) hipFree( sl.dev );
+  aa_ctx * ctx = s->ctx;
   delete s;
+  if ( --ctx->live_streams == 0 && ctx->dying ) ctx_free( ctx );
 }
 
 static uint8_t * slot_plane( aa_stream * s, int slot, int plane )
@@ -439,6 +451,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
   std::vector<const aa_dev_frame *> inter_jobs, intra_jobs, lf_jobs;
   std::vector<const FrameRec *> intra_recs;
   unsigned max_mbs = 0; int max_mbw = 0, max_mbh = 0;
+  bool same_geometry = true;     // two-frames-per-wave loop filter needs equal macroblock dimensions in the batch
   uint64_t total_mbs = 0;
   for ( int i = 0; i < n; i++ ) {
     aa_stream * s = streams[i];
@@ -455,6 +468,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
     if ( h.num_intra_mbs < h.num_macroblocks ) inter_jobs.push_back( r.dev_job );
     if ( h.has_intra_mb ) { intra_jobs.push_back( r.dev_job ); intra_recs.push_back( &r ); }
     if ( h.loop_filter_level ) lf_jobs.push_back( r.dev_job );
+    if ( i > 0 && ( h.mb_width != streams[0]->frames[frame_index[0]].hdr.mb_width || h.mb_height != streams[0]->frames[frame_index[0]].hdr.mb_height ) ) same_geometry = false;
     max_mbs = std::max<unsigned>( max_mbs, h.num_macroblocks );
     max_mbw = std::max<int>( max_mbw, h.mb_width ); max_mbh = std::max<int>( max_mbh, h.mb_height );
     total_mbs += h.num_macroblocks;
@@ -505,7 +519,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
                                  sizeof( aa_sync_ws ) - AA_SYNC_WS_ZERO_FROM + sizeof( int ) * size_t( cnt ) * max_mbh, ctx->compute ) );
         LaunchTimer t( ctx, kind );
         const int e = kind == 1 ? aa::launch_recon_intra_rows( list, cnt, max_mbh, ctx->ws, ctx->compute )
-                                : aa::launch_loopfilter_rows( list, cnt, max_mbh, ctx->ws, ctx->compute );
+                                : aa::launch_loopfilter_rows( list, cnt, max_mbh, ctx->ws, ctx->compute, same_geometry && cnt > 1 );
         if ( e ) return hip_fail( static_cast<hipError_t>( e ), kind == 1 ? "k_recon_intra_rows" : "k_loopfilter_rows" );
       }
       return AA_OK;

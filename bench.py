@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=96, help="independent streams per GPU")
     ap.add_argument("--frames", type=int, default=12, help="frames per stream")
     ap.add_argument("--schedule", default="rows", choices=["rows", "diagonal"])
+    ap.add_argument("--queues", type=int, default=1, help="independent HIP queues (contexts) the streams are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
@@ -74,9 +75,17 @@ def main():
     mbs_per_frame = ((width + 15) // 16) * ((height + 15) // 16)
     mbs_per_step = S * F * mbs_per_frame
 
-    ctx = aa.Context(local_rank)
-    ctx.set_schedule(args.schedule)
-    decs = [aa.Decoder(ctx, width, height) for _ in range(S)]
+    Q = max(1, min(args.queues, S))
+    ctxs = [aa.Context(local_rank) for _ in range(Q)]
+    for c in ctxs:
+        c.set_schedule(args.schedule)
+    ctx = ctxs[0]
+    decs = [aa.Decoder(ctxs[i % Q], width, height) for i in range(S)]
+    groups = [[d for i, d in enumerate(decs) if i % Q == q] for q in range(Q)]
+
+    def sync_all():
+        for c in ctxs:
+            c.sync()
 
     # ---- multi-GPU only: one-shot entry-state hand-off (outside the timed region).  Rank 0 decodes the head (key frame)
     # of a shared GOP; its DecoderState blob and reference raster are broadcast (RCCL over xGMI) and every rank continues
@@ -133,21 +142,25 @@ def main():
     compressed_bytes = sum(len(fr) for st in streams for fr in st)
 
     # ---- H2D of the parsed records on the copy stream ----
-    ctx.sync()
+    sync_all()
     t0 = time.perf_counter()
     for d in decs:
         d.upload()
-    ctx.sync()
+    sync_all()
     t_h2d = time.perf_counter() - t0
 
-    def one_step():
+    def one_pass():
         for f in range(F):
-            ctx.decode_batch(decs, [f] * S)
+            for q in range(Q):
+                ctxs[q].decode_batch(groups[q], [f] * len(groups[q]))
+
+    def one_step():
+        one_pass()
         for d in decs:
             d.rewind()
 
     def barrier():
-        ctx.sync()
+        sync_all()
         if dist is not None:
             dist.barrier()
 
@@ -157,7 +170,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-    ctx.sync()
+    sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
@@ -172,12 +185,13 @@ def main():
     roofline = None
     kstats = None
     if not args.no_profile_pass:
-        ctx.profile(True)
-        ctx.kernel_stats(reset=True)
-        for f in range(F):
-            ctx.decode_batch(decs, [f] * S)
-        kstats = ctx.kernel_stats(reset=True)
-        ctx.profile(False)
+        for c in ctxs:
+            c.profile(True); c.kernel_stats(reset=True)
+        one_pass()
+        kstats = None
+        for c in ctxs:
+            st = c.kernel_stats(reset=True); c.profile(False)
+            kstats = st if kstats is None else {k: kstats[k] + st[k] for k in st}
         for d in decs:
             d.rewind()
         names = ("recon_inter", "recon_intra", "loopfilter")
@@ -222,8 +236,7 @@ def main():
     if rank == 0 and not args.no_verify:
         ref_decode = os.path.join(ROOT, "oracle", "_ref", "ref_decode")
         if os.path.exists(ref_decode):
-            for f in range(F):
-                ctx.decode_batch(decs, [f] * S)
+            one_pass()
             raw = os.path.join(workload.cache_dir(), "bench_verify_%d.raw" % os.getpid())
             subprocess.run([ref_decode, paths[0], raw], check=True, stdout=subprocess.DEVNULL)
             ref = open(raw, "rb").read(); os.unlink(raw)
@@ -242,7 +255,7 @@ def main():
                                    "parsed records resident in HBM" % (args.config, S, width, height, F, F - 1,
                                                                         workload.CONFIGS[args.config][3], workload.CONFIGS[args.config][4]),
                        "streams_per_gpu": S, "frames_per_stream": F, "macroblocks_per_step_per_gpu": mbs_per_step,
-                       "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective", "schedule": args.schedule},
+                       "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective", "schedule": args.schedule, "queues": Q},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "host": {"parse_mb_per_s_per_core": round(mbs_per_step / sum(per_stream_parse_s), 1),
                      "parse_threads": nthreads, "parse_wall_s": round(t_parse_wall, 3),

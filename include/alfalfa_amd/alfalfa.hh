@@ -1,0 +1,404 @@
+// alfalfa.hh -- C++ mirror of the reference's decoder surface for THIS path, over the C ABI (alfalfa_amd.h).
+//
+// Same class and method names as excamera/alfalfa so that callers compile against either implementation:
+//   exceptions  Invalid / Unsupported / LogicError                     (util/exception.hh:76-98)
+//   Optional<T> initialized() / get() / get_or()                       (util/optional.hh)
+//   Chunk       non-owning {buffer,size} view, bounds-checked          (util/chunk.hh:38-143)
+//   IVF         container index: width/height/frame_count/frame(i)     (util/ivf.hh, ivf.cc:36-82)
+//   VP8Raster   Y()/U()/V().at(col,row), width/height (padded), display_width/height, dump(), display_rectangle_as_planar()
+//                                                                      (util/raster.hh:48-90, decoder/vp8_raster.hh:53-316)
+//   RasterHandle  get() / operator const VP8Raster & -- lazy, cached host copy of a device-resident raster
+//                                                                      (decoder/raster_handle.hh:77-123)
+//   References  last / golden / alternative                            (decoder/decoder.hh:123-149)
+//   Decoder     Decoder(width,height), get_frame_output, parse_and_decode_frame, get_references, example_raster,
+//               get_width/get_height                                   (decoder/decoder.hh:244-300)
+//   FramePlayer / FilePlayer (= Player)  decode / advance / eof / cur_frame_no   (decoder/player.hh:40-97)
+// What is NOT mirrored (host-side plumbing outside the hot path): Frame<> object graphs
+// (parse_frame<F>/decode_frame<F> are replaced by get_frame_output), boost-based hash()/minihash, state (de)serialisation.
+//
+// Everything lives in namespace alfalfa_amd; define ALFALFA_AMD_GLOBAL_NAMES before including to also export the
+// names into the global namespace (drop-in for code written against the reference headers).
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+extern "C" {
+#include "../alfalfa_amd.h"
+}
+
+namespace alfalfa_amd {
+
+// ---------------------------------------------------------------- exceptions (what() strings as in the reference)
+class internal_error : public std::runtime_error
+{
+public:
+  internal_error( const std::string & attempt, const std::string & error ) : std::runtime_error( attempt + ": " + error ) {}
+  explicit internal_error( const std::string & whole ) : std::runtime_error( whole ) {}
+};
+class Invalid : public internal_error
+{
+public:
+  explicit Invalid( const std::string & e ) : internal_error( "invalid bitstream", e ) {}
+  Invalid( const std::string & whole, int ) : internal_error( whole ) {}
+};
+class Unsupported : public internal_error
+{
+public:
+  explicit Unsupported( const std::string & e ) : internal_error( "unsupported bitstream", e ) {}
+  Unsupported( const std::string & whole, int ) : internal_error( whole ) {}
+};
+class LogicError : public internal_error
+{
+public:
+  LogicError() : internal_error( "internal error", "logic error" ) {}
+};
+class DeviceError : public std::runtime_error     // HIP failure or no GPU: the path has no CPU fallback
+{
+public:
+  explicit DeviceError( const std::string & e ) : std::runtime_error( e ) {}
+};
+
+inline void check( const aa_status s )
+{
+  if ( s == AA_OK ) return;
+  const std::string msg = aa_last_error();     // already carries the reference's "invalid bitstream: ..." prefix
+  switch ( s ) {
+  case AA_ERR_INVALID: throw Invalid( msg, 0 );
+  case AA_ERR_UNSUPPORTED: throw Unsupported( msg, 0 );
+  case AA_ERR_OUT_OF_RANGE: throw std::out_of_range( msg );
+  case AA_ERR_LOGIC: throw LogicError();
+  case AA_ERR_ARGUMENT: throw std::invalid_argument( msg );
+  default: throw DeviceError( msg );
+  }
+}
+
+// ---------------------------------------------------------------- Optional
+template <class T>
+class Optional
+{
+  bool initialized_ = false;
+  T value_ {};
+public:
+  Optional() = default;
+  Optional( const T & v ) : initialized_( true ), value_( v ) {}
+  Optional( const bool init, const T & v ) : initialized_( init ), value_( init ? v : T() ) {}
+  bool initialized() const { return initialized_; }
+  const T & get() const { if ( !initialized_ ) throw std::runtime_error( "attempt to get uninitialized Optional" ); return value_; }
+  const T & get_or( const T & fallback ) const { return initialized_ ? value_ : fallback; }
+  void clear() { initialized_ = false; value_ = T(); }
+};
+template <class T> Optional<T> make_optional( const bool init, const T & v ) { return Optional<T>( init, v ); }
+
+// ---------------------------------------------------------------- Chunk
+class Chunk
+{
+  const uint8_t * buffer_;
+  uint64_t size_;
+  void bounds_check( const uint64_t length ) const { if ( length > size_ ) throw std::out_of_range( "attempted to read past end of chunk" ); }
+public:
+  Chunk( const uint8_t * buffer, const uint64_t size ) : buffer_( buffer ), size_( size ) {}
+  explicit Chunk( const std::string & s ) : buffer_( reinterpret_cast<const uint8_t *>( s.data() ) ), size_( s.size() ) {}
+  explicit Chunk( const std::vector<uint8_t> & v ) : buffer_( v.data() ), size_( v.size() ) {}
+  const uint8_t * buffer() const { return buffer_; }
+  const uint64_t & size() const { return size_; }
+  Chunk operator()( const uint64_t offset ) const { return operator()( offset, size_ - offset ); }
+  Chunk operator()( const uint64_t offset, const uint64_t length ) const { bounds_check( offset ); bounds_check( offset + length ); return Chunk( buffer_ + offset, length ); }
+  std::string to_string() const { return std::string( reinterpret_cast<const char *>( buffer_ ), size_ ); }
+  const uint8_t & octet() const { bounds_check( 1 ); return *buffer_; }
+  uint16_t le16() const { bounds_check( 2 ); return static_cast<uint16_t>( buffer_[0] | ( buffer_[1] << 8 ) ); }
+  uint64_t le32() const { bounds_check( 4 ); return uint64_t( buffer_[0] ) | ( uint64_t( buffer_[1] ) << 8 ) | ( uint64_t( buffer_[2] ) << 16 ) | ( uint64_t( buffer_[3] ) << 24 ); }
+  uint64_t bits( const uint64_t bit_offset, const uint64_t bit_length ) const
+  {
+    const uint64_t byte_len = 1 + ( bit_offset + bit_length - 1 ) / 8;
+    bounds_check( byte_len );
+    if ( byte_len > 8 || bit_length > 63 ) throw std::out_of_range( "bit offset and length not supported" );
+    uint64_t val = 0;
+    for ( uint64_t i = 0; i < byte_len; i++ ) val |= uint64_t( buffer_[i] ) << ( i * 8 );
+    return ( val >> bit_offset ) & ( ( uint64_t( 1 ) << bit_length ) - 1 );
+  }
+};
+
+// ---------------------------------------------------------------- IVF
+class IVF
+{
+  std::vector<uint8_t> data_;     // the reference mmaps; a host read is equivalent for callers
+  std::string fourcc_;
+  uint16_t width_ = 0, height_ = 0;
+  uint32_t frame_rate_ = 0, time_scale_ = 0, frame_count_ = 0, expected_decoder_minihash_ = 0;
+  std::vector<std::pair<uint64_t, uint32_t>> frame_index_;
+public:
+  static constexpr int supported_header_len = 32;
+  static constexpr int frame_header_len = 12;
+  explicit IVF( const std::string & filename )
+  {
+    std::ifstream in( filename, std::ios::binary );
+    if ( !in ) throw std::runtime_error( "open (" + filename + "): cannot open file" );
+    data_.assign( std::istreambuf_iterator<char>( in ), std::istreambuf_iterator<char>() );
+    try {
+      const Chunk file( data_.data(), data_.size() );
+      const Chunk header = file( 0, supported_header_len );
+      fourcc_ = header( 8, 4 ).to_string();
+      width_ = header( 12, 2 ).le16(); height_ = header( 14, 2 ).le16();
+      frame_rate_ = static_cast<uint32_t>( header( 16, 4 ).le32() ); time_scale_ = static_cast<uint32_t>( header( 20, 4 ).le32() );
+      frame_count_ = static_cast<uint32_t>( header( 24, 4 ).le32() ); expected_decoder_minihash_ = static_cast<uint32_t>( header( 28, 4 ).le32() );
+      if ( header( 0, 4 ).to_string() != "DKIF" ) throw Invalid( "missing IVF file header" );
+      if ( header( 4, 2 ).le16() != 0 ) throw Unsupported( "not an IVF version 0 file" );
+      if ( header( 6, 2 ).le16() != supported_header_len ) throw Unsupported( "unsupported IVF header length" );
+      frame_index_.reserve( frame_count_ );
+      uint64_t position = supported_header_len;
+      for ( uint32_t i = 0; i < frame_count_; i++ ) {
+        const uint32_t frame_len = static_cast<uint32_t>( file( position, frame_header_len ).le32() );
+        (void) file( position + frame_header_len, frame_len );
+        frame_index_.emplace_back( position + frame_header_len, frame_len );
+        position += frame_header_len + frame_len;
+      }
+    } catch ( const std::out_of_range & ) {
+      throw Invalid( "IVF file truncated" );
+    }
+  }
+  const std::string & fourcc() const { return fourcc_; }
+  uint16_t width() const { return width_; }
+  uint16_t height() const { return height_; }
+  uint32_t frame_rate() const { return frame_rate_; }
+  uint32_t time_scale() const { return time_scale_; }
+  uint32_t frame_count() const { return frame_count_; }
+  Chunk frame( const uint32_t & index ) const { const auto & e = frame_index_.at( index ); return Chunk( data_.data() + e.first, e.second ); }
+  size_t size() const { return data_.size(); }
+  uint32_t expected_decoder_minihash() const { return expected_decoder_minihash_; }
+};
+
+// ---------------------------------------------------------------- rasters
+class Plane     // TwoD<uint8_t> as seen by raster users: at(col,row), width(), height()
+{
+  unsigned width_, height_;
+  std::vector<uint8_t> storage_;
+public:
+  Plane( const unsigned w, const unsigned h ) : width_( w ), height_( h ), storage_( size_t( w ) * h ) {}
+  uint8_t & at( const unsigned column, const unsigned row ) { return storage_[size_t( row ) * width_ + column]; }
+  const uint8_t & at( const unsigned column, const unsigned row ) const { return storage_[size_t( row ) * width_ + column]; }
+  unsigned width() const { return width_; }
+  unsigned height() const { return height_; }
+  std::vector<uint8_t>::const_iterator begin() const { return storage_.begin(); }
+  std::vector<uint8_t>::const_iterator end() const { return storage_.end(); }
+  bool operator==( const Plane & o ) const { return width_ == o.width_ && height_ == o.height_ && storage_ == o.storage_; }
+};
+
+class VP8Raster
+{
+  uint16_t display_width_, display_height_, width_, height_;
+  Plane Y_, U_, V_;
+public:
+  static unsigned macroblock_dimension( const unsigned num ) { return ( num + 15 ) / 16; }
+  VP8Raster( const unsigned display_width, const unsigned display_height )
+    : display_width_( display_width ), display_height_( display_height ),
+      width_( 16 * macroblock_dimension( display_width ) ), height_( 16 * macroblock_dimension( display_height ) ),
+      Y_( width_, height_ ), U_( width_ / 2, height_ / 2 ), V_( width_ / 2, height_ / 2 ) {}
+  Plane & Y() { return Y_; }
+  Plane & U() { return U_; }
+  Plane & V() { return V_; }
+  const Plane & Y() const { return Y_; }
+  const Plane & U() const { return U_; }
+  const Plane & V() const { return V_; }
+  uint16_t width() const { return width_; }
+  uint16_t height() const { return height_; }
+  uint16_t display_width() const { return display_width_; }
+  uint16_t display_height() const { return display_height_; }
+  uint16_t chroma_display_width() const { return ( 1 + display_width_ ) / 2; }
+  uint16_t chroma_display_height() const { return ( 1 + display_height_ ) / 2; }
+  bool operator==( const VP8Raster & o ) const { return Y_ == o.Y_ && U_ == o.U_ && V_ == o.V_; }
+  bool operator!=( const VP8Raster & o ) const { return !operator==( o ); }
+  std::vector<Chunk> display_rectangle_as_planar() const     // raster.cc:85-104
+  {
+    std::vector<Chunk> ret;
+    for ( uint16_t row = 0; row < display_height(); row++ ) ret.emplace_back( &Y().at( 0, row ), display_width() );
+    for ( uint16_t row = 0; row < chroma_display_height(); row++ ) ret.emplace_back( &U().at( 0, row ), chroma_display_width() );
+    for ( uint16_t row = 0; row < chroma_display_height(); row++ ) ret.emplace_back( &V().at( 0, row ), chroma_display_width() );
+    return ret;
+  }
+  void dump( FILE * file ) const                              // raster.cc:107-114
+  {
+    for ( const auto & chunk : display_rectangle_as_planar() )
+      if ( 1 != fwrite( chunk.buffer(), chunk.size(), 1, file ) ) throw std::runtime_error( "fwrite returned short write" );
+  }
+};
+
+// One HIP device context per process by default (device = $ALFALFA_AMD_DEVICE or 0), so that the reference's
+// `Decoder( width, height )` signature keeps working unchanged.
+class GpuContext
+{
+  aa_ctx * ctx_ = nullptr;
+public:
+  explicit GpuContext( const int device ) { check( aa_ctx_create( device, &ctx_ ) ); }
+  ~GpuContext() { aa_ctx_destroy( ctx_ ); }
+  GpuContext( const GpuContext & ) = delete;
+  GpuContext & operator=( const GpuContext & ) = delete;
+  aa_ctx * get() const { return ctx_; }
+  void sync() const { check( aa_ctx_sync( ctx_ ) ); }
+  static const std::shared_ptr<GpuContext> & process_default()
+  {
+    static const std::shared_ptr<GpuContext> ctx = [] {
+      const char * e = std::getenv( "ALFALFA_AMD_DEVICE" );
+      return std::make_shared<GpuContext>( e ? std::atoi( e ) : 0 );
+    }();
+    return ctx;
+  }
+};
+
+namespace detail {
+struct StreamOwner     // shared by a Decoder and every RasterHandle it handed out (rasters outlive the Decoder object)
+{
+  std::shared_ptr<GpuContext> ctx;
+  aa_stream * stream = nullptr;
+  uint16_t width, height;
+  StreamOwner( std::shared_ptr<GpuContext> c, const uint16_t w, const uint16_t h ) : ctx( std::move( c ) ), width( w ), height( h )
+  { check( aa_stream_create( ctx->get(), w, h, &stream ) ); }
+  ~StreamOwner() { aa_stream_destroy( stream ); }
+  StreamOwner( const StreamOwner & ) = delete;
+  StreamOwner & operator=( const StreamOwner & ) = delete;
+};
+struct RasterState
+{
+  std::shared_ptr<StreamOwner> owner;
+  int frame_index;                         // -1: the blank initial reference
+  std::unique_ptr<VP8Raster> host;         // filled on first get()
+};
+}
+
+class RasterHandle
+{
+  std::shared_ptr<detail::RasterState> state_;
+public:
+  RasterHandle() = default;
+  RasterHandle( std::shared_ptr<detail::StreamOwner> owner, const int frame_index )
+    : state_( std::make_shared<detail::RasterState>() ) { state_->owner = std::move( owner ); state_->frame_index = frame_index; }
+  // lazy D2H: the raster stays in HBM until somebody looks at the pixels (raster_handle.hh:100-106 `get()`)
+  const VP8Raster & get() const
+  {
+    if ( !state_ ) throw LogicError();
+    if ( !state_->host ) {
+      auto r = std::unique_ptr<VP8Raster>( new VP8Raster( state_->owner->width, state_->owner->height ) );
+      if ( state_->frame_index >= 0 )
+        check( aa_stream_download( state_->owner->stream, state_->frame_index, &r->Y().at( 0, 0 ), &r->U().at( 0, 0 ), &r->V().at( 0, 0 ) ) );
+      state_->host = std::move( r );
+    }
+    return *state_->host;
+  }
+  operator const VP8Raster & () const { return get(); }
+  int frame_index() const { return state_ ? state_->frame_index : -1; }
+  bool operator==( const RasterHandle & o ) const { return get() == o.get(); }
+  bool operator!=( const RasterHandle & o ) const { return !operator==( o ); }
+};
+
+struct References
+{
+  RasterHandle last, golden, alternative;
+};
+
+class Decoder
+{
+  std::shared_ptr<detail::StreamOwner> owner_;
+  std::vector<RasterHandle> handles_;      // frame index -> handle (so References can name earlier frames)
+  RasterHandle handle_for( const int frame_index ) const
+  {
+    if ( frame_index < 0 ) return RasterHandle( owner_, -1 );
+    return handles_.at( frame_index );
+  }
+public:
+  Decoder( const uint16_t width, const uint16_t height ) : Decoder( GpuContext::process_default(), width, height ) {}
+  Decoder( std::shared_ptr<GpuContext> ctx, const uint16_t width, const uint16_t height )
+    : owner_( std::make_shared<detail::StreamOwner>( std::move( ctx ), width, height ) ) {}
+
+  uint16_t get_width() const { return owner_->width; }
+  uint16_t get_height() const { return owner_->height; }
+
+  // Decoder::get_frame_output (decoder.cc:125-135): (shown, raster) -- hidden frames still update the references
+  std::pair<bool, RasterHandle> get_frame_output( const Chunk & compressed_frame )
+  {
+    int index = -1, shown = 0;
+    check( aa_stream_decode( owner_->stream, compressed_frame.buffer(), compressed_frame.size(), &index, &shown ) );
+    if ( static_cast<int>( handles_.size() ) <= index ) handles_.resize( index + 1 );
+    handles_[index] = RasterHandle( owner_, index );
+    return std::make_pair( shown != 0, handles_[index] );
+  }
+  Optional<RasterHandle> parse_and_decode_frame( const Chunk & compressed_frame )   // decoder.cc:137-141
+  {
+    const std::pair<bool, RasterHandle> out = get_frame_output( compressed_frame );
+    return make_optional( out.first, out.second );
+  }
+  References get_references() const
+  {
+    int l = -1, g = -1, a = -1;
+    check( aa_stream_references( owner_->stream, &l, &g, &a ) );
+    return References { handle_for( l ), handle_for( g ), handle_for( a ) };
+  }
+  const VP8Raster & example_raster() const { example_ = get_references().last; return example_.get(); }
+  aa_stream * native_handle() const { return owner_->stream; }
+private:
+  mutable RasterHandle example_;
+};
+
+class FramePlayer
+{
+  uint16_t width_, height_;
+protected:
+  Decoder decoder_;
+public:
+  FramePlayer( const uint16_t width, const uint16_t height ) : width_( width ), height_( height ), decoder_( width, height ) {}
+  Optional<RasterHandle> decode( const Chunk & chunk ) { return decoder_.parse_and_decode_frame( chunk ); }   // player.cc:60-63
+  const VP8Raster & example_raster() const { return decoder_.example_raster(); }
+  uint16_t width() const { return width_; }
+  uint16_t height() const { return height_; }
+  const Decoder & current_decoder() const { return decoder_; }
+  References current_references() const { return decoder_.get_references(); }
+};
+
+class FilePlayer : public FramePlayer
+{
+  IVF file_;
+  unsigned int frame_no_ = 0;
+  std::string filename_;
+  FilePlayer( const std::string & filename, IVF && file )
+    : FramePlayer( file.width(), file.height() ), file_( std::move( file ) ), filename_( filename )
+  {
+    if ( file_.fourcc() != "VP80" ) throw Unsupported( "not a VP8 file" );
+    while ( frame_no_ < file_.frame_count() ) {          // start at the first key frame (player.cc:96-105)
+      if ( !( file_.frame( frame_no_ ).octet() & 1 ) ) break;
+      frame_no_++;
+    }
+  }
+public:
+  explicit FilePlayer( const std::string & filename ) : FilePlayer( filename, IVF( filename ) ) {}
+  RasterHandle advance()                                  // player.cc:134-144
+  {
+    while ( !eof() ) {
+      Optional<RasterHandle> raster = decode( file_.frame( frame_no_++ ) );
+      if ( raster.initialized() ) return raster.get();
+    }
+    throw Unsupported( "hidden frames at end of file" );
+  }
+  bool eof() const { return frame_no_ == file_.frame_count(); }
+  unsigned int cur_frame_no() const { return frame_no_ - 1; }
+  long unsigned int original_size() const { return file_.frame( cur_frame_no() ).size(); }
+};
+
+using Player = FilePlayer;
+
+inline void print_exception( const char * argv0, const std::exception & e ) { std::fprintf( stderr, "%s: %s\n", argv0, e.what() ); }
+
+} // namespace alfalfa_amd
+
+#ifdef ALFALFA_AMD_GLOBAL_NAMES
+using alfalfa_amd::Chunk; using alfalfa_amd::Decoder; using alfalfa_amd::FilePlayer; using alfalfa_amd::FramePlayer;
+using alfalfa_amd::Invalid; using alfalfa_amd::IVF; using alfalfa_amd::LogicError; using alfalfa_amd::Optional;
+using alfalfa_amd::Player; using alfalfa_amd::RasterHandle; using alfalfa_amd::References; using alfalfa_amd::Unsupported;
+using alfalfa_amd::VP8Raster; using alfalfa_amd::print_exception;
+#endif
