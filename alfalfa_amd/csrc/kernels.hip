@@ -333,11 +333,12 @@ struct alignas( 16 ) IntraLds {
 // (macroblock.cc:523-551) with VP8Raster::Block<N>::predictors (prediction.cc:99-167).
 // kShared: neighbours may have been produced by another workgroup of this launch (row-pipelined schedule).
 template <bool kShared>
-__device__ void intra_macroblock( const aa_dev_frame & f, const aa_mb_info & mb, const int col, const int row, IntraLds & L, const int lane )
+__device__ void intra_macroblock( const aa_dev_frame & f, const aa_mb_info & mb, const int col, const int row, IntraLds & L, const int lane,
+                                  const bool residual_ready = false )
 {
   const int pw = f.mbw * 16, cw = pw >> 1;
   const bool has_res = mb.flags & AA_MB_HAS_NONZERO;
-  if ( has_res ) compute_residual( mb, f, L.r, lane );
+  if ( has_res && !residual_ready ) compute_residual( mb, f, L.r, lane );
 
   const int x0 = col * 16, y0 = row * 16;
   const uint8_t * Y = f.cur[0];
@@ -471,7 +472,7 @@ __device__ __forceinline__ void wait_progress( const int * progress, const int n
 {
   int spins = 0;
   while ( __hip_atomic_load( progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) < need ) {
-    __builtin_amdgcn_s_sleep( 2 );
+    __builtin_amdgcn_s_sleep( 8 );
     ++spins;
     // watchdog: sticky error word; once any wait has expired every other wait gives up within 1024 polls
     if ( ( spins & 1023 ) == 0 && __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
@@ -500,10 +501,13 @@ __global__ __launch_bounds__( kLanes ) void k_recon_intra_rows( const aa_frame_l
       while ( m ) {
         const int col = w * 64 + __ffsll( static_cast<long long>( m ) ) - 1;
         m &= m - 1;
-        // everything left of `col` in this row is final; then wait for the row above
+        // everything left of `col` in this row is final
         publish_progress( &progress[row], col, lane );
+        // the residual (dequant, iWHT, IDCTs) does not depend on any neighbour: compute it BEFORE waiting for the row above
+        const aa_mb_info & mb = f.mbs[row * mbw + col];
+        if ( mb.flags & AA_MB_HAS_NONZERO ) compute_residual( mb, f, L.r, lane );
         if ( row > 0 ) wait_progress( &progress[row - 1], min( col + 2, mbw ), ws, 1 );
-        intra_macroblock<true>( f, f.mbs[row * mbw + col], col, row, L, lane );
+        intra_macroblock<true>( f, mb, col, row, L, lane, true );
       }
     }
   }
@@ -776,7 +780,7 @@ __global__ __launch_bounds__( kLanes ) void k_loopfilter_rows( const aa_frame_li
     if ( row > 0 ) {
       int spins = 0;
       while ( !__all( seen >= need ) ) {
-        __builtin_amdgcn_s_sleep( 1 );
+        __builtin_amdgcn_s_sleep( 8 );
         if ( seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
         ++spins;
         if ( ( spins & 1023 ) == 0 && __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;

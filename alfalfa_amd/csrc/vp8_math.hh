@@ -181,12 +181,27 @@ AA_HD LfParams lf_params( int level, int sharpness, bool key_frame )
   return p;
 }
 
+// |a - b| of two pixel values (0..255): one v_sad_u8 on the device
+AA_HD int absdiff_u8( int a, int b )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+  return static_cast<int>( __builtin_amdgcn_sad_u8( static_cast<unsigned>( a ), static_cast<unsigned>( b ), 0u ) );
+#else
+  return iabs( a - b );
+#endif
+}
+AA_HD int imax( int a, int b ) { return a > b ? a : b; }
+
+// vp8_filter_mask / vp8_hevmask.  Written without short-circuit operators on purpose: `||` chains compile to a cascade
+// of exec-mask branches per edge on gfx950; max-of-differences is straight-line VALU (v_sad_u8 + v_max3).
 AA_HD bool lf_mask( int limit, int blimit, int p3, int p2, int p1, int p0, int q0, int q1, int q2, int q3 )
 {
-  return !( iabs( p3 - p2 ) > limit || iabs( p2 - p1 ) > limit || iabs( p1 - p0 ) > limit || iabs( q1 - q0 ) > limit
-            || iabs( q2 - q1 ) > limit || iabs( q3 - q2 ) > limit || ( iabs( p0 - q0 ) * 2 + iabs( p1 - q1 ) / 2 ) > blimit );
+  const int m = imax( imax( imax( absdiff_u8( p3, p2 ), absdiff_u8( p2, p1 ) ), imax( absdiff_u8( p1, p0 ), absdiff_u8( q1, q0 ) ) ),
+                      imax( absdiff_u8( q2, q1 ), absdiff_u8( q3, q2 ) ) );
+  const int e = absdiff_u8( p0, q0 ) * 2 + ( absdiff_u8( p1, q1 ) >> 1 );
+  return ( static_cast<int>( m <= limit ) & static_cast<int>( e <= blimit ) ) != 0;
 }
-AA_HD bool lf_hev( int thresh, int p1, int p0, int q0, int q1 ) { return iabs( p1 - p0 ) > thresh || iabs( q1 - q0 ) > thresh; }
+AA_HD bool lf_hev( int thresh, int p1, int p0, int q0, int q1 ) { return imax( absdiff_u8( p1, p0 ), absdiff_u8( q1, q0 ) ) > thresh; }
 
 // vp8_filter (sub-block edges): p[0..3] = p1,p0,q0,q1 in place
 AA_HD void lf_subblock( bool mask, bool hev, int & p1, int & p0, int & q0, int & q1 )

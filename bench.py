@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="1080p_inter_lf")
-    ap.add_argument("--streams", type=int, default=96, help="independent streams per GPU")
+    ap.add_argument("--streams", type=int, default=120, help="independent streams per GPU")
     ap.add_argument("--frames", type=int, default=12, help="frames per stream")
     ap.add_argument("--schedule", default="rows", choices=["rows", "diagonal"])
     ap.add_argument("--queues", type=int, default=1, help="independent HIP queues (contexts) the streams are spread over")

@@ -1,3 +1,7 @@
+// Hardware probe (gfx950): checks v_alignbyte / v_dot4_i32_i8 primitives and the packed six-tap routine of kernels.hip against a
+// scalar host model on random inputs.  This is how the hipcc 7.2 issue around v_ashr_pk_u8_i32 (a pair of clamp255(x >> 7)
+// folded into one instruction whose upper 16 result bits are then assumed zero) was isolated; see sixtap_x4 in kernels.hip.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/hw_probe_sixtap.hip -o /tmp/probe && /tmp/probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
