@@ -30,6 +30,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 # + reconstruction write 384 (k_recon_inter) ; loop filter read+write 768 (k_loopfilter)
 BYTES_PER_MB = {"recon_inter": 80 + 800 + 384 + 384, "recon_intra": 80 + 800 + 384, "loopfilter": 768}
 PATH_BYTES_PER_MB = 2416       # inter + deblock, whole path
+# HBM bytes per macroblock measured with rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KiB -> bytes, per launch / MBs per launch),
+# profiles/r01c_final.md; used for roofline.traffic (counters cannot be read from inside this process)
+PMC_TRAFFIC_BYTES_PER_MB = {"recon_inter": 497 + 384, "loopfilter": 1909 + 2099, "recon_intra": None}
+KERNEL_NAMES = {"rows": {"recon_inter": "k_recon_inter", "recon_intra": "k_recon_intra_rows", "loopfilter": "k_loopfilter_rows"},
+                "diagonal": {"recon_inter": "k_recon_inter", "recon_intra": "k_recon_intra", "loopfilter": "k_loopfilter"}}
 
 
 def parse_args():
@@ -140,6 +145,12 @@ def main():
         per_stream_parse_s = list(ex.map(parse_stream, range(S)))
     t_parse_wall = time.perf_counter() - t0
     compressed_bytes = sum(len(fr) for st in streams for fr in st)
+    # the parser alone (no pinned/device allocation, one thread): the serial BoolDecoder rate per host core
+    pp = aa.Parser(width, height)
+    t0 = time.perf_counter()
+    for fr in streams[0]:
+        pp.parse(fr)
+    parser_only = len(streams[0]) * mbs_per_frame / (time.perf_counter() - t0)
 
     # ---- H2D of the parsed records on the copy stream ----
     sync_all()
@@ -203,8 +214,11 @@ def main():
         bytes_per_launch = BYTES_PER_MB[dom] * mbs_total / launches
         avg_ms = total_ms / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        traffic = PMC_TRAFFIC_BYTES_PER_MB.get(dom) if args.schedule == "rows" else None
+        roofline = {"bound": "hbm", "kernel": KERNEL_NAMES[args.schedule][dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": None if traffic is None else round(traffic * mbs_total / launches),
+                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r01c_final.md (bytes per launch)",
                     "avg_launch_us": round(avg_ms * 1e3, 3), "launches_per_step": launches,
                     "algorithmic_bytes_per_launch": round(bytes_per_launch),
                     "path_frac_of_hbm_peak": round(value / world * PATH_BYTES_PER_MB / (HBM_PEAK_GBS * 1e9), 5)}
@@ -257,8 +271,10 @@ def main():
                        "streams_per_gpu": S, "frames_per_stream": F, "macroblocks_per_step_per_gpu": mbs_per_step,
                        "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective", "schedule": args.schedule, "queues": Q},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
-            "host": {"parse_mb_per_s_per_core": round(mbs_per_step / sum(per_stream_parse_s), 1),
-                     "parse_threads": nthreads, "parse_wall_s": round(t_parse_wall, 3),
+            "host": {"parser_mb_per_s_per_core": round(parser_only, 1),
+                     "parse_into_pinned_staging": {"threads": nthreads, "wall_s": round(t_parse_wall, 3),
+                                                   "mb_per_s_aggregate": round(mbs_per_step / t_parse_wall, 1),
+                                                   "note": "includes first-touch hipHostMalloc/hipMalloc of the frame store and raster slots"},
                      "h2d_s": round(t_h2d, 3), "stream_generation_s": round(t_gen, 1)},
             "kernel_stats": kstats, "verified_bit_exact_vs_reference": verified, "entry_state_handoff": handoff,
         }
