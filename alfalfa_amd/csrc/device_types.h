@@ -32,7 +32,7 @@ struct aa_sync_ws {
 };
 #define AA_SYNC_WS_ZERO_FROM 16   // byte offset of `ticket`
 
-#define AA_MAX_BATCH 256       // frames per launch: kernel argument = 256 pointers (2 KiB) passed by value
+#define AA_MAX_BATCH 120       // frames per launch and kind: kernel argument = 120 pointers (960 B) passed by value
 
 struct aa_frame_list {
   const aa_dev_frame * f[AA_MAX_BATCH];

@@ -141,16 +141,14 @@ struct alignas( 16 ) InterLds {     // ~5 KB: 32 single-wave workgroups fit one 
   };
 };
 
-// grid.x = macroblock (XCD-aware order), grid.y = frame in batch
-__global__ __launch_bounds__( kLanes ) void k_recon_inter( const aa_frame_list list, const unsigned max_mbs )
+// One inter macroblock by one wave.  `bx` = workgroup index within the frame's run of blocks (XCD-aware order).
+__device__ __forceinline__ void recon_inter_body( const aa_dev_frame & f, const unsigned bx, const unsigned max_mbs, InterLds & L )
 {
-  __shared__ InterLds L;
-  const aa_dev_frame & f = *list.f[blockIdx.y];
   const unsigned total = static_cast<unsigned>( f.mbw ) * f.mbh;
   // workgroup b lands on XCD b % 8 (each XCD has its own L2): give each XCD a contiguous run of macroblocks so that
   // horizontally adjacent MBs, which share reference-window cache lines and output lines, hit the same L2.
   const unsigned chunk = ( max_mbs + 7u ) >> 3;
-  const unsigned mi = ( blockIdx.x & 7u ) * chunk + ( blockIdx.x >> 3 );
+  const unsigned mi = ( bx & 7u ) * chunk + ( bx >> 3 );
   if ( mi >= total ) return;
   const aa_mb_info & mb = f.mbs[mi];
   if ( !( mb.flags & AA_MB_INTER ) ) return;
@@ -302,6 +300,13 @@ __global__ __launch_bounds__( kLanes ) void k_recon_inter( const aa_frame_list l
     }
     *reinterpret_cast<uint32_t *>( f.cur[1 + pl] + static_cast<size_t>( row * 8 + r ) * cw + col * 8 + c4 ) = out;
   }
+}
+
+// grid.x = macroblock (XCD-aware order), grid.y = frame in batch
+__global__ __launch_bounds__( kLanes ) void k_recon_inter( const aa_frame_list list, const unsigned max_mbs )
+{
+  __shared__ InterLds L;
+  recon_inter_body( *list.f[blockIdx.y], blockIdx.x, max_mbs, L );
 }
 
 // ---- global accesses that other workgroups of the SAME launch consume / produced -----------------------------------
@@ -480,11 +485,10 @@ __device__ __forceinline__ void wait_progress( const int * progress, const int n
   }
 }
 
-// grid.x = n_frames * mbh_max workgroups; ticket t -> (frame t / mbh_max, row t % mbh_max)
-__global__ __launch_bounds__( kLanes ) void k_recon_intra_rows( const aa_frame_list list, const int n_frames, const int mbh_max, aa_sync_ws * ws )
+// ticket t -> (frame t / mbh_max, row t % mbh_max)
+__device__ __forceinline__ void recon_intra_rows_body( const aa_frame_list & list, const int n_frames, const int mbh_max, aa_sync_ws * ws,
+                                                        IntraLds & L, int & s_ticket )
 {
-  __shared__ IntraLds L;
-  __shared__ int s_ticket;
   const int lane = threadIdx.x;
   const int t = take_ticket( ws, &s_ticket, lane );
   const int fi = t / mbh_max, row = t % mbh_max;
@@ -512,6 +516,14 @@ __global__ __launch_bounds__( kLanes ) void k_recon_intra_rows( const aa_frame_l
     }
   }
   publish_progress( &progress[row], mbw, lane );
+}
+
+// grid.x = n_frames * mbh_max workgroups
+__global__ __launch_bounds__( kLanes ) void k_recon_intra_rows( const aa_frame_list list, const int n_frames, const int mbh_max, aa_sync_ws * ws )
+{
+  __shared__ IntraLds L;
+  __shared__ int s_ticket;
+  recon_intra_rows_body( list, n_frames, mbh_max, ws, L, s_ticket );
 }
 
 struct alignas( 16 ) LfLds {
@@ -678,11 +690,16 @@ __device__ void lf_passes_horizontal( LfLds & L, const bool active, const bool h
 //     filtered by another workgroup of this launch), run the horizontal passes;
 //   * every store is write-through; progress[row] = col+1 is published one step late, once the stores have drained
 //     behind the next MB's prefetch (s_waitcnt vmcnt(0) after its first pass), so the drain is never waited for.
-__global__ __launch_bounds__( kLanes ) void k_loopfilter_rows( const aa_frame_list list, const int n_frames, const int mbh_max, aa_sync_ws * ws, const int fpw )
+struct alignas( 16 ) LfRowsLds {
+  LfLds tile[2];
+  uint16_t info[2][kMaxMbw];     // per MB of the row: lf_level | flags << 8
+};
+
+__device__ __forceinline__ void loopfilter_rows_body( const aa_frame_list & list, const int n_frames, const int mbh_max, aa_sync_ws * ws, const int fpw,
+                                                       LfRowsLds & S, int & s_ticket )
 {
-  __shared__ LfLds L2[2];
-  __shared__ uint16_t s_info[2][kMaxMbw];
-  __shared__ int s_ticket;
+  LfLds ( &L2 )[2] = S.tile;
+  uint16_t ( &s_info )[2][kMaxMbw] = S.info;
   const int lane = threadIdx.x, half = lane >> 5, hl = lane & 31;
   const int t = take_ticket( ws, &s_ticket, lane );
   const int group = t / mbh_max, row = t % mbh_max;
@@ -827,6 +844,13 @@ __global__ __launch_bounds__( kLanes ) void k_loopfilter_rows( const aa_frame_li
   if ( hl == 0 && pending >= 0 ) __hip_atomic_store( &progress[row], pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
 }
 
+__global__ __launch_bounds__( kLanes ) void k_loopfilter_rows( const aa_frame_list list, const int n_frames, const int mbh_max, aa_sync_ws * ws, const int fpw )
+{
+  __shared__ LfRowsLds S;
+  __shared__ int s_ticket;
+  loopfilter_rows_body( list, n_frames, mbh_max, ws, fpw, S, s_ticket );
+}
+
 } // namespace
 
 int launch_recon_inter( const aa_frame_list & list, int n, unsigned max_mbs, void * stream )
@@ -863,5 +887,6 @@ int launch_loopfilter_rows( const aa_frame_list & list, int n, int mbh_max, aa_s
   hipLaunchKernelGGL( k_loopfilter_rows, dim3( ( ( n + fpw - 1 ) / fpw ) * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n, mbh_max, ws, fpw );
   return static_cast<int>( hipGetLastError() );
 }
+
 
 } // namespace aa

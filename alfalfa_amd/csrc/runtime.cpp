@@ -151,6 +151,26 @@ void drain_profile( aa_ctx * ctx )
   ctx->pending.clear();
 }
 
+aa_status ensure_ws( aa_ctx * ctx, aa_sync_ws ** ws, size_t * have, int max_mbh )
+{
+  const size_t need = sizeof( aa_sync_ws ) + sizeof( int ) * size_t( AA_MAX_BATCH ) * max_mbh;
+  if ( need <= *have ) return AA_OK;
+  HIP_TRY( hipStreamSynchronize( ctx->compute ) );
+  int err = 0;
+  if ( *ws ) { (void) hipMemcpy( &err, &( *ws )->error, sizeof err, hipMemcpyDeviceToHost ); (void) hipFree( *ws ); }
+  *ws = nullptr; *have = 0;
+  HIP_TRY( hipMalloc( reinterpret_cast<void **>( ws ), need ) );
+  HIP_TRY( hipMemset( *ws, 0, need ) );
+  if ( err ) HIP_TRY( hipMemcpy( &( *ws )->error, &err, sizeof err, hipMemcpyHostToDevice ) );   // the error word is sticky
+  *have = need;
+  return AA_OK;
+}
+aa_status zero_ws( aa_ctx * ctx, aa_sync_ws * ws, int frames, int max_mbh )
+{
+  HIP_TRY( hipMemsetAsync( reinterpret_cast<uint8_t *>( ws ) + AA_SYNC_WS_ZERO_FROM, 0,
+                           sizeof( aa_sync_ws ) - AA_SYNC_WS_ZERO_FROM + sizeof( int ) * size_t( frames ) * max_mbh, ctx->compute ) );
+  return AA_OK;
+}
 struct LaunchTimer {
   aa_ctx * ctx; int kind; hipEvent_t a = nullptr;
   LaunchTimer( aa_ctx * c, int k ) : ctx( c ), kind( k ) { if ( ctx->profile ) { a = get_event( ctx ); (void) hipEventRecord( a, ctx->compute ); } }
@@ -285,6 +305,7 @@ static aa_status check_watchdog( aa_ctx * ctx )
 aa_status aa_ctx_sync( aa_ctx * ctx )
 {
   if ( !ctx ) return fail( AA_ERR_ARGUMENT, "null ctx" );
+  if ( aa_status st = set_device( ctx ) ) return st;
   HIP_TRY( hipStreamSynchronize( ctx->copy ) );
   HIP_TRY( hipStreamSynchronize( ctx->compute ) );
   return check_watchdog( ctx );
@@ -500,23 +521,14 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
   const int ndiag = max_mbw + 2 * ( max_mbh - 1 );
   if ( ctx->schedule == 0 ) {
     // 2+3. row-pipelined kernels: one launch each; macroblock rows are ordered in-launch (ticket + progress words)
-    const size_t need = sizeof( aa_sync_ws ) + sizeof( int ) * size_t( AA_MAX_BATCH ) * max_mbh;
-    if ( need > ctx->ws_bytes ) {
-      HIP_TRY( hipStreamSynchronize( ctx->compute ) );
-      if ( ctx->ws ) (void) hipFree( ctx->ws );
-      ctx->ws = nullptr; ctx->ws_bytes = 0;
-      HIP_TRY( hipMalloc( reinterpret_cast<void **>( &ctx->ws ), need ) );
-      HIP_TRY( hipMemset( ctx->ws, 0, need ) );
-      ctx->ws_bytes = need;
-    }
+    if ( aa_status st = ensure_ws( ctx, &ctx->ws, &ctx->ws_bytes, max_mbh ) ) return st;
     auto rows_launch = [&]( const std::vector<const aa_dev_frame *> & jobs, int kind ) -> aa_status {
       if ( jobs.empty() ) return AA_OK;
       for ( size_t base = 0; base < jobs.size(); base += AA_MAX_BATCH ) {
         aa_frame_list list;
         const int cnt = static_cast<int>( std::min<size_t>( AA_MAX_BATCH, jobs.size() - base ) );
         for ( int k = 0; k < AA_MAX_BATCH; k++ ) list.f[k] = k < cnt ? jobs[base + k] : nullptr;
-        HIP_TRY( hipMemsetAsync( reinterpret_cast<uint8_t *>( ctx->ws ) + AA_SYNC_WS_ZERO_FROM, 0,
-                                 sizeof( aa_sync_ws ) - AA_SYNC_WS_ZERO_FROM + sizeof( int ) * size_t( cnt ) * max_mbh, ctx->compute ) );
+        if ( aa_status st = zero_ws( ctx, ctx->ws, cnt, max_mbh ) ) return st;
         LaunchTimer t( ctx, kind );
         const int e = kind == 1 ? aa::launch_recon_intra_rows( list, cnt, max_mbh, ctx->ws, ctx->compute )
                                 : aa::launch_loopfilter_rows( list, cnt, max_mbh, ctx->ws, ctx->compute, same_geometry && cnt > 1 );

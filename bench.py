@@ -86,7 +86,7 @@ def main():
         c.set_schedule(args.schedule)
     ctx = ctxs[0]
     decs = [aa.Decoder(ctxs[i % Q], width, height) for i in range(S)]
-    groups = [[d for i, d in enumerate(decs) if i % Q == q] for q in range(Q)]
+    batches = [(ctxs[q], [d for i, d in enumerate(decs) if i % Q == q]) for q in range(Q)]      # (context, decoders submitted together)
 
     def sync_all():
         for c in ctxs:
@@ -162,8 +162,8 @@ def main():
 
     def one_pass():
         for f in range(F):
-            for q in range(Q):
-                ctxs[q].decode_batch(groups[q], [f] * len(groups[q]))
+            for c, part in batches:
+                c.decode_batch(part, [f] * len(part))
 
     def one_step():
         one_pass()

@@ -114,3 +114,4 @@ def test_row_pipelined_schedule_under_load(gpu_ctx):
             assert got == want, "repeat %d: row-pipelined output differs" % rep
     finally:
         gpu_ctx.set_schedule("rows")
+
