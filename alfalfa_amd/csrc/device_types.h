@@ -22,13 +22,14 @@ struct aa_dev_frame {
   uint32_t pad;
 };
 
+#define AA_MAX_XCD 16
+
 // In-launch ordering state of the row-pipelined kernels; zeroed (hipMemsetAsync) before every such launch.
 struct aa_sync_ws {
   int error;                   // != 0: a bounded spin expired (sticky; reported as AA_ERR_HIP by the host).  NOT zeroed per launch.
   int pad0[3];
-  int ticket;                  // next (frame,row) to hand out        -- zeroed from here on before every launch
-  int pad1[3];
-  int progress[1];             // [frame in launch][mbh_max]: macroblock columns of that row that are final
+  int ticket[AA_MAX_XCD];      // per-XCD queue: next (unit,row) to hand out  -- zeroed from here on before every launch
+  int progress[1];             // [unit in launch][mbh_max]: macroblock columns of that row that are final
 };
 #define AA_SYNC_WS_ZERO_FROM 16   // byte offset of `ticket`
 
@@ -43,6 +44,10 @@ namespace aa {
 int launch_recon_inter( const aa_frame_list & list, int n, unsigned max_mbs, void * stream );
 int launch_recon_intra_diagonal( const aa_frame_list & list, int n, int diagonal, int row_lo, int rows, void * stream );
 int launch_loopfilter_diagonal( const aa_frame_list & list, int n, int diagonal, int row_lo, int rows, void * stream );
-int launch_recon_intra_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, void * stream );
-int launch_loopfilter_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, void * stream, bool pair_frames );
+// Row kernels are XCD-affine: unit u (frame / group) is processed by workgroups that run on XCD u % n_xcd.
+int launch_recon_intra_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, int n_xcd, void * stream );
+// list = groups of four frames of one geometry (slot 0 never null, missing frames null)
+int launch_loopfilter_rows4( const aa_frame_list & list, int n_groups, int mbh_max, aa_sync_ws * ws, int n_xcd, void * stream );
+// out16[x] += number of workgroups (of `blocks`) that ran on XCD x
+int launch_probe_xcds( int * out16, int blocks, void * stream );
 }

@@ -310,16 +310,19 @@ __global__ __launch_bounds__( kLanes ) void k_recon_inter( const aa_frame_list l
 }
 
 // ---- global accesses that other workgroups of the SAME launch consume / produced -----------------------------------
-// Row-pipelined kernels hand pixels from one workgroup to another inside a launch.  Per-XCD L2s are not coherent and a
-// CU's L1 is never refreshed by other CUs' stores, so (MI355X_MICROARCH.md "inter-workgroup visibility", valid form
-// "{sc1 stores and sc1 loads on both sides}") shared pixels are written with write-through agent-scope stores, the
-// producing wave drains them (s_waitcnt vmcnt(0)) before it publishes its progress word, and consumers read them with
-// agent-scope (L1-bypassing) loads after one relaxed poll of that word.  No fences.
+// Row-pipelined kernels hand pixels from one workgroup to another inside a launch.  Per-XCD L2s are not coherent with
+// each other and a CU's L1 is never refreshed by other CUs' stores (MI355X_MICROARCH.md "inter-workgroup visibility").
+// The row kernels are therefore XCD-AFFINE: every macroblock row of a frame is processed by a workgroup of the SAME XCD
+// (per-XCD ticket queues indexed by the hardware XCC_ID, see take_ticket), so the XCD's L2 is the coherence point:
+//   producer: ordinary (sc0) stores -- the line STAYS in the XCD's L2 -- drained with s_waitcnt vmcnt(0) before the
+//             progress word is stored;
+//   consumer: one relaxed poll of the progress word, then sc1 loads (bypass the CU's L1, served by the L2).
+// No fences, no write-through to HBM, no fabric round trip per hand-off (measured with sc1 stores: the loop filter moved
+// 5x its algorithmic bytes and was transaction bound).
 template <bool kShared>
 __device__ __forceinline__ void store_u32( uint8_t * p, uint32_t v )
 {
-  if ( kShared ) __hip_atomic_store( reinterpret_cast<uint32_t *>( p ), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-  else *reinterpret_cast<uint32_t *>( p ) = v;
+  *reinterpret_cast<uint32_t *>( p ) = v;        // kShared: same instruction -- an ordinary store is what keeps the line in the XCD's L2
 }
 template <bool kShared>
 __device__ __forceinline__ uint32_t load_u32( const uint8_t * p )
@@ -456,74 +459,88 @@ __global__ __launch_bounds__( kLanes ) void k_recon_intra( const aa_frame_list l
 }
 
 // ---- in-launch ordering for the row-pipelined kernels ------------------------------------------------------------
-// One workgroup (one wave) owns one macroblock row of one frame and walks it left to right; row r may work on column c
-// once row r-1 has finished column min(c+1, mbw-1) (left/above/above-right dependencies of intra prediction and of the
-// loop filter: the same 2:1 wavefront as the per-diagonal launches, without 254 kernel boundaries).
-// Deadlock freedom does not rely on residency or dispatch order: rows are handed out by an atomic TICKET in dependency
-// order, so the row a workgroup waits for is always held by a workgroup that is already running.  Every spin is
-// bounded; on expiry the kernel records an error code and carries on (the host reports AA_ERR_HIP, never a hang).
-__device__ __forceinline__ int take_ticket( aa_sync_ws * ws, int * slot, const int lane )
+// One workgroup (one wave) owns one macroblock row of one unit (a frame, or a group of four frames) and walks it left to
+// right; row r may work on column c once row r-1 has finished column min(c+1, mbw-1) (left/above/above-right
+// dependencies of intra prediction and of the loop filter: the same 2:1 wavefront as the per-diagonal launches, without
+// 254 kernel boundaries).
+// Work is handed out by TICKET, one queue per XCD: unit u belongs to XCD u % n_xcd, and a workgroup only ever takes
+// tickets of the XCD it really runs on (HW_REG_XCC_ID), in dependency order (unit-major, rows ascending).  So
+//   * all rows of a unit run on one XCD -> hand-offs go through that XCD's L2 (see above);
+//   * deadlock freedom does not rely on residency or dispatch order: the row a workgroup waits for has a lower ticket
+//     of the same queue and is therefore held by a workgroup that is already running;
+//   * a workgroup keeps taking tickets until its queue is empty, so every queue is drained as long as ONE workgroup
+//     lands on each XCD (the grid has n_xcd x the work of the fullest queue; with the observed round-robin placement
+//     block b -> XCD b % 8 every workgroup takes exactly one ticket).
+// Every spin is bounded; on expiry the kernel records an error code and carries on (the host reports AA_ERR_HIP).
+__device__ __forceinline__ int xcc_id() { return static_cast<int>( __builtin_amdgcn_s_getreg( 20 | ( 0 << 6 ) | ( 3 << 11 ) ) ); }   // HW_REG_XCC_ID[3:0]
+
+__device__ __forceinline__ int take_ticket( aa_sync_ws * ws, const int xcc, int * slot, const int lane )
 {
-  if ( lane == 0 ) *slot = atomicAdd( &ws->ticket, 1 );
+  __syncthreads();                 // the previous ticket's readers are done with *slot
+  if ( lane == 0 ) *slot = __hip_atomic_fetch_add( &ws->ticket[xcc], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );   // performed in this XCD's L2
   __syncthreads();
   return *slot;
 }
 __device__ __forceinline__ void publish_progress( int * progress, const int value, const int lane )
 {
-  asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );      // every store of this wave has been written through
-  if ( lane == 0 ) __hip_atomic_store( progress, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );      // every store of this wave has reached the L2
+  if ( lane == 0 ) __hip_atomic_store( progress, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
 }
 __device__ __forceinline__ void wait_progress( const int * progress, const int need, aa_sync_ws * ws, const int code )
 {
   int spins = 0;
   while ( __hip_atomic_load( progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) < need ) {
-    __builtin_amdgcn_s_sleep( 8 );
+    __builtin_amdgcn_s_sleep( 4 );
     ++spins;
     // watchdog: sticky error word; once any wait has expired every other wait gives up within 1024 polls
     if ( ( spins & 1023 ) == 0 && __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
-    if ( spins > ( 1 << 21 ) ) { __hip_atomic_store( &ws->error, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); break; }
+    if ( spins > ( 1 << 21 ) ) { atomicExch( &ws->error, code ); break; }
   }
 }
 
-// ticket t -> (frame t / mbh_max, row t % mbh_max)
-__device__ __forceinline__ void recon_intra_rows_body( const aa_frame_list & list, const int n_frames, const int mbh_max, aa_sync_ws * ws,
+// ticket t of queue x -> (frame (t / mbh_max) * n_xcd + x, row t % mbh_max)
+__device__ __forceinline__ void recon_intra_rows_body( const aa_frame_list & list, const int n_frames, const int mbh_max, aa_sync_ws * ws, const int n_xcd,
                                                         IntraLds & L, int & s_ticket )
 {
   const int lane = threadIdx.x;
-  const int t = take_ticket( ws, &s_ticket, lane );
-  const int fi = t / mbh_max, row = t % mbh_max;
-  if ( fi >= n_frames ) return;
-  const aa_dev_frame & f = *list.f[fi];
-  if ( row >= f.mbh ) return;
-  int * progress = ws->progress + fi * mbh_max;
-  const int mbw = f.mbw;
-  if ( f.has_intra ) {
-    const int words = ( mbw + 63 ) >> 6;
-    const unsigned long long * mask = f.intra_rows + static_cast<size_t>( row ) * words;
-    for ( int w = 0; w < words; w++ ) {
-      unsigned long long m = mask[w];
-      while ( m ) {
-        const int col = w * 64 + __ffsll( static_cast<long long>( m ) ) - 1;
-        m &= m - 1;
-        // everything left of `col` in this row is final
-        publish_progress( &progress[row], col, lane );
-        // the residual (dequant, iWHT, IDCTs) does not depend on any neighbour: compute it BEFORE waiting for the row above
-        const aa_mb_info & mb = f.mbs[row * mbw + col];
-        if ( mb.flags & AA_MB_HAS_NONZERO ) compute_residual( mb, f, L.r, lane );
-        if ( row > 0 ) wait_progress( &progress[row - 1], min( col + 2, mbw ), ws, 1 );
-        intra_macroblock<true>( f, mb, col, row, L, lane, true );
+  const int xcc = xcc_id();
+  if ( xcc >= n_xcd ) { if ( lane == 0 ) atomicExch( &ws->error, 3 ); return; }
+  for ( ;; ) {
+    const int t = take_ticket( ws, xcc, &s_ticket, lane );
+    const int fi = ( t / mbh_max ) * n_xcd + xcc, row = t % mbh_max;
+    if ( fi >= n_frames ) return;
+    const aa_dev_frame & f = *list.f[fi];
+    if ( row >= f.mbh ) continue;
+    int * progress = ws->progress + fi * mbh_max;
+    const int mbw = f.mbw;
+    if ( f.has_intra ) {
+      const int words = ( mbw + 63 ) >> 6;
+      const unsigned long long * mask = f.intra_rows + static_cast<size_t>( row ) * words;
+      for ( int w = 0; w < words; w++ ) {
+        unsigned long long m = mask[w];
+        while ( m ) {
+          const int col = w * 64 + __ffsll( static_cast<long long>( m ) ) - 1;
+          m &= m - 1;
+          // everything left of `col` in this row is final
+          publish_progress( &progress[row], col, lane );
+          // the residual (dequant, iWHT, IDCTs) does not depend on any neighbour: compute it BEFORE waiting for the row above
+          const aa_mb_info & mb = f.mbs[row * mbw + col];
+          if ( mb.flags & AA_MB_HAS_NONZERO ) compute_residual( mb, f, L.r, lane );
+          if ( row > 0 ) wait_progress( &progress[row - 1], min( col + 2, mbw ), ws, 1 );
+          intra_macroblock<true>( f, mb, col, row, L, lane, true );
+        }
       }
     }
+    publish_progress( &progress[row], mbw, lane );
   }
-  publish_progress( &progress[row], mbw, lane );
 }
 
-// grid.x = n_frames * mbh_max workgroups
-__global__ __launch_bounds__( kLanes ) void k_recon_intra_rows( const aa_frame_list list, const int n_frames, const int mbh_max, aa_sync_ws * ws )
+// grid.x = n_xcd * ceil(n_frames / n_xcd) * mbh_max workgroups
+__global__ __launch_bounds__( kLanes ) void k_recon_intra_rows( const aa_frame_list list, const int n_frames, const int mbh_max, aa_sync_ws * ws, const int n_xcd )
 {
   __shared__ IntraLds L;
   __shared__ int s_ticket;
-  recon_intra_rows_body( list, n_frames, mbh_max, ws, L, s_ticket );
+  recon_intra_rows_body( list, n_frames, mbh_max, ws, n_xcd, L, s_ticket );
 }
 
 struct alignas( 16 ) LfLds {
@@ -637,218 +654,218 @@ __global__ __launch_bounds__( kLanes ) void k_loopfilter( const aa_frame_list li
   }
 }
 
-constexpr int kMaxMbw = 1024;     // 16383 px / 16
-
-// ---- row-pipelined loop filter ------------------------------------------------------------------------------------
-// The vertical-edge passes (left MB edge + inner vertical edges) of a macroblock touch only its own 16 pixel rows, so
-// they do not depend on the macroblock row above; only the horizontal-edge passes (top MB edge + inner horizontal
-// edges) do.  Splitting them takes half of the filter arithmetic off the cross-row critical path.
-__device__ void lf_passes_vertical( LfLds & L, const bool active, const bool have_left, const bool inner, const LfParams & P, const int hl )
-{
-  const bool is_y = active && hl < 16, is_c = active && hl >= 16;
-  const int cl = ( hl - 16 ) & 7, cp = ( hl - 16 ) >> 3;
-  if ( have_left ) {
-    if ( is_y ) lf_edge( &L.y[4 + hl][4], 1, true, P );
-    else if ( is_c ) lf_edge( &L.c[cp][4 + cl][4], 1, true, P );
-  }
-  __syncthreads();
-  if ( is_y && inner ) lf_edge( &L.y[4 + hl][8], 1, false, P );
-  else if ( is_c && inner ) lf_edge( &L.c[cp][4 + cl][8], 1, false, P );
-  __syncthreads();
-  if ( is_y && inner ) lf_edge( &L.y[4 + hl][12], 1, false, P );
-  __syncthreads();
-  if ( is_y && inner ) lf_edge( &L.y[4 + hl][16], 1, false, P );
-  __syncthreads();
-}
-__device__ void lf_passes_horizontal( LfLds & L, const bool active, const bool have_top, const bool inner, const LfParams & P, const int hl )
-{
-  const bool is_y = active && hl < 16, is_c = active && hl >= 16;
-  const int cl = ( hl - 16 ) & 7, cp = ( hl - 16 ) >> 3;
-  if ( have_top ) {
-    if ( is_y ) lf_edge( &L.y[4][4 + hl], 20, true, P );
-    else if ( is_c ) lf_edge( &L.c[cp][4][4 + cl], 12, true, P );
-  }
-  __syncthreads();
-  if ( is_y && inner ) lf_edge( &L.y[8][4 + hl], 20, false, P );
-  else if ( is_c && inner ) lf_edge( &L.c[cp][8][4 + cl], 12, false, P );
-  __syncthreads();
-  if ( is_y && inner ) lf_edge( &L.y[12][4 + hl], 20, false, P );
-  __syncthreads();
-  if ( is_y && inner ) lf_edge( &L.y[16][4 + hl], 20, false, P );
-  __syncthreads();
-}
-
-// ticket -> (group of `fpw` frames, MB row).  fpw = 2: lanes 0..31 filter row `row` of frame 2g, lanes 32..63 the same
-// row of frame 2g+1 (same geometry, guaranteed by the host); fpw = 1: the upper half idles.  The edge passes keep only
-// 16 (luma) + 16 (chroma) lanes of a frame busy, so pairing frames doubles the work per issued instruction.
-// Per macroblock, per half:
-//   * level/flags of the whole row are preloaded into LDS once; the MB's own 16 rows (produced by earlier launches) are
-//     PREFETCHED with plain loads while the previous MB is filtered; the 4 columns to the left are the half's own
-//     previous MB, carried over in LDS;
-//   * vertical passes run first (no dependency on the row above); the poll of progress[row-1] is issued before them;
-//   * then wait for progress[row-1] >= min(col+2, mbw), fetch the 4 rows above with agent-scope loads (they were
-//     filtered by another workgroup of this launch), run the horizontal passes;
-//   * every store is write-through; progress[row] = col+1 is published one step late, once the stores have drained
-//     behind the next MB's prefetch (s_waitcnt vmcnt(0) after its first pass), so the drain is never waited for.
-struct alignas( 16 ) LfRowsLds {
-  LfLds tile[2];
-  uint16_t info[2][kMaxMbw];     // per MB of the row: lf_level | flags << 8
+// ---- row-pipelined loop filter, packed arithmetic, FOUR frames per wave ----------------------------------------------
+// 16 lanes per frame ("slot").  A lane filters TWO positions of an edge at once in packed int16 (vp8_math.hh pk2):
+//   vertical edges   (V phase): lane j < 8 owns luma pixel rows 2j, 2j+1; lane 8+k owns chroma rows 2(k&3), +1 of plane k>>2;
+//   horizontal edges (H phase): lane j < 8 owns luma columns 2j, 2j+1;    lane 8+k the chroma columns likewise.
+// A lane keeps its two 20-pixel lines (12 for chroma) in registers for all four (two) edges of the phase, so the LDS
+// tile is read and written once per phase instead of once per edge.  Chroma lanes run the SAME instruction stream as
+// luma lanes (same row stride, edges 2 and 3 gated off), so a step costs one luma lane's instructions for four
+// macroblocks.  The tile keeps chroma in front of luma so that the chroma lanes' (ignored) reads of rows 12..19 stay
+// inside the tile.
+struct alignas( 16 ) LfTile4 {
+  uint8_t c[12][32];     // rows -4..7; U in bytes 0..15 (columns -4..-1 at 4..7, 0..7 at 8..15), V in bytes 16..31
+  uint8_t y[20][32];     // rows -4..15; columns -4..-1 at 12..15, columns 0..15 at 16..31
 };
+struct alignas( 16 ) LfRows4Lds { LfTile4 tile[4]; };
 
-__device__ __forceinline__ void loopfilter_rows_body( const aa_frame_list & list, const int n_frames, const int mbh_max, aa_sync_ws * ws, const int fpw,
-                                                       LfRowsLds & S, int & s_ticket )
+__device__ __forceinline__ uint64_t load_u64_shared( const uint8_t * p )
 {
-  LfLds ( &L2 )[2] = S.tile;
-  uint16_t ( &s_info )[2][kMaxMbw] = S.info;
-  const int lane = threadIdx.x, half = lane >> 5, hl = lane & 31;
-  const int t = take_ticket( ws, &s_ticket, lane );
-  const int group = t / mbh_max, row = t % mbh_max;
-  if ( group * fpw >= n_frames ) return;
-  const aa_dev_frame & f0 = *list.f[group * fpw];
+  return __hip_atomic_load( reinterpret_cast<const uint64_t *>( p ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+}
+
+// the (up to) four edges of a phase on a lane's two lines: v[i] = packed pixels at position -4 + i
+__device__ __forceinline__ void lf_edges_pk( pk2 ( &v )[20], const LfParamsPk & P, const pk2 g0, const pk2 g1, const pk2 g23 )
+{
+  if ( __any( g0 != 0u ) ) lf_edge_pk( P, true, g0, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7] );
+  if ( __any( g1 != 0u ) ) {
+    lf_edge_pk( P, false, g1, v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11] );
+    if ( __any( g23 != 0u ) ) {
+      lf_edge_pk( P, false, g23, v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15] );
+      lf_edge_pk( P, false, g23, v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19] );
+    }
+  }
+}
+
+// ticket -> (group of four frames with one geometry, MB row); list.f[4g] is never null, the host pads groups with null.
+// Per macroblock step: own 16 rows are PREFETCHED one step ahead with plain 128/64-bit loads (earlier launches produced
+// them); the four columns to the left are the previous step's right edge, carried in LDS; V phase; the previous step's
+// progress is published once its stores have drained (they drain behind the V phase); wait for progress[row-1] >=
+// min(col+2, mbw); fetch the four rows above with sc1 (L1-bypassing, L2-served) loads; H phase; store (ordinary stores:
+// the next row's workgroup runs on the same XCD and finds rows 12..15 in its L2).
+__device__ __forceinline__ void loopfilter_rows4_row( const aa_frame_list & list, const int group, const int row, const int mbh_max, aa_sync_ws * ws,
+                                                       LfRows4Lds & S )
+{
+  const int lane = threadIdx.x, slot = lane >> 4, l = lane & 15;
+  const aa_dev_frame & f0 = *list.f[group * 4];
   if ( row >= f0.mbh ) return;
-  const int fi = group * fpw + half;
-  const bool have = half < fpw && fi < n_frames;
-  const aa_dev_frame & f = *list.f[have ? fi : group * fpw];
-  const bool frame_on = have && f.loop_filter_level != 0;
+  const aa_dev_frame * const fp = list.f[group * 4 + slot];
+  const bool frame_on = fp != nullptr && fp->loop_filter_level != 0;
   if ( !__any( frame_on ) ) return;
-  LfLds & L = L2[half];
-  int * progress = ws->progress + ( have ? fi : group * fpw ) * mbh_max;
+  const aa_dev_frame & f = fp ? *fp : f0;
+  LfTile4 & T = S.tile[slot];
+  int * const progress = ws->progress + group * mbh_max;
   const int mbw = f0.mbw, pw = mbw * 16, cw = pw >> 1;
   const int y0 = row * 16, cy0 = row * 8;
-  uint8_t * const Y = f.cur[0];
-  uint8_t * const C0 = f.cur[1];
-  uint8_t * const C1 = f.cur[2];
   const int sharp = f.sharpness; const bool key = f.key_frame;
-  for ( int c = hl; c < mbw; c += 32 ) {
-    int v = 0;
-    if ( frame_on ) { const aa_mb_info & m = f.mbs[row * mbw + c]; v = m.lf_level | ( m.flags << 8 ); }
-    s_info[half][c] = static_cast<uint16_t>( v );
-  }
-  __syncthreads();
+  const bool luma = l < 8;
+  const int k8 = l & 7;
+  // phase roles
+  uint8_t * const vbase = luma ? &T.y[4 + 2 * l][12] : &T.c[4 + 2 * ( k8 & 3 )][16 * ( k8 >> 2 ) + 4];   // two rows (+32): halo dword, then body
+  uint8_t * const hbase = luma ? &T.y[0][16 + 2 * l] : &T.c[0][16 * ( k8 >> 2 ) + 8 + 2 * ( k8 & 3 )];   // two columns, rows at +32 r
+  // bulk roles: lane l <-> luma row l and chroma row l & 7 of plane l >> 3
+  const int bpl = l >> 3, br = l & 7;
+  uint8_t * const yrow = f.cur[0] + static_cast<size_t>( y0 + l ) * pw;
+  uint8_t * const crow = f.cur[1 + bpl] + static_cast<size_t>( cy0 + br ) * cw;
+  uint8_t * const ly = &T.y[4 + l][16];
+  uint8_t * const lc = &T.c[4 + br][16 * bpl + 8];
+  // rows above: lanes 0..7 luma row -4 + (l >> 1), half l & 1; lanes 8..15 chroma plane k8 >> 2, row -4 + (k8 & 3); 8 bytes each
+  uint8_t * const toprow = luma ? f.cur[0] + static_cast<ptrdiff_t>( y0 - 4 + ( l >> 1 ) ) * pw + 8 * ( l & 1 )
+                                : f.cur[1 + ( k8 >> 2 )] + static_cast<ptrdiff_t>( cy0 - 4 + ( k8 & 3 ) ) * cw;
+  uint8_t * const ltop = luma ? &T.y[l >> 1][16 + 8 * ( l & 1 )] : &T.c[k8 & 3][16 * ( k8 >> 2 ) + 8];
+  const int topstep = luma ? 16 : 8;
+  const aa_mb_info * const mbrow = f.mbs + static_cast<size_t>( row ) * mbw;
 
-  // bulk-transfer roles inside a half: luma 64 dwords = 2 per lane, chroma 32 dwords = 1 per lane
-  const int yr0 = 4 + ( hl >> 2 ), yr1 = yr0 + 8, yd = 1 + ( hl & 3 );
-  const int cpl = hl >> 4, cr = 4 + ( ( hl >> 1 ) & 7 ), cd = 1 + ( hl & 1 );
-  const uint8_t * yrow0 = Y + static_cast<size_t>( y0 - 4 + yr0 ) * pw - 4 + yd * 4;
-  const uint8_t * yrow1 = yrow0 + static_cast<size_t>( 8 ) * pw;
-  const uint8_t * crow = ( cpl ? C1 : C0 ) + static_cast<size_t>( cy0 - 4 + cr ) * cw - 4 + cd * 4;
-  // store slots (which dword of the LDS tile this lane writes back, and where): 5 luma/chroma slots per lane,
-  // resolved once per row instead of per macroblock.  kind: 0 unused, 1 always, 2 only when col > 0 (left columns);
-  // +4: the dword lies in the bottom 4 pixel rows of this MB row, which the NEXT row's workgroup reads in this launch
-  // -> write-through (sc1) store.  Everything else is read by nobody before the launch ends -> plain (L2 write-back,
-  // the 8 macroblocks sharing a 128-B line combine there) store; measured: all-write-through moved 6x the algorithmic bytes.
-  uint8_t * st_ptr[5]; int st_lds[5]; int st_kind[5]; int st_step[5];
-  {
-    int k = 0;
-    for ( int i = hl; i < 100 && k < 5; i += 32 ) {            // luma: 20 rows x 5 dwords
-      const int r = i / 5, d = i % 5;
-      if ( r == 0 || ( r < 4 && ( d == 0 || row == 0 ) ) ) continue;
-      st_ptr[k] = Y + static_cast<ptrdiff_t>( y0 - 4 + r ) * pw - 4 + d * 4; st_lds[k] = r * 20 + d * 4; st_kind[k] = ( d == 0 ? 2 : 1 ) | ( r >= 16 ? 4 : 0 ); st_step[k] = 16; k++;
-    }
-    for ( int i = hl; i < 72 && k < 5; i += 32 ) {             // chroma: 2 planes x 12 rows x 3 dwords
-      const int pl = i / 36, e = i % 36, r = e / 3, d = e % 3;
-      if ( r == 0 || ( r < 4 && ( d == 0 || row == 0 ) ) ) continue;
-      st_ptr[k] = ( pl ? C1 : C0 ) + static_cast<ptrdiff_t>( cy0 - 4 + r ) * cw - 4 + d * 4; st_lds[k] = 400 + pl * 144 + r * 12 + d * 4; st_kind[k] = ( d == 0 ? 2 : 1 ) | ( r >= 8 ? 4 : 0 ); st_step[k] = 8; k++;
-    }
-    for ( ; k < 5; k++ ) { st_ptr[k] = Y; st_lds[k] = 0; st_kind[k] = 0; st_step[k] = 0; }
-  }
-  const uint8_t * const lds_base = &L.y[0][0];     // LfLds: y[20][20] (400 B) followed by c[2][12][12]
-
+  int info = frame_on ? *reinterpret_cast<const uint16_t *>( &mbrow[0].flags ) : 0;     // flags | lf_level << 8
   bool carried = false, prefetched = false;
-  uint32_t pre_y0 = 0, pre_y1 = 0, pre_c = 0;
+  uint4 pre_y = make_uint4( 0, 0, 0, 0 ); uint2 pre_c = make_uint2( 0, 0 );
   int pending = -1;
   for ( int col = 0; col < mbw; col++ ) {
-    const int info = s_info[half][col];
-    const int level = info & 0xFF;
+    const int level = info >> 8;
     const bool active = level != 0;
+    const bool inner = !( info & AA_MB_LF_SKIP_INNER );
     const int x0 = col * 16, cx0 = col * 8;
-    if ( !__any( active ) ) {           // neither frame filters this macroblock
+    const bool more = col + 1 < mbw;
+    if ( !__any( active ) ) {           // no frame of the group filters this macroblock
+      info = ( frame_on && more ) ? *reinterpret_cast<const uint16_t *>( &mbrow[col + 1].flags ) : 0;
       carried = false; prefetched = false;
       asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-      if ( hl == 0 && frame_on ) __hip_atomic_store( &progress[row], col + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      if ( lane == 0 ) __hip_atomic_store( &progress[row], col + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
       pending = -1;
       continue;
     }
-    if ( active && !prefetched ) {
-      pre_y0 = *reinterpret_cast<const uint32_t *>( yrow0 + x0 ); pre_y1 = *reinterpret_cast<const uint32_t *>( yrow1 + x0 );
-      pre_c = *reinterpret_cast<const uint32_t *>( crow + cx0 );
-    }
+    if ( active && !prefetched ) { pre_y = *reinterpret_cast<const uint4 *>( yrow + x0 ); pre_c = *reinterpret_cast<const uint2 *>( crow + cx0 ); }
     if ( active && !carried && col > 0 ) {   // left neighbour columns straight from memory
-      if ( hl < 16 ) *reinterpret_cast<uint32_t *>( &L.y[4 + hl][0] ) = *reinterpret_cast<const uint32_t *>( Y + static_cast<size_t>( y0 + hl ) * pw + x0 - 4 );
-      else { const int l = hl - 16; *reinterpret_cast<uint32_t *>( &L.c[l >> 3][4 + ( l & 7 )][0] ) = *reinterpret_cast<const uint32_t *>( ( ( l >> 3 ) ? C1 : C0 ) + static_cast<size_t>( cy0 + ( l & 7 ) ) * cw + cx0 - 4 ); }
+      *reinterpret_cast<uint32_t *>( ly - 4 ) = *reinterpret_cast<const uint32_t *>( yrow + x0 - 4 );
+      *reinterpret_cast<uint32_t *>( lc - 4 ) = *reinterpret_cast<const uint32_t *>( crow + cx0 - 4 );
     }
-    if ( active ) {
-      *reinterpret_cast<uint32_t *>( &L.y[yr0][yd * 4] ) = pre_y0; *reinterpret_cast<uint32_t *>( &L.y[yr1][yd * 4] ) = pre_y1;
-      *reinterpret_cast<uint32_t *>( &L.c[cpl][cr][cd * 4] ) = pre_c;
-    }
-    // everything issued so far (previous MB's write-through stores included) has completed: publish the previous MB
-    asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-    if ( hl == 0 && pending >= 0 ) __hip_atomic_store( &progress[row], pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-    pending = -1;
+    if ( active ) { *reinterpret_cast<uint4 *>( ly ) = pre_y; *reinterpret_cast<uint2 *>( lc ) = pre_c; }
+    // in flight during the V phase: the next macroblock's level, its own rows, the poll of the row above
+    const int info_next = ( frame_on && more ) ? *reinterpret_cast<const uint16_t *>( &mbrow[col + 1].flags ) : 0;
     const int need = min( col + 2, mbw );
     int seen = need;
-    if ( row > 0 && active ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );   // consumed after the vertical passes
+    if ( row > 0 ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
     __syncthreads();
 
-    const LfParams P = lf_params( active ? level : 1, sharp, key );
-    const bool inner = !( ( info >> 8 ) & AA_MB_LF_SKIP_INNER );
-    lf_passes_vertical( L, active, col > 0, inner, P, hl );
+    const LfParamsPk P = lf_params_pk( lf_params( active ? level : 1, sharp, key ) );
+    const pk2 g_on = active ? ~0u : 0u, g_in = ( active && inner ) ? ~0u : 0u, g_in23 = ( active && inner && luma ) ? ~0u : 0u;
+    {   // ---- V phase: left MB edge, inner vertical edges ----
+      uint32_t a[5], b[5];
+      a[0] = *reinterpret_cast<const uint32_t *>( vbase ); b[0] = *reinterpret_cast<const uint32_t *>( vbase + 32 );
+      { const uint2 u = *reinterpret_cast<const uint2 *>( vbase + 4 ); a[1] = u.x; a[2] = u.y; }
+      { const uint2 u = *reinterpret_cast<const uint2 *>( vbase + 12 ); a[3] = u.x; a[4] = u.y; }
+      { const uint2 u = *reinterpret_cast<const uint2 *>( vbase + 36 ); b[1] = u.x; b[2] = u.y; }
+      { const uint2 u = *reinterpret_cast<const uint2 *>( vbase + 44 ); b[3] = u.x; b[4] = u.y; }
+      pk2 v[20];
+#pragma unroll
+      for ( int d = 0; d < 5; d++ ) {
+        v[4 * d] = pk_from_bytes<0>( a[d], b[d] ); v[4 * d + 1] = pk_from_bytes<1>( a[d], b[d] );
+        v[4 * d + 2] = pk_from_bytes<2>( a[d], b[d] ); v[4 * d + 3] = pk_from_bytes<3>( a[d], b[d] );
+      }
+      lf_edges_pk( v, P, col > 0 ? g_on : 0u, g_in, g_in23 );
+#pragma unroll
+      for ( int d = 0; d < 5; d++ ) pk_to_dwords( v[4 * d], v[4 * d + 1], v[4 * d + 2], v[4 * d + 3], a[d], b[d] );
+      if ( active ) {
+        *reinterpret_cast<uint32_t *>( vbase ) = a[0]; *reinterpret_cast<uint32_t *>( vbase + 32 ) = b[0];
+        *reinterpret_cast<uint2 *>( vbase + 4 ) = make_uint2( a[1], a[2] ); *reinterpret_cast<uint2 *>( vbase + 36 ) = make_uint2( b[1], b[2] );
+        if ( luma ) { *reinterpret_cast<uint2 *>( vbase + 12 ) = make_uint2( a[3], a[4] ); *reinterpret_cast<uint2 *>( vbase + 44 ) = make_uint2( b[3], b[4] ); }
+      }
+    }
+    // the previous step's stores have drained behind the V phase: publish it
+    asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+    if ( lane == 0 && pending >= 0 ) __hip_atomic_store( &progress[row], pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+    pending = -1;
+    // prefetch the next macroblock's own rows (consumed at the top of the next step)
+    prefetched = more && ( info_next >> 8 ) != 0;
+    if ( prefetched ) { pre_y = *reinterpret_cast<const uint4 *>( yrow + x0 + 16 ); pre_c = *reinterpret_cast<const uint2 *>( crow + cx0 + 8 ); }
 
     if ( row > 0 ) {
       int spins = 0;
       while ( !__all( seen >= need ) ) {
-        __builtin_amdgcn_s_sleep( 8 );
+        __builtin_amdgcn_s_sleep( 4 );
         if ( seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
         ++spins;
         if ( ( spins & 1023 ) == 0 && __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
-        if ( spins > ( 1 << 21 ) ) { __hip_atomic_store( &ws->error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ); break; }
+        if ( spins > ( 1 << 21 ) ) { atomicExch( &ws->error, 2 ); break; }
       }
-      if ( active ) {
-        if ( hl < 16 ) {             // 4 rows x 4 dwords above the luma block
-          const int r = hl >> 2, d = 1 + ( hl & 3 );
-          *reinterpret_cast<uint32_t *>( &L.y[r][d * 4] ) = load_u32<true>( Y + static_cast<size_t>( y0 - 4 + r ) * pw + x0 - 4 + d * 4 );
-        } else {                     // 2 planes x 4 rows x 2 dwords above the chroma blocks
-          const int l = hl - 16, pl = l >> 3, r = ( l >> 1 ) & 3, d = 1 + ( l & 1 );
-          *reinterpret_cast<uint32_t *>( &L.c[pl][r][d * 4] ) = load_u32<true>( ( pl ? C1 : C0 ) + static_cast<size_t>( cy0 - 4 + r ) * cw + cx0 - 4 + d * 4 );
-        }
-      }
-      __syncthreads();
+      if ( active ) *reinterpret_cast<uint64_t *>( ltop ) = load_u64_shared( toprow + col * topstep );
     }
+    __syncthreads();
 
-    lf_passes_horizontal( L, active, row > 0, inner, P, hl );
-
-    if ( active ) {   // write-through stores: rows -3..-1 x cols 0..15 (previous MB row), rows 0..15 x cols -4..15
+    {   // ---- H phase: top MB edge, inner horizontal edges ----
+      pk2 v[20];
 #pragma unroll
-      for ( int k = 0; k < 5; k++ )
-        if ( ( st_kind[k] & 1 ) || ( ( st_kind[k] & 2 ) && col > 0 ) ) {
-          const uint32_t v = *reinterpret_cast<const uint32_t *>( lds_base + st_lds[k] );
-          if ( st_kind[k] & 4 ) store_u32<true>( st_ptr[k] + col * st_step[k], v );
-          else store_u32<false>( st_ptr[k] + col * st_step[k], v );
+      for ( int r = 0; r < 20; r++ ) v[r] = pk_from_u16( *reinterpret_cast<const uint16_t *>( hbase + 32 * r ) );
+      lf_edges_pk( v, P, row > 0 ? g_on : 0u, g_in, g_in23 );
+      if ( active ) {
+#pragma unroll
+        for ( int r = 1; r < 12; r++ ) *reinterpret_cast<uint16_t *>( hbase + 32 * r ) = static_cast<uint16_t>( pk_to_u16( v[r] ) );
+        if ( luma ) {
+#pragma unroll
+          for ( int r = 12; r < 20; r++ ) *reinterpret_cast<uint16_t *>( hbase + 32 * r ) = static_cast<uint16_t>( pk_to_u16( v[r] ) );
         }
+      }
     }
-    if ( frame_on ) pending = col + 1;
-    // prefetch the next macroblock's own rows while these stores drain
-    prefetched = col + 1 < mbw && ( s_info[half][col + 1] & 0xFF ) != 0;
-    if ( prefetched ) {
-      pre_y0 = *reinterpret_cast<const uint32_t *>( yrow0 + x0 + 16 ); pre_y1 = *reinterpret_cast<const uint32_t *>( yrow1 + x0 + 16 );
-      pre_c = *reinterpret_cast<const uint32_t *>( crow + cx0 + 8 );
+    __syncthreads();
+
+    if ( active ) {
+      const uint4 oy = *reinterpret_cast<const uint4 *>( ly ); const uint2 oc = *reinterpret_cast<const uint2 *>( lc );
+      *reinterpret_cast<uint4 *>( yrow + x0 ) = oy;
+      *reinterpret_cast<uint2 *>( crow + cx0 ) = oc;
+      if ( col > 0 ) {        // columns -4..-1: final now (the left MB edge of this macroblock was the last to touch them)
+        *reinterpret_cast<uint32_t *>( yrow + x0 - 4 ) = *reinterpret_cast<const uint32_t *>( ly - 4 );
+        *reinterpret_cast<uint32_t *>( crow + cx0 - 4 ) = *reinterpret_cast<const uint32_t *>( lc - 4 );
+      }
+      if ( row > 0 ) *reinterpret_cast<uint64_t *>( toprow + col * topstep ) = *reinterpret_cast<const uint64_t *>( ltop );
+      // carry the filtered right edge over as the next macroblock's left neighbour columns
+      *reinterpret_cast<uint32_t *>( ly - 4 ) = *reinterpret_cast<const uint32_t *>( ly + 12 );
+      *reinterpret_cast<uint32_t *>( lc - 4 ) = *reinterpret_cast<const uint32_t *>( lc + 4 );
     }
-    if ( active ) {                  // carry the filtered right edge over as the next macroblock's left neighbour columns
-      if ( hl < 16 ) *reinterpret_cast<uint32_t *>( &L.y[4 + hl][0] ) = *reinterpret_cast<const uint32_t *>( &L.y[4 + hl][16] );
-      else { const int l = hl - 16; *reinterpret_cast<uint32_t *>( &L.c[l >> 3][4 + ( l & 7 )][0] ) = *reinterpret_cast<const uint32_t *>( &L.c[l >> 3][4 + ( l & 7 )][8] ); }
-    }
+    pending = col + 1;
     carried = active;
+    info = info_next;
     __syncthreads();
   }
   asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-  if ( hl == 0 && pending >= 0 ) __hip_atomic_store( &progress[row], pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  if ( lane == 0 && pending >= 0 ) __hip_atomic_store( &progress[row], pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
 }
 
-__global__ __launch_bounds__( kLanes ) void k_loopfilter_rows( const aa_frame_list list, const int n_frames, const int mbh_max, aa_sync_ws * ws, const int fpw )
+// ticket t of queue x -> (group (t / mbh_max) * n_xcd + x, row t % mbh_max)
+__device__ __forceinline__ void loopfilter_rows4_body( const aa_frame_list & list, const int n_groups, const int mbh_max, aa_sync_ws * ws, const int n_xcd,
+                                                        LfRows4Lds & S, int & s_ticket )
 {
-  __shared__ LfRowsLds S;
+  const int xcc = xcc_id();
+  if ( xcc >= n_xcd ) { if ( threadIdx.x == 0 ) atomicExch( &ws->error, 3 ); return; }
+  for ( ;; ) {
+    const int t = take_ticket( ws, xcc, &s_ticket, threadIdx.x );
+    const int group = ( t / mbh_max ) * n_xcd + xcc;
+    if ( group >= n_groups ) return;
+    loopfilter_rows4_row( list, group, t % mbh_max, mbh_max, ws, S );
+  }
+}
+
+// grid.x = n_xcd * ceil(n_groups / n_xcd) * mbh_max workgroups
+__global__ __launch_bounds__( kLanes ) void k_loopfilter_rows4( const aa_frame_list list, const int n_groups, const int mbh_max, aa_sync_ws * ws, const int n_xcd )
+{
+  __shared__ LfRows4Lds S;
   __shared__ int s_ticket;
-  loopfilter_rows_body( list, n_frames, mbh_max, ws, fpw, S, s_ticket );
+  loopfilter_rows4_body( list, n_groups, mbh_max, ws, n_xcd, S, s_ticket );
+}
+
+// Which XCDs do workgroups of this device land on?  out[x] = number of workgroups of the launch that ran on XCD x.
+__global__ void k_probe_xcds( int * out )
+{
+  if ( threadIdx.x == 0 ) atomicAdd( &out[xcc_id() & 15], 1 );
 }
 
 } // namespace
@@ -876,17 +893,20 @@ static unsigned test_lds_pad()
   static const unsigned pad = [] { const char * e = std::getenv( "ALFALFA_AMD_TEST_LDS_PAD" ); return e ? static_cast<unsigned>( std::atoi( e ) ) : 0u; }();
   return pad;
 }
-int launch_recon_intra_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, void * stream )
+int launch_recon_intra_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, int n_xcd, void * stream )
 {
-  hipLaunchKernelGGL( k_recon_intra_rows, dim3( n * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n, mbh_max, ws );
+  hipLaunchKernelGGL( k_recon_intra_rows, dim3( n_xcd * ( ( n + n_xcd - 1 ) / n_xcd ) * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n, mbh_max, ws, n_xcd );
   return static_cast<int>( hipGetLastError() );
 }
-int launch_loopfilter_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, void * stream, bool pair_frames )
+int launch_loopfilter_rows4( const aa_frame_list & list, int n_groups, int mbh_max, aa_sync_ws * ws, int n_xcd, void * stream )
 {
-  const int fpw = pair_frames ? 2 : 1;
-  hipLaunchKernelGGL( k_loopfilter_rows, dim3( ( ( n + fpw - 1 ) / fpw ) * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n, mbh_max, ws, fpw );
+  hipLaunchKernelGGL( k_loopfilter_rows4, dim3( n_xcd * ( ( n_groups + n_xcd - 1 ) / n_xcd ) * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n_groups, mbh_max, ws, n_xcd );
   return static_cast<int>( hipGetLastError() );
 }
-
+int launch_probe_xcds( int * out16, int blocks, void * stream )
+{
+  hipLaunchKernelGGL( k_probe_xcds, dim3( blocks ), dim3( kLanes ), 0, static_cast<hipStream_t>( stream ), out16 );
+  return static_cast<int>( hipGetLastError() );
+}
 
 } // namespace aa

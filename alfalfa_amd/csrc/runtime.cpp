@@ -75,6 +75,8 @@ struct aa_ctx {
   bool dying = false;
   bool profile = false;
   int schedule = 0;            // 0: row-pipelined persistent kernels (default), 1: one launch per 2:1 anti-diagonal
+  int n_xcd = 1;               // XCDs workgroups land on (probed at creation); row kernels keep a unit on one XCD
+  int xcd_share[AA_MAX_XCD] = {};
   aa_sync_ws * ws = nullptr;   // in-launch ordering state of the row-pipelined kernels
   size_t ws_bytes = 0;
   aa_kernel_stats stats {};
@@ -272,6 +274,24 @@ aa_status aa_ctx_create( int device, aa_ctx ** out )
   HIP_TRY( hipStreamCreateWithFlags( &ctx->copy, hipStreamNonBlocking ) );
   HIP_TRY( hipEventCreateWithFlags( &ctx->upload_done, hipEventDisableTiming ) );
   if ( const char * e = std::getenv( "ALFALFA_AMD_SCHEDULE" ) ) ctx->schedule = std::string( e ) == "diagonal" ? 1 : 0;
+  // The row-pipelined kernels keep every unit on one XCD (per-XCD ticket queues indexed by the hardware XCC_ID): find
+  // out which XCC ids workgroups of this device really land on.  They must be 0..n-1, each reached by a modest grid.
+  {
+    int * d = nullptr; int h[AA_MAX_XCD] = {};
+    HIP_TRY( hipMalloc( reinterpret_cast<void **>( &d ), sizeof h ) );
+    HIP_TRY( hipMemset( d, 0, sizeof h ) );
+    const int e2 = aa::launch_probe_xcds( d, 2048, ctx->compute );
+    if ( e2 ) { (void) hipFree( d ); return hip_fail( static_cast<hipError_t>( e2 ), "k_probe_xcds" ); }
+    HIP_TRY( hipStreamSynchronize( ctx->compute ) );
+    HIP_TRY( hipMemcpy( h, d, sizeof h, hipMemcpyDeviceToHost ) );
+    (void) hipFree( d );
+    int n_xcd = 0;
+    while ( n_xcd < AA_MAX_XCD && h[n_xcd] > 0 ) n_xcd++;
+    for ( int x = n_xcd; x < AA_MAX_XCD; x++ ) if ( h[x] ) return fail( AA_ERR_HIP, "unexpected XCC id layout on this device (ids are not 0..n-1)" );
+    if ( n_xcd == 0 ) return fail( AA_ERR_HIP, "XCD probe kernel did not run" );
+    for ( int x = 0; x < n_xcd; x++ ) ctx->xcd_share[x] = h[x];
+    ctx->n_xcd = n_xcd;
+  }
   *out = ctx.release();
   return AA_OK;
 }
@@ -298,7 +318,8 @@ static aa_status check_watchdog( aa_ctx * ctx )
   if ( !ctx->ws ) return AA_OK;
   int err = 0;
   HIP_TRY( hipMemcpy( &err, &ctx->ws->error, sizeof err, hipMemcpyDeviceToHost ) );
-  if ( err ) return fail( AA_ERR_HIP, std::string( "row-pipelined kernel " ) + ( err == 1 ? "k_recon_intra_rows" : "k_loopfilter_rows" )
+  if ( err == 3 ) return fail( AA_ERR_HIP, "row-pipelined kernel: a workgroup ran on an XCD outside the probed set (output is not valid)" );
+  if ( err ) return fail( AA_ERR_HIP, std::string( "row-pipelined kernel " ) + ( err == 1 ? "k_recon_intra_rows" : "k_loopfilter_rows4" )
                                       + ": a bounded wait for the macroblock row above expired (output is not valid)" );
   return AA_OK;
 }
@@ -471,6 +492,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
   if ( aa_status st = set_device( ctx ) ) return st;
   std::vector<const aa_dev_frame *> inter_jobs, intra_jobs, lf_jobs;
   std::vector<const FrameRec *> intra_recs;
+  std::vector<uint32_t> lf_geometry;
   unsigned max_mbs = 0; int max_mbw = 0, max_mbh = 0;
   bool same_geometry = true;     // two-frames-per-wave loop filter needs equal macroblock dimensions in the batch
   uint64_t total_mbs = 0;
@@ -488,7 +510,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
     const aa_frame_header & h = r.hdr;
     if ( h.num_intra_mbs < h.num_macroblocks ) inter_jobs.push_back( r.dev_job );
     if ( h.has_intra_mb ) { intra_jobs.push_back( r.dev_job ); intra_recs.push_back( &r ); }
-    if ( h.loop_filter_level ) lf_jobs.push_back( r.dev_job );
+    if ( h.loop_filter_level ) { lf_jobs.push_back( r.dev_job ); lf_geometry.push_back( ( static_cast<uint32_t>( h.mb_width ) << 16 ) | h.mb_height ); }
     if ( i > 0 && ( h.mb_width != streams[0]->frames[frame_index[0]].hdr.mb_width || h.mb_height != streams[0]->frames[frame_index[0]].hdr.mb_height ) ) same_geometry = false;
     max_mbs = std::max<unsigned>( max_mbs, h.num_macroblocks );
     max_mbw = std::max<int>( max_mbw, h.mb_width ); max_mbh = std::max<int>( max_mbh, h.mb_height );
@@ -530,14 +552,39 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
         for ( int k = 0; k < AA_MAX_BATCH; k++ ) list.f[k] = k < cnt ? jobs[base + k] : nullptr;
         if ( aa_status st = zero_ws( ctx, ctx->ws, cnt, max_mbh ) ) return st;
         LaunchTimer t( ctx, kind );
-        const int e = kind == 1 ? aa::launch_recon_intra_rows( list, cnt, max_mbh, ctx->ws, ctx->compute )
-                                : aa::launch_loopfilter_rows( list, cnt, max_mbh, ctx->ws, ctx->compute, same_geometry && cnt > 1 );
-        if ( e ) return hip_fail( static_cast<hipError_t>( e ), kind == 1 ? "k_recon_intra_rows" : "k_loopfilter_rows" );
+        const int e = aa::launch_recon_intra_rows( list, cnt, max_mbh, ctx->ws, ctx->n_xcd, ctx->compute );
+        if ( e ) return hip_fail( static_cast<hipError_t>( e ), "k_recon_intra_rows" );
       }
       return AA_OK;
     };
     if ( aa_status st = rows_launch( intra_jobs, 1 ) ) return st;
-    if ( aa_status st = rows_launch( lf_jobs, 2 ) ) return st;
+    // loop filter: four frames of ONE geometry per wave.  Bucket by geometry, pad every bucket to a multiple of four
+    // with null frames (slot 0 of a group is never null), split at group boundaries when a list is full.
+    if ( !lf_jobs.empty() ) {
+      std::vector<std::pair<uint32_t, const aa_dev_frame *>> keyed;
+      keyed.reserve( lf_geometry.size() );
+      for ( size_t i = 0; i < lf_jobs.size(); i++ ) keyed.emplace_back( lf_geometry[i], lf_jobs[i] );
+      if ( !same_geometry ) std::stable_sort( keyed.begin(), keyed.end(), []( const auto & a, const auto & b ) { return a.first < b.first; } );
+      aa_frame_list list;
+      int filled = 0;
+      auto launch = [&]() -> aa_status {
+        if ( !filled ) return AA_OK;
+        for ( int k = filled; k < AA_MAX_BATCH; k++ ) list.f[k] = nullptr;
+        if ( aa_status st = zero_ws( ctx, ctx->ws, filled / 4, max_mbh ) ) return st;
+        LaunchTimer t( ctx, 2 );
+        if ( const int e = aa::launch_loopfilter_rows4( list, filled / 4, max_mbh, ctx->ws, ctx->n_xcd, ctx->compute ) ) return hip_fail( static_cast<hipError_t>( e ), "k_loopfilter_rows4" );
+        filled = 0;
+        return AA_OK;
+      };
+      for ( size_t i = 0; i < keyed.size(); ) {
+        size_t j = i;
+        while ( j < keyed.size() && j - i < 4 && keyed[j].first == keyed[i].first ) j++;
+        for ( size_t k = 0; k < 4; k++ ) list.f[filled++] = i + k < j ? keyed[i + k].second : nullptr;
+        i = j;
+        if ( filled + 4 > AA_MAX_BATCH ) if ( aa_status st = launch() ) return st;
+      }
+      if ( aa_status st = launch() ) return st;
+    }
     return AA_OK;
   }
   // ---- ALFALFA_AMD_SCHEDULE=diagonal: the kernel boundary is the inter-workgroup synchronisation ----

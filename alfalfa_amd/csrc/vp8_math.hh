@@ -1,7 +1,7 @@
 // Per-element integer arithmetic of the VP8 reconstruction path, shared by every HIP kernel.
 //
 // Everything here is a pure function of its arguments (no memory, no lane ids) and is marked
-// AA_HD so that tests/csrc/math_check.cpp can compile the SAME source for the host and pin it
+// AA_HD so that tests/cpp/math_check.cc can compile the SAME source for the host and pin it
 // against the oracle on CPU; the product only ever calls these from device code.
 // Reference: transform.cc:47-137 (iWHT, IDCT), quantization.cc:118-121 (dequant), prediction.cc
 // (intra predictors :197-618, six-tap :645-653,861-915), loopfilter_filters.hh:50-183.
@@ -235,6 +235,129 @@ AA_HD void lf_macroblock( bool mask, bool hev, int & p2, int & p1, int & p0, int
   q1 = ( sclamp( qs1 - u ) ^ 0x80 ) & 0xFF; p1 = ( sclamp( ps1 + u ) ^ 0x80 ) & 0xFF;
   u = sclamp( ( 63 + f * 9 ) >> 7 );
   q2 = ( sclamp( qs2 - u ) ^ 0x80 ) & 0xFF; p2 = ( sclamp( ps2 + u ) ^ 0x80 ) & 0xFF;
+}
+
+// ---- packed arithmetic: two int16 lanes per 32-bit register (v_pk_*_i16 on gfx950) ------------------------------------
+// The loop filter works on pixel values 0..255 and intermediates within +-3600, so two filter positions fit one VGPR and
+// every VALU instruction does the work of two.  On the host the same functions are emulated half by half (math_check).
+typedef uint32_t pk2;
+#if defined( __HIP_DEVICE_COMPILE__ )
+typedef short pk_v2s __attribute__( ( ext_vector_type( 2 ) ) );
+typedef unsigned short pk_v2u __attribute__( ( ext_vector_type( 2 ) ) );
+AA_HD pk_v2s pk_s( pk2 a ) { return __builtin_bit_cast( pk_v2s, a ); }
+AA_HD pk2 pk_r( pk_v2s a ) { return __builtin_bit_cast( pk2, a ); }
+AA_HD pk2 pk_add( pk2 a, pk2 b ) { return pk_r( pk_s( a ) + pk_s( b ) ); }
+AA_HD pk2 pk_sub( pk2 a, pk2 b ) { return pk_r( pk_s( a ) - pk_s( b ) ); }
+AA_HD pk2 pk_min( pk2 a, pk2 b ) { return pk_r( __builtin_elementwise_min( pk_s( a ), pk_s( b ) ) ); }
+AA_HD pk2 pk_max( pk2 a, pk2 b ) { return pk_r( __builtin_elementwise_max( pk_s( a ), pk_s( b ) ) ); }
+AA_HD pk2 pk_mul( pk2 a, pk2 b ) { return pk_r( pk_s( a ) * pk_s( b ) ); }
+template <int N> AA_HD pk2 pk_ashr( pk2 a ) { return pk_r( pk_s( a ) >> static_cast<short>( N ) ); }
+template <int N> AA_HD pk2 pk_shl( pk2 a ) { return pk_r( pk_s( a ) << static_cast<short>( N ) ); }
+template <int N> AA_HD pk2 pk_lshr( pk2 a ) { return __builtin_bit_cast( pk2, __builtin_bit_cast( pk_v2u, a ) >> static_cast<unsigned short>( N ) ); }
+#else
+AA_HD int pk_lo( pk2 a ) { return static_cast<int16_t>( a & 0xFFFFu ); }
+AA_HD int pk_hi( pk2 a ) { return static_cast<int16_t>( a >> 16 ); }
+AA_HD pk2 pk_make( int lo, int hi ) { return ( static_cast<uint32_t>( lo ) & 0xFFFFu ) | ( static_cast<uint32_t>( hi ) << 16 ); }
+AA_HD pk2 pk_add( pk2 a, pk2 b ) { return pk_make( pk_lo( a ) + pk_lo( b ), pk_hi( a ) + pk_hi( b ) ); }
+AA_HD pk2 pk_sub( pk2 a, pk2 b ) { return pk_make( pk_lo( a ) - pk_lo( b ), pk_hi( a ) - pk_hi( b ) ); }
+AA_HD pk2 pk_min( pk2 a, pk2 b ) { return pk_make( pk_lo( a ) < pk_lo( b ) ? pk_lo( a ) : pk_lo( b ), pk_hi( a ) < pk_hi( b ) ? pk_hi( a ) : pk_hi( b ) ); }
+AA_HD pk2 pk_max( pk2 a, pk2 b ) { return pk_make( pk_lo( a ) > pk_lo( b ) ? pk_lo( a ) : pk_lo( b ), pk_hi( a ) > pk_hi( b ) ? pk_hi( a ) : pk_hi( b ) ); }
+AA_HD pk2 pk_mul( pk2 a, pk2 b ) { return pk_make( pk_lo( a ) * pk_lo( b ), pk_hi( a ) * pk_hi( b ) ); }
+template <int N> AA_HD pk2 pk_ashr( pk2 a ) { return pk_make( pk_lo( a ) >> N, pk_hi( a ) >> N ); }
+template <int N> AA_HD pk2 pk_shl( pk2 a ) { return pk_make( pk_lo( a ) << N, pk_hi( a ) << N ); }
+template <int N> AA_HD pk2 pk_lshr( pk2 a ) { return pk_make( ( a & 0xFFFFu ) >> N, ( a >> 16 ) >> N ); }
+#endif
+AA_HD pk2 pk_splat( int v ) { return ( static_cast<uint32_t>( v ) & 0xFFFFu ) * 0x10001u; }
+AA_HD pk2 pk_absdiff( pk2 a, pk2 b ) { return pk_max( pk_sub( a, b ), pk_sub( b, a ) ); }
+AA_HD pk2 pk_sclamp( pk2 a ) { return pk_min( pk_max( a, pk_splat( -128 ) ), pk_splat( 127 ) ); }
+AA_HD pk2 pk_clamp255( pk2 a ) { return pk_min( pk_max( a, 0u ), pk_splat( 255 ) ); }
+// per half: 0xFFFF where x <= 0 / x > 0 (x signed), else 0 -- no compare instructions (there is no packed compare)
+AA_HD pk2 pk_mask_le0( pk2 x ) { return pk_sub( pk_min( pk_max( x, 0u ), pk_splat( 1 ) ), pk_splat( 1 ) ); }
+AA_HD pk2 pk_mask_gt0( pk2 x ) { return pk_sub( 0u, pk_min( pk_max( x, 0u ), pk_splat( 1 ) ) ); }
+
+// v_perm_b32: byte k of the result is byte sel[k] of the 8-byte value {hi:lo} (0..3 = lo, 4..7 = hi), 0x0c = constant 0
+AA_HD uint32_t perm_b32( uint32_t hi, uint32_t lo, uint32_t sel )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+  return __builtin_amdgcn_perm( hi, lo, sel );
+#else
+  const uint64_t both = ( static_cast<uint64_t>( hi ) << 32 ) | lo;
+  uint32_t r = 0;
+  for ( int k = 0; k < 4; k++ ) {
+    const uint32_t s = ( sel >> ( 8 * k ) ) & 0xFFu;
+    const uint32_t byte = s <= 7 ? static_cast<uint32_t>( ( both >> ( 8 * s ) ) & 0xFFu ) : 0u;   // only 0..7 and 0x0c are used
+    r |= byte << ( 8 * k );
+  }
+  return r;
+#endif
+}
+// byte K of dword a (-> low half) and of dword b (-> high half), zero-extended
+template <int K> AA_HD pk2 pk_from_bytes( uint32_t a, uint32_t b ) { return perm_b32( b, a, 0x0c000c00u | ( ( 4u + K ) << 16 ) | K ); }
+// the two bytes of a 16-bit LDS read -> {byte 0, byte 1}, and back
+AA_HD pk2 pk_from_u16( uint32_t w ) { return perm_b32( 0u, w, 0x0c010c00u ); }
+AA_HD uint32_t pk_to_u16( pk2 v ) { return perm_b32( 0u, v, 0x0c0c0200u ); }
+// four packed pixels (x0..x3 of both positions) -> the dword of position A (low halves) and of position B (high halves)
+AA_HD void pk_to_dwords( pk2 x0, pk2 x1, pk2 x2, pk2 x3, uint32_t & a, uint32_t & b )
+{
+  const uint32_t t01 = perm_b32( x1, x0, 0x06020400u ), t23 = perm_b32( x3, x2, 0x06020400u );    // {A0,A1,B0,B1}, {A2,A3,B2,B3}
+  a = perm_b32( t23, t01, 0x05040100u ); b = perm_b32( t23, t01, 0x07060302u );
+}
+
+struct LfParamsPk { pk2 interior_limit, mb_limit, sb_limit, hev_threshold; };
+AA_HD LfParamsPk lf_params_pk( const LfParams & p )
+{
+  LfParamsPk q;
+  q.interior_limit = pk_splat( p.interior_limit ); q.mb_limit = pk_splat( p.mb_limit );
+  q.sb_limit = pk_splat( p.sb_limit ); q.hev_threshold = pk_splat( p.hev_threshold );
+  return q;
+}
+
+// lf_mask / lf_hev of two filter positions at once; `gate` (0 or ~0 per half) switches positions off.
+AA_HD void lf_masks_pk( pk2 limit, pk2 blimit, pk2 thresh, pk2 gate, pk2 p3, pk2 p2, pk2 p1, pk2 p0, pk2 q0, pk2 q1, pk2 q2, pk2 q3,
+                        pk2 & mask, pk2 & hev )
+{
+  const pk2 dp = pk_absdiff( p1, p0 ), dq = pk_absdiff( q1, q0 );
+  const pk2 inner = pk_max( dp, dq );
+  const pk2 m = pk_max( pk_max( pk_max( pk_absdiff( p3, p2 ), pk_absdiff( p2, p1 ) ), inner ),
+                        pk_max( pk_absdiff( q2, q1 ), pk_absdiff( q3, q2 ) ) );
+  const pk2 e = pk_add( pk_shl<1>( pk_absdiff( p0, q0 ) ), pk_lshr<1>( pk_absdiff( p1, q1 ) ) );
+  mask = pk_mask_le0( pk_max( pk_sub( m, limit ), pk_sub( e, blimit ) ) ) & gate;
+  hev = pk_mask_gt0( pk_sub( inner, thresh ) );
+}
+// lf_subblock on two positions (pixel values stay in the unsigned domain: sclamp(a - 128 + d) + 128 == clamp255(a + d))
+AA_HD void lf_subblock_pk( pk2 mask, pk2 hev, pk2 & p1, pk2 & p0, pk2 & q0, pk2 & q1 )
+{
+  const pk2 a = pk_sclamp( pk_sub( p1, q1 ) ) & hev;
+  const pk2 f = pk_sclamp( pk_add( pk_mul( pk_sub( q0, p0 ), pk_splat( 3 ) ), a ) ) & mask;
+  const pk2 f1 = pk_ashr<3>( pk_min( pk_add( f, pk_splat( 4 ) ), pk_splat( 127 ) ) );
+  const pk2 f2 = pk_ashr<3>( pk_min( pk_add( f, pk_splat( 3 ) ), pk_splat( 127 ) ) );
+  q0 = pk_clamp255( pk_sub( q0, f1 ) ); p0 = pk_clamp255( pk_add( p0, f2 ) );
+  const pk2 g = pk_ashr<1>( pk_add( f1, pk_splat( 1 ) ) ) & ~hev;
+  q1 = pk_clamp255( pk_sub( q1, g ) ); p1 = pk_clamp255( pk_add( p1, g ) );
+}
+// lf_macroblock on two positions
+AA_HD void lf_macroblock_pk( pk2 mask, pk2 hev, pk2 & p2, pk2 & p1, pk2 & p0, pk2 & q0, pk2 & q1, pk2 & q2 )
+{
+  const pk2 w = pk_sclamp( pk_add( pk_mul( pk_sub( q0, p0 ), pk_splat( 3 ) ), pk_sclamp( pk_sub( p1, q1 ) ) ) ) & mask;
+  const pk2 fh = w & hev;
+  const pk2 f1 = pk_ashr<3>( pk_min( pk_add( fh, pk_splat( 4 ) ), pk_splat( 127 ) ) );
+  const pk2 f2 = pk_ashr<3>( pk_min( pk_add( fh, pk_splat( 3 ) ), pk_splat( 127 ) ) );
+  const pk2 Q0 = pk_clamp255( pk_sub( q0, f1 ) ), P0 = pk_clamp255( pk_add( p0, f2 ) );
+  const pk2 f = w & ~hev;                        // |63 + f * 27| <= 3519: the reference's clamp of u never acts
+  pk2 u = pk_ashr<7>( pk_add( pk_mul( f, pk_splat( 27 ) ), pk_splat( 63 ) ) );
+  q0 = pk_clamp255( pk_sub( Q0, u ) ); p0 = pk_clamp255( pk_add( P0, u ) );
+  u = pk_ashr<7>( pk_add( pk_mul( f, pk_splat( 18 ) ), pk_splat( 63 ) ) );
+  q1 = pk_clamp255( pk_sub( q1, u ) ); p1 = pk_clamp255( pk_add( p1, u ) );
+  u = pk_ashr<7>( pk_add( pk_mul( f, pk_splat( 9 ) ), pk_splat( 63 ) ) );
+  q2 = pk_clamp255( pk_sub( q2, u ) ); p2 = pk_clamp255( pk_add( p2, u ) );
+}
+// One edge on two positions: eight packed pixels p3..q3 across the edge, in place.
+AA_HD void lf_edge_pk( const LfParamsPk & P, bool mb_edge, pk2 gate, pk2 & p3, pk2 & p2, pk2 & p1, pk2 & p0, pk2 & q0, pk2 & q1, pk2 & q2, pk2 & q3 )
+{
+  pk2 mask, hev;
+  lf_masks_pk( P.interior_limit, mb_edge ? P.mb_limit : P.sb_limit, P.hev_threshold, gate, p3, p2, p1, p0, q0, q1, q2, q3, mask, hev );
+  if ( mb_edge ) lf_macroblock_pk( mask, hev, p2, p1, p0, q0, q1, q2 );
+  else lf_subblock_pk( mask, hev, p1, p0, q0, q1 );
 }
 
 } // namespace aa
