@@ -33,7 +33,7 @@ struct aa_sync_ws {
 };
 #define AA_SYNC_WS_ZERO_FROM 16   // byte offset of `ticket`
 
-#define AA_MAX_BATCH 120       // frames per launch and kind: kernel argument = 120 pointers (960 B) passed by value
+#define AA_MAX_BATCH 480       // frames per launch and kind: kernel argument = 480 pointers (3840 B) passed by value (limit 4 KB)
 
 struct aa_frame_list {
   const aa_dev_frame * f[AA_MAX_BATCH];

@@ -666,6 +666,7 @@ __global__ __launch_bounds__( kLanes ) void k_loopfilter( const aa_frame_list li
 struct alignas( 16 ) LfTile4 {
   uint8_t c[12][32];     // rows -4..7; U in bytes 0..15 (columns -4..-1 at 4..7, 0..7 at 8..15), V in bytes 16..31
   uint8_t y[20][32];     // rows -4..15; columns -4..-1 at 12..15, columns 0..15 at 16..31
+  uint8_t pad[32];       // 1056-byte stride: the four slots of a wave land on different LDS banks (all lanes read the same row)
 };
 struct alignas( 16 ) LfRows4Lds { LfTile4 tile[4]; };
 
@@ -694,7 +695,7 @@ __device__ __forceinline__ void lf_edges_pk( pk2 ( &v )[20], const LfParamsPk & 
 // min(col+2, mbw); fetch the four rows above with sc1 (L1-bypassing, L2-served) loads; H phase; store (ordinary stores:
 // the next row's workgroup runs on the same XCD and finds rows 12..15 in its L2).
 __device__ __forceinline__ void loopfilter_rows4_row( const aa_frame_list & list, const int group, const int row, const int mbh_max, aa_sync_ws * ws,
-                                                       LfRows4Lds & S )
+                                                       LfRows4Lds & S, const int dbg )
 {
   const int lane = threadIdx.x, slot = lane >> 4, l = lane & 15;
   const aa_dev_frame & f0 = *list.f[group * 4];
@@ -744,7 +745,7 @@ __device__ __forceinline__ void loopfilter_rows4_row( const aa_frame_list & list
       pending = -1;
       continue;
     }
-    if ( active && !prefetched ) { pre_y = *reinterpret_cast<const uint4 *>( yrow + x0 ); pre_c = *reinterpret_cast<const uint2 *>( crow + cx0 ); }
+    if ( active && !prefetched && !( dbg & 2 ) ) { pre_y = *reinterpret_cast<const uint4 *>( yrow + x0 ); pre_c = *reinterpret_cast<const uint2 *>( crow + cx0 ); }
     if ( active && !carried && col > 0 ) {   // left neighbour columns straight from memory
       *reinterpret_cast<uint32_t *>( ly - 4 ) = *reinterpret_cast<const uint32_t *>( yrow + x0 - 4 );
       *reinterpret_cast<uint32_t *>( lc - 4 ) = *reinterpret_cast<const uint32_t *>( crow + cx0 - 4 );
@@ -772,7 +773,7 @@ __device__ __forceinline__ void loopfilter_rows4_row( const aa_frame_list & list
         v[4 * d] = pk_from_bytes<0>( a[d], b[d] ); v[4 * d + 1] = pk_from_bytes<1>( a[d], b[d] );
         v[4 * d + 2] = pk_from_bytes<2>( a[d], b[d] ); v[4 * d + 3] = pk_from_bytes<3>( a[d], b[d] );
       }
-      lf_edges_pk( v, P, col > 0 ? g_on : 0u, g_in, g_in23 );
+      if ( !( dbg & 4 ) ) lf_edges_pk( v, P, col > 0 ? g_on : 0u, g_in, g_in23 );
 #pragma unroll
       for ( int d = 0; d < 5; d++ ) pk_to_dwords( v[4 * d], v[4 * d + 1], v[4 * d + 2], v[4 * d + 3], a[d], b[d] );
       if ( active ) {
@@ -787,18 +788,18 @@ __device__ __forceinline__ void loopfilter_rows4_row( const aa_frame_list & list
     pending = -1;
     // prefetch the next macroblock's own rows (consumed at the top of the next step)
     prefetched = more && ( info_next >> 8 ) != 0;
-    if ( prefetched ) { pre_y = *reinterpret_cast<const uint4 *>( yrow + x0 + 16 ); pre_c = *reinterpret_cast<const uint2 *>( crow + cx0 + 8 ); }
+    if ( prefetched && !( dbg & 2 ) ) { pre_y = *reinterpret_cast<const uint4 *>( yrow + x0 + 16 ); pre_c = *reinterpret_cast<const uint2 *>( crow + cx0 + 8 ); }
 
     if ( row > 0 ) {
       int spins = 0;
-      while ( !__all( seen >= need ) ) {
+      while ( !__all( seen >= need ) && !( dbg & 16 ) ) {
         __builtin_amdgcn_s_sleep( 4 );
         if ( seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
         ++spins;
         if ( ( spins & 1023 ) == 0 && __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
         if ( spins > ( 1 << 21 ) ) { atomicExch( &ws->error, 2 ); break; }
       }
-      if ( active ) *reinterpret_cast<uint64_t *>( ltop ) = load_u64_shared( toprow + col * topstep );
+      if ( active && !( dbg & 8 ) ) *reinterpret_cast<uint64_t *>( ltop ) = load_u64_shared( toprow + col * topstep );
     }
     __syncthreads();
 
@@ -806,7 +807,7 @@ __device__ __forceinline__ void loopfilter_rows4_row( const aa_frame_list & list
       pk2 v[20];
 #pragma unroll
       for ( int r = 0; r < 20; r++ ) v[r] = pk_from_u16( *reinterpret_cast<const uint16_t *>( hbase + 32 * r ) );
-      lf_edges_pk( v, P, row > 0 ? g_on : 0u, g_in, g_in23 );
+      if ( !( dbg & 4 ) ) lf_edges_pk( v, P, row > 0 ? g_on : 0u, g_in, g_in23 );
       if ( active ) {
 #pragma unroll
         for ( int r = 1; r < 12; r++ ) *reinterpret_cast<uint16_t *>( hbase + 32 * r ) = static_cast<uint16_t>( pk_to_u16( v[r] ) );
@@ -820,13 +821,15 @@ __device__ __forceinline__ void loopfilter_rows4_row( const aa_frame_list & list
 
     if ( active ) {
       const uint4 oy = *reinterpret_cast<const uint4 *>( ly ); const uint2 oc = *reinterpret_cast<const uint2 *>( lc );
-      *reinterpret_cast<uint4 *>( yrow + x0 ) = oy;
-      *reinterpret_cast<uint2 *>( crow + cx0 ) = oc;
-      if ( col > 0 ) {        // columns -4..-1: final now (the left MB edge of this macroblock was the last to touch them)
-        *reinterpret_cast<uint32_t *>( yrow + x0 - 4 ) = *reinterpret_cast<const uint32_t *>( ly - 4 );
-        *reinterpret_cast<uint32_t *>( crow + cx0 - 4 ) = *reinterpret_cast<const uint32_t *>( lc - 4 );
+      if ( !( dbg & 1 ) ) {
+        *reinterpret_cast<uint4 *>( yrow + x0 ) = oy;
+        *reinterpret_cast<uint2 *>( crow + cx0 ) = oc;
+        if ( col > 0 ) {        // columns -4..-1: final now (the left MB edge of this macroblock was the last to touch them)
+          *reinterpret_cast<uint32_t *>( yrow + x0 - 4 ) = *reinterpret_cast<const uint32_t *>( ly - 4 );
+          *reinterpret_cast<uint32_t *>( crow + cx0 - 4 ) = *reinterpret_cast<const uint32_t *>( lc - 4 );
+        }
+        if ( row > 0 ) *reinterpret_cast<uint64_t *>( toprow + col * topstep ) = *reinterpret_cast<const uint64_t *>( ltop );
       }
-      if ( row > 0 ) *reinterpret_cast<uint64_t *>( toprow + col * topstep ) = *reinterpret_cast<const uint64_t *>( ltop );
       // carry the filtered right edge over as the next macroblock's left neighbour columns
       *reinterpret_cast<uint32_t *>( ly - 4 ) = *reinterpret_cast<const uint32_t *>( ly + 12 );
       *reinterpret_cast<uint32_t *>( lc - 4 ) = *reinterpret_cast<const uint32_t *>( lc + 4 );
@@ -842,7 +845,7 @@ __device__ __forceinline__ void loopfilter_rows4_row( const aa_frame_list & list
 
 // ticket t of queue x -> (group (t / mbh_max) * n_xcd + x, row t % mbh_max)
 __device__ __forceinline__ void loopfilter_rows4_body( const aa_frame_list & list, const int n_groups, const int mbh_max, aa_sync_ws * ws, const int n_xcd,
-                                                        LfRows4Lds & S, int & s_ticket )
+                                                        LfRows4Lds & S, int & s_ticket, const int dbg )
 {
   const int xcc = xcc_id();
   if ( xcc >= n_xcd ) { if ( threadIdx.x == 0 ) atomicExch( &ws->error, 3 ); return; }
@@ -850,16 +853,16 @@ __device__ __forceinline__ void loopfilter_rows4_body( const aa_frame_list & lis
     const int t = take_ticket( ws, xcc, &s_ticket, threadIdx.x );
     const int group = ( t / mbh_max ) * n_xcd + xcc;
     if ( group >= n_groups ) return;
-    loopfilter_rows4_row( list, group, t % mbh_max, mbh_max, ws, S );
+    loopfilter_rows4_row( list, group, t % mbh_max, mbh_max, ws, S, dbg );
   }
 }
 
 // grid.x = n_xcd * ceil(n_groups / n_xcd) * mbh_max workgroups
-__global__ __launch_bounds__( kLanes ) void k_loopfilter_rows4( const aa_frame_list list, const int n_groups, const int mbh_max, aa_sync_ws * ws, const int n_xcd )
+__global__ __launch_bounds__( kLanes ) void k_loopfilter_rows4( const aa_frame_list list, const int n_groups, const int mbh_max, aa_sync_ws * ws, const int n_xcd, const int dbg )
 {
   __shared__ LfRows4Lds S;
   __shared__ int s_ticket;
-  loopfilter_rows4_body( list, n_groups, mbh_max, ws, n_xcd, S, s_ticket );
+  loopfilter_rows4_body( list, n_groups, mbh_max, ws, n_xcd, S, s_ticket, dbg );
 }
 
 // Which XCDs do workgroups of this device land on?  out[x] = number of workgroups of the launch that ran on XCD x.
@@ -886,6 +889,13 @@ int launch_loopfilter_diagonal( const aa_frame_list & list, int n, int diagonal,
   hipLaunchKernelGGL( k_loopfilter, dim3( rows, n ), dim3( kLanes ), 0, static_cast<hipStream_t>( stream ), list, diagonal, row_lo );
   return static_cast<int>( hipGetLastError() );
 }
+// Measurement hook (tools/row_kernel_probe.py): ALFALFA_AMD_LF_DEBUG=<bits> switches parts of the loop-filter row kernel
+// OFF (1 stores, 2 own-row loads, 4 filter arithmetic, 8 loads of the rows above, 16 waiting).  Output is then invalid.
+static int lf_debug_bits()
+{
+  static const int bits = [] { const char * e = std::getenv( "ALFALFA_AMD_LF_DEBUG" ); return e ? std::atoi( e ) : 0; }();
+  return bits;
+}
 // Test hook: ALFALFA_AMD_TEST_LDS_PAD=<bytes> adds dynamic LDS to the row-pipelined launches to force PARTIAL residency
 // (the ordering protocol must not depend on every workgroup being resident).
 static unsigned test_lds_pad()
@@ -900,7 +910,7 @@ int launch_recon_intra_rows( const aa_frame_list & list, int n, int mbh_max, aa_
 }
 int launch_loopfilter_rows4( const aa_frame_list & list, int n_groups, int mbh_max, aa_sync_ws * ws, int n_xcd, void * stream )
 {
-  hipLaunchKernelGGL( k_loopfilter_rows4, dim3( n_xcd * ( ( n_groups + n_xcd - 1 ) / n_xcd ) * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n_groups, mbh_max, ws, n_xcd );
+  hipLaunchKernelGGL( k_loopfilter_rows4, dim3( n_xcd * ( ( n_groups + n_xcd - 1 ) / n_xcd ) * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n_groups, mbh_max, ws, n_xcd, lf_debug_bits() );
   return static_cast<int>( hipGetLastError() );
 }
 int launch_probe_xcds( int * out16, int blocks, void * stream )

@@ -272,8 +272,9 @@ AA_HD pk2 pk_absdiff( pk2 a, pk2 b ) { return pk_max( pk_sub( a, b ), pk_sub( b,
 AA_HD pk2 pk_sclamp( pk2 a ) { return pk_min( pk_max( a, pk_splat( -128 ) ), pk_splat( 127 ) ); }
 AA_HD pk2 pk_clamp255( pk2 a ) { return pk_min( pk_max( a, 0u ), pk_splat( 255 ) ); }
 // per half: 0xFFFF where x <= 0 / x > 0 (x signed), else 0 -- no compare instructions (there is no packed compare)
-AA_HD pk2 pk_mask_le0( pk2 x ) { return pk_sub( pk_min( pk_max( x, 0u ), pk_splat( 1 ) ), pk_splat( 1 ) ); }
-AA_HD pk2 pk_mask_gt0( pk2 x ) { return pk_sub( 0u, pk_min( pk_max( x, 0u ), pk_splat( 1 ) ) ); }
+// (|x| is far below 2^15 here, so x - 1 and -x cannot wrap: the sign bit smeared over the half is the answer)
+AA_HD pk2 pk_mask_le0( pk2 x ) { return pk_ashr<15>( pk_sub( x, pk_splat( 1 ) ) ); }
+AA_HD pk2 pk_mask_gt0( pk2 x ) { return pk_ashr<15>( pk_sub( 0u, x ) ); }
 
 // v_perm_b32: byte k of the result is byte sel[k] of the 8-byte value {hi:lo} (0..3 = lo, 4..7 = hi), 0x0c = constant 0
 AA_HD uint32_t perm_b32( uint32_t hi, uint32_t lo, uint32_t sel )

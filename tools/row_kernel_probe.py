@@ -42,6 +42,7 @@ def run(config, S, F=3):
 
 if __name__ == "__main__":
     Ss = [int(a) for a in sys.argv[1:]] or [4, 32, 120]
-    for cfg in ("probe_1row", "probe_4rows", "probe_1col", "1080p_inter_lf"):
+    cfgs = os.environ.get("PROBE_CONFIGS", "probe_1row,probe_4rows,probe_1col,1080p_inter_lf").split(",")
+    for cfg in cfgs:
         for S in Ss:
             run(cfg, S)
