@@ -654,21 +654,34 @@ __global__ __launch_bounds__( kLanes ) void k_loopfilter( const aa_frame_list li
   }
 }
 
-// ---- row-pipelined loop filter, packed arithmetic, FOUR frames per wave ----------------------------------------------
+// ---- row-pipelined loop filter: packed arithmetic, FOUR frames per wave, strip-staged I/O ----------------------------
 // 16 lanes per frame ("slot").  A lane filters TWO positions of an edge at once in packed int16 (vp8_math.hh pk2):
 //   vertical edges   (V phase): lane j < 8 owns luma pixel rows 2j, 2j+1; lane 8+k owns chroma rows 2(k&3), +1 of plane k>>2;
 //   horizontal edges (H phase): lane j < 8 owns luma columns 2j, 2j+1;    lane 8+k the chroma columns likewise.
-// A lane keeps its two 20-pixel lines (12 for chroma) in registers for all four (two) edges of the phase, so the LDS
-// tile is read and written once per phase instead of once per edge.  Chroma lanes run the SAME instruction stream as
-// luma lanes (same row stride, edges 2 and 3 gated off), so a step costs one luma lane's instructions for four
-// macroblocks.  The tile keeps chroma in front of luma so that the chroma lanes' (ignored) reads of rows 12..19 stay
-// inside the tile.
-struct alignas( 16 ) LfTile4 {
-  uint8_t c[12][32];     // rows -4..7; U in bytes 0..15 (columns -4..-1 at 4..7, 0..7 at 8..15), V in bytes 16..31
-  uint8_t y[20][32];     // rows -4..15; columns -4..-1 at 12..15, columns 0..15 at 16..31
-  uint8_t pad[32];       // 1056-byte stride: the four slots of a wave land on different LDS banks (all lanes read the same row)
+// A lane keeps its two 20-pixel lines (12 for chroma) in registers for all four (two) edges of a phase.  Chroma lanes
+// run the SAME instruction stream as luma lanes (same LDS row stride, edges 2 and 3 gated off).
+//
+// Memory traffic is what bounded the per-macroblock version of this kernel (every lane of every load/store touched its
+// own 128-byte line: ~130 L2 requests per macroblock).  Here a workgroup stages a STRIP of eight macroblocks (128 luma
+// columns = one cache line per pixel row) in LDS:
+//   * the strip's own 16 rows are loaded with lanes running ALONG rows (whole lines), one strip ahead, into registers;
+//   * the filter phases work in place on the strip;
+//   * rows [16r-4, 16r+12) of the frame -- final once this macroblock row has passed -- are stored back whole-line at the
+//     end of the strip; only the strip's last four columns, which the next strip's left MB edge still modifies, follow
+//     as 4-byte fix-ups;
+//   * the bottom four rows (chroma: four) are NOT written to the frame by this row: they go, one 128-byte line per
+//     macroblock, to a BOUNDARY buffer; the workgroup of the next macroblock row reads that line as its rows -4..-1,
+//     finishes them with its top MB edge and stores them with its own strip.  Frame rows are therefore written by
+//     exactly one workgroup and cross-row hand-off costs one line per macroblock each way (+ a 4-byte-column fix-up).
+constexpr int kStripMbs = 8;
+struct alignas( 16 ) LfStrip {
+  uint8_t c[12][144];        // chroma rows -4..7 of the MB row: U strip columns 0..63 at bytes 16..79, V at 80..143
+  uint8_t y[20][144];        // luma rows -4..15: strip columns 0..127 at bytes 16..143 (144 = odd multiple of 16: rows spread over banks)
+  uint8_t halo_y[16][4];     // columns -4..-1 of rows 0..15: the previous strip's right edge
+  uint8_t halo_c[2][8][4];
+  uint8_t pad[32];           // the four slots of a wave start on different banks
 };
-struct alignas( 16 ) LfRows4Lds { LfTile4 tile[4]; };
+struct alignas( 16 ) LfStripLds { LfStrip slot[4]; };
 
 __device__ __forceinline__ uint64_t load_u64_shared( const uint8_t * p )
 {
@@ -688,164 +701,226 @@ __device__ __forceinline__ void lf_edges_pk( pk2 ( &v )[20], const LfParamsPk & 
   }
 }
 
-// ticket -> (group of four frames with one geometry, MB row); list.f[4g] is never null, the host pads groups with null.
-// Per macroblock step: own 16 rows are PREFETCHED one step ahead with plain 128/64-bit loads (earlier launches produced
-// them); the four columns to the left are the previous step's right edge, carried in LDS; V phase; the previous step's
-// progress is published once its stores have drained (they drain behind the V phase); wait for progress[row-1] >=
-// min(col+2, mbw); fetch the four rows above with sc1 (L1-bypassing, L2-served) loads; H phase; store (ordinary stores:
-// the next row's workgroup runs on the same XCD and finds rows 12..15 in its L2).
-__device__ __forceinline__ void loopfilter_rows4_row( const aa_frame_list & list, const int group, const int row, const int mbh_max, aa_sync_ws * ws,
-                                                       LfRows4Lds & S, const int dbg )
+// One macroblock row of a group of four frames of one geometry (list.f[4g] is never null, the host pads with null).
+// bnd: boundary buffer, 128 bytes per (frame of the launch, MB row, MB column): luma rows 12..15 x 16 B, U rows 4..7 x 8 B,
+// V rows 4..7 x 8 B of that macroblock after its own filtering.
+__device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list, const int group, const int row, const int mbh_max, const int mbw_max,
+                                                       aa_sync_ws * ws, uint8_t * bnd, LfStripLds & S, const int dbg )
 {
   const int lane = threadIdx.x, slot = lane >> 4, l = lane & 15;
   const aa_dev_frame & f0 = *list.f[group * 4];
-  if ( row >= f0.mbh ) return;
+  const int mbh = f0.mbh;
+  if ( row >= mbh ) return;
   const aa_dev_frame * const fp = list.f[group * 4 + slot];
   const bool frame_on = fp != nullptr && fp->loop_filter_level != 0;
   if ( !__any( frame_on ) ) return;
   const aa_dev_frame & f = fp ? *fp : f0;
-  LfTile4 & T = S.tile[slot];
+  LfStrip & T = S.slot[slot];
   int * const progress = ws->progress + group * mbh_max;
   const int mbw = f0.mbw, pw = mbw * 16, cw = pw >> 1;
   const int y0 = row * 16, cy0 = row * 8;
   const int sharp = f.sharpness; const bool key = f.key_frame;
+  const bool last_row = row == mbh - 1;
   const bool luma = l < 8;
-  const int k8 = l & 7;
-  // phase roles
-  uint8_t * const vbase = luma ? &T.y[4 + 2 * l][12] : &T.c[4 + 2 * ( k8 & 3 )][16 * ( k8 >> 2 ) + 4];   // two rows (+32): halo dword, then body
-  uint8_t * const hbase = luma ? &T.y[0][16 + 2 * l] : &T.c[0][16 * ( k8 >> 2 ) + 8 + 2 * ( k8 & 3 )];   // two columns, rows at +32 r
-  // bulk roles: lane l <-> luma row l and chroma row l & 7 of plane l >> 3
-  const int bpl = l >> 3, br = l & 7;
-  uint8_t * const yrow = f.cur[0] + static_cast<size_t>( y0 + l ) * pw;
-  uint8_t * const crow = f.cur[1 + bpl] + static_cast<size_t>( cy0 + br ) * cw;
-  uint8_t * const ly = &T.y[4 + l][16];
-  uint8_t * const lc = &T.c[4 + br][16 * bpl + 8];
-  // rows above: lanes 0..7 luma row -4 + (l >> 1), half l & 1; lanes 8..15 chroma plane k8 >> 2, row -4 + (k8 & 3); 8 bytes each
-  uint8_t * const toprow = luma ? f.cur[0] + static_cast<ptrdiff_t>( y0 - 4 + ( l >> 1 ) ) * pw + 8 * ( l & 1 )
-                                : f.cur[1 + ( k8 >> 2 )] + static_cast<ptrdiff_t>( cy0 - 4 + ( k8 & 3 ) ) * cw;
-  uint8_t * const ltop = luma ? &T.y[l >> 1][16 + 8 * ( l & 1 )] : &T.c[k8 & 3][16 * ( k8 >> 2 ) + 8];
-  const int topstep = luma ? 16 : 8;
+  const int k8 = l & 7, cp = k8 >> 2, cj = k8 & 3;     // chroma lanes (l >= 8): plane, line/column pair
+  // ---- phase roles (pointers for strip position 0; + 16 k (luma) / 8 k (chroma) per macroblock) ----
+  uint8_t * const vrow = luma ? &T.y[4 + 2 * l][16] : &T.c[4 + 2 * cj][16 + 64 * cp];          // row A; row B at +144
+  uint8_t * const vhalo = luma ? &T.halo_y[2 * l][0] : &T.halo_c[cp][2 * cj][0];                // row A; row B at +4
+  uint8_t * const hcol = luma ? &T.y[0][16 + 2 * l] : &T.c[0][16 + 64 * cp + 2 * cj];          // rows at +144 r
+  const int mbstep = luma ? 16 : 8;
+  // ---- bulk roles: lanes along rows.  instr i: luma row 2i + (l>>3), 16-byte chunk l&7 (= MB of the strip);
+  //      chroma plane i>>2, row 2(i&3) + (l>>3), 8-byte chunk l&7 ----
+  const int brow = l >> 3, bchunk = l & 7;
+  uint8_t * const gy = f.cur[0] + static_cast<size_t>( y0 + brow ) * pw + 16 * bchunk;          // + 2 i pw + 128 s
+  uint8_t * const gu = f.cur[1] + static_cast<size_t>( cy0 + brow ) * cw + 8 * bchunk;          // + 2 i cw + 64 s
+  uint8_t * const gv = f.cur[2] + static_cast<size_t>( cy0 + brow ) * cw + 8 * bchunk;
+  uint8_t * const sy = &T.y[4 + brow][16 + 16 * bchunk];                                        // + 288 i
+  uint8_t * const sc = &T.c[4 + brow][16 + 8 * bchunk];                                         // + 288 i (+ 64 for V)
+  // ---- boundary roles: lanes 0..3 luma rows 12..15 (16 B), 4,5 U row pairs (2 x 8 B), 6,7 V ----
+  const int bl = l & 7, bq = ( bl - 4 ) & 3;
+  uint8_t * const bsrc = bl < 4 ? &T.y[16 + bl][16] : &T.c[8 + 2 * ( bq & 1 )][16 + 64 * ( bq >> 1 )];      // own bottom rows (2nd chroma row at +144)
+  uint8_t * const btop = bl < 4 ? &T.y[bl][16] : &T.c[2 * ( bq & 1 )][16 + 64 * ( bq >> 1 )];                // rows -4..-1
+  const int bstep = bl < 4 ? 16 : 8;
+  const size_t bnd_row = ( static_cast<size_t>( group * 4 + slot ) * mbh_max + row ) * mbw_max;             // in 128-byte lines
+  uint8_t * const bnd_own = bnd + bnd_row * 128 + 16 * bl;
+  const uint8_t * const bnd_top = bnd + ( bnd_row - mbw_max ) * 128 + 16 * bl;
+  // fix-up of the previous macroblock's last four columns in its boundary line: lanes 0..3 luma rows 12..15, 4..7 U rows 4..7, 8..11 V
+  const int fq = l >> 2, fr = l & 3;
+  const int fix_off = fq == 0 ? 16 * fr + 12 : 64 + 32 * ( fq - 1 ) + 8 * fr + 4;
+  uint8_t * const fix_src0 = fq == 0 ? &T.halo_y[12 + fr][0] : &T.halo_c[( fq - 1 ) & 1][4 + fr][0];       // strip position 0: the halo
+  uint8_t * const fix_srck = fq == 0 ? &T.y[16 + fr][16 - 4] : &T.c[8 + fr][16 + 64 * ( ( fq - 1 ) & 1 ) - 4];   // + 16 k / 8 k
+  const int fix_step = fq == 0 ? 16 : 8;
+  // frame fix-up of a finished strip's last four columns: lane l <-> luma row l, chroma plane l>>3 row l&7
+  uint8_t * const fy = f.cur[0] + static_cast<size_t>( y0 + l ) * pw - 4;                        // + 128 s
+  uint8_t * const fc = f.cur[1 + ( l >> 3 )] + static_cast<size_t>( cy0 + ( l & 7 ) ) * cw - 4;  // + 64 s
   const aa_mb_info * const mbrow = f.mbs + static_cast<size_t>( row ) * mbw;
 
+  const int n_strips = ( mbw + kStripMbs - 1 ) / kStripMbs;
+  uint4 py[8]; uint2 pc[8];
+#pragma unroll
+  for ( int i = 0; i < 8; i++ ) { py[i] = make_uint4( 0, 0, 0, 0 ); pc[i] = make_uint2( 0, 0 ); }
+  // own rows of strip s -> registers (lanes along rows: whole lines)
+  auto prefetch = [&]( const int s ) {
+    const bool in = frame_on && !( dbg & 2 ) && s * kStripMbs + bchunk < mbw;
+    if ( in ) {
+#pragma unroll
+      for ( int i = 0; i < 8; i++ ) py[i] = *reinterpret_cast<const uint4 *>( gy + static_cast<size_t>( 2 * i ) * pw + 128 * s );
+#pragma unroll
+      for ( int i = 0; i < 4; i++ ) pc[i] = *reinterpret_cast<const uint2 *>( gu + static_cast<size_t>( 2 * i ) * cw + 64 * s );
+#pragma unroll
+      for ( int i = 0; i < 4; i++ ) pc[4 + i] = *reinterpret_cast<const uint2 *>( gv + static_cast<size_t>( 2 * i ) * cw + 64 * s );
+    }
+  };
+  prefetch( 0 );
   int info = frame_on ? *reinterpret_cast<const uint16_t *>( &mbrow[0].flags ) : 0;     // flags | lf_level << 8
-  bool carried = false, prefetched = false;
-  uint4 pre_y = make_uint4( 0, 0, 0, 0 ); uint2 pre_c = make_uint2( 0, 0 );
   int pending = -1;
-  for ( int col = 0; col < mbw; col++ ) {
-    const int level = info >> 8;
-    const bool active = level != 0;
-    const bool inner = !( info & AA_MB_LF_SKIP_INNER );
-    const int x0 = col * 16, cx0 = col * 8;
-    const bool more = col + 1 < mbw;
-    if ( !__any( active ) ) {           // no frame of the group filters this macroblock
-      info = ( frame_on && more ) ? *reinterpret_cast<const uint16_t *>( &mbrow[col + 1].flags ) : 0;
-      carried = false; prefetched = false;
+  for ( int s = 0; s < n_strips; s++ ) {
+    const int nmb = min( kStripMbs, mbw - s * kStripMbs );
+    // ---- strip turn-over: keep the right edge as the new left neighbour, then drop the prefetched rows in ----
+    if ( s > 0 ) {
+      *reinterpret_cast<uint32_t *>( &T.halo_y[l][0] ) = *reinterpret_cast<const uint32_t *>( &T.y[4 + l][16 + 124] );
+      *reinterpret_cast<uint32_t *>( &T.halo_c[l >> 3][l & 7][0] ) = *reinterpret_cast<const uint32_t *>( &T.c[4 + ( l & 7 )][16 + 64 * ( l >> 3 ) + 60] );
+      __syncthreads();
+    }
+#pragma unroll
+    for ( int i = 0; i < 8; i++ ) *reinterpret_cast<uint4 *>( sy + 288 * i ) = py[i];
+#pragma unroll
+    for ( int i = 0; i < 4; i++ ) { *reinterpret_cast<uint2 *>( sc + 288 * i ) = pc[i]; *reinterpret_cast<uint2 *>( sc + 288 * i + 64 ) = pc[4 + i]; }
+    __syncthreads();
+
+    for ( int k = 0; k < nmb; k++ ) {
+      const int col = s * kStripMbs + k;
+      const int level = info >> 8;
+      const bool active = level != 0;
+      const bool inner = !( info & AA_MB_LF_SKIP_INNER );
+      const bool more = col + 1 < mbw;
+      // in flight during the V phase: the next macroblock's level, the poll of the row above
+      const int info_next = ( frame_on && more ) ? *reinterpret_cast<const uint16_t *>( &mbrow[col + 1].flags ) : 0;
+      const int need = min( col + 2, mbw );
+      int seen = need;
+      if ( row > 0 ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      const bool any_active = __any( active );
+      const LfParamsPk P = lf_params_pk( lf_params( active ? level : 1, sharp, key ) );
+      const pk2 g_on = active ? ~0u : 0u, g_in = ( active && inner ) ? ~0u : 0u, g_in23 = ( active && inner && luma ) ? ~0u : 0u;
+
+      if ( any_active && !( dbg & 4 ) ) {   // ---- V phase: left MB edge, inner vertical edges ----
+        uint8_t * const ra = vrow + mbstep * k;
+        uint8_t * const ha = k == 0 ? vhalo : ra - 4;          // columns -4..-1: the halo at strip position 0, else the previous MB
+        uint8_t * const hb = k == 0 ? vhalo + 4 : ra + 144 - 4;
+        uint32_t a[5], b[5];
+        a[0] = *reinterpret_cast<const uint32_t *>( ha ); b[0] = *reinterpret_cast<const uint32_t *>( hb );
+        { const uint2 u = *reinterpret_cast<const uint2 *>( ra ); a[1] = u.x; a[2] = u.y; }
+        { const uint2 u = *reinterpret_cast<const uint2 *>( ra + 8 ); a[3] = u.x; a[4] = u.y; }
+        { const uint2 u = *reinterpret_cast<const uint2 *>( ra + 144 ); b[1] = u.x; b[2] = u.y; }
+        { const uint2 u = *reinterpret_cast<const uint2 *>( ra + 152 ); b[3] = u.x; b[4] = u.y; }
+        pk2 v[20];
+#pragma unroll
+        for ( int d = 0; d < 5; d++ ) {
+          v[4 * d] = pk_from_bytes<0>( a[d], b[d] ); v[4 * d + 1] = pk_from_bytes<1>( a[d], b[d] );
+          v[4 * d + 2] = pk_from_bytes<2>( a[d], b[d] ); v[4 * d + 3] = pk_from_bytes<3>( a[d], b[d] );
+        }
+        lf_edges_pk( v, P, col > 0 ? g_on : 0u, g_in, g_in23 );
+#pragma unroll
+        for ( int d = 0; d < 5; d++ ) pk_to_dwords( v[4 * d], v[4 * d + 1], v[4 * d + 2], v[4 * d + 3], a[d], b[d] );
+        if ( active ) {
+          *reinterpret_cast<uint32_t *>( ha ) = a[0]; *reinterpret_cast<uint32_t *>( hb ) = b[0];
+          *reinterpret_cast<uint2 *>( ra ) = make_uint2( a[1], a[2] ); *reinterpret_cast<uint2 *>( ra + 144 ) = make_uint2( b[1], b[2] );
+          if ( luma ) { *reinterpret_cast<uint2 *>( ra + 8 ) = make_uint2( a[3], a[4] ); *reinterpret_cast<uint2 *>( ra + 152 ) = make_uint2( b[3], b[4] ); }
+        }
+      }
+      // the previous step's stores have drained behind the V phase: publish it
       asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-      if ( lane == 0 ) __hip_atomic_store( &progress[row], col + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+      if ( lane == 0 && pending >= 0 ) __hip_atomic_store( &progress[row], pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
       pending = -1;
-      continue;
-    }
-    if ( active && !prefetched && !( dbg & 2 ) ) { pre_y = *reinterpret_cast<const uint4 *>( yrow + x0 ); pre_c = *reinterpret_cast<const uint2 *>( crow + cx0 ); }
-    if ( active && !carried && col > 0 ) {   // left neighbour columns straight from memory
-      *reinterpret_cast<uint32_t *>( ly - 4 ) = *reinterpret_cast<const uint32_t *>( yrow + x0 - 4 );
-      *reinterpret_cast<uint32_t *>( lc - 4 ) = *reinterpret_cast<const uint32_t *>( crow + cx0 - 4 );
-    }
-    if ( active ) { *reinterpret_cast<uint4 *>( ly ) = pre_y; *reinterpret_cast<uint2 *>( lc ) = pre_c; }
-    // in flight during the V phase: the next macroblock's level, its own rows, the poll of the row above
-    const int info_next = ( frame_on && more ) ? *reinterpret_cast<const uint16_t *>( &mbrow[col + 1].flags ) : 0;
-    const int need = min( col + 2, mbw );
-    int seen = need;
-    if ( row > 0 ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-    __syncthreads();
 
-    const LfParamsPk P = lf_params_pk( lf_params( active ? level : 1, sharp, key ) );
-    const pk2 g_on = active ? ~0u : 0u, g_in = ( active && inner ) ? ~0u : 0u, g_in23 = ( active && inner && luma ) ? ~0u : 0u;
-    {   // ---- V phase: left MB edge, inner vertical edges ----
-      uint32_t a[5], b[5];
-      a[0] = *reinterpret_cast<const uint32_t *>( vbase ); b[0] = *reinterpret_cast<const uint32_t *>( vbase + 32 );
-      { const uint2 u = *reinterpret_cast<const uint2 *>( vbase + 4 ); a[1] = u.x; a[2] = u.y; }
-      { const uint2 u = *reinterpret_cast<const uint2 *>( vbase + 12 ); a[3] = u.x; a[4] = u.y; }
-      { const uint2 u = *reinterpret_cast<const uint2 *>( vbase + 36 ); b[1] = u.x; b[2] = u.y; }
-      { const uint2 u = *reinterpret_cast<const uint2 *>( vbase + 44 ); b[3] = u.x; b[4] = u.y; }
-      pk2 v[20];
-#pragma unroll
-      for ( int d = 0; d < 5; d++ ) {
-        v[4 * d] = pk_from_bytes<0>( a[d], b[d] ); v[4 * d + 1] = pk_from_bytes<1>( a[d], b[d] );
-        v[4 * d + 2] = pk_from_bytes<2>( a[d], b[d] ); v[4 * d + 3] = pk_from_bytes<3>( a[d], b[d] );
-      }
-      if ( !( dbg & 4 ) ) lf_edges_pk( v, P, col > 0 ? g_on : 0u, g_in, g_in23 );
-#pragma unroll
-      for ( int d = 0; d < 5; d++ ) pk_to_dwords( v[4 * d], v[4 * d + 1], v[4 * d + 2], v[4 * d + 3], a[d], b[d] );
-      if ( active ) {
-        *reinterpret_cast<uint32_t *>( vbase ) = a[0]; *reinterpret_cast<uint32_t *>( vbase + 32 ) = b[0];
-        *reinterpret_cast<uint2 *>( vbase + 4 ) = make_uint2( a[1], a[2] ); *reinterpret_cast<uint2 *>( vbase + 36 ) = make_uint2( b[1], b[2] );
-        if ( luma ) { *reinterpret_cast<uint2 *>( vbase + 12 ) = make_uint2( a[3], a[4] ); *reinterpret_cast<uint2 *>( vbase + 44 ) = make_uint2( b[3], b[4] ); }
-      }
-    }
-    // the previous step's stores have drained behind the V phase: publish it
-    asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-    if ( lane == 0 && pending >= 0 ) __hip_atomic_store( &progress[row], pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
-    pending = -1;
-    // prefetch the next macroblock's own rows (consumed at the top of the next step)
-    prefetched = more && ( info_next >> 8 ) != 0;
-    if ( prefetched && !( dbg & 2 ) ) { pre_y = *reinterpret_cast<const uint4 *>( yrow + x0 + 16 ); pre_c = *reinterpret_cast<const uint2 *>( crow + cx0 + 8 ); }
-
-    if ( row > 0 ) {
-      int spins = 0;
-      while ( !__all( seen >= need ) && !( dbg & 16 ) ) {
-        __builtin_amdgcn_s_sleep( 4 );
-        if ( seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-        ++spins;
-        if ( ( spins & 1023 ) == 0 && __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
-        if ( spins > ( 1 << 21 ) ) { atomicExch( &ws->error, 2 ); break; }
-      }
-      if ( active && !( dbg & 8 ) ) *reinterpret_cast<uint64_t *>( ltop ) = load_u64_shared( toprow + col * topstep );
-    }
-    __syncthreads();
-
-    {   // ---- H phase: top MB edge, inner horizontal edges ----
-      pk2 v[20];
-#pragma unroll
-      for ( int r = 0; r < 20; r++ ) v[r] = pk_from_u16( *reinterpret_cast<const uint16_t *>( hbase + 32 * r ) );
-      if ( !( dbg & 4 ) ) lf_edges_pk( v, P, row > 0 ? g_on : 0u, g_in, g_in23 );
-      if ( active ) {
-#pragma unroll
-        for ( int r = 1; r < 12; r++ ) *reinterpret_cast<uint16_t *>( hbase + 32 * r ) = static_cast<uint16_t>( pk_to_u16( v[r] ) );
-        if ( luma ) {
-#pragma unroll
-          for ( int r = 12; r < 20; r++ ) *reinterpret_cast<uint16_t *>( hbase + 32 * r ) = static_cast<uint16_t>( pk_to_u16( v[r] ) );
+      if ( row > 0 ) {
+        int spins = 0;
+        while ( !__all( seen >= need ) && !( dbg & 16 ) ) {
+          __builtin_amdgcn_s_sleep( 4 );
+          if ( seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+          ++spins;
+          if ( ( spins & 1023 ) == 0 && __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
+          if ( spins > ( 1 << 21 ) ) { atomicExch( &ws->error, 2 ); break; }
+        }
+        // rows -4..-1: the boundary line the row above left for this macroblock (sc1: bypass L1, served by the XCD's L2)
+        if ( frame_on && l < 8 && !( dbg & 8 ) ) {
+          const uint8_t * src = bnd_top + static_cast<size_t>( col ) * 128;
+          const uint64_t lo = load_u64_shared( src ), hi = load_u64_shared( src + 8 );
+          uint8_t * dst = btop + bstep * k;
+          if ( bl < 4 ) { *reinterpret_cast<uint64_t *>( dst ) = lo; *reinterpret_cast<uint64_t *>( dst + 8 ) = hi; }
+          else { *reinterpret_cast<uint64_t *>( dst ) = lo; *reinterpret_cast<uint64_t *>( dst + 144 ) = hi; }
         }
       }
-    }
-    __syncthreads();
+      // the next strip's own rows: issued here so that no wait of THIS step covers them (vmcnt completes in order); they
+      // have the rest of the strip to arrive
+      if ( k == 0 && s + 1 < n_strips ) prefetch( s + 1 );
+      __syncthreads();
 
-    if ( active ) {
-      const uint4 oy = *reinterpret_cast<const uint4 *>( ly ); const uint2 oc = *reinterpret_cast<const uint2 *>( lc );
-      if ( !( dbg & 1 ) ) {
-        *reinterpret_cast<uint4 *>( yrow + x0 ) = oy;
-        *reinterpret_cast<uint2 *>( crow + cx0 ) = oc;
-        if ( col > 0 ) {        // columns -4..-1: final now (the left MB edge of this macroblock was the last to touch them)
-          *reinterpret_cast<uint32_t *>( yrow + x0 - 4 ) = *reinterpret_cast<const uint32_t *>( ly - 4 );
-          *reinterpret_cast<uint32_t *>( crow + cx0 - 4 ) = *reinterpret_cast<const uint32_t *>( lc - 4 );
+      if ( any_active && !( dbg & 4 ) ) {   // ---- H phase: top MB edge, inner horizontal edges ----
+        uint8_t * const hc = hcol + mbstep * k;
+        pk2 v[20];
+#pragma unroll
+        for ( int r = 0; r < 20; r++ ) v[r] = pk_from_u16( *reinterpret_cast<const uint16_t *>( hc + 144 * r ) );
+        lf_edges_pk( v, P, row > 0 ? g_on : 0u, g_in, g_in23 );
+        if ( active ) {
+#pragma unroll
+          for ( int r = 1; r < 12; r++ ) *reinterpret_cast<uint16_t *>( hc + 144 * r ) = static_cast<uint16_t>( pk_to_u16( v[r] ) );
+          if ( luma ) {
+#pragma unroll
+            for ( int r = 12; r < 20; r++ ) *reinterpret_cast<uint16_t *>( hc + 144 * r ) = static_cast<uint16_t>( pk_to_u16( v[r] ) );
+          }
         }
-        if ( row > 0 ) *reinterpret_cast<uint64_t *>( toprow + col * topstep ) = *reinterpret_cast<const uint64_t *>( ltop );
       }
-      // carry the filtered right edge over as the next macroblock's left neighbour columns
-      *reinterpret_cast<uint32_t *>( ly - 4 ) = *reinterpret_cast<const uint32_t *>( ly + 12 );
-      *reinterpret_cast<uint32_t *>( lc - 4 ) = *reinterpret_cast<const uint32_t *>( lc + 4 );
+      __syncthreads();
+
+      if ( frame_on && !( dbg & 1 ) ) {
+        if ( !last_row ) {
+          // this macroblock's bottom rows -> its boundary line (its last four columns are not final yet: fixed up by the next step)
+          if ( l < 8 ) {
+            const uint8_t * src = bsrc + bstep * k;
+            uint4 q;
+            if ( bl < 4 ) q = *reinterpret_cast<const uint4 *>( src );
+            else { const uint2 u0 = *reinterpret_cast<const uint2 *>( src ), u1 = *reinterpret_cast<const uint2 *>( src + 144 ); q = make_uint4( u0.x, u0.y, u1.x, u1.y ); }
+            *reinterpret_cast<uint4 *>( bnd_own + static_cast<size_t>( col ) * 128 ) = q;
+          }
+          if ( col > 0 && l < 12 ) {
+            const uint8_t * src = k == 0 ? fix_src0 : fix_srck + fix_step * k;
+            *reinterpret_cast<uint32_t *>( bnd + ( bnd_row + col - 1 ) * 128 + fix_off ) = *reinterpret_cast<const uint32_t *>( src );
+          }
+        }
+        if ( k == 0 && s > 0 ) {
+          // the previous strip's last four columns are final now
+          if ( l < 12 || last_row ) *reinterpret_cast<uint32_t *>( fy + 128 * s ) = *reinterpret_cast<const uint32_t *>( &T.halo_y[l][0] );
+          if ( ( l & 7 ) < 4 || last_row ) *reinterpret_cast<uint32_t *>( fc + 64 * s ) = *reinterpret_cast<const uint32_t *>( &T.halo_c[l >> 3][l & 7][0] );
+        }
+        if ( k == nmb - 1 && bchunk < nmb ) {
+          // ---- the strip is done: rows -4..11 (chroma -4..3) back to the frame, whole lines; the last MB row also its bottom rows ----
+#pragma unroll
+          for ( int i = 0; i < 10; i++ ) {          // strip rows 2i + brow = frame rows y0 - 4 + 2i + brow
+            if ( ( i >= 2 || row > 0 ) && ( i < 8 || last_row ) )
+              *reinterpret_cast<uint4 *>( gy + ( static_cast<ptrdiff_t>( 2 * i ) - 4 ) * pw + 128 * s ) = *reinterpret_cast<const uint4 *>( sy + 288 * i - 4 * 144 );
+          }
+#pragma unroll
+          for ( int i = 0; i < 6; i++ ) {           // chroma strip rows 2i + brow = chroma rows cy0 - 4 + 2i + brow
+            if ( ( i >= 2 || row > 0 ) && ( i < 4 || last_row ) ) {
+              *reinterpret_cast<uint2 *>( gu + ( static_cast<ptrdiff_t>( 2 * i ) - 4 ) * cw + 64 * s ) = *reinterpret_cast<const uint2 *>( sc + 288 * i - 4 * 144 );
+              *reinterpret_cast<uint2 *>( gv + ( static_cast<ptrdiff_t>( 2 * i ) - 4 ) * cw + 64 * s ) = *reinterpret_cast<const uint2 *>( sc + 288 * i - 4 * 144 + 64 );
+            }
+          }
+        }
+      }
+      pending = col + 1;
+      info = info_next;
+      __syncthreads();
     }
-    pending = col + 1;
-    carried = active;
-    info = info_next;
-    __syncthreads();
   }
   asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
   if ( lane == 0 && pending >= 0 ) __hip_atomic_store( &progress[row], pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
 }
 
 // ticket t of queue x -> (group (t / mbh_max) * n_xcd + x, row t % mbh_max)
-__device__ __forceinline__ void loopfilter_rows4_body( const aa_frame_list & list, const int n_groups, const int mbh_max, aa_sync_ws * ws, const int n_xcd,
-                                                        LfRows4Lds & S, int & s_ticket, const int dbg )
+__device__ __forceinline__ void loopfilter_rows4_body( const aa_frame_list & list, const int n_groups, const int mbh_max, const int mbw_max, aa_sync_ws * ws, uint8_t * bnd,
+                                                        const int n_xcd, LfStripLds & S, int & s_ticket, const int dbg )
 {
   const int xcc = xcc_id();
   if ( xcc >= n_xcd ) { if ( threadIdx.x == 0 ) atomicExch( &ws->error, 3 ); return; }
@@ -853,16 +928,17 @@ __device__ __forceinline__ void loopfilter_rows4_body( const aa_frame_list & lis
     const int t = take_ticket( ws, xcc, &s_ticket, threadIdx.x );
     const int group = ( t / mbh_max ) * n_xcd + xcc;
     if ( group >= n_groups ) return;
-    loopfilter_rows4_row( list, group, t % mbh_max, mbh_max, ws, S, dbg );
+    loopfilter_strip_row( list, group, t % mbh_max, mbh_max, mbw_max, ws, bnd, S, dbg );
   }
 }
 
 // grid.x = n_xcd * ceil(n_groups / n_xcd) * mbh_max workgroups
-__global__ __launch_bounds__( kLanes ) void k_loopfilter_rows4( const aa_frame_list list, const int n_groups, const int mbh_max, aa_sync_ws * ws, const int n_xcd, const int dbg )
+__global__ __launch_bounds__( kLanes ) void k_loopfilter_rows4( const aa_frame_list list, const int n_groups, const int mbh_max, const int mbw_max, aa_sync_ws * ws, uint8_t * bnd,
+                                                                 const int n_xcd, const int dbg )
 {
-  __shared__ LfRows4Lds S;
+  __shared__ LfStripLds S;
   __shared__ int s_ticket;
-  loopfilter_rows4_body( list, n_groups, mbh_max, ws, n_xcd, S, s_ticket, dbg );
+  loopfilter_rows4_body( list, n_groups, mbh_max, mbw_max, ws, bnd, n_xcd, S, s_ticket, dbg );
 }
 
 // Which XCDs do workgroups of this device land on?  out[x] = number of workgroups of the launch that ran on XCD x.
@@ -908,9 +984,9 @@ int launch_recon_intra_rows( const aa_frame_list & list, int n, int mbh_max, aa_
   hipLaunchKernelGGL( k_recon_intra_rows, dim3( n_xcd * ( ( n + n_xcd - 1 ) / n_xcd ) * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n, mbh_max, ws, n_xcd );
   return static_cast<int>( hipGetLastError() );
 }
-int launch_loopfilter_rows4( const aa_frame_list & list, int n_groups, int mbh_max, aa_sync_ws * ws, int n_xcd, void * stream )
+int launch_loopfilter_rows4( const aa_frame_list & list, int n_groups, int mbh_max, int mbw_max, aa_sync_ws * ws, uint8_t * boundary, int n_xcd, void * stream )
 {
-  hipLaunchKernelGGL( k_loopfilter_rows4, dim3( n_xcd * ( ( n_groups + n_xcd - 1 ) / n_xcd ) * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n_groups, mbh_max, ws, n_xcd, lf_debug_bits() );
+  hipLaunchKernelGGL( k_loopfilter_rows4, dim3( n_xcd * ( ( n_groups + n_xcd - 1 ) / n_xcd ) * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n_groups, mbh_max, mbw_max, ws, boundary, n_xcd, lf_debug_bits() );
   return static_cast<int>( hipGetLastError() );
 }
 int launch_probe_xcds( int * out16, int blocks, void * stream )

@@ -77,6 +77,8 @@ struct aa_ctx {
   int schedule = 0;            // 0: row-pipelined persistent kernels (default), 1: one launch per 2:1 anti-diagonal
   int n_xcd = 1;               // XCDs workgroups land on (probed at creation); row kernels keep a unit on one XCD
   int xcd_share[AA_MAX_XCD] = {};
+  uint8_t * boundary = nullptr; // loop filter: hand-off lines between macroblock rows (transient within a launch)
+  size_t boundary_bytes = 0;
   aa_sync_ws * ws = nullptr;   // in-launch ordering state of the row-pipelined kernels
   size_t ws_bytes = 0;
   aa_kernel_stats stats {};
@@ -310,6 +312,7 @@ static void ctx_free( aa_ctx * ctx )
   for ( auto e : ctx->free_events ) (void) hipEventDestroy( e );
   (void) hipEventDestroy( ctx->upload_done );
   if ( ctx->ws ) (void) hipFree( ctx->ws );
+  if ( ctx->boundary ) (void) hipFree( ctx->boundary );
   (void) hipStreamDestroy( ctx->compute ); (void) hipStreamDestroy( ctx->copy );
   delete ctx;
 }
@@ -571,8 +574,16 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
         if ( !filled ) return AA_OK;
         for ( int k = filled; k < AA_MAX_BATCH; k++ ) list.f[k] = nullptr;
         if ( aa_status st = zero_ws( ctx, ctx->ws, filled / 4, max_mbh ) ) return st;
+        const size_t need = size_t( filled ) * max_mbh * max_mbw * 128;
+        if ( need > ctx->boundary_bytes ) {
+          HIP_TRY( hipStreamSynchronize( ctx->compute ) );
+          if ( ctx->boundary ) (void) hipFree( ctx->boundary );
+          ctx->boundary = nullptr; ctx->boundary_bytes = 0;
+          HIP_TRY( hipMalloc( reinterpret_cast<void **>( &ctx->boundary ), need ) );
+          ctx->boundary_bytes = need;
+        }
         LaunchTimer t( ctx, 2 );
-        if ( const int e = aa::launch_loopfilter_rows4( list, filled / 4, max_mbh, ctx->ws, ctx->n_xcd, ctx->compute ) ) return hip_fail( static_cast<hipError_t>( e ), "k_loopfilter_rows4" );
+        if ( const int e = aa::launch_loopfilter_rows4( list, filled / 4, max_mbh, max_mbw, ctx->ws, ctx->boundary, ctx->n_xcd, ctx->compute ) ) return hip_fail( static_cast<hipError_t>( e ), "k_loopfilter_rows4" );
         filled = 0;
         return AA_OK;
       };
