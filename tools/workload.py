@@ -42,10 +42,34 @@ def have_reference_tools():
 
 def make_stream(config, frames, seed):
     """-> path of an IVF (1 key frame + frames-1 inter frames; all key frames for *_intra)."""
-    import make_y4m
-    w, h, ent, qi, lf, sharp = CONFIGS[config]
     key = "%s_f%d_s%d" % (config, frames, seed)
     path = os.path.join(cache_dir(), key + ".ivf")
+    if os.path.exists(path):
+        return path
+    # several ranks of one node may ask for the same stream at the same time: the first takes a lock file, the others wait
+    lock = path + ".lock"
+    try:
+        os.close(os.open(lock, os.O_CREAT | os.O_EXCL | os.O_WRONLY))
+    except FileExistsError:
+        import time
+        deadline = time.time() + 600
+        while time.time() < deadline:
+            if os.path.exists(path):
+                return path
+            if not os.path.exists(lock):
+                break
+            time.sleep(0.2)
+        return path if os.path.exists(path) else _generate(config, frames, seed, path, None)     # stale lock: generate anyway
+    try:
+        return _generate(config, frames, seed, path, lock)
+    finally:
+        if os.path.exists(lock):
+            os.unlink(lock)
+
+
+def _generate(config, frames, seed, path, lock):
+    import make_y4m
+    w, h, ent, qi, lf, sharp = CONFIGS[config]
     if os.path.exists(path):
         return path
     if not have_reference_tools():
