@@ -45,8 +45,9 @@ int launch_recon_inter( const aa_frame_list & list, int n, unsigned max_mbs, voi
 int launch_recon_intra_diagonal( const aa_frame_list & list, int n, int diagonal, int row_lo, int rows, void * stream );
 int launch_loopfilter_diagonal( const aa_frame_list & list, int n, int diagonal, int row_lo, int rows, void * stream );
 // Row kernels are XCD-affine: unit u (frame / group) is processed by workgroups that run on XCD u % n_xcd.
-int launch_recon_intra_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, int n_xcd, void * stream );
 // list = groups of four frames of one geometry (slot 0 never null, missing frames null)
+// list = groups of four frames (any geometry; slot 0 never null, missing frames null)
+int launch_recon_intra4( const aa_frame_list & list, int n_groups, int mbh_max, aa_sync_ws * ws, int n_xcd, void * stream );
 // boundary: 128 bytes per (frame slot of the list, MB row, MB column) = 4 * n_groups * mbh_max * mbw_max lines; transient
 int launch_loopfilter_rows4( const aa_frame_list & list, int n_groups, int mbh_max, int mbw_max, aa_sync_ws * ws, uint8_t * boundary, int n_xcd, void * stream );
 // out16[x] += number of workgroups (of `blocks`) that ran on XCD x

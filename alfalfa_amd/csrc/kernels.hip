@@ -481,176 +481,259 @@ __device__ __forceinline__ int take_ticket( aa_sync_ws * ws, const int xcc, int 
   __syncthreads();
   return *slot;
 }
-__device__ __forceinline__ void publish_progress( int * progress, const int value, const int lane )
+
+// ---- row-pipelined intra prediction, FOUR frames per wave ---------------------------------------------------------------
+// 16 lanes per frame ("slot"); each slot walks the intra macroblocks of ITS frame's row on its own (key frames: all four
+// in lock step; inter frames: whatever sparse columns each frame has).  A 4x4 sub-block is 16 pixels = 16 lanes, a 16x16
+// prediction is 16 rows = 16 lanes, the two chroma planes are 2 x 8 rows = 16 lanes, the 16 luma IDCTs are 16 lanes: the
+// per-macroblock version of this kernel kept 16 of 64 lanes busy through the serial B_PRED chain.  The 4x4 predictors are
+// evaluated from a table (vp8_math.hh bpred_entry) so that four macroblocks with four different modes share one
+// instruction stream; each IDCT runs both passes in one lane's registers (no LDS round trip, no barrier).
+struct alignas( 16 ) Intra4Slot {
+  alignas( 16 ) int16_t res[24][16];   // residual of block b at [row*4+col]
+  alignas( 16 ) uint8_t y[17][48];     // [row+1][col+16]: row 0 = the row above (cols -4..19), byte 15 = the column to the left
+  alignas( 16 ) uint8_t c[2][9][32];   // chroma likewise: cols -4..7 at bytes 12..23
+  alignas( 16 ) uint8_t E[16];         // edge array of the current 4x4 sub-block (vp8_math.hh bpred_pixel)
+  alignas( 16 ) int16_t y2[32];        // Y2: dequantised coefficients / block DCs [0..15], first-pass results [16..31]
+};
+struct alignas( 16 ) Intra4Lds { Intra4Slot slot[4]; uint32_t tab[160]; };
+
+// dequantise + inverse DCT of one 4x4 block in one lane's registers: d[8] = 16 packed int16 coefficients -> 16 residuals
+__device__ __forceinline__ void idct_block_regs( const uint32_t ( &d )[8], const int fdc, const int fac, const bool replace_dc, const int dc, int ( &r )[16] )
 {
-  asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );      // every store of this wave has reached the L2
-  if ( lane == 0 ) __hip_atomic_store( progress, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
-}
-__device__ __forceinline__ void wait_progress( const int * progress, const int need, aa_sync_ws * ws, const int code )
-{
-  int spins = 0;
-  while ( __hip_atomic_load( progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) < need ) {
-    __builtin_amdgcn_s_sleep( 4 );
-    ++spins;
-    // watchdog: sticky error word; once any wait has expired every other wait gives up within 1024 polls
-    if ( ( spins & 1023 ) == 0 && __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
-    if ( spins > ( 1 << 21 ) ) { atomicExch( &ws->error, code ); break; }
-  }
+  int c[16];
+#pragma unroll
+  for ( int i = 0; i < 8; i++ ) { c[2 * i] = static_cast<int16_t>( d[i] & 0xFFFFu ); c[2 * i + 1] = static_cast<int>( d[i] ) >> 16; }
+  c[0] = dequant( c[0], fdc );
+#pragma unroll
+  for ( int i = 1; i < 16; i++ ) c[i] = dequant( c[i], fac );
+  if ( replace_dc ) c[0] = dc;
+  int im[16];
+#pragma unroll
+  for ( int i = 0; i < 4; i++ ) { const Quad v = idct_pass1( c[i], c[i + 4], c[i + 8], c[i + 12] ); im[i * 4] = v.v0; im[i * 4 + 1] = v.v1; im[i * 4 + 2] = v.v2; im[i * 4 + 3] = v.v3; }
+#pragma unroll
+  for ( int i = 0; i < 4; i++ ) { const Quad v = idct_pass2( im[i], im[i + 4], im[i + 8], im[i + 12] ); r[i * 4] = v.v0; r[i * 4 + 1] = v.v1; r[i * 4 + 2] = v.v2; r[i * 4 + 3] = v.v3; }
 }
 
-// ticket t of queue x -> (frame (t / mbh_max) * n_xcd + x, row t % mbh_max)
-__device__ __forceinline__ void recon_intra_rows_body( const aa_frame_list & list, const int n_frames, const int mbh_max, aa_sync_ws * ws, const int n_xcd,
-                                                        IntraLds & L, int & s_ticket )
+// n pixels of a 16x16 / 8x8 prediction row (+ residual): above = packed above pixels, res = pointer to 4 int16 residuals
+__device__ __forceinline__ uint32_t bigpred_x4( const int mode, const uint32_t above, const int left, const int corner, const int dc, const bool has_res, const int16_t * res )
 {
-  const int lane = threadIdx.x;
-  const int xcc = xcc_id();
-  if ( xcc >= n_xcd ) { if ( lane == 0 ) atomicExch( &ws->error, 3 ); return; }
+  uint32_t out = 0;
+#pragma unroll
+  for ( int j = 0; j < 4; j++ ) {
+    int v = bigpred_pixel( mode, ( above >> ( 8 * j ) ) & 0xFF, left, corner, dc );
+    if ( has_res ) v = clamp255( v + res[j] );
+    out |= static_cast<uint32_t>( v ) << ( 8 * j );
+  }
+  return out;
+}
+
+__device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, const int group, const int row, const int mbh_max, aa_sync_ws * ws, Intra4Lds & L )
+{
+  const int lane = threadIdx.x, slot = lane >> 4, l = lane & 15;
+  Intra4Slot & S = L.slot[slot];
+  const aa_dev_frame * const fp = list.f[group * 4 + slot];
+  const aa_dev_frame & f = fp ? *fp : *list.f[group * 4];
+  const bool frame_on = fp != nullptr && row < fp->mbh;
+  const int mbw = f.mbw, pw = mbw * 16, cw = pw >> 1;
+  const int y0 = row * 16, cy0 = row * 8;
+  int * const progress = ws->progress + ( group * 4 + slot ) * mbh_max;
+  uint8_t * const Y = f.cur[0];
+  uint8_t * const Cl = f.cur[1 + ( l >> 3 )];       // the chroma plane this lane serves in the left-column and row roles
+  const int words = ( frame_on && f.has_intra ) ? ( mbw + 63 ) >> 6 : 0;
+  const unsigned long long * const mask = f.intra_rows + static_cast<size_t>( row ) * ( ( mbw + 63 ) >> 6 );
+  int w = 0;
+  unsigned long long m = words ? mask[0] : 0ull;
+
   for ( ;; ) {
-    const int t = take_ticket( ws, xcc, &s_ticket, lane );
-    const int fi = ( t / mbh_max ) * n_xcd + xcc, row = t % mbh_max;
-    if ( fi >= n_frames ) return;
-    const aa_dev_frame & f = *list.f[fi];
-    if ( row >= f.mbh ) continue;
-    int * progress = ws->progress + fi * mbh_max;
-    const int mbw = f.mbw;
-    if ( f.has_intra ) {
-      const int words = ( mbw + 63 ) >> 6;
-      const unsigned long long * mask = f.intra_rows + static_cast<size_t>( row ) * words;
-      for ( int w = 0; w < words; w++ ) {
-        unsigned long long m = mask[w];
-        while ( m ) {
-          const int col = w * 64 + __ffsll( static_cast<long long>( m ) ) - 1;
-          m &= m - 1;
-          // everything left of `col` in this row is final
-          publish_progress( &progress[row], col, lane );
-          // the residual (dequant, iWHT, IDCTs) does not depend on any neighbour: compute it BEFORE waiting for the row above
-          const aa_mb_info & mb = f.mbs[row * mbw + col];
-          if ( mb.flags & AA_MB_HAS_NONZERO ) compute_residual( mb, f, L.r, lane );
-          if ( row > 0 ) wait_progress( &progress[row - 1], min( col + 2, mbw ), ws, 1 );
-          intra_macroblock<true>( f, mb, col, row, L, lane, true );
+    while ( m == 0 && w + 1 < words ) { ++w; m = mask[w]; }
+    const bool on = m != 0;
+    if ( !__any( on ) ) break;
+    const int col = on ? w * 64 + __ffsll( static_cast<long long>( m ) ) - 1 : 0;
+    m &= m - 1;
+    // everything left of `col` in this row is final: the previous macroblock's stores have reached the L2
+    asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+    if ( on && l == 0 ) __hip_atomic_store( &progress[row], col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+
+    const aa_mb_info * const mb = f.mbs + static_cast<size_t>( row ) * mbw + col;
+    uint4 hd = make_uint4( 0, 0, 0, 0 ), bm = make_uint4( 0, 0, 0, 0 );
+    if ( on ) { hd = *reinterpret_cast<const uint4 *>( mb ); bm = *reinterpret_cast<const uint4 *>( mb->u.b_mode ); }
+    const int y_mode = hd.x & 0xFF, uv_mode = ( hd.x >> 8 ) & 0xFF, segment = ( hd.x >> 24 ) & 3, flags = hd.y & 0xFF;
+    const uint32_t nz_mask = hd.z, coeff_index = hd.w;
+    const bool has_res = on && ( flags & AA_MB_HAS_NONZERO );
+    const bool has_y2 = has_res && ( flags & AA_MB_HAS_Y2 );
+    int seen = 0;
+    const int need = min( col + 2, mbw );
+    if ( on && row > 0 ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+
+    // ---- residual: needs no neighbour, runs before the wait for the row above ----
+    if ( __any( has_res ) ) {
+      const int16_t * const src = f.coeffs + static_cast<size_t>( coeff_index ) * 16;
+      const uint16_t * const q = f.quant[segment];
+      const bool y2_stored = has_y2 && ( ( nz_mask >> 24 ) & 1u );
+      if ( __any( y2_stored ) ) {
+        if ( y2_stored ) S.y2[l] = static_cast<int16_t>( dequant( src[__popc( nz_mask & 0xFFFFFFu ) * 16 + l], q[l ? 3 : 2] ) );
+        __syncthreads();
+        if ( y2_stored && l < 4 ) {
+          const Quad v = iwht_pass1( S.y2[l], S.y2[l + 4], S.y2[l + 8], S.y2[l + 12] );
+          S.y2[16 + l] = static_cast<int16_t>( v.v0 ); S.y2[16 + l + 4] = static_cast<int16_t>( v.v1 );
+          S.y2[16 + l + 8] = static_cast<int16_t>( v.v2 ); S.y2[16 + l + 12] = static_cast<int16_t>( v.v3 );
+        }
+        __syncthreads();
+        if ( y2_stored && l < 4 ) {
+          const int o = l * 4;
+          const Quad v = iwht_pass2( S.y2[16 + o], S.y2[16 + o + 1], S.y2[16 + o + 2], S.y2[16 + o + 3] );
+          S.y2[o] = static_cast<int16_t>( v.v0 ); S.y2[o + 1] = static_cast<int16_t>( v.v1 );
+          S.y2[o + 2] = static_cast<int16_t>( v.v2 ); S.y2[o + 3] = static_cast<int16_t>( v.v3 );
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for ( int round = 0; round < 2; round++ ) {
+        const int blk = round == 0 ? l : 16 + ( l & 7 );
+        const bool mine = has_res && ( round == 0 || l < 8 );
+        const bool stored = mine && ( ( nz_mask >> blk ) & 1u );
+        const bool wht_dc = round == 0 && has_y2;
+        const int dc = ( wht_dc && y2_stored ) ? S.y2[blk] : 0;
+        if ( __any( mine ) ) {
+          uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+          if ( stored ) {
+            const uint4 * p = reinterpret_cast<const uint4 *>( src + __popc( nz_mask & ( ( 1u << blk ) - 1u ) ) * 16 );
+            const uint4 a = p[0], b = p[1];
+            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+          }
+          const int base = round == 0 ? 0 : 4;
+          int r[16];
+          idct_block_regs( d, q[base], q[base + 1], wht_dc, dc, r );
+          if ( mine ) {
+            uint32_t o[8];
+#pragma unroll
+            for ( int i = 0; i < 8; i++ ) o[i] = ( static_cast<uint32_t>( r[2 * i] ) & 0xFFFFu ) | ( static_cast<uint32_t>( r[2 * i + 1] ) << 16 );
+            uint4 * dst = reinterpret_cast<uint4 *>( &S.res[blk][0] );
+            dst[0] = make_uint4( o[0], o[1], o[2], o[3] ); dst[1] = make_uint4( o[4], o[5], o[6], o[7] );
+          }
         }
       }
     }
-    publish_progress( &progress[row], mbw, lane );
+
+    // ---- wait for the row above, then stage the neighbours (sc1 loads: L1-bypassing, served by this XCD's L2) ----
+    if ( row > 0 ) {
+      int spins = 0;
+      while ( !__all( !on || seen >= need ) ) {
+        __builtin_amdgcn_s_sleep( 4 );
+        if ( on && seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        ++spins;
+        if ( ( spins & 1023 ) == 0 && __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
+        if ( spins > ( 1 << 21 ) ) { atomicExch( &ws->error, 1 ); break; }
+      }
+    }
+    const int x0 = col * 16, cx0 = col * 8;
+    if ( on ) {
+      if ( l < 6 ) {               // the row above, cols -4..19 as six dwords (prediction.cc:99-167 edge rules)
+        uint32_t v;
+        const uint8_t * a = Y + static_cast<size_t>( y0 - 1 ) * pw;
+        if ( y0 == 0 ) v = 0x7F7F7F7Fu;
+        else if ( l == 0 ) v = x0 > 0 ? load_u32<true>( a + x0 - 4 ) : 0x81818181u;
+        else if ( l <= 4 ) v = load_u32<true>( a + x0 + ( l - 1 ) * 4 );
+        else if ( x0 + 16 >= pw ) v = 0x01010101u * ( load_u32<true>( a + pw - 4 ) >> 24 );      // replicate: prediction.cc:144-151
+        else v = load_u32<true>( a + x0 + 16 );
+        *reinterpret_cast<uint32_t *>( &S.y[0][12 + l * 4] ) = v;
+      } else if ( l < 12 ) {
+        const int pl = ( l - 6 ) / 3, i = ( l - 6 ) % 3;
+        const uint8_t * a = f.cur[1 + pl] + static_cast<size_t>( cy0 - 1 ) * cw;
+        uint32_t v;
+        if ( cy0 == 0 ) v = 0x7F7F7F7Fu;
+        else if ( i == 0 ) v = cx0 > 0 ? load_u32<true>( a + cx0 - 4 ) : 0x81818181u;
+        else v = load_u32<true>( a + cx0 + ( i - 1 ) * 4 );
+        *reinterpret_cast<uint32_t *>( &S.c[pl][0][12 + i * 4] ) = v;
+      }
+      S.y[l + 1][15] = x0 > 0 ? static_cast<uint8_t>( load_u32<true>( Y + static_cast<size_t>( y0 + l ) * pw + x0 - 4 ) >> 24 ) : 129;
+      S.c[l >> 3][( l & 7 ) + 1][15] = cx0 > 0 ? static_cast<uint8_t>( load_u32<true>( Cl + static_cast<size_t>( cy0 + ( l & 7 ) ) * cw + cx0 - 4 ) >> 24 ) : 129;
+    }
+    __syncthreads();
+
+    // ---- chroma: lane = (plane l >> 3, row l & 7), 8 pixels (prediction.cc:435-450) ----
+    if ( on ) {
+      const int pl = l >> 3, r = l & 7;
+      const uint32_t a0 = *reinterpret_cast<const uint32_t *>( &S.c[pl][0][16] ), a1 = *reinterpret_cast<const uint32_t *>( &S.c[pl][0][20] );
+      const int sa = absdiff_sum4( a0 ) + absdiff_sum4( a1 );
+      int sl = 0;
+#pragma unroll
+      for ( int i = 0; i < 8; i++ ) sl += S.c[pl][i + 1][15];
+      const int dc = bigpred_dc( sa, sl, row > 0, col > 0, 3 );
+      const int corner = S.c[pl][0][15], left = S.c[pl][r + 1][15];
+      const int blk = 16 + pl * 4 + ( r >> 2 ) * 2;
+      const uint32_t o0 = bigpred_x4( uv_mode, a0, left, corner, dc, has_res, &S.res[blk][( r & 3 ) * 4] );
+      const uint32_t o1 = bigpred_x4( uv_mode, a1, left, corner, dc, has_res, &S.res[blk + 1][( r & 3 ) * 4] );
+      *reinterpret_cast<uint2 *>( Cl + static_cast<size_t>( cy0 + r ) * cw + cx0 ) = make_uint2( o0, o1 );
+    }
+    // ---- luma 16x16: lane = row ----
+    const bool bp = on && y_mode == B_PRED;
+    if ( on && !bp ) {
+      const int r = l;
+      uint32_t a[4];
+      int sa = 0, sl = 0;
+#pragma unroll
+      for ( int k = 0; k < 4; k++ ) { a[k] = *reinterpret_cast<const uint32_t *>( &S.y[0][16 + 4 * k] ); sa += absdiff_sum4( a[k] ); }
+#pragma unroll
+      for ( int i = 0; i < 16; i++ ) sl += S.y[i + 1][15];
+      const int dc = bigpred_dc( sa, sl, row > 0, col > 0, 4 );
+      const int corner = S.y[0][15], left = S.y[r + 1][15];
+      uint32_t o[4];
+#pragma unroll
+      for ( int k = 0; k < 4; k++ ) o[k] = bigpred_x4( y_mode, a[k], left, corner, dc, has_res, &S.res[( r >> 2 ) * 4 + k][( r & 3 ) * 4] );
+      *reinterpret_cast<uint4 *>( Y + static_cast<size_t>( y0 + r ) * pw + x0 ) = make_uint4( o[0], o[1], o[2], o[3] );
+    }
+    // ---- luma B_PRED: 16 sub-blocks in raster order, lane = pixel (macroblock.cc:541-544) ----
+    if ( __any( bp ) ) {
+#pragma unroll 1
+      for ( int b = 0; b < 16; b++ ) {
+        const int bx = b & 3, by = b >> 2;
+        const int ar = by * 4, ac = bx * 4 + 15;          // tile position of (row -1, col -1) of this sub-block
+        if ( bp && l < 13 ) {
+          int er, ec;
+          if ( l < 4 ) { er = ar + 4 - l; ec = ac; }
+          else if ( l < 9 ) { er = ar; ec = ac + ( l - 4 ); }
+          else if ( bx == 3 ) { er = 0; ec = 32 + ( l - 9 ); }        // above-right of column 3: the row above the MACROBLOCK (prediction.cc:153-160)
+          else { er = ar; ec = ac + ( l - 4 ); }
+          S.E[l] = S.y[er][ec];
+        }
+        __syncthreads();
+        int v = 0;
+        if ( bp ) {
+          const uint32_t word = by == 0 ? bm.x : ( by == 1 ? bm.y : ( by == 2 ? bm.z : bm.w ) );
+          const int mode = ( word >> ( 8 * bx ) ) & 0xFF;
+          const uint32_t e = L.tab[mode * 16 + l];
+          const uint32_t d0 = *reinterpret_cast<const uint32_t *>( &S.E[0] ), d1 = *reinterpret_cast<const uint32_t *>( &S.E[4] ),
+                         d2 = *reinterpret_cast<const uint32_t *>( &S.E[8] );
+          const int dc = ( absdiff_sum4( d0 ) + absdiff_sum4( __builtin_amdgcn_alignbyte( d2, d1, 1 ) ) + 4 ) >> 3;
+          v = bpred_eval( e >> 24, S.E[e & 0xFF], S.E[( e >> 8 ) & 0xFF], S.E[( e >> 16 ) & 0xFF], dc );
+          if ( has_res ) v = clamp255( v + S.res[b][l] );
+          S.y[ar + 1 + ( l >> 2 )][ac + 1 + ( l & 3 )] = static_cast<uint8_t>( v );
+        }
+        __syncthreads();
+      }
+      if ( bp ) *reinterpret_cast<uint4 *>( Y + static_cast<size_t>( y0 + l ) * pw + x0 ) = *reinterpret_cast<const uint4 *>( &S.y[l + 1][16] );
+    }
+    __syncthreads();
   }
+  asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+  if ( frame_on && l == 0 ) __hip_atomic_store( &progress[row], mbw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
 }
 
-// grid.x = n_xcd * ceil(n_frames / n_xcd) * mbh_max workgroups
-__global__ __launch_bounds__( kLanes ) void k_recon_intra_rows( const aa_frame_list list, const int n_frames, const int mbh_max, aa_sync_ws * ws, const int n_xcd )
+// ticket t of queue x -> (group (t / mbh_max) * n_xcd + x, row t % mbh_max)
+__global__ __launch_bounds__( kLanes ) void k_recon_intra4( const aa_frame_list list, const int n_groups, const int mbh_max, aa_sync_ws * ws, const int n_xcd )
 {
-  __shared__ IntraLds L;
+  __shared__ Intra4Lds L;
   __shared__ int s_ticket;
-  recon_intra_rows_body( list, n_frames, mbh_max, ws, n_xcd, L, s_ticket );
-}
-
-struct alignas( 16 ) LfLds {
-  alignas( 16 ) uint8_t y[20][20];      // rows -4..15, cols -4..15
-  alignas( 16 ) uint8_t c[2][12][12];   // rows -4..7, cols -4..7
-};
-
-// One edge position handled by one lane: p = pointer to the first q-side pixel, s = step across the edge.
-__device__ __forceinline__ void lf_edge( uint8_t * p, const int s, const bool mb_edge, const LfParams & P )
-{
-  int p3 = p[-4 * s], p2 = p[-3 * s], p1 = p[-2 * s], p0 = p[-s], q0 = p[0], q1 = p[s], q2 = p[2 * s], q3 = p[3 * s];
-  const bool mask = lf_mask( P.interior_limit, mb_edge ? P.mb_limit : P.sb_limit, p3, p2, p1, p0, q0, q1, q2, q3 );
-  const bool hev = lf_hev( P.hev_threshold, p1, p0, q0, q1 );
-  if ( mb_edge ) {
-    lf_macroblock( mask, hev, p2, p1, p0, q0, q1, q2 );
-    p[-3 * s] = static_cast<uint8_t>( p2 ); p[2 * s] = static_cast<uint8_t>( q2 );
-  } else {
-    lf_subblock( mask, hev, p1, p0, q0, q1 );
-  }
-  p[-2 * s] = static_cast<uint8_t>( p1 ); p[-s] = static_cast<uint8_t>( p0 ); p[0] = static_cast<uint8_t>( q0 ); p[s] = static_cast<uint8_t>( q1 );
-}
-
-// The eight dependent edge passes of NormalLoopFilter::filter (loopfilter.cc:133-154) on the LDS copy of one MB:
-// left MB edge, inner vertical edges, top MB edge, inner horizontal edges.  Lanes 0..15 luma line, 16..23 U, 24..31 V.
-__device__ void lf_passes( LfLds & L, const bool have_left, const bool have_top, const bool inner, const LfParams & P, const int lane )
-{
-  const bool is_y = lane < 16, is_c = lane >= 16 && lane < 32;
-  const int cl = ( lane - 16 ) & 7, cp = ( lane - 16 ) >> 3;
-  if ( have_left ) {
-    if ( is_y ) lf_edge( &L.y[4 + lane][4], 1, true, P );
-    else if ( is_c ) lf_edge( &L.c[cp][4 + cl][4], 1, true, P );
-  }
-  __syncthreads();
-  if ( inner ) {
-    if ( is_y ) lf_edge( &L.y[4 + lane][8], 1, false, P );
-    else if ( is_c ) lf_edge( &L.c[cp][4 + cl][8], 1, false, P );
-    __syncthreads();
-    if ( is_y ) lf_edge( &L.y[4 + lane][12], 1, false, P );
-    __syncthreads();
-    if ( is_y ) lf_edge( &L.y[4 + lane][16], 1, false, P );
-    __syncthreads();
-  }
-  if ( have_top ) {
-    if ( is_y ) lf_edge( &L.y[4][4 + lane], 20, true, P );
-    else if ( is_c ) lf_edge( &L.c[cp][4][4 + cl], 12, true, P );
-  }
-  __syncthreads();
-  if ( inner ) {
-    if ( is_y ) lf_edge( &L.y[8][4 + lane], 20, false, P );
-    else if ( is_c ) lf_edge( &L.c[cp][8][4 + cl], 12, false, P );
-    __syncthreads();
-    if ( is_y ) lf_edge( &L.y[12][4 + lane], 20, false, P );
-    __syncthreads();
-    if ( is_y ) lf_edge( &L.y[16][4 + lane], 20, false, P );
-    __syncthreads();
-  }
-}
-
-// grid as k_recon_intra.  All MBs with col + 2*row == d are independent: their read/write footprints
-// ([x0-4,x0+15] x [y0-4,y0+15]) are disjoint and everything they read was finished by diagonals < d.
-__global__ __launch_bounds__( kLanes ) void k_loopfilter( const aa_frame_list list, const int diagonal, const int row_lo )
-{
-  __shared__ LfLds L;
-  const aa_dev_frame & f = *list.f[blockIdx.y];
-  if ( !f.loop_filter_level ) return;
-  const int row = row_lo + blockIdx.x, col = diagonal - 2 * row;
-  if ( row >= f.mbh || col < 0 || col >= f.mbw ) return;
-  const aa_mb_info & mb = f.mbs[row * f.mbw + col];
-  const int level = mb.lf_level;
-  if ( level == 0 ) return;
-  const int lane = threadIdx.x;
-  const int pw = f.mbw * 16, cw = pw >> 1;
-  const int x0 = col * 16, y0 = row * 16, cx0 = col * 8, cy0 = row * 8;
-  const LfParams P = lf_params( level, f.sharpness, f.key_frame );
-
-  // ---- stage: 20 rows x 5 dwords (Y), 2 x 12 rows x 3 dwords (U,V) ----
-  uint8_t * Y = f.cur[0];
-  for ( int i = lane; i < 100; i += kLanes ) {
-    const int r = i / 5, d = i % 5;
-    const int gy = y0 - 4 + r, gx = x0 - 4 + d * 4;
-    uint32_t v = 0;
-    if ( gy >= 0 && gx >= 0 ) v = *reinterpret_cast<const uint32_t *>( Y + static_cast<size_t>( gy ) * pw + gx );
-    *reinterpret_cast<uint32_t *>( &L.y[r][d * 4] ) = v;
-  }
-  for ( int i = lane; i < 72; i += kLanes ) {
-    const int pl = i / 36, e = i % 36, r = e / 3, d = e % 3;
-    const int gy = cy0 - 4 + r, gx = cx0 - 4 + d * 4;
-    uint32_t v = 0;
-    if ( gy >= 0 && gx >= 0 ) v = *reinterpret_cast<const uint32_t *>( f.cur[1 + pl] + static_cast<size_t>( gy ) * cw + gx );
-    *reinterpret_cast<uint32_t *>( &L.c[pl][r][d * 4] ) = v;
-  }
-  __syncthreads();
-
-  lf_passes( L, col > 0, row > 0, !( mb.flags & AA_MB_LF_SKIP_INNER ), P, lane );
-
-  // ---- write back what this MB may have modified: rows/cols -3..15 minus the untouched corner.
-  // Dword stores over [-4,15] are safe: nothing else touches that footprint during this launch.
-  for ( int i = lane; i < 100; i += kLanes ) {
-    const int r = i / 5, d = i % 5;
-    const int gy = y0 - 4 + r, gx = x0 - 4 + d * 4;
-    if ( r == 0 || gy < 0 || gx < 0 ) continue;            // row -4 is never modified
-    if ( r < 4 && d == 0 ) continue;                        // corner block
-    *reinterpret_cast<uint32_t *>( Y + static_cast<size_t>( gy ) * pw + gx ) = *reinterpret_cast<const uint32_t *>( &L.y[r][d * 4] );
-  }
-  for ( int i = lane; i < 72; i += kLanes ) {
-    const int pl = i / 36, e = i % 36, r = e / 3, d = e % 3;
-    const int gy = cy0 - 4 + r, gx = cx0 - 4 + d * 4;
-    if ( r == 0 || gy < 0 || gx < 0 ) continue;
-    if ( r < 4 && d == 0 ) continue;
-    *reinterpret_cast<uint32_t *>( f.cur[1 + pl] + static_cast<size_t>( gy ) * cw + gx ) = *reinterpret_cast<const uint32_t *>( &L.c[pl][r][d * 4] );
+  for ( int i = threadIdx.x; i < 160; i += kLanes ) L.tab[i] = bpred_entry( i >> 4, i & 3, ( i >> 2 ) & 3 );
+  const int xcc = xcc_id();
+  if ( xcc >= n_xcd ) { if ( threadIdx.x == 0 ) atomicExch( &ws->error, 3 ); return; }
+  for ( ;; ) {
+    const int t = take_ticket( ws, xcc, &s_ticket, threadIdx.x );
+    const int group = ( t / mbh_max ) * n_xcd + xcc;
+    if ( group >= n_groups ) return;
+    recon_intra4_row( list, group, t % mbh_max, mbh_max, ws, L );
   }
 }
 
@@ -979,14 +1062,14 @@ static unsigned test_lds_pad()
   static const unsigned pad = [] { const char * e = std::getenv( "ALFALFA_AMD_TEST_LDS_PAD" ); return e ? static_cast<unsigned>( std::atoi( e ) ) : 0u; }();
   return pad;
 }
-int launch_recon_intra_rows( const aa_frame_list & list, int n, int mbh_max, aa_sync_ws * ws, int n_xcd, void * stream )
-{
-  hipLaunchKernelGGL( k_recon_intra_rows, dim3( n_xcd * ( ( n + n_xcd - 1 ) / n_xcd ) * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n, mbh_max, ws, n_xcd );
-  return static_cast<int>( hipGetLastError() );
-}
 int launch_loopfilter_rows4( const aa_frame_list & list, int n_groups, int mbh_max, int mbw_max, aa_sync_ws * ws, uint8_t * boundary, int n_xcd, void * stream )
 {
   hipLaunchKernelGGL( k_loopfilter_rows4, dim3( n_xcd * ( ( n_groups + n_xcd - 1 ) / n_xcd ) * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n_groups, mbh_max, mbw_max, ws, boundary, n_xcd, lf_debug_bits() );
+  return static_cast<int>( hipGetLastError() );
+}
+int launch_recon_intra4( const aa_frame_list & list, int n_groups, int mbh_max, aa_sync_ws * ws, int n_xcd, void * stream )
+{
+  hipLaunchKernelGGL( k_recon_intra4, dim3( n_xcd * ( ( n_groups + n_xcd - 1 ) / n_xcd ) * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n_groups, mbh_max, ws, n_xcd );
   return static_cast<int>( hipGetLastError() );
 }
 int launch_probe_xcds( int * out16, int blocks, void * stream )

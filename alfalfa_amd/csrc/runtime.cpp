@@ -322,7 +322,7 @@ static aa_status check_watchdog( aa_ctx * ctx )
   int err = 0;
   HIP_TRY( hipMemcpy( &err, &ctx->ws->error, sizeof err, hipMemcpyDeviceToHost ) );
   if ( err == 3 ) return fail( AA_ERR_HIP, "row-pipelined kernel: a workgroup ran on an XCD outside the probed set (output is not valid)" );
-  if ( err ) return fail( AA_ERR_HIP, std::string( "row-pipelined kernel " ) + ( err == 1 ? "k_recon_intra_rows" : "k_loopfilter_rows4" )
+  if ( err ) return fail( AA_ERR_HIP, std::string( "row-pipelined kernel " ) + ( err == 1 ? "k_recon_intra4" : "k_loopfilter_rows4" )
                                       + ": a bounded wait for the macroblock row above expired (output is not valid)" );
   return AA_OK;
 }
@@ -547,20 +547,16 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
   if ( ctx->schedule == 0 ) {
     // 2+3. row-pipelined kernels: one launch each; macroblock rows are ordered in-launch (ticket + progress words)
     if ( aa_status st = ensure_ws( ctx, &ctx->ws, &ctx->ws_bytes, max_mbh ) ) return st;
-    auto rows_launch = [&]( const std::vector<const aa_dev_frame *> & jobs, int kind ) -> aa_status {
-      if ( jobs.empty() ) return AA_OK;
-      for ( size_t base = 0; base < jobs.size(); base += AA_MAX_BATCH ) {
-        aa_frame_list list;
-        const int cnt = static_cast<int>( std::min<size_t>( AA_MAX_BATCH, jobs.size() - base ) );
-        for ( int k = 0; k < AA_MAX_BATCH; k++ ) list.f[k] = k < cnt ? jobs[base + k] : nullptr;
-        if ( aa_status st = zero_ws( ctx, ctx->ws, cnt, max_mbh ) ) return st;
-        LaunchTimer t( ctx, kind );
-        const int e = aa::launch_recon_intra_rows( list, cnt, max_mbh, ctx->ws, ctx->n_xcd, ctx->compute );
-        if ( e ) return hip_fail( static_cast<hipError_t>( e ), "k_recon_intra_rows" );
-      }
-      return AA_OK;
-    };
-    if ( aa_status st = rows_launch( intra_jobs, 1 ) ) return st;
+    // intra rows: four frames per wave (any geometry), groups padded with null frames
+    for ( size_t base = 0; base < intra_jobs.size(); base += AA_MAX_BATCH ) {
+      aa_frame_list list;
+      const int cnt = static_cast<int>( std::min<size_t>( AA_MAX_BATCH, intra_jobs.size() - base ) );
+      const int groups = ( cnt + 3 ) / 4;
+      for ( int k = 0; k < AA_MAX_BATCH; k++ ) list.f[k] = k < cnt ? intra_jobs[base + k] : nullptr;
+      if ( aa_status st = zero_ws( ctx, ctx->ws, groups * 4, max_mbh ) ) return st;
+      LaunchTimer t( ctx, 1 );
+      if ( const int e = aa::launch_recon_intra4( list, groups, max_mbh, ctx->ws, ctx->n_xcd, ctx->compute ) ) return hip_fail( static_cast<hipError_t>( e ), "k_recon_intra4" );
+    }
     // loop filter: four frames of ONE geometry per wave.  Bucket by geometry, pad every bucket to a multiple of four
     // with null frames (slot 0 of a group is never null), split at group boundaries when a list is full.
     if ( !lf_jobs.empty() ) {

@@ -136,6 +136,64 @@ AA_HD int bpred_pixel( int mode, const uint8_t * E, int c, int r )
   }
 }
 
+// The same ten 4x4 predictors as data: every mode except DC and TM is "average of up to three entries of E", so a lane
+// can evaluate ANY mode with one table look-up and three byte reads instead of a ten-way branch (four macroblocks with
+// four different modes share one wave in k_recon_intra4).  Entry = i0 | i1 << 8 | i2 << 16 | kind << 24;
+// kind 0: avg3(E[i0],E[i1],E[i2])  1: avg2(E[i0],E[i1])  2: E[i0]  3: TM clamp255(E[i0] + E[i1] - E[i2])  4: DC
+enum : int { BP_AVG3 = 0, BP_AVG2 = 1, BP_COPY = 2, BP_TM = 3, BP_DC = 4 };
+AA_HD uint32_t bpred_entry( int mode, int c, int r )
+{
+  int i0 = 0, i1 = 0, i2 = 0, kind = BP_AVG3;
+  const int A = 5;                    // index of above[0] in E
+  switch ( mode ) {
+  case 0: kind = BP_DC; break;
+  case 1: kind = BP_TM; i0 = 3 - r; i1 = A + c; i2 = 4; break;
+  case 2: i0 = A + c - 1; i1 = A + c; i2 = A + c + 1; break;
+  case 3: if ( r < 3 ) { i0 = 4 - r; i1 = 3 - r; i2 = 2 - r; } else { i0 = 1; i1 = 0; i2 = 0; } break;
+  case 4: { const int i = c + r; if ( i < 6 ) { i0 = A + i; i1 = A + i + 1; i2 = A + i + 2; } else { i0 = A + 6; i1 = A + 7; i2 = A + 7; } break; }
+  case 5: { const int d = c - r + 3; i0 = d; i1 = d + 1; i2 = d + 2; break; }
+  case 6: {
+    const int k = 2 * c - r;
+    if ( k == -3 ) { i0 = 1; i1 = 2; i2 = 3; }
+    else if ( k == -2 ) { i0 = 2; i1 = 3; i2 = 4; }
+    else if ( k == -1 ) { i0 = 3; i1 = 4; i2 = 5; }
+    else if ( k & 1 ) { i0 = 4 + ( k >> 1 ); i1 = i0 + 1; i2 = i0 + 2; }
+    else { kind = BP_AVG2; i0 = 4 + ( k >> 1 ); i1 = i0 + 1; }
+    break; }
+  case 7: {
+    if ( c == 3 && r == 2 ) { i0 = A + 4; i1 = A + 5; i2 = A + 6; }
+    else if ( c == 3 && r == 3 ) { i0 = A + 5; i1 = A + 6; i2 = A + 7; }
+    else { const int i = c + ( r >> 1 ); i0 = A + i; i1 = A + i + 1; i2 = A + i + 2; if ( !( r & 1 ) ) kind = BP_AVG2; }
+    break; }
+  case 8: {
+    const int k = 2 * ( 3 - r ) + c;
+    if ( k >= 8 ) { i0 = k - 4; i1 = k - 3; i2 = k - 2; }
+    else { i0 = k >> 1; i1 = i0 + 1; i2 = i0 + 2; if ( !( k & 1 ) ) kind = BP_AVG2; }
+    break; }
+  default: {
+    const int k = 2 * r + c;
+    if ( k >= 6 ) { kind = BP_COPY; i0 = 0; }
+    else if ( k == 5 ) { i0 = 1; i1 = 0; i2 = 0; }
+    else { const int i = k >> 1; i0 = 3 - i; i1 = 2 - i; i2 = 1 - i; if ( !( k & 1 ) ) kind = BP_AVG2; }
+    break; }
+  }
+  if ( kind == BP_AVG2 || kind == BP_COPY || kind == BP_DC ) i2 = 0;        // unused taps must still be valid indices
+  if ( kind == BP_COPY || kind == BP_DC ) i1 = 0;
+  return ( static_cast<uint32_t>( i0 ) & 0xFFu ) | ( ( static_cast<uint32_t>( i1 ) & 0xFFu ) << 8 ) | ( ( static_cast<uint32_t>( i2 ) & 0xFFu ) << 16 )
+         | ( static_cast<uint32_t>( kind ) << 24 );
+}
+// evaluate an entry: e0,e1,e2 = E[i0],E[i1],E[i2]; dc = (sum of above[0..3] and left[0..3] + 4) >> 3
+AA_HD int bpred_eval( int kind, int e0, int e1, int e2, int dc )
+{
+  const int a3 = ( e0 + 2 * e1 + e2 + 2 ) >> 2, a2 = ( e0 + e1 + 1 ) >> 1, tm = clamp255( e0 + e1 - e2 );
+  int v = a3;
+  v = kind == BP_AVG2 ? a2 : v;
+  v = kind == BP_COPY ? e0 : v;
+  v = kind == BP_TM ? tm : v;
+  v = kind == BP_DC ? dc : v;
+  return v;
+}
+
 // ---- 16x16 / 8x8 intra predictors, one output pixel.  A[-1..n-1], L[0..n-1]; dc = precomputed DC value ----
 AA_HD int bigpred_pixel( int mode, int above, int left, int corner, int dc )
 {
@@ -191,6 +249,15 @@ AA_HD int absdiff_u8( int a, int b )
 #endif
 }
 AA_HD int imax( int a, int b ) { return a > b ? a : b; }
+// sum of the four bytes of a dword
+AA_HD int absdiff_sum4( uint32_t v )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+  return static_cast<int>( __builtin_amdgcn_sad_u8( v, 0u, 0u ) );
+#else
+  return static_cast<int>( ( v & 0xFF ) + ( ( v >> 8 ) & 0xFF ) + ( ( v >> 16 ) & 0xFF ) + ( v >> 24 ) );
+#endif
+}
 
 // vp8_filter_mask / vp8_hevmask.  Written without short-circuit operators on purpose: `||` chains compile to a cascade
 // of exec-mask branches per edge on gfx950; max-of-differences is straight-line VALU (v_sad_u8 + v_max3).

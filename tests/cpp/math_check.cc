@@ -59,6 +59,18 @@ int main()
     const uint32_t w = a & 0xFFFFu;
     if ( pk_from_u16( w ) != ( ( w & 0xFFu ) | ( ( w >> 8 ) << 16 ) ) || pk_to_u16( pk_from_u16( w ) ) != w ) { std::printf( "pk_u16\n" ); return 1; }
   }
+  for ( int it = 0; it < 20000; it++ ) {            // table form of the ten 4x4 predictors == the switch form
+    uint8_t E[13];
+    for ( int i = 0; i < 13; i++ ) E[i] = rnd() & 255;
+    int dc = 4; for ( int i = 0; i < 4; i++ ) dc += E[5 + i] + E[i];
+    dc >>= 3;
+    for ( int mode = 0; mode < 10; mode++ ) for ( int r = 0; r < 4; r++ ) for ( int c = 0; c < 4; c++ ) {
+      const uint32_t e = bpred_entry( mode, c, r );
+      const int got = bpred_eval( e >> 24, E[e & 0xFF], E[( e >> 8 ) & 0xFF], E[( e >> 16 ) & 0xFF], dc );
+      if ( ( e & 0xFF ) > 12 || ( ( e >> 8 ) & 0xFF ) > 12 || ( ( e >> 16 ) & 0xFF ) > 12 || got != bpred_pixel( mode, E, c, r ) ) {
+        std::printf( "bpred table: mode %d r %d c %d got %d want %d\n", mode, r, c, got, bpred_pixel( mode, E, c, r ) ); return 1; }
+    }
+  }
   std::printf( "OK %ld edge pairs\n", checked );
   return 0;
 }
