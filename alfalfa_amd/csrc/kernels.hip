@@ -482,6 +482,117 @@ __device__ __forceinline__ int take_ticket( aa_sync_ws * ws, const int xcc, int 
   return *slot;
 }
 
+struct alignas( 16 ) LfLds {
+  alignas( 16 ) uint8_t y[20][20];      // rows -4..15, cols -4..15
+  alignas( 16 ) uint8_t c[2][12][12];   // rows -4..7, cols -4..7
+};
+
+// One edge position handled by one lane: p = pointer to the first q-side pixel, s = step across the edge.
+__device__ __forceinline__ void lf_edge( uint8_t * p, const int s, const bool mb_edge, const LfParams & P )
+{
+  int p3 = p[-4 * s], p2 = p[-3 * s], p1 = p[-2 * s], p0 = p[-s], q0 = p[0], q1 = p[s], q2 = p[2 * s], q3 = p[3 * s];
+  const bool mask = lf_mask( P.interior_limit, mb_edge ? P.mb_limit : P.sb_limit, p3, p2, p1, p0, q0, q1, q2, q3 );
+  const bool hev = lf_hev( P.hev_threshold, p1, p0, q0, q1 );
+  if ( mb_edge ) {
+    lf_macroblock( mask, hev, p2, p1, p0, q0, q1, q2 );
+    p[-3 * s] = static_cast<uint8_t>( p2 ); p[2 * s] = static_cast<uint8_t>( q2 );
+  } else {
+    lf_subblock( mask, hev, p1, p0, q0, q1 );
+  }
+  p[-2 * s] = static_cast<uint8_t>( p1 ); p[-s] = static_cast<uint8_t>( p0 ); p[0] = static_cast<uint8_t>( q0 ); p[s] = static_cast<uint8_t>( q1 );
+}
+
+// The eight dependent edge passes of NormalLoopFilter::filter (loopfilter.cc:133-154) on the LDS copy of one MB:
+// left MB edge, inner vertical edges, top MB edge, inner horizontal edges.  Lanes 0..15 luma line, 16..23 U, 24..31 V.
+__device__ void lf_passes( LfLds & L, const bool have_left, const bool have_top, const bool inner, const LfParams & P, const int lane )
+{
+  const bool is_y = lane < 16, is_c = lane >= 16 && lane < 32;
+  const int cl = ( lane - 16 ) & 7, cp = ( lane - 16 ) >> 3;
+  if ( have_left ) {
+    if ( is_y ) lf_edge( &L.y[4 + lane][4], 1, true, P );
+    else if ( is_c ) lf_edge( &L.c[cp][4 + cl][4], 1, true, P );
+  }
+  __syncthreads();
+  if ( inner ) {
+    if ( is_y ) lf_edge( &L.y[4 + lane][8], 1, false, P );
+    else if ( is_c ) lf_edge( &L.c[cp][4 + cl][8], 1, false, P );
+    __syncthreads();
+    if ( is_y ) lf_edge( &L.y[4 + lane][12], 1, false, P );
+    __syncthreads();
+    if ( is_y ) lf_edge( &L.y[4 + lane][16], 1, false, P );
+    __syncthreads();
+  }
+  if ( have_top ) {
+    if ( is_y ) lf_edge( &L.y[4][4 + lane], 20, true, P );
+    else if ( is_c ) lf_edge( &L.c[cp][4][4 + cl], 12, true, P );
+  }
+  __syncthreads();
+  if ( inner ) {
+    if ( is_y ) lf_edge( &L.y[8][4 + lane], 20, false, P );
+    else if ( is_c ) lf_edge( &L.c[cp][8][4 + cl], 12, false, P );
+    __syncthreads();
+    if ( is_y ) lf_edge( &L.y[12][4 + lane], 20, false, P );
+    __syncthreads();
+    if ( is_y ) lf_edge( &L.y[16][4 + lane], 20, false, P );
+    __syncthreads();
+  }
+}
+
+// grid as k_recon_intra.  All MBs with col + 2*row == d are independent: their read/write footprints
+// ([x0-4,x0+15] x [y0-4,y0+15]) are disjoint and everything they read was finished by diagonals < d.
+__global__ __launch_bounds__( kLanes ) void k_loopfilter( const aa_frame_list list, const int diagonal, const int row_lo )
+{
+  __shared__ LfLds L;
+  const aa_dev_frame & f = *list.f[blockIdx.y];
+  if ( !f.loop_filter_level ) return;
+  const int row = row_lo + blockIdx.x, col = diagonal - 2 * row;
+  if ( row >= f.mbh || col < 0 || col >= f.mbw ) return;
+  const aa_mb_info & mb = f.mbs[row * f.mbw + col];
+  const int level = mb.lf_level;
+  if ( level == 0 ) return;
+  const int lane = threadIdx.x;
+  const int pw = f.mbw * 16, cw = pw >> 1;
+  const int x0 = col * 16, y0 = row * 16, cx0 = col * 8, cy0 = row * 8;
+  const LfParams P = lf_params( level, f.sharpness, f.key_frame );
+
+  // ---- stage: 20 rows x 5 dwords (Y), 2 x 12 rows x 3 dwords (U,V) ----
+  uint8_t * Y = f.cur[0];
+  for ( int i = lane; i < 100; i += kLanes ) {
+    const int r = i / 5, d = i % 5;
+    const int gy = y0 - 4 + r, gx = x0 - 4 + d * 4;
+    uint32_t v = 0;
+    if ( gy >= 0 && gx >= 0 ) v = *reinterpret_cast<const uint32_t *>( Y + static_cast<size_t>( gy ) * pw + gx );
+    *reinterpret_cast<uint32_t *>( &L.y[r][d * 4] ) = v;
+  }
+  for ( int i = lane; i < 72; i += kLanes ) {
+    const int pl = i / 36, e = i % 36, r = e / 3, d = e % 3;
+    const int gy = cy0 - 4 + r, gx = cx0 - 4 + d * 4;
+    uint32_t v = 0;
+    if ( gy >= 0 && gx >= 0 ) v = *reinterpret_cast<const uint32_t *>( f.cur[1 + pl] + static_cast<size_t>( gy ) * cw + gx );
+    *reinterpret_cast<uint32_t *>( &L.c[pl][r][d * 4] ) = v;
+  }
+  __syncthreads();
+
+  lf_passes( L, col > 0, row > 0, !( mb.flags & AA_MB_LF_SKIP_INNER ), P, lane );
+
+  // ---- write back what this MB may have modified: rows/cols -3..15 minus the untouched corner.
+  // Dword stores over [-4,15] are safe: nothing else touches that footprint during this launch.
+  for ( int i = lane; i < 100; i += kLanes ) {
+    const int r = i / 5, d = i % 5;
+    const int gy = y0 - 4 + r, gx = x0 - 4 + d * 4;
+    if ( r == 0 || gy < 0 || gx < 0 ) continue;            // row -4 is never modified
+    if ( r < 4 && d == 0 ) continue;                        // corner block
+    *reinterpret_cast<uint32_t *>( Y + static_cast<size_t>( gy ) * pw + gx ) = *reinterpret_cast<const uint32_t *>( &L.y[r][d * 4] );
+  }
+  for ( int i = lane; i < 72; i += kLanes ) {
+    const int pl = i / 36, e = i % 36, r = e / 3, d = e % 3;
+    const int gy = cy0 - 4 + r, gx = cx0 - 4 + d * 4;
+    if ( r == 0 || gy < 0 || gx < 0 ) continue;
+    if ( r < 4 && d == 0 ) continue;
+    *reinterpret_cast<uint32_t *>( f.cur[1 + pl] + static_cast<size_t>( gy ) * cw + gx ) = *reinterpret_cast<const uint32_t *>( &L.c[pl][r][d * 4] );
+  }
+}
+
 // ---- row-pipelined intra prediction, FOUR frames per wave ---------------------------------------------------------------
 // 16 lanes per frame ("slot"); each slot walks the intra macroblocks of ITS frame's row on its own (key frames: all four
 // in lock step; inter frames: whatever sparse columns each frame has).  A 4x4 sub-block is 16 pixels = 16 lanes, a 16x16
