@@ -41,7 +41,10 @@ struct aa_frame_list {
 
 // kernels.hip launchers (plain C++ signatures so runtime.cpp needs no HIP kernel syntax)
 namespace aa {
-int launch_recon_inter( const aa_frame_list & list, int n, unsigned max_mbs, void * stream );
+// whole-vector inter macroblocks, four per wave
+int launch_recon_inter4( const aa_frame_list & list, int n, unsigned max_mbs, void * stream );
+// one inter macroblock per wave; split_only: only SPLITMV macroblocks (the rest is launch_recon_inter4's)
+int launch_recon_inter( const aa_frame_list & list, int n, unsigned max_mbs, bool split_only, void * stream );
 int launch_recon_intra_diagonal( const aa_frame_list & list, int n, int diagonal, int row_lo, int rows, void * stream );
 int launch_loopfilter_diagonal( const aa_frame_list & list, int n, int diagonal, int row_lo, int rows, void * stream );
 // Row kernels are XCD-affine: unit u (frame / group) is processed by workgroups that run on XCD u % n_xcd.

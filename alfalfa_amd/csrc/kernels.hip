@@ -10,6 +10,7 @@
 // and by the raster-order dependency chains; every kernel stages its working set in LDS and touches each
 // global byte once.  Batches of independent frames (streams / GOPs) fill the chip: grid.y = frame in batch.
 #include <hip/hip_runtime.h>
+#include <cstddef>
 
 #include <cstdlib>
 
@@ -142,7 +143,7 @@ struct alignas( 16 ) InterLds {     // ~5 KB: 32 single-wave workgroups fit one 
 };
 
 // One inter macroblock by one wave.  `bx` = workgroup index within the frame's run of blocks (XCD-aware order).
-__device__ __forceinline__ void recon_inter_body( const aa_dev_frame & f, const unsigned bx, const unsigned max_mbs, InterLds & L )
+__device__ __forceinline__ void recon_inter_body( const aa_dev_frame & f, const unsigned bx, const unsigned max_mbs, InterLds & L, const bool split_only )
 {
   const unsigned total = static_cast<unsigned>( f.mbw ) * f.mbh;
   // workgroup b lands on XCD b % 8 (each XCD has its own L2): give each XCD a contiguous run of macroblocks so that
@@ -152,6 +153,7 @@ __device__ __forceinline__ void recon_inter_body( const aa_dev_frame & f, const 
   if ( mi >= total ) return;
   const aa_mb_info & mb = f.mbs[mi];
   if ( !( mb.flags & AA_MB_INTER ) ) return;
+  if ( split_only && mb.y_mode != SPLITMV ) return;       // whole-vector macroblocks are k_recon_inter4's
   const int lane = threadIdx.x;
   const int col = mi % f.mbw, row = mi / f.mbw;
   const int pw = f.mbw * 16, ph = f.mbh * 16, cw = pw >> 1, ch = ph >> 1;
@@ -303,10 +305,10 @@ __device__ __forceinline__ void recon_inter_body( const aa_dev_frame & f, const 
 }
 
 // grid.x = macroblock (XCD-aware order), grid.y = frame in batch
-__global__ __launch_bounds__( kLanes ) void k_recon_inter( const aa_frame_list list, const unsigned max_mbs )
+__global__ __launch_bounds__( kLanes ) void k_recon_inter( const aa_frame_list list, const unsigned max_mbs, const int split_only )
 {
   __shared__ InterLds L;
-  recon_inter_body( *list.f[blockIdx.y], blockIdx.x, max_mbs, L );
+  recon_inter_body( *list.f[blockIdx.y], blockIdx.x, max_mbs, L, split_only != 0 );
 }
 
 // ---- global accesses that other workgroups of the SAME launch consume / produced -----------------------------------
@@ -848,6 +850,244 @@ __global__ __launch_bounds__( kLanes ) void k_recon_intra4( const aa_frame_list 
   }
 }
 
+// ---- inter macroblocks, FOUR per wave ----------------------------------------------------------------------------------
+// 16 lanes per macroblock ("slot"), four consecutive macroblocks of a frame per wave.  The one-macroblock-per-wave body
+// above (still used for SPLITMV) left lanes idle in every phase -- 96 IDCT tasks, 136 + 96 filter tasks and 96 output
+// dwords on 64 lanes, the inverse WHT on 4 -- and paid its scalar set-up per macroblock.  Here:
+//   * residual: each lane runs whole 4x4 IDCTs in its registers (16 luma blocks = 16 lanes, 8 chroma blocks = 8 lanes);
+//   * six-tap passes: luma and chroma tasks of a macroblock form ONE list (136 horizontal, 96 vertical) walked 16 at a
+//     time with per-lane source / taps / destination, so partially filled rounds are shared by all four macroblocks;
+//   * output: lane = pixel row (luma 16 B per lane, chroma 8 B per lane).
+struct alignas( 16 ) Inter4Slot {
+  alignas( 16 ) int16_t res[24][16];        // residual of block b at [row*4+col]
+  alignas( 16 ) uint8_t wy[21][24];         // luma reference window rows -2..18, 24 bytes from the aligned column
+  uint8_t wc[2][13][16];                    // chroma windows (directly follows wy: the staging loop treats both as one dword array)
+  alignas( 16 ) uint8_t ty[16][24];         // first-pass output, TRANSPOSED (column-major): the vertical pass also reads consecutive bytes
+  alignas( 16 ) uint8_t tc[2][8][16];
+  alignas( 16 ) uint8_t pred[384];          // Y 16x16 | U 8x8 | V 8x8, row-major
+  alignas( 16 ) int16_t y2[32];
+};
+struct alignas( 16 ) Inter4Lds { Inter4Slot slot[4]; uint32_t taps[16]; };
+static_assert( offsetof( Inter4Slot, wc ) == offsetof( Inter4Slot, wy ) + 21 * 24, "wy and wc must be contiguous" );
+
+// sixtap_x4 with per-lane offset / fraction / taps (see sixtap_x4): d0 d1 d2 = 12 source bytes, outputs k take bytes o+k..o+k+5
+__device__ __forceinline__ uint32_t sixtap_x4_lane( const uint32_t d0, const uint32_t d1, const uint32_t d2, const int o, const int frac, const uint32_t t0123, const uint32_t t45 )
+{
+  const uint32_t w0 = __builtin_amdgcn_alignbyte( d1, d0, o ), w1 = __builtin_amdgcn_alignbyte( d2, d1, o ), w2 = __builtin_amdgcn_alignbyte( 0u, d2, o );
+  const uint32_t ident = __builtin_amdgcn_alignbyte( w1, w0, 2 );          // fraction 0: the centre tap 128 does not fit int8
+  const uint32_t b0 = w0 ^ 0x80808080u, b1 = w1 ^ 0x80808080u, b2 = w2 ^ 0x80808080u;
+  uint32_t out = 0;
+#pragma unroll
+  for ( int k = 0; k < 4; k++ ) {
+    const int a = static_cast<int>( __builtin_amdgcn_alignbyte( b1, b0, k ) ), b = static_cast<int>( __builtin_amdgcn_alignbyte( b2, b1, k ) );
+    int v = __builtin_amdgcn_sdot4( a, static_cast<int>( t0123 ), __builtin_amdgcn_sdot4( b, static_cast<int>( t45 ), 16384 + 64, false ), false ) >> 7;
+    asm volatile( "" : "+v"( v ) );          // keeps shift and clamp apart (hipcc 7.2 v_ashr_pk_u8_i32 mis-fold, see sixtap_x4)
+    out |= static_cast<uint32_t>( clamp255( v ) ) << ( 8 * k );
+  }
+  return frac == 0 ? ident : out;
+}
+
+// `bq` = workgroup index within the frame's run of blocks (XCD-aware order); macroblocks 4 q .. 4 q + 3
+__device__ __forceinline__ void recon_inter4_body( const aa_dev_frame & f, const unsigned bq, const unsigned max_quads, Inter4Lds & L )
+{
+  const int lane = threadIdx.x, slot = lane >> 4, l = lane & 15;
+  Inter4Slot & S = L.slot[slot];
+  if ( lane < 16 ) {            // packed six-tap coefficients of the 8 fractions: taps[2 f] = t0..t3, taps[2 f + 1] = t4,t5
+    uint32_t a, b; pack_taps( lane >> 1, a, b ); L.taps[lane] = ( lane & 1 ) ? b : a;
+  }
+  const unsigned total = static_cast<unsigned>( f.mbw ) * f.mbh;
+  const unsigned chunk = ( max_quads + 7u ) >> 3;          // each XCD (block b -> XCD b % 8) gets a contiguous run of quads
+  const unsigned qi = ( bq & 7u ) * chunk + ( bq >> 3 );
+  const unsigned mi = qi * 4u + slot;
+  const int mbw = f.mbw, pw = mbw * 16, ph = f.mbh * 16, cw = pw >> 1, ch = ph >> 1;
+  bool on = qi < max_quads && mi < total;
+  const aa_mb_info * const mb = f.mbs + ( on ? mi : 0u );
+  uint4 hd = make_uint4( 0, 0, 0, 0 ); uint32_t mvw = 0;
+  if ( on ) { hd = *reinterpret_cast<const uint4 *>( mb ); mvw = *reinterpret_cast<const uint32_t *>( &mb->u.mv[0][0] ); }
+  const int y_mode = hd.x & 0xFF, ref_frame = ( hd.x >> 16 ) & 3, segment = ( hd.x >> 24 ) & 3, flags = hd.y & 0xFF;
+  const uint32_t nz_mask = hd.z, coeff_index = hd.w;
+  on = on && ( flags & AA_MB_INTER ) && y_mode != SPLITMV;
+  if ( !__any( on ) ) return;
+  const int col = on ? static_cast<int>( mi % static_cast<unsigned>( mbw ) ) : 0, row = on ? static_cast<int>( mi / static_cast<unsigned>( mbw ) ) : 0;
+  const bool has_res = on && ( flags & AA_MB_HAS_NONZERO );
+  const bool has_y2 = has_res && ( flags & AA_MB_HAS_Y2 );
+  const uint8_t * const * ref = f.ref[on ? ref_frame : 1];
+  const uint8_t * const ref_y = ref[0], * const ref_u = ref[1], * const ref_v = ref[2];
+  // Y 16x16 with the MB vector, U/V 8x8 with the derived chroma vector (macroblock.cc:583-586)
+  const int mvx = static_cast<int16_t>( mvw & 0xFFFFu ), mvy = static_cast<int>( mvw ) >> 16;
+  const int cmx = chroma_mv( 4 * mvx ), cmy = chroma_mv( 4 * mvy );
+  const int sxy = col * 16 + ( mvx >> 3 ) - 2, syy = row * 16 + ( mvy >> 3 ) - 2;     // window origins (Q9: arithmetic shift)
+  const int sxc = col * 8 + ( cmx >> 3 ) - 2, syc = row * 8 + ( cmy >> 3 ) - 2;
+  // aligned-dword staging when the windows lie inside the planes, else byte-wise coordinate clamping (EdgeExtendedRaster)
+  const int axy = sxy & ~3, axc = sxc & ~3;
+  const bool inside = sxy >= 0 && syy >= 0 && axy + 24 <= pw && syy + 21 <= ph && sxc >= 0 && syc >= 0 && axc + 16 <= cw && syc + 13 <= ch;
+  const bool fast = on && inside;
+  // ---- reference windows: 126 + 104 dwords per macroblock, 15 per lane; issued before the residual work ----
+  uint32_t wreg[15];
+#pragma unroll
+  for ( int k = 0; k < 15; k++ ) {
+    const int i = l + 16 * k;
+    wreg[k] = 0;
+    if ( fast ) {
+      if ( i < 126 ) { const int r = i / 6, d = i % 6; wreg[k] = *reinterpret_cast<const uint32_t *>( ref_y + static_cast<size_t>( syy + r ) * pw + axy + d * 4 ); }
+      else if ( i < 230 ) { const int j = i - 126, pl = j / 52, e = j % 52, r = e >> 2, d = e & 3;
+                            wreg[k] = *reinterpret_cast<const uint32_t *>( ( pl ? ref_v : ref_u ) + static_cast<size_t>( syc + r ) * cw + axc + d * 4 ); }
+    }
+  }
+
+  // ---- residual ----
+  if ( __any( has_res ) ) {
+    const int16_t * const src = f.coeffs + static_cast<size_t>( coeff_index ) * 16;
+    const uint16_t * const q = f.quant[segment];
+    const bool y2_stored = has_y2 && ( ( nz_mask >> 24 ) & 1u );
+    if ( __any( y2_stored ) ) {
+      if ( y2_stored ) S.y2[l] = static_cast<int16_t>( dequant( src[__popc( nz_mask & 0xFFFFFFu ) * 16 + l], q[l ? 3 : 2] ) );
+      __syncthreads();
+      if ( y2_stored && l < 4 ) {
+        const Quad v = iwht_pass1( S.y2[l], S.y2[l + 4], S.y2[l + 8], S.y2[l + 12] );
+        S.y2[16 + l] = static_cast<int16_t>( v.v0 ); S.y2[16 + l + 4] = static_cast<int16_t>( v.v1 );
+        S.y2[16 + l + 8] = static_cast<int16_t>( v.v2 ); S.y2[16 + l + 12] = static_cast<int16_t>( v.v3 );
+      }
+      __syncthreads();
+      if ( y2_stored && l < 4 ) {
+        const int o = l * 4;
+        const Quad v = iwht_pass2( S.y2[16 + o], S.y2[16 + o + 1], S.y2[16 + o + 2], S.y2[16 + o + 3] );
+        S.y2[o] = static_cast<int16_t>( v.v0 ); S.y2[o + 1] = static_cast<int16_t>( v.v1 );
+        S.y2[o + 2] = static_cast<int16_t>( v.v2 ); S.y2[o + 3] = static_cast<int16_t>( v.v3 );
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for ( int round = 0; round < 2; round++ ) {
+      const int blk = round == 0 ? l : 16 + ( l & 7 );
+      const bool mine = has_res && ( round == 0 || l < 8 );
+      const bool stored = mine && ( ( nz_mask >> blk ) & 1u );
+      const bool wht_dc = round == 0 && has_y2;
+      const int dc = ( wht_dc && y2_stored ) ? S.y2[blk] : 0;
+      if ( __any( mine ) ) {
+        uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        if ( stored ) {
+          const uint4 * p = reinterpret_cast<const uint4 *>( src + __popc( nz_mask & ( ( 1u << blk ) - 1u ) ) * 16 );
+          const uint4 a = p[0], b = p[1];
+          d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+        }
+        const int base = round == 0 ? 0 : 4;
+        int r[16];
+        idct_block_regs( d, q[base], q[base + 1], wht_dc, dc, r );
+        if ( mine ) {
+          uint32_t o[8];
+#pragma unroll
+          for ( int i = 0; i < 8; i++ ) o[i] = ( static_cast<uint32_t>( r[2 * i] ) & 0xFFFFu ) | ( static_cast<uint32_t>( r[2 * i + 1] ) << 16 );
+          uint4 * dst = reinterpret_cast<uint4 *>( &S.res[blk][0] );
+          dst[0] = make_uint4( o[0], o[1], o[2], o[3] ); dst[1] = make_uint4( o[4], o[5], o[6], o[7] );
+        }
+      }
+    }
+  }
+
+  // ---- windows -> LDS ----
+  {
+    uint32_t * flat = reinterpret_cast<uint32_t *>( &S.wy[0][0] );          // wy (126 dwords) is directly followed by wc (104 dwords)
+    if ( fast ) {
+#pragma unroll
+      for ( int k = 0; k < 15; k++ ) { const int i = l + 16 * k; if ( i < 230 ) flat[i] = wreg[k]; }
+    }
+    if ( __any( on && !inside ) ) {
+      if ( on && !inside ) {
+        uint8_t * by = &S.wy[0][0];
+        for ( int i = l; i < 21 * 24; i += 16 ) {
+          const int r = i / 24, c = i % 24;
+          by[i] = ref_y[static_cast<size_t>( clampi( syy + r, 0, ph - 1 ) ) * pw + clampi( sxy + c, 0, pw - 1 )];
+        }
+        uint8_t * bc = &S.wc[0][0][0];
+        for ( int i = l; i < 2 * 13 * 16; i += 16 ) {
+          const int pl = i / 208, e = i % 208, r = e >> 4, c = e & 15;
+          bc[i] = ( pl ? ref_v : ref_u )[static_cast<size_t>( clampi( syc + r, 0, ch - 1 ) ) * cw + clampi( sxc + c, 0, cw - 1 )];
+        }
+      }
+    }
+  }
+  const int oy = inside ? ( sxy & 3 ) : 0, oc = inside ? ( sxc & 3 ) : 0;
+  __syncthreads();
+
+  // ---- horizontal pass: 84 luma + 52 chroma tasks of four outputs; results to the transposed buffers t[column][row] ----
+  const uint8_t * const wyb = &S.wy[0][0]; const uint8_t * const wcb = &S.wc[0][0][0];
+  uint8_t * const tyb = &S.ty[0][0]; uint8_t * const tcb = &S.tc[0][0][0];
+  if ( on ) {
+#pragma unroll 1
+    for ( int t = l; t < 136; t += 16 ) {
+      const bool lu = t < 84;
+      const int j = t - 84, pl = j >= 26 ? 1 : 0, e = j - 26 * pl;
+      const int r = lu ? t >> 2 : e >> 1, g = lu ? t & 3 : e & 1;
+      const uint8_t * sp = lu ? wyb + r * 24 + g * 4 : wcb + pl * 208 + r * 16 + g * 4;
+      const int frac = lu ? mvx & 7 : cmx & 7;
+      const uint32_t o4 = sixtap_x4_lane( *reinterpret_cast<const uint32_t *>( sp ), *reinterpret_cast<const uint32_t *>( sp + 4 ), *reinterpret_cast<const uint32_t *>( sp + 8 ),
+                                          lu ? oy : oc, frac, L.taps[2 * frac], L.taps[2 * frac + 1] );
+      uint8_t * tb = lu ? tyb + ( g * 4 ) * 24 + r : tcb + pl * 128 + ( g * 4 ) * 16 + r;
+      const int ts = lu ? 24 : 16;
+      tb[0] = static_cast<uint8_t>( o4 ); tb[ts] = static_cast<uint8_t>( o4 >> 8 ); tb[2 * ts] = static_cast<uint8_t>( o4 >> 16 ); tb[3 * ts] = static_cast<uint8_t>( o4 >> 24 );
+    }
+  }
+  __syncthreads();
+  // ---- vertical pass: 64 luma + 32 chroma tasks: (column c, row group i) -> rows 4i..4i+3 of column c ----
+  if ( on ) {
+#pragma unroll
+    for ( int k = 0; k < 6; k++ ) {
+      const int t = l + 16 * k;
+      const bool lu = k < 4;
+      const int j = t - 64, pl = j >> 4, c = lu ? t >> 2 : ( j >> 1 ) & 7, i = lu ? t & 3 : j & 1;
+      const uint8_t * sp = lu ? tyb + c * 24 + i * 4 : tcb + pl * 128 + c * 16 + i * 4;
+      const int frac = lu ? mvy & 7 : cmy & 7;
+      const uint32_t o4 = sixtap_x4_lane( *reinterpret_cast<const uint32_t *>( sp ), *reinterpret_cast<const uint32_t *>( sp + 4 ), *reinterpret_cast<const uint32_t *>( sp + 8 ),
+                                          0, frac, L.taps[2 * frac], L.taps[2 * frac + 1] );
+      uint8_t * pb = lu ? S.pred + ( i * 4 ) * 16 + c : S.pred + 256 + pl * 64 + ( i * 4 ) * 8 + c;
+      const int ps = lu ? 16 : 8;
+      pb[0] = static_cast<uint8_t>( o4 ); pb[ps] = static_cast<uint8_t>( o4 >> 8 ); pb[2 * ps] = static_cast<uint8_t>( o4 >> 16 ); pb[3 * ps] = static_cast<uint8_t>( o4 >> 24 );
+    }
+  }
+  __syncthreads();
+
+  // ---- prediction + residual -> raster: lane = luma row l (16 B), and chroma plane l >> 3 row l & 7 (8 B) ----
+  if ( on ) {
+    uint32_t o[4];
+#pragma unroll
+    for ( int k = 0; k < 4; k++ ) {
+      const uint32_t p4 = *reinterpret_cast<const uint32_t *>( S.pred + l * 16 + 4 * k );
+      const int16_t * rs = &S.res[( l >> 2 ) * 4 + k][( l & 3 ) * 4];
+      uint32_t out = p4;
+      if ( has_res ) {
+        out = 0;
+#pragma unroll
+        for ( int j = 0; j < 4; j++ ) out |= static_cast<uint32_t>( clamp255( static_cast<int>( ( p4 >> ( 8 * j ) ) & 0xFF ) + rs[j] ) ) << ( 8 * j );
+      }
+      o[k] = out;
+    }
+    *reinterpret_cast<uint4 *>( f.cur[0] + static_cast<size_t>( row * 16 + l ) * pw + col * 16 ) = make_uint4( o[0], o[1], o[2], o[3] );
+    const int pl = l >> 3, r = l & 7;
+    uint32_t oc2[2];
+#pragma unroll
+    for ( int k = 0; k < 2; k++ ) {
+      const uint32_t p4 = *reinterpret_cast<const uint32_t *>( S.pred + 256 + pl * 64 + r * 8 + 4 * k );
+      const int16_t * rs = &S.res[16 + pl * 4 + ( r >> 2 ) * 2 + k][( r & 3 ) * 4];
+      uint32_t out = p4;
+      if ( has_res ) {
+        out = 0;
+#pragma unroll
+        for ( int j = 0; j < 4; j++ ) out |= static_cast<uint32_t>( clamp255( static_cast<int>( ( p4 >> ( 8 * j ) ) & 0xFF ) + rs[j] ) ) << ( 8 * j );
+      }
+      oc2[k] = out;
+    }
+    *reinterpret_cast<uint2 *>( f.cur[1 + pl] + static_cast<size_t>( row * 8 + r ) * cw + col * 8 ) = make_uint2( oc2[0], oc2[1] );
+  }
+}
+
+// grid.x = quad of macroblocks (XCD-aware order), grid.y = frame in batch
+__global__ __launch_bounds__( kLanes ) void k_recon_inter4( const aa_frame_list list, const unsigned max_quads )
+{
+  __shared__ Inter4Lds L;
+  recon_inter4_body( *list.f[blockIdx.y], blockIdx.x, max_quads, L );
+}
+
 // ---- row-pipelined loop filter: packed arithmetic, FOUR frames per wave, strip-staged I/O ----------------------------
 // 16 lanes per frame ("slot").  A lane filters TWO positions of an edge at once in packed int16 (vp8_math.hh pk2):
 //   vertical edges   (V phase): lane j < 8 owns luma pixel rows 2j, 2j+1; lane 8+k owns chroma rows 2(k&3), +1 of plane k>>2;
@@ -1143,10 +1383,17 @@ __global__ void k_probe_xcds( int * out )
 
 } // namespace
 
-int launch_recon_inter( const aa_frame_list & list, int n, unsigned max_mbs, void * stream )
+int launch_recon_inter( const aa_frame_list & list, int n, unsigned max_mbs, bool split_only, void * stream )
 {
   const unsigned blocks = ( ( max_mbs + 7u ) >> 3 ) * 8u;
-  hipLaunchKernelGGL( k_recon_inter, dim3( blocks, n ), dim3( kLanes ), 0, static_cast<hipStream_t>( stream ), list, max_mbs );
+  hipLaunchKernelGGL( k_recon_inter, dim3( blocks, n ), dim3( kLanes ), 0, static_cast<hipStream_t>( stream ), list, max_mbs, split_only ? 1 : 0 );
+  return static_cast<int>( hipGetLastError() );
+}
+int launch_recon_inter4( const aa_frame_list & list, int n, unsigned max_mbs, void * stream )
+{
+  const unsigned quads = ( max_mbs + 3u ) >> 2;
+  const unsigned blocks = ( ( quads + 7u ) >> 3 ) * 8u;
+  hipLaunchKernelGGL( k_recon_inter4, dim3( blocks, n ), dim3( kLanes ), 0, static_cast<hipStream_t>( stream ), list, quads );
   return static_cast<int>( hipGetLastError() );
 }
 int launch_recon_intra_diagonal( const aa_frame_list & list, int n, int diagonal, int row_lo, int rows, void * stream )

@@ -60,6 +60,7 @@ struct FrameRec {
   int out_slot = -1;
   int ref_after[3] = { -1, -1, -1 };       // References (last, golden, alt) after this frame, as frame indices
   std::vector<uint8_t> intra_diagonals;    // [d] != 0: diagonal d holds an intra MB
+  bool has_split = false;                  // some macroblock is SPLITMV (handled by the one-macroblock-per-wave kernel)
   bool handle_held = true;
 };
 
@@ -434,6 +435,9 @@ aa_status aa_stream_parse( aa_stream * s, const uint8_t * data, size_t size, int
         intra_rows[r * words_per_row + ( col >> 6 )] |= 1ull << ( col & 63 );
       }
 
+  if ( !h.key_frame )
+    for ( size_t i = 0; i < nmb; i++ ) if ( mbs[i].y_mode == 9 /* SPLITMV */ ) { rec.has_split = true; break; }
+
   // raster slots: output + the References this frame predicts from; then Frame::copy_to on slot ids
   int out_slot;
   if ( aa_status st = alloc_slot( s, &out_slot ) ) return st;
@@ -497,6 +501,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
   std::vector<const FrameRec *> intra_recs;
   std::vector<uint32_t> lf_geometry;
   unsigned max_mbs = 0; int max_mbw = 0, max_mbh = 0;
+  bool any_split = false;
   bool same_geometry = true;     // two-frames-per-wave loop filter needs equal macroblock dimensions in the batch
   uint64_t total_mbs = 0;
   for ( int i = 0; i < n; i++ ) {
@@ -511,7 +516,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
     aa_stream * s = streams[i];
     const FrameRec & r = s->frames[frame_index[i]];
     const aa_frame_header & h = r.hdr;
-    if ( h.num_intra_mbs < h.num_macroblocks ) inter_jobs.push_back( r.dev_job );
+    if ( h.num_intra_mbs < h.num_macroblocks ) { inter_jobs.push_back( r.dev_job ); any_split = any_split || r.has_split; }
     if ( h.has_intra_mb ) { intra_jobs.push_back( r.dev_job ); intra_recs.push_back( &r ); }
     if ( h.loop_filter_level ) { lf_jobs.push_back( r.dev_job ); lf_geometry.push_back( ( static_cast<uint32_t>( h.mb_width ) << 16 ) | h.mb_height ); }
     if ( i > 0 && ( h.mb_width != streams[0]->frames[frame_index[0]].hdr.mb_width || h.mb_height != streams[0]->frames[frame_index[0]].hdr.mb_height ) ) same_geometry = false;
@@ -537,11 +542,16 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
     return AA_OK;
   };
 
-  // 1. every inter-coded macroblock of the batch, one launch
+  // 1. every inter-coded macroblock of the batch: whole-vector macroblocks four per wave; SPLITMV ones (if any) one per wave
   if ( !inter_jobs.empty() ) {
-    const int e = for_each_list( inter_jobs, [&]( const aa_frame_list & l, int cnt ) {
-      LaunchTimer t( ctx, 0 ); return aa::launch_recon_inter( l, cnt, max_mbs, ctx->compute ); } );
-    if ( aa_status st = check( e, "k_recon_inter" ) ) return st;
+    int e = for_each_list( inter_jobs, [&]( const aa_frame_list & l, int cnt ) {
+      LaunchTimer t( ctx, 0 ); return aa::launch_recon_inter4( l, cnt, max_mbs, ctx->compute ); } );
+    if ( aa_status st = check( e, "k_recon_inter4" ) ) return st;
+    if ( any_split ) {
+      e = for_each_list( inter_jobs, [&]( const aa_frame_list & l, int cnt ) {
+        LaunchTimer t( ctx, 0 ); return aa::launch_recon_inter( l, cnt, max_mbs, true, ctx->compute ); } );
+      if ( aa_status st = check( e, "k_recon_inter" ) ) return st;
+    }
   }
   const int ndiag = max_mbw + 2 * ( max_mbh - 1 );
   if ( ctx->schedule == 0 ) {
