@@ -71,7 +71,7 @@ SYMBOLS = [
     ("aa_ctx_set_schedule", C.c_int, [_P, C.c_int]), ("aa_ctx_compute_stream", _P, [_P]), ("aa_ctx_copy_stream", _P, [_P]),
     ("aa_stream_create", C.c_int, [_P, C.c_uint16, C.c_uint16, C.POINTER(_P)]), ("aa_stream_destroy", None, [_P]),
     ("aa_stream_parse", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(FrameHeader)]),
-    ("aa_stream_upload", C.c_int, [_P]),
+    ("aa_stream_upload", C.c_int, [_P]), ("aa_stream_release_staging", C.c_int, [_P]),
     ("aa_decode_batch", C.c_int, [_P, C.POINTER(_P), C.c_int, C.POINTER(C.c_int)]),
     ("aa_stream_decode", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("aa_stream_frame_count", C.c_int, [_P]), ("aa_stream_release_before", C.c_int, [_P, C.c_int]),

@@ -466,7 +466,9 @@ __global__ __launch_bounds__( kLanes ) void k_recon_intra( const aa_frame_list l
 // dependencies of intra prediction and of the loop filter: the same 2:1 wavefront as the per-diagonal launches, without
 // 254 kernel boundaries).
 // Work is handed out by TICKET, one queue per XCD: unit u belongs to XCD u % n_xcd, and a workgroup only ever takes
-// tickets of the XCD it really runs on (HW_REG_XCC_ID), in dependency order (unit-major, rows ascending).  So
+// tickets of the XCD it really runs on (HW_REG_XCC_ID), in dependency order: ROW-major (row 0 of every unit of the XCD,
+// then row 1, ...), so that when fewer workgroups are resident than there are rows the chip sweeps all units top to
+// bottom ONCE instead of running the 2:1 wavefront's critical path once per batch of resident units.  So
 //   * all rows of a unit run on one XCD -> hand-offs go through that XCD's L2 (see above);
 //   * deadlock freedom does not rely on residency or dispatch order: the row a workgroup waits for has a lower ticket
 //     of the same queue and is therefore held by a workgroup that is already running;
@@ -834,7 +836,6 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
   if ( frame_on && l == 0 ) __hip_atomic_store( &progress[row], mbw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
 }
 
-// ticket t of queue x -> (group (t / mbh_max) * n_xcd + x, row t % mbh_max)
 __global__ __launch_bounds__( kLanes ) void k_recon_intra4( const aa_frame_list list, const int n_groups, const int mbh_max, aa_sync_ws * ws, const int n_xcd )
 {
   __shared__ Intra4Lds L;
@@ -844,9 +845,9 @@ __global__ __launch_bounds__( kLanes ) void k_recon_intra4( const aa_frame_list 
   if ( xcc >= n_xcd ) { if ( threadIdx.x == 0 ) atomicExch( &ws->error, 3 ); return; }
   for ( ;; ) {
     const int t = take_ticket( ws, xcc, &s_ticket, threadIdx.x );
-    const int group = ( t / mbh_max ) * n_xcd + xcc;
-    if ( group >= n_groups ) return;
-    recon_intra4_row( list, group, t % mbh_max, mbh_max, ws, L );
+    const int mine = xcc < n_groups ? ( n_groups - xcc + n_xcd - 1 ) / n_xcd : 0;     // groups of this XCD: xcc, xcc + n_xcd, ...
+    if ( t >= mine * mbh_max ) return;
+    recon_intra4_row( list, ( t % mine ) * n_xcd + xcc, t / mine, mbh_max, ws, L );    // ROW-major: see take_ticket
   }
 }
 
@@ -1352,7 +1353,6 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
   if ( lane == 0 && pending >= 0 ) __hip_atomic_store( &progress[row], pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
 }
 
-// ticket t of queue x -> (group (t / mbh_max) * n_xcd + x, row t % mbh_max)
 __device__ __forceinline__ void loopfilter_rows4_body( const aa_frame_list & list, const int n_groups, const int mbh_max, const int mbw_max, aa_sync_ws * ws, uint8_t * bnd,
                                                         const int n_xcd, LfStripLds & S, int & s_ticket, const int dbg )
 {
@@ -1360,9 +1360,9 @@ __device__ __forceinline__ void loopfilter_rows4_body( const aa_frame_list & lis
   if ( xcc >= n_xcd ) { if ( threadIdx.x == 0 ) atomicExch( &ws->error, 3 ); return; }
   for ( ;; ) {
     const int t = take_ticket( ws, xcc, &s_ticket, threadIdx.x );
-    const int group = ( t / mbh_max ) * n_xcd + xcc;
-    if ( group >= n_groups ) return;
-    loopfilter_strip_row( list, group, t % mbh_max, mbh_max, mbw_max, ws, bnd, S, dbg );
+    const int mine = xcc < n_groups ? ( n_groups - xcc + n_xcd - 1 ) / n_xcd : 0;     // groups of this XCD: xcc, xcc + n_xcd, ...
+    if ( t >= mine * mbh_max ) return;
+    loopfilter_strip_row( list, ( t % mine ) * n_xcd + xcc, t / mine, mbh_max, mbw_max, ws, bnd, S, dbg );    // ROW-major: see take_ticket
   }
 }
 

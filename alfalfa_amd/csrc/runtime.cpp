@@ -385,7 +385,7 @@ void aa_stream_destroy( aa_stream * s )
   if ( !s ) return;
   (void) hipSetDevice( s->ctx->device );
   (void) hipStreamSynchronize( s->ctx->compute ); (void) hipStreamSynchronize( s->ctx->copy );
-  for ( auto & c : s->chunks ) { (void) hipHostFree( c.host ); (void) hipFree( c.dev ); }
+  for ( auto & c : s->chunks ) { if ( c.host ) (void) hipHostFree( c.host ); (void) hipFree( c.dev ); }
   for ( auto & sl : s->slots ) (void) hipFree( sl.dev );
   aa_ctx * ctx = s->ctx;
   delete s;
@@ -481,7 +481,7 @@ aa_status aa_stream_upload( aa_stream * s )
   if ( aa_status st = set_device( s->ctx ) ) return st;
   bool any = false;
   for ( auto & c : s->chunks ) {
-    if ( c.uploaded < c.used ) {
+    if ( c.host && c.uploaded < c.used ) {
       HIP_TRY( hipMemcpyAsync( c.dev + c.uploaded, c.host + c.uploaded, c.used - c.uploaded, hipMemcpyHostToDevice, s->ctx->copy ) );
       c.uploaded = c.used; any = true;
     }
@@ -490,6 +490,22 @@ aa_status aa_stream_upload( aa_stream * s )
     HIP_TRY( hipEventRecord( s->ctx->upload_done, s->ctx->copy ) );
     HIP_TRY( hipStreamWaitEvent( s->ctx->compute, s->ctx->upload_done, 0 ) );
   }
+  return AA_OK;
+}
+
+aa_status aa_stream_release_staging( aa_stream * s )
+{
+  if ( !s ) return fail( AA_ERR_ARGUMENT, "null stream" );
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  if ( aa_status st = aa_stream_upload( s ) ) return st;
+  HIP_TRY( hipStreamSynchronize( s->ctx->copy ) );
+  for ( auto & c : s->chunks ) {
+    if ( !c.host ) continue;
+    HIP_TRY( hipHostFree( c.host ) );
+    c.host = nullptr;
+    c.capacity = c.used;           // sealed: the next frame is staged in a new chunk
+  }
+  for ( auto & f : s->frames ) f.host_job = nullptr;
   return AA_OK;
 }
 

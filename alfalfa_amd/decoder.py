@@ -128,6 +128,10 @@ class Decoder:
     def upload(self):
         capi.check(self.L.aa_stream_upload(self.h))
 
+    def release_staging(self):
+        """Free the pinned host staging of everything parsed so far (uploads it first)."""
+        capi.check(self.L.aa_stream_release_staging(self.h))
+
     def decode_frame(self, frame_index):
         self.ctx.decode_batch([self], [frame_index])
 

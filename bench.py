@@ -33,7 +33,7 @@ PATH_BYTES_PER_MB = 2416       # inter + deblock, whole path
 # HBM bytes per macroblock measured with rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KiB -> bytes, per launch / MBs per launch),
 # profiles/r01e_kernels.md; used for roofline.traffic (counters cannot be read from inside this process)
 PMC_TRAFFIC_BYTES_PER_MB = {"recon_inter": 496 + 384, "loopfilter": 351 + 576, "recon_intra": None}
-KERNEL_NAMES = {"rows": {"recon_inter": "k_recon_inter", "recon_intra": "k_recon_intra4", "loopfilter": "k_loopfilter_rows4"},
+KERNEL_NAMES = {"rows": {"recon_inter": "k_recon_inter4", "recon_intra": "k_recon_intra4", "loopfilter": "k_loopfilter_rows4"},
                 "diagonal": {"recon_inter": "k_recon_inter", "recon_intra": "k_recon_intra", "loopfilter": "k_loopfilter"}}
 
 
@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="1080p_inter_lf")
-    ap.add_argument("--streams", type=int, default=240, help="independent streams per GPU")
+    ap.add_argument("--streams", type=int, default=480, help="independent streams per GPU")
     ap.add_argument("--frames", type=int, default=12, help="frames per stream")
     ap.add_argument("--schedule", default="rows", choices=["rows", "diagonal"])
     ap.add_argument("--queues", type=int, default=1, help="independent HIP queues (contexts) the streams are spread over")
@@ -141,26 +141,31 @@ def main():
         for fr in streams[i]:
             decs[i].parse_frame(fr)
         return time.perf_counter() - t
-    nthreads = min(S, os.cpu_count() or 1)
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=nthreads) as ex:
-        per_stream_parse_s = list(ex.map(parse_stream, range(S)))
-    t_parse_wall = time.perf_counter() - t0
+    nthreads = min(S, os.cpu_count() or 1, 128)
     compressed_bytes = sum(len(fr) for st in streams for fr in st)
+    # waves of `nthreads` streams: parse (one host thread per stream) -> H2D on the copy stream -> give the pinned staging
+    # back, so that pinned host memory stays bounded however many streams a GPU holds
+    per_stream_parse_s = []
+    t_parse_wall = t_h2d = 0.0
+    with ThreadPoolExecutor(max_workers=nthreads) as ex:
+        for base in range(0, S, nthreads):
+            ids = range(base, min(S, base + nthreads))
+            t0 = time.perf_counter()
+            per_stream_parse_s += list(ex.map(parse_stream, ids))
+            t_parse_wall += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for i in ids:
+                decs[i].upload()
+            sync_all()
+            t_h2d += time.perf_counter() - t0
+            for i in ids:
+                decs[i].release_staging()
     # the parser alone (no pinned/device allocation, one thread): the serial BoolDecoder rate per host core
     pp = aa.Parser(width, height)
     t0 = time.perf_counter()
     for fr in streams[0]:
         pp.parse(fr)
     parser_only = len(streams[0]) * mbs_per_frame / (time.perf_counter() - t0)
-
-    # ---- H2D of the parsed records on the copy stream ----
-    sync_all()
-    t0 = time.perf_counter()
-    for d in decs:
-        d.upload()
-    sync_all()
-    t_h2d = time.perf_counter() - t0
 
     def one_pass():
         for f in range(F):

@@ -155,6 +155,10 @@ void aa_stream_destroy( aa_stream * s );
 aa_status aa_stream_parse( aa_stream * s, const uint8_t * data, size_t size, int * frame_index, aa_frame_header * hdr_out );
 /* hipMemcpyAsync (copy stream) of every parsed, not yet uploaded frame's records into HBM. */
 aa_status aa_stream_upload( aa_stream * s );
+/* Give the pinned host staging of everything uploaded so far back to the system (the device copy is what decode reads).
+ * Waits for this context's copy stream.  Later aa_stream_parse calls stage into fresh pinned memory.  Optional: a
+ * long-lived bundle decoder that parses ahead of decoding calls it to bound pinned memory. */
+aa_status aa_stream_release_staging( aa_stream * s );
 /* Device half for frame `frame_index` of each of n streams (all on the same ctx): reconstruct, loop-filter,
  * update references.  Frames of one stream must be submitted in order.  Asynchronous. */
 aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, const int * frame_index );
