@@ -616,12 +616,15 @@ struct alignas( 16 ) Intra4Lds { Intra4Slot slot[4]; uint32_t tab[160]; };
 // dequantise + inverse DCT of one 4x4 block in one lane's registers: d[8] = 16 packed int16 coefficients -> 16 residuals
 __device__ __forceinline__ void idct_block_regs( const uint32_t ( &d )[8], const int fdc, const int fac, const bool replace_dc, const int dc, int ( &r )[16] )
 {
+  // dequantise two coefficients per instruction: the int16 wrap-around of the reference (quantization.cc:110-121) is
+  // exactly the low half of the product
+  const pk2 fpair = pk_splat( fac ), f0 = ( static_cast<uint32_t>( fdc ) & 0xFFFFu ) | ( static_cast<uint32_t>( fac ) << 16 );
   int c[16];
 #pragma unroll
-  for ( int i = 0; i < 8; i++ ) { c[2 * i] = static_cast<int16_t>( d[i] & 0xFFFFu ); c[2 * i + 1] = static_cast<int>( d[i] ) >> 16; }
-  c[0] = dequant( c[0], fdc );
-#pragma unroll
-  for ( int i = 1; i < 16; i++ ) c[i] = dequant( c[i], fac );
+  for ( int i = 0; i < 8; i++ ) {
+    const pk2 m = pk_mul( d[i], i == 0 ? f0 : fpair );
+    c[2 * i] = static_cast<int16_t>( m & 0xFFFFu ); c[2 * i + 1] = static_cast<int>( m ) >> 16;
+  }
   if ( replace_dc ) c[0] = dc;
   int im[16];
 #pragma unroll
@@ -877,15 +880,28 @@ __device__ __forceinline__ uint32_t sixtap_x4_lane( const uint32_t d0, const uin
   const uint32_t w0 = __builtin_amdgcn_alignbyte( d1, d0, o ), w1 = __builtin_amdgcn_alignbyte( d2, d1, o ), w2 = __builtin_amdgcn_alignbyte( 0u, d2, o );
   const uint32_t ident = __builtin_amdgcn_alignbyte( w1, w0, 2 );          // fraction 0: the centre tap 128 does not fit int8
   const uint32_t b0 = w0 ^ 0x80808080u, b1 = w1 ^ 0x80808080u, b2 = w2 ^ 0x80808080u;
-  uint32_t out = 0;
+  int v[4];
 #pragma unroll
   for ( int k = 0; k < 4; k++ ) {
     const int a = static_cast<int>( __builtin_amdgcn_alignbyte( b1, b0, k ) ), b = static_cast<int>( __builtin_amdgcn_alignbyte( b2, b1, k ) );
-    int v = __builtin_amdgcn_sdot4( a, static_cast<int>( t0123 ), __builtin_amdgcn_sdot4( b, static_cast<int>( t45 ), 16384 + 64, false ), false ) >> 7;
-    asm volatile( "" : "+v"( v ) );          // keeps shift and clamp apart (hipcc 7.2 v_ashr_pk_u8_i32 mis-fold, see sixtap_x4)
-    out |= static_cast<uint32_t>( clamp255( v ) ) << ( 8 * k );
+    v[k] = __builtin_amdgcn_sdot4( a, static_cast<int>( t0123 ), __builtin_amdgcn_sdot4( b, static_cast<int>( t45 ), 16384 + 64, false ), false );
   }
+  // v_ashr_pk_u8_i32 = {sat_u8(s0 >> 7), sat_u8(s1 >> 7)} in the LOW 16 bits, upper bits left alone (tools/hw_probe_pk.hip):
+  // the permute picks bytes 0,1 of each pair, so nothing depends on those upper bits
+  const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32( v[0], v[1], 7 ), hi = __builtin_amdgcn_ashr_pk_u8_i32( v[2], v[3], 7 );
+  const uint32_t out = __builtin_amdgcn_perm( hi, lo, 0x05040100u );
   return frac == 0 ? ident : out;
+}
+
+// four prediction pixels + four int16 residuals -> four clamped pixels, in packed int16 (v_sat_pk_u8_i16 = two clamp255)
+__device__ __forceinline__ uint32_t add_residual_x4( const uint32_t p4, const int16_t * res )
+{
+  const uint2 r = *reinterpret_cast<const uint2 *>( res );
+  const pk2 s0 = pk_add( __builtin_amdgcn_perm( 0u, p4, 0x0c010c00u ), r.x ), s1 = pk_add( __builtin_amdgcn_perm( 0u, p4, 0x0c030c02u ), r.y );
+  uint32_t b0, b1;
+  asm( "v_sat_pk_u8_i16 %0, %1" : "=v"( b0 ) : "v"( s0 ) );
+  asm( "v_sat_pk_u8_i16 %0, %1" : "=v"( b1 ) : "v"( s1 ) );
+  return b0 | ( b1 << 16 );
 }
 
 // `bq` = workgroup index within the frame's run of blocks (XCD-aware order); macroblocks 4 q .. 4 q + 3
@@ -924,15 +940,26 @@ __device__ __forceinline__ void recon_inter4_body( const aa_dev_frame & f, const
   const bool inside = sxy >= 0 && syy >= 0 && axy + 24 <= pw && syy + 21 <= ph && sxc >= 0 && syc >= 0 && axc + 16 <= cw && syc + 13 <= ch;
   const bool fast = on && inside;
   // ---- reference windows: 126 + 104 dwords per macroblock, 15 per lane; issued before the residual work ----
+  // dword i = l + 16 k of the macroblock's 230: luma row i / 6, dword i % 6; written so that the per-k part is constant:
+  // i = 6 (l/6 + 2k) + (l%6 + 4k)  ->  row = l/6 + 2k + (4k)/6 + (l%6 + (4k)%6 >= 6), dword likewise
   uint32_t wreg[15];
+  const int l6 = l / 6, lm = l - 6 * l6;
+  const uint8_t * const wy0 = ref_y + static_cast<ptrdiff_t>( syy ) * pw + axy;
+  const uint8_t * const wu0 = ref_u + static_cast<ptrdiff_t>( syc ) * cw + axc;
+  const uint8_t * const wv0 = ref_v + static_cast<ptrdiff_t>( syc ) * cw + axc;
 #pragma unroll
   for ( int k = 0; k < 15; k++ ) {
     const int i = l + 16 * k;
     wreg[k] = 0;
     if ( fast ) {
-      if ( i < 126 ) { const int r = i / 6, d = i % 6; wreg[k] = *reinterpret_cast<const uint32_t *>( ref_y + static_cast<size_t>( syy + r ) * pw + axy + d * 4 ); }
-      else if ( i < 230 ) { const int j = i - 126, pl = j / 52, e = j % 52, r = e >> 2, d = e & 3;
-                            wreg[k] = *reinterpret_cast<const uint32_t *>( ( pl ? ref_v : ref_u ) + static_cast<size_t>( syc + r ) * cw + axc + d * 4 ); }
+      if ( k < 7 || ( k == 7 && i < 126 ) ) {
+        const int carry = lm + ( 4 * k ) % 6 >= 6 ? 1 : 0;
+        const int r = l6 + 2 * k + ( 4 * k ) / 6 + carry, d = lm + ( 4 * k ) % 6 - 6 * carry;
+        wreg[k] = *reinterpret_cast<const uint32_t *>( wy0 + static_cast<ptrdiff_t>( r ) * pw + d * 4 );
+      } else if ( i < 230 ) {
+        const int j = i - 126, pl = j >= 52 ? 1 : 0, e = j - 52 * pl;
+        wreg[k] = *reinterpret_cast<const uint32_t *>( ( pl ? wv0 : wu0 ) + static_cast<ptrdiff_t>( e >> 2 ) * cw + ( e & 3 ) * 4 );
+      }
     }
   }
 
@@ -1054,13 +1081,7 @@ __device__ __forceinline__ void recon_inter4_body( const aa_dev_frame & f, const
 #pragma unroll
     for ( int k = 0; k < 4; k++ ) {
       const uint32_t p4 = *reinterpret_cast<const uint32_t *>( S.pred + l * 16 + 4 * k );
-      const int16_t * rs = &S.res[( l >> 2 ) * 4 + k][( l & 3 ) * 4];
-      uint32_t out = p4;
-      if ( has_res ) {
-        out = 0;
-#pragma unroll
-        for ( int j = 0; j < 4; j++ ) out |= static_cast<uint32_t>( clamp255( static_cast<int>( ( p4 >> ( 8 * j ) ) & 0xFF ) + rs[j] ) ) << ( 8 * j );
-      }
+      const uint32_t out = has_res ? add_residual_x4( p4, &S.res[( l >> 2 ) * 4 + k][( l & 3 ) * 4] ) : p4;
       o[k] = out;
     }
     *reinterpret_cast<uint4 *>( f.cur[0] + static_cast<size_t>( row * 16 + l ) * pw + col * 16 ) = make_uint4( o[0], o[1], o[2], o[3] );
@@ -1069,13 +1090,7 @@ __device__ __forceinline__ void recon_inter4_body( const aa_dev_frame & f, const
 #pragma unroll
     for ( int k = 0; k < 2; k++ ) {
       const uint32_t p4 = *reinterpret_cast<const uint32_t *>( S.pred + 256 + pl * 64 + r * 8 + 4 * k );
-      const int16_t * rs = &S.res[16 + pl * 4 + ( r >> 2 ) * 2 + k][( r & 3 ) * 4];
-      uint32_t out = p4;
-      if ( has_res ) {
-        out = 0;
-#pragma unroll
-        for ( int j = 0; j < 4; j++ ) out |= static_cast<uint32_t>( clamp255( static_cast<int>( ( p4 >> ( 8 * j ) ) & 0xFF ) + rs[j] ) ) << ( 8 * j );
-      }
+      const uint32_t out = has_res ? add_residual_x4( p4, &S.res[16 + pl * 4 + ( r >> 2 ) * 2 + k][( r & 3 ) * 4] ) : p4;
       oc2[k] = out;
     }
     *reinterpret_cast<uint2 *>( f.cur[1 + pl] + static_cast<size_t>( row * 8 + r ) * cw + col * 8 ) = make_uint2( oc2[0], oc2[1] );

@@ -72,9 +72,9 @@ def main():
     from alfalfa_amd import sharding
     width, height = workload.CONFIGS[args.config][:2]
     S, F = args.streams, args.frames
-    # stream ids are disjoint across ranks; their CONTENT is drawn from a pool of 480 synthetic videos so that the one-off
+    # stream ids are disjoint across ranks; their CONTENT is drawn from a pool of 120 synthetic videos so that the one-off
     # generation cost (reference encoder, cached on disk) stays bounded on an 8-GPU node
-    seeds = [100 + (g - 100) % 480 for g in sharding.stream_ids(rank, world, S)]
+    seeds = [100 + (g - 100) % 120 for g in sharding.stream_ids(rank, world, S)]
     t0 = time.time()
     paths = workload.make_streams(args.config, F, seeds)
     t_gen = time.time() - t0
