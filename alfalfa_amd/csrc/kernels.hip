@@ -1038,12 +1038,33 @@ __device__ __forceinline__ void recon_inter4_body( const aa_dev_frame & f, const
   const int oy = inside ? ( sxy & 3 ) : 0, oc = inside ? ( sxc & 3 ) : 0;
   __syncthreads();
 
-  // ---- horizontal pass: 84 luma + 52 chroma tasks of four outputs; results to the transposed buffers t[column][row] ----
+  // A plane whose vector has no fractional part is a COPY of the window (both six-tap passes are the identity then: the
+  // reference always runs them, prediction.cc:875-915, libvpx-style decoders branch to a copy).  Decided per wave: the
+  // general task lists below only run for the planes that some macroblock of the wave really filters.
+  const bool luma_general = __any( on && ( ( mvx | mvy ) & 7 ) != 0 ), chroma_general = __any( on && ( ( cmx | cmy ) & 7 ) != 0 );
   const uint8_t * const wyb = &S.wy[0][0]; const uint8_t * const wcb = &S.wc[0][0][0];
   uint8_t * const tyb = &S.ty[0][0]; uint8_t * const tcb = &S.tc[0][0][0];
-  if ( on ) {
+  if ( !luma_general && on ) {          // lane = pixel row: bytes oy+2 .. oy+17 of window row l+2
+    const uint2 * rp = reinterpret_cast<const uint2 *>( wyb + ( l + 2 ) * 24 );
+    const uint2 a = rp[0], b = rp[1], c = rp[2];
+    const bool q = oy + 2 >= 4; const int sft = ( oy + 2 ) & 3;
+    const uint32_t e0 = q ? a.y : a.x, e1 = q ? b.x : a.y, e2 = q ? b.y : b.x, e3 = q ? c.x : b.y, e4 = q ? c.y : c.x;
+    *reinterpret_cast<uint4 *>( S.pred + l * 16 ) = make_uint4( __builtin_amdgcn_alignbyte( e1, e0, sft ), __builtin_amdgcn_alignbyte( e2, e1, sft ),
+                                                                __builtin_amdgcn_alignbyte( e3, e2, sft ), __builtin_amdgcn_alignbyte( e4, e3, sft ) );
+  }
+  if ( !chroma_general && on ) {        // lane = (plane, pixel row): bytes oc+2 .. oc+9 of window row r+2
+    const int pl = l >> 3, r = l & 7;
+    const uint2 * rp = reinterpret_cast<const uint2 *>( wcb + pl * 208 + ( r + 2 ) * 16 );
+    const uint2 a = rp[0], b = rp[1];
+    const bool q = oc + 2 >= 4; const int sft = ( oc + 2 ) & 3;
+    const uint32_t e0 = q ? a.y : a.x, e1 = q ? b.x : a.y, e2 = q ? b.y : b.x;
+    *reinterpret_cast<uint2 *>( S.pred + 256 + pl * 64 + r * 8 ) = make_uint2( __builtin_amdgcn_alignbyte( e1, e0, sft ), __builtin_amdgcn_alignbyte( e2, e1, sft ) );
+  }
+  // ---- horizontal pass: 84 luma + 52 chroma tasks of four outputs; results to the transposed buffers t[column][row] ----
+  if ( on && ( luma_general || chroma_general ) ) {
+    const int t_end = chroma_general ? 136 : 84;
 #pragma unroll 1
-    for ( int t = l; t < 136; t += 16 ) {
+    for ( int t = ( luma_general ? 0 : 84 ) + l; t < t_end; t += 16 ) {
       const bool lu = t < 84;
       const int j = t - 84, pl = j >= 26 ? 1 : 0, e = j - 26 * pl;
       const int r = lu ? t >> 2 : e >> 1, g = lu ? t & 3 : e & 1;
@@ -1061,8 +1082,9 @@ __device__ __forceinline__ void recon_inter4_body( const aa_dev_frame & f, const
   if ( on ) {
 #pragma unroll
     for ( int k = 0; k < 6; k++ ) {
-      const int t = l + 16 * k;
       const bool lu = k < 4;
+      if ( lu ? !luma_general : !chroma_general ) continue;
+      const int t = l + 16 * k;
       const int j = t - 64, pl = j >> 4, c = lu ? t >> 2 : ( j >> 1 ) & 7, i = lu ? t & 3 : j & 1;
       const uint8_t * sp = lu ? tyb + c * 24 + i * 4 : tcb + pl * 128 + c * 16 + i * 4;
       const int frac = lu ? mvy & 7 : cmy & 7;
