@@ -662,6 +662,7 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
   const unsigned long long * const mask = f.intra_rows + static_cast<size_t>( row ) * ( ( mbw + 63 ) >> 6 );
   int w = 0;
   unsigned long long m = words ? mask[0] : 0ull;
+  bool row_done = false;
 
   for ( ;; ) {
     while ( m == 0 && w + 1 < words ) { ++w; m = mask[w]; }
@@ -669,9 +670,12 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
     if ( !__any( on ) ) break;
     const int col = on ? w * 64 + __ffsll( static_cast<long long>( m ) ) - 1 : 0;
     m &= m - 1;
-    // everything left of `col` in this row is final: the previous macroblock's stores have reached the L2
+    // everything left of `col` in this row is final: the previous macroblock's stores have reached the L2.  A slot that
+    // has run out of intra macroblocks publishes the whole row at once -- it must not hold the rows below it back until
+    // the OTHER three frames of the wave are through.
     asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-    if ( on && l == 0 ) __hip_atomic_store( &progress[row], col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+    if ( frame_on && l == 0 && ( on || !row_done ) ) __hip_atomic_store( &progress[row], on ? col : mbw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+    row_done = row_done || !on;
 
     const aa_mb_info * const mb = f.mbs + static_cast<size_t>( row ) * mbw + col;
     uint4 hd = make_uint4( 0, 0, 0, 0 ), bm = make_uint4( 0, 0, 0, 0 );
@@ -836,7 +840,7 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
     __syncthreads();
   }
   asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-  if ( frame_on && l == 0 ) __hip_atomic_store( &progress[row], mbw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+  if ( frame_on && l == 0 && !row_done ) __hip_atomic_store( &progress[row], mbw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
 }
 
 __global__ __launch_bounds__( kLanes ) void k_recon_intra4( const aa_frame_list list, const int n_groups, const int mbh_max, aa_sync_ws * ws, const int n_xcd )
