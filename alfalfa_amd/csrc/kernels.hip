@@ -1149,10 +1149,13 @@ __global__ __launch_bounds__( kLanes ) void k_recon_inter4( const aa_frame_list 
 //     macroblock, to a BOUNDARY buffer; the workgroup of the next macroblock row reads that line as its rows -4..-1,
 //     finishes them with its top MB edge and stores them with its own strip.  Frame rows are therefore written by
 //     exactly one workgroup and cross-row hand-off costs one line per macroblock each way (+ a 4-byte-column fix-up).
-constexpr int kStripMbs = 8;
+constexpr int kStripMbs = 4;                         // 8: whole 128-byte lines, 19 KB of LDS per wave; 4: half lines, 11 KB -> more waves per SIMD
+constexpr int kStripRow = 16 + 16 * kStripMbs;        // LDS row: 16 bytes of padding + the strip's luma columns (U | V halves for chroma rows)
+constexpr int kStripRpi = 16 / kStripMbs;             // pixel rows covered by one bulk load/store instruction (16 lanes = chunks x rows)
+static_assert( ( kStripRow / 16 ) % 2 == 1, "odd multiple of 16: consecutive rows start on different banks" );
 struct alignas( 16 ) LfStrip {
-  uint8_t c[12][144];        // chroma rows -4..7 of the MB row: U strip columns 0..63 at bytes 16..79, V at 80..143
-  uint8_t y[20][144];        // luma rows -4..15: strip columns 0..127 at bytes 16..143 (144 = odd multiple of 16: rows spread over banks)
+  uint8_t c[12][kStripRow];  // chroma rows -4..7 of the MB row: U strip columns at bytes 16.., V after them
+  uint8_t y[20][kStripRow];  // luma rows -4..15: strip columns at bytes 16..
   uint8_t halo_y[16][4];     // columns -4..-1 of rows 0..15: the previous strip's right edge
   uint8_t halo_c[2][8][4];
   uint8_t pad[32];           // the four slots of a wave start on different banks
@@ -1200,22 +1203,22 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
   const bool luma = l < 8;
   const int k8 = l & 7, cp = k8 >> 2, cj = k8 & 3;     // chroma lanes (l >= 8): plane, line/column pair
   // ---- phase roles (pointers for strip position 0; + 16 k (luma) / 8 k (chroma) per macroblock) ----
-  uint8_t * const vrow = luma ? &T.y[4 + 2 * l][16] : &T.c[4 + 2 * cj][16 + 64 * cp];          // row A; row B at +144
+  uint8_t * const vrow = luma ? &T.y[4 + 2 * l][16] : &T.c[4 + 2 * cj][16 + 8 * kStripMbs * cp];          // row A; row B at +kStripRow
   uint8_t * const vhalo = luma ? &T.halo_y[2 * l][0] : &T.halo_c[cp][2 * cj][0];                // row A; row B at +4
-  uint8_t * const hcol = luma ? &T.y[0][16 + 2 * l] : &T.c[0][16 + 64 * cp + 2 * cj];          // rows at +144 r
+  uint8_t * const hcol = luma ? &T.y[0][16 + 2 * l] : &T.c[0][16 + 8 * kStripMbs * cp + 2 * cj];          // rows at +kStripRow r
   const int mbstep = luma ? 16 : 8;
   // ---- bulk roles: lanes along rows.  instr i: luma row 2i + (l>>3), 16-byte chunk l&7 (= MB of the strip);
   //      chroma plane i>>2, row 2(i&3) + (l>>3), 8-byte chunk l&7 ----
-  const int brow = l >> 3, bchunk = l & 7;
-  uint8_t * const gy = f.cur[0] + static_cast<size_t>( y0 + brow ) * pw + 16 * bchunk;          // + 2 i pw + 128 s
-  uint8_t * const gu = f.cur[1] + static_cast<size_t>( cy0 + brow ) * cw + 8 * bchunk;          // + 2 i cw + 64 s
+  const int brow = l / kStripMbs, bchunk = l % kStripMbs;
+  uint8_t * const gy = f.cur[0] + static_cast<size_t>( y0 + brow ) * pw + 16 * bchunk;          // + kStripRpi i pw + 16 kStripMbs s
+  uint8_t * const gu = f.cur[1] + static_cast<size_t>( cy0 + brow ) * cw + 8 * bchunk;          // + kStripRpi i cw + 8 kStripMbs s
   uint8_t * const gv = f.cur[2] + static_cast<size_t>( cy0 + brow ) * cw + 8 * bchunk;
-  uint8_t * const sy = &T.y[4 + brow][16 + 16 * bchunk];                                        // + 288 i
-  uint8_t * const sc = &T.c[4 + brow][16 + 8 * bchunk];                                         // + 288 i (+ 64 for V)
+  uint8_t * const sy = &T.y[4 + brow][16 + 16 * bchunk];                                        // + kStripRpi kStripRow i
+  uint8_t * const sc = &T.c[4 + brow][16 + 8 * bchunk];                                         // + kStripRpi kStripRow i (+ 8 kStripMbs for V)
   // ---- boundary roles: lanes 0..3 luma rows 12..15 (16 B), 4,5 U row pairs (2 x 8 B), 6,7 V ----
   const int bl = l & 7, bq = ( bl - 4 ) & 3;
-  uint8_t * const bsrc = bl < 4 ? &T.y[16 + bl][16] : &T.c[8 + 2 * ( bq & 1 )][16 + 64 * ( bq >> 1 )];      // own bottom rows (2nd chroma row at +144)
-  uint8_t * const btop = bl < 4 ? &T.y[bl][16] : &T.c[2 * ( bq & 1 )][16 + 64 * ( bq >> 1 )];                // rows -4..-1
+  uint8_t * const bsrc = bl < 4 ? &T.y[16 + bl][16] : &T.c[8 + 2 * ( bq & 1 )][16 + 8 * kStripMbs * ( bq >> 1 )];      // own bottom rows (2nd chroma row at +kStripRow)
+  uint8_t * const btop = bl < 4 ? &T.y[bl][16] : &T.c[2 * ( bq & 1 )][16 + 8 * kStripMbs * ( bq >> 1 )];                // rows -4..-1
   const int bstep = bl < 4 ? 16 : 8;
   const size_t bnd_row = ( static_cast<size_t>( group * 4 + slot ) * mbh_max + row ) * mbw_max;             // in 128-byte lines
   uint8_t * const bnd_own = bnd + bnd_row * 128 + 16 * bl;
@@ -1224,27 +1227,27 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
   const int fq = l >> 2, fr = l & 3;
   const int fix_off = fq == 0 ? 16 * fr + 12 : 64 + 32 * ( fq - 1 ) + 8 * fr + 4;
   uint8_t * const fix_src0 = fq == 0 ? &T.halo_y[12 + fr][0] : &T.halo_c[( fq - 1 ) & 1][4 + fr][0];       // strip position 0: the halo
-  uint8_t * const fix_srck = fq == 0 ? &T.y[16 + fr][16 - 4] : &T.c[8 + fr][16 + 64 * ( ( fq - 1 ) & 1 ) - 4];   // + 16 k / 8 k
+  uint8_t * const fix_srck = fq == 0 ? &T.y[16 + fr][16 - 4] : &T.c[8 + fr][16 + 8 * kStripMbs * ( ( fq - 1 ) & 1 ) - 4];   // + 16 k / 8 k
   const int fix_step = fq == 0 ? 16 : 8;
   // frame fix-up of a finished strip's last four columns: lane l <-> luma row l, chroma plane l>>3 row l&7
-  uint8_t * const fy = f.cur[0] + static_cast<size_t>( y0 + l ) * pw - 4;                        // + 128 s
-  uint8_t * const fc = f.cur[1 + ( l >> 3 )] + static_cast<size_t>( cy0 + ( l & 7 ) ) * cw - 4;  // + 64 s
+  uint8_t * const fy = f.cur[0] + static_cast<size_t>( y0 + l ) * pw - 4;                        // + 16 kStripMbs s
+  uint8_t * const fc = f.cur[1 + ( l >> 3 )] + static_cast<size_t>( cy0 + ( l & 7 ) ) * cw - 4;  // + 8 kStripMbs s
   const aa_mb_info * const mbrow = f.mbs + static_cast<size_t>( row ) * mbw;
 
   const int n_strips = ( mbw + kStripMbs - 1 ) / kStripMbs;
-  uint4 py[8]; uint2 pc[8];
+  uint4 py[kStripMbs]; uint2 pc[kStripMbs];
 #pragma unroll
-  for ( int i = 0; i < 8; i++ ) { py[i] = make_uint4( 0, 0, 0, 0 ); pc[i] = make_uint2( 0, 0 ); }
+  for ( int i = 0; i < kStripMbs; i++ ) { py[i] = make_uint4( 0, 0, 0, 0 ); pc[i] = make_uint2( 0, 0 ); }
   // own rows of strip s -> registers (lanes along rows: whole lines)
   auto prefetch = [&]( const int s ) {
     const bool in = frame_on && !( dbg & 2 ) && s * kStripMbs + bchunk < mbw;
     if ( in ) {
 #pragma unroll
-      for ( int i = 0; i < 8; i++ ) py[i] = *reinterpret_cast<const uint4 *>( gy + static_cast<size_t>( 2 * i ) * pw + 128 * s );
+      for ( int i = 0; i < kStripMbs; i++ ) py[i] = *reinterpret_cast<const uint4 *>( gy + static_cast<size_t>( kStripRpi * i ) * pw + 16 * kStripMbs * s );
 #pragma unroll
-      for ( int i = 0; i < 4; i++ ) pc[i] = *reinterpret_cast<const uint2 *>( gu + static_cast<size_t>( 2 * i ) * cw + 64 * s );
+      for ( int i = 0; i < kStripMbs / 2; i++ ) pc[i] = *reinterpret_cast<const uint2 *>( gu + static_cast<size_t>( kStripRpi * i ) * cw + 8 * kStripMbs * s );
 #pragma unroll
-      for ( int i = 0; i < 4; i++ ) pc[4 + i] = *reinterpret_cast<const uint2 *>( gv + static_cast<size_t>( 2 * i ) * cw + 64 * s );
+      for ( int i = 0; i < kStripMbs / 2; i++ ) pc[kStripMbs / 2 + i] = *reinterpret_cast<const uint2 *>( gv + static_cast<size_t>( kStripRpi * i ) * cw + 8 * kStripMbs * s );
     }
   };
   prefetch( 0 );
@@ -1254,14 +1257,14 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
     const int nmb = min( kStripMbs, mbw - s * kStripMbs );
     // ---- strip turn-over: keep the right edge as the new left neighbour, then drop the prefetched rows in ----
     if ( s > 0 ) {
-      *reinterpret_cast<uint32_t *>( &T.halo_y[l][0] ) = *reinterpret_cast<const uint32_t *>( &T.y[4 + l][16 + 124] );
-      *reinterpret_cast<uint32_t *>( &T.halo_c[l >> 3][l & 7][0] ) = *reinterpret_cast<const uint32_t *>( &T.c[4 + ( l & 7 )][16 + 64 * ( l >> 3 ) + 60] );
+      *reinterpret_cast<uint32_t *>( &T.halo_y[l][0] ) = *reinterpret_cast<const uint32_t *>( &T.y[4 + l][16 + 16 * kStripMbs - 4] );
+      *reinterpret_cast<uint32_t *>( &T.halo_c[l >> 3][l & 7][0] ) = *reinterpret_cast<const uint32_t *>( &T.c[4 + ( l & 7 )][16 + 8 * kStripMbs * ( l >> 3 ) + 8 * kStripMbs - 4] );
       __syncthreads();
     }
 #pragma unroll
-    for ( int i = 0; i < 8; i++ ) *reinterpret_cast<uint4 *>( sy + 288 * i ) = py[i];
+    for ( int i = 0; i < kStripMbs; i++ ) *reinterpret_cast<uint4 *>( sy + kStripRpi * kStripRow * i ) = py[i];
 #pragma unroll
-    for ( int i = 0; i < 4; i++ ) { *reinterpret_cast<uint2 *>( sc + 288 * i ) = pc[i]; *reinterpret_cast<uint2 *>( sc + 288 * i + 64 ) = pc[4 + i]; }
+    for ( int i = 0; i < kStripMbs / 2; i++ ) { *reinterpret_cast<uint2 *>( sc + kStripRpi * kStripRow * i ) = pc[i]; *reinterpret_cast<uint2 *>( sc + kStripRpi * kStripRow * i + 8 * kStripMbs ) = pc[kStripMbs / 2 + i]; }
     __syncthreads();
 
     for ( int k = 0; k < nmb; k++ ) {
@@ -1282,13 +1285,13 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
       if ( any_active && !( dbg & 4 ) ) {   // ---- V phase: left MB edge, inner vertical edges ----
         uint8_t * const ra = vrow + mbstep * k;
         uint8_t * const ha = k == 0 ? vhalo : ra - 4;          // columns -4..-1: the halo at strip position 0, else the previous MB
-        uint8_t * const hb = k == 0 ? vhalo + 4 : ra + 144 - 4;
+        uint8_t * const hb = k == 0 ? vhalo + 4 : ra + kStripRow - 4;
         uint32_t a[5], b[5];
         a[0] = *reinterpret_cast<const uint32_t *>( ha ); b[0] = *reinterpret_cast<const uint32_t *>( hb );
         { const uint2 u = *reinterpret_cast<const uint2 *>( ra ); a[1] = u.x; a[2] = u.y; }
         { const uint2 u = *reinterpret_cast<const uint2 *>( ra + 8 ); a[3] = u.x; a[4] = u.y; }
-        { const uint2 u = *reinterpret_cast<const uint2 *>( ra + 144 ); b[1] = u.x; b[2] = u.y; }
-        { const uint2 u = *reinterpret_cast<const uint2 *>( ra + 152 ); b[3] = u.x; b[4] = u.y; }
+        { const uint2 u = *reinterpret_cast<const uint2 *>( ra + kStripRow ); b[1] = u.x; b[2] = u.y; }
+        { const uint2 u = *reinterpret_cast<const uint2 *>( ra + kStripRow + 8 ); b[3] = u.x; b[4] = u.y; }
         pk2 v[20];
 #pragma unroll
         for ( int d = 0; d < 5; d++ ) {
@@ -1300,8 +1303,8 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
         for ( int d = 0; d < 5; d++ ) pk_to_dwords( v[4 * d], v[4 * d + 1], v[4 * d + 2], v[4 * d + 3], a[d], b[d] );
         if ( active ) {
           *reinterpret_cast<uint32_t *>( ha ) = a[0]; *reinterpret_cast<uint32_t *>( hb ) = b[0];
-          *reinterpret_cast<uint2 *>( ra ) = make_uint2( a[1], a[2] ); *reinterpret_cast<uint2 *>( ra + 144 ) = make_uint2( b[1], b[2] );
-          if ( luma ) { *reinterpret_cast<uint2 *>( ra + 8 ) = make_uint2( a[3], a[4] ); *reinterpret_cast<uint2 *>( ra + 152 ) = make_uint2( b[3], b[4] ); }
+          *reinterpret_cast<uint2 *>( ra ) = make_uint2( a[1], a[2] ); *reinterpret_cast<uint2 *>( ra + kStripRow ) = make_uint2( b[1], b[2] );
+          if ( luma ) { *reinterpret_cast<uint2 *>( ra + 8 ) = make_uint2( a[3], a[4] ); *reinterpret_cast<uint2 *>( ra + kStripRow + 8 ) = make_uint2( b[3], b[4] ); }
         }
       }
       // the previous step's stores have drained behind the V phase: publish it
@@ -1324,7 +1327,7 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
           const uint64_t lo = load_u64_shared( src ), hi = load_u64_shared( src + 8 );
           uint8_t * dst = btop + bstep * k;
           if ( bl < 4 ) { *reinterpret_cast<uint64_t *>( dst ) = lo; *reinterpret_cast<uint64_t *>( dst + 8 ) = hi; }
-          else { *reinterpret_cast<uint64_t *>( dst ) = lo; *reinterpret_cast<uint64_t *>( dst + 144 ) = hi; }
+          else { *reinterpret_cast<uint64_t *>( dst ) = lo; *reinterpret_cast<uint64_t *>( dst + kStripRow ) = hi; }
         }
       }
       // the next strip's own rows: issued here so that no wait of THIS step covers them (vmcnt completes in order); they
@@ -1336,14 +1339,14 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
         uint8_t * const hc = hcol + mbstep * k;
         pk2 v[20];
 #pragma unroll
-        for ( int r = 0; r < 20; r++ ) v[r] = pk_from_u16( *reinterpret_cast<const uint16_t *>( hc + 144 * r ) );
+        for ( int r = 0; r < 20; r++ ) v[r] = pk_from_u16( *reinterpret_cast<const uint16_t *>( hc + kStripRow * r ) );
         lf_edges_pk( v, P, row > 0 ? g_on : 0u, g_in, g_in23 );
         if ( active ) {
 #pragma unroll
-          for ( int r = 1; r < 12; r++ ) *reinterpret_cast<uint16_t *>( hc + 144 * r ) = static_cast<uint16_t>( pk_to_u16( v[r] ) );
+          for ( int r = 1; r < 12; r++ ) *reinterpret_cast<uint16_t *>( hc + kStripRow * r ) = static_cast<uint16_t>( pk_to_u16( v[r] ) );
           if ( luma ) {
 #pragma unroll
-            for ( int r = 12; r < 20; r++ ) *reinterpret_cast<uint16_t *>( hc + 144 * r ) = static_cast<uint16_t>( pk_to_u16( v[r] ) );
+            for ( int r = 12; r < 20; r++ ) *reinterpret_cast<uint16_t *>( hc + kStripRow * r ) = static_cast<uint16_t>( pk_to_u16( v[r] ) );
           }
         }
       }
@@ -1356,7 +1359,7 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
             const uint8_t * src = bsrc + bstep * k;
             uint4 q;
             if ( bl < 4 ) q = *reinterpret_cast<const uint4 *>( src );
-            else { const uint2 u0 = *reinterpret_cast<const uint2 *>( src ), u1 = *reinterpret_cast<const uint2 *>( src + 144 ); q = make_uint4( u0.x, u0.y, u1.x, u1.y ); }
+            else { const uint2 u0 = *reinterpret_cast<const uint2 *>( src ), u1 = *reinterpret_cast<const uint2 *>( src + kStripRow ); q = make_uint4( u0.x, u0.y, u1.x, u1.y ); }
             *reinterpret_cast<uint4 *>( bnd_own + static_cast<size_t>( col ) * 128 ) = q;
           }
           if ( col > 0 && l < 12 ) {
@@ -1366,21 +1369,21 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
         }
         if ( k == 0 && s > 0 ) {
           // the previous strip's last four columns are final now
-          if ( l < 12 || last_row ) *reinterpret_cast<uint32_t *>( fy + 128 * s ) = *reinterpret_cast<const uint32_t *>( &T.halo_y[l][0] );
-          if ( ( l & 7 ) < 4 || last_row ) *reinterpret_cast<uint32_t *>( fc + 64 * s ) = *reinterpret_cast<const uint32_t *>( &T.halo_c[l >> 3][l & 7][0] );
+          if ( l < 12 || last_row ) *reinterpret_cast<uint32_t *>( fy + 16 * kStripMbs * s ) = *reinterpret_cast<const uint32_t *>( &T.halo_y[l][0] );
+          if ( ( l & 7 ) < 4 || last_row ) *reinterpret_cast<uint32_t *>( fc + 8 * kStripMbs * s ) = *reinterpret_cast<const uint32_t *>( &T.halo_c[l >> 3][l & 7][0] );
         }
         if ( k == nmb - 1 && bchunk < nmb ) {
           // ---- the strip is done: rows -4..11 (chroma -4..3) back to the frame, whole lines; the last MB row also its bottom rows ----
 #pragma unroll
-          for ( int i = 0; i < 10; i++ ) {          // strip rows 2i + brow = frame rows y0 - 4 + 2i + brow
-            if ( ( i >= 2 || row > 0 ) && ( i < 8 || last_row ) )
-              *reinterpret_cast<uint4 *>( gy + ( static_cast<ptrdiff_t>( 2 * i ) - 4 ) * pw + 128 * s ) = *reinterpret_cast<const uint4 *>( sy + 288 * i - 4 * 144 );
+          for ( int i = 0; i < 20 / kStripRpi; i++ ) {          // strip rows kStripRpi i + brow = frame rows y0 - 4 + kStripRpi i + brow
+            if ( ( ( i + 1 ) * kStripRpi > 4 || row > 0 ) && ( i * kStripRpi < 16 || last_row ) )
+              *reinterpret_cast<uint4 *>( gy + ( static_cast<ptrdiff_t>( kStripRpi * i ) - 4 ) * pw + 16 * kStripMbs * s ) = *reinterpret_cast<const uint4 *>( sy + kStripRpi * kStripRow * i - 4 * kStripRow );
           }
 #pragma unroll
-          for ( int i = 0; i < 6; i++ ) {           // chroma strip rows 2i + brow = chroma rows cy0 - 4 + 2i + brow
-            if ( ( i >= 2 || row > 0 ) && ( i < 4 || last_row ) ) {
-              *reinterpret_cast<uint2 *>( gu + ( static_cast<ptrdiff_t>( 2 * i ) - 4 ) * cw + 64 * s ) = *reinterpret_cast<const uint2 *>( sc + 288 * i - 4 * 144 );
-              *reinterpret_cast<uint2 *>( gv + ( static_cast<ptrdiff_t>( 2 * i ) - 4 ) * cw + 64 * s ) = *reinterpret_cast<const uint2 *>( sc + 288 * i - 4 * 144 + 64 );
+          for ( int i = 0; i < 12 / kStripRpi; i++ ) {          // chroma strip rows kStripRpi i + brow = chroma rows cy0 - 4 + kStripRpi i + brow
+            if ( ( ( i + 1 ) * kStripRpi > 4 || row > 0 ) && ( i * kStripRpi < 8 || last_row ) ) {
+              *reinterpret_cast<uint2 *>( gu + ( static_cast<ptrdiff_t>( kStripRpi * i ) - 4 ) * cw + 8 * kStripMbs * s ) = *reinterpret_cast<const uint2 *>( sc + kStripRpi * kStripRow * i - 4 * kStripRow );
+              *reinterpret_cast<uint2 *>( gv + ( static_cast<ptrdiff_t>( kStripRpi * i ) - 4 ) * cw + 8 * kStripMbs * s ) = *reinterpret_cast<const uint2 *>( sc + kStripRpi * kStripRow * i - 4 * kStripRow + 8 * kStripMbs );
             }
           }
         }
@@ -1408,7 +1411,7 @@ __device__ __forceinline__ void loopfilter_rows4_body( const aa_frame_list & lis
 }
 
 // grid.x = n_xcd * ceil(n_groups / n_xcd) * mbh_max workgroups
-__global__ __launch_bounds__( kLanes ) void k_loopfilter_rows4( const aa_frame_list list, const int n_groups, const int mbh_max, const int mbw_max, aa_sync_ws * ws, uint8_t * bnd,
+__global__ __launch_bounds__( kLanes ) __attribute__( ( amdgpu_waves_per_eu( 3 ) ) ) void k_loopfilter_rows4( const aa_frame_list list, const int n_groups, const int mbh_max, const int mbw_max, aa_sync_ws * ws, uint8_t * bnd,
                                                                  const int n_xcd, const int dbg )
 {
   __shared__ LfStripLds S;
