@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -46,12 +47,15 @@ struct Chunk {
   uint8_t * host = nullptr;   // pinned
   uint8_t * dev = nullptr;
   size_t capacity = 0, used = 0, uploaded = 0;
+  size_t pinned_bytes = 0;    // size of the host allocation (capacity shrinks to `used` when the chunk is sealed)
 };
 
 struct Slot {
   uint8_t * dev = nullptr;
   int refs = 0;               // References + frame handles holding this raster
+  bool owns = false;          // first slot of a block of kSlotBlock rasters allocated with one hipMalloc
 };
+constexpr int kSlotBlock = 4;
 
 struct FrameRec {
   aa_frame_header hdr;
@@ -78,6 +82,8 @@ struct aa_ctx {
   int schedule = 0;            // 0: row-pipelined persistent kernels (default), 1: one launch per 2:1 anti-diagonal
   int n_xcd = 1;               // XCDs workgroups land on (probed at creation); row kernels keep a unit on one XCD
   int xcd_share[AA_MAX_XCD] = {};
+  std::mutex pool_mu;           // pinned staging chunks given back by aa_stream_release_staging, reused by later parses
+  std::vector<std::pair<uint8_t *, size_t>> pinned_pool;
   uint8_t * boundary = nullptr; // loop filter: hand-off lines between macroblock rows (transient within a launch)
   size_t boundary_bytes = 0;
   aa_sync_ws * ws = nullptr;   // in-launch ordering state of the row-pipelined kernels
@@ -109,10 +115,12 @@ aa_status set_device( aa_ctx * ctx ) { HIP_TRY( hipSetDevice( ctx->device ) ); r
 aa_status alloc_slot( aa_stream * s, int * out )
 {
   for ( size_t i = 0; i < s->slots.size(); i++ ) if ( s->slots[i].refs == 0 ) { *out = static_cast<int>( i ); return AA_OK; }
-  Slot sl;
-  HIP_TRY( hipMalloc( reinterpret_cast<void **>( &sl.dev ), s->slot_bytes ) );
-  s->slots.push_back( sl );
-  *out = static_cast<int>( s->slots.size() - 1 );
+  // rasters are allocated four at a time: allocation calls serialise in the driver, and parser threads of many streams
+  // call this concurrently
+  uint8_t * block = nullptr;
+  HIP_TRY( hipMalloc( reinterpret_cast<void **>( &block ), s->slot_bytes * kSlotBlock ) );
+  *out = static_cast<int>( s->slots.size() );
+  for ( int k = 0; k < kSlotBlock; k++ ) { Slot sl; sl.dev = block + s->slot_bytes * k; sl.owns = k == 0; s->slots.push_back( sl ); }
   return AA_OK;
 }
 void retain( aa_stream * s, int slot ) { if ( slot >= 0 ) s->slots[slot].refs++; }
@@ -128,9 +136,15 @@ aa_status reserve( aa_stream * s, size_t bytes, Chunk ** out )
   if ( s->chunks.empty() || s->chunks.back().used + bytes > s->chunks.back().capacity ) {
     Chunk c;
     c.capacity = std::max( kChunkBytes, align_up( bytes ) );
-    HIP_TRY( hipHostMalloc( reinterpret_cast<void **>( &c.host ), c.capacity, hipHostMallocDefault ) );
+    {
+      std::lock_guard<std::mutex> g( s->ctx->pool_mu );
+      auto & pool = s->ctx->pinned_pool;
+      for ( size_t i = 0; i < pool.size(); i++ ) if ( pool[i].second == c.capacity ) { c.host = pool[i].first; pool[i] = pool.back(); pool.pop_back(); break; }
+    }
+    if ( !c.host ) HIP_TRY( hipHostMalloc( reinterpret_cast<void **>( &c.host ), c.capacity, hipHostMallocDefault ) );
     hipError_t e = hipMalloc( reinterpret_cast<void **>( &c.dev ), c.capacity );
     if ( e != hipSuccess ) { (void) hipHostFree( c.host ); return hip_fail( e, "hipMalloc(frame store chunk)" ); }
+    c.pinned_bytes = c.capacity;
     s->chunks.push_back( c );
   }
   *out = &s->chunks.back();
@@ -314,6 +328,7 @@ static void ctx_free( aa_ctx * ctx )
   (void) hipEventDestroy( ctx->upload_done );
   if ( ctx->ws ) (void) hipFree( ctx->ws );
   if ( ctx->boundary ) (void) hipFree( ctx->boundary );
+  for ( auto & pc : ctx->pinned_pool ) (void) hipHostFree( pc.first );
   (void) hipStreamDestroy( ctx->compute ); (void) hipStreamDestroy( ctx->copy );
   delete ctx;
 }
@@ -386,7 +401,7 @@ void aa_stream_destroy( aa_stream * s )
   (void) hipSetDevice( s->ctx->device );
   (void) hipStreamSynchronize( s->ctx->compute ); (void) hipStreamSynchronize( s->ctx->copy );
   for ( auto & c : s->chunks ) { if ( c.host ) (void) hipHostFree( c.host ); (void) hipFree( c.dev ); }
-  for ( auto & sl : s->slots ) (void) hipFree( sl.dev );
+  for ( auto & sl : s->slots ) if ( sl.owns ) (void) hipFree( sl.dev );
   aa_ctx * ctx = s->ctx;
   delete s;
   if ( --ctx->live_streams == 0 && ctx->dying ) ctx_free( ctx );
@@ -501,7 +516,7 @@ aa_status aa_stream_release_staging( aa_stream * s )
   HIP_TRY( hipStreamSynchronize( s->ctx->copy ) );
   for ( auto & c : s->chunks ) {
     if ( !c.host ) continue;
-    HIP_TRY( hipHostFree( c.host ) );
+    { std::lock_guard<std::mutex> g( s->ctx->pool_mu ); s->ctx->pinned_pool.emplace_back( c.host, c.pinned_bytes ); }
     c.host = nullptr;
     c.capacity = c.used;           // sealed: the next frame is staged in a new chunk
   }
@@ -600,6 +615,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
         if ( need > ctx->boundary_bytes ) {
           HIP_TRY( hipStreamSynchronize( ctx->compute ) );
           if ( ctx->boundary ) (void) hipFree( ctx->boundary );
+  for ( auto & pc : ctx->pinned_pool ) (void) hipHostFree( pc.first );
           ctx->boundary = nullptr; ctx->boundary_bytes = 0;
           HIP_TRY( hipMalloc( reinterpret_cast<void **>( &ctx->boundary ), need ) );
           ctx->boundary_bytes = need;

@@ -13,6 +13,9 @@
 //   Decoder     Decoder(width,height), get_frame_output, parse_and_decode_frame, get_references, example_raster,
 //               get_width/get_height                                   (decoder/decoder.hh:244-300)
 //   FramePlayer / FilePlayer (= Player)  decode / advance / eof / cur_frame_no   (decoder/player.hh:40-97)
+//   FileDescriptor (write only), YUV4MPEGHeader, YUV4MPEGFrameWriter  -- what vp8decode / xc-decode-bundle write with
+//                                                                      (util/file_descriptor.hh, input/yuv4mpeg.{hh,cc})
+//   Decoder::get_frame_outputs  -- NOT in the reference: one frame of each of N decoders as one GPU batch step
 // What is NOT mirrored (host-side plumbing outside the hot path): Frame<> object graphs
 // (parse_frame<F>/decode_frame<F> are replaced by get_frame_output), boost-based hash()/minihash, state (de)serialisation.
 //
@@ -329,6 +332,29 @@ public:
     handles_[index] = RasterHandle( owner_, index );
     return std::make_pair( shown != 0, handles_[index] );
   }
+  // N independent decoders, one frame each, as ONE batch step on the GPU (aa_decode_batch): what fills the chip when an
+  // ExCamera bundle or a set of streams is decoded (the reference loops over its decoders one after the other).
+  // All decoders must live on the same GpuContext.  Returns (shown, raster) per decoder.
+  static std::vector<std::pair<bool, RasterHandle>> get_frame_outputs( const std::vector<Decoder *> & decoders, const std::vector<Chunk> & frames )
+  {
+    if ( decoders.size() != frames.size() || decoders.empty() ) throw std::invalid_argument( "get_frame_outputs: one frame per decoder" );
+    std::vector<aa_stream *> streams( decoders.size() );
+    std::vector<int> index( decoders.size() ), shown( decoders.size() );
+    for ( size_t i = 0; i < decoders.size(); i++ ) {
+      aa_frame_header h;
+      check( aa_stream_parse( decoders[i]->owner_->stream, frames[i].buffer(), frames[i].size(), &index[i], &h ) );
+      shown[i] = h.show_frame; streams[i] = decoders[i]->owner_->stream;
+    }
+    check( aa_decode_batch( decoders[0]->owner_->ctx->get(), streams.data(), static_cast<int>( streams.size() ), index.data() ) );
+    std::vector<std::pair<bool, RasterHandle>> out;
+    for ( size_t i = 0; i < decoders.size(); i++ ) {
+      Decoder & d = *decoders[i];
+      if ( static_cast<int>( d.handles_.size() ) <= index[i] ) d.handles_.resize( index[i] + 1 );
+      d.handles_[index[i]] = RasterHandle( d.owner_, index[i] );
+      out.emplace_back( shown[i] != 0, d.handles_[index[i]] );
+    }
+    return out;
+  }
   Optional<RasterHandle> parse_and_decode_frame( const Chunk & compressed_frame )   // decoder.cc:137-141
   {
     const std::pair<bool, RasterHandle> out = get_frame_output( compressed_frame );
@@ -358,6 +384,7 @@ public:
   uint16_t width() const { return width_; }
   uint16_t height() const { return height_; }
   const Decoder & current_decoder() const { return decoder_; }
+  Decoder & mutable_decoder() { return decoder_; }
   References current_references() const { return decoder_.get_references(); }
 };
 
@@ -392,6 +419,59 @@ public:
 
 using Player = FilePlayer;
 
+// ---------------------------------------------------------------- output side of the front-ends (util/file_descriptor.hh, input/yuv4mpeg.{hh,cc})
+class FileDescriptor       // the subset vp8decode / xc-decode-bundle use: wrap a FILE* or an fd, write strings and chunks
+{
+  FILE * file_ = nullptr;
+  bool owned_ = false;
+public:
+  FileDescriptor() = default;
+  explicit FileDescriptor( FILE * f ) : file_( f ), owned_( true ) { if ( !f ) throw std::runtime_error( "fopen: cannot open file" ); }
+  explicit FileDescriptor( const int fd ) : file_( fd == 1 ? stdout : fd == 2 ? stderr : fdopen( fd, "wb" ) ), owned_( fd > 2 ) { if ( !file_ ) throw std::runtime_error( "fdopen failed" ); }
+  FileDescriptor( FileDescriptor && o ) noexcept : file_( o.file_ ), owned_( o.owned_ ) { o.file_ = nullptr; o.owned_ = false; }
+  FileDescriptor & operator=( FileDescriptor && o ) noexcept { if ( this != &o ) { close(); file_ = o.file_; owned_ = o.owned_; o.file_ = nullptr; o.owned_ = false; } return *this; }
+  FileDescriptor( const FileDescriptor & ) = delete;
+  FileDescriptor & operator=( const FileDescriptor & ) = delete;
+  ~FileDescriptor() { close(); }
+  void close() { if ( file_ && owned_ ) std::fclose( file_ ); file_ = nullptr; }
+  bool valid() const { return file_ != nullptr; }
+  long tell() const { return std::ftell( file_ ); }
+  void write( const std::string & s ) { if ( !s.empty() && std::fwrite( s.data(), s.size(), 1, file_ ) != 1 ) throw std::runtime_error( "fwrite returned short write" ); }
+  void write( const Chunk & c ) { if ( c.size() && std::fwrite( c.buffer(), c.size(), 1, file_ ) != 1 ) throw std::runtime_error( "fwrite returned short write" ); }
+};
+
+struct YUV4MPEGHeader      // yuv4mpeg.hh:40-65; header text yuv4mpeg.cc:85-128
+{
+  enum InterlacingMode { PROGRESSIVE, TOP_FIELD_FIRST, BOTTOM_FIELD_FIRST, MIXED_MODES };
+  enum ColorSpace { C420jpeg, C420paldv, C420, C422, C444 };
+  uint16_t width = 0, height = 0, fps_numerator = 0, fps_denominator = 0, pixel_aspect_ratio_numerator = 0, pixel_aspect_ratio_denominator = 0;
+  InterlacingMode interlacing_mode = PROGRESSIVE;
+  ColorSpace color_space = C420;
+  YUV4MPEGHeader() = default;
+  explicit YUV4MPEGHeader( const VP8Raster & r )      // yuv4mpeg.cc:44-50: display size, 24 fps, square pixels, progressive 4:2:0
+    : width( r.display_width() ), height( r.display_height() ), fps_numerator( 24 ), fps_denominator( 1 ),
+      pixel_aspect_ratio_numerator( 1 ), pixel_aspect_ratio_denominator( 1 ) {}
+  size_t y_plane_length() const { return size_t( width ) * height; }
+  size_t uv_plane_length() const { return size_t( width ) * height / 4; }
+  size_t frame_length() const { return size_t( width ) * height * 3 / 2; }
+  std::string to_string() const
+  {
+    static const char * const im = "ptbm";
+    static const char * const cs[] = { "C420jpeg XYSCSS=420JPEG", "C420paldv XYSCSS=420PALDV", "C420 XYSCSS=420", "C422 XYSCSS=422", "C444 XYSCSS=444" };
+    return "YUV4MPEG2 W" + std::to_string( width ) + " H" + std::to_string( height ) + " F" + std::to_string( fps_numerator ) + ":" + std::to_string( fps_denominator )
+           + " I" + std::string( 1, im[interlacing_mode] ) + " A" + std::to_string( pixel_aspect_ratio_numerator ) + ":" + std::to_string( pixel_aspect_ratio_denominator )
+           + " " + cs[color_space] + "\n";
+  }
+};
+struct YUV4MPEGFrameWriter
+{
+  static void write( const VP8Raster & r, FileDescriptor & fd )      // yuv4mpeg.cc:309-317
+  {
+    fd.write( std::string( "FRAME\n" ) );
+    for ( const auto & chunk : r.display_rectangle_as_planar() ) fd.write( chunk );
+  }
+};
+
 inline void print_exception( const char * argv0, const std::exception & e ) { std::fprintf( stderr, "%s: %s\n", argv0, e.what() ); }
 
 } // namespace alfalfa_amd
@@ -401,4 +481,5 @@ using alfalfa_amd::Chunk; using alfalfa_amd::Decoder; using alfalfa_amd::FilePla
 using alfalfa_amd::Invalid; using alfalfa_amd::IVF; using alfalfa_amd::LogicError; using alfalfa_amd::Optional;
 using alfalfa_amd::Player; using alfalfa_amd::RasterHandle; using alfalfa_amd::References; using alfalfa_amd::Unsupported;
 using alfalfa_amd::VP8Raster; using alfalfa_amd::print_exception;
+using alfalfa_amd::FileDescriptor; using alfalfa_amd::YUV4MPEGHeader; using alfalfa_amd::YUV4MPEGFrameWriter;
 #endif

@@ -12,17 +12,36 @@ BUILD = os.path.join(ROOT, "tests", "cpp", "_build")
 EXE = os.path.join(BUILD, "decode_to_stdout")
 
 
-def build_exe():
+def build_exe(src=None, name="decode_to_stdout"):
     from alfalfa_amd import build as b
     b.build()
     os.makedirs(BUILD, exist_ok=True)
-    src = os.path.join(ROOT, "tests", "cpp", "decode_to_stdout.cc")
+    src = src or os.path.join(ROOT, "tests", "cpp", "decode_to_stdout.cc")
+    exe = os.path.join(BUILD, name)
     hdr = os.path.join(ROOT, "include", "alfalfa_amd", "alfalfa.hh")
-    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(b.LIB)):
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(b.LIB)):
         libdir = os.path.dirname(b.LIB)
-        subprocess.run(["g++", "-std=c++14", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), src, "-o", EXE,
+        subprocess.run(["g++", "-std=c++14", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), src, "-o", exe,
                         "-L" + libdir, "-lalfalfa_amd", "-Wl,-rpath," + libdir], check=True)
-    return EXE
+    return exe
+
+
+def build_example(name):
+    return build_exe(os.path.join(ROOT, "examples", name + ".cc"), name)
+
+
+def y4m_payload(data, name):
+    """Check a YUV4MPEG2 stream written by the front-ends and return the concatenated frames (== decode-to-stdout's dump)."""
+    w, h = GOLDEN[name]["width"], GOLDEN[name]["height"]
+    header = ("YUV4MPEG2 W%d H%d F24:1 Ip A1:1 C420 XYSCSS=420\n" % (w, h)).encode()       # yuv4mpeg.cc:44-50,85-128
+    assert data.startswith(header)
+    frame = w * h + 2 * (((w + 1) // 2) * ((h + 1) // 2))
+    body, out = data[len(header):], b""
+    assert len(body) % (6 + frame) == 0
+    for off in range(0, len(body), 6 + frame):
+        assert body[off:off + 6] == b"FRAME\n"
+        out += body[off + 6:off + 6 + frame]
+    return out
 
 
 def test_cpp_mirror_builds_and_fails_loudly_without_gpu():
@@ -41,3 +60,33 @@ def test_decode_to_stdout_sha1_matches_reference(name):
     exe = build_exe()
     r = subprocess.run([exe, os.path.join(GOLDEN_DIR, name + ".ivf")], capture_output=True, check=True)
     assert hashlib.sha1(r.stdout).hexdigest() == GOLDEN[name]["display_sha1"]
+
+
+def test_frontend_ports_build_and_fail_loudly_without_gpu(tmp_path):
+    from alfalfa_amd import capi
+    for name in ("vp8decode", "decode_many"):
+        exe = build_example(name)
+        r = subprocess.run([exe], capture_output=True)
+        assert r.returncode != 0 and b"Usage" in r.stderr
+    if capi.device_count() == 0:
+        r = subprocess.run([build_example("vp8decode"), "-o", str(tmp_path / "o.y4m"), os.path.join(GOLDEN_DIR, "qcif_q30.ivf")], capture_output=True)
+        assert r.returncode != 0 and b"no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["qcif_q30_lf24", "w200_q40_lf63s7", "synth_175x143_s3"])
+def test_vp8decode_y4m_matches_reference_dump(tmp_path, name):
+    """frontend/vp8decode.cc port: `-o out.y4m` = header + FRAME-delimited display rectangles of the shown frames."""
+    out = tmp_path / "o.y4m"
+    subprocess.run([build_example("vp8decode"), "-o", str(out), os.path.join(GOLDEN_DIR, name + ".ivf")], check=True)
+    assert hashlib.sha1(y4m_payload(out.read_bytes(), name)).hexdigest() == GOLDEN[name]["display_sha1"]
+
+
+@pytest.mark.gpu
+def test_decode_many_lockstep_batches_match_reference_dumps(tmp_path):
+    """Every golden stream at once, mixed frame sizes and lengths, one aa_decode_batch per frame index."""
+    names = sorted(GOLDEN)
+    subprocess.run([build_example("decode_many"), "-d", str(tmp_path)] + [os.path.join(GOLDEN_DIR, n + ".ivf") for n in names], check=True)
+    for n in names:
+        data = (tmp_path / (n + ".ivf.y4m")).read_bytes()
+        assert hashlib.sha1(y4m_payload(data, n)).hexdigest() == GOLDEN[n]["display_sha1"], n
