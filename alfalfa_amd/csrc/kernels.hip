@@ -663,6 +663,7 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
   int w = 0;
   unsigned long long m = words ? mask[0] : 0ull;
   bool row_done = false;
+  int seen = row > 0 ? 0 : 0x7FFFFFFF;     // columns of the row above known to be final (progress only grows)
 
   for ( ;; ) {
     while ( m == 0 && w + 1 < words ) { ++w; m = mask[w]; }
@@ -684,9 +685,8 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
     const uint32_t nz_mask = hd.z, coeff_index = hd.w;
     const bool has_res = on && ( flags & AA_MB_HAS_NONZERO );
     const bool has_y2 = has_res && ( flags & AA_MB_HAS_Y2 );
-    int seen = 0;
     const int need = min( col + 2, mbw );
-    if ( on && row > 0 ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    if ( on && row > 0 && seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
 
     // ---- residual: needs no neighbour, runs before the wait for the row above ----
     if ( __any( has_res ) ) {
@@ -1253,6 +1253,7 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
   prefetch( 0 );
   int info = frame_on ? *reinterpret_cast<const uint16_t *>( &mbrow[0].flags ) : 0;     // flags | lf_level << 8
   int pending = -1;
+  int seen = row > 0 ? 0 : mbw;        // columns of the row above known to be final
   for ( int s = 0; s < n_strips; s++ ) {
     const int nmb = min( kStripMbs, mbw - s * kStripMbs );
     // ---- strip turn-over: keep the right edge as the new left neighbour, then drop the prefetched rows in ----
@@ -1276,8 +1277,8 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
       // in flight during the V phase: the next macroblock's level, the poll of the row above
       const int info_next = ( frame_on && more ) ? *reinterpret_cast<const uint16_t *>( &mbrow[col + 1].flags ) : 0;
       const int need = min( col + 2, mbw );
-      int seen = need;
-      if ( row > 0 ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      // progress only grows: what an earlier poll saw stays valid, so a row that runs well behind the row above polls rarely
+      if ( row > 0 && seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
       const bool any_active = __any( active );
       const LfParamsPk P = lf_params_pk( lf_params( active ? level : 1, sharp, key ) );
       const pk2 g_on = active ? ~0u : 0u, g_in = ( active && inner ) ? ~0u : 0u, g_in23 = ( active && inner && luma ) ? ~0u : 0u;
