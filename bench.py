@@ -285,9 +285,21 @@ def main():
                      "h2d_s": round(t_h2d, 3), "stream_generation_s": round(t_gen, 1)},
             "kernel_stats": kstats, "verified_bit_exact_vs_reference": verified, "entry_state_handoff": handoff,
         }
-        print(json.dumps(line))
+    else:
+        line = None
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # the JSON line is the LAST thing on stdout: flush what C libraries (RCCL's version banner) still hold in stdio
+        # buffers first
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -115,3 +115,26 @@ def test_row_pipelined_schedule_under_load(gpu_ctx):
     finally:
         gpu_ctx.set_schedule("rows")
 
+
+
+def test_release_staging_then_parse_more(gpu_ctx):
+    """aa_stream_release_staging gives the pinned staging back (and to the context's pool); frames parsed afterwards are
+    staged in fresh (pooled) pinned memory and decode exactly as before."""
+    name = "w200_q40_lf63s7"
+    w, h, frames = golden_frames(name)
+    a, b = aa.Decoder(gpu_ctx, w, h), aa.Decoder(gpu_ctx, w, h)
+    for fr in frames[:3]:
+        a.parse_frame(fr)
+    a.release_staging()                      # uploads, waits, frees the host side
+    for fr in frames[:3]:
+        b.parse_frame(fr)                    # reuses the pooled pinned chunk
+    for f in range(3):
+        gpu_ctx.decode_batch([a, b], [f, f])
+    b.release_staging()
+    for fr in frames[3:]:
+        a.parse_frame(fr); b.parse_frame(fr)
+    for f in range(3, len(frames)):
+        gpu_ctx.decode_batch([a, b], [f, f])
+    for f in range(len(frames)):
+        assert sha256(a.raster_bytes(f)) == GOLDEN[name]["raster_sha256"][f], f
+        assert sha256(b.raster_bytes(f)) == GOLDEN[name]["raster_sha256"][f], f
