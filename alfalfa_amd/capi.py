@@ -62,6 +62,8 @@ SYMBOLS = [
     ("aa_parser_get_probs", C.c_int, [_P, _U8P]),
     ("aa_parser_get_segmentation", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int8), C.POINTER(C.c_int8), _U8P]),
     ("aa_parser_get_filter_adjustments", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int8), C.POINTER(C.c_int8)]),
+    ("aa_parser_serialize_state", C.c_int, [_P, _P, C.c_size_t, _P]), ("aa_parser_deserialize_state", C.c_int, [_P, _P, C.c_size_t]),
+    ("aa_stream_serialize", C.c_int, [_P, _P, C.c_size_t, _P]), ("aa_stream_deserialize", C.c_int, [_P, _P, C.c_size_t]),
     ("aa_parser_state_size", C.c_size_t, [_P]), ("aa_parser_export_state", C.c_int, [_P, _P, C.c_size_t]),
     ("aa_parser_import_state", C.c_int, [_P, C.c_char_p, C.c_size_t]),
     ("aa_stream_state_size", C.c_size_t, [_P]), ("aa_stream_export_state", C.c_int, [_P, _P, C.c_size_t]),

@@ -195,6 +195,95 @@ void Parser::import_state( const uint8_t * in, size_t size )
   std::memcpy( seg_.map.data(), in, seg_.map.size() );
 }
 
+// ---- the reference's state wire format (enc_state_serializer.hh:43-56,64-86; decoder.cc:283-330,342-376,396-474;
+// probability_tables.cc:126-195) ----
+namespace {
+enum : uint8_t { T_PROB_TABLE, T_FILT_ADJ, T_SEGM_ABS, T_SEGM_REL, T_DECODER_STATE, T_OPT_EMPTY, T_OPT_FULL };
+void put32( std::vector<uint8_t> & o, uint32_t v ) { for ( int i = 0; i < 4; i++ ) o.push_back( static_cast<uint8_t>( v >> ( 8 * i ) ) ); }
+void put16( std::vector<uint8_t> & o, uint16_t v ) { o.push_back( static_cast<uint8_t>( v ) ); o.push_back( static_cast<uint8_t>( v >> 8 ) ); }
+struct Reader
+{
+  const uint8_t * p; size_t n, at = 0;
+  void need( size_t k ) const { if ( at + k > n ) throw ParseError( AA_ERR_INVALID, "invalid decoder state: truncated" ); }
+  uint8_t u8() { need( 1 ); return p[at++]; }
+  uint16_t u16() { need( 2 ); const uint16_t v = static_cast<uint16_t>( p[at] | ( p[at + 1] << 8 ) ); at += 2; return v; }
+  uint32_t u32() { need( 4 ); const uint32_t v = p[at] | ( p[at + 1] << 8 ) | ( p[at + 2] << 16 ) | ( static_cast<uint32_t>( p[at + 3] ) << 24 ); at += 4; return v; }
+  void bytes( void * dst, size_t k ) { need( k ); std::memcpy( dst, p + at, k ); at += k; }
+  void expect( uint8_t tag, const char * what ) { if ( u8() != tag ) throw ParseError( AA_ERR_INVALID, std::string( "invalid decoder state: expected " ) + what ); }
+};
+}
+
+void Parser::serialize_reference( std::vector<uint8_t> & o ) const
+{
+  o.push_back( T_DECODER_STATE );
+  const size_t len_at = o.size();
+  put32( o, 0 );
+  const size_t body = o.size();
+  put16( o, width_ ); put16( o, height_ );
+  o.push_back( T_PROB_TABLE ); put32( o, 1101 );
+  const uint8_t * t = &probs_.coeff[0][0][0][0];
+  o.insert( o.end(), t, t + 1056 ); o.insert( o.end(), probs_.y_mode, probs_.y_mode + 4 );
+  o.insert( o.end(), probs_.uv_mode, probs_.uv_mode + 3 ); o.insert( o.end(), &probs_.mv[0][0], &probs_.mv[0][0] + 38 );
+  if ( seg_.enabled ) {
+    o.push_back( T_OPT_FULL );
+    o.push_back( seg_.absolute ? T_SEGM_ABS : T_SEGM_REL );
+    // The reference sizes its segment map by the frame's PIXEL dimensions (DecoderState hands width/height to
+    // Segmentation, decoder.cc:238, decoder_state.hh:170-176); only the top-left mb_width x mb_height corner is ever
+    // touched, the rest keeps the initial 3.  The wire format carries the whole thing.
+    put32( o, 4u + 4u + 4u + static_cast<uint32_t>( width_ ) * height_ );
+    put16( o, width_ ); put16( o, height_ );
+    for ( int i = 0; i < 4; i++ ) o.push_back( static_cast<uint8_t>( seg_.quant[i] ) );
+    for ( int i = 0; i < 4; i++ ) o.push_back( static_cast<uint8_t>( seg_.lf[i] ) );
+    for ( unsigned r = 0; r < height_; r++ )
+      for ( unsigned c = 0; c < width_; c++ ) o.push_back( ( r < mbh_ && c < mbw_ ) ? seg_.map[static_cast<size_t>( r ) * mbw_ + c] : 3 );
+  } else o.push_back( T_OPT_EMPTY );
+  if ( fadj_.enabled ) {
+    o.push_back( T_OPT_FULL );
+    o.push_back( T_FILT_ADJ ); put32( o, 8 );
+    for ( int i = 0; i < 4; i++ ) o.push_back( static_cast<uint8_t>( fadj_.ref[i] ) );
+    for ( int i = 0; i < 4; i++ ) o.push_back( static_cast<uint8_t>( fadj_.mode[i] ) );
+  } else o.push_back( T_OPT_EMPTY );
+  // the reference's length field counts 4 (dims) + each part's len+5 + the two option tags (decoder.cc:287-311)
+  const uint32_t len = static_cast<uint32_t>( o.size() - body );
+  for ( int i = 0; i < 4; i++ ) o[len_at + i] = static_cast<uint8_t>( len >> ( 8 * i ) );
+}
+
+size_t Parser::deserialize_reference( const uint8_t * in, size_t size )
+{
+  Reader r { in, size };
+  r.expect( T_DECODER_STATE, "DECODER_STATE" );
+  (void) r.u32();
+  const uint16_t w = r.u16(), h = r.u16();
+  if ( w != width_ || h != height_ ) throw ParseError( AA_ERR_INVALID, "invalid decoder state: frame size differs from this decoder's" );
+  r.expect( T_PROB_TABLE, "PROB_TABLE" );
+  if ( r.u32() != 1101 ) throw ParseError( AA_ERR_INVALID, "invalid decoder state: probability table length" );
+  ProbTables pt;
+  r.bytes( pt.coeff, 1056 ); r.bytes( pt.y_mode, 4 ); r.bytes( pt.uv_mode, 3 ); r.bytes( pt.mv, 38 );
+  SegmentationState sg; sg.map.assign( static_cast<size_t>( mbw_ ) * mbh_, 3 );
+  uint8_t opt = r.u8();
+  if ( opt == T_OPT_FULL ) {
+    const uint8_t tag = r.u8();
+    if ( tag != T_SEGM_ABS && tag != T_SEGM_REL ) throw ParseError( AA_ERR_INVALID, "invalid decoder state: expected SEGM_ABS/SEGM_REL" );
+    sg.enabled = true; sg.absolute = tag == T_SEGM_ABS;
+    const uint32_t len = r.u32();
+    const uint16_t mw = r.u16(), mh = r.u16();        // pixel dimensions, see serialize_reference
+    if ( mw != width_ || mh != height_ || len != 12u + static_cast<uint32_t>( mw ) * mh ) throw ParseError( AA_ERR_INVALID, "invalid decoder state: segmentation map size" );
+    r.bytes( sg.quant, 4 ); r.bytes( sg.lf, 4 );
+    r.need( static_cast<size_t>( mw ) * mh );
+    for ( unsigned row = 0; row < mbh_; row++ ) std::memcpy( &sg.map[static_cast<size_t>( row ) * mbw_], r.p + r.at + static_cast<size_t>( row ) * mw, mbw_ );
+    r.at += static_cast<size_t>( mw ) * mh;
+  } else if ( opt != T_OPT_EMPTY ) throw ParseError( AA_ERR_INVALID, "invalid decoder state: option tag" );
+  FilterAdjustState fa;
+  opt = r.u8();
+  if ( opt == T_OPT_FULL ) {
+    r.expect( T_FILT_ADJ, "FILT_ADJ" );
+    if ( r.u32() != 8 ) throw ParseError( AA_ERR_INVALID, "invalid decoder state: filter adjustment length" );
+    fa.enabled = true; r.bytes( fa.ref, 4 ); r.bytes( fa.mode, 4 );
+  } else if ( opt != T_OPT_EMPTY ) throw ParseError( AA_ERR_INVALID, "invalid decoder state: option tag" );
+  probs_ = pt; seg_ = sg; fadj_ = fa;       // nothing is changed unless the whole blob parsed
+  return r.at;
+}
+
 void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa_mb_info * mbs, int16_t * coeff_out )
 {
   // ---- frame tag + partition split: uncompressed_chunk.cc:34-130 ----

@@ -67,6 +67,12 @@ public:
   void export_state( uint8_t * out ) const;
   void import_state( const uint8_t * in, size_t size );   // throws ParseError(AA_ERR_ARGUMENT) on a foreign / mismatching blob
 
+  // The same state in the REFERENCE's wire format (DecoderState::serialize / deserialize, decoder.cc:283-330; tags and
+  // little-endian integers of enc_state_serializer.hh:43-56): [DECODER_STATE][u32 len][u16 w][u16 h][PROB_TABLE ...]
+  // [OPT_FULL SEGM_ABS|SEGM_REL ... | OPT_EMPTY][OPT_FULL FILT_ADJ ... | OPT_EMPTY].
+  void serialize_reference( std::vector<uint8_t> & out ) const;
+  size_t deserialize_reference( const uint8_t * in, size_t size );   // returns the bytes consumed; throws ParseError(AA_ERR_INVALID)
+
   const ProbTables & probs() const { return probs_; }
   const SegmentationState & segmentation() const { return seg_; }
   const FilterAdjustState & filter_adjustments() const { return fadj_; }

@@ -275,6 +275,32 @@ aa_status aa_parser_export_state( const aa_parser * p, uint8_t * buf, size_t cap
 aa_status aa_parser_import_state( aa_parser * p, const uint8_t * buf, size_t size )
 { return p ? import_state_common( p->impl, buf, size ) : fail( AA_ERR_ARGUMENT, "null parser" ); }
 
+/* DecoderState in the reference's wire format (DecoderState::serialize, decoder.cc:283-313) */
+static aa_status serialize_out( const std::vector<uint8_t> & blob, uint8_t * buf, size_t capacity, size_t * size )
+{
+  if ( size ) *size = blob.size();
+  if ( !buf ) return AA_OK;                         // size query
+  if ( capacity < blob.size() ) return fail( AA_ERR_ARGUMENT, "serialize: buffer too small" );
+  std::memcpy( buf, blob.data(), blob.size() );
+  return AA_OK;
+}
+aa_status aa_parser_serialize_state( const aa_parser * p, uint8_t * buf, size_t capacity, size_t * size )
+{
+  if ( !p ) return fail( AA_ERR_ARGUMENT, "null parser" );
+  std::vector<uint8_t> blob;
+  p->impl.serialize_reference( blob );
+  return serialize_out( blob, buf, capacity, size );
+}
+aa_status aa_parser_deserialize_state( aa_parser * p, const uint8_t * buf, size_t size )
+{
+  if ( !p || !buf ) return fail( AA_ERR_ARGUMENT, "null argument" );
+  aa::Parser trial = p->impl;                        // the parser changes only if the whole blob is good
+  try { if ( trial.deserialize_reference( buf, size ) != size ) return fail( AA_ERR_INVALID, "invalid decoder state: trailing bytes" ); }
+  catch ( const aa::ParseError & e ) { return fail( e.code, e.message ); }
+  p->impl = trial;
+  return AA_OK;
+}
+
 /* ---------------- context ---------------- */
 aa_status aa_ctx_create( int device, aa_ctx ** out )
 {
@@ -742,6 +768,66 @@ aa_status aa_stream_export_state( const aa_stream * s, uint8_t * buf, size_t cap
 { return s ? export_state_common( s->parser, buf, capacity ) : fail( AA_ERR_ARGUMENT, "null stream" ); }
 aa_status aa_stream_import_state( aa_stream * s, const uint8_t * buf, size_t size )
 { return s ? import_state_common( s->parser, buf, size ) : fail( AA_ERR_ARGUMENT, "null stream" ); }
+
+/* Decoder::serialize / Decoder::deserialize (decoder.cc:54-81): [DECODER][u32 len] DecoderState References, where
+ * References = [REFERENCES][u32 len][u16 display w][u16 display h][REF_LAST][u32 len] padded Y, U, V of the LAST reference
+ * only (decoder.cc:177-197; golden and alternative alias it after loading, :171-175). */
+aa_status aa_stream_serialize( aa_stream * s, uint8_t * buf, size_t capacity, size_t * size )
+{
+  if ( !s ) return fail( AA_ERR_ARGUMENT, "null stream" );
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  if ( s->next_submit != static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_LOGIC, "aa_stream_serialize: parsed frames are still waiting to be decoded" );
+  const int slot = s->cur_ref_slot[0];
+  if ( slot < 0 ) return fail( AA_ERR_LOGIC, "aa_stream_serialize: nothing decoded or imported yet (the reference would write an uninitialised raster)" );
+  std::vector<uint8_t> blob;
+  blob.push_back( 11 /* DECODER */ );
+  blob.insert( blob.end(), 4, 0 );
+  s->parser.serialize_reference( blob );
+  const size_t raster = s->plane_bytes[0] + 2 * s->plane_bytes[1];
+  blob.push_back( 7 /* REFERENCES */ );
+  const uint32_t rlen = static_cast<uint32_t>( 4 + 5 + raster );
+  for ( int i = 0; i < 4; i++ ) blob.push_back( static_cast<uint8_t>( rlen >> ( 8 * i ) ) );
+  const uint16_t dims[2] = { s->parser.width(), s->parser.height() };
+  for ( int k = 0; k < 2; k++ ) { blob.push_back( static_cast<uint8_t>( dims[k] ) ); blob.push_back( static_cast<uint8_t>( dims[k] >> 8 ) ); }
+  blob.push_back( 8 /* REF_LAST */ );
+  for ( int i = 0; i < 4; i++ ) blob.push_back( static_cast<uint8_t>( static_cast<uint32_t>( raster ) >> ( 8 * i ) ) );
+  const uint32_t total = static_cast<uint32_t>( blob.size() + raster - 5 );
+  for ( int i = 0; i < 4; i++ ) blob[1 + i] = static_cast<uint8_t>( total >> ( 8 * i ) );
+  if ( size ) *size = blob.size() + raster;
+  if ( !buf ) return AA_OK;                         // size query
+  if ( capacity < blob.size() + raster ) return fail( AA_ERR_ARGUMENT, "aa_stream_serialize: buffer too small" );
+  std::memcpy( buf, blob.data(), blob.size() );
+  HIP_TRY( hipStreamSynchronize( s->ctx->compute ) );
+  if ( aa_status st = check_watchdog( s->ctx ) ) return st;
+  uint8_t * dst = buf + blob.size();
+  for ( int p = 0; p < 3; p++ ) { HIP_TRY( hipMemcpy( dst, slot_plane( s, slot, p ), s->plane_bytes[p], hipMemcpyDeviceToHost ) ); dst += s->plane_bytes[p]; }
+  return AA_OK;
+}
+
+static aa_status import_common( aa_stream * s, const void * const src[3], hipMemcpyKind kind );
+aa_status aa_stream_deserialize( aa_stream * s, const uint8_t * buf, size_t size )
+{
+  if ( !s || !buf ) return fail( AA_ERR_ARGUMENT, "null argument" );
+  if ( s->next_submit != static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_LOGIC, "aa_stream_deserialize: parsed frames are still waiting to be decoded" );
+  if ( size < 5 || buf[0] != 11 ) return fail( AA_ERR_INVALID, "invalid decoder state: expected DECODER" );
+  const size_t raster = s->plane_bytes[0] + 2 * s->plane_bytes[1];
+  aa::Parser trial = s->parser;                     // the stream changes only if the whole blob is good
+  size_t at = 5;
+  try { at += trial.deserialize_reference( buf + at, size - at ); }
+  catch ( const aa::ParseError & e ) { return fail( e.code, e.message ); }
+  if ( size < at + 9 + 5 + raster || buf[at] != 7 ) return fail( AA_ERR_INVALID, "invalid decoder state: expected REFERENCES" );
+  const unsigned w = buf[at + 5] | ( buf[at + 6] << 8 ), h = buf[at + 7] | ( buf[at + 8] << 8 );
+  at += 9;
+  if ( w != s->parser.width() || h != s->parser.height() ) return fail( AA_ERR_INVALID, "invalid decoder state: reference size differs from this decoder's" );
+  if ( buf[at] != 8 ) return fail( AA_ERR_INVALID, "invalid decoder state: no REF_LAST raster" );
+  const size_t rl = buf[at + 1] | ( buf[at + 2] << 8 ) | ( buf[at + 3] << 16 ) | ( static_cast<size_t>( buf[at + 4] ) << 24 );
+  at += 5;
+  if ( rl != raster || size != at + raster ) return fail( AA_ERR_INVALID, "invalid decoder state: raster length" );
+  const void * src[3] = { buf + at, buf + at + s->plane_bytes[0], buf + at + s->plane_bytes[0] + s->plane_bytes[1] };
+  if ( aa_status st = import_common( s, src, hipMemcpyHostToDevice ) ) return st;
+  s->parser = trial;
+  return AA_OK;
+}
 
 static aa_status import_common( aa_stream * s, const void * const src[3], hipMemcpyKind kind )
 {

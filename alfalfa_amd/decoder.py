@@ -49,6 +49,17 @@ class Parser:
     def import_state(self, blob):
         capi.check(self.L.aa_parser_import_state(self.h, blob, len(blob)))
 
+    def serialize_state(self):
+        """DecoderState in the reference's wire format (DecoderState::serialize, decoder.cc:283-313)."""
+        n = C.c_size_t(0)
+        capi.check(self.L.aa_parser_serialize_state(self.h, None, 0, C.byref(n)))
+        buf = (C.c_uint8 * n.value)()
+        capi.check(self.L.aa_parser_serialize_state(self.h, buf, n.value, C.byref(n)))
+        return bytes(buf)
+
+    def deserialize_state(self, blob):
+        capi.check(self.L.aa_parser_deserialize_state(self.h, blob, len(blob)))
+
     def probs(self):
         out = (C.c_uint8 * 1101)()
         capi.check(self.L.aa_parser_get_probs(self.h, out))
@@ -188,6 +199,18 @@ class Decoder:
 
     def import_state(self, blob):
         capi.check(self.L.aa_stream_import_state(self.h, blob, len(blob)))
+
+    def serialize(self):
+        """The decoder as the reference writes it to a .state file (Decoder::serialize, decoder.cc:54-69)."""
+        n = C.c_size_t(0)
+        capi.check(self.L.aa_stream_serialize(self.h, None, 0, C.byref(n)))
+        buf = (C.c_uint8 * n.value)()
+        capi.check(self.L.aa_stream_serialize(self.h, buf, n.value, C.byref(n)))
+        return bytes(buf)
+
+    def deserialize(self, blob):
+        """Load a reference-format decoder state (EncoderStateDeserializer::build<Decoder>, decoder.cc:48-52,71-81)."""
+        capi.check(self.L.aa_stream_deserialize(self.h, blob, len(blob)))
 
     def plane_sizes(self):
         pw, ph = self.padded_width, self.padded_height

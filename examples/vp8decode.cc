@@ -1,6 +1,7 @@
 // vp8decode on the MI355X decode path: the reference's frontend/vp8decode.cc (:43-101) written against the mirror
 // headers -- same option letters, same output (YUV4MPEG2: header of the first shown raster, then one FRAME per shown
-// frame).  `-s decoder_state` needs the reference's state wire format and is refused.
+// frame).  `-s decoder_state` continues from a reference-format state file (EncoderStateDeserializer::build<Player>); the
+// reference's minihash check of state against IVF header is the one thing missing.
 //   g++ -std=c++14 -O2 -Iinclude examples/vp8decode.cc -Lalfalfa_amd/lib -lalfalfa_amd -Wl,-rpath,$PWD/alfalfa_amd/lib
 #define ALFALFA_AMD_GLOBAL_NAMES
 #include "alfalfa_amd/alfalfa.hh"
@@ -21,18 +22,20 @@ int main( int argc, char * argv[] )
   try {
     if ( argc < 2 ) return usage( argv[0] );
     FileDescriptor y4m_fd;
+    char * decoder_state = nullptr;
     while ( true ) {
       const int opt = getopt( argc, argv, "s:o:" );
       if ( opt == -1 ) break;
       switch ( static_cast<char>( opt ) ) {
-      case 's': throw Unsupported( "decoder state files (EncoderStateDeserializer) are not part of this path yet" );
+      case 's': decoder_state = optarg; break;
       case 'o': y4m_fd = FileDescriptor( fopen( optarg, "wb" ) ); break;
       default: return usage( argv[0] );
       }
     }
     if ( optind >= argc ) return usage( argv[0] );
 
-    Player player( argv[optind] );
+    Player player = decoder_state == nullptr ? Player( argv[optind] )
+                                             : EncoderStateDeserializer::build<Player>( decoder_state, string( argv[optind] ) );
     while ( not player.eof() ) {
       RasterHandle raster = player.advance();
       if ( y4m_fd.valid() ) {

@@ -124,6 +124,11 @@ size_t aa_parser_state_size( const aa_parser * p );
 aa_status aa_parser_export_state( const aa_parser * p, uint8_t * buf, size_t capacity );
 aa_status aa_parser_import_state( aa_parser * p, const uint8_t * buf, size_t size );
 
+/* The same state in the REFERENCE's wire format: DecoderState::serialize / DecoderState::deserialize
+ * (decoder.cc:283-330; tags and little-endian integers of enc_state_serializer.hh:43-86).  buf == NULL: size query. */
+aa_status aa_parser_serialize_state( const aa_parser * p, uint8_t * buf, size_t capacity, size_t * size );
+aa_status aa_parser_deserialize_state( aa_parser * p, const uint8_t * buf, size_t size );
+
 /* ------------------------------------------------------------------------------------------------
  * Device context: one per GPU (one process per GPU in multi-GPU runs).
  * ---------------------------------------------------------------------------------------------- */
@@ -192,6 +197,14 @@ aa_status aa_stream_export_raster( aa_stream * s, int frame_index, void * y_dev,
 size_t aa_stream_state_size( const aa_stream * s );
 aa_status aa_stream_export_state( const aa_stream * s, uint8_t * buf, size_t capacity );
 aa_status aa_stream_import_state( aa_stream * s, const uint8_t * buf, size_t size );
+
+/* The whole decoder as the reference writes it to a `.state` file: Decoder::serialize / Decoder::deserialize
+ * (decoder.cc:54-81) = DecoderState + References (the LAST raster only; golden and alternative alias it after loading,
+ * decoder.cc:171-197).  Files written by the reference's xc-enc -O / read by vp8decode -s and xc-decode-bundle load here
+ * and vice versa.  Everything parsed must have been submitted; serialize waits for the device.  buf == NULL: size query.
+ * (Decoder::minihash, boost::hash_combine based, is not provided.) */
+aa_status aa_stream_serialize( aa_stream * s, uint8_t * buf, size_t capacity, size_t * size );
+aa_status aa_stream_deserialize( aa_stream * s, const uint8_t * buf, size_t size );
 
 /* Padded plane geometry for a display size (VP8Raster ctor, prediction.cc:94-97). */
 void aa_raster_geometry( uint16_t width, uint16_t height, uint32_t * padded_width, uint32_t * padded_height );

@@ -17,7 +17,9 @@
 //                                                                      (util/file_descriptor.hh, input/yuv4mpeg.{hh,cc})
 //   Decoder::get_frame_outputs  -- NOT in the reference: one frame of each of N decoders as one GPU batch step
 // What is NOT mirrored (host-side plumbing outside the hot path): Frame<> object graphs
-// (parse_frame<F>/decode_frame<F> are replaced by get_frame_output), boost-based hash()/minihash, state (de)serialisation.
+// (parse_frame<F>/decode_frame<F> are replaced by get_frame_output), boost-based hash()/minihash.
+//   EncoderStateSerializer / EncoderStateDeserializer, Decoder / FramePlayer / FilePlayer ::serialize, ::deserialize
+//               -- the reference's `.state` files, byte-compatible    (decoder/enc_state_serializer.hh, decoder.cc:48-81)
 //
 // Everything lives in namespace alfalfa_amd; define ALFALFA_AMD_GLOBAL_NAMES before including to also export the
 // names into the global namespace (drop-in for code written against the reference headers).
@@ -306,6 +308,41 @@ struct References
   RasterHandle last, golden, alternative;
 };
 
+// ---------------------------------------------------------------- decoder state files (decoder/enc_state_serializer.hh:58-179)
+// Byte-compatible with the reference: a file written by either implementation loads in the other (aa_stream_serialize).
+class EncoderStateSerializer
+{
+  std::vector<uint8_t> data_;
+public:
+  void append( const std::vector<uint8_t> & bytes ) { data_.insert( data_.end(), bytes.begin(), bytes.end() ); }
+  const std::vector<uint8_t> & data() const { return data_; }
+  void write( FILE * file ) const { if ( !data_.empty() && std::fwrite( data_.data(), data_.size(), 1, file ) != 1 ) throw std::runtime_error( "fwrite returned short write" ); }
+  void write( const std::string & filename ) const
+  {
+    FILE * f = std::fopen( filename.c_str(), "wb" );
+    if ( !f ) throw std::runtime_error( "cannot open " + filename );
+    try { write( f ); } catch ( ... ) { std::fclose( f ); throw; }
+    std::fclose( f );
+  }
+};
+class EncoderStateDeserializer
+{
+  std::vector<uint8_t> data_;
+public:
+  explicit EncoderStateDeserializer( const std::string & filename )
+  {
+    std::ifstream in( filename, std::ios::binary );
+    if ( !in ) throw std::runtime_error( "cannot open " + filename );
+    data_.assign( std::istreambuf_iterator<char>( in ), std::istreambuf_iterator<char>() );
+  }
+  explicit EncoderStateDeserializer( const char * filename ) : EncoderStateDeserializer( std::string( filename ) ) {}
+  explicit EncoderStateDeserializer( std::vector<uint8_t> bytes ) : data_( std::move( bytes ) ) {}
+  const std::vector<uint8_t> & data() const { return data_; }
+  size_t size() const { return data_.size(); }
+  template <typename T, typename F, typename... Ps>
+  static T build( F f, Ps... ps ) { EncoderStateDeserializer idata( f ); return T::deserialize( idata, ps... ); }     // enc_state_serializer.hh:125-128
+};
+
 class Decoder
 {
   std::shared_ptr<detail::StreamOwner> owner_;
@@ -368,6 +405,27 @@ public:
   }
   const VP8Raster & example_raster() const { example_ = get_references().last; return example_.get(); }
   aa_stream * native_handle() const { return owner_->stream; }
+
+  // Decoder::serialize (decoder.cc:54-69): DecoderState + the LAST reference raster, in the reference's wire format
+  size_t serialize( EncoderStateSerializer & odata ) const
+  {
+    size_t n = 0;
+    check( aa_stream_serialize( owner_->stream, nullptr, 0, &n ) );
+    std::vector<uint8_t> bytes( n );
+    check( aa_stream_serialize( owner_->stream, bytes.data(), bytes.size(), &n ) );
+    odata.append( bytes );
+    return n;
+  }
+  // Decoder::deserialize (decoder.cc:48-52,71-81); the frame size comes from the blob ([DECODER][len][DECODER_STATE][len][w][h]...)
+  static Decoder deserialize( EncoderStateDeserializer & idata ) { return deserialize( idata, GpuContext::process_default() ); }
+  static Decoder deserialize( EncoderStateDeserializer & idata, std::shared_ptr<GpuContext> ctx )
+  {
+    const std::vector<uint8_t> & b = idata.data();
+    if ( b.size() < 14 || b[0] != 11 || b[5] != 4 ) throw Invalid( "decoder state: not a serialized Decoder" );
+    Decoder d( std::move( ctx ), static_cast<uint16_t>( b[10] | ( b[11] << 8 ) ), static_cast<uint16_t>( b[12] | ( b[13] << 8 ) ) );
+    check( aa_stream_deserialize( d.owner_->stream, b.data(), b.size() ) );
+    return d;
+  }
 private:
   mutable RasterHandle example_;
 };
@@ -379,6 +437,10 @@ protected:
   Decoder decoder_;
 public:
   FramePlayer( const uint16_t width, const uint16_t height ) : width_( width ), height_( height ), decoder_( width, height ) {}
+  explicit FramePlayer( EncoderStateDeserializer & idata )                                  // player.cc:43-54
+    : width_( 0 ), height_( 0 ), decoder_( Decoder::deserialize( idata ) ) { width_ = decoder_.get_width(); height_ = decoder_.get_height(); }
+  static FramePlayer deserialize( EncoderStateDeserializer & idata ) { return FramePlayer( idata ); }
+  size_t serialize( EncoderStateSerializer & odata ) const { return decoder_.serialize( odata ); }   // player.cc:56-58
   Optional<RasterHandle> decode( const Chunk & chunk ) { return decoder_.parse_and_decode_frame( chunk ); }   // player.cc:60-63
   const VP8Raster & example_raster() const { return decoder_.example_raster(); }
   uint16_t width() const { return width_; }
@@ -402,8 +464,16 @@ class FilePlayer : public FramePlayer
       frame_no_++;
     }
   }
+  FilePlayer( const std::string & filename, IVF && file, EncoderStateDeserializer & idata )      // player.cc:108-124: continue from a state
+    : FramePlayer( idata ), file_( std::move( file ) ), filename_( filename )
+  {
+    if ( file_.fourcc() != "VP80" ) throw Unsupported( "not a VP8 file" );
+    if ( file_.width() != decoder_.get_width() || file_.height() != decoder_.get_height() ) throw Unsupported( "state vs. file dimension mismatch" );
+    // the reference also checks Decoder::minihash against the IVF header here; minihash (boost::hash_combine) is not provided
+  }
 public:
   explicit FilePlayer( const std::string & filename ) : FilePlayer( filename, IVF( filename ) ) {}
+  static FilePlayer deserialize( EncoderStateDeserializer & idata, const std::string & filename ) { return FilePlayer( filename, IVF( filename ), idata ); }
   RasterHandle advance()                                  // player.cc:134-144
   {
     while ( !eof() ) {
@@ -482,4 +552,5 @@ using alfalfa_amd::Invalid; using alfalfa_amd::IVF; using alfalfa_amd::LogicErro
 using alfalfa_amd::Player; using alfalfa_amd::RasterHandle; using alfalfa_amd::References; using alfalfa_amd::Unsupported;
 using alfalfa_amd::VP8Raster; using alfalfa_amd::print_exception;
 using alfalfa_amd::FileDescriptor; using alfalfa_amd::YUV4MPEGHeader; using alfalfa_amd::YUV4MPEGFrameWriter;
+using alfalfa_amd::EncoderStateSerializer; using alfalfa_amd::EncoderStateDeserializer;
 #endif

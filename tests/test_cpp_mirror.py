@@ -68,6 +68,8 @@ def test_frontend_ports_build_and_fail_loudly_without_gpu(tmp_path):
         exe = build_example(name)
         r = subprocess.run([exe], capture_output=True)
         assert r.returncode != 0 and b"Usage" in r.stderr
+    r = subprocess.run([build_example("xc_decode_bundle"), "a", "b"], capture_output=True)
+    assert r.returncode != 0 and b"Usage" in r.stderr
     if capi.device_count() == 0:
         r = subprocess.run([build_example("vp8decode"), "-o", str(tmp_path / "o.y4m"), os.path.join(GOLDEN_DIR, "qcif_q30.ivf")], capture_output=True)
         assert r.returncode != 0 and b"no HIP device" in r.stderr
@@ -90,3 +92,43 @@ def test_decode_many_lockstep_batches_match_reference_dumps(tmp_path):
     for n in names:
         data = (tmp_path / (n + ".ivf.y4m")).read_bytes()
         assert hashlib.sha1(y4m_payload(data, n)).hexdigest() == GOLDEN[n]["display_sha1"], n
+
+
+def _write_ivf(path, name, frames):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from ivf_io import write_ivf
+    write_ivf(path, GOLDEN[name]["width"], GOLDEN[name]["height"], frames)
+
+
+@pytest.mark.gpu
+def test_xc_decode_bundle_carries_one_decoder_across_files(tmp_path):
+    """frontend/decode-bundle.cc port: a stream cut into three IVF pieces, names on stdin, one YUV4MPEG2 video on stdout."""
+    from conftest import golden_frames
+    name = "w200_q40_lf63s7"
+    _, _, frames = golden_frames(name)
+    cuts = [(0, 3), (3, 4), (4, len(frames))]
+    paths = []
+    for a, b in cuts:
+        paths.append(str(tmp_path / ("piece_%d.ivf" % a)))
+        _write_ivf(paths[-1], name, frames[a:b])
+    r = subprocess.run([build_example("xc_decode_bundle")], input=("\n".join(paths) + "\n").encode(), capture_output=True, check=True)
+    assert hashlib.sha1(y4m_payload(r.stdout, name)).hexdigest() == GOLDEN[name]["display_sha1"]
+
+
+@pytest.mark.gpu
+def test_vp8decode_resumes_from_a_state_file_written_by_the_reference(tmp_path):
+    """`vp8decode -s state` (EncoderStateDeserializer::build<Player>): the fixture was written by the reference after 3 frames."""
+    from conftest import golden_frames
+    name, n = "qcif_q30_lf24", 3
+    _, _, frames = golden_frames(name)
+    whole, rest = str(tmp_path / "whole.y4m"), str(tmp_path / "rest.y4m")
+    cont = str(tmp_path / "cont.ivf")
+    _write_ivf(cont, name, frames[n:])
+    exe = build_example("vp8decode")
+    subprocess.run([exe, "-o", whole, os.path.join(GOLDEN_DIR, name + ".ivf")], check=True)
+    subprocess.run([exe, "-s", os.path.join(GOLDEN_DIR, "%s_f%d.state" % (name, n)), "-o", rest, cont], check=True)
+    full, tail = y4m_payload(open(whole, "rb").read(), name), y4m_payload(open(rest, "rb").read(), name)
+    shown_before = sum(GOLDEN[name]["shown"][:n])
+    frame = len(full) // sum(GOLDEN[name]["shown"])
+    assert tail == full[shown_before * frame:]
