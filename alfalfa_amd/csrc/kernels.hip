@@ -1,14 +1,19 @@
-// HIP kernels (gfx950 / CDNA4) for the VP8 reconstruction hot path: one 64-lane wavefront per macroblock.
+// HIP kernels (gfx950 / CDNA4) for the VP8 reconstruction hot path.  64-lane waves, 16 lanes per macroblock: every unit of
+// work here is 16 wide (a 4x4 sub-block, the rows of a 16x16 prediction, 2 x 8 chroma rows, 16 luma IDCTs, the lines of
+// a filter edge), so a wave carries four independent macroblocks / frames.
 //
-//   k_recon_inter   all inter-coded MBs of a batch of frames: six-tap motion compensation from LDS-staged,
-//                   coordinate-clamped reference windows + dequant / iWHT / IDCT residual    (macroblock.cc:553-601)
-//   k_recon_intra   intra MBs of one 2:1 anti-diagonal (col + 2*row == d): neighbours (left, above, above-left,
-//                   above-right) are final when the diagonal is launched                          (macroblock.cc:523-551)
-//   k_loopfilter    normal loop filter of one 2:1 anti-diagonal, in place on the output raster   (loopfilter.cc:133-154)
+//   k_recon_inter4      whole-vector inter MBs, four consecutive MBs per wave: in-register dequant/IDCT, six-tap motion
+//                       compensation from LDS-staged reference windows (integer vectors: a copy)     (macroblock.cc:553-601)
+//   k_recon_inter       SPLITMV macroblocks, one per wave (launched only when a frame has any)
+//   k_recon_intra4      row-pipelined intra prediction, four frames per wave                       (macroblock.cc:523-551)
+//   k_loopfilter_rows4  row-pipelined normal loop filter, four frames per wave, packed int16 arithmetic, strip-staged
+//                       whole-line I/O                                                              (loopfilter.cc:133-154)
+//   k_recon_intra / k_loopfilter   the first schedule (one launch per 2:1 anti-diagonal, one MB per wave), kept as an
+//                       independent implementation for A/B runs (ALFALFA_AMD_SCHEDULE=diagonal)
 //
-// No MFMA: nothing here is a dense contraction.  The path is integer stencil/gather work bounded by HBM traffic
-// and by the raster-order dependency chains; every kernel stages its working set in LDS and touches each
-// global byte once.  Batches of independent frames (streams / GOPs) fill the chip: grid.y = frame in batch.
+// No MFMA: nothing here is a dense contraction.  The path is integer stencil/gather work; what binds it is instruction
+// issue and the raster-order dependency wavefront, HBM traffic stays near the algorithmic bytes.  Batches of independent
+// frames (streams / GOPs) fill the chip.  The row-pipelined kernels are XCD-affine (see take_ticket).
 #include <hip/hip_runtime.h>
 #include <cstddef>
 

@@ -8,9 +8,10 @@
 //   * rasters are slots of 3 tightly packed padded planes (VP8Raster, raster.hh:54-56); slots are assigned when a
 //     frame is PARSED by replaying Frame::copy_to (frame.cc:271-307) on slot ids, so each job is self-contained
 //     and device execution never consults the host;
-//   * decode = k_recon_inter + k_recon_intra_rows + k_loopfilter_rows: three launches per batch step (the two row-pipelined
-//     kernels order macroblock rows in-launch by ticket + progress words); ALFALFA_AMD_SCHEDULE=diagonal selects the
-//     launch-per-anti-diagonal schedule instead (kept for A/B measurement).
+//   * decode = k_recon_inter4 + k_recon_intra4 + k_loopfilter_rows4: three launches per batch step (the two row-pipelined
+//     kernels order macroblock rows in-launch by per-XCD tickets + progress words); ALFALFA_AMD_SCHEDULE=diagonal selects
+//     the launch-per-anti-diagonal schedule instead (kept for A/B measurement);
+//   * pinned staging is pooled per context and can be given back once uploaded (aa_stream_release_staging).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
