@@ -79,8 +79,8 @@ def test_hip_matches_oracle_on_synthetic_feature_streams(gpu_ctx, seed):
 
 
 def test_row_pipelined_schedule_under_load(gpu_ctx):
-    """The in-launch ordering of the row-pipelined kernels (per-XCD tickets, progress words, hand-off through the XCD's L2;
-    XCDs) must give the same bytes as the launch-per-diagonal schedule when the chip is full: 16 concurrent 720p
+    """The in-launch ordering of the row-pipelined kernels (per-XCD tickets, progress words, hand-off through the XCD's L2)
+    must give the same bytes as the launch-per-diagonal schedule when the chip is full: 16 concurrent 720p
     streams (inter frames with loop filter + an all-intra stream), every frame of every stream, repeated."""
     import hashlib
     import workload
