@@ -638,6 +638,64 @@ __device__ __forceinline__ void idct_block_regs( const uint32_t ( &d )[8], const
   for ( int i = 0; i < 4; i++ ) { const Quad v = idct_pass2( im[i], im[i + 4], im[i + 8], im[i + 12] ); r[i * 4] = v.v0; r[i * 4 + 1] = v.v1; r[i * 4 + 2] = v.v2; r[i * 4 + 3] = v.v3; }
 }
 
+// Residual of up to four macroblocks (one per 16-lane slot): dequantise, inverse WHT of Y2 (through S.y2), then whole
+// 4x4 inverse DCTs in each lane's registers -- 16 luma blocks = 16 lanes, then 8 chroma blocks -- into S.res[block][row*4+col].
+// Macroblock::apply_walsh / DCTCoefficients::{dequantize,iwht,idct_add} (macroblock.cc:504-521, quantization.cc:95-126,
+// transform.cc:47-137).  Called by the whole wave (contains barriers).
+template <class Slot>
+__device__ __forceinline__ void residual_x4( Slot & S, const aa_dev_frame & f, const bool has_res, const bool has_y2, const uint32_t nz_mask,
+                                             const uint32_t coeff_index, const int segment, const int l )
+{
+  if ( __any( has_res ) ) {
+    const int16_t * const src = f.coeffs + static_cast<size_t>( coeff_index ) * 16;
+    const uint16_t * const q = f.quant[segment];
+    const bool y2_stored = has_y2 && ( ( nz_mask >> 24 ) & 1u );
+    if ( __any( y2_stored ) ) {
+      if ( y2_stored ) S.y2[l] = static_cast<int16_t>( dequant( src[__popc( nz_mask & 0xFFFFFFu ) * 16 + l], q[l ? 3 : 2] ) );
+      __syncthreads();
+      if ( y2_stored && l < 4 ) {
+        const Quad v = iwht_pass1( S.y2[l], S.y2[l + 4], S.y2[l + 8], S.y2[l + 12] );
+        S.y2[16 + l] = static_cast<int16_t>( v.v0 ); S.y2[16 + l + 4] = static_cast<int16_t>( v.v1 );
+        S.y2[16 + l + 8] = static_cast<int16_t>( v.v2 ); S.y2[16 + l + 12] = static_cast<int16_t>( v.v3 );
+      }
+      __syncthreads();
+      if ( y2_stored && l < 4 ) {
+        const int o = l * 4;
+        const Quad v = iwht_pass2( S.y2[16 + o], S.y2[16 + o + 1], S.y2[16 + o + 2], S.y2[16 + o + 3] );
+        S.y2[o] = static_cast<int16_t>( v.v0 ); S.y2[o + 1] = static_cast<int16_t>( v.v1 );
+        S.y2[o + 2] = static_cast<int16_t>( v.v2 ); S.y2[o + 3] = static_cast<int16_t>( v.v3 );
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for ( int round = 0; round < 2; round++ ) {
+      const int blk = round == 0 ? l : 16 + ( l & 7 );
+      const bool mine = has_res && ( round == 0 || l < 8 );
+      const bool stored = mine && ( ( nz_mask >> blk ) & 1u );
+      const bool wht_dc = round == 0 && has_y2;
+      const int dc = ( wht_dc && y2_stored ) ? S.y2[blk] : 0;
+      if ( __any( mine ) ) {
+        uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        if ( stored ) {
+          const uint4 * p = reinterpret_cast<const uint4 *>( src + __popc( nz_mask & ( ( 1u << blk ) - 1u ) ) * 16 );
+          const uint4 a = p[0], b = p[1];
+          d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+        }
+        const int base = round == 0 ? 0 : 4;
+        int r[16];
+        idct_block_regs( d, q[base], q[base + 1], wht_dc, dc, r );
+        if ( mine ) {
+          uint32_t o[8];
+#pragma unroll
+          for ( int i = 0; i < 8; i++ ) o[i] = ( static_cast<uint32_t>( r[2 * i] ) & 0xFFFFu ) | ( static_cast<uint32_t>( r[2 * i + 1] ) << 16 );
+          uint4 * dst = reinterpret_cast<uint4 *>( &S.res[blk][0] );
+          dst[0] = make_uint4( o[0], o[1], o[2], o[3] ); dst[1] = make_uint4( o[4], o[5], o[6], o[7] );
+        }
+      }
+    }
+  }
+}
+
 // n pixels of a 16x16 / 8x8 prediction row (+ residual): above = packed above pixels, res = pointer to 4 int16 residuals
 __device__ __forceinline__ uint32_t bigpred_x4( const int mode, const uint32_t above, const int left, const int corner, const int dc, const bool has_res, const int16_t * res )
 {
@@ -694,54 +752,7 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
     if ( on && row > 0 && seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
 
     // ---- residual: needs no neighbour, runs before the wait for the row above ----
-    if ( __any( has_res ) ) {
-      const int16_t * const src = f.coeffs + static_cast<size_t>( coeff_index ) * 16;
-      const uint16_t * const q = f.quant[segment];
-      const bool y2_stored = has_y2 && ( ( nz_mask >> 24 ) & 1u );
-      if ( __any( y2_stored ) ) {
-        if ( y2_stored ) S.y2[l] = static_cast<int16_t>( dequant( src[__popc( nz_mask & 0xFFFFFFu ) * 16 + l], q[l ? 3 : 2] ) );
-        __syncthreads();
-        if ( y2_stored && l < 4 ) {
-          const Quad v = iwht_pass1( S.y2[l], S.y2[l + 4], S.y2[l + 8], S.y2[l + 12] );
-          S.y2[16 + l] = static_cast<int16_t>( v.v0 ); S.y2[16 + l + 4] = static_cast<int16_t>( v.v1 );
-          S.y2[16 + l + 8] = static_cast<int16_t>( v.v2 ); S.y2[16 + l + 12] = static_cast<int16_t>( v.v3 );
-        }
-        __syncthreads();
-        if ( y2_stored && l < 4 ) {
-          const int o = l * 4;
-          const Quad v = iwht_pass2( S.y2[16 + o], S.y2[16 + o + 1], S.y2[16 + o + 2], S.y2[16 + o + 3] );
-          S.y2[o] = static_cast<int16_t>( v.v0 ); S.y2[o + 1] = static_cast<int16_t>( v.v1 );
-          S.y2[o + 2] = static_cast<int16_t>( v.v2 ); S.y2[o + 3] = static_cast<int16_t>( v.v3 );
-        }
-        __syncthreads();
-      }
-#pragma unroll
-      for ( int round = 0; round < 2; round++ ) {
-        const int blk = round == 0 ? l : 16 + ( l & 7 );
-        const bool mine = has_res && ( round == 0 || l < 8 );
-        const bool stored = mine && ( ( nz_mask >> blk ) & 1u );
-        const bool wht_dc = round == 0 && has_y2;
-        const int dc = ( wht_dc && y2_stored ) ? S.y2[blk] : 0;
-        if ( __any( mine ) ) {
-          uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-          if ( stored ) {
-            const uint4 * p = reinterpret_cast<const uint4 *>( src + __popc( nz_mask & ( ( 1u << blk ) - 1u ) ) * 16 );
-            const uint4 a = p[0], b = p[1];
-            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
-          }
-          const int base = round == 0 ? 0 : 4;
-          int r[16];
-          idct_block_regs( d, q[base], q[base + 1], wht_dc, dc, r );
-          if ( mine ) {
-            uint32_t o[8];
-#pragma unroll
-            for ( int i = 0; i < 8; i++ ) o[i] = ( static_cast<uint32_t>( r[2 * i] ) & 0xFFFFu ) | ( static_cast<uint32_t>( r[2 * i + 1] ) << 16 );
-            uint4 * dst = reinterpret_cast<uint4 *>( &S.res[blk][0] );
-            dst[0] = make_uint4( o[0], o[1], o[2], o[3] ); dst[1] = make_uint4( o[4], o[5], o[6], o[7] );
-          }
-        }
-      }
-    }
+    residual_x4( S, f, has_res, has_y2, nz_mask, coeff_index, segment, l );
 
     // ---- wait for the row above, then stage the neighbours (sc1 loads: L1-bypassing, served by this XCD's L2) ----
     if ( row > 0 ) {
@@ -973,54 +984,7 @@ __device__ __forceinline__ void recon_inter4_body( const aa_dev_frame & f, const
   }
 
   // ---- residual ----
-  if ( __any( has_res ) ) {
-    const int16_t * const src = f.coeffs + static_cast<size_t>( coeff_index ) * 16;
-    const uint16_t * const q = f.quant[segment];
-    const bool y2_stored = has_y2 && ( ( nz_mask >> 24 ) & 1u );
-    if ( __any( y2_stored ) ) {
-      if ( y2_stored ) S.y2[l] = static_cast<int16_t>( dequant( src[__popc( nz_mask & 0xFFFFFFu ) * 16 + l], q[l ? 3 : 2] ) );
-      __syncthreads();
-      if ( y2_stored && l < 4 ) {
-        const Quad v = iwht_pass1( S.y2[l], S.y2[l + 4], S.y2[l + 8], S.y2[l + 12] );
-        S.y2[16 + l] = static_cast<int16_t>( v.v0 ); S.y2[16 + l + 4] = static_cast<int16_t>( v.v1 );
-        S.y2[16 + l + 8] = static_cast<int16_t>( v.v2 ); S.y2[16 + l + 12] = static_cast<int16_t>( v.v3 );
-      }
-      __syncthreads();
-      if ( y2_stored && l < 4 ) {
-        const int o = l * 4;
-        const Quad v = iwht_pass2( S.y2[16 + o], S.y2[16 + o + 1], S.y2[16 + o + 2], S.y2[16 + o + 3] );
-        S.y2[o] = static_cast<int16_t>( v.v0 ); S.y2[o + 1] = static_cast<int16_t>( v.v1 );
-        S.y2[o + 2] = static_cast<int16_t>( v.v2 ); S.y2[o + 3] = static_cast<int16_t>( v.v3 );
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for ( int round = 0; round < 2; round++ ) {
-      const int blk = round == 0 ? l : 16 + ( l & 7 );
-      const bool mine = has_res && ( round == 0 || l < 8 );
-      const bool stored = mine && ( ( nz_mask >> blk ) & 1u );
-      const bool wht_dc = round == 0 && has_y2;
-      const int dc = ( wht_dc && y2_stored ) ? S.y2[blk] : 0;
-      if ( __any( mine ) ) {
-        uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        if ( stored ) {
-          const uint4 * p = reinterpret_cast<const uint4 *>( src + __popc( nz_mask & ( ( 1u << blk ) - 1u ) ) * 16 );
-          const uint4 a = p[0], b = p[1];
-          d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
-        }
-        const int base = round == 0 ? 0 : 4;
-        int r[16];
-        idct_block_regs( d, q[base], q[base + 1], wht_dc, dc, r );
-        if ( mine ) {
-          uint32_t o[8];
-#pragma unroll
-          for ( int i = 0; i < 8; i++ ) o[i] = ( static_cast<uint32_t>( r[2 * i] ) & 0xFFFFu ) | ( static_cast<uint32_t>( r[2 * i + 1] ) << 16 );
-          uint4 * dst = reinterpret_cast<uint4 *>( &S.res[blk][0] );
-          dst[0] = make_uint4( o[0], o[1], o[2], o[3] ); dst[1] = make_uint4( o[4], o[5], o[6], o[7] );
-        }
-      }
-    }
-  }
+  residual_x4( S, f, has_res, has_y2, nz_mask, coeff_index, segment, l );
 
   // ---- windows -> LDS ----
   {
@@ -1257,8 +1221,7 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
   };
   prefetch( 0 );
   int info = frame_on ? *reinterpret_cast<const uint16_t *>( &mbrow[0].flags ) : 0;     // flags | lf_level << 8
-  int pending = -1;
-  int seen = row > 0 ? 0 : mbw;        // columns of the row above known to be final
+  int seen = row > 0 ? 0 : mbw;        // boundary lines of the row above known to be complete
   for ( int s = 0; s < n_strips; s++ ) {
     const int nmb = min( kStripMbs, mbw - s * kStripMbs );
     // ---- strip turn-over: keep the right edge as the new left neighbour, then drop the prefetched rows in ----
@@ -1281,7 +1244,7 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
       const bool more = col + 1 < mbw;
       // in flight during the V phase: the next macroblock's level, the poll of the row above
       const int info_next = ( frame_on && more ) ? *reinterpret_cast<const uint16_t *>( &mbrow[col + 1].flags ) : 0;
-      const int need = min( col + 2, mbw );
+      const int need = col + 1;           // boundary lines 0..col of the row above complete (the last one only at its row's end)
       // progress only grows: what an earlier poll saw stays valid, so a row that runs well behind the row above polls rarely
       if ( row > 0 && seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
       const bool any_active = __any( active );
@@ -1313,10 +1276,13 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
           if ( luma ) { *reinterpret_cast<uint2 *>( ra + 8 ) = make_uint2( a[3], a[4] ); *reinterpret_cast<uint2 *>( ra + kStripRow + 8 ) = make_uint2( b[3], b[4] ); }
         }
       }
-      // the previous step's stores have drained behind the V phase: publish it
-      asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-      if ( lane == 0 && pending >= 0 ) __hip_atomic_store( &progress[row], pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
-      pending = -1;
+      // The left MB edge just run was the last thing to touch the previous macroblock's right columns: complete its
+      // boundary line now, so that the row below can use it one step earlier than if this waited for the end of the step.
+      __syncthreads();
+      if ( frame_on && !last_row && col > 0 && l < 12 && !( dbg & 1 ) ) {
+        const uint8_t * src = k == 0 ? fix_src0 : fix_srck + fix_step * k;
+        *reinterpret_cast<uint32_t *>( bnd + ( bnd_row + col - 1 ) * 128 + fix_off ) = *reinterpret_cast<const uint32_t *>( src );
+      }
 
       if ( row > 0 ) {
         int spins = 0;
@@ -1336,6 +1302,10 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
           else { *reinterpret_cast<uint64_t *>( dst ) = lo; *reinterpret_cast<uint64_t *>( dst + kStripRow ) = hi; }
         }
       }
+      // every boundary line up to macroblock col-1 is complete and has reached the L2 (the fix-up above drained behind the
+      // wait for the row above): publish
+      asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+      if ( lane == 0 && col > 0 ) __hip_atomic_store( &progress[row], col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
       // the next strip's own rows: issued here so that no wait of THIS step covers them (vmcnt completes in order); they
       // have the rest of the strip to arrive
       if ( k == 0 && s + 1 < n_strips ) prefetch( s + 1 );
@@ -1368,10 +1338,6 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
             else { const uint2 u0 = *reinterpret_cast<const uint2 *>( src ), u1 = *reinterpret_cast<const uint2 *>( src + kStripRow ); q = make_uint4( u0.x, u0.y, u1.x, u1.y ); }
             *reinterpret_cast<uint4 *>( bnd_own + static_cast<size_t>( col ) * 128 ) = q;
           }
-          if ( col > 0 && l < 12 ) {
-            const uint8_t * src = k == 0 ? fix_src0 : fix_srck + fix_step * k;
-            *reinterpret_cast<uint32_t *>( bnd + ( bnd_row + col - 1 ) * 128 + fix_off ) = *reinterpret_cast<const uint32_t *>( src );
-          }
         }
         if ( k == 0 && s > 0 ) {
           // the previous strip's last four columns are final now
@@ -1394,13 +1360,12 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
           }
         }
       }
-      pending = col + 1;
       info = info_next;
       __syncthreads();
     }
   }
-  asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-  if ( lane == 0 && pending >= 0 ) __hip_atomic_store( &progress[row], pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+  asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );       // the last macroblock's line has no right neighbour to wait for
+  if ( lane == 0 ) __hip_atomic_store( &progress[row], mbw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
 }
 
 __device__ __forceinline__ void loopfilter_rows4_body( const aa_frame_list & list, const int n_groups, const int mbh_max, const int mbw_max, aa_sync_ws * ws, uint8_t * bnd,
