@@ -674,7 +674,8 @@ __device__ __forceinline__ void residual_x4( Slot & S, const aa_dev_frame & f, c
       const bool stored = mine && ( ( nz_mask >> blk ) & 1u );
       const bool wht_dc = round == 0 && has_y2;
       const int dc = ( wht_dc && y2_stored ) ? S.y2[blk] : 0;
-      if ( __any( mine ) ) {
+      if ( !__any( mine ) ) continue;
+      if ( __any( stored ) ) {
         uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         if ( stored ) {
           const uint4 * p = reinterpret_cast<const uint4 *>( src + __popc( nz_mask & ( ( 1u << blk ) - 1u ) ) * 16 );
@@ -691,6 +692,13 @@ __device__ __forceinline__ void residual_x4( Slot & S, const aa_dev_frame & f, c
           uint4 * dst = reinterpret_cast<uint4 *>( &S.res[blk][0] );
           dst[0] = make_uint4( o[0], o[1], o[2], o[3] ); dst[1] = make_uint4( o[4], o[5], o[6], o[7] );
         }
+      } else if ( mine ) {
+        // no block of this round carries coefficients in any of the four macroblocks (low-entropy streams: Y2-only or
+        // chroma-less macroblocks): the inverse DCT of a block that is nothing but its DC is that DC, (dc + 4) >> 3,
+        // everywhere (both passes of transform.cc:100-137 with c[1..15] = 0)
+        const pk2 v = pk_splat( ( static_cast<int16_t>( dc ) + 4 ) >> 3 );
+        uint4 * dst = reinterpret_cast<uint4 *>( &S.res[blk][0] );
+        dst[0] = make_uint4( v, v, v, v ); dst[1] = make_uint4( v, v, v, v );
       }
     }
   }
