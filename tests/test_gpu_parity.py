@@ -138,3 +138,36 @@ def test_release_staging_then_parse_more(gpu_ctx):
     for f in range(len(frames)):
         assert sha256(a.raster_bytes(f)) == GOLDEN[name]["raster_sha256"][f], f
         assert sha256(b.raster_bytes(f)) == GOLDEN[name]["raster_sha256"][f], f
+
+
+def test_row_kernels_do_not_depend_on_residency():
+    """Deadlock freedom and ordering of the ticketed row kernels must not rely on every workgroup being resident:
+    ALFALFA_AMD_TEST_LDS_PAD adds 100 KB of dynamic LDS to their launches (one workgroup per CU = 256 resident waves for
+    540 macroblock rows per launch); same bytes as the unconstrained run.  The hook is read once per process -> subprocesses."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = (
+        "import sys, hashlib, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import alfalfa_amd as aa, workload\n"
+        "paths = workload.make_streams('720p_inter', 3, list(range(300, 348)))\n"
+        "ctx = aa.Context(0); decs = []\n"
+        "for p in paths:\n"
+        "    w, h, frames = aa.read_ivf(p); d = aa.Decoder(ctx, w, h)\n"
+        "    for fr in frames: d.parse_frame(fr)\n"
+        "    decs.append(d)\n"
+        "for f in range(3): ctx.decode_batch(decs, [f] * len(decs))\n"
+        "ctx.sync()\n"
+        "print(json.dumps([hashlib.sha256(d.raster_bytes(2)).hexdigest() for d in decs]))\n" % (ROOT, os.path.join(ROOT, "tools")))
+    outs = []
+    for pad in (None, "100000"):
+        env = dict(os.environ)
+        env.pop("ALFALFA_AMD_TEST_LDS_PAD", None)
+        if pad:
+            env["ALFALFA_AMD_TEST_LDS_PAD"] = pad
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1] and len(set(outs[0])) > 1
