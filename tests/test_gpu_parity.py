@@ -171,3 +171,32 @@ def test_row_kernels_do_not_depend_on_residency():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1] and len(set(outs[0])) > 1
+
+
+@pytest.mark.parametrize("name", ["qcif_q30_lf24", "w200_q40_lf63s7"])
+def test_hip_matches_oracle_on_truncated_frames(gpu_ctx, name):
+    """Frames whose partitions end early (zeros are read past the end, bool_decoder.hh:56-65): garbage in, the SAME garbage out."""
+    from test_parser_vs_oracle import truncated
+    w, h, frames = golden_frames(name)
+    dec, ora = aa.Decoder(gpu_ctx, w, h), vo.OracleDecoder(w, h)
+    for i, fr in enumerate(truncated(frames)):
+        _, fi = dec.get_frame_output(fr)
+        ora.decode(fr)
+        assert dec.raster_bytes(fi) == ora.raster_bytes(), (name, i)
+
+
+def test_hip_matches_oracle_on_large_and_extreme_geometries(gpu_ctx):
+    """2560x1440 (160x90 macroblocks, more than two 8-macroblock strips per row and rows beyond one residency round for a
+    single group), a one-macroblock-wide 16x4096 column and a one-row 4096x16 strip (the degenerate wavefronts)."""
+    import vp8_synth
+    import workload
+    cases = [aa.read_ivf(workload.make_stream("1440p_inter_lf", 3, 500))]
+    for w, h, seed in ((16, 4096, 901), (4096, 16, 902), (24, 1000, 903)):
+        cases.append((w, h, vp8_synth.feature_stream(w, h, seed, 4).frames))
+    for w, h, frames in cases:
+        dec, ora = aa.Decoder(gpu_ctx, w, h), vo.OracleDecoder(w, h)
+        for i, fr in enumerate(frames):
+            shown, fi = dec.get_frame_output(fr)
+            assert ora.decode(fr) == shown
+            got, want = dec.raster_bytes(fi), ora.raster_bytes()
+            assert got == want, "%dx%d frame %d: %s" % (w, h, i, first_diff(got, want, dec.padded_width, dec.padded_height))

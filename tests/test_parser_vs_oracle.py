@@ -42,3 +42,45 @@ def test_parser_error_types():
     # a failed parse must not have consumed decoder state: the real stream still parses
     for fr in frames:
         p.parse(fr)
+
+
+def truncated(frames):
+    """Every frame with a third of what follows its first partition cut off: the reference's BoolDecoder reads zeros past
+    the end of a partition (bool_decoder.hh:56-65), so such frames still decode -- deterministically."""
+    out = []
+    for fr in frames:
+        tag = fr[0] | (fr[1] << 8) | (fr[2] << 16)
+        off = (3 if tag & 1 else 10) + ((tag >> 5) & 0x7FFFF)
+        rest = len(fr) - off
+        out.append(fr[:off + max(1, rest * 2 // 3)] if rest > 1 else fr)
+    return out
+
+
+@pytest.mark.parametrize("name", ["qcif_q30_lf24", "w200_q40_lf63s7", "qcif_allkey_q20"])
+def test_truncated_frames_parse_like_the_oracle_and_the_reference(name, tmp_path):
+    w, h, frames = golden_frames(name)
+    cut = truncated(frames)
+    p, d = aa.Parser(w, h), vo.OracleDecoder(w, h)
+    rasters = []
+    for fr in cut:
+        hdr, mb, cf = p.parse(fr)
+        d.decode(fr)
+        compare(hdr, mb, cf, d.macroblocks(), d.frame_info())
+        rasters.append(d.raster_bytes())
+    if vo.ref_available():                       # build container only: the live reference decodes them to the same bytes
+        ivf, raw = str(tmp_path / "c.ivf"), str(tmp_path / "c.raw")
+        vo.write_ivf(ivf, w, h, cut)
+        info = vo.ref_decode(ivf, raw)
+        data = open(raw, "rb").read()
+        fs = len(data) // len(info)
+        assert [data[i * fs:(i + 1) * fs] for i in range(len(cut))] == rasters
+
+
+def test_truncated_partition_table_is_out_of_range():
+    """Cutting into the partition size table of a multi-partition frame is the reference's std::out_of_range
+    ("attempted to read past end of chunk", chunk.hh:54-59), not a crash and not Invalid."""
+    w, h, frames = golden_frames("synth_96x80_s1")
+    cut = truncated(frames)
+    with pytest.raises(aa.AlfalfaError) as e:
+        aa.Parser(w, h).parse(cut[0])
+    assert e.value.kind == "OutOfRange" and "past end of chunk" in e.value.message

@@ -23,6 +23,7 @@ CONFIGS = {
     "1080p_inter_lf": (1920, 1080, "high", 20, 24, 0),
     "1080p_inter_lf_lowentropy": (1920, 1080, "low", 40, 24, 0),
     "cif_inter_lf": (352, 288, "high", 20, 24, 0),          # small stand-in for quick checks
+    "1440p_inter_lf": (2560, 1440, "high", 20, 24, 0),      # bigger than any bench config: parity test only
     # geometry probes for tools/row_kernel_probe.py: one MB row (no cross-row waits) / one MB column (pure hand-off chain)
     "probe_1row": (1920, 16, "high", 20, 24, 0),
     "probe_1col": (16, 1088, "high", 20, 24, 0),
