@@ -613,7 +613,6 @@ struct alignas( 16 ) Intra4Slot {
   alignas( 16 ) int16_t res[24][16];   // residual of block b at [row*4+col]
   alignas( 16 ) uint8_t y[17][48];     // [row+1][col+16]: row 0 = the row above (cols -4..19), byte 15 = the column to the left
   alignas( 16 ) uint8_t c[2][9][32];   // chroma likewise: cols -4..7 at bytes 12..23
-  alignas( 16 ) uint8_t E[16];         // edge array of the current 4x4 sub-block (vp8_math.hh bpred_pixel)
   alignas( 16 ) int16_t y2[32];        // Y2: dequantised coefficients / block DCs [0..15], first-pass results [16..31]
 };
 struct alignas( 16 ) Intra4Lds { Intra4Slot slot[4]; uint32_t tab[160]; };
@@ -836,24 +835,23 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
       for ( int b = 0; b < 16; b++ ) {
         const int bx = b & 3, by = b >> 2;
         const int ar = by * 4, ac = bx * 4 + 15;          // tile position of (row -1, col -1) of this sub-block
-        if ( bp && l < 13 ) {
-          int er, ec;
-          if ( l < 4 ) { er = ar + 4 - l; ec = ac; }
-          else if ( l < 9 ) { er = ar; ec = ac + ( l - 4 ); }
-          else if ( bx == 3 ) { er = 0; ec = 32 + ( l - 9 ); }        // above-right of column 3: the row above the MACROBLOCK (prediction.cc:153-160)
-          else { er = ar; ec = ac + ( l - 4 ); }
-          S.E[l] = S.y[er][ec];
-        }
-        __syncthreads();
-        int v = 0;
         if ( bp ) {
           const uint32_t word = by == 0 ? bm.x : ( by == 1 ? bm.y : ( by == 2 ? bm.z : bm.w ) );
           const int mode = ( word >> ( 8 * bx ) ) & 0xFF;
           const uint32_t e = L.tab[mode * 16 + l];
-          const uint32_t d0 = *reinterpret_cast<const uint32_t *>( &S.E[0] ), d1 = *reinterpret_cast<const uint32_t *>( &S.E[4] ),
-                         d2 = *reinterpret_cast<const uint32_t *>( &S.E[8] );
-          const int dc = ( absdiff_sum4( d0 ) + absdiff_sum4( __builtin_amdgcn_alignbyte( d2, d1, 1 ) ) + 4 ) >> 3;
-          v = bpred_eval( e >> 24, S.E[e & 0xFF], S.E[( e >> 8 ) & 0xFF], S.E[( e >> 16 ) & 0xFF], dc );
+          // E[i] of vp8_math.hh straight from the tile: i < 4 the column to the left (bottom up), 4 the corner, 5..12 the row
+          // above -- of which 9..12 (above-right) come from the row above the MACROBLOCK in sub-block column 3
+          // (prediction.cc:153-160).  A sub-block's taps never lie inside the sub-block itself, so one barrier per step.
+          const uint8_t * const tile = &S.y[0][0];
+          auto tap = [&]( const int i ) -> int {
+            const bool left = i < 4;
+            const int trow = left ? ar + 4 - i : ( ( i >= 9 && bx == 3 ) ? 0 : ar );
+            return tile[trow * 48 + ac + ( left ? 0 : i - 4 )];
+          };
+          const int e0 = tap( e & 0xFF ), e1 = tap( ( e >> 8 ) & 0xFF ), e2 = tap( ( e >> 16 ) & 0xFF );
+          const uint32_t above4 = *reinterpret_cast<const uint32_t *>( &S.y[ar][ac + 1] );
+          const int dc = ( absdiff_sum4( above4 ) + S.y[ar + 1][ac] + S.y[ar + 2][ac] + S.y[ar + 3][ac] + S.y[ar + 4][ac] + 4 ) >> 3;
+          int v = bpred_eval( e >> 24, e0, e1, e2, dc );
           if ( has_res ) v = clamp255( v + S.res[b][l] );
           S.y[ar + 1 + ( l >> 2 )][ac + 1 + ( l & 3 )] = static_cast<uint8_t>( v );
         }
