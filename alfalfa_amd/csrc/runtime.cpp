@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -49,6 +50,7 @@ struct Chunk {
   uint8_t * dev = nullptr;
   size_t capacity = 0, used = 0, uploaded = 0;
   size_t pinned_bytes = 0;    // size of the host allocation (capacity shrinks to `used` when the chunk is sealed)
+  size_t dev_bytes = 0;       // size of the device piece
 };
 
 struct Slot {
@@ -85,6 +87,13 @@ struct aa_ctx {
   int xcd_share[AA_MAX_XCD] = {};
   std::mutex pool_mu;           // pinned staging chunks given back by aa_stream_release_staging, reused by later parses
   std::vector<std::pair<uint8_t *, size_t>> pinned_pool;
+  // Device memory of the streams (frame-store chunks, raster blocks) is carved out of 256-MiB slabs: allocation calls
+  // serialise in the driver and hundreds of parser threads make them at once.  Freed pieces go to per-size free lists
+  // (streams of one frame size all ask for the same two sizes); slabs are returned when the context dies.
+  std::vector<uint8_t *> dev_slabs;
+  uint8_t * cur_slab = nullptr;
+  size_t slab_used = 0;
+  std::map<size_t, std::vector<uint8_t *>> dev_free;
   uint8_t * boundary = nullptr; // loop filter: hand-off lines between macroblock rows (transient within a launch)
   size_t boundary_bytes = 0;
   aa_sync_ws * ws = nullptr;   // in-launch ordering state of the row-pipelined kernels
@@ -113,13 +122,42 @@ namespace {
 
 aa_status set_device( aa_ctx * ctx ) { HIP_TRY( hipSetDevice( ctx->device ) ); return AA_OK; }
 
+constexpr size_t kSlabBytes = size_t( 256 ) << 20;
+aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out )
+{
+  bytes = align_up( bytes );
+  std::lock_guard<std::mutex> g( ctx->pool_mu );
+  auto it = ctx->dev_free.find( bytes );
+  if ( it != ctx->dev_free.end() && !it->second.empty() ) { *out = it->second.back(); it->second.pop_back(); return AA_OK; }
+  if ( bytes > kSlabBytes / 2 ) {                 // big pieces get their own allocation (still recycled through the free list)
+    HIP_TRY( hipMalloc( reinterpret_cast<void **>( out ), bytes ) );
+    ctx->dev_slabs.push_back( *out );
+    return AA_OK;
+  }
+  if ( ctx->dev_slabs.empty() || ctx->slab_used + bytes > kSlabBytes ) {
+    uint8_t * slab = nullptr;
+    HIP_TRY( hipMalloc( reinterpret_cast<void **>( &slab ), kSlabBytes ) );
+    ctx->dev_slabs.push_back( slab ); ctx->slab_used = 0;
+    ctx->cur_slab = slab;
+  }
+  *out = ctx->cur_slab + ctx->slab_used;
+  ctx->slab_used += bytes;
+  return AA_OK;
+}
+void dev_free( aa_ctx * ctx, uint8_t * p, size_t bytes )
+{
+  if ( !p ) return;
+  std::lock_guard<std::mutex> g( ctx->pool_mu );
+  ctx->dev_free[align_up( bytes )].push_back( p );
+}
+
 aa_status alloc_slot( aa_stream * s, int * out )
 {
   for ( size_t i = 0; i < s->slots.size(); i++ ) if ( s->slots[i].refs == 0 ) { *out = static_cast<int>( i ); return AA_OK; }
   // rasters are allocated four at a time: allocation calls serialise in the driver, and parser threads of many streams
   // call this concurrently
   uint8_t * block = nullptr;
-  HIP_TRY( hipMalloc( reinterpret_cast<void **>( &block ), s->slot_bytes * kSlotBlock ) );
+  if ( aa_status st = dev_alloc( s->ctx, s->slot_bytes * kSlotBlock, &block ) ) return st;
   *out = static_cast<int>( s->slots.size() );
   for ( int k = 0; k < kSlotBlock; k++ ) { Slot sl; sl.dev = block + s->slot_bytes * k; sl.owns = k == 0; s->slots.push_back( sl ); }
   return AA_OK;
@@ -143,9 +181,8 @@ aa_status reserve( aa_stream * s, size_t bytes, Chunk ** out )
       for ( size_t i = 0; i < pool.size(); i++ ) if ( pool[i].second == c.capacity ) { c.host = pool[i].first; pool[i] = pool.back(); pool.pop_back(); break; }
     }
     if ( !c.host ) HIP_TRY( hipHostMalloc( reinterpret_cast<void **>( &c.host ), c.capacity, hipHostMallocDefault ) );
-    hipError_t e = hipMalloc( reinterpret_cast<void **>( &c.dev ), c.capacity );
-    if ( e != hipSuccess ) { (void) hipHostFree( c.host ); return hip_fail( e, "hipMalloc(frame store chunk)" ); }
-    c.pinned_bytes = c.capacity;
+    c.pinned_bytes = c.dev_bytes = c.capacity;
+    if ( aa_status st = dev_alloc( s->ctx, c.capacity, &c.dev ) ) { std::lock_guard<std::mutex> g( s->ctx->pool_mu ); s->ctx->pinned_pool.emplace_back( c.host, c.pinned_bytes ); return st; }
     s->chunks.push_back( c );
   }
   *out = &s->chunks.back();
@@ -356,6 +393,7 @@ static void ctx_free( aa_ctx * ctx )
   if ( ctx->ws ) (void) hipFree( ctx->ws );
   if ( ctx->boundary ) (void) hipFree( ctx->boundary );
   for ( auto & pc : ctx->pinned_pool ) (void) hipHostFree( pc.first );
+  for ( uint8_t * slab : ctx->dev_slabs ) (void) hipFree( slab );
   (void) hipStreamDestroy( ctx->compute ); (void) hipStreamDestroy( ctx->copy );
   delete ctx;
 }
@@ -427,8 +465,11 @@ void aa_stream_destroy( aa_stream * s )
   if ( !s ) return;
   (void) hipSetDevice( s->ctx->device );
   (void) hipStreamSynchronize( s->ctx->compute ); (void) hipStreamSynchronize( s->ctx->copy );
-  for ( auto & c : s->chunks ) { if ( c.host ) (void) hipHostFree( c.host ); (void) hipFree( c.dev ); }
-  for ( auto & sl : s->slots ) if ( sl.owns ) (void) hipFree( sl.dev );
+  for ( auto & c : s->chunks ) {
+    if ( c.host ) { std::lock_guard<std::mutex> g( s->ctx->pool_mu ); s->ctx->pinned_pool.emplace_back( c.host, c.pinned_bytes ); }
+    dev_free( s->ctx, c.dev, c.dev_bytes );
+  }
+  for ( auto & sl : s->slots ) if ( sl.owns ) dev_free( s->ctx, sl.dev, s->slot_bytes * kSlotBlock );
   aa_ctx * ctx = s->ctx;
   delete s;
   if ( --ctx->live_streams == 0 && ctx->dying ) ctx_free( ctx );
@@ -642,7 +683,6 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
         if ( need > ctx->boundary_bytes ) {
           HIP_TRY( hipStreamSynchronize( ctx->compute ) );
           if ( ctx->boundary ) (void) hipFree( ctx->boundary );
-  for ( auto & pc : ctx->pinned_pool ) (void) hipHostFree( pc.first );
           ctx->boundary = nullptr; ctx->boundary_bytes = 0;
           HIP_TRY( hipMalloc( reinterpret_cast<void **>( &ctx->boundary ), need ) );
           ctx->boundary_bytes = need;
