@@ -27,7 +27,7 @@ struct aa_dev_frame {
 // In-launch ordering state of the row-pipelined kernels; zeroed (hipMemsetAsync) before every such launch.
 struct aa_sync_ws {
   int error;                   // != 0: a bounded spin expired (sticky; reported as AA_ERR_HIP by the host).  NOT zeroed per launch.
-  int pad0[3];
+  int where[3];                // diagnostics of the FIRST expired wait: unit, row, need << 16 | seen
   int ticket[AA_MAX_XCD];      // per-XCD queue: next (unit,row) to hand out  -- zeroed from here on before every launch
   int progress[1];             // [unit in launch][mbh_max]: macroblock columns of that row that are final
 };

@@ -769,7 +769,7 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
         if ( on && seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
         ++spins;
         if ( ( spins & 1023 ) == 0 && __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
-        if ( spins > ( 1 << 21 ) ) { atomicExch( &ws->error, 1 ); break; }
+        if ( spins > ( 1 << 21 ) ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 1 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( need << 16 ) | ( seen & 0xFFFF ); } break; }
       }
     }
     const int x0 = col * 16, cx0 = col * 8;
@@ -1159,7 +1159,7 @@ __device__ __forceinline__ void lf_edges_pk( pk2 ( &v )[20], const LfParamsPk & 
 // bnd: boundary buffer, 128 bytes per (frame of the launch, MB row, MB column): luma rows 12..15 x 16 B, U rows 4..7 x 8 B,
 // V rows 4..7 x 8 B of that macroblock after its own filtering.
 __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list, const int group, const int row, const int mbh_max, const int mbw_max,
-                                                       aa_sync_ws * ws, uint8_t * bnd, LfStripLds & S, const int dbg )
+                                                       aa_sync_ws * ws, uint8_t * bnd, LfStripLds & S, const int dbg, const int home_xcc )
 {
   const int lane = threadIdx.x, slot = lane >> 4, l = lane & 15;
   const aa_dev_frame & f0 = *list.f[group * 4];
@@ -1296,8 +1296,13 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
           __builtin_amdgcn_s_sleep( 4 );
           if ( seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
           ++spins;
-          if ( ( spins & 1023 ) == 0 && __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
-          if ( spins > ( 1 << 21 ) ) { atomicExch( &ws->error, 2 ); break; }
+          if ( ( spins & 1023 ) == 0 ) {
+            if ( __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
+            // the hand-off is only coherent inside one XCD: a wave that finds itself on another one (context save / restore
+            // under queue oversubscription) says so instead of waiting for the watchdog
+            if ( xcc_id() != home_xcc ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 4 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( home_xcc << 16 ) | xcc_id(); } break; }
+          }
+          if ( spins > ( 1 << 21 ) ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 2 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( need << 16 ) | ( seen & 0xFFFF ); } break; }
         }
         // rows -4..-1: the boundary line the row above left for this macroblock (sc1: bypass L1, served by the XCD's L2)
         if ( frame_on && l < 8 && !( dbg & 8 ) ) {
@@ -1383,7 +1388,7 @@ __device__ __forceinline__ void loopfilter_rows4_body( const aa_frame_list & lis
     const int t = take_ticket( ws, xcc, &s_ticket, threadIdx.x );
     const int mine = xcc < n_groups ? ( n_groups - xcc + n_xcd - 1 ) / n_xcd : 0;     // groups of this XCD: xcc, xcc + n_xcd, ...
     if ( t >= mine * mbh_max ) return;
-    loopfilter_strip_row( list, ( t % mine ) * n_xcd + xcc, t / mine, mbh_max, mbw_max, ws, bnd, S, dbg );    // ROW-major: see take_ticket
+    loopfilter_strip_row( list, ( t % mine ) * n_xcd + xcc, t / mine, mbh_max, mbw_max, ws, bnd, S, dbg, xcc );    // ROW-major: see take_ticket
   }
 }
 

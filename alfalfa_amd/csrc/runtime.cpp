@@ -403,8 +403,23 @@ static aa_status check_watchdog( aa_ctx * ctx )
   int err = 0;
   HIP_TRY( hipMemcpy( &err, &ctx->ws->error, sizeof err, hipMemcpyDeviceToHost ) );
   if ( err == 3 ) return fail( AA_ERR_HIP, "row-pipelined kernel: a workgroup ran on an XCD outside the probed set (output is not valid)" );
-  if ( err ) return fail( AA_ERR_HIP, std::string( "row-pipelined kernel " ) + ( err == 1 ? "k_recon_intra4" : "k_loopfilter_rows4" )
-                                      + ": a bounded wait for the macroblock row above expired (output is not valid)" );
+  if ( err == 4 ) {
+    int hdr[4] = {};
+    (void) hipMemcpy( hdr, ctx->ws, sizeof hdr, hipMemcpyDeviceToHost );
+    return fail( AA_ERR_HIP, "row-pipelined kernel: a wave of unit " + std::to_string( hdr[1] ) + " row " + std::to_string( hdr[2] ) + " moved from XCD "
+                               + std::to_string( hdr[3] >> 16 ) + " to XCD " + std::to_string( hdr[3] & 0xFFFF ) + " (context save/restore under queue oversubscription?): "
+                               "the in-launch hand-off is only coherent inside one XCD (output is not valid)" );
+  }
+  if ( err ) {
+    int hdr[4 + AA_MAX_XCD] = {};
+    (void) hipMemcpy( hdr, ctx->ws, sizeof hdr, hipMemcpyDeviceToHost );
+    std::string tickets;
+    for ( int x = 0; x < ctx->n_xcd; x++ ) tickets += ( x ? "," : "" ) + std::to_string( hdr[4 + x] );
+    return fail( AA_ERR_HIP, std::string( "row-pipelined kernel " ) + ( err == 1 ? "k_recon_intra4" : "k_loopfilter_rows4" )
+                               + ": a bounded wait for the macroblock row above expired (output is not valid); first at unit " + std::to_string( hdr[1] )
+                               + " row " + std::to_string( hdr[2] ) + ", needed " + std::to_string( hdr[3] >> 16 ) + " saw " + std::to_string( hdr[3] & 0xFFFF )
+                               + "; tickets handed out per XCD (last launch): " + tickets );
+  }
   return AA_OK;
 }
 aa_status aa_ctx_sync( aa_ctx * ctx )
