@@ -40,6 +40,16 @@ for i, fr in enumerate(frames):
     if i: hs.update(mb.tobytes()); hs.update(cf.tobytes())
 assert hh.digest() == hs.digest(), "continuation differs from straight parse"
 assert sharding.digests_agree(dist, hh.digest())
+# the same hand-off in the REFERENCE's wire format (DecoderState::serialize, what a reference-built rank would send)
+wire = b""
+if rank == 0:
+    wire = head.serialize_state()
+wire = sharding.broadcast_bytes(dist, wire, 0)
+cont2 = aa.Parser(w, h); cont2.deserialize_state(wire)
+h2 = hashlib.sha256()
+for fr in frames[1:]:
+    hdr, mb, cf = cont2.parse(fr); h2.update(mb.tobytes()); h2.update(cf.tobytes())
+assert h2.digest() == hs.digest(), "continuation from the reference-format state differs"
 dist.barrier(); dist.destroy_process_group()
 open(os.path.join(sys.argv[2], "rank%d.ok" % rank), "w").write("ok")
 '''
