@@ -838,20 +838,19 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
         if ( bp ) {
           const uint32_t word = by == 0 ? bm.x : ( by == 1 ? bm.y : ( by == 2 ? bm.z : bm.w ) );
           const int mode = ( word >> ( 8 * bx ) ) & 0xFF;
+          // L.tab: bpred_entry with each E index already turned into a tile offset from (row -1, col -1) of the sub-block:
+          // i < 4 the column to the left (bottom up), 4 the corner, 5..12 the row above -- of which 9..12 (above-right,
+          // flag bit) come from the row above the MACROBLOCK in sub-block column 3 (prediction.cc:153-160).  A sub-block's
+          // taps never lie inside the sub-block itself, so one barrier per step.
           const uint32_t e = L.tab[mode * 16 + l];
-          // E[i] of vp8_math.hh straight from the tile: i < 4 the column to the left (bottom up), 4 the corner, 5..12 the row
-          // above -- of which 9..12 (above-right) come from the row above the MACROBLOCK in sub-block column 3
-          // (prediction.cc:153-160).  A sub-block's taps never lie inside the sub-block itself, so one barrier per step.
-          const uint8_t * const tile = &S.y[0][0];
-          auto tap = [&]( const int i ) -> int {
-            const bool left = i < 4;
-            const int trow = left ? ar + 4 - i : ( ( i >= 9 && bx == 3 ) ? 0 : ar );
-            return tile[trow * 48 + ac + ( left ? 0 : i - 4 )];
-          };
-          const int e0 = tap( e & 0xFF ), e1 = tap( ( e >> 8 ) & 0xFF ), e2 = tap( ( e >> 16 ) & 0xFF );
+          const uint8_t * const org = &S.y[ar][ac];
+          const int lift = bx == 3 ? ar * 48 : 0;
+          const int e0 = org[static_cast<int>( e & 0xFF ) - ( ( e >> 24 ) & 1 ? lift : 0 )];
+          const int e1 = org[static_cast<int>( ( e >> 8 ) & 0xFF ) - ( ( e >> 25 ) & 1 ? lift : 0 )];
+          const int e2 = org[static_cast<int>( ( e >> 16 ) & 0xFF ) - ( ( e >> 26 ) & 1 ? lift : 0 )];
           const uint32_t above4 = *reinterpret_cast<const uint32_t *>( &S.y[ar][ac + 1] );
           const int dc = ( absdiff_sum4( above4 ) + S.y[ar + 1][ac] + S.y[ar + 2][ac] + S.y[ar + 3][ac] + S.y[ar + 4][ac] + 4 ) >> 3;
-          int v = bpred_eval( e >> 24, e0, e1, e2, dc );
+          int v = bpred_eval( e >> 27, e0, e1, e2, dc );
           if ( has_res ) v = clamp255( v + S.res[b][l] );
           S.y[ar + 1 + ( l >> 2 )][ac + 1 + ( l & 3 )] = static_cast<uint8_t>( v );
         }
@@ -869,7 +868,16 @@ __global__ __launch_bounds__( kLanes ) void k_recon_intra4( const aa_frame_list 
 {
   __shared__ Intra4Lds L;
   __shared__ int s_ticket;
-  for ( int i = threadIdx.x; i < 160; i += kLanes ) L.tab[i] = bpred_entry( i >> 4, i & 3, ( i >> 2 ) & 3 );
+  for ( int i = threadIdx.x; i < 160; i += kLanes ) {       // (mode, pixel) -> three tile offsets, above-right flags, kind
+    const uint32_t e = bpred_entry( i >> 4, i & 3, ( i >> 2 ) & 3 );
+    uint32_t packed = ( e >> 24 ) << 27;
+    for ( int k = 0; k < 3; k++ ) {
+      const uint32_t idx = ( e >> ( 8 * k ) ) & 0xFF;
+      packed |= ( idx < 4 ? ( 4 - idx ) * 48 : idx - 4 ) << ( 8 * k );
+      packed |= ( idx >= 9 ? 1u : 0u ) << ( 24 + k );
+    }
+    L.tab[i] = packed;
+  }
   const int xcc = xcc_id();
   if ( xcc >= n_xcd ) { if ( threadIdx.x == 0 ) atomicExch( &ws->error, 3 ); return; }
   for ( ;; ) {
