@@ -831,7 +831,7 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
     }
     // ---- luma B_PRED: 16 sub-blocks in raster order, lane = pixel (macroblock.cc:541-544) ----
     if ( __any( bp ) ) {
-#pragma unroll 1
+#pragma unroll                // sub-block position known at compile time: mode byte, tile addresses and the column-3 rule fold away
       for ( int b = 0; b < 16; b++ ) {
         const int bx = b & 3, by = b >> 2;
         const int ar = by * 4, ac = bx * 4 + 15;          // tile position of (row -1, col -1) of this sub-block
