@@ -9,14 +9,14 @@ import pytest
 from conftest import GOLDEN, GOLDEN_DIR, ROOT
 
 BUILD = os.path.join(ROOT, "tests", "cpp", "_build")
-EXE = os.path.join(BUILD, "decode_to_stdout")
+EXE = os.path.join(BUILD, "dump_shown_frames")
 
 
-def build_exe(src=None, name="decode_to_stdout"):
+def build_exe(src=None, name="dump_shown_frames"):
     from alfalfa_amd import build as b
     b.build()
     os.makedirs(BUILD, exist_ok=True)
-    src = src or os.path.join(ROOT, "tests", "cpp", "decode_to_stdout.cc")
+    src = src or os.path.join(ROOT, "tests", "cpp", "dump_shown_frames.cc")
     exe = os.path.join(BUILD, name)
     hdr = os.path.join(ROOT, "include", "alfalfa_amd", "alfalfa.hh")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(b.LIB)):
@@ -64,23 +64,23 @@ def test_decode_to_stdout_sha1_matches_reference(name):
 
 def test_frontend_ports_build_and_fail_loudly_without_gpu(tmp_path):
     from alfalfa_amd import capi
-    for name in ("vp8decode", "decode_many"):
+    for name in ("ivf_to_y4m", "decode_many"):
         exe = build_example(name)
         r = subprocess.run([exe], capture_output=True)
         assert r.returncode != 0 and b"Usage" in r.stderr
-    r = subprocess.run([build_example("xc_decode_bundle"), "a", "b"], capture_output=True)
+    r = subprocess.run([build_example("decode_chain"), "a", "b"], capture_output=True)
     assert r.returncode != 0 and b"Usage" in r.stderr
     if capi.device_count() == 0:
-        r = subprocess.run([build_example("vp8decode"), "-o", str(tmp_path / "o.y4m"), os.path.join(GOLDEN_DIR, "qcif_q30.ivf")], capture_output=True)
+        r = subprocess.run([build_example("ivf_to_y4m"), "-o", str(tmp_path / "o.y4m"), os.path.join(GOLDEN_DIR, "qcif_q30.ivf")], capture_output=True)
         assert r.returncode != 0 and b"no HIP device" in r.stderr
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["qcif_q30_lf24", "w200_q40_lf63s7", "synth_175x143_s3"])
-def test_vp8decode_y4m_matches_reference_dump(tmp_path, name):
+def test_ivf_to_y4m_matches_reference_dump(tmp_path, name):
     """frontend/vp8decode.cc port: `-o out.y4m` = header + FRAME-delimited display rectangles of the shown frames."""
     out = tmp_path / "o.y4m"
-    subprocess.run([build_example("vp8decode"), "-o", str(out), os.path.join(GOLDEN_DIR, name + ".ivf")], check=True)
+    subprocess.run([build_example("ivf_to_y4m"), "-o", str(out), os.path.join(GOLDEN_DIR, name + ".ivf")], check=True)
     assert hashlib.sha1(y4m_payload(out.read_bytes(), name)).hexdigest() == GOLDEN[name]["display_sha1"]
 
 
@@ -102,7 +102,7 @@ def _write_ivf(path, name, frames):
 
 
 @pytest.mark.gpu
-def test_xc_decode_bundle_carries_one_decoder_across_files(tmp_path):
+def test_decode_chain_carries_one_decoder_across_files(tmp_path):
     """frontend/decode-bundle.cc port: a stream cut into three IVF pieces, names on stdin, one YUV4MPEG2 video on stdout."""
     from conftest import golden_frames
     name = "w200_q40_lf63s7"
@@ -112,12 +112,12 @@ def test_xc_decode_bundle_carries_one_decoder_across_files(tmp_path):
     for a, b in cuts:
         paths.append(str(tmp_path / ("piece_%d.ivf" % a)))
         _write_ivf(paths[-1], name, frames[a:b])
-    r = subprocess.run([build_example("xc_decode_bundle")], input=("\n".join(paths) + "\n").encode(), capture_output=True, check=True)
+    r = subprocess.run([build_example("decode_chain")], input=("\n".join(paths) + "\n").encode(), capture_output=True, check=True)
     assert hashlib.sha1(y4m_payload(r.stdout, name)).hexdigest() == GOLDEN[name]["display_sha1"]
 
 
 @pytest.mark.gpu
-def test_vp8decode_resumes_from_a_state_file_written_by_the_reference(tmp_path):
+def test_ivf_to_y4m_resumes_from_a_state_file_written_by_the_reference(tmp_path):
     """`vp8decode -s state` (EncoderStateDeserializer::build<Player>): the fixture was written by the reference after 3 frames."""
     from conftest import golden_frames
     name, n = "qcif_q30_lf24", 3
@@ -125,7 +125,7 @@ def test_vp8decode_resumes_from_a_state_file_written_by_the_reference(tmp_path):
     whole, rest = str(tmp_path / "whole.y4m"), str(tmp_path / "rest.y4m")
     cont = str(tmp_path / "cont.ivf")
     _write_ivf(cont, name, frames[n:])
-    exe = build_example("vp8decode")
+    exe = build_example("ivf_to_y4m")
     subprocess.run([exe, "-o", whole, os.path.join(GOLDEN_DIR, name + ".ivf")], check=True)
     subprocess.run([exe, "-s", os.path.join(GOLDEN_DIR, "%s_f%d.state" % (name, n)), "-o", rest, cont], check=True)
     full, tail = y4m_payload(open(whole, "rb").read(), name), y4m_payload(open(rest, "rb").read(), name)
