@@ -1047,39 +1047,60 @@ __device__ __forceinline__ void recon_inter4_body( const aa_dev_frame & f, const
     const uint32_t e0 = q ? a.y : a.x, e1 = q ? b.x : a.y, e2 = q ? b.y : b.x;
     *reinterpret_cast<uint2 *>( S.pred + 256 + pl * 64 + r * 8 ) = make_uint2( __builtin_amdgcn_alignbyte( e1, e0, sft ), __builtin_amdgcn_alignbyte( e2, e1, sft ) );
   }
-  // ---- horizontal pass: 84 luma + 52 chroma tasks of four outputs; results to the transposed buffers t[column][row] ----
-  if ( on && ( luma_general || chroma_general ) ) {
-    const int t_end = chroma_general ? 136 : 84;
-#pragma unroll 1
-    for ( int t = ( luma_general ? 0 : 84 ) + l; t < t_end; t += 16 ) {
-      const bool lu = t < 84;
-      const int j = t - 84, pl = j >= 26 ? 1 : 0, e = j - 26 * pl;
-      const int r = lu ? t >> 2 : e >> 1, g = lu ? t & 3 : e & 1;
-      const uint8_t * sp = lu ? wyb + r * 24 + g * 4 : wcb + pl * 208 + r * 16 + g * 4;
-      const int frac = lu ? mvx & 7 : cmx & 7;
-      const uint32_t o4 = sixtap_x4_lane( *reinterpret_cast<const uint32_t *>( sp ), *reinterpret_cast<const uint32_t *>( sp + 4 ), *reinterpret_cast<const uint32_t *>( sp + 8 ),
-                                          lu ? oy : oc, frac, L.taps[2 * frac], L.taps[2 * frac + 1] );
-      uint8_t * tb = lu ? tyb + ( g * 4 ) * 24 + r : tcb + pl * 128 + ( g * 4 ) * 16 + r;
-      const int ts = lu ? 24 : 16;
-      tb[0] = static_cast<uint8_t>( o4 ); tb[ts] = static_cast<uint8_t>( o4 >> 8 ); tb[2 * ts] = static_cast<uint8_t>( o4 >> 16 ); tb[3 * ts] = static_cast<uint8_t>( o4 >> 24 );
+  // ---- horizontal pass: 84 luma + 52 chroma tasks of four outputs; results to the transposed buffers t[column][row].
+  //      Two unrolled task lists (instead of one 136-task loop) so that plane, strides and tap registers are compile-time ----
+  if ( on && luma_general ) {
+    const int frac = mvx & 7;
+    const uint32_t t0 = L.taps[2 * frac], t1 = L.taps[2 * frac + 1];
+#pragma unroll
+    for ( int k = 0; k < 6; k++ ) {
+      const int t = l + 16 * k;
+      if ( k == 5 && t >= 84 ) continue;
+      const int r = t >> 2, g = t & 3;
+      const uint8_t * sp = wyb + r * 24 + g * 4;
+      const uint32_t o4 = sixtap_x4_lane( *reinterpret_cast<const uint32_t *>( sp ), *reinterpret_cast<const uint32_t *>( sp + 4 ), *reinterpret_cast<const uint32_t *>( sp + 8 ), oy, frac, t0, t1 );
+      uint8_t * tb = tyb + ( g * 4 ) * 24 + r;
+      tb[0] = static_cast<uint8_t>( o4 ); tb[24] = static_cast<uint8_t>( o4 >> 8 ); tb[48] = static_cast<uint8_t>( o4 >> 16 ); tb[72] = static_cast<uint8_t>( o4 >> 24 );
+    }
+  }
+  if ( on && chroma_general ) {
+    const int frac = cmx & 7;
+    const uint32_t t0 = L.taps[2 * frac], t1 = L.taps[2 * frac + 1];
+#pragma unroll
+    for ( int k = 0; k < 4; k++ ) {
+      const int j = l + 16 * k;
+      if ( k == 3 && j >= 52 ) continue;
+      const int pl = j >= 26 ? 1 : 0, e = j - 26 * pl, r = e >> 1, g = e & 1;
+      const uint8_t * sp = wcb + pl * 208 + r * 16 + g * 4;
+      const uint32_t o4 = sixtap_x4_lane( *reinterpret_cast<const uint32_t *>( sp ), *reinterpret_cast<const uint32_t *>( sp + 4 ), *reinterpret_cast<const uint32_t *>( sp + 8 ), oc, frac, t0, t1 );
+      uint8_t * tb = tcb + pl * 128 + ( g * 4 ) * 16 + r;
+      tb[0] = static_cast<uint8_t>( o4 ); tb[16] = static_cast<uint8_t>( o4 >> 8 ); tb[32] = static_cast<uint8_t>( o4 >> 16 ); tb[48] = static_cast<uint8_t>( o4 >> 24 );
     }
   }
   __syncthreads();
   // ---- vertical pass: 64 luma + 32 chroma tasks: (column c, row group i) -> rows 4i..4i+3 of column c ----
-  if ( on ) {
+  if ( on && luma_general ) {
+    const int frac = mvy & 7;
+    const uint32_t t0 = L.taps[2 * frac], t1 = L.taps[2 * frac + 1];
 #pragma unroll
-    for ( int k = 0; k < 6; k++ ) {
-      const bool lu = k < 4;
-      if ( lu ? !luma_general : !chroma_general ) continue;
-      const int t = l + 16 * k;
-      const int j = t - 64, pl = j >> 4, c = lu ? t >> 2 : ( j >> 1 ) & 7, i = lu ? t & 3 : j & 1;
-      const uint8_t * sp = lu ? tyb + c * 24 + i * 4 : tcb + pl * 128 + c * 16 + i * 4;
-      const int frac = lu ? mvy & 7 : cmy & 7;
-      const uint32_t o4 = sixtap_x4_lane( *reinterpret_cast<const uint32_t *>( sp ), *reinterpret_cast<const uint32_t *>( sp + 4 ), *reinterpret_cast<const uint32_t *>( sp + 8 ),
-                                          0, frac, L.taps[2 * frac], L.taps[2 * frac + 1] );
-      uint8_t * pb = lu ? S.pred + ( i * 4 ) * 16 + c : S.pred + 256 + pl * 64 + ( i * 4 ) * 8 + c;
-      const int ps = lu ? 16 : 8;
-      pb[0] = static_cast<uint8_t>( o4 ); pb[ps] = static_cast<uint8_t>( o4 >> 8 ); pb[2 * ps] = static_cast<uint8_t>( o4 >> 16 ); pb[3 * ps] = static_cast<uint8_t>( o4 >> 24 );
+    for ( int k = 0; k < 4; k++ ) {
+      const int t = l + 16 * k, c = t >> 2, i = t & 3;
+      const uint8_t * sp = tyb + c * 24 + i * 4;
+      const uint32_t o4 = sixtap_x4_lane( *reinterpret_cast<const uint32_t *>( sp ), *reinterpret_cast<const uint32_t *>( sp + 4 ), *reinterpret_cast<const uint32_t *>( sp + 8 ), 0, frac, t0, t1 );
+      uint8_t * pb = S.pred + ( i * 4 ) * 16 + c;
+      pb[0] = static_cast<uint8_t>( o4 ); pb[16] = static_cast<uint8_t>( o4 >> 8 ); pb[32] = static_cast<uint8_t>( o4 >> 16 ); pb[48] = static_cast<uint8_t>( o4 >> 24 );
+    }
+  }
+  if ( on && chroma_general ) {
+    const int frac = cmy & 7;
+    const uint32_t t0 = L.taps[2 * frac], t1 = L.taps[2 * frac + 1];
+#pragma unroll
+    for ( int k = 0; k < 2; k++ ) {
+      const int j = l + 16 * k, pl = j >> 4, c = ( j >> 1 ) & 7, i = j & 1;
+      const uint8_t * sp = tcb + pl * 128 + c * 16 + i * 4;
+      const uint32_t o4 = sixtap_x4_lane( *reinterpret_cast<const uint32_t *>( sp ), *reinterpret_cast<const uint32_t *>( sp + 4 ), *reinterpret_cast<const uint32_t *>( sp + 8 ), 0, frac, t0, t1 );
+      uint8_t * pb = S.pred + 256 + pl * 64 + ( i * 4 ) * 8 + c;
+      pb[0] = static_cast<uint8_t>( o4 ); pb[8] = static_cast<uint8_t>( o4 >> 8 ); pb[16] = static_cast<uint8_t>( o4 >> 16 ); pb[24] = static_cast<uint8_t>( o4 >> 24 );
     }
   }
   __syncthreads();
