@@ -1257,6 +1257,8 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
   prefetch( 0 );
   int info = frame_on ? *reinterpret_cast<const uint16_t *>( &mbrow[0].flags ) : 0;     // flags | lf_level << 8
   int seen = row > 0 ? 0 : mbw;        // boundary lines of the row above known to be complete
+  LfParamsPk P = lf_params_pk( lf_params( 1, sharp, key ) );
+  int p_level = -1;                    // the level P was computed for
   for ( int s = 0; s < n_strips; s++ ) {
     const int nmb = min( kStripMbs, mbw - s * kStripMbs );
     // ---- strip turn-over: keep the right edge as the new left neighbour, then drop the prefetched rows in ----
@@ -1283,7 +1285,7 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
       // progress only grows: what an earlier poll saw stays valid, so a row that runs well behind the row above polls rarely
       if ( row > 0 && seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
       const bool any_active = __any( active );
-      const LfParamsPk P = lf_params_pk( lf_params( active ? level : 1, sharp, key ) );
+      if ( !__all( level == p_level ) ) { P = lf_params_pk( lf_params( active ? level : 1, sharp, key ) ); p_level = level; }     // levels rarely change along a row
       const pk2 g_on = active ? ~0u : 0u, g_in = ( active && inner ) ? ~0u : 0u, g_in23 = ( active && inner && luma ) ? ~0u : 0u;
 
       if ( any_active && !( dbg & 4 ) ) {   // ---- V phase: left MB edge, inner vertical edges ----
