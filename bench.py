@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 BYTES_PER_MB = {"recon_inter": 80 + 800 + 384 + 384, "recon_intra": 80 + 800 + 384, "loopfilter": 768}
 PATH_BYTES_PER_MB = 2416       # inter + deblock, whole path
 # HBM bytes per macroblock measured with rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KiB -> bytes, per launch / MBs per launch),
-# profiles/r01i_kernels.md; used for roofline.traffic (counters cannot be read from inside this process)
+# profiles/r01j_kernels.md; used for roofline.traffic (counters cannot be read from inside this process)
 PMC_TRAFFIC_BYTES_PER_MB = {"recon_inter": 497 + 404, "loopfilter": 356 + 649, "recon_intra": None}
 KERNEL_NAMES = {"rows": {"recon_inter": "k_recon_inter4", "recon_intra": "k_recon_intra4", "loopfilter": "k_loopfilter_rows4"},
                 "diagonal": {"recon_inter": "k_recon_inter", "recon_intra": "k_recon_intra", "loopfilter": "k_loopfilter"}}
@@ -225,7 +225,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": KERNEL_NAMES[args.schedule][dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": None if traffic is None else round(traffic * mbs_total / launches),
-                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r01i_kernels.md (bytes per launch)",
+                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r01j_kernels.md (bytes per launch)",
                     "avg_launch_us": round(avg_ms * 1e3, 3), "launches_per_step": launches,
                     "algorithmic_bytes_per_launch": round(bytes_per_launch),
                     "path_frac_of_hbm_peak": round(value / world * PATH_BYTES_PER_MB / (HBM_PEAK_GBS * 1e9), 5)}
