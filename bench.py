@@ -32,7 +32,7 @@ BYTES_PER_MB = {"recon_inter": 80 + 800 + 384 + 384, "recon_intra": 80 + 800 + 3
 PATH_BYTES_PER_MB = 2416       # inter + deblock, whole path
 # HBM bytes per macroblock measured with rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KiB -> bytes, per launch / MBs per launch),
 # profiles/r01j_kernels.md; used for roofline.traffic (counters cannot be read from inside this process)
-PMC_TRAFFIC_BYTES_PER_MB = {"recon_inter": 497 + 404, "loopfilter": 356 + 649, "recon_intra": None}
+PMC_TRAFFIC_BYTES_PER_MB = {"recon_inter": 497 + 407, "loopfilter": 356 + 653, "recon_intra": None}
 KERNEL_NAMES = {"rows": {"recon_inter": "k_recon_inter4", "recon_intra": "k_recon_intra4", "loopfilter": "k_loopfilter_rows4"},
                 "diagonal": {"recon_inter": "k_recon_inter", "recon_intra": "k_recon_intra", "loopfilter": "k_loopfilter"}}
 
