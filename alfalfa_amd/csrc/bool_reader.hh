@@ -8,10 +8,13 @@
 #include <cstddef>
 #include <cstdint>
 
+#include "parse_common.hh"
+
 namespace aa {
 
 class BoolReader
 {
+  const uint8_t * begin_ = nullptr;
   const uint8_t * p_ = nullptr;
   const uint8_t * end_ = nullptr;
   uint64_t value_ = 0;   // window, most significant bits first
@@ -38,8 +41,20 @@ public:
 
   void reset( const uint8_t * data, size_t size )
   {
-    p_ = data; end_ = data + size; value_ = 0; count_ = -8; range_ = 255;
+    begin_ = p_ = data; end_ = data + size; value_ = 0; count_ = -8; range_ = 255;
     fill();
+  }
+
+  // Window-independent form of the current state (parse_common.hh): a reader of any window width, e.g. a GPU lane,
+  // continues from it and returns the same bits.
+  BoolState state() const
+  {
+    const int real = count_ >= kLotsOfBits / 2 ? count_ - kLotsOfBits : count_;   // valid bits below the active byte
+    BoolState st;
+    st.bitpos = static_cast<uint32_t>( 8 * ( p_ - begin_ ) - real );
+    st.range = static_cast<uint8_t>( range_ );
+    st.active = static_cast<uint8_t>( value_ >> ( kWindow - 8 ) );
+    return st;
   }
 
   inline int get( const uint32_t prob )

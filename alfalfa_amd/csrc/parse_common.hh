@@ -1,0 +1,340 @@
+// Macroblock-header parse shared by the host parser (parser.cpp) and the device parser (parse_kernels.hip).
+//
+// One implementation of what the reference does in the Macroblock constructor and decode_prediction_modes
+// (macroblock.cc:43-111,342-456), the motion-vector census (scorer.hh, macroblock.cc:143-195,301-312), MotionVector
+// reading (macroblock.cc:198-229,283-287), split-MV sub-block prediction (macroblock.cc:231-281) and the per-macroblock
+// loop-filter level (frame.cc:144-166, macroblock.cc:611-623, loopfilter.cc:59-79), templated on the boolean decoder so
+// that the same statements run on a host core (64-bit window, bool_reader.hh) and in a GPU lane (32-bit window below).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/alfalfa_amd.h"
+#include "vp8_tables.h"
+
+#if defined( __HIPCC__ )
+#define AA_HD __host__ __device__
+#else
+#define AA_HD
+#endif
+
+namespace aa {
+
+enum MbMode : uint8_t { DC_PRED, V_PRED, H_PRED, TM_PRED, B_PRED, NEARESTMV, NEARMV, ZEROMV, NEWMV, SPLITMV };
+enum BMode : uint8_t { B_DC_PRED, B_TM_PRED, B_VE_PRED, B_HE_PRED, B_LD_PRED, B_RD_PRED, B_VR_PRED, B_VL_PRED,
+                       B_HD_PRED, B_HU_PRED, LEFT4X4, ABOVE4X4, ZERO4X4, NEW4X4 };
+enum RefFrame : uint8_t { CURRENT_FRAME, LAST_FRAME, GOLDEN_FRAME, ALTREF_FRAME };
+enum BlockType { Y_AFTER_Y2 = 0, Y2 = 1, UV = 2, Y_WITHOUT_Y2 = 3 };   // block.hh:46
+
+// RFC 6386 trees as in modemv_data.cc:162-281 (leaves stored as -value, inner nodes as positive even indices)
+constexpr int8_t kKfYModeTree[8] = { -B_PRED, 2, 4, 6, -DC_PRED, -V_PRED, -H_PRED, -TM_PRED };
+constexpr int8_t kYModeTree[8] = { -DC_PRED, 2, 4, 6, -V_PRED, -H_PRED, -TM_PRED, -B_PRED };
+constexpr int8_t kUvModeTree[6] = { -DC_PRED, 2, -V_PRED, 4, -H_PRED, -TM_PRED };
+constexpr int8_t kBModeTree[18] = { -B_DC_PRED, 2, -B_TM_PRED, 4, -B_VE_PRED, 6, 8, 12, -B_HE_PRED, 10,
+                                    -B_RD_PRED, -B_VR_PRED, -B_LD_PRED, 14, -B_VL_PRED, 16, -B_HD_PRED, -B_HU_PRED };
+constexpr int8_t kSmallMvTree[14] = { 2, 8, 4, 6, -0, -1, -2, -3, 10, 12, -4, -5, -6, -7 };
+constexpr int8_t kMvRefTree[8] = { -ZEROMV, 2, -NEARESTMV, 4, -NEARMV, 6, -NEWMV, -SPLITMV };
+constexpr int8_t kSubMvRefTree[6] = { -LEFT4X4, 2, -ABOVE4X4, 4, -ZERO4X4, -NEW4X4 };
+constexpr int8_t kSplitMvTree[6] = { -3, 2, -2, 4, -0, -1 };
+constexpr int8_t kSegmentIdTree[6] = { 2, 4, -0, -1, -2, -3 };
+
+constexpr uint8_t kZigzag[16] = { 0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15 };
+constexpr uint8_t kBand[17] = { 0, 1, 2, 3, 6, 4, 5, 6, 6, 6, 6, 6, 6, 6, 6, 7, 0 };
+
+// mv_partitions (modemv_data.cc:245-276): partition index of each raster-order sub-block
+constexpr uint8_t kSplitLayout[4][16] = { { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1 },
+                                          { 0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1, 1 },
+                                          { 0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3 },
+                                          { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15 } };
+constexpr uint8_t kSplitFirst[4][16] = { { 0, 8 }, { 0, 2 }, { 0, 2, 8, 10 }, { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15 } };
+constexpr uint8_t kSplitCount[4] = { 2, 2, 4, 16 };
+
+// Everything the macroblock loop of one frame needs that is decided by the frame header and the persistent DecoderState
+// (decoder_state.hh:72-167).  Written by the host header pre-pass (Parser::parse_header); read by the host macroblock loop
+// or, unchanged, by the device parse kernels (one record per frame in HBM).  Plain data, no pointers.
+struct FrameParams {
+  uint32_t first_off, first_size;        // first partition: byte range inside the frame (uncompressed_chunk.cc:117-130)
+  uint32_t bd_bitpos;                    // boolean decoder hand-over at the first macroblock header (see BoolState)
+  uint8_t bd_range, bd_active;
+  uint8_t key, nparts;
+  uint32_t part_off[8], part_size[8];    // DCT partitions (uncompressed_chunk.cc:132-155)
+  uint16_t mbw, mbh;
+  uint8_t seg_enabled, seg_update_map, seg_tree_probs[3];
+  uint8_t skip_enabled, prob_skip, prob_inter, prob_last, prob_golden;
+  uint8_t sign_bias_golden, sign_bias_alt;
+  uint8_t loop_filter_level, fadj_enabled;
+  int8_t fadj_ref[4], fadj_mode[4];
+  int16_t seg_level[4];                  // loop-filter level per segment before the per-macroblock adjustments (Q3: unclamped)
+  uint8_t y_mode_probs[4], uv_mode_probs[3], mv_probs[2][19];
+  uint8_t pad[3];
+  uint8_t coeff_probs[4][8][3][11];      // this frame's token probabilities
+};
+
+// Arithmetic-decoder state in a window-independent form.  The window of a VP8 boolean decoder is "8 active bits that
+// have been through the subtractions" followed by raw stream bits that nothing has touched yet (a subtraction of
+// split << (W-8) never borrows from below).  So (range, active byte, index of the first raw bit not yet shifted into the
+// active byte) says everything, whatever the window width of the reader that continues.
+struct BoolState { uint32_t bitpos; uint8_t range, active; };
+
+// Boolean decoder with a 32-bit window over a byte range; same arithmetic as the reference's BoolDecoder
+// (bool_decoder.hh:45-120).  Used by the GPU lanes of the macroblock-header kernel (and, on the host, by the tests that
+// replay the device algorithm).  Bytes past the end read as zero.
+class BoolReader32
+{
+  const uint8_t * base_ = nullptr;
+  uint32_t pos_ = 0, end_ = 0;   // next byte to append, end of the partition (offsets from base_)
+  uint32_t value_ = 0;           // window, most significant bits first
+  int count_ = 0;                // valid bits below the 8 being compared
+  uint32_t range_ = 255;
+
+public:
+  AA_HD BoolReader32() {}
+  AA_HD void resume( const uint8_t * base, uint32_t size, const BoolState & st )
+  {
+    base_ = base; end_ = size; range_ = st.range;
+    // raw bits from st.bitpos up to the next byte boundary + 16 go below the active byte; from there on whole bytes
+    const uint32_t byte = st.bitpos >> 3, r = st.bitpos & 7;
+    uint32_t b = 0;
+    for ( int k = 0; k < 3; k++ ) b = ( b << 8 ) | ( byte + k < end_ ? base_[byte + k] : 0u );
+    value_ = ( static_cast<uint32_t>( st.active ) << 24 ) | ( ( b << r ) & 0xFFFFFFu );
+    count_ = 24 - static_cast<int>( r );
+    pos_ = byte + 3;
+  }
+  AA_HD void reset( const uint8_t * base, uint32_t size )     // fresh partition: the first byte is the active byte
+  {
+    BoolState st; st.bitpos = 8; st.range = 255; st.active = size ? base[0] : 0;
+    resume( base, size, st );
+  }
+  AA_HD inline int get( const uint32_t prob )
+  {
+    const uint32_t split = 1 + ( ( ( range_ - 1 ) * prob ) >> 8 );
+    if ( count_ < 0 ) {                                         // one byte always fits: 8 + count_ < 8
+      const uint32_t byte = pos_ < end_ ? base_[pos_] : 0u;
+      pos_++;
+      value_ |= byte << ( 16 - count_ );
+      count_ += 8;
+    }
+    const uint32_t bigsplit = split << 24;
+    int bit;
+    uint32_t range;
+    if ( value_ >= bigsplit ) { range = range_ - split; value_ -= bigsplit; bit = 1; }
+    else { range = split; bit = 0; }
+    const int shift = __builtin_clz( range ) - 24;
+    range_ = range << shift;
+    value_ <<= shift;
+    count_ -= shift;
+    return bit;
+  }
+  AA_HD inline int flag() { return get( 128 ); }
+  AA_HD inline int literal( int bits ) { int v = 0; while ( bits-- ) v = ( v << 1 ) | get( 128 ); return v; }
+  AA_HD inline int tree( const int8_t * nodes, const uint8_t * probs )
+  {
+    int i = 0;
+    while ( ( i = nodes[i + get( probs[i >> 1] )] ) > 0 ) {}
+    return -i;
+  }
+};
+
+struct Mv {
+  int16_t x = 0, y = 0;
+  AA_HD bool zero() const { return x == 0 && y == 0; }
+  AA_HD bool operator==( const Mv & o ) const { return x == o.x && y == o.y; }
+};
+
+AA_HD inline int clamp_int( int v, int lo, int hi ) { return v < lo ? lo : ( v > hi ? hi : v ); }
+
+// MotionVector::read_component, macroblock.cc:198-229
+template <class BD>
+AA_HD inline int16_t read_mv_component( BD & bd, const uint8_t * p )
+{
+  enum { MV_IS_SHORT, SIGN, SHORT, BITS = SHORT + 8 - 1, MV_LONG_BITS = 10 };
+  int x = 0;
+  if ( bd.get( p[MV_IS_SHORT] ) ) {
+    for ( int i = 0; i < 3; i++ ) x += bd.get( p[BITS + i] ) << i;
+    for ( int i = MV_LONG_BITS - 1; i > 3; i-- ) x += bd.get( p[BITS + i] ) << i;
+    if ( !( x & 0xFFF0 ) || bd.get( p[BITS + 3] ) ) x += 8;
+  } else {
+    x = bd.tree( kSmallMvTree, p + SHORT );
+  }
+  x <<= 1;
+  if ( x && bd.get( p[SIGN] ) ) x = -x;
+  return static_cast<int16_t>( x );
+}
+
+template <class BD>
+AA_HD inline Mv read_mv( BD & bd, const FrameParams & fp )
+{
+  Mv m;
+  m.y = read_mv_component( bd, fp.mv_probs[0] );   // row first (macroblock.cc:283-287)
+  m.x = read_mv_component( bd, fp.mv_probs[1] );
+  return m;
+}
+
+// Scorer::clamp, macroblock.cc:183-195
+AA_HD inline Mv clamp_mv( Mv m, unsigned col, unsigned row, unsigned mbw, unsigned mbh )
+{
+  const int to_left = clamp_int( -( static_cast<int>( col * 16 ) << 3 ) - 128, -32768, 32767 );
+  const int to_right = clamp_int( ( static_cast<int>( ( mbw - 1 - col ) * 16 ) << 3 ) + 128, -32768, 32767 );
+  const int to_top = clamp_int( -( static_cast<int>( row * 16 ) << 3 ) - 128, -32768, 32767 );
+  const int to_bottom = clamp_int( ( static_cast<int>( ( mbh - 1 - row ) * 16 ) << 3 ) + 128, -32768, 32767 );
+  m.x = static_cast<int16_t>( clamp_int( m.x, to_left, to_right ) );
+  m.y = static_cast<int16_t>( clamp_int( m.y, to_top, to_bottom ) );
+  return m;
+}
+
+// Final loop-filter level of one macroblock: frame.cc:144-166, macroblock.cc:611-623, loopfilter.cc:59-79
+AA_HD inline uint8_t mb_lf_level( const FrameParams & fp, unsigned segment_id, unsigned ref_frame, unsigned y_mode )
+{
+  if ( !fp.loop_filter_level ) return 0;
+  int level = fp.seg_level[segment_id];
+  if ( fp.fadj_enabled ) {
+    level += fp.fadj_ref[ref_frame];
+    if ( ref_frame == CURRENT_FRAME ) level += ( y_mode == B_PRED ) ? fp.fadj_mode[0] : 0;
+    else if ( y_mode == ZEROMV ) level += fp.fadj_mode[1];
+    else if ( y_mode == SPLITMV ) level += fp.fadj_mode[3];
+    else level += fp.fadj_mode[2];
+  }
+  return static_cast<uint8_t>( level <= 0 ? 0 : ( level > 63 ? 63 : level ) );
+}
+
+AA_HD inline bool mv_flipped( const FrameParams & fp, unsigned ref_frame )    // motion_vectors_flipped_, macroblock.cc:464-465
+{
+  return ( ref_frame == GOLDEN_FRAME && fp.sign_bias_golden ) || ( ref_frame == ALTREF_FRAME && fp.sign_bias_alt );
+}
+
+// Header of macroblock (col,row): segment id, skip flag, reference frame, prediction modes, motion vectors.  Writes the
+// whole record mbs[mi] except nz_mask / coeff_index / the HAS_NONZERO and LF_SKIP_INNER flags, which belong to the token
+// parse.  `segmap`: the persistent segment map (mb_width*mb_height), or null when the caller resolves inherited segment ids
+// afterwards (device parser: frames of one stream are parsed concurrently; see k_segment_fixup).
+// Returns the record's flags (INTER | HAS_Y2 | SKIP).
+template <class BD>
+AA_HD inline uint8_t parse_mb_header( BD & bd, const FrameParams & fp, aa_mb_info * mbs, unsigned mi, unsigned col, unsigned row,
+                                      uint8_t * segmap )
+{
+  const unsigned mbw = fp.mbw, mbh = fp.mbh;
+  const bool key = fp.key;
+  aa_mb_info & mb = mbs[mi];
+  {
+    uint32_t * w = reinterpret_cast<uint32_t *>( &mb );
+    for ( unsigned k = 0; k < sizeof( aa_mb_info ) / 4; k++ ) w[k] = 0;
+  }
+
+  // Macroblock ctor: segment id, skip flag, inter/intra + reference (macroblock.cc:43-71, 458-465)
+  unsigned segment_id = 0;
+  if ( fp.seg_enabled ) {
+    if ( fp.seg_update_map ) {
+      segment_id = static_cast<unsigned>( bd.tree( kSegmentIdTree, fp.seg_tree_probs ) );
+      if ( segmap ) segmap[mi] = static_cast<uint8_t>( segment_id );
+    } else if ( segmap ) segment_id = segmap[mi];
+  }
+  mb.segment_id = static_cast<uint8_t>( segment_id );
+  const bool skip = fp.skip_enabled ? bd.get( fp.prob_skip ) : false;
+  bool inter = false;
+  if ( !key ) {
+    inter = bd.get( fp.prob_inter );
+    if ( inter ) {
+      mb.ref_frame = LAST_FRAME;
+      if ( bd.get( fp.prob_last ) ) mb.ref_frame = bd.get( fp.prob_golden ) ? ALTREF_FRAME : GOLDEN_FRAME;
+    }
+  }
+
+  if ( !inter ) {
+    // ---- intra modes: macroblock.cc:84-111 (key) / 354-376 (inter frame) ----
+    mb.y_mode = static_cast<uint8_t>( key ? bd.tree( kKfYModeTree, k_kf_y_mode_probs ) : bd.tree( kYModeTree, fp.y_mode_probs ) );
+    if ( mb.y_mode == B_PRED ) {
+      for ( int b = 0; b < 16; b++ ) {
+        if ( key ) {
+          int above_mode = B_DC_PRED, left_mode = B_DC_PRED;
+          if ( b >= 4 ) above_mode = mb.u.b_mode[b - 4];
+          else if ( row > 0 ) above_mode = mbs[mi - mbw].u.b_mode[b + 12];
+          if ( b & 3 ) left_mode = mb.u.b_mode[b - 1];
+          else if ( col > 0 ) left_mode = mbs[mi - 1].u.b_mode[b + 3];
+          mb.u.b_mode[b] = static_cast<uint8_t>( bd.tree( kBModeTree, k_kf_b_mode_probs + ( above_mode * 10 + left_mode ) * 9 ) );
+        } else {
+          mb.u.b_mode[b] = static_cast<uint8_t>( bd.tree( kBModeTree, k_b_mode_probs ) );
+        }
+      }
+    } else {
+      constexpr uint8_t kImplied[4] = { B_DC_PRED, B_VE_PRED, B_HE_PRED, B_TM_PRED };   // macroblock.hh:134-143
+      const uint8_t m = kImplied[mb.y_mode];
+      for ( int b = 0; b < 16; b++ ) mb.u.b_mode[b] = m;
+    }
+    mb.uv_mode = static_cast<uint8_t>( key ? bd.tree( kUvModeTree, k_kf_uv_mode_probs ) : bd.tree( kUvModeTree, fp.uv_mode_probs ) );
+  } else {
+    // ---- inter modes: census (scorer.hh, macroblock.cc:143-181,301-312) then mode / MVs (:377-455) ----
+    mb.flags |= AA_MB_INTER;
+    uint8_t score[4] = { 0, 0, 0, 0 };
+    Mv cand[4];
+    int idx = 0, split_score = 0;
+    const bool my_flip = mv_flipped( fp, mb.ref_frame );
+    auto consider = [&]( unsigned ni, int weight ) {
+      const aa_mb_info & nb = mbs[ni];
+      if ( !( nb.flags & AA_MB_INTER ) ) return;
+      Mv mv; mv.x = nb.u.mv[15][0]; mv.y = nb.u.mv[15][1];
+      if ( mv_flipped( fp, nb.ref_frame ) != my_flip ) { mv.x = static_cast<int16_t>( -mv.x ); mv.y = static_cast<int16_t>( -mv.y ); }
+      if ( mv.zero() ) score[0] += weight;
+      else {
+        if ( !( mv == cand[idx] ) ) cand[++idx] = mv;
+        score[idx] += weight;
+      }
+      if ( nb.y_mode == SPLITMV ) split_score += weight;
+    };
+    if ( row > 0 ) consider( mi - mbw, 2 );
+    if ( col > 0 ) consider( mi - 1, 2 );
+    if ( row > 0 && col > 0 ) consider( mi - mbw - 1, 1 );
+    if ( score[3] && cand[idx] == cand[1] ) score[1] += score[3];                       // Q8
+    if ( score[2] > score[1] ) {
+      const uint8_t ts = score[1]; score[1] = score[2]; score[2] = ts;
+      const Mv tm = cand[1]; cand[1] = cand[2]; cand[2] = tm;
+    }
+    if ( score[1] >= score[0] ) cand[0] = cand[1];
+    const uint8_t mode_probs[4] = { k_mv_counts_to_probs[score[0] * 4 + 0], k_mv_counts_to_probs[score[1] * 4 + 1],
+                                    k_mv_counts_to_probs[score[2] * 4 + 2], k_mv_counts_to_probs[split_score * 4 + 3] };
+    mb.y_mode = static_cast<uint8_t>( bd.tree( kMvRefTree, mode_probs ) );
+    Mv base;
+    switch ( mb.y_mode ) {
+    case NEARESTMV: base = clamp_mv( cand[1], col, row, mbw, mbh ); break;
+    case NEARMV: base = clamp_mv( cand[2], col, row, mbw, mbh ); break;
+    case ZEROMV: break;
+    case NEWMV: {
+      const Mv delta = read_mv( bd, fp );
+      const Mv best = clamp_mv( cand[0], col, row, mbw, mbh );
+      base.x = static_cast<int16_t>( delta.x + best.x ); base.y = static_cast<int16_t>( delta.y + best.y );
+      break; }
+    default: {   // SPLITMV (the tree has no other leaf)
+      mb.split_partition = static_cast<uint8_t>( bd.tree( kSplitMvTree, k_split_mv_probs ) );
+      const Mv best = clamp_mv( cand[0], col, row, mbw, mbh );
+      const uint8_t * layout = kSplitLayout[mb.split_partition];
+      for ( int part = 0; part < kSplitCount[mb.split_partition]; part++ ) {
+        const int b = kSplitFirst[mb.split_partition][part];
+        // YBlock::read_subblock_inter_prediction, macroblock.cc:231-281
+        Mv lmv, amv;
+        if ( b & 3 ) { lmv.x = mb.u.mv[b - 1][0]; lmv.y = mb.u.mv[b - 1][1]; }
+        else if ( col > 0 && ( mbs[mi - 1].flags & AA_MB_INTER ) ) { lmv.x = mbs[mi - 1].u.mv[b + 3][0]; lmv.y = mbs[mi - 1].u.mv[b + 3][1]; }
+        if ( b >= 4 ) { amv.x = mb.u.mv[b - 4][0]; amv.y = mb.u.mv[b - 4][1]; }
+        else if ( row > 0 && ( mbs[mi - mbw].flags & AA_MB_INTER ) ) { amv.x = mbs[mi - mbw].u.mv[b + 12][0]; amv.y = mbs[mi - mbw].u.mv[b + 12][1]; }
+        int ctx = 0;
+        if ( lmv == amv ) ctx = lmv.zero() ? 4 : 3;
+        else if ( amv.zero() ) ctx = 2;
+        else if ( lmv.zero() ) ctx = 1;
+        Mv m;
+        switch ( bd.tree( kSubMvRefTree, k_submv_ref_probs + ctx * 3 ) ) {
+        case LEFT4X4: m = lmv; break;
+        case ABOVE4X4: m = amv; break;
+        case ZERO4X4: break;
+        default: { const Mv d = read_mv( bd, fp ); m.x = static_cast<int16_t>( d.x + best.x ); m.y = static_cast<int16_t>( d.y + best.y ); break; }   // NEW4X4
+        }
+        for ( int k = 0; k < 16; k++ ) if ( layout[k] == part ) { mb.u.mv[k][0] = m.x; mb.u.mv[k][1] = m.y; }
+      }
+      break; }
+    }
+    if ( mb.y_mode != SPLITMV ) for ( int k = 0; k < 16; k++ ) { mb.u.mv[k][0] = base.x; mb.u.mv[k][1] = base.y; }
+  }
+
+  if ( !( mb.y_mode == B_PRED || mb.y_mode == SPLITMV ) ) mb.flags |= AA_MB_HAS_Y2;
+  if ( skip ) mb.flags |= AA_MB_SKIP;
+  mb.lf_level = mb_lf_level( fp, segment_id, mb.ref_frame, mb.y_mode );
+  return mb.flags;
+}
+
+} // namespace aa

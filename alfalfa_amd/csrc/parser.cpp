@@ -4,81 +4,11 @@
 #include <cstring>
 
 #include "bool_reader.hh"
-#include "vp8_tables.h"
+#include "parse_common.hh"
 
 namespace aa {
 
 namespace {
-
-enum MbMode : uint8_t { DC_PRED, V_PRED, H_PRED, TM_PRED, B_PRED, NEARESTMV, NEARMV, ZEROMV, NEWMV, SPLITMV };
-enum BMode : uint8_t { B_DC_PRED, B_TM_PRED, B_VE_PRED, B_HE_PRED, B_LD_PRED, B_RD_PRED, B_VR_PRED, B_VL_PRED,
-                       B_HD_PRED, B_HU_PRED, LEFT4X4, ABOVE4X4, ZERO4X4, NEW4X4 };
-enum RefFrame : uint8_t { CURRENT_FRAME, LAST_FRAME, GOLDEN_FRAME, ALTREF_FRAME };
-enum BlockType { Y_AFTER_Y2 = 0, Y2 = 1, UV = 2, Y_WITHOUT_Y2 = 3 };   // block.hh:46
-
-// RFC 6386 trees as in modemv_data.cc:162-281
-constexpr int8_t kKfYModeTree[8] = { -B_PRED, 2, 4, 6, -DC_PRED, -V_PRED, -H_PRED, -TM_PRED };
-constexpr int8_t kYModeTree[8] = { -DC_PRED, 2, 4, 6, -V_PRED, -H_PRED, -TM_PRED, -B_PRED };
-constexpr int8_t kUvModeTree[6] = { -DC_PRED, 2, -V_PRED, 4, -H_PRED, -TM_PRED };
-constexpr int8_t kBModeTree[18] = { -B_DC_PRED, 2, -B_TM_PRED, 4, -B_VE_PRED, 6, 8, 12, -B_HE_PRED, 10,
-                                    -B_RD_PRED, -B_VR_PRED, -B_LD_PRED, 14, -B_VL_PRED, 16, -B_HD_PRED, -B_HU_PRED };
-constexpr int8_t kSmallMvTree[14] = { 2, 8, 4, 6, -0, -1, -2, -3, 10, 12, -4, -5, -6, -7 };
-constexpr int8_t kMvRefTree[8] = { -ZEROMV, 2, -NEARESTMV, 4, -NEARMV, 6, -NEWMV, -SPLITMV };
-constexpr int8_t kSubMvRefTree[6] = { -LEFT4X4, 2, -ABOVE4X4, 4, -ZERO4X4, -NEW4X4 };
-constexpr int8_t kSplitMvTree[6] = { -3, 2, -2, 4, -0, -1 };
-constexpr int8_t kSegmentIdTree[6] = { 2, 4, -0, -1, -2, -3 };
-
-constexpr uint8_t kZigzag[16] = { 0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15 };
-constexpr uint8_t kBand[16] = { 0, 1, 2, 3, 6, 4, 5, 6, 6, 6, 6, 6, 6, 6, 6, 7 };
-
-// mv_partitions (modemv_data.cc:245-276): partition index of each raster-order sub-block
-constexpr uint8_t kSplitLayout[4][16] = { { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1 },
-                                          { 0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1, 1 },
-                                          { 0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3 },
-                                          { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15 } };
-constexpr uint8_t kSplitFirst[4][16] = { { 0, 8 }, { 0, 2 }, { 0, 2, 8, 10 }, { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15 } };
-constexpr uint8_t kSplitCount[4] = { 2, 2, 4, 16 };
-
-struct Mv { int16_t x = 0, y = 0; bool zero() const { return x == 0 && y == 0; } bool operator==( const Mv & o ) const { return x == o.x && y == o.y; } };
-
-inline int clamp( int v, int lo, int hi ) { return v < lo ? lo : ( v > hi ? hi : v ); }
-
-// MotionVector::read_component, macroblock.cc:198-229
-int16_t read_mv_component( BoolReader & bd, const uint8_t * p )
-{
-  enum { MV_IS_SHORT, SIGN, SHORT, BITS = SHORT + 8 - 1, MV_LONG_BITS = 10 };
-  int x = 0;
-  if ( bd.get( p[MV_IS_SHORT] ) ) {
-    for ( int i = 0; i < 3; i++ ) x += bd.get( p[BITS + i] ) << i;
-    for ( int i = MV_LONG_BITS - 1; i > 3; i-- ) x += bd.get( p[BITS + i] ) << i;
-    if ( !( x & 0xFFF0 ) || bd.get( p[BITS + 3] ) ) x += 8;
-  } else {
-    x = bd.tree( kSmallMvTree, p + SHORT );
-  }
-  x <<= 1;
-  if ( x && bd.get( p[SIGN] ) ) x = -x;
-  return static_cast<int16_t>( x );
-}
-
-Mv read_mv( BoolReader & bd, const ProbTables & pt )
-{
-  Mv m;
-  m.y = read_mv_component( bd, pt.mv[0] );   // row first (macroblock.cc:283-287)
-  m.x = read_mv_component( bd, pt.mv[1] );
-  return m;
-}
-
-// Scorer::clamp, macroblock.cc:183-195
-Mv clamp_mv( Mv m, unsigned col, unsigned row, unsigned mbw, unsigned mbh )
-{
-  const int to_left = clamp( -( static_cast<int>( col * 16 ) << 3 ) - 128, -32768, 32767 );
-  const int to_right = clamp( ( static_cast<int>( ( mbw - 1 - col ) * 16 ) << 3 ) + 128, -32768, 32767 );
-  const int to_top = clamp( -( static_cast<int>( row * 16 ) << 3 ) - 128, -32768, 32767 );
-  const int to_bottom = clamp( ( static_cast<int>( ( mbh - 1 - row ) * 16 ) << 3 ) + 128, -32768, 32767 );
-  m.x = static_cast<int16_t>( clamp( m.x, to_left, to_right ) );
-  m.y = static_cast<int16_t>( clamp( m.y, to_top, to_bottom ) );
-  return m;
-}
 
 // Block::parse_tokens, tokens.cc:50-135.  Returns true iff a non-zero token was decoded (Q1).
 // `out` must be 16 zeroed int16 (de-zigzagged positions are written).
@@ -161,7 +91,7 @@ void ProbTables::set_defaults()
 
 Parser::Parser( uint16_t width, uint16_t height )
   : width_( width ), height_( height ), mbw_( ( width + 15u ) / 16u ), mbh_( ( height + 15u ) / 16u ),
-    above_nz_( static_cast<size_t>( mbw_ ) * 9 ), flipped_( static_cast<size_t>( mbw_ ) * mbh_ )
+    above_nz_( static_cast<size_t>( mbw_ ) * 9 )
 {
   probs_.set_defaults();
   seg_.map.assign( static_cast<size_t>( mbw_ ) * mbh_, 3 );
@@ -284,7 +214,13 @@ size_t Parser::deserialize_reference( const uint8_t * in, size_t size )
   return r.at;
 }
 
-void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa_mb_info * mbs, int16_t * coeff_out )
+void Parser::parse_header( const uint8_t * data, size_t size, aa_frame_header & hdr, FrameParams & fp )
+{
+  BoolReader bd;
+  parse_header_impl( data, size, hdr, fp, bd );
+}
+
+void Parser::parse_header_impl( const uint8_t * data, size_t size, aa_frame_header & hdr, FrameParams & fp, BoolReader & bd )
 {
   // ---- frame tag + partition split: uncompressed_chunk.cc:34-130 ----
   if ( size < 3 ) throw ParseError( AA_ERR_INVALID, "invalid bitstream: VP8 frame truncated" );
@@ -313,7 +249,7 @@ void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa
   const uint8_t * rest = data + first_off + first_len;
   const size_t rest_len = size - first_off - first_len;
 
-  BoolReader bd( data + first_off, first_len );
+  bd.reset( data + first_off, first_len );
 
   // ---- frame header: frame_header.hh:194-295 ----
   std::memset( &hdr, 0, sizeof hdr );
@@ -379,29 +315,30 @@ void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa
   hdr.sign_bias_golden = sign_bias_golden; hdr.sign_bias_alternate = sign_bias_alt;
 
   // ---- state transition: decoder_state.hh:72-167 ----
-  ProbTables fp;            // this frame's tables
-  if ( key ) fp.set_defaults();   // key frames reset the persistent state (decoder.cc:234-240), applied below once the header is valid
-  else fp = probs_;
+  ProbTables ft;            // this frame's tables
+  if ( key ) ft.set_defaults();   // key frames reset the persistent state (decoder.cc:234-240), applied below once the header is valid
+  else ft = probs_;
   for ( int i = 0; i < 4; i++ ) for ( int j = 0; j < 8; j++ ) for ( int k = 0; k < 3; k++ ) for ( int l = 0; l < 11; l++ )
-    if ( bd.get( k_coeff_update_probs[( ( i * 8 + j ) * 3 + k ) * 11 + l] ) ) fp.coeff[i][j][k][l] = static_cast<uint8_t>( bd.literal( 8 ) );
+    if ( bd.get( k_coeff_update_probs[( ( i * 8 + j ) * 3 + k ) * 11 + l] ) ) ft.coeff[i][j][k][l] = static_cast<uint8_t>( bd.literal( 8 ) );
   const bool skip_enabled = bd.flag();
   const int prob_skip = skip_enabled ? bd.literal( 8 ) : 0;
   int prob_inter = 0, prob_last = 0, prob_golden = 0;
   if ( !key ) {
     prob_inter = bd.literal( 8 ); prob_last = bd.literal( 8 ); prob_golden = bd.literal( 8 );
-    if ( bd.flag() ) for ( int i = 0; i < 4; i++ ) fp.y_mode[i] = static_cast<uint8_t>( bd.literal( 8 ) );
-    if ( bd.flag() ) for ( int i = 0; i < 3; i++ ) fp.uv_mode[i] = static_cast<uint8_t>( bd.literal( 8 ) );
+    if ( bd.flag() ) for ( int i = 0; i < 4; i++ ) ft.y_mode[i] = static_cast<uint8_t>( bd.literal( 8 ) );
+    if ( bd.flag() ) for ( int i = 0; i < 3; i++ ) ft.uv_mode[i] = static_cast<uint8_t>( bd.literal( 8 ) );
     for ( int i = 0; i < 2; i++ ) for ( int j = 0; j < 19; j++ )
-      if ( bd.get( k_mv_update_probs[i * 19 + j] ) ) { const int x = bd.literal( 7 ); fp.mv[i][j] = static_cast<uint8_t>( x ? x << 1 : 1 ); }
+      if ( bd.get( k_mv_update_probs[i * 19 + j] ) ) { const int x = bd.literal( 7 ); ft.mv[i][j] = static_cast<uint8_t>( x ? x << 1 : 1 ); }
   }
   if ( color_space || clamping_type ) throw ParseError( AA_ERR_UNSUPPORTED, "unsupported bitstream: VP8 color_space and clamping_type bits" );
   if ( filter_type ) throw ParseError( AA_ERR_UNSUPPORTED, "unsupported bitstream: VP8 'simple' in-loop deblocking filter" );
 
+  bool seg_reset = false;       // the persistent segment map restarts at all-3 with this frame
   if ( key ) {
     probs_.set_defaults();
     seg_.enabled = seg_enabled; seg_.absolute = false;
     std::memset( seg_.quant, 0, 4 ); std::memset( seg_.lf, 0, 4 );
-    if ( seg_enabled ) std::memset( seg_.map.data(), 3, seg_.map.size() );     // Segmentation ctor: map(width, height, 3)
+    if ( seg_enabled ) { std::memset( seg_.map.data(), 3, seg_.map.size() ); seg_reset = true; }    // Segmentation ctor: map(width, height, 3)
     fadj_.enabled = lf_adj_enabled; std::memset( fadj_.ref, 0, 4 ); std::memset( fadj_.mode, 0, 4 );
   } else {
     if ( lf_adj_enabled ) { if ( !fadj_.enabled ) { fadj_.enabled = true; std::memset( fadj_.ref, 0, 4 ); std::memset( fadj_.mode, 0, 4 ); } }
@@ -409,11 +346,11 @@ void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa
     if ( seg_enabled ) {
       if ( !seg_.enabled ) {
         seg_.enabled = true; seg_.absolute = false; std::memset( seg_.quant, 0, 4 ); std::memset( seg_.lf, 0, 4 );
-        std::memset( seg_.map.data(), 3, seg_.map.size() );
+        std::memset( seg_.map.data(), 3, seg_.map.size() ); seg_reset = true;
       }
     } else seg_.enabled = false;
   }
-  if ( refresh_entropy ) probs_ = fp;
+  if ( refresh_entropy ) probs_ = ft;
   if ( lf_adj_enabled && lf_delta_update )
     for ( int i = 0; i < 4; i++ ) { fadj_.ref[i] = static_cast<int8_t>( ref_delta[i] ); fadj_.mode[i] = static_cast<int8_t>( mode_delta[i] ); }
   if ( seg_enabled && seg_update_data ) {
@@ -429,13 +366,12 @@ void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa
     const Quantizer q = make_quantizer( qi, qdelta );
     std::memcpy( hdr.quant[s], q.f, sizeof q.f );
   }
-  int seg_level[4];
+  std::memset( &fp, 0, sizeof fp );
   for ( int s = 0; s < 4; s++ )
-    seg_level[s] = seg_.enabled ? seg_.lf[s] + ( seg_.absolute ? 0 : hdr.loop_filter_level ) : hdr.loop_filter_level;   // Q3: unclamped
+    fp.seg_level[s] = static_cast<int16_t>( seg_.enabled ? seg_.lf[s] + ( seg_.absolute ? 0 : hdr.loop_filter_level ) : hdr.loop_filter_level );   // Q3: unclamped
 
   // ---- DCT partitions: uncompressed_chunk.cc:132-155 ----
   const int nparts = hdr.num_dct_partitions;
-  BoolReader parts[8];
   {
     if ( rest_len < static_cast<size_t>( 3 * ( nparts - 1 ) ) ) throw ParseError( AA_ERR_OUT_OF_RANGE, "attempted to read past end of chunk" );
     const uint8_t * p = rest + 3 * ( nparts - 1 );
@@ -446,14 +382,43 @@ void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa
         len = rest[3 * i] | ( rest[3 * i + 1] << 8 ) | ( static_cast<size_t>( rest[3 * i + 2] ) << 16 );
         if ( len > left ) throw ParseError( AA_ERR_OUT_OF_RANGE, "attempted to read past end of chunk" );
       }
-      parts[i].reset( p, len ); p += len; left -= len;
+      fp.part_off[i] = static_cast<uint32_t>( p - data ); fp.part_size[i] = static_cast<uint32_t>( len );
+      p += len; left -= len;
     }
   }
+
+  // ---- what the macroblock loop (host: Parser::parse below; device: parse_kernels.hip) needs ----
+  fp.first_off = first_off; fp.first_size = first_len;
+  const BoolState bs = bd.state();
+  fp.bd_bitpos = bs.bitpos; fp.bd_range = bs.range; fp.bd_active = bs.active;
+  fp.key = key; fp.nparts = static_cast<uint8_t>( nparts );
+  fp.mbw = static_cast<uint16_t>( mbw_ ); fp.mbh = static_cast<uint16_t>( mbh_ );
+  fp.seg_enabled = seg_enabled; fp.seg_update_map = seg_update_map;
+  std::memcpy( fp.seg_tree_probs, seg_tree_probs, 3 );
+  fp.skip_enabled = skip_enabled; fp.prob_skip = static_cast<uint8_t>( prob_skip );
+  fp.prob_inter = static_cast<uint8_t>( prob_inter ); fp.prob_last = static_cast<uint8_t>( prob_last ); fp.prob_golden = static_cast<uint8_t>( prob_golden );
+  fp.sign_bias_golden = sign_bias_golden; fp.sign_bias_alt = sign_bias_alt;
+  fp.loop_filter_level = hdr.loop_filter_level; fp.fadj_enabled = fadj_.enabled;
+  std::memcpy( fp.fadj_ref, fadj_.ref, 4 ); std::memcpy( fp.fadj_mode, fadj_.mode, 4 );
+  std::memcpy( fp.y_mode_probs, ft.y_mode, 4 ); std::memcpy( fp.uv_mode_probs, ft.uv_mode, 3 ); std::memcpy( fp.mv_probs, ft.mv, 38 );
+  std::memcpy( fp.coeff_probs, ft.coeff, sizeof ft.coeff );
+  seg_map_reset_ = seg_reset;
+}
+
+void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa_mb_info * mbs, int16_t * coeff_out )
+{
+  FrameParams fp;
+  BoolReader bd;                 // the first partition's decoder continues right behind the frame header
+  parse_header_impl( data, size, hdr, fp, bd );
+  const int nparts = fp.nparts;
+  BoolReader parts[8];
+  for ( int i = 0; i < nparts; i++ ) parts[i].reset( data + fp.part_off[i], fp.part_size[i] );
 
   // ---- macroblock headers + tokens ----
   std::memset( above_nz_.data(), 0, above_nz_.size() );
   uint32_t coeff_blocks = 0, intra_mbs = 0;
   const unsigned mbw = mbw_, mbh = mbh_;
+  uint8_t * segmap = seg_.enabled ? seg_.map.data() : nullptr;
 
   for ( unsigned row = 0; row < mbh; row++ ) {
     uint8_t left_nz[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -461,116 +426,9 @@ void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa
     for ( unsigned col = 0; col < mbw; col++ ) {
       const unsigned mi = row * mbw + col;
       aa_mb_info & mb = mbs[mi];
-      std::memset( &mb, 0, sizeof mb );
-
-      // Macroblock ctor: segment id, skip flag, inter/intra + reference (macroblock.cc:43-71, 458-465)
-      if ( seg_enabled && seg_update_map ) seg_.map[mi] = static_cast<uint8_t>( bd.tree( kSegmentIdTree, seg_tree_probs ) );
-      mb.segment_id = seg_.enabled ? seg_.map[mi] : 0;
-      const bool skip = skip_enabled ? bd.get( prob_skip ) : false;
-      bool inter = false;
-      if ( !key ) {
-        inter = bd.get( prob_inter );
-        if ( inter ) {
-          mb.ref_frame = LAST_FRAME;
-          if ( bd.get( prob_last ) ) mb.ref_frame = bd.get( prob_golden ) ? ALTREF_FRAME : GOLDEN_FRAME;
-          flipped_[mi] = ( mb.ref_frame == GOLDEN_FRAME && sign_bias_golden ) || ( mb.ref_frame == ALTREF_FRAME && sign_bias_alt );
-        }
-      }
-
-      if ( !inter ) {
-        // ---- intra modes: macroblock.cc:84-111 (key) / 354-376 (inter frame) ----
-        intra_mbs++;
-        mb.y_mode = static_cast<uint8_t>( key ? bd.tree( kKfYModeTree, k_kf_y_mode_probs ) : bd.tree( kYModeTree, fp.y_mode ) );
-        if ( mb.y_mode == B_PRED ) {
-          for ( int b = 0; b < 16; b++ ) {
-            if ( key ) {
-              int above_mode = B_DC_PRED, left_mode = B_DC_PRED;
-              if ( b >= 4 ) above_mode = mb.u.b_mode[b - 4];
-              else if ( row > 0 ) above_mode = mbs[mi - mbw].u.b_mode[b + 12];
-              if ( b & 3 ) left_mode = mb.u.b_mode[b - 1];
-              else if ( col > 0 ) left_mode = mbs[mi - 1].u.b_mode[b + 3];
-              mb.u.b_mode[b] = static_cast<uint8_t>( bd.tree( kBModeTree, k_kf_b_mode_probs + ( above_mode * 10 + left_mode ) * 9 ) );
-            } else {
-              mb.u.b_mode[b] = static_cast<uint8_t>( bd.tree( kBModeTree, k_b_mode_probs ) );
-            }
-          }
-        } else {
-          static constexpr uint8_t kImplied[4] = { B_DC_PRED, B_VE_PRED, B_HE_PRED, B_TM_PRED };   // macroblock.hh:134-143
-          std::memset( mb.u.b_mode, kImplied[mb.y_mode], 16 );
-        }
-        mb.uv_mode = static_cast<uint8_t>( key ? bd.tree( kUvModeTree, k_kf_uv_mode_probs ) : bd.tree( kUvModeTree, fp.uv_mode ) );
-      } else {
-        // ---- inter modes: census (scorer.hh, macroblock.cc:143-181,301-312) then mode / MVs (:377-455) ----
-        mb.flags |= AA_MB_INTER;
-        uint8_t score[4] = { 0, 0, 0, 0 };
-        Mv cand[4];
-        int idx = 0, split_score = 0;
-        const bool my_flip = flipped_[mi];
-        auto consider = [&]( unsigned ni, int weight ) {
-          const aa_mb_info & nb = mbs[ni];
-          if ( !( nb.flags & AA_MB_INTER ) ) return;
-          Mv mv; mv.x = nb.u.mv[15][0]; mv.y = nb.u.mv[15][1];
-          if ( static_cast<bool>( flipped_[ni] ) != my_flip ) { mv.x = static_cast<int16_t>( -mv.x ); mv.y = static_cast<int16_t>( -mv.y ); }
-          if ( mv.zero() ) score[0] += weight;
-          else {
-            if ( !( mv == cand[idx] ) ) cand[++idx] = mv;
-            score[idx] += weight;
-          }
-          if ( nb.y_mode == SPLITMV ) split_score += weight;
-        };
-        if ( row > 0 ) consider( mi - mbw, 2 );
-        if ( col > 0 ) consider( mi - 1, 2 );
-        if ( row > 0 && col > 0 ) consider( mi - mbw - 1, 1 );
-        if ( score[3] && cand[idx] == cand[1] ) score[1] += score[3];                       // Q8
-        if ( score[2] > score[1] ) { std::swap( score[1], score[2] ); std::swap( cand[1], cand[2] ); }
-        if ( score[1] >= score[0] ) cand[0] = cand[1];
-        const uint8_t mode_probs[4] = { k_mv_counts_to_probs[score[0] * 4 + 0], k_mv_counts_to_probs[score[1] * 4 + 1],
-                                        k_mv_counts_to_probs[score[2] * 4 + 2], k_mv_counts_to_probs[split_score * 4 + 3] };
-        mb.y_mode = static_cast<uint8_t>( bd.tree( kMvRefTree, mode_probs ) );
-        Mv base;
-        switch ( mb.y_mode ) {
-        case NEARESTMV: base = clamp_mv( cand[1], col, row, mbw, mbh ); break;
-        case NEARMV: base = clamp_mv( cand[2], col, row, mbw, mbh ); break;
-        case ZEROMV: break;
-        case NEWMV: {
-          const Mv delta = read_mv( bd, fp );
-          const Mv best = clamp_mv( cand[0], col, row, mbw, mbh );
-          base.x = static_cast<int16_t>( delta.x + best.x ); base.y = static_cast<int16_t>( delta.y + best.y );
-          break; }
-        case SPLITMV: {
-          mb.split_partition = static_cast<uint8_t>( bd.tree( kSplitMvTree, k_split_mv_probs ) );
-          const Mv best = clamp_mv( cand[0], col, row, mbw, mbh );
-          const uint8_t * layout = kSplitLayout[mb.split_partition];
-          for ( int part = 0; part < kSplitCount[mb.split_partition]; part++ ) {
-            const int b = kSplitFirst[mb.split_partition][part];
-            // YBlock::read_subblock_inter_prediction, macroblock.cc:231-281
-            Mv lmv, amv;
-            if ( b & 3 ) { lmv.x = mb.u.mv[b - 1][0]; lmv.y = mb.u.mv[b - 1][1]; }
-            else if ( col > 0 && ( mbs[mi - 1].flags & AA_MB_INTER ) ) { lmv.x = mbs[mi - 1].u.mv[b + 3][0]; lmv.y = mbs[mi - 1].u.mv[b + 3][1]; }
-            if ( b >= 4 ) { amv.x = mb.u.mv[b - 4][0]; amv.y = mb.u.mv[b - 4][1]; }
-            else if ( row > 0 && ( mbs[mi - mbw].flags & AA_MB_INTER ) ) { amv.x = mbs[mi - mbw].u.mv[b + 12][0]; amv.y = mbs[mi - mbw].u.mv[b + 12][1]; }
-            int ctx = 0;
-            if ( lmv == amv ) ctx = lmv.zero() ? 4 : 3;
-            else if ( amv.zero() ) ctx = 2;
-            else if ( lmv.zero() ) ctx = 1;
-            Mv m;
-            switch ( bd.tree( kSubMvRefTree, k_submv_ref_probs + ctx * 3 ) ) {
-            case LEFT4X4: m = lmv; break;
-            case ABOVE4X4: m = amv; break;
-            case ZERO4X4: break;
-            case NEW4X4: { const Mv d = read_mv( bd, fp ); m.x = static_cast<int16_t>( d.x + best.x ); m.y = static_cast<int16_t>( d.y + best.y ); break; }
-            }
-            for ( int k = 0; k < 16; k++ ) if ( layout[k] == part ) { mb.u.mv[k][0] = m.x; mb.u.mv[k][1] = m.y; }
-          }
-          break; }
-        default: throw ParseError( AA_ERR_LOGIC, "logic error" );
-        }
-        if ( mb.y_mode != SPLITMV ) for ( int k = 0; k < 16; k++ ) { mb.u.mv[k][0] = base.x; mb.u.mv[k][1] = base.y; }
-      }
-
-      const bool has_y2 = !( mb.y_mode == B_PRED || mb.y_mode == SPLITMV );
-      if ( has_y2 ) mb.flags |= AA_MB_HAS_Y2;
-      if ( skip ) mb.flags |= AA_MB_SKIP;
+      const uint8_t flags = parse_mb_header( bd, fp, mbs, mi, col, row, segmap );
+      const bool skip = flags & AA_MB_SKIP, has_y2 = flags & AA_MB_HAS_Y2;
+      if ( !( flags & AA_MB_INTER ) ) intra_mbs++;
 
       // ---- tokens: Macroblock::parse_tokens (macroblock.cc:475-502); storage order = nz_mask bit order ----
       uint8_t * anz = &above_nz_[static_cast<size_t>( col ) * 9];
@@ -584,7 +442,7 @@ void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa
         bool y2_nz = false;
         if ( has_y2 ) {
           std::memset( y2_block, 0, sizeof y2_block );
-          y2_nz = parse_block( tok, fp.coeff[Y2], 0, anz[8] + left_nz[8], y2_block );
+          y2_nz = parse_block( tok, fp.coeff_probs[Y2], 0, anz[8] + left_nz[8], y2_block );
           anz[8] = left_nz[8] = y2_nz;
         }
         const int ytype = has_y2 ? Y_AFTER_Y2 : Y_WITHOUT_Y2;
@@ -594,7 +452,7 @@ void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa
           int16_t * slot = coeff_out + static_cast<size_t>( coeff_blocks ) * 16;
           std::memset( slot, 0, 32 );
           const int bx = b & 3, by = b >> 2;
-          const bool nz = parse_block( tok, fp.coeff[ytype], yfirst, anz[bx] + left_nz[by], slot );
+          const bool nz = parse_block( tok, fp.coeff_probs[ytype], yfirst, anz[bx] + left_nz[by], slot );
           anz[bx] = left_nz[by] = nz;
           if ( nz ) { mask |= 1u << b; coeff_blocks++; }
         }
@@ -602,7 +460,7 @@ void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa
           int16_t * slot = coeff_out + static_cast<size_t>( coeff_blocks ) * 16;
           std::memset( slot, 0, 32 );
           uint8_t & a = anz[4 + pl * 2 + ( b & 1 )]; uint8_t & l = left_nz[4 + pl * 2 + ( b >> 1 )];
-          const bool nz = parse_block( tok, fp.coeff[UV], 0, a + l, slot );
+          const bool nz = parse_block( tok, fp.coeff_probs[UV], 0, a + l, slot );
           a = l = nz;
           if ( nz ) { mask |= 1u << ( 16 + pl * 4 + b ); coeff_blocks++; }
         }
@@ -615,19 +473,6 @@ void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa
       }
       if ( any ) mb.flags |= AA_MB_HAS_NONZERO;
       if ( has_y2 && !any ) mb.flags |= AA_MB_LF_SKIP_INNER;
-
-      // ---- per-MB loop filter level: frame.cc:144-166, macroblock.cc:611-623, loopfilter.cc:59-79 ----
-      if ( hdr.loop_filter_level ) {
-        int level = seg_level[mb.segment_id];
-        if ( fadj_.enabled ) {
-          level += fadj_.ref[mb.ref_frame];
-          if ( mb.ref_frame == CURRENT_FRAME ) level += ( mb.y_mode == B_PRED ) ? fadj_.mode[0] : 0;
-          else if ( mb.y_mode == ZEROMV ) level += fadj_.mode[1];
-          else if ( mb.y_mode == SPLITMV ) level += fadj_.mode[3];
-          else level += fadj_.mode[2];
-        }
-        mb.lf_level = static_cast<uint8_t>( level <= 0 ? 0 : ( level > 63 ? 63 : level ) );
-      }
     }
   }
   hdr.num_coeff_blocks = coeff_blocks;

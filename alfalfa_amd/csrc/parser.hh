@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/alfalfa_amd.h"
+#include "parse_common.hh"
 
 namespace aa {
 
@@ -55,6 +56,15 @@ public:
   // Throws ParseError.  mb_out: mb_width*mb_height records.  coeff_out: worst case 25*16 int16 per MB.
   void parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa_mb_info * mb_out, int16_t * coeff_out );
 
+  // Header pre-pass only: frame tag, partition split, frame header, state transition (everything of `parse` that is serial
+  // across the frames of a stream), no macroblock data.  `fp` receives what the macroblock loop needs, including the boolean
+  // decoder's state at the first macroblock header; the device parser (parse_kernels.hip) takes it from there.  The
+  // persistent segment MAP is not maintained by this call (it is macroblock data): see segment_map_reset().
+  void parse_header( const uint8_t * data, size_t size, aa_frame_header & hdr, FrameParams & fp );
+  // whether the last header restarted the persistent segment map at all-3 (key frame / segmentation switched on)
+  bool segment_map_reset() const { return seg_map_reset_; }
+  std::vector<uint8_t> & segment_map() { return seg_.map; }
+
   uint16_t width() const { return width_; }
   uint16_t height() const { return height_; }
   unsigned mb_width() const { return mbw_; }
@@ -78,13 +88,14 @@ public:
   const FilterAdjustState & filter_adjustments() const { return fadj_; }
 
 private:
+  void parse_header_impl( const uint8_t * data, size_t size, aa_frame_header & hdr, FrameParams & fp, class BoolReader & bd );
+  bool seg_map_reset_ = false;
   uint16_t width_, height_;
   unsigned mbw_, mbh_;
   ProbTables probs_;
   SegmentationState seg_;
   FilterAdjustState fadj_;
   std::vector<uint8_t> above_nz_;   // per MB column: 4 Y, 2 U, 2 V, 1 Y2
-  std::vector<uint8_t> flipped_;    // per MB: motion_vectors_flipped_ (macroblock.cc:464-465)
 };
 
 } // namespace aa
