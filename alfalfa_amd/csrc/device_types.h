@@ -39,8 +39,18 @@ struct aa_frame_list {
   const aa_dev_frame * f[AA_MAX_BATCH];
 };
 
-// kernels.hip launchers (plain C++ signatures so runtime.cpp needs no HIP kernel syntax)
+// one stream's share of a segment-map pass: its frames are order[first .. first+count) (bit 31 of an entry: the map restarts
+// at all-3 with that frame), map = the stream's persistent segment map in HBM (mb_width*mb_height bytes)
+struct aa_seg_stream { uint8_t * map; uint32_t first, count; };
+
+// kernels.hip / parse_kernels.hip launchers (plain C++ signatures so runtime.cpp needs no HIP kernel syntax)
 namespace aa {
+struct ParseJob;   // tok_fsm.hh
+// device-side entropy decode of n frames (jobs resident in HBM): macroblock headers, then (streams with segmentation only)
+// the segment-map pass, then tokens
+int launch_parse_mb_headers( const ParseJob * jobs, int n, void * stream );
+int launch_segment_fixup( const ParseJob * jobs, const aa_seg_stream * streams, int n_streams, const uint32_t * order, void * stream );
+int launch_parse_tokens( const ParseJob * jobs, int n, int max_mbw, void * stream );
 // whole-vector inter macroblocks, four per wave
 int launch_recon_inter4( const aa_frame_list & list, int n, unsigned max_mbs, void * stream );
 // one inter macroblock per wave; split_only: only SPLITMV macroblocks (the rest is launch_recon_inter4's)

@@ -53,6 +53,7 @@ constexpr uint8_t kSplitCount[4] = { 2, 2, 4, 16 };
 // (decoder_state.hh:72-167).  Written by the host header pre-pass (Parser::parse_header); read by the host macroblock loop
 // or, unchanged, by the device parse kernels (one record per frame in HBM).  Plain data, no pointers.
 struct FrameParams {
+  uint8_t coeff_probs[4][8][3][11];      // this frame's token probabilities (first: 16-byte aligned in a ParseJob)
   uint32_t first_off, first_size;        // first partition: byte range inside the frame (uncompressed_chunk.cc:117-130)
   uint32_t bd_bitpos;                    // boolean decoder hand-over at the first macroblock header (see BoolState)
   uint8_t bd_range, bd_active;
@@ -67,8 +68,10 @@ struct FrameParams {
   int16_t seg_level[4];                  // loop-filter level per segment before the per-macroblock adjustments (Q3: unclamped)
   uint8_t y_mode_probs[4], uv_mode_probs[3], mv_probs[2][19];
   uint8_t pad[3];
-  uint8_t coeff_probs[4][8][3][11];      // this frame's token probabilities
 };
+static_assert( sizeof( FrameParams ) % 4 == 0, "FrameParams is copied as words" );
+
+
 
 // Arithmetic-decoder state in a window-independent form.  The window of a VP8 boolean decoder is "8 active bits that
 // have been through the subtractions" followed by raw stream bits that nothing has touched yet (a subtraction of
@@ -195,6 +198,17 @@ AA_HD inline uint8_t mb_lf_level( const FrameParams & fp, unsigned segment_id, u
     else level += fp.fadj_mode[2];
   }
   return static_cast<uint8_t>( level <= 0 ? 0 : ( level > 63 ? 63 : level ) );
+}
+
+// One macroblock of the segment-map pass that follows a device parse (frames of a stream in order): a frame that updates
+// the map publishes its ids, a frame that does not inherits them (and only now learns its loop-filter levels).
+AA_HD inline void segment_fixup( const FrameParams & fp, aa_mb_info & mb, uint8_t & map )
+{
+  if ( fp.seg_update_map ) map = mb.segment_id;
+  else {
+    mb.segment_id = map;
+    mb.lf_level = mb_lf_level( fp, map, mb.ref_frame, mb.y_mode );
+  }
 }
 
 AA_HD inline bool mv_flipped( const FrameParams & fp, unsigned ref_frame )    // motion_vectors_flipped_, macroblock.cc:464-465

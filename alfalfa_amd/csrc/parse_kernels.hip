@@ -1,0 +1,129 @@
+// Device-side entropy decode: the reference's HOT LOOP #1 -- Frame::parse_macroblock_headers and
+// Frame::parse_tokens (frame.cc:95-137) over BoolDecoder (bool_decoder.hh:45-120) -- with one GPU lane per arithmetic-coded
+// chain.  A VP8 partition is strictly serial, so the parallelism is across (stream, frame, partition kind): the host runs
+// only the frame-header pre-pass (Parser::parse_header, ~1 k bools per frame, serial across the frames of a stream because
+// of the persistent probability tables); everything per macroblock happens here, records written straight into HBM in the
+// layout the reconstruction kernels read.
+//
+//   k_parse_mb_headers  one lane per frame: first partition behind the frame header -> aa_mb_info (modes, motion vectors,
+//                       segment, loop-filter level), the flags byte array the token lanes read, intra row bitmasks.
+//                       The code is parse_mb_header() of parse_common.hh, the same statements the host parser runs.
+//   k_segment_fixup     only for streams that use segmentation: walks the frames of a stream in order, maintains the persistent
+//                       segment map and gives frames that inherit it their ids and loop-filter levels.
+//   k_parse_tokens      one lane per frame: DCT partitions -> coefficient blocks, nz_mask, coeff_index, flags.  Flat state
+//                       machine, one bool per step (tok_fsm.hh).
+//
+// A lane is latency-bound (dependent ALU chain + one LDS read per bool), not throughput-bound: what makes this fast is the
+// number of chains in flight (hundreds of streams x frames), which is why the kernels use few lanes per wave (divergent
+// events -- macroblock / row boundaries -- then stall few neighbours) and spread over as many SIMDs as there are chains.
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+#include "tok_fsm.hh"
+
+namespace {
+
+using aa::ParseJob;
+
+__global__ __launch_bounds__( 64 ) void k_parse_mb_headers( const ParseJob * jobs, int n, int lanes )
+{
+  const int lane = threadIdx.x;
+  const int j = blockIdx.x * lanes + lane;
+  if ( lane >= lanes || j >= n ) return;
+  const ParseJob & J = jobs[j];
+  const aa::FrameParams & fp = J.fp;
+  aa::BoolReader32 bd;
+  aa::BoolState st; st.bitpos = fp.bd_bitpos; st.range = fp.bd_range; st.active = fp.bd_active;
+  bd.resume( J.data + fp.first_off, fp.first_size, st );
+  const unsigned mbw = fp.mbw, mbh = fp.mbh;
+  const unsigned words_per_row = ( mbw + 63 ) / 64;
+  uint32_t intra = 0, split = 0;
+  unsigned mi = 0;
+  for ( unsigned row = 0; row < mbh; row++ ) {
+    unsigned long long word = 0;
+    for ( unsigned col = 0; col < mbw; col++, mi++ ) {
+      const uint8_t flags = aa::parse_mb_header( bd, fp, J.mbs, mi, col, row, static_cast<uint8_t *>( nullptr ) );
+      J.mbflags[mi] = flags;
+      if ( !( flags & AA_MB_INTER ) ) { intra++; word |= 1ull << ( col & 63 ); }
+      else if ( J.mbs[mi].y_mode == aa::SPLITMV ) split = 1;
+      if ( ( col & 63 ) == 63 || col + 1 == mbw ) { J.intra_rows[row * words_per_row + ( col >> 6 )] = word; word = 0; }
+    }
+  }
+  J.summary->num_intra_mbs = intra;
+  J.summary->has_split = split;
+}
+
+__global__ __launch_bounds__( 256 ) void k_segment_fixup( const ParseJob * jobs, const aa_seg_stream * streams, const uint32_t * order )
+{
+  const aa_seg_stream s = streams[blockIdx.x];
+  for ( uint32_t k = 0; k < s.count; k++ ) {
+    const uint32_t o = order[s.first + k];
+    const ParseJob & J = jobs[o & 0x7FFFFFFFu];
+    if ( !J.fp.seg_enabled ) continue;
+    if ( o >> 31 ) {                                    // the map restarts at all-3 (Segmentation ctor, decoder_state.hh:170-176)
+      for ( uint32_t mi = threadIdx.x; mi < J.nmb; mi += blockDim.x ) s.map[mi] = 3;
+      __syncthreads();
+    }
+    for ( uint32_t mi = threadIdx.x; mi < J.nmb; mi += blockDim.x ) aa::segment_fixup( J.fp, J.mbs[mi], s.map[mi] );
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__( 64 ) void k_parse_tokens( const ParseJob * jobs, int n, int lanes, uint32_t lane_bytes )
+{
+  extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t smem[];
+  const int lane = threadIdx.x;
+  const int j = blockIdx.x * lanes + lane;
+  const bool active = lane < lanes && j < n;
+  uint8_t * lds = smem + static_cast<uint32_t>( active ? lane : 0 ) * lane_bytes;
+  aa::tok::Lane L;
+  aa::tok::Frame F = aa::tok::frame_of( &jobs[active ? j : 0] );
+  L.st = aa::tok::ST_DONE;
+  L.pend_wpos = L.pend_mwpos = aa::tok::kNoPend;
+  if ( active ) aa::tok::begin_frame( L, lds, F );
+  for ( ;; ) {
+    if ( active ) aa::tok::top_up( L, lds, F );
+    if ( !__any( L.st != aa::tok::ST_DONE ) ) break;
+    for ( uint32_t it = 0; it < aa::tok::kPeriod; it++ ) aa::tok::step( L, lds, F );
+  }
+}
+
+} // namespace
+
+namespace aa {
+
+static int parse_lanes()
+{
+  static const int lanes = [] {
+    const char * e = getenv( "ALFALFA_AMD_PARSE_LANES" );
+    const int v = e ? atoi( e ) : 16;
+    return v < 1 ? 1 : ( v > 64 ? 64 : v );
+  }();
+  return lanes;
+}
+
+int launch_parse_mb_headers( const ParseJob * jobs, int n, void * stream )
+{
+  const int lanes = parse_lanes();
+  hipLaunchKernelGGL( k_parse_mb_headers, dim3( ( n + lanes - 1 ) / lanes ), dim3( 64 ), 0, static_cast<hipStream_t>( stream ), jobs, n, lanes );
+  return static_cast<int>( hipGetLastError() );
+}
+
+int launch_segment_fixup( const ParseJob * jobs, const aa_seg_stream * streams, int n_streams, const uint32_t * order, void * stream )
+{
+  hipLaunchKernelGGL( k_segment_fixup, dim3( n_streams ), dim3( 256 ), 0, static_cast<hipStream_t>( stream ), jobs, streams, order );
+  return static_cast<int>( hipGetLastError() );
+}
+
+int launch_parse_tokens( const ParseJob * jobs, int n, int max_mbw, void * stream )
+{
+  const uint32_t lane_bytes = tok::lane_lds_bytes( static_cast<uint32_t>( max_mbw ) );
+  int lanes = parse_lanes();
+  if ( static_cast<uint32_t>( lanes ) * lane_bytes > 65536u ) lanes = static_cast<int>( 65536u / lane_bytes );
+  if ( lanes < 1 ) return static_cast<int>( hipErrorInvalidValue );
+  hipLaunchKernelGGL( k_parse_tokens, dim3( ( n + lanes - 1 ) / lanes ), dim3( 64 ), static_cast<size_t>( lanes ) * lane_bytes,
+                      static_cast<hipStream_t>( stream ), jobs, n, lanes, lane_bytes );
+  return static_cast<int>( hipGetLastError() );
+}
+
+} // namespace aa

@@ -1,0 +1,115 @@
+// Test harness (not product code): replays the DEVICE parse algorithm on the host, one lane at a time, so that the state
+// machine of alfalfa_amd/csrc/tok_fsm.hh and the 32-bit boolean decoder of parse_common.hh can be checked against the host
+// parser without a GPU.  Built by tests/test_fsm_sim.py with plain g++ from the product's own sources:
+//   g++ -shared fsm_sim.cc ../../alfalfa_amd/csrc/parser.cpp
+// It follows parse_kernels.hip statement for statement: header pre-pass (Parser::parse_header, the real product code),
+// k_parse_mb_headers' loop, k_segment_fixup's loop, k_parse_tokens' loop.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../alfalfa_amd/csrc/parser.hh"
+#include "../../alfalfa_amd/csrc/tok_fsm.hh"
+
+namespace {
+struct Sim {
+  aa::Parser parser;
+  std::vector<uint8_t> segmap;     // the stream's persistent segment map as the device keeps it
+  Sim( uint16_t w, uint16_t h ) : parser( w, h ), segmap( size_t( parser.mb_width() ) * parser.mb_height(), 3 ) {}
+};
+void * aligned( size_t bytes ) { void * p = nullptr; if ( posix_memalign( &p, 256, bytes ? bytes : 256 ) ) return nullptr; std::memset( p, 0xA5, bytes ); return p; }
+}
+
+extern "C" {
+
+void * fsm_sim_create( uint16_t w, uint16_t h ) { return new Sim( w, h ); }
+void fsm_sim_destroy( void * s ) { delete static_cast<Sim *>( s ); }
+
+// -> 0 ok, else the aa_status of the header pre-pass.  mbs: nmb records; coeffs: 25*nmb+1 blocks; steps: diagnostics
+int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_header * hdr, aa_mb_info * mbs, int16_t * coeffs,
+                   uint32_t * steps )
+{
+  Sim & S = *static_cast<Sim *>( handle );
+  aa::ParseJob J;
+  std::memset( &J, 0, sizeof J );
+  try { S.parser.parse_header( data, size, *hdr, J.fp ); }
+  catch ( const aa::ParseError & e ) { return e.code; }
+  const uint32_t nmb = uint32_t( J.fp.mbw ) * J.fp.mbh;
+  // device buffers as the runtime lays them out: 16-byte aligned, padded, garbage-filled
+  J.size = uint32_t( size ); J.data_padded = ( J.size + 15 ) & ~15u;
+  uint8_t * dev_data = static_cast<uint8_t *>( aligned( J.data_padded ) );
+  std::memcpy( dev_data, data, size );
+  J.data = dev_data;
+  J.nmb = nmb; J.flags_padded = ( nmb + 15 ) & ~15u;
+  J.mbflags = static_cast<uint8_t *>( aligned( J.flags_padded ) );
+  J.mbs = static_cast<aa_mb_info *>( aligned( nmb * sizeof( aa_mb_info ) ) );
+  J.coeffs = static_cast<int16_t *>( aligned( ( size_t( nmb ) * 25 + 1 ) * 32 ) );
+  const unsigned words_per_row = ( J.fp.mbw + 63 ) / 64;
+  J.intra_rows = static_cast<unsigned long long *>( aligned( size_t( words_per_row ) * J.fp.mbh * 8 ) );
+  aa::FrameSummary sum; std::memset( &sum, 0, sizeof sum );
+  J.summary = &sum;
+
+  // ---- k_parse_mb_headers ----
+  {
+    aa::BoolReader32 bd;
+    aa::BoolState st; st.bitpos = J.fp.bd_bitpos; st.range = J.fp.bd_range; st.active = J.fp.bd_active;
+    bd.resume( J.data + J.fp.first_off, J.fp.first_size, st );
+    unsigned mi = 0; uint32_t intra = 0, split = 0;
+    for ( unsigned row = 0; row < J.fp.mbh; row++ ) {
+      unsigned long long word = 0;
+      for ( unsigned col = 0; col < J.fp.mbw; col++, mi++ ) {
+        const uint8_t flags = aa::parse_mb_header( bd, J.fp, J.mbs, mi, col, row, static_cast<uint8_t *>( nullptr ) );
+        J.mbflags[mi] = flags;
+        if ( !( flags & AA_MB_INTER ) ) { intra++; word |= 1ull << ( col & 63 ); }
+        else if ( J.mbs[mi].y_mode == aa::SPLITMV ) split = 1;
+        if ( ( col & 63 ) == 63 || col + 1 == J.fp.mbw ) { J.intra_rows[row * words_per_row + ( col >> 6 )] = word; word = 0; }
+      }
+    }
+    sum.num_intra_mbs = intra; sum.has_split = split;
+  }
+  // ---- k_segment_fixup ----
+  if ( J.fp.seg_enabled ) {
+    if ( S.parser.segment_map_reset() ) std::memset( S.segmap.data(), 3, S.segmap.size() );
+    for ( uint32_t mi = 0; mi < nmb; mi++ ) aa::segment_fixup( J.fp, J.mbs[mi], S.segmap[mi] );
+  }
+  // ---- k_parse_tokens ----
+  {
+    std::vector<uint8_t> lds_store( aa::tok::lane_lds_bytes( J.fp.mbw ) + 16 );
+    uint8_t * lds = reinterpret_cast<uint8_t *>( ( reinterpret_cast<uintptr_t>( lds_store.data() ) + 15 ) & ~uintptr_t( 15 ) );
+    std::memset( lds, 0xA5, aa::tok::lane_lds_bytes( J.fp.mbw ) );
+    aa::tok::Lane L;
+    std::memset( &L, 0xA5, sizeof L );
+    aa::tok::Frame F = aa::tok::frame_of( &J );
+    L.st = aa::tok::ST_DONE; L.pend_wpos = L.pend_mwpos = aa::tok::kNoPend;
+    aa::tok::begin_frame( L, lds, F );
+    for ( ;; ) {
+      aa::tok::top_up( L, lds, F );
+      if ( L.st == aa::tok::ST_DONE ) break;
+      for ( uint32_t it = 0; it < aa::tok::kPeriod; it++ ) aa::tok::step( L, lds, F );
+    }
+  }
+  hdr->num_coeff_blocks = sum.num_coeff_blocks;
+  hdr->num_intra_mbs = sum.num_intra_mbs;
+  hdr->has_intra_mb = sum.num_intra_mbs != 0;
+  if ( steps ) *steps = sum.steps;
+  std::memcpy( mbs, J.mbs, nmb * sizeof( aa_mb_info ) );
+  std::memcpy( coeffs, J.coeffs, size_t( sum.num_coeff_blocks ) * 32 );
+  // the intra row masks must say what the records say
+  int bad = 0;
+  for ( unsigned row = 0; row < J.fp.mbh; row++ ) for ( unsigned col = 0; col < J.fp.mbw; col++ ) {
+    const bool bit = ( J.intra_rows[row * words_per_row + ( col >> 6 )] >> ( col & 63 ) ) & 1;
+    if ( bit != !( J.mbs[row * J.fp.mbw + col].flags & AA_MB_INTER ) ) bad = 1;
+  }
+  free( dev_data ); free( J.mbflags ); free( J.mbs ); free( J.coeffs ); free( J.intra_rows );
+  return bad ? 100 : 0;
+}
+
+// persistent state for comparison with the host parser's
+void fsm_sim_segmap( void * handle, uint8_t * out ) { Sim & S = *static_cast<Sim *>( handle ); std::memcpy( out, S.segmap.data(), S.segmap.size() ); }
+void fsm_sim_probs( void * handle, uint8_t * out )
+{
+  const aa::ProbTables & t = static_cast<Sim *>( handle )->parser.probs();
+  std::memcpy( out, t.coeff, 1056 ); std::memcpy( out + 1056, t.y_mode, 4 ); std::memcpy( out + 1060, t.uv_mode, 3 ); std::memcpy( out + 1063, t.mv, 38 );
+}
+
+} // extern "C"

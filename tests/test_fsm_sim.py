@@ -1,0 +1,110 @@
+"""The DEVICE parse algorithm replayed on the host (tests/cpp/fsm_sim.cc: the same parse_common.hh / tok_fsm.hh statements
+the GPU lanes run, one lane at a time) against the product's host parser: every macroblock record and every coefficient
+block byte for byte, on the golden streams, the synthetic feature streams (SPLITMV, golden/altref, segmentation with and
+without map updates, 1-8 partitions, ...) and truncated frames.  CPU only; the GPU run of the same comparison is
+tests/test_gpu_device_parse.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import alfalfa_amd as aa
+from alfalfa_amd import capi
+from conftest import GOLDEN, ROOT, golden_frames
+
+BUILD = os.path.join(ROOT, "tests", "cpp", "_build")
+LIB = os.path.join(BUILD, "libfsm_sim.so")
+CSRC = os.path.join(ROOT, "alfalfa_amd", "csrc")
+
+
+def sim_lib():
+    srcs = [os.path.join(ROOT, "tests", "cpp", "fsm_sim.cc"), os.path.join(CSRC, "parser.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("tok_fsm.hh", "parse_common.hh", "parser.hh", "bool_reader.hh")]
+    os.makedirs(BUILD, exist_ok=True)
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wextra", "-fPIC", "-shared"] + srcs + ["-o", LIB], check=True)
+    L = C.CDLL(LIB)
+    L.fsm_sim_create.restype = C.c_void_p
+    L.fsm_sim_create.argtypes = [C.c_uint16, C.c_uint16]
+    L.fsm_sim_destroy.argtypes = [C.c_void_p]
+    L.fsm_sim_frame.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(capi.FrameHeader), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+    L.fsm_sim_segmap.argtypes = [C.c_void_p, C.c_void_p]
+    L.fsm_sim_probs.argtypes = [C.c_void_p, C.c_void_p]
+    return L
+
+
+class Sim:
+    def __init__(self, w, h):
+        self.L = sim_lib()
+        self.h = self.L.fsm_sim_create(w, h)
+        self.mbw, self.mbh = (w + 15) // 16, (h + 15) // 16
+        n = self.mbw * self.mbh
+        self.mb = np.zeros(n, dtype=capi.MB_INFO_DTYPE)
+        self.cf = np.zeros((n * 25 + 1) * 16, dtype=np.int16)
+
+    def __del__(self):
+        self.L.fsm_sim_destroy(self.h)
+
+    def frame(self, data):
+        hdr, steps = capi.FrameHeader(), C.c_uint32()
+        rc = self.L.fsm_sim_frame(self.h, data, len(data), C.byref(hdr), self.mb.ctypes.data, self.cf.ctypes.data, C.byref(steps))
+        assert rc == 0, rc
+        h = hdr.as_dict()
+        return h, self.mb.copy(), self.cf[:h["num_coeff_blocks"] * 16].copy(), steps.value
+
+    def segmap(self):
+        out = np.zeros(self.mbw * self.mbh, np.uint8)
+        self.L.fsm_sim_segmap(self.h, out.ctypes.data)
+        return out
+
+    def probs(self):
+        out = np.zeros(1101, np.uint8)
+        self.L.fsm_sim_probs(self.h, out.ctypes.data)
+        return out
+
+
+def check_stream(w, h, frames):
+    host, sim = aa.Parser(w, h), Sim(w, h)
+    for i, fr in enumerate(frames):
+        hh, hmb, hcf = host.parse(fr)
+        sh, smb, scf, steps = sim.frame(fr)
+        assert sh == hh, (i, {k: (sh[k], hh[k]) for k in hh if sh[k] != hh[k]})
+        a, b = smb.view(np.uint8).reshape(-1, 80), hmb.reshape(-1).view(np.uint8).reshape(-1, 80)
+        if not (a == b).all():
+            bad = np.nonzero((a != b).any(axis=1))[0]
+            m = int(bad[0])
+            raise AssertionError("frame %d: %d macroblock records differ, first mb %d (col %d row %d): device-algorithm %r host %r"
+                                 % (i, len(bad), m, m % sim.mbw, m // sim.mbw, smb[m], hmb.reshape(-1)[m]))
+        assert (scf.reshape(-1, 16) == hcf).all(), "frame %d: coefficient blocks differ" % i
+        assert (sim.probs() == host.probs()).all()
+        if hh["segmentation_enabled"]:
+            assert (sim.segmap() == host.segmentation()["map"].reshape(-1)).all(), "frame %d: segment map" % i
+        assert steps > 0
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_device_algorithm_matches_host_parser_on_goldens(name):
+    check_stream(*golden_frames(name))
+
+
+@pytest.mark.parametrize("seed", list(range(200, 224)))
+def test_device_algorithm_matches_host_parser_on_synthetic_feature_streams(seed):
+    import vp8_synth
+    sizes = [(96, 80), (33, 17), (64, 64), (175, 143), (16, 16), (200, 48), (320, 176), (48, 256)]
+    w, h = sizes[seed % len(sizes)]
+    check_stream(w, h, vp8_synth.feature_stream(w, h, seed, 8).frames)
+
+
+@pytest.mark.parametrize("name", ["qcif_q30_lf24", "w200_q40_lf63s7", "qcif_allkey_q20"])
+def test_device_algorithm_matches_host_parser_on_truncated_frames(name):
+    from test_parser_vs_oracle import truncated
+    w, h, frames = golden_frames(name)
+    check_stream(w, h, truncated(frames))
+
+
+def test_device_algorithm_on_extreme_geometries():
+    import vp8_synth
+    for w, h, seed in ((16, 4096, 901), (4096, 16, 902), (24, 1000, 903), (2000, 32, 904)):
+        check_stream(w, h, vp8_synth.feature_stream(w, h, seed, 3).frames)
