@@ -38,10 +38,16 @@ class FrameHeader(C.Structure):
         return d
 
 
+class FrameIn(C.Structure):
+    _fields_ = [("stream", C.c_void_p), ("data", C.c_char_p), ("size", C.c_size_t)]
+
+
 class KernelStats(C.Structure):
     _fields_ = [("recon_inter_ms", C.c_double), ("recon_intra_ms", C.c_double), ("loopfilter_ms", C.c_double),
                 ("recon_inter_launches", C.c_uint64), ("recon_intra_launches", C.c_uint64),
-                ("loopfilter_launches", C.c_uint64), ("macroblocks", C.c_uint64)]
+                ("loopfilter_launches", C.c_uint64), ("macroblocks", C.c_uint64),
+                ("parse_headers_ms", C.c_double), ("parse_tokens_ms", C.c_double), ("parse_launches", C.c_uint64),
+                ("parsed_macroblocks", C.c_uint64)]
 
 
 class AlfalfaError(RuntimeError):
@@ -76,8 +82,11 @@ SYMBOLS = [
     ("aa_stream_upload", C.c_int, [_P]), ("aa_stream_release_staging", C.c_int, [_P]),
     ("aa_decode_batch", C.c_int, [_P, C.POINTER(_P), C.c_int, C.POINTER(C.c_int)]),
     ("aa_stream_decode", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("aa_submit_frames", C.c_int, [_P, C.POINTER(FrameIn), C.c_int, C.POINTER(C.c_int), C.c_int]),
+    ("aa_stream_frame_header", C.c_int, [_P, C.c_int, C.POINTER(FrameHeader)]),
+    ("aa_stream_read_records", C.c_int, [_P, C.c_int, _P, _P, C.c_size_t]),
     ("aa_stream_frame_count", C.c_int, [_P]), ("aa_stream_release_before", C.c_int, [_P, C.c_int]),
-    ("aa_stream_rewind", C.c_int, [_P]),
+    ("aa_stream_rewind", C.c_int, [_P]), ("aa_stream_rewind_to", C.c_int, [_P, C.c_int]),
     ("aa_stream_download", C.c_int, [_P, C.c_int, _P, _P, _P]),
     ("aa_stream_raster_device", C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     ("aa_stream_references", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

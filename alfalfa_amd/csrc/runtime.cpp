@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -23,11 +24,13 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/alfalfa_amd.h"
 #include "device_types.h"
 #include "parser.hh"
+#include "tok_fsm.hh"
 
 namespace {
 
@@ -51,6 +54,19 @@ struct Chunk {
   size_t capacity = 0, used = 0, uploaded = 0;
   size_t pinned_bytes = 0;    // size of the host allocation (capacity shrinks to `used` when the chunk is sealed)
   size_t dev_bytes = 0;       // size of the device piece
+  int live_frames = 0;        // frames whose records live here and have not been released
+};
+
+// One aa_submit_frames call: a pinned arena mirrored in HBM holding the parse jobs, the reconstruction job records, the
+// result summaries and the compressed frames themselves; the device parser writes each frame's records into that frame's own
+// record block.  Lives until the last of its frames is released.
+struct Batch {
+  uint8_t * host = nullptr, * dev = nullptr;
+  size_t host_bytes = 0, dev_bytes = 0;
+  int n = 0, live = 0;
+  hipEvent_t done = nullptr;                 // parse kernels finished and the summaries are back in `host`
+  bool done_seen = false;
+  size_t summaries_off = 0;
 };
 
 struct Slot {
@@ -69,6 +85,13 @@ struct FrameRec {
   std::vector<uint8_t> intra_diagonals;    // [d] != 0: diagonal d holds an intra MB
   bool has_split = false;                  // some macroblock is SPLITMV (handled by the one-macroblock-per-wave kernel)
   bool handle_held = true;
+  int chunk = -1;                          // host-parsed frame: index of the frame-store chunk holding its records
+  Batch * batch = nullptr;                 // device-parsed frame: its submit call ...
+  int batch_item = -1;                     // ... and its index there
+  bool summary_pending = false;            // counts (intra macroblocks, coefficient blocks, SPLITMV) not yet read back from the device parser
+  uint8_t * rec_block = nullptr;           // device-parsed frame: its record block in HBM
+  size_t rec_bytes = 0;
+  bool records_released = false;
 };
 
 } // namespace
@@ -79,8 +102,19 @@ struct aa_ctx {
   int device = 0;
   hipStream_t compute = nullptr, copy = nullptr;
   hipEvent_t upload_done = nullptr;
-  int live_streams = 0;        // aa_ctx_destroy is deferred until the last stream is gone (bindings may finalise in any order)
-  bool dying = false;
+  std::atomic<int> refs { 1 };   // the context handle + one per stream: freed by whoever drops the last (bindings may finalise in any order)
+  // device-side entropy decode: submit calls rotate over a few HIP streams so that the parse of one batch runs beside the
+  // parse of the next and beside reconstruction (a parse is a few thousand latency-bound chains, not a chip-filling kernel)
+  hipStream_t parse_streams[3] = { nullptr, nullptr, nullptr };
+  int next_parse_stream = 0;
+  hipEvent_t last_seg_batch = nullptr;  // segment-map passes of consecutive batches must run in order
+  // Device pieces given back while kernels that read them may still be queued: they become reusable once an event recorded
+  // on the compute stream after the release has fired ("epochs": one event per group of releases, recorded lazily).
+  struct PendingFree { uint8_t * p; size_t bytes; uint64_t epoch; };
+  std::vector<PendingFree> pending_free;
+  std::vector<std::pair<uint64_t, hipEvent_t>> epoch_events;   // closed epochs, oldest first
+  uint64_t open_epoch = 1;
+  bool open_epoch_used = false;
   bool profile = false;
   int schedule = 0;            // 0: row-pipelined persistent kernels (default), 1: one launch per 2:1 anti-diagonal
   int n_xcd = 1;               // XCDs workgroups land on (probed at creation); row kernels keep a unit on one XCD
@@ -107,6 +141,8 @@ struct aa_ctx {
 struct aa_stream {
   aa_ctx * ctx;
   aa::Parser parser;
+  uint8_t * dev_segmap = nullptr;   // persistent segment map in HBM (device-parsed frames), mb_width*mb_height bytes
+  bool segmap_on_device = false;    // which copy is current: the parser's (host) or dev_segmap
   uint32_t pw, ph;
   size_t plane_bytes[3], slot_bytes;
   std::vector<Chunk> chunks;
@@ -115,6 +151,7 @@ struct aa_stream {
   int cur_ref_slot[3];     // slot ids of last/golden/alt at PARSE time
   int cur_ref_frame[3];    // frame indices (for aa_stream_references)
   int next_submit = 0;     // device half progress
+  int first_live = 0;      // frames below this index are fully released (aa_stream_release_before scans from here)
   aa_stream( aa_ctx * c, uint16_t w, uint16_t h ) : ctx( c ), parser( w, h ) {}
 };
 
@@ -123,32 +160,73 @@ namespace {
 aa_status set_device( aa_ctx * ctx ) { HIP_TRY( hipSetDevice( ctx->device ) ); return AA_OK; }
 
 constexpr size_t kSlabBytes = size_t( 256 ) << 20;
+
+// pool_mu held.  Close the open epoch if anything was released in it (one event on the compute stream covers every launch made
+// before now, hence every launch made before those releases), then hand pieces of fired epochs to the free lists.
+void collect_pending( aa_ctx * ctx, bool wait_oldest )
+{
+  if ( ctx->open_epoch_used ) {
+    hipEvent_t e = nullptr;
+    if ( hipEventCreateWithFlags( &e, hipEventDisableTiming ) == hipSuccess && hipEventRecord( e, ctx->compute ) == hipSuccess ) {
+      ctx->epoch_events.emplace_back( ctx->open_epoch, e );
+      ctx->open_epoch++; ctx->open_epoch_used = false;
+    } else if ( e ) (void) hipEventDestroy( e );
+  }
+  uint64_t fired = 0;
+  while ( !ctx->epoch_events.empty() ) {
+    hipEvent_t e = ctx->epoch_events.front().second;
+    hipError_t q = hipEventQuery( e );
+    if ( q != hipSuccess && wait_oldest ) { q = hipEventSynchronize( e ); wait_oldest = false; }
+    if ( q != hipSuccess ) break;
+    fired = ctx->epoch_events.front().first;
+    (void) hipEventDestroy( e );
+    ctx->epoch_events.erase( ctx->epoch_events.begin() );
+  }
+  if ( !fired ) return;
+  size_t keep = 0;
+  for ( auto & pf : ctx->pending_free ) {
+    if ( pf.epoch <= fired ) ctx->dev_free[pf.bytes].push_back( pf.p );
+    else ctx->pending_free[keep++] = pf;
+  }
+  ctx->pending_free.resize( keep );
+}
+
 aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out )
 {
   bytes = align_up( bytes );
   std::lock_guard<std::mutex> g( ctx->pool_mu );
-  auto it = ctx->dev_free.find( bytes );
-  if ( it != ctx->dev_free.end() && !it->second.empty() ) { *out = it->second.back(); it->second.pop_back(); return AA_OK; }
-  if ( bytes > kSlabBytes / 2 ) {                 // big pieces get their own allocation (still recycled through the free list)
-    HIP_TRY( hipMalloc( reinterpret_cast<void **>( out ), bytes ) );
-    ctx->dev_slabs.push_back( *out );
-    return AA_OK;
+  for ( int attempt = 0; attempt < 3; attempt++ ) {
+    auto it = ctx->dev_free.find( bytes );
+    if ( it != ctx->dev_free.end() && !it->second.empty() ) { *out = it->second.back(); it->second.pop_back(); return AA_OK; }
+    if ( attempt == 0 && !ctx->pending_free.empty() ) { collect_pending( ctx, false ); continue; }
+    hipError_t e;
+    if ( bytes > kSlabBytes / 2 ) {                 // big pieces get their own allocation (still recycled through the free list)
+      e = hipMalloc( reinterpret_cast<void **>( out ), bytes );
+      if ( e == hipSuccess ) { ctx->dev_slabs.push_back( *out ); return AA_OK; }
+    } else {
+      if ( ctx->cur_slab && ctx->slab_used + bytes <= kSlabBytes ) { *out = ctx->cur_slab + ctx->slab_used; ctx->slab_used += bytes; return AA_OK; }
+      uint8_t * slab = nullptr;
+      e = hipMalloc( reinterpret_cast<void **>( &slab ), kSlabBytes );
+      if ( e == hipSuccess ) {
+        ctx->dev_slabs.push_back( slab ); ctx->cur_slab = slab; ctx->slab_used = bytes;
+        *out = slab;
+        return AA_OK;
+      }
+    }
+    // out of HBM: what was released but may still be read by queued kernels comes back once they have run
+    (void) hipGetLastError();
+    if ( attempt == 2 || ctx->pending_free.empty() ) return hip_fail( e, "hipMalloc (frame store)" );
+    collect_pending( ctx, true );
   }
-  if ( ctx->dev_slabs.empty() || ctx->slab_used + bytes > kSlabBytes ) {
-    uint8_t * slab = nullptr;
-    HIP_TRY( hipMalloc( reinterpret_cast<void **>( &slab ), kSlabBytes ) );
-    ctx->dev_slabs.push_back( slab ); ctx->slab_used = 0;
-    ctx->cur_slab = slab;
-  }
-  *out = ctx->cur_slab + ctx->slab_used;
-  ctx->slab_used += bytes;
-  return AA_OK;
+  return fail( AA_ERR_HIP, "device allocation failed" );
 }
-void dev_free( aa_ctx * ctx, uint8_t * p, size_t bytes )
+// `deferred`: kernels already queued may still read the piece
+void dev_free( aa_ctx * ctx, uint8_t * p, size_t bytes, bool deferred = false )
 {
   if ( !p ) return;
   std::lock_guard<std::mutex> g( ctx->pool_mu );
-  ctx->dev_free[align_up( bytes )].push_back( p );
+  if ( deferred ) { ctx->pending_free.push_back( { p, align_up( bytes ), ctx->open_epoch } ); ctx->open_epoch_used = true; }
+  else ctx->dev_free[align_up( bytes )].push_back( p );
 }
 
 aa_status alloc_slot( aa_stream * s, int * out )
@@ -172,7 +250,12 @@ void set_ref( aa_stream * s, int which, int slot, int frame )
 
 aa_status reserve( aa_stream * s, size_t bytes, Chunk ** out )
 {
-  if ( s->chunks.empty() || s->chunks.back().used + bytes > s->chunks.back().capacity ) {
+  if ( s->chunks.empty() || !s->chunks.back().dev || s->chunks.back().used + bytes > s->chunks.back().capacity ) {
+    if ( !s->chunks.empty() && s->chunks.back().dev && s->chunks.back().live_frames == 0 ) {   // every frame of the old tail is gone already
+      Chunk & t = s->chunks.back();
+      if ( t.host ) { std::lock_guard<std::mutex> g( s->ctx->pool_mu ); s->ctx->pinned_pool.emplace_back( t.host, t.pinned_bytes ); t.host = nullptr; }
+      dev_free( s->ctx, t.dev, t.dev_bytes, true ); t.dev = nullptr;
+    }
     Chunk c;
     c.capacity = std::max( kChunkBytes, align_up( bytes ) );
     {
@@ -201,7 +284,9 @@ void drain_profile( aa_ctx * ctx )
     if ( hipEventSynchronize( t.b ) == hipSuccess && hipEventElapsedTime( &ms, t.a, t.b ) == hipSuccess ) {
       if ( t.kind == 0 ) { ctx->stats.recon_inter_ms += ms; ctx->stats.recon_inter_launches++; }
       else if ( t.kind == 1 ) { ctx->stats.recon_intra_ms += ms; ctx->stats.recon_intra_launches++; }
-      else { ctx->stats.loopfilter_ms += ms; ctx->stats.loopfilter_launches++; }
+      else if ( t.kind == 2 ) { ctx->stats.loopfilter_ms += ms; ctx->stats.loopfilter_launches++; }
+      else if ( t.kind == 3 ) { ctx->stats.parse_headers_ms += ms; ctx->stats.parse_launches++; }
+      else ctx->stats.parse_tokens_ms += ms;
     }
     ctx->free_events.push_back( t.a ); ctx->free_events.push_back( t.b );
   }
@@ -228,11 +313,117 @@ aa_status zero_ws( aa_ctx * ctx, aa_sync_ws * ws, int frames, int max_mbh )
                            sizeof( aa_sync_ws ) - AA_SYNC_WS_ZERO_FROM + sizeof( int ) * size_t( frames ) * max_mbh, ctx->compute ) );
   return AA_OK;
 }
-struct LaunchTimer {
-  aa_ctx * ctx; int kind; hipEvent_t a = nullptr;
-  LaunchTimer( aa_ctx * c, int k ) : ctx( c ), kind( k ) { if ( ctx->profile ) { a = get_event( ctx ); (void) hipEventRecord( a, ctx->compute ); } }
-  ~LaunchTimer() { if ( ctx->profile ) { hipEvent_t b = get_event( ctx ); (void) hipEventRecord( b, ctx->compute ); ctx->pending.push_back( { a, b, kind } ); if ( ctx->pending.size() >= 8192 ) drain_profile( ctx ); } }
+struct LaunchTimer {     // events on the stream the kernel is launched on
+  aa_ctx * ctx; int kind; hipEvent_t a = nullptr; hipStream_t st;
+  LaunchTimer( aa_ctx * c, int k, hipStream_t on = nullptr ) : ctx( c ), kind( k ), st( on ? on : c->compute ) { if ( ctx->profile ) { a = get_event( ctx ); (void) hipEventRecord( a, st ); } }
+  ~LaunchTimer() { if ( ctx->profile ) { hipEvent_t b = get_event( ctx ); (void) hipEventRecord( b, st ); ctx->pending.push_back( { a, b, kind } ); if ( ctx->pending.size() >= 8192 ) drain_profile( ctx ); } }
 };
+
+} // namespace
+
+static uint8_t * slot_plane( aa_stream * s, int slot, int plane )
+{
+  uint8_t * p = s->slots[slot].dev;
+  if ( plane >= 1 ) p += s->plane_bytes[0];
+  if ( plane >= 2 ) p += s->plane_bytes[1];
+  return p;
+}
+
+namespace {
+
+// Give a frame's records back (device-parsed: its record block and its share of the batch arena; host-parsed: its share of
+// a frame-store chunk, freed when the chunk's last frame goes).  `deferred`: queued kernels may still read them.
+void release_records( aa_stream * s, FrameRec & f, bool deferred )
+{
+  if ( f.records_released ) return;
+  f.records_released = true;
+  aa_ctx * ctx = s->ctx;
+  if ( f.rec_block ) { dev_free( ctx, f.rec_block, f.rec_bytes, deferred ); f.rec_block = nullptr; }
+  if ( Batch * b = f.batch ) {
+    bool last;
+    { std::lock_guard<std::mutex> g( ctx->pool_mu ); last = --b->live == 0; }
+    if ( last ) {
+      if ( !b->done_seen ) (void) hipEventSynchronize( b->done );     // never parsed-and-forgotten while kernels still write
+      (void) hipEventDestroy( b->done );
+      { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); }
+      dev_free( ctx, b->dev, b->dev_bytes, deferred );
+      delete b;
+    }
+    f.batch = nullptr;
+  }
+  if ( f.chunk >= 0 && f.chunk < static_cast<int>( s->chunks.size() ) ) {
+    Chunk & c = s->chunks[f.chunk];
+    const bool is_tail = f.chunk + 1 == static_cast<int>( s->chunks.size() ) && c.host != nullptr;   // still being filled
+    if ( --c.live_frames == 0 && !is_tail && c.dev ) {
+      if ( c.host ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( c.host, c.pinned_bytes ); c.host = nullptr; }
+      dev_free( ctx, c.dev, c.dev_bytes, deferred ); c.dev = nullptr;
+    }
+  }
+  f.host_job = nullptr; f.dev_job = nullptr;
+}
+
+uint8_t * pinned_get( aa_ctx * ctx, size_t bytes, size_t * got )
+{
+  {
+    std::lock_guard<std::mutex> g( ctx->pool_mu );
+    auto & pool = ctx->pinned_pool;
+    for ( size_t i = 0; i < pool.size(); i++ )
+      if ( pool[i].second >= bytes && pool[i].second <= bytes + bytes / 2 ) {
+        uint8_t * p = pool[i].first; *got = pool[i].second;
+        pool[i] = pool.back(); pool.pop_back();
+        return p;
+      }
+  }
+  uint8_t * p = nullptr;
+  if ( hipHostMalloc( reinterpret_cast<void **>( &p ), bytes, hipHostMallocDefault ) != hipSuccess ) return nullptr;
+  *got = bytes;
+  return p;
+}
+
+// References bookkeeping of one appended frame: output slot, the rasters it predicts from, then Frame::copy_to on slot ids
+// (frame.cc:271-307).  Fills the reconstruction job record `job` (host copy) except the record pointers.
+aa_status place_frame( aa_stream * s, FrameRec & rec, aa_dev_frame * job )
+{
+  const aa_frame_header & h = rec.hdr;
+  int out_slot;
+  if ( aa_status st = alloc_slot( s, &out_slot ) ) return st;
+  retain( s, out_slot );   // the frame's own handle (RasterHandle returned to the caller)
+  rec.out_slot = out_slot;
+  std::memset( job, 0, sizeof *job );
+  for ( int p = 0; p < 3; p++ ) job->cur[p] = slot_plane( s, out_slot, p );
+  for ( int r = 0; r < 3; r++ ) for ( int p = 0; p < 3; p++ ) job->ref[r + 1][p] = slot_plane( s, s->cur_ref_slot[r], p );
+  std::memcpy( job->quant, h.quant, sizeof job->quant );
+  job->mbw = h.mb_width; job->mbh = h.mb_height;
+  job->key_frame = h.key_frame; job->loop_filter_level = h.loop_filter_level;
+  job->sharpness = h.sharpness_level; job->has_intra = h.has_intra_mb;
+
+  const int fi = static_cast<int>( s->frames.size() );
+  enum { LAST = 0, GOLDEN = 1, ALT = 2 };
+  if ( h.key_frame ) { for ( int i = 0; i < 3; i++ ) set_ref( s, i, out_slot, fi ); }
+  else {
+    if ( h.copy_buffer_to_alternate == 1 ) set_ref( s, ALT, s->cur_ref_slot[LAST], s->cur_ref_frame[LAST] );
+    else if ( h.copy_buffer_to_alternate == 2 ) set_ref( s, ALT, s->cur_ref_slot[GOLDEN], s->cur_ref_frame[GOLDEN] );
+    if ( h.copy_buffer_to_golden == 1 ) set_ref( s, GOLDEN, s->cur_ref_slot[LAST], s->cur_ref_frame[LAST] );
+    else if ( h.copy_buffer_to_golden == 2 ) set_ref( s, GOLDEN, s->cur_ref_slot[ALT], s->cur_ref_frame[ALT] );
+    if ( h.refresh_golden ) set_ref( s, GOLDEN, out_slot, fi );
+    if ( h.refresh_alternate ) set_ref( s, ALT, out_slot, fi );
+    if ( h.refresh_last ) set_ref( s, LAST, out_slot, fi );
+  }
+  for ( int i = 0; i < 3; i++ ) rec.ref_after[i] = s->cur_ref_frame[i];
+  return AA_OK;
+}
+
+// The persistent segment map has two homes: the host parser's (frames parsed by aa_stream_parse) and dev_segmap (frames
+// parsed on the device).  Whoever parsed last owns the current copy; the other side is refreshed on demand.
+aa_status segmap_to_host( aa_stream * s )
+{
+  if ( !s->segmap_on_device ) return AA_OK;
+  for ( auto ps : s->ctx->parse_streams ) HIP_TRY( hipStreamSynchronize( ps ) );
+  std::vector<uint8_t> & m = s->parser.segment_map();
+  HIP_TRY( hipMemcpy( m.data(), s->dev_segmap, m.size(), hipMemcpyDeviceToHost ) );
+  s->segmap_on_device = false;
+  return AA_OK;
+}
 
 } // namespace
 
@@ -354,6 +545,7 @@ aa_status aa_ctx_create( int device, aa_ctx ** out )
   HIP_TRY( hipStreamCreateWithFlags( &ctx->compute, hipStreamNonBlocking ) );
   HIP_TRY( hipStreamCreateWithFlags( &ctx->copy, hipStreamNonBlocking ) );
   HIP_TRY( hipEventCreateWithFlags( &ctx->upload_done, hipEventDisableTiming ) );
+  for ( auto & ps : ctx->parse_streams ) HIP_TRY( hipStreamCreateWithFlags( &ps, hipStreamNonBlocking ) );
   if ( const char * e = std::getenv( "ALFALFA_AMD_SCHEDULE" ) ) ctx->schedule = std::string( e ) == "diagonal" ? 1 : 0;
   // The row-pipelined kernels keep every unit on one XCD (per-XCD ticket queues indexed by the hardware XCC_ID): find
   // out which XCC ids workgroups of this device really land on.  They must be 0..n-1, each reached by a modest grid.
@@ -380,13 +572,15 @@ static void ctx_free( aa_ctx * ctx );
 void aa_ctx_destroy( aa_ctx * ctx )
 {
   if ( !ctx ) return;
-  if ( ctx->live_streams > 0 ) { ctx->dying = true; return; }
-  ctx_free( ctx );
+  if ( --ctx->refs == 0 ) ctx_free( ctx );
 }
 static void ctx_free( aa_ctx * ctx )
 {
   (void) hipSetDevice( ctx->device );
   (void) hipStreamSynchronize( ctx->compute ); (void) hipStreamSynchronize( ctx->copy );
+  for ( auto ps : ctx->parse_streams ) if ( ps ) { (void) hipStreamSynchronize( ps ); (void) hipStreamDestroy( ps ); }
+  for ( auto & ee : ctx->epoch_events ) (void) hipEventDestroy( ee.second );
+  if ( ctx->last_seg_batch ) (void) hipEventDestroy( ctx->last_seg_batch );
   drain_profile( ctx );
   for ( auto e : ctx->free_events ) (void) hipEventDestroy( e );
   (void) hipEventDestroy( ctx->upload_done );
@@ -427,6 +621,7 @@ aa_status aa_ctx_sync( aa_ctx * ctx )
   if ( !ctx ) return fail( AA_ERR_ARGUMENT, "null ctx" );
   if ( aa_status st = set_device( ctx ) ) return st;
   HIP_TRY( hipStreamSynchronize( ctx->copy ) );
+  for ( auto ps : ctx->parse_streams ) HIP_TRY( hipStreamSynchronize( ps ) );
   HIP_TRY( hipStreamSynchronize( ctx->compute ) );
   return check_watchdog( ctx );
 }
@@ -441,7 +636,7 @@ void * aa_ctx_copy_stream( aa_ctx * ctx ) { return ctx ? ctx->copy : nullptr; }
 aa_status aa_ctx_profile( aa_ctx * ctx, int enable )
 {
   if ( !ctx ) return fail( AA_ERR_ARGUMENT, "null ctx" );
-  if ( !enable ) { (void) hipStreamSynchronize( ctx->compute ); drain_profile( ctx ); }
+  if ( !enable ) { (void) hipStreamSynchronize( ctx->compute ); for ( auto ps : ctx->parse_streams ) (void) hipStreamSynchronize( ps ); drain_profile( ctx ); }
   ctx->profile = enable != 0;
   return AA_OK;
 }
@@ -449,6 +644,7 @@ aa_status aa_ctx_kernel_stats( aa_ctx * ctx, aa_kernel_stats * out, int reset )
 {
   if ( !ctx || !out ) return fail( AA_ERR_ARGUMENT, "null argument" );
   HIP_TRY( hipStreamSynchronize( ctx->compute ) );
+  for ( auto ps : ctx->parse_streams ) HIP_TRY( hipStreamSynchronize( ps ) );
   drain_profile( ctx );
   *out = ctx->stats;
   if ( reset ) ctx->stats = aa_kernel_stats {};
@@ -468,10 +664,13 @@ aa_status aa_stream_create( aa_ctx * ctx, uint16_t width, uint16_t height, aa_st
   // References(width, height): all three references alias one (blank) raster (decoder.cc:161-169)
   int slot;
   if ( aa_status st = alloc_slot( s.get(), &slot ) ) return st;
-  HIP_TRY( hipMemsetAsync( s->slots[slot].dev, 0, s->slot_bytes, ctx->compute ) );
+  if ( hipError_t e = hipMemsetAsync( s->slots[slot].dev, 0, s->slot_bytes, ctx->compute ) ) {
+    dev_free( ctx, s->slots[slot].dev, s->slot_bytes * kSlotBlock );
+    return hip_fail( e, "hipMemsetAsync (blank reference raster)" );
+  }
   for ( int i = 0; i < 3; i++ ) { s->cur_ref_slot[i] = -1; s->cur_ref_frame[i] = -1; }
   for ( int i = 0; i < 3; i++ ) set_ref( s.get(), i, slot, -1 );
-  ctx->live_streams++;
+  ctx->refs++;
   *out = s.release();
   return AA_OK;
 }
@@ -480,22 +679,17 @@ void aa_stream_destroy( aa_stream * s )
   if ( !s ) return;
   (void) hipSetDevice( s->ctx->device );
   (void) hipStreamSynchronize( s->ctx->compute ); (void) hipStreamSynchronize( s->ctx->copy );
+  for ( auto ps : s->ctx->parse_streams ) (void) hipStreamSynchronize( ps );
   for ( auto & c : s->chunks ) {
     if ( c.host ) { std::lock_guard<std::mutex> g( s->ctx->pool_mu ); s->ctx->pinned_pool.emplace_back( c.host, c.pinned_bytes ); }
     dev_free( s->ctx, c.dev, c.dev_bytes );
   }
+  for ( auto & f : s->frames ) release_records( s, f, false );
   for ( auto & sl : s->slots ) if ( sl.owns ) dev_free( s->ctx, sl.dev, s->slot_bytes * kSlotBlock );
+  dev_free( s->ctx, s->dev_segmap, size_t( s->parser.mb_width() ) * s->parser.mb_height() );
   aa_ctx * ctx = s->ctx;
   delete s;
-  if ( --ctx->live_streams == 0 && ctx->dying ) ctx_free( ctx );
-}
-
-static uint8_t * slot_plane( aa_stream * s, int slot, int plane )
-{
-  uint8_t * p = s->slots[slot].dev;
-  if ( plane >= 1 ) p += s->plane_bytes[0];
-  if ( plane >= 2 ) p += s->plane_bytes[1];
-  return p;
+  if ( --ctx->refs == 0 ) ctx_free( ctx );
 }
 
 aa_status aa_stream_parse( aa_stream * s, const uint8_t * data, size_t size, int * frame_index, aa_frame_header * hdr_out )
@@ -516,6 +710,7 @@ aa_status aa_stream_parse( aa_stream * s, const uint8_t * data, size_t size, int
   unsigned long long * intra_rows = reinterpret_cast<unsigned long long *>( c->host + off + job_bytes + mb_bytes );
   int16_t * coeffs = reinterpret_cast<int16_t *>( c->host + off + job_bytes + mb_bytes + rows_bytes );
 
+  if ( aa_status st = segmap_to_host( s ) ) return st;
   FrameRec rec;
   try { s->parser.parse( data, size, rec.hdr, mbs, coeffs ); }
   catch ( const aa::ParseError & e ) { return fail( e.code, e.message ); }
@@ -537,36 +732,15 @@ aa_status aa_stream_parse( aa_stream * s, const uint8_t * data, size_t size, int
     for ( size_t i = 0; i < nmb; i++ ) if ( mbs[i].y_mode == 9 /* SPLITMV */ ) { rec.has_split = true; break; }
 
   // raster slots: output + the References this frame predicts from; then Frame::copy_to on slot ids
-  int out_slot;
-  if ( aa_status st = alloc_slot( s, &out_slot ) ) return st;
-  retain( s, out_slot );   // the frame's own handle (RasterHandle returned to the caller)
-  rec.out_slot = out_slot;
-  std::memset( job, 0, sizeof *job );
-  for ( int p = 0; p < 3; p++ ) job->cur[p] = slot_plane( s, out_slot, p );
-  for ( int r = 0; r < 3; r++ ) for ( int p = 0; p < 3; p++ ) job->ref[r + 1][p] = slot_plane( s, s->cur_ref_slot[r], p );
+  if ( aa_status st = place_frame( s, rec, job ) ) return st;
   job->mbs = reinterpret_cast<const aa_mb_info *>( c->dev + off + job_bytes );
   job->intra_rows = reinterpret_cast<const unsigned long long *>( c->dev + off + job_bytes + mb_bytes );
   job->coeffs = reinterpret_cast<const int16_t *>( c->dev + off + job_bytes + mb_bytes + rows_bytes );
-  std::memcpy( job->quant, h.quant, sizeof job->quant );
-  job->mbw = h.mb_width; job->mbh = h.mb_height;
-  job->key_frame = h.key_frame; job->loop_filter_level = h.loop_filter_level;
-  job->sharpness = h.sharpness_level; job->has_intra = h.has_intra_mb;
   rec.host_job = job;
   rec.dev_job = reinterpret_cast<const aa_dev_frame *>( c->dev + off );
-
+  rec.chunk = static_cast<int>( c - s->chunks.data() );
+  c->live_frames++;
   const int fi = static_cast<int>( s->frames.size() );
-  enum { LAST = 0, GOLDEN = 1, ALT = 2 };
-  if ( h.key_frame ) { for ( int i = 0; i < 3; i++ ) set_ref( s, i, out_slot, fi ); }
-  else {
-    if ( h.copy_buffer_to_alternate == 1 ) set_ref( s, ALT, s->cur_ref_slot[LAST], s->cur_ref_frame[LAST] );
-    else if ( h.copy_buffer_to_alternate == 2 ) set_ref( s, ALT, s->cur_ref_slot[GOLDEN], s->cur_ref_frame[GOLDEN] );
-    if ( h.copy_buffer_to_golden == 1 ) set_ref( s, GOLDEN, s->cur_ref_slot[LAST], s->cur_ref_frame[LAST] );
-    else if ( h.copy_buffer_to_golden == 2 ) set_ref( s, GOLDEN, s->cur_ref_slot[ALT], s->cur_ref_frame[ALT] );
-    if ( h.refresh_golden ) set_ref( s, GOLDEN, out_slot, fi );
-    if ( h.refresh_alternate ) set_ref( s, ALT, out_slot, fi );
-    if ( h.refresh_last ) set_ref( s, LAST, out_slot, fi );
-  }
-  for ( int i = 0; i < 3; i++ ) rec.ref_after[i] = s->cur_ref_frame[i];
   s->frames.push_back( std::move( rec ) );
   if ( frame_index ) *frame_index = fi;
   if ( hdr_out ) *hdr_out = h;
@@ -607,6 +781,245 @@ aa_status aa_stream_release_staging( aa_stream * s )
   return AA_OK;
 }
 
+
+/* ---------------- device-side entropy decode ---------------- */
+namespace {
+struct SubmitItem {
+  aa_stream * s; const uint8_t * data; size_t size;
+  size_t data_off;          // in the batch arena
+  aa_status status = AA_OK; std::string error;
+  int frame_index = -1;
+  bool seg_enabled = false, seg_reset = false;
+};
+
+// one frame of one stream: header pre-pass on the host, compressed bytes into the pinned arena, record block + raster slot
+aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_host, aa_dev_frame * dframes_host )
+{
+  aa_stream * s = it.s;
+  aa_ctx * ctx = s->ctx;
+  aa::ParseJob & J = jobs_host[item];
+  FrameRec rec;
+  try { s->parser.parse_header( it.data, it.size, rec.hdr, J.fp ); }
+  catch ( const aa::ParseError & e ) { it.error = e.message; return e.code; }
+  it.seg_enabled = J.fp.seg_enabled; it.seg_reset = s->parser.segment_map_reset();
+  std::memcpy( b->host + it.data_off, it.data, it.size );
+
+  const uint32_t nmb = uint32_t( J.fp.mbw ) * J.fp.mbh;
+  const size_t mb_bytes = align_up( size_t( nmb ) * sizeof( aa_mb_info ) );
+  const size_t words_per_row = ( J.fp.mbw + 63 ) / 64;
+  const size_t rows_bytes = align_up( words_per_row * J.fp.mbh * sizeof( unsigned long long ) );
+  const uint32_t flags_padded = ( nmb + 15u ) & ~15u;
+  const size_t flags_bytes = align_up( flags_padded );
+  const size_t coeff_bytes = align_up( ( size_t( nmb ) * 25 + 1 ) * 32 );
+  rec.rec_bytes = mb_bytes + rows_bytes + flags_bytes + coeff_bytes;
+  if ( aa_status st = dev_alloc( ctx, rec.rec_bytes, &rec.rec_block ) ) { it.error = g_last_error; return st; }
+  uint8_t * blk = rec.rec_block;
+
+  J.data = b->dev + it.data_off;
+  J.size = static_cast<uint32_t>( it.size ); J.data_padded = ( J.size + 15u ) & ~15u;
+  J.nmb = nmb; J.flags_padded = flags_padded;
+  J.mbs = reinterpret_cast<aa_mb_info *>( blk );
+  J.intra_rows = reinterpret_cast<unsigned long long *>( blk + mb_bytes );
+  J.mbflags = blk + mb_bytes + rows_bytes;
+  J.coeffs = reinterpret_cast<int16_t *>( blk + mb_bytes + rows_bytes + flags_bytes );
+  J.summary = reinterpret_cast<aa::FrameSummary *>( b->dev + b->summaries_off ) + item;
+
+  aa_dev_frame * job = &dframes_host[item];
+  rec.hdr.has_intra_mb = 1;              // until the device parser has counted: the row masks say which macroblocks are intra
+  if ( aa_status st = place_frame( s, rec, job ) ) { it.error = g_last_error; dev_free( ctx, rec.rec_block, rec.rec_bytes ); return st; }
+  job->mbs = J.mbs; job->intra_rows = J.intra_rows; job->coeffs = J.coeffs;
+  rec.host_job = job;
+  rec.dev_job = reinterpret_cast<const aa_dev_frame *>( b->dev + ( reinterpret_cast<uint8_t *>( job ) - b->host ) );
+  rec.batch = b; rec.batch_item = item; rec.summary_pending = true;
+  it.frame_index = static_cast<int>( s->frames.size() );
+  s->frames.push_back( std::move( rec ) );
+  return AA_OK;
+}
+} // namespace
+
+aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int * frame_index_out, int threads )
+{
+  if ( !ctx || !frames || n <= 0 ) return fail( AA_ERR_ARGUMENT, "aa_submit_frames: bad argument" );
+  if ( aa_status st = set_device( ctx ) ) return st;
+  std::vector<SubmitItem> items( n );
+  // arena layout: parse jobs | reconstruction job records | summaries | segment-pass lists | compressed frames
+  const size_t jobs_bytes = align_up( size_t( n ) * sizeof( aa::ParseJob ) );
+  const size_t dframes_bytes = align_up( size_t( n ) * sizeof( aa_dev_frame ) );
+  const size_t sums_bytes = align_up( size_t( n ) * sizeof( aa::FrameSummary ) );
+  const size_t seg_bytes = align_up( size_t( n ) * ( sizeof( aa_seg_stream ) + sizeof( uint32_t ) ) );
+  size_t off = jobs_bytes + dframes_bytes + sums_bytes + seg_bytes;
+  std::map<aa_stream *, std::vector<int>> by_stream;
+  std::vector<aa_stream *> stream_order;
+  for ( int i = 0; i < n; i++ ) {
+    if ( !frames[i].stream || !frames[i].data || frames[i].stream->ctx != ctx ) return fail( AA_ERR_ARGUMENT, "aa_submit_frames: null frame or stream of another context" );
+    items[i].s = frames[i].stream; items[i].data = frames[i].data; items[i].size = frames[i].size;
+    items[i].data_off = off;
+    off += align_up( frames[i].size + 16 );
+    auto & v = by_stream[frames[i].stream];
+    if ( v.empty() ) stream_order.push_back( frames[i].stream );
+    v.push_back( i );
+  }
+  for ( aa_stream * s : stream_order )
+    if ( s->next_submit > static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_LOGIC, "aa_submit_frames: stream state is inconsistent" );
+
+  std::unique_ptr<Batch> b( new Batch );
+  const size_t arena = ( off + ( size_t( 16 ) << 20 ) - 1 ) & ~( ( size_t( 16 ) << 20 ) - 1 );
+  b->host = pinned_get( ctx, arena, &b->host_bytes );
+  if ( !b->host ) return fail( AA_ERR_HIP, "aa_submit_frames: pinned staging allocation failed" );
+  b->dev_bytes = arena;
+  if ( aa_status st = dev_alloc( ctx, arena, &b->dev ) ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); return st; }
+  b->n = n; b->summaries_off = jobs_bytes + dframes_bytes;
+  aa::ParseJob * jobs_host = reinterpret_cast<aa::ParseJob *>( b->host );
+  aa_dev_frame * dframes_host = reinterpret_cast<aa_dev_frame *>( b->host + jobs_bytes );
+  std::memset( b->host, 0, jobs_bytes + dframes_bytes + sums_bytes + seg_bytes );
+
+  // ---- host half, one worker per stream at a time (the header pre-pass is serial across the frames of a stream) ----
+  {
+    std::atomic<size_t> next { 0 };
+    auto work = [&]() {
+      (void) hipSetDevice( ctx->device );
+      for ( ;; ) {
+        const size_t k = next.fetch_add( 1 );
+        if ( k >= stream_order.size() ) return;
+        bool broken = false;
+        for ( int i : by_stream[stream_order[k]] ) {
+          SubmitItem & it = items[i];
+          if ( broken ) { it.status = AA_ERR_LOGIC; it.error = "an earlier frame of this stream in the same call failed"; continue; }
+          it.status = submit_one( b.get(), it, i, jobs_host, dframes_host );
+          if ( it.status != AA_OK ) broken = true;
+        }
+      }
+    };
+    int nt = threads > 0 ? threads : static_cast<int>( std::thread::hardware_concurrency() );
+    nt = std::max( 1, std::min<int>( { nt, static_cast<int>( stream_order.size() ), 256 } ) );
+    if ( nt == 1 ) work();
+    else {
+      std::vector<std::thread> pool;
+      for ( int t = 0; t < nt; t++ ) pool.emplace_back( work );
+      for ( auto & t : pool ) t.join();
+    }
+  }
+  aa_status first_error = AA_OK; std::string first_message;
+  int appended = 0, max_mbw = 0;
+  for ( int i = 0; i < n; i++ ) {
+    if ( frame_index_out ) frame_index_out[i] = items[i].frame_index;
+    if ( items[i].status == AA_OK ) { appended++; max_mbw = std::max<int>( max_mbw, jobs_host[i].fp.mbw ); }
+    else {
+      jobs_host[i].nmb = 0;                        // the kernels skip it
+      if ( first_error == AA_OK ) { first_error = items[i].status; first_message = items[i].error; }
+    }
+  }
+  if ( !appended ) {
+    { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); }
+    dev_free( ctx, b->dev, b->dev_bytes );
+    return fail( first_error, first_message );
+  }
+  b->live = appended;
+
+  // ---- segment-map pass lists (only streams that use segmentation in this batch) ----
+  aa_seg_stream * seg_streams = reinterpret_cast<aa_seg_stream *>( b->host + jobs_bytes + dframes_bytes + sums_bytes );
+  uint32_t * seg_order = reinterpret_cast<uint32_t *>( seg_streams + n );
+  int n_seg_streams = 0; uint32_t n_seg_order = 0;
+  hipStream_t ps = ctx->parse_streams[ctx->next_parse_stream];
+  ctx->next_parse_stream = ( ctx->next_parse_stream + 1 ) % 3;
+  for ( aa_stream * s : stream_order ) {
+    bool any = false;
+    for ( int i : by_stream[s] ) if ( items[i].status == AA_OK && items[i].seg_enabled ) any = true;
+    if ( !any && !s->segmap_on_device ) continue;
+    if ( !any ) continue;
+    const size_t map_bytes = size_t( s->parser.mb_width() ) * s->parser.mb_height();
+    if ( !s->dev_segmap ) if ( aa_status st = dev_alloc( ctx, map_bytes, &s->dev_segmap ) ) return st;
+    if ( !s->segmap_on_device ) {                  // the host parser owns the current map: hand it over
+      HIP_TRY( hipMemcpyAsync( s->dev_segmap, s->parser.segment_map().data(), map_bytes, hipMemcpyHostToDevice, ps ) );
+      HIP_TRY( hipStreamSynchronize( ps ) );
+      s->segmap_on_device = true;
+    }
+    aa_seg_stream & ss = seg_streams[n_seg_streams++];
+    ss.map = s->dev_segmap; ss.first = n_seg_order; ss.count = 0;
+    for ( int i : by_stream[s] ) if ( items[i].status == AA_OK ) { seg_order[n_seg_order++] = static_cast<uint32_t>( i ) | ( items[i].seg_reset ? 0x80000000u : 0u ); ss.count++; }
+  }
+
+  // ---- device half: arena to HBM on the copy stream, then the three parse kernels on one of the parse streams ----
+  HIP_TRY( hipEventCreateWithFlags( &b->done, hipEventDisableTiming ) );
+  HIP_TRY( hipMemcpyAsync( b->dev, b->host, off, hipMemcpyHostToDevice, ctx->copy ) );
+  hipEvent_t up = get_event( ctx );
+  HIP_TRY( hipEventRecord( up, ctx->copy ) );
+  HIP_TRY( hipStreamWaitEvent( ps, up, 0 ) );
+  ctx->free_events.push_back( up );
+  const aa::ParseJob * jobs_dev = reinterpret_cast<const aa::ParseJob *>( b->dev );
+  {
+    LaunchTimer t( ctx, 3, ps );
+    if ( int e = aa::launch_parse_mb_headers( jobs_dev, n, ps ) ) return hip_fail( static_cast<hipError_t>( e ), "k_parse_mb_headers" );
+  }
+  if ( n_seg_streams ) {
+    if ( ctx->last_seg_batch ) HIP_TRY( hipStreamWaitEvent( ps, ctx->last_seg_batch, 0 ) );
+    const uint8_t * segs_dev = b->dev + jobs_bytes + dframes_bytes + sums_bytes;
+    if ( int e = aa::launch_segment_fixup( jobs_dev, reinterpret_cast<const aa_seg_stream *>( segs_dev ), n_seg_streams,
+                                           reinterpret_cast<const uint32_t *>( segs_dev + size_t( n ) * sizeof( aa_seg_stream ) ), ps ) )
+      return hip_fail( static_cast<hipError_t>( e ), "k_segment_fixup" );
+    if ( !ctx->last_seg_batch ) HIP_TRY( hipEventCreateWithFlags( &ctx->last_seg_batch, hipEventDisableTiming ) );
+    HIP_TRY( hipEventRecord( ctx->last_seg_batch, ps ) );
+  }
+  {
+    LaunchTimer t( ctx, 4, ps );
+    if ( int e = aa::launch_parse_tokens( jobs_dev, n, max_mbw, ps ) ) return hip_fail( static_cast<hipError_t>( e ), "k_parse_tokens" );
+  }
+  for ( int i = 0; i < n; i++ ) if ( items[i].status == AA_OK ) ctx->stats.parsed_macroblocks += jobs_host[i].nmb;
+  HIP_TRY( hipMemcpyAsync( b->host + b->summaries_off, b->dev + b->summaries_off, size_t( n ) * sizeof( aa::FrameSummary ), hipMemcpyDeviceToHost, ps ) );
+  HIP_TRY( hipEventRecord( b->done, ps ) );
+  b.release();
+  if ( first_error != AA_OK ) return fail( first_error, first_message );
+  return AA_OK;
+}
+
+// counts the device parser produced (intra macroblocks, coefficient blocks, SPLITMV) -> the frame's header; waits for the parse
+static aa_status resolve_summary( aa_stream * s, FrameRec & r )
+{
+  if ( !r.summary_pending ) return AA_OK;
+  Batch * b = r.batch;
+  if ( !b ) return fail( AA_ERR_LOGIC, "frame records were released before the frame was decoded" );
+  if ( !b->done_seen ) { HIP_TRY( hipEventSynchronize( b->done ) ); b->done_seen = true; }
+  const aa::FrameSummary & sum = reinterpret_cast<const aa::FrameSummary *>( b->host + b->summaries_off )[r.batch_item];
+  if ( sum.steps == 0xFFFFFFFFu ) return fail( AA_ERR_HIP, "device parser: a token lane exceeded the step bound of its frame size (records are not valid)" );
+  r.hdr.num_coeff_blocks = sum.num_coeff_blocks;
+  r.hdr.num_intra_mbs = sum.num_intra_mbs;
+  r.hdr.has_intra_mb = sum.num_intra_mbs != 0;
+  r.has_split = sum.has_split != 0;
+  r.intra_diagonals.assign( r.hdr.mb_width + 2 * ( r.hdr.mb_height - 1 ), r.hdr.has_intra_mb ? 1 : 0 );   // diagonal schedule: all of them
+  r.summary_pending = false;
+  (void) s;
+  return AA_OK;
+}
+
+aa_status aa_stream_frame_header( aa_stream * s, int fi, aa_frame_header * out )
+{
+  if ( !s || !out || fi < 0 || fi >= static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_ARGUMENT, "aa_stream_frame_header: bad argument" );
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  if ( aa_status st = resolve_summary( s, s->frames[fi] ) ) return st;
+  *out = s->frames[fi].hdr;
+  return AA_OK;
+}
+
+/* Debug / test view of a frame's parsed records as they sit in HBM (host- or device-parsed alike). */
+aa_status aa_stream_read_records( aa_stream * s, int fi, aa_mb_info * mb_out, int16_t * coeff_out, size_t coeff_capacity_blocks )
+{
+  if ( !s || fi < 0 || fi >= static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_ARGUMENT, "aa_stream_read_records: bad argument" );
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  FrameRec & r = s->frames[fi];
+  if ( r.records_released ) return fail( AA_ERR_LOGIC, "aa_stream_read_records: frame records were released" );
+  if ( aa_status st = resolve_summary( s, r ) ) return st;
+  if ( aa_status st = aa_stream_upload( s ) ) return st;
+  HIP_TRY( hipStreamSynchronize( s->ctx->copy ) );
+  aa_dev_frame job;
+  HIP_TRY( hipMemcpy( &job, r.dev_job, sizeof job, hipMemcpyDeviceToHost ) );
+  if ( mb_out ) HIP_TRY( hipMemcpy( mb_out, job.mbs, size_t( r.hdr.num_macroblocks ) * sizeof( aa_mb_info ), hipMemcpyDeviceToHost ) );
+  if ( coeff_out ) {
+    if ( coeff_capacity_blocks < r.hdr.num_coeff_blocks ) return fail( AA_ERR_ARGUMENT, "aa_stream_read_records: coefficient buffer too small" );
+    HIP_TRY( hipMemcpy( coeff_out, job.coeffs, size_t( r.hdr.num_coeff_blocks ) * 32, hipMemcpyDeviceToHost ) );
+  }
+  return AA_OK;
+}
+
 aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, const int * frame_index )
 {
   if ( !ctx || !streams || !frame_index || n <= 0 ) return fail( AA_ERR_ARGUMENT, "aa_decode_batch: bad argument" );
@@ -627,6 +1040,13 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
   }
   for ( int i = 0; i < n; i++ ) if ( aa_status st = aa_stream_upload( streams[i] ) ) return st;
   for ( int i = 0; i < n; i++ ) {
+    if ( streams[i]->frames[frame_index[i]].records_released ) return fail( AA_ERR_LOGIC, "aa_decode_batch: frame records were released" );
+    if ( aa_status st = resolve_summary( streams[i], streams[i]->frames[frame_index[i]] ) ) return st;
+  }
+  // frames count as submitted only once every launch of the batch has been queued (a failed launch must not leave them
+  // looking decoded)
+  struct Advance { aa_stream * const * streams; int n; bool ok = false; ~Advance() { if ( ok ) for ( int i = 0; i < n; i++ ) streams[i]->next_submit++; } } advance { streams, n };
+  for ( int i = 0; i < n; i++ ) {
     aa_stream * s = streams[i];
     const FrameRec & r = s->frames[frame_index[i]];
     const aa_frame_header & h = r.hdr;
@@ -637,7 +1057,6 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
     max_mbs = std::max<unsigned>( max_mbs, h.num_macroblocks );
     max_mbw = std::max<int>( max_mbw, h.mb_width ); max_mbh = std::max<int>( max_mbh, h.mb_height );
     total_mbs += h.num_macroblocks;
-    s->next_submit++;
   }
   ctx->stats.macroblocks += total_mbs;
 
@@ -716,6 +1135,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
       }
       if ( aa_status st = launch() ) return st;
     }
+    advance.ok = true;
     return AA_OK;
   }
   // ---- ALFALFA_AMD_SCHEDULE=diagonal: the kernel boundary is the inter-workgroup synchronisation ----
@@ -742,6 +1162,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
       if ( aa_status st = check( e, "k_loopfilter" ) ) return st;
     }
   }
+  advance.ok = true;
   return AA_OK;
 }
 
@@ -762,15 +1183,34 @@ aa_status aa_stream_release_before( aa_stream * s, int first_kept )
 {
   if ( !s ) return fail( AA_ERR_ARGUMENT, "null stream" );
   const int n = std::min<int>( first_kept, static_cast<int>( s->frames.size() ) );
-  for ( int i = 0; i < n; i++ ) if ( s->frames[i].handle_held ) { s->frames[i].handle_held = false; release( s, s->frames[i].out_slot ); }
+  for ( int i = s->first_live; i < n; i++ ) {
+    FrameRec & f = s->frames[i];
+    if ( f.handle_held ) { f.handle_held = false; release( s, f.out_slot ); }
+    if ( i < s->next_submit ) release_records( s, f, true );       // decoded: nothing will read its records again once queued kernels ran
+    std::vector<uint8_t>().swap( f.intra_diagonals );
+  }
+  while ( s->first_live < n && s->frames[s->first_live].records_released ) s->first_live++;
   return AA_OK;
 }
 
 aa_status aa_stream_rewind( aa_stream * s )
 {
   if ( !s ) return fail( AA_ERR_ARGUMENT, "null stream" );
-  for ( const auto & f : s->frames ) if ( !f.handle_held ) return fail( AA_ERR_LOGIC, "aa_stream_rewind: frames were released; slots may have been reused" );
+  for ( const auto & f : s->frames ) if ( !f.handle_held || f.records_released ) return fail( AA_ERR_LOGIC, "aa_stream_rewind: frames were released; slots may have been reused" );
   s->next_submit = 0;
+  return AA_OK;
+}
+
+aa_status aa_stream_rewind_to( aa_stream * s, int fi )
+{
+  if ( !s || fi < 0 || fi > static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_ARGUMENT, "aa_stream_rewind_to: bad argument" );
+  if ( fi > s->next_submit ) return fail( AA_ERR_LOGIC, "aa_stream_rewind_to: that frame has not been decoded yet" );
+  for ( size_t i = fi; i < s->frames.size(); i++ )
+    if ( !s->frames[i].handle_held || s->frames[i].records_released ) return fail( AA_ERR_LOGIC, "aa_stream_rewind_to: frames were released; slots may have been reused" );
+  if ( fi < static_cast<int>( s->frames.size() ) && fi > 0 && !s->frames[fi].hdr.key_frame )
+    for ( int r : s->frames[fi - 1].ref_after )
+      if ( r < 0 || !s->frames[r].handle_held ) return fail( AA_ERR_LOGIC, "aa_stream_rewind_to: a raster that frame predicts from was released" );
+  s->next_submit = fi;
   return AA_OK;
 }
 
@@ -821,9 +1261,17 @@ aa_status aa_stream_export_raster( aa_stream * s, int fi, void * y, void * u, vo
 }
 size_t aa_stream_state_size( const aa_stream * s ) { return s ? s->parser.state_size() : 0; }
 aa_status aa_stream_export_state( const aa_stream * s, uint8_t * buf, size_t capacity )
-{ return s ? export_state_common( s->parser, buf, capacity ) : fail( AA_ERR_ARGUMENT, "null stream" ); }
+{
+  if ( !s ) return fail( AA_ERR_ARGUMENT, "null stream" );
+  if ( aa_status st = segmap_to_host( const_cast<aa_stream *>( s ) ) ) return st;
+  return export_state_common( s->parser, buf, capacity );
+}
 aa_status aa_stream_import_state( aa_stream * s, const uint8_t * buf, size_t size )
-{ return s ? import_state_common( s->parser, buf, size ) : fail( AA_ERR_ARGUMENT, "null stream" ); }
+{
+  if ( !s ) return fail( AA_ERR_ARGUMENT, "null stream" );
+  if ( aa_status st = segmap_to_host( s ) ) return st;      // (also settles ownership: the imported map lives on the host side)
+  return import_state_common( s->parser, buf, size );
+}
 
 /* Decoder::serialize / Decoder::deserialize (decoder.cc:54-81): [DECODER][u32 len] DecoderState References, where
  * References = [REFERENCES][u32 len][u16 display w][u16 display h][REF_LAST][u32 len] padded Y, U, V of the LAST reference
@@ -835,6 +1283,7 @@ aa_status aa_stream_serialize( aa_stream * s, uint8_t * buf, size_t capacity, si
   if ( s->next_submit != static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_LOGIC, "aa_stream_serialize: parsed frames are still waiting to be decoded" );
   const int slot = s->cur_ref_slot[0];
   if ( slot < 0 ) return fail( AA_ERR_LOGIC, "aa_stream_serialize: nothing decoded or imported yet (the reference would write an uninitialised raster)" );
+  if ( aa_status st = segmap_to_host( s ) ) return st;
   std::vector<uint8_t> blob;
   blob.push_back( 11 /* DECODER */ );
   blob.insert( blob.end(), 4, 0 );
@@ -866,6 +1315,7 @@ aa_status aa_stream_deserialize( aa_stream * s, const uint8_t * buf, size_t size
   if ( !s || !buf ) return fail( AA_ERR_ARGUMENT, "null argument" );
   if ( s->next_submit != static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_LOGIC, "aa_stream_deserialize: parsed frames are still waiting to be decoded" );
   if ( size < 5 || buf[0] != 11 ) return fail( AA_ERR_INVALID, "invalid decoder state: expected DECODER" );
+  if ( aa_status st = segmap_to_host( s ) ) return st;
   const size_t raster = s->plane_bytes[0] + 2 * s->plane_bytes[1];
   aa::Parser trial = s->parser;                     // the stream changes only if the whole blob is good
   size_t at = 5;

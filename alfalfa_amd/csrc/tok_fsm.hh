@@ -105,6 +105,7 @@ struct Frame {
   AA_GLOBAL aa_mb_info * mbs;
   AA_GLOBAL int16_t * coeffs;
   uint32_t data_padded, flags_padded, nmb, mbw, nparts;
+  uint32_t max_steps;           // no frame of this size can take more steps: a lane that gets there stops (never a hung GPU)
 };
 AA_HD inline Frame frame_of( const ParseJob * job )
 {
@@ -112,6 +113,9 @@ AA_HD inline Frame frame_of( const ParseJob * job )
   F.job = (const AA_GLOBAL ParseJob *) job;
   F.data = (const AA_GLOBAL uint8_t *) job->data; F.mbflags = (const AA_GLOBAL uint8_t *) job->mbflags;
   F.mbs = (AA_GLOBAL aa_mb_info *) job->mbs; F.coeffs = (AA_GLOBAL int16_t *) job->coeffs;
+  // per macroblock at most 25 blocks x 16 tokens x (11 tree nodes + 11 extra bits + sign), plus one event step
+  const uint64_t bound = static_cast<uint64_t>( job->nmb ) * ( 25u * 16u * 23u + 2u ) + 64u;
+  F.max_steps = bound > 0xFFFFFFF0ull ? 0xFFFFFFF0u : static_cast<uint32_t>( bound );
   F.data_padded = job->data_padded; F.flags_padded = job->flags_padded; F.nmb = job->nmb; F.mbw = job->fp.mbw; F.nparts = job->fp.nparts;
   return F;
 }
@@ -348,7 +352,12 @@ AA_HD inline void begin_macroblock( Lane & L, uint8_t * lds, const Frame & J )
 AA_HD inline void step( Lane & L, uint8_t * lds, const Frame & J )
 {
   if ( L.st == ST_DONE ) return;
-  L.steps++;
+  if ( ++L.steps > J.max_steps ) {             // cannot happen for any input; if it does the frame is reported, not hung on
+    AA_GLOBAL FrameSummary * sum = (AA_GLOBAL FrameSummary *) J.job->summary;
+    sum->num_coeff_blocks = L.coeff_blocks; sum->steps = 0xFFFFFFFFu;
+    L.st = ST_DONE;
+    return;
+  }
   if ( L.st == ST_MB ) { begin_macroblock( L, lds, J ); if ( L.st >= ST_MB ) return; }
 
   // the two LDS reads of a step: the probability of this node and the next stream byte

@@ -109,6 +109,25 @@ class Context:
     def compute_stream(self):
         return self.L.aa_ctx_compute_stream(self.h)
 
+    def submit_frames(self, pairs, threads=0):
+        """Device-side entropy decode (aa_submit_frames): pairs = [(decoder, frame bytes), ...], frames of one decoder in
+        stream order.  Host: frame-header pre-pass only; the macroblock headers and tokens are parsed on the GPU.
+        -> frame index of every pair in its stream."""
+        return self.submit_prepared(self.prepare_frames(pairs), threads)
+
+    def prepare_frames(self, pairs):
+        """The ctypes argument block of submit_frames, reusable across calls with the same (decoder, bytes) pairs."""
+        n = len(pairs)
+        arr = (capi.FrameIn * n)()
+        for i, (d, fr) in enumerate(pairs):
+            arr[i].stream, arr[i].data, arr[i].size = d.h.value, fr, len(fr)
+        return arr, (C.c_int * n)(), [fr for _, fr in pairs]      # (keeps the byte strings alive)
+
+    def submit_prepared(self, prepared, threads=0):
+        arr, out, _keep = prepared
+        capi.check(self.L.aa_submit_frames(self.h, arr, len(arr), out, threads))
+        return list(out)
+
     def decode_batch(self, decoders, frame_indices):
         n = len(decoders)
         arr = (C.c_void_p * n)(*[d.h for d in decoders])
@@ -159,8 +178,25 @@ class Decoder:
     def frame_count(self):
         return self.L.aa_stream_frame_count(self.h)
 
+    def frame_header(self, frame_index):
+        hdr = FrameHeader()
+        capi.check(self.L.aa_stream_frame_header(self.h, frame_index, C.byref(hdr)))
+        return hdr.as_dict()
+
+    def read_records(self, frame_index):
+        """A frame's parsed records as they sit in HBM -> (header dict, mb_info [mbh, mbw], coefficient blocks [n, 16])."""
+        h = self.frame_header(frame_index)
+        mbw, mbh = h["mb_width"], h["mb_height"]
+        mb = np.zeros(mbw * mbh, dtype=MB_INFO_DTYPE)
+        cf = np.zeros((max(1, h["num_coeff_blocks"]), 16), dtype=np.int16)
+        capi.check(self.L.aa_stream_read_records(self.h, frame_index, mb.ctypes.data_as(C.c_void_p), cf.ctypes.data_as(C.c_void_p), len(cf)))
+        return h, mb.reshape(mbh, mbw), cf[:h["num_coeff_blocks"]]
+
     def rewind(self):
         capi.check(self.L.aa_stream_rewind(self.h))
+
+    def rewind_to(self, frame_index):
+        capi.check(self.L.aa_stream_rewind_to(self.h, frame_index))
 
     def release_before(self, first_kept):
         capi.check(self.L.aa_stream_release_before(self.h, first_kept))

@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
-"""bench.py -- 1080p macroblocks/s of the VP8 decode hot path on MI355X (BASELINE.json metric).
+"""bench.py -- 1080p macroblocks/s of the VP8 decode hot path on MI355X (BASELINE.json metric), END TO END.
 
-One "step" = one pass of the device half of the hot path (reconstruct + loop filter + reference update) over one
-batch: S independent synthetic 1920x1080 inter-frame streams (1 key + F-1 inter frames each, loop filter level 24),
-i.e. S*F*8160 macroblocks, whose parsed records are ALREADY RESIDENT IN HBM when the timed region starts.  Host parse
-and H2D rates are measured separately and reported beside it (they are never part of `value`).
+One "step" = one pass of the WHOLE hot path over one batch: S independent synthetic 1920x1080 inter-frame streams
+(1 key + F-1 inter frames each, loop filter level 24) = S*F*8160 macroblocks, from COMPRESSED FRAMES IN HOST MEMORY to
+filtered rasters in HBM:
+    host    frame-header pre-pass (serial across the frames of a stream) + staging of the compressed bytes   [C++ workers]
+    H2D     the compressed frames themselves (~36 B/macroblock instead of ~360 B of parsed records)
+    GPU     BoolDecoder entropy decode: macroblock headers + tokens, one lane per (stream, frame)   [k_parse_*]
+    GPU     reconstruction + loop filter + reference update                                        [k_recon_*, k_loopfilter_*]
+Steps are pipelined (`--depth`: the parse of the next step(s) runs beside the reconstruction of this one); frames are
+released as they are consumed, so memory is a ring.  `value` is that end-to-end rate.  The reconstruction-only rate
+with parsed records already resident in HBM (last round's number) is reported beside it as `device_half`.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -27,14 +33,22 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic bytes per macroblock, SURVEY.md 8(d): descriptor 80 + dense coefficients 800 + reference read 384
-# + reconstruction write 384 (k_recon_inter) ; loop filter read+write 768 (k_loopfilter)
-BYTES_PER_MB = {"recon_inter": 80 + 800 + 384 + 384, "recon_intra": 80 + 800 + 384, "loopfilter": 768}
+# + reconstruction write 384 (k_recon_inter) ; loop filter read+write 768 (k_loopfilter); the entropy decode reads the
+# compressed macroblock and writes the descriptor + dense coefficients that the survey's model has the reconstruction read
+BYTES_PER_MB = {"recon_inter": 80 + 800 + 384 + 384, "recon_intra": 80 + 800 + 384, "loopfilter": 768, "parse_tokens": 80 + 800,
+                "parse_headers": 80}
 PATH_BYTES_PER_MB = 2416       # inter + deblock, whole path
-# HBM bytes per macroblock measured with rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KiB -> bytes, per launch / MBs per launch),
-# profiles/r01j_kernels.md; used for roofline.traffic (counters cannot be read from inside this process)
-PMC_TRAFFIC_BYTES_PER_MB = {"recon_inter": 497 + 407, "loopfilter": 356 + 653, "recon_intra": None}
-KERNEL_NAMES = {"rows": {"recon_inter": "k_recon_inter4", "recon_intra": "k_recon_intra4", "loopfilter": "k_loopfilter_rows4"},
-                "diagonal": {"recon_inter": "k_recon_inter", "recon_intra": "k_recon_intra", "loopfilter": "k_loopfilter"}}
+KERNEL_NAMES = {"recon_inter": "k_recon_inter4", "recon_intra": "k_recon_intra4", "loopfilter": "k_loopfilter_rows4",
+                "parse_tokens": "k_parse_tokens", "parse_headers": "k_parse_mb_headers"}
+
+
+def pmc_traffic(config):
+    """HBM bytes per macroblock per kernel from the rocprofv3 PMC passes of THIS config (tools/profile_round.sh writes
+    profiles/pmc_traffic.json); None when that config was never profiled."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(config)
+    except (OSError, ValueError):
+        return None
 
 
 def parse_args():
@@ -44,19 +58,21 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="1080p_inter_lf")
     ap.add_argument("--streams", type=int, default=480, help="independent streams per GPU")
-    ap.add_argument("--frames", type=int, default=12, help="frames per stream")
+    ap.add_argument("--frames", type=int, default=12, help="frames per stream per step")
+    ap.add_argument("--depth", type=int, default=2, help="steps whose entropy decode may be in flight ahead of reconstruction")
+    ap.add_argument("--threads", type=int, default=0, help="host workers of the header pre-pass (0: cores / local ranks)")
     ap.add_argument("--schedule", default="rows", choices=["rows", "diagonal"])
-    ap.add_argument("--queues", type=int, default=1, help="independent HIP queues (contexts) the streams are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--no-device-half", action="store_true")
+    ap.add_argument("--small-batches", default="1,8,64", help="stream counts for the small-batch end-to-end figures ('' = skip)")
     return ap.parse_args()
 
 
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")); local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     dist = None
     if world > 1 or os.environ.get("AA_BENCH_FORCE_DIST"):     # the env switch lets a 1-GPU box exercise the RCCL path
         import torch
@@ -68,10 +84,11 @@ def main():
 
     import alfalfa_amd as aa
     import workload
-
     from alfalfa_amd import sharding
+
     width, height = workload.CONFIGS[args.config][:2]
     S, F = args.streams, args.frames
+    threads = args.threads or max(1, (os.cpu_count() or 1) // max(1, local_world))
     # stream ids are disjoint across ranks; their CONTENT is drawn from a pool of 120 synthetic videos so that the one-off
     # generation cost (reference encoder, cached on disk) stays bounded on an 8-GPU node
     seeds = [100 + (g - 100) % 120 for g in sharding.stream_ids(rank, world, S)]
@@ -81,18 +98,15 @@ def main():
     streams = [aa.read_ivf(p)[2] for p in paths]
     mbs_per_frame = ((width + 15) // 16) * ((height + 15) // 16)
     mbs_per_step = S * F * mbs_per_frame
+    compressed_bytes = sum(len(fr) for st in streams for fr in st)
 
-    Q = max(1, min(args.queues, S))
-    ctxs = [aa.Context(local_rank) for _ in range(Q)]
-    for c in ctxs:
-        c.set_schedule(args.schedule)
-    ctx = ctxs[0]
-    decs = [aa.Decoder(ctxs[i % Q], width, height) for i in range(S)]
-    batches = [(ctxs[q], [d for i, d in enumerate(decs) if i % Q == q]) for q in range(Q)]      # (context, decoders submitted together)
+    ctx = aa.Context(local_rank)
+    ctx.set_schedule(args.schedule)
 
-    def sync_all():
-        for c in ctxs:
-            c.sync()
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
 
     # ---- multi-GPU only: one-shot entry-state hand-off (outside the timed region).  Rank 0 decodes the head (key frame)
     # of a shared GOP; its DecoderState blob and reference raster are broadcast (RCCL over xGMI) and every rank continues
@@ -135,61 +149,50 @@ def main():
         if not agree:
             raise SystemExit("entry-state hand-off mismatch across ranks")
 
-    # ---- host half: serial BoolDecoder parse into pinned staging, one host thread per stream ----
-    def parse_stream(i):
-        t = time.perf_counter()
-        for fr in streams[i]:
-            decs[i].parse_frame(fr)
-        return time.perf_counter() - t
-    nthreads = min(S, os.cpu_count() or 1, 128)
-    compressed_bytes = sum(len(fr) for st in streams for fr in st)
-    # waves of `nthreads` streams: parse (one host thread per stream) -> H2D on the copy stream -> give the pinned staging
-    # back, so that pinned host memory stays bounded however many streams a GPU holds
-    per_stream_parse_s = []
-    t_parse_wall = t_h2d = 0.0
-    with ThreadPoolExecutor(max_workers=nthreads) as ex:
-        for base in range(0, S, nthreads):
-            ids = range(base, min(S, base + nthreads))
-            t0 = time.perf_counter()
-            per_stream_parse_s += list(ex.map(parse_stream, ids))
-            t_parse_wall += time.perf_counter() - t0
-            t0 = time.perf_counter()
-            for i in ids:
-                decs[i].upload()
-            sync_all()
-            t_h2d += time.perf_counter() - t0
-            for i in ids:
-                decs[i].release_staging()
-    # the parser alone (no pinned/device allocation, one thread): the serial BoolDecoder rate per host core
-    pp = aa.Parser(width, height)
-    t0 = time.perf_counter()
-    for fr in streams[0]:
-        pp.parse(fr)
-    parser_only = len(streams[0]) * mbs_per_frame / (time.perf_counter() - t0)
+    # ---- the end-to-end pipeline over a set of long-running decoders ----
+    class Pipeline:
+        def __init__(self, stream_list):
+            self.decs = [aa.Decoder(ctx, width, height) for _ in stream_list]
+            self.n = len(stream_list)
+            # stream-major: frames of one stream are consecutive (a worker takes a whole stream)
+            self.prepared = ctx.prepare_frames([(d, fr) for d, st in zip(self.decs, stream_list) for fr in st])
+            self.submitted = 0          # steps handed to the GPU parser
+            self.decoded = 0            # steps whose reconstruction has been queued
+            self.host_s = 0.0
 
-    def one_pass():
-        for f in range(F):
-            for c, part in batches:
-                c.decode_batch(part, [f] * len(part))
+        def submit(self):
+            t = time.perf_counter()
+            ctx.submit_prepared(self.prepared, threads)
+            self.host_s += time.perf_counter() - t
+            self.submitted += 1
 
-    def one_step():
-        one_pass()
-        for d in decs:
-            d.rewind()
+        def decode(self, release=True):
+            base = self.decoded * F
+            for f in range(F):
+                ctx.decode_batch(self.decs, [base + f] * self.n)
+            self.decoded += 1
+            if release:                 # this step's frames are consumed; the next step starts on a key frame
+                for d in self.decs:
+                    d.release_before(base + F)
 
-    def barrier():
-        sync_all()
-        if dist is not None:
-            dist.barrier()
+        def run(self, steps, depth):
+            """`steps` whole steps, the entropy decode of up to `depth` steps in flight ahead of reconstruction."""
+            target = self.decoded + steps
+            while self.decoded < target:
+                while self.submitted < min(target, self.decoded + depth):
+                    self.submit()
+                self.decode()
 
-    for _ in range(args.warmup):
-        one_step()
+    pipe = Pipeline(streams)
+    depth = max(1, args.depth)
+    pipe.run(args.warmup, depth)
     barrier()
+    pipe.host_s = 0.0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    sync_all()
+    pipe.run(args.steps, depth)
+    ctx.sync()
     elapsed = time.perf_counter() - t0
+    host_submit_s = pipe.host_s / max(1, args.steps)
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -199,51 +202,142 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * mbs_per_step * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel: per-launch HIP events on the compute stream, extra identical pass ----
-    roofline = None
-    kstats = None
-    if not args.no_profile_pass:
-        for c in ctxs:
-            c.profile(True); c.kernel_stats(reset=True)
-        one_pass()
-        kstats = None
-        for c in ctxs:
-            st = c.kernel_stats(reset=True); c.profile(False)
-            kstats = st if kstats is None else {k: kstats[k] + st[k] for k in st}
-        for d in decs:
-            d.rewind()
-        names = ("recon_inter", "recon_intra", "loopfilter")
-        dom = max(names, key=lambda k: kstats[k + "_ms"])
-        launches = max(1, kstats[dom + "_launches"])
-        total_ms = kstats[dom + "_ms"]
-        # units per launch: inter = inter frames' MBs of one frame-step; loop filter = every MB once per frame-step
-        mbs_total = S * (F - 1) * mbs_per_frame if dom == "recon_inter" else S * F * mbs_per_frame
-        bytes_per_launch = BYTES_PER_MB[dom] * mbs_total / launches
-        avg_ms = total_ms / launches
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = PMC_TRAFFIC_BYTES_PER_MB.get(dom) if args.schedule == "rows" else None
-        roofline = {"bound": "hbm", "kernel": KERNEL_NAMES[args.schedule][dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": None if traffic is None else round(traffic * mbs_total / launches),
-                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r01j_kernels.md (bytes per launch)",
-                    "avg_launch_us": round(avg_ms * 1e3, 3), "launches_per_step": launches,
-                    "algorithmic_bytes_per_launch": round(bytes_per_launch),
-                    "path_frac_of_hbm_peak": round(value / world * PATH_BYTES_PER_MB / (HBM_PEAK_GBS * 1e9), 5)}
+    # ---- per-kernel timing of one more (un-pipelined) step: HIP events on the streams the kernels run on ----
+    ctx.profile(True); ctx.kernel_stats(reset=True)
+    t0 = time.perf_counter()
+    pipe.submit()
+    ctx.sync()
+    t_parse_alone = time.perf_counter() - t0
+    pipe.decode(release=False)
+    ctx.sync()
+    kstats = ctx.kernel_stats(reset=True); ctx.profile(False)
+    verify_decs, verify_base = pipe.decs, (pipe.decoded - 1) * F
 
-    # ---- cpu_baseline leg (rank 0, 1 GPU only): the REFERENCE decoder (oracle/_ref, built without x86 asm) on one of
-    # the streams, single thread; its output doubles as the parity gate for that stream ----
-    cpu_baseline = None
+    launches_per_step = {"recon_inter": max(1, kstats["recon_inter_launches"]), "recon_intra": max(1, kstats["recon_intra_launches"]),
+                         "loopfilter": max(1, kstats["loopfilter_launches"]), "parse_tokens": 1, "parse_headers": 1}
+    units = {"recon_inter": S * (F - 1) * mbs_per_frame if not args.config.endswith("_intra") else 0, "recon_intra": S * F * mbs_per_frame,
+             "loopfilter": S * F * mbs_per_frame, "parse_tokens": S * F * mbs_per_frame, "parse_headers": S * F * mbs_per_frame}
+    traffic = pmc_traffic(args.config) or {}
+
+    def roof(k):
+        ms = kstats[k + "_ms"]
+        if ms <= 0 or units[k] == 0:
+            return None
+        n = launches_per_step[k]
+        bytes_per_launch = BYTES_PER_MB[k] * units[k] / n
+        achieved = bytes_per_launch / (ms / n * 1e-3) / 1e9
+        tr = traffic.get(k)
+        return {"bound": "hbm", "kernel": KERNEL_NAMES[k], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None if tr is None else round(tr * units[k] / n),
+                "avg_launch_us": round(ms / n * 1e3, 3), "launches_per_step": n, "ms_per_step": round(ms, 3),
+                "algorithmic_bytes_per_launch": round(bytes_per_launch)}
+    roofs = {k: roof(k) for k in BYTES_PER_MB}
+    dom = max((k for k in roofs if roofs[k]), key=lambda k: kstats[k + "_ms"])
+    roofline = dict(roofs[dom])
+    roofline["note"] = ("dominant kernel by time; k_parse_tokens is a latency-bound serial arithmetic decode per lane (one bool per ~100 cycles), "
+                        "HBM is the nominal roof the contract prices against, not what binds it")
+    roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this config)" if traffic else None
+    roofline["path_frac_of_hbm_peak"] = round(value / world * PATH_BYTES_PER_MB / (HBM_PEAK_GBS * 1e9), 5)
+
+    # ---- bit-exactness against the REFERENCE decoder: every distinct stream of the batch, first / middle / last frame
+    # (the last one depends on all the others through the references) ----
     verified = None
+    ref_decode = os.path.join(ROOT, "oracle", "_ref", "ref_decode")
+    if rank == 0 and not args.no_verify and os.path.exists(ref_decode):
+        distinct = {}
+        for i, sd in enumerate(seeds):
+            distinct.setdefault(sd, i)
+        check_frames = sorted({0, F // 2, F - 1})
+
+        def ref_hashes(i):
+            raw = os.path.join(workload.cache_dir(), "bench_verify_%d_%d.raw" % (os.getpid(), i))
+            subprocess.run([ref_decode, paths[i], raw], check=True, stdout=subprocess.DEVNULL)
+            with open(raw, "rb") as fh:
+                ref = fh.read()
+            os.unlink(raw)
+            fs = len(ref) // F
+            return i, [hashlib.sha256(ref[f * fs:(f + 1) * fs]).digest() for f in check_frames]
+        with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+            refs = list(ex.map(ref_hashes, distinct.values()))
+        bad = [(i, f) for i, hs in refs for f, hsh in zip(check_frames, hs)
+               if hashlib.sha256(verify_decs[i].raster_bytes(verify_base + f)).digest() != hsh]
+        verified = {"streams_checked": len(refs), "frames_per_stream": len(check_frames), "bit_exact": not bad}
+        if bad:
+            raise SystemExit("PARITY FAILURE: HIP output differs from the reference decoder on (stream, frame) %r" % bad[:8])
+
+    # ---- device half alone (last round's metric): the step just parsed stays resident, reconstruction replayed ----
+    device_half = None
+    if not args.no_device_half:
+        reps = max(2, min(args.steps, 5))
+
+        def replay():
+            for f in range(F):
+                ctx.decode_batch(pipe.decs, [verify_base + f] * S)
+            for d in pipe.decs:
+                d.rewind_to(verify_base)
+        for d in pipe.decs:
+            d.rewind_to(verify_base)
+        replay(); ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            replay()
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / reps
+        device_half = {"value": round(mbs_per_step / dt, 1), "unit": "macroblocks/s", "ms_per_step": round(dt * 1e3, 3),
+                       "note": "reconstruction + loop filter only, parsed records resident in HBM (round-1 metric)"}
+    del pipe
+
+    # ---- small batches: the reference's actual callers (one stream, one 8-chunk ExCamera bundle), end to end ----
+    small = {}
+    if rank == 0 and args.small_batches:
+        for n in [int(x) for x in args.small_batches.split(",") if x]:
+            if n >= S:
+                continue
+            p = Pipeline(streams[:n])
+            p.run(1, depth); ctx.sync()
+            reps = 3
+            t0 = time.perf_counter()
+            p.run(reps, depth); ctx.sync()
+            dt = (time.perf_counter() - t0) / reps
+            # the same streams through the host parser path (aa_stream_decode: one host core per stream, no batching)
+            d1 = aa.Decoder(ctx, width, height)
+            t0 = time.perf_counter()
+            for fr in streams[0]:
+                d1.get_frame_output(fr)
+            ctx.sync()
+            dt_host = time.perf_counter() - t0
+            small[str(n)] = {"gpu_parser_mb_per_s": round(n * F * mbs_per_frame / dt, 1), "ms_per_step": round(dt * 1e3, 2)}
+            small.setdefault("1_host_parser", {"mb_per_s": round(F * mbs_per_frame / dt_host, 1), "ms_per_frame": round(dt_host / F * 1e3, 2),
+                                               "note": "aa_stream_decode: serial BoolDecoder on one host core, frame by frame (Decoder::get_frame_output)"})
+            del p, d1
+
+    # ---- host parser (the product's C++ BoolDecoder path used for single streams): rate per core ----
+    pp = aa.Parser(width, height)
+    t0 = time.perf_counter()
+    for fr in streams[0]:
+        pp.parse(fr)
+    parser_only = len(streams[0]) * mbs_per_frame / (time.perf_counter() - t0)
+
+    # ---- cpu_baseline leg (rank 0, 1 GPU only): the REFERENCE decoder (oracle/_ref, built without x86 asm), one thread
+    # and 8 concurrent processes ----
+    cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ref_time = os.path.join(ROOT, "oracle", "_ref", "ref_time")
         if os.path.exists(ref_time):
-            reps = max(1, int(round(15.0 / (F * mbs_per_frame / 90000.0))))
+            reps = max(1, int(round(12.0 / (F * mbs_per_frame / 90000.0))))
             out = subprocess.run([ref_time, paths[0], str(reps)], check=True, capture_output=True, text=True).stdout
             r = json.loads(out)
+            t0 = time.perf_counter()
+            procs = [subprocess.Popen([ref_time, paths[i % len(paths)], str(max(1, reps // 2))], stdout=subprocess.PIPE, text=True) for i in range(8)]
+            outs = [json.loads(p.communicate()[0]) for p in procs]
+            wall8 = time.perf_counter() - t0
             cpu_baseline = {"value": round(r["mb_per_s"], 1), "unit": "macroblocks/s", "cores": 1, "kind": "reference",
                             "sample": "stream seed %d (%d frames %dx%d) decoded %d times by oracle/_ref/ref_time; "
                                       "reference built without x86 asm (no assembler in the image)" % (seeds[0], F, width, height, reps),
-                            "parse_fraction": round(r["parse_s"] / r["seconds"], 3)}
+                            "phases": {"parse_fraction": round(r["parse_s"] / r["seconds"], 3),
+                                       "reconstruct_and_loopfilter_fraction": round(r["decode_s"] / r["seconds"], 3)},
+                            "eight_processes": {"value": round(sum(o["macroblocks"] for o in outs) / wall8, 1), "cores": 8,
+                                                "note": "8 concurrent ref_time processes on 8 streams, wall clock incl. process start"}}
         else:   # reference binary not built: time our C restatement instead ("port")
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import vp8_oracle as vo
@@ -254,35 +348,28 @@ def main():
             dt = time.perf_counter() - t1
             cpu_baseline = {"value": round(F * mbs_per_frame / dt, 1), "unit": "macroblocks/s", "cores": 1, "kind": "port",
                             "sample": "stream seed %d (%d frames %dx%d) decoded once by oracle/liboracle.so" % (seeds[0], F, width, height)}
-    if rank == 0 and not args.no_verify:
-        ref_decode = os.path.join(ROOT, "oracle", "_ref", "ref_decode")
-        if os.path.exists(ref_decode):
-            one_pass()
-            raw = os.path.join(workload.cache_dir(), "bench_verify_%d.raw" % os.getpid())
-            subprocess.run([ref_decode, paths[0], raw], check=True, stdout=subprocess.DEVNULL)
-            ref = open(raw, "rb").read(); os.unlink(raw)
-            fs = len(ref) // F
-            verified = all(decs[0].raster_bytes(f) == ref[f * fs:(f + 1) * fs] for f in range(F))
-            if not verified:
-                raise SystemExit("PARITY FAILURE: HIP output differs from the reference decoder on the bench stream")
 
     if rank == 0:
+        cfg = workload.CONFIGS[args.config]
+        shape = "all key frames" if args.config.endswith("_intra") else "1 key + %d inter" % (F - 1)
         line = {
             "metric": "1080p macroblocks/s decode (bit-exact vs reference)" if height == 1080 else "%dp macroblocks/s decode (bit-exact vs reference)" % height,
             "value": round(value, 1), "unit": "macroblocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s: %d independent %dx%d streams per GPU x %d frames (1 key + %d inter, y_ac_qi %d, loop filter %d), "
-                                   "parsed records resident in HBM" % (args.config, S, width, height, F, F - 1,
-                                                                        workload.CONFIGS[args.config][3], workload.CONFIGS[args.config][4]),
+            "config": {"workload": "%s: %d independent %dx%d streams per GPU x %d frames (%s, y_ac_qi %d, loop filter %d), END TO END: "
+                                   "compressed frames in host memory -> entropy decode on the GPU -> reconstruction + loop filter -> rasters in HBM"
+                                   % (args.config, S, width, height, F, shape, cfg[3], cfg[4]),
                        "streams_per_gpu": S, "frames_per_stream": F, "macroblocks_per_step_per_gpu": mbs_per_step,
-                       "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective", "schedule": args.schedule, "queues": Q},
+                       "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective",
+                       "schedule": args.schedule, "pipeline_depth": depth, "host_threads": threads},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
-            "host": {"parser_mb_per_s_per_core": round(parser_only, 1),
-                     "parse_into_pinned_staging": {"threads": nthreads, "wall_s": round(t_parse_wall, 3),
-                                                   "mb_per_s_aggregate": round(mbs_per_step / t_parse_wall, 1),
-                                                   "note": "includes first-touch hipHostMalloc/hipMalloc of the frame store and raster slots"},
-                     "h2d_s": round(t_h2d, 3), "stream_generation_s": round(t_gen, 1)},
+            "kernels": roofs, "device_half": device_half,
+            "stages": {"host_prepass_and_staging_s_per_step": round(host_submit_s, 4),
+                       "entropy_decode_alone_s_per_step": round(t_parse_alone, 4),
+                       "note": "entropy_decode_alone = one step's submit -> parse finished with nothing else on the GPU (a latency: the longest chain, a key frame)"},
+            "small_batches": small,
+            "host": {"parser_mb_per_s_per_core": round(parser_only, 1), "stream_generation_s": round(t_gen, 1)},
             "kernel_stats": kstats, "verified_bit_exact_vs_reference": verified, "entry_state_handoff": handoff,
         }
     else:

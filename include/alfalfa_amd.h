@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 1
+#define AA_ABI_VERSION 2
 
 typedef enum aa_status {
   AA_OK = 0,
@@ -170,12 +170,36 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
 /* Convenience = parse + upload + decode_batch(n=1): Decoder::get_frame_output (decoder.cc:125-135). */
 aa_status aa_stream_decode( aa_stream * s, const uint8_t * data, size_t size, int * frame_index, int * shown );
 
-/* Number of frames appended so far; drop host+device records of frames < first_kept (rasters stay while referenced). */
+/* ---- Device-side entropy decode (reference HOT LOOP #1: Frame::parse_macroblock_headers / parse_tokens,
+ * frame.cc:95-137, tokens.cc:50-135, over BoolDecoder bool_decoder.hh:45-120).
+ * aa_stream_parse runs the serial BoolDecoder on ONE host core per stream; a GPU consumes the output of ~1000 such cores.
+ * aa_submit_frames instead does only the frame-header pre-pass on the host (decoder_state.hh:72-167: the part that is serial
+ * across the frames of a stream) and hands the compressed frames themselves to the GPU, where every (stream, frame) is an
+ * independent lane: macroblock headers and tokens are parsed in HBM, into the same records aa_stream_parse would have
+ * produced.  Frames may be many per stream (in order) and of many streams; streams are processed in parallel by `threads`
+ * host workers (0: one per core).  Asynchronous; aa_decode_batch of those frames orders itself behind the parse.
+ * frame_index_out[i] (may be NULL) = index of frame i in its stream, -1 if it was not appended.  On a bitstream error the
+ * failing frame and the later frames of ITS stream in this call are not appended, everything else is; the first error is
+ * returned (same classes as aa_stream_parse). */
+typedef struct aa_frame_in { aa_stream * stream; const uint8_t * data; size_t size; } aa_frame_in;
+aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int * frame_index_out, int threads );
+/* Header of an appended frame.  For device-parsed frames the counts (num_coeff_blocks, num_intra_mbs, has_intra_mb) are known
+ * only once the parse has run: this call waits for it. */
+aa_status aa_stream_frame_header( aa_stream * s, int frame_index, aa_frame_header * out );
+/* Test / debug view: a frame's parsed records as they sit in HBM (host- or device-parsed), copied back.  mb_out:
+ * mb_width*mb_height records; coeff_out: up to coeff_capacity_blocks blocks of 16 (either may be NULL). */
+aa_status aa_stream_read_records( aa_stream * s, int frame_index, aa_mb_info * mb_out, int16_t * coeff_out, size_t coeff_capacity_blocks );
+
+/* Number of frames appended so far.  aa_stream_release_before: the caller is done with frames < first_kept -- their raster
+ * handles are dropped (a raster lives on while a reference points at it: RasterHandle semantics, raster_handle.cc:113-122)
+ * and the parsed records of the decoded ones go back to the context's pools (reused once queued kernels have run). */
 int aa_stream_frame_count( const aa_stream * s );
 aa_status aa_stream_release_before( aa_stream * s, int first_kept );
 /* Forget all frames but keep decoder state? No: rewind the DEVICE half to frame 0 so the same resident
  * records can be decoded again (used by bench.py's steps; parser state is untouched). */
 aa_status aa_stream_rewind( aa_stream * s );
+/* Same, to frame `frame_index` (a key frame, or a frame whose reference rasters are all still held). */
+aa_status aa_stream_rewind_to( aa_stream * s, int frame_index );
 
 /* Output raster of a decoded frame (VP8Raster: three padded planes, stride = padded width, raster.hh:54-56).
  * Synchronises with the compute stream, then D2H.  Any pointer may be NULL. */
@@ -215,6 +239,9 @@ typedef struct aa_kernel_stats {
   double recon_inter_ms, recon_intra_ms, loopfilter_ms;      /* summed launch durations */
   uint64_t recon_inter_launches, recon_intra_launches, loopfilter_launches;
   uint64_t macroblocks;                                      /* MBs processed by decode_batch calls */
+  double parse_headers_ms, parse_tokens_ms;                  /* device-side entropy decode: k_parse_mb_headers, k_parse_tokens */
+  uint64_t parse_launches;                                   /* aa_submit_frames calls timed */
+  uint64_t parsed_macroblocks;                               /* MBs handed to the device parser */
 } aa_kernel_stats;
 aa_status aa_ctx_profile( aa_ctx * ctx, int enable );
 aa_status aa_ctx_kernel_stats( aa_ctx * ctx, aa_kernel_stats * out, int reset );

@@ -1,0 +1,161 @@
+"""Device-side entropy decode (aa_submit_frames: macroblock headers and tokens parsed by GPU lanes) on a real MI355X:
+  * every macroblock record and every coefficient block the GPU parser leaves in HBM equals, byte for byte, what the host
+    parser (aa_parser_parse) produces -- goldens, 24 synthetic feature seeds, truncated frames, extreme geometries;
+  * frames decoded through that path equal the oracle / the committed reference hashes;
+  * many streams x many frames in one call, interleaved with host-parsed frames, with frames released on the way."""
+import numpy as np
+import pytest
+
+import alfalfa_amd as aa
+import vp8_oracle as vo
+from conftest import GOLDEN, golden_frames, sha256
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_records_equal(got, want, what):
+    gh, gmb, gcf = got
+    wh, wmb, wcf = want
+    assert gh == wh, (what, {k: (gh[k], wh[k]) for k in wh if gh[k] != wh[k]})
+    a, b = gmb.reshape(-1).view(np.uint8).reshape(-1, 80), wmb.reshape(-1).view(np.uint8).reshape(-1, 80)
+    if not (a == b).all():
+        bad = np.nonzero((a != b).any(axis=1))[0]
+        m = int(bad[0])
+        raise AssertionError("%s: %d macroblock records differ, first mb %d: gpu %r host %r" % (what, len(bad), m, gmb.reshape(-1)[m], wmb.reshape(-1)[m]))
+    assert gcf.shape == wcf.shape and (gcf == wcf).all(), "%s: coefficient blocks differ" % what
+
+
+def check_stream(ctx, w, h, frames, want_hashes=None, per_call=None):
+    """Submit the stream to the GPU parser (all frames in one call, or per_call at a time), compare records with the host
+    parser's and rasters with the oracle's."""
+    dec, host, ora = aa.Decoder(ctx, w, h), aa.Parser(w, h), vo.OracleDecoder(w, h)
+    per_call = per_call or len(frames)
+    for base in range(0, len(frames), per_call):
+        part = frames[base:base + per_call]
+        idx = ctx.submit_frames([(dec, fr) for fr in part])
+        assert idx == list(range(base, base + len(part)))
+        for k, fr in enumerate(part):
+            fi = base + k
+            assert_records_equal(dec.read_records(fi), host.parse(fr), "frame %d" % fi)
+            ctx.decode_batch([dec], [fi])
+            ora.decode(fr)
+            got = dec.raster_bytes(fi)
+            assert got == ora.raster_bytes(), "frame %d raster" % fi
+            if want_hashes:
+                assert sha256(got) == want_hashes[fi]
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_gpu_parser_matches_host_parser_and_reference(gpu_ctx, name):
+    w, h, frames = golden_frames(name)
+    check_stream(gpu_ctx, w, h, frames, GOLDEN[name]["raster_sha256"])
+
+
+@pytest.mark.parametrize("seed", list(range(200, 224)))
+def test_gpu_parser_on_synthetic_feature_streams(gpu_ctx, seed):
+    import vp8_synth
+    sizes = [(96, 80), (33, 17), (64, 64), (175, 143), (16, 16), (200, 48), (320, 176), (48, 256)]
+    w, h = sizes[seed % len(sizes)]
+    check_stream(gpu_ctx, w, h, vp8_synth.feature_stream(w, h, seed, 8).frames, per_call=3 if seed % 2 else None)
+
+
+@pytest.mark.parametrize("name", ["qcif_q30_lf24", "w200_q40_lf63s7", "qcif_allkey_q20"])
+def test_gpu_parser_on_truncated_frames(gpu_ctx, name):
+    from test_parser_vs_oracle import truncated
+    w, h, frames = golden_frames(name)
+    check_stream(gpu_ctx, w, h, truncated(frames))
+
+
+def test_gpu_parser_on_extreme_geometries(gpu_ctx):
+    import vp8_synth
+    for w, h, seed in ((16, 4096, 901), (4096, 16, 902), (24, 1000, 903), (2000, 32, 904)):
+        check_stream(gpu_ctx, w, h, vp8_synth.feature_stream(w, h, seed, 3).frames)
+
+
+def test_many_streams_many_frames_in_one_call(gpu_ctx):
+    """The bench's shape in small: every frame of every stream handed over in ONE call (frames of a stream in order, streams
+    interleaved), then decoded in lock step; old frames released on the way."""
+    names = ["qcif_q30_lf24", "qcif_q30", "qcif_allkey_q20", "cif_q60_lf40s5", "w200_q40_lf63s7", "synth_96x80_s1", "synth_175x143_s3"] * 3
+    streams = [golden_frames(n) for n in names]
+    decs = [aa.Decoder(gpu_ctx, w, h) for w, h, _ in streams]
+    nf = min(len(f) for _, _, f in streams)
+    pairs = [(decs[i], streams[i][2][f]) for f in range(nf) for i in range(len(decs))]
+    idx = gpu_ctx.submit_frames(pairs, threads=4)
+    assert idx == [f for f in range(nf) for _ in decs]
+    for f in range(nf):
+        gpu_ctx.decode_batch(decs, [f] * len(decs))
+        if f >= 2:
+            for d in decs:
+                d.release_before(f - 1)
+    for d, n in zip(decs, names):
+        for f in (nf - 2, nf - 1):
+            assert sha256(d.raster_bytes(f)) == GOLDEN[n]["raster_sha256"][f], (n, f)
+
+
+def test_host_and_device_parsed_frames_interleave(gpu_ctx):
+    """A stream may switch between aa_stream_parse (host) and aa_submit_frames (device) at any frame, segmentation map and
+    all: the persistent state travels with it."""
+    import vp8_synth
+    for seed, (w, h) in ((203, (175, 143)), (211, (175, 143)), (208, (96, 80)), (216, (96, 80))):
+        frames = vp8_synth.feature_stream(w, h, seed, 10).frames
+        dec, ora = aa.Decoder(gpu_ctx, w, h), vo.OracleDecoder(w, h)
+        for i, fr in enumerate(frames):
+            if (i // 2) % 2 == 0:
+                fi = gpu_ctx.submit_frames([(dec, fr)])[0]
+                gpu_ctx.decode_batch([dec], [fi])
+            else:
+                _, fi = dec.get_frame_output(fr)
+            ora.decode(fr)
+            assert dec.raster_bytes(fi) == ora.raster_bytes(), (seed, i)
+        # and the DecoderState that comes out is the one a pure host parse reaches
+        p = aa.Parser(w, h)
+        for fr in frames:
+            p.parse(fr)
+        assert dec.export_state() == p.export_state()
+
+
+def test_bad_frame_in_a_batch(gpu_ctx):
+    """A bitstream error stops ITS stream at that frame (same error class as the host parser) and nothing else."""
+    w, h, frames = golden_frames("qcif_q30")
+    a, b = aa.Decoder(gpu_ctx, w, h), aa.Decoder(gpu_ctx, w, h)
+    bad = bytearray(frames[1]); bad[0] |= (2 << 1)          # VP8 version 2: Unsupported
+    with pytest.raises(aa.AlfalfaError) as e:
+        gpu_ctx.submit_frames([(a, frames[0]), (b, frames[0]), (a, bytes(bad)), (b, frames[1]), (a, frames[2]), (b, frames[2])])
+    assert e.value.kind == "Unsupported"
+    assert a.frame_count() == 1 and b.frame_count() == 3
+    for f in range(3):
+        gpu_ctx.decode_batch([b], [f])
+        assert sha256(b.raster_bytes(f)) == GOLDEN["qcif_q30"]["raster_sha256"][f]
+    # stream a goes on from where it stopped
+    idx = gpu_ctx.submit_frames([(a, frames[1]), (a, frames[2])])
+    assert idx == [1, 2]
+    for f in range(3):
+        gpu_ctx.decode_batch([a], [f])
+    assert sha256(a.raster_bytes(2)) == GOLDEN["qcif_q30"]["raster_sha256"][2]
+
+
+def test_long_stream_holds_memory_flat(gpu_ctx):
+    """2000 frames through one decoder with aa_stream_release_before trailing by a few frames: HBM use stays flat
+    (records and rasters are recycled; RasterHandle semantics of raster_handle.cc:113-122)."""
+    import torch
+    w, h, frames = golden_frames("cif_q60_lf40s5")
+    dec = aa.Decoder(gpu_ctx, w, h)
+    want = GOLDEN["cif_q60_lf40s5"]["raster_sha256"]
+    used = []
+    n = 0
+    for rep in range(2000 // len(frames)):
+        use_gpu_parser = rep % 2 == 0
+        if use_gpu_parser:
+            idx = gpu_ctx.submit_frames([(dec, fr) for fr in frames])
+            for fi in idx:
+                gpu_ctx.decode_batch([dec], [fi])
+        else:
+            for fr in frames:
+                _, fi = dec.get_frame_output(fr)
+        n += len(frames)
+        assert sha256(dec.raster_bytes(n - 1)) == want[len(frames) - 1]
+        dec.release_before(n - 1)
+        if rep % 25 == 24:
+            free, _total = torch.cuda.mem_get_info(0)
+            used.append(free)
+    assert max(used[1:]) - min(used[1:]) <= 64 << 20, used
