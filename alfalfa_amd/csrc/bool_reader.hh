@@ -49,11 +49,13 @@ public:
   // continues from it and returns the same bits.
   BoolState state() const
   {
-    const int real = count_ >= kLotsOfBits / 2 ? count_ - kLotsOfBits : count_;   // valid bits below the active byte
+    BoolReader t = *this;
+    if ( t.count_ < 0 ) t.fill();     // this reader refills lazily: make the 8 bits being compared whole first
+    const int real = t.count_ >= kLotsOfBits / 2 ? t.count_ - kLotsOfBits : t.count_;   // valid bits below the active byte
     BoolState st;
-    st.bitpos = static_cast<uint32_t>( 8 * ( p_ - begin_ ) - real );
-    st.range = static_cast<uint8_t>( range_ );
-    st.active = static_cast<uint8_t>( value_ >> ( kWindow - 8 ) );
+    st.bitpos = static_cast<uint32_t>( 8 * ( t.p_ - t.begin_ ) - real );   // (past the end: zeros that were shifted in)
+    st.range = static_cast<uint8_t>( t.range_ );
+    st.active = static_cast<uint8_t>( t.value_ >> ( kWindow - 8 ) );
     return st;
   }
 

@@ -31,6 +31,7 @@ __global__ __launch_bounds__( 64 ) void k_parse_mb_headers( const ParseJob * job
   const int j = blockIdx.x * lanes + lane;
   if ( lane >= lanes || j >= n ) return;
   const ParseJob & J = jobs[j];
+  if ( J.nmb == 0 ) return;                      // a frame the host header pre-pass rejected
   const aa::FrameParams & fp = J.fp;
   aa::BoolReader32 bd;
   aa::BoolState st; st.bitpos = fp.bd_bitpos; st.range = fp.bd_range; st.active = fp.bd_active;
@@ -59,7 +60,7 @@ __global__ __launch_bounds__( 256 ) void k_segment_fixup( const ParseJob * jobs,
   for ( uint32_t k = 0; k < s.count; k++ ) {
     const uint32_t o = order[s.first + k];
     const ParseJob & J = jobs[o & 0x7FFFFFFFu];
-    if ( !J.fp.seg_enabled ) continue;
+    if ( !J.fp.seg_enabled || J.nmb == 0 ) continue;
     if ( o >> 31 ) {                                    // the map restarts at all-3 (Segmentation ctor, decoder_state.hh:170-176)
       for ( uint32_t mi = threadIdx.x; mi < J.nmb; mi += blockDim.x ) s.map[mi] = 3;
       __syncthreads();
@@ -74,7 +75,7 @@ __global__ __launch_bounds__( 64 ) void k_parse_tokens( const ParseJob * jobs, i
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t smem[];
   const int lane = threadIdx.x;
   const int j = blockIdx.x * lanes + lane;
-  const bool active = lane < lanes && j < n;
+  const bool active = lane < lanes && j < n && jobs[j < n ? j : 0].nmb != 0;
   uint8_t * lds = smem + static_cast<uint32_t>( active ? lane : 0 ) * lane_bytes;
   aa::tok::Lane L;
   aa::tok::Frame F = aa::tok::frame_of( &jobs[active ? j : 0] );

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <vector>
 
+#include "../../alfalfa_amd/csrc/bool_reader.hh"
 #include "../../alfalfa_amd/csrc/parser.hh"
 #include "../../alfalfa_amd/csrc/tok_fsm.hh"
 
@@ -102,6 +103,24 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
   }
   free( dev_data ); free( J.mbflags ); free( J.mbs ); free( J.coeffs ); free( J.intra_rows );
   return bad ? 100 : 0;
+}
+
+// Hand-over of a boolean decoder between window widths: after every one of the first `n` bools of the host reader (64-bit
+// window) its exported state must let the 32-bit reader continue with the same bits.  probs cycle through a fixed pattern.
+// -> number of hand-over points at which the two readers disagreed within the next `look` bools
+int fsm_sim_handover_check( const uint8_t * data, size_t size, int n, int look )
+{
+  static const uint8_t probs[8] = { 128, 1, 255, 200, 37, 128, 250, 90 };
+  int bad = 0;
+  aa::BoolReader host( data, size );
+  for ( int k = 0; k < n; k++ ) {
+    aa::BoolReader h2 = host;
+    aa::BoolReader32 dev;
+    dev.resume( data, static_cast<uint32_t>( size ), host.state() );
+    for ( int j = 0; j < look; j++ ) if ( h2.get( probs[( k + j ) & 7] ) != dev.get( probs[( k + j ) & 7] ) ) { bad++; break; }
+    host.get( probs[k & 7] );
+  }
+  return bad;
 }
 
 // persistent state for comparison with the host parser's

@@ -32,6 +32,7 @@ def sim_lib():
     L.fsm_sim_frame.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(capi.FrameHeader), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
     L.fsm_sim_segmap.argtypes = [C.c_void_p, C.c_void_p]
     L.fsm_sim_probs.argtypes = [C.c_void_p, C.c_void_p]
+    L.fsm_sim_handover_check.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int]
     return L
 
 
@@ -108,3 +109,21 @@ def test_device_algorithm_on_extreme_geometries():
     import vp8_synth
     for w, h, seed in ((16, 4096, 901), (4096, 16, 902), (24, 1000, 903), (2000, 32, 904)):
         check_stream(w, h, vp8_synth.feature_stream(w, h, seed, 3).frames)
+
+
+def test_bool_decoder_hand_over_between_window_widths():
+    """Parser::parse_header hands its 64-bit-window decoder over to a GPU lane's 32-bit one wherever the frame header happens
+    to end -- including right when the host reader owes itself a refill, and past the end of the data."""
+    rng = np.random.default_rng(7)
+    L = sim_lib()
+    for size in (1, 2, 3, 5, 9, 40, 300):
+        data = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+        assert L.fsm_sim_handover_check(data, size, min(8 * size + 40, 1500), 64) == 0, size
+
+
+def test_device_algorithm_on_a_1080p_bench_stream():
+    """A stream of the benchmark workload (the reference encoder's output at 1920x1080)."""
+    import workload
+    if not workload.have_reference_tools():
+        pytest.skip("oracle/_ref (stream generator) not built")
+    check_stream(*aa.read_ivf(workload.make_stream("1080p_inter_lf", 3, 105)))
