@@ -45,7 +45,8 @@ __device__ void compute_residual( const aa_mb_info & mb, const aa_dev_frame & f,
   uint32_t * z = reinterpret_cast<uint32_t *>( &L.cf[0][0] );
   for ( int i = lane; i < 200; i += kLanes ) z[i] = 0;
   const uint32_t mask = mb.nz_mask;
-  if ( lane < 25 && ( ( mask >> lane ) & 1u ) ) L.map[__popc( mask & ( ( 1u << lane ) - 1u ) )] = static_cast<uint8_t>( lane );
+  // storage order: Y2 (bit 24) first, then bit order
+  if ( lane < 25 && ( ( mask >> lane ) & 1u ) ) L.map[lane == 24 ? 0 : __popc( mask & ( ( 1u << lane ) - 1u ) ) + static_cast<int>( mask >> 24 )] = static_cast<uint8_t>( lane );
   __syncthreads();
   const int n = __popc( mask ) * 16;
   const int16_t * src = f.coeffs + static_cast<size_t>( mb.coeff_index ) * 16;
@@ -650,7 +651,7 @@ __device__ __forceinline__ void residual_x4( Slot & S, const aa_dev_frame & f, c
     const uint16_t * const q = f.quant[segment];
     const bool y2_stored = has_y2 && ( ( nz_mask >> 24 ) & 1u );
     if ( __any( y2_stored ) ) {
-      if ( y2_stored ) S.y2[l] = static_cast<int16_t>( dequant( src[__popc( nz_mask & 0xFFFFFFu ) * 16 + l], q[l ? 3 : 2] ) );
+      if ( y2_stored ) S.y2[l] = static_cast<int16_t>( dequant( src[l], q[l ? 3 : 2] ) );     // a stored Y2 block comes first
       __syncthreads();
       if ( y2_stored && l < 4 ) {
         const Quad v = iwht_pass1( S.y2[l], S.y2[l + 4], S.y2[l + 8], S.y2[l + 12] );
@@ -677,7 +678,7 @@ __device__ __forceinline__ void residual_x4( Slot & S, const aa_dev_frame & f, c
       if ( __any( stored ) ) {
         uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         if ( stored ) {
-          const uint4 * p = reinterpret_cast<const uint4 *>( src + __popc( nz_mask & ( ( 1u << blk ) - 1u ) ) * 16 );
+          const uint4 * p = reinterpret_cast<const uint4 *>( src + ( __popc( nz_mask & ( ( 1u << blk ) - 1u ) ) + static_cast<int>( nz_mask >> 24 ) ) * 16 );
           const uint4 a = p[0], b = p[1];
           d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
         }

@@ -77,15 +77,27 @@ __global__ __launch_bounds__( 64 ) void k_parse_tokens( const ParseJob * jobs, i
   const int j = blockIdx.x * lanes + lane;
   const bool active = lane < lanes && j < n && jobs[j < n ? j : 0].nmb != 0;
   uint8_t * lds = smem + static_cast<uint32_t>( active ? lane : 0 ) * lane_bytes;
+  // the node and block tables, once per workgroup, behind the lanes' slices
+  uint32_t * tab = reinterpret_cast<uint32_t *>( smem + static_cast<uint32_t>( lanes ) * lane_bytes );
+  {
+    const uint32_t * nsrc = reinterpret_cast<const uint32_t *>( &aa::tok::kNodeTable );
+    const uint32_t * bsrc = reinterpret_cast<const uint32_t *>( &aa::tok::kBlockTable );
+    constexpr uint32_t nw = sizeof( aa::tok::NodeTable ) / 4, bw = sizeof( aa::tok::BlockTable ) / 4;
+    for ( uint32_t k = lane; k < nw + bw; k += 64 ) tab[k] = k < nw ? nsrc[k] : bsrc[k - nw];
+  }
+  __syncthreads();
+  aa::tok::Tables T;
+  T.nodes = reinterpret_cast<const aa::V8 *>( tab );
+  T.blocks = reinterpret_cast<const aa::V8 *>( tab + sizeof( aa::tok::NodeTable ) / 4 );
   aa::tok::Lane L;
   aa::tok::Frame F = aa::tok::frame_of( &jobs[active ? j : 0] );
-  L.st = aa::tok::ST_DONE;
+  L.node = aa::tok::N_DONE;
   L.pend_wpos = L.pend_mwpos = aa::tok::kNoPend;
   if ( active ) aa::tok::begin_frame( L, lds, F );
   for ( ;; ) {
     if ( active ) aa::tok::top_up( L, lds, F );
-    if ( !__any( L.st != aa::tok::ST_DONE ) ) break;
-    for ( uint32_t it = 0; it < aa::tok::kPeriod; it++ ) aa::tok::step( L, lds, F );
+    if ( !__any( L.node != aa::tok::N_DONE ) ) break;
+    aa::tok::run_period( L, lds, T, F );
   }
 }
 
@@ -120,9 +132,9 @@ int launch_parse_tokens( const ParseJob * jobs, int n, int max_mbw, void * strea
 {
   const uint32_t lane_bytes = tok::lane_lds_bytes( static_cast<uint32_t>( max_mbw ) );
   int lanes = parse_lanes();
-  if ( static_cast<uint32_t>( lanes ) * lane_bytes > 65536u ) lanes = static_cast<int>( 65536u / lane_bytes );
+  if ( static_cast<uint32_t>( lanes ) * lane_bytes + tok::kTablesBytes > 65536u ) lanes = static_cast<int>( ( 65536u - tok::kTablesBytes ) / lane_bytes );
   if ( lanes < 1 ) return static_cast<int>( hipErrorInvalidValue );
-  hipLaunchKernelGGL( k_parse_tokens, dim3( ( n + lanes - 1 ) / lanes ), dim3( 64 ), static_cast<size_t>( lanes ) * lane_bytes,
+  hipLaunchKernelGGL( k_parse_tokens, dim3( ( n + lanes - 1 ) / lanes ), dim3( 64 ), static_cast<size_t>( lanes ) * lane_bytes + tok::kTablesBytes,
                       static_cast<hipStream_t>( stream ), jobs, n, lanes, lane_bytes );
   return static_cast<int>( hipGetLastError() );
 }

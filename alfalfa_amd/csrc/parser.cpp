@@ -430,7 +430,7 @@ void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa
       const bool skip = flags & AA_MB_SKIP, has_y2 = flags & AA_MB_HAS_Y2;
       if ( !( flags & AA_MB_INTER ) ) intra_mbs++;
 
-      // ---- tokens: Macroblock::parse_tokens (macroblock.cc:475-502); storage order = nz_mask bit order ----
+      // ---- tokens: Macroblock::parse_tokens (macroblock.cc:475-502); storage order = parse order: Y2, Y0..15, U, V ----
       uint8_t * anz = &above_nz_[static_cast<size_t>( col ) * 9];
       mb.coeff_index = coeff_blocks;
       bool any = false;
@@ -438,16 +438,16 @@ void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa
         std::memset( anz, 0, 8 ); std::memset( left_nz, 0, 8 );
         if ( has_y2 ) { anz[8] = 0; left_nz[8] = 0; }   // a non-coded Y2 leaves the chain untouched (frame.cc:255-269)
       } else {
-        int16_t y2_block[16];
-        bool y2_nz = false;
-        if ( has_y2 ) {
-          std::memset( y2_block, 0, sizeof y2_block );
-          y2_nz = parse_block( tok, fp.coeff_probs[Y2], 0, anz[8] + left_nz[8], y2_block );
-          anz[8] = left_nz[8] = y2_nz;
+        uint32_t mask = 0;
+        if ( has_y2 ) {                        // parsed first and stored first
+          int16_t * slot = coeff_out + static_cast<size_t>( coeff_blocks ) * 16;
+          std::memset( slot, 0, 32 );
+          const bool nz = parse_block( tok, fp.coeff_probs[Y2], 0, anz[8] + left_nz[8], slot );
+          anz[8] = left_nz[8] = nz;
+          if ( nz ) { mask |= 1u << 24; coeff_blocks++; }
         }
         const int ytype = has_y2 ? Y_AFTER_Y2 : Y_WITHOUT_Y2;
         const int yfirst = has_y2 ? 1 : 0;
-        uint32_t mask = 0;
         for ( int b = 0; b < 16; b++ ) {
           int16_t * slot = coeff_out + static_cast<size_t>( coeff_blocks ) * 16;
           std::memset( slot, 0, 32 );
@@ -463,10 +463,6 @@ void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa
           const bool nz = parse_block( tok, fp.coeff_probs[UV], 0, a + l, slot );
           a = l = nz;
           if ( nz ) { mask |= 1u << ( 16 + pl * 4 + b ); coeff_blocks++; }
-        }
-        if ( y2_nz ) {
-          std::memcpy( coeff_out + static_cast<size_t>( coeff_blocks ) * 16, y2_block, 32 );
-          mask |= 1u << 24; coeff_blocks++;
         }
         mb.nz_mask = mask;
         any = mask != 0;

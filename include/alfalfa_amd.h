@@ -60,7 +60,8 @@ typedef struct aa_mb_info {
                             (segment + ref + mode adjustments applied, loopfilter.cc:43-79, macroblock.cc:611-623) */
   uint8_t split_partition; /* SPLITMV partition id (mv_partitions index) */
   uint8_t reserved;
-  uint32_t nz_mask;      /* bit b set: block b has stored coefficients. b: 0..15 Y (raster), 16..19 U, 20..23 V, 24 Y2 */
+  uint32_t nz_mask;      /* bit b set: block b has stored coefficients. b: 0..15 Y (raster), 16..19 U, 20..23 V, 24 Y2.
+                            Stored blocks follow each other in PARSE order: Y2 (if bit 24), then bits 0..23 ascending */
   uint32_t coeff_index;  /* index (in 16-coefficient blocks) of this MB's first stored block in the frame's coefficient array */
   union {
     uint8_t b_mode[16];  /* B_PRED: bmode of each 4x4 (intra MBs) */

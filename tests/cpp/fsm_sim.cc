@@ -81,12 +81,13 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
     aa::tok::Lane L;
     std::memset( &L, 0xA5, sizeof L );
     aa::tok::Frame F = aa::tok::frame_of( &J );
-    L.st = aa::tok::ST_DONE; L.pend_wpos = L.pend_mwpos = aa::tok::kNoPend;
+    aa::tok::Tables T { aa::tok::kNodeTable.n, aa::tok::kBlockTable.b };
+    L.node = aa::tok::N_DONE; L.pend_wpos = L.pend_mwpos = aa::tok::kNoPend;
     aa::tok::begin_frame( L, lds, F );
     for ( ;; ) {
       aa::tok::top_up( L, lds, F );
-      if ( L.st == aa::tok::ST_DONE ) break;
-      for ( uint32_t it = 0; it < aa::tok::kPeriod; it++ ) aa::tok::step( L, lds, F );
+      if ( L.node == aa::tok::N_DONE ) break;
+      aa::tok::run_period( L, lds, T, F );
     }
   }
   hdr->num_coeff_blocks = sum.num_coeff_blocks;

@@ -12,7 +12,7 @@ def expand_coeffs(mb, cf):
     for r in range(mbh):
         for c in range(mbw):
             m = int(mb["nz_mask"][r, c]); k = int(mb["coeff_index"][r, c])
-            for b in range(25):
+            for b in [24] + list(range(24)):          # storage order = parse order: Y2 first
                 if (m >> b) & 1:
                     dense[r, c, b] = cf[k]; k += 1
     return dense
