@@ -319,6 +319,11 @@ AA_HD inline void top_up( Lane & L, uint8_t * lds, const Frame & J )
 #else
 #define AA_ANY( x ) ( x )
 #endif
+#if defined( __clang__ )
+#define AA_SELECT( c ) __builtin_unpredictable( c )   // keep `c ? a : b` a select: lanes disagree, there is nothing to predict
+#else
+#define AA_SELECT( c ) ( c )
+#endif
 
 AA_HD inline void store_mb( const Frame & J, uint32_t mi, uint32_t nz_mask, uint32_t coeff_index, uint32_t flags )
 {
@@ -426,9 +431,9 @@ AA_HD inline void step( Lane & L, uint8_t * lds, const Tables & T, const Frame &
   const uint32_t act = h >> 29;
   const bool setm = act == A_SETMAG, emit = act == A_EMIT, zero = act == A_ZERO;
   const uint32_t shifted = 2 * L.mag + ( bit ? 1u : 0u );
-  const uint32_t kept = __builtin_unpredictable( act == A_XBIT ) ? shifted : L.mag;
-  const uint32_t mag = __builtin_unpredictable( setm ) ? ( h >> 15 ) & 7u : kept;
-  const uint32_t tinfo = __builtin_unpredictable( setm ) ? ( h >> 18 ) & 0x1FFu : L.tinfo;
+  const uint32_t kept = AA_SELECT( act == A_XBIT ) ? shifted : L.mag;
+  const uint32_t mag = AA_SELECT( setm ) ? ( h >> 15 ) & 7u : kept;
+  const uint32_t tinfo = AA_SELECT( setm ) ? ( h >> 18 ) & 0x1FFu : L.tinfo;
   L.mag = mag; L.tinfo = tinfo;
   if ( emit ) {                                 // the sign: the token is complete (tokens.cc:126-133)
     const int32_t m = static_cast<int32_t>( mag + ( tinfo & 127u ) );
