@@ -76,28 +76,18 @@ __global__ __launch_bounds__( 64 ) void k_parse_tokens( const ParseJob * jobs, i
   const int lane = threadIdx.x;
   const int j = blockIdx.x * lanes + lane;
   const bool active = lane < lanes && j < n && jobs[j < n ? j : 0].nmb != 0;
-  uint8_t * lds = smem + static_cast<uint32_t>( active ? lane : 0 ) * lane_bytes;
-  // the node and block tables, once per workgroup, behind the lanes' slices
-  uint32_t * tab = reinterpret_cast<uint32_t *>( smem + static_cast<uint32_t>( lanes ) * lane_bytes );
-  {
-    const uint32_t * nsrc = reinterpret_cast<const uint32_t *>( &aa::tok::kNodeTable );
-    const uint32_t * bsrc = reinterpret_cast<const uint32_t *>( &aa::tok::kBlockTable );
-    constexpr uint32_t nw = sizeof( aa::tok::NodeTable ) / 4, bw = sizeof( aa::tok::BlockTable ) / 4;
-    for ( uint32_t k = lane; k < nw + bw; k += 64 ) tab[k] = k < nw ? nsrc[k] : bsrc[k - nw];
-  }
+  for ( uint32_t k = lane; k < aa::tok::kTablesBytes / 4; k += 64 ) reinterpret_cast<uint32_t *>( smem )[k] = aa::tok::table_word( k );
   __syncthreads();
-  aa::tok::Tables T;
-  T.nodes = reinterpret_cast<const aa::V8 *>( tab );
-  T.blocks = reinterpret_cast<const aa::V8 *>( tab + sizeof( aa::tok::NodeTable ) / 4 );
   aa::tok::Lane L;
   aa::tok::Frame F = aa::tok::frame_of( &jobs[active ? j : 0] );
-  L.node = aa::tok::N_DONE;
+  L.rec = aa::tok::R_DONE;
+  L.base = aa::tok::kTablesBytes;
   L.pend_wpos = L.pend_mwpos = aa::tok::kNoPend;
-  if ( active ) aa::tok::begin_frame( L, lds, F );
+  if ( active ) aa::tok::begin_frame( L, smem, aa::tok::kTablesBytes + static_cast<uint32_t>( lane ) * lane_bytes, F );
   for ( ;; ) {
-    if ( active ) aa::tok::top_up( L, lds, F );
-    if ( !__any( L.node != aa::tok::N_DONE ) ) break;
-    aa::tok::run_period( L, lds, T, F );
+    if ( active ) aa::tok::top_up( L, smem, F );
+    if ( !__any( L.rec != aa::tok::R_DONE ) ) break;
+    aa::tok::run_period( L, smem, F );
   }
 }
 

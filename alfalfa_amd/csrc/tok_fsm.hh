@@ -71,7 +71,11 @@ constexpr uint32_t kPeriod = 64;          // steps between ring top-ups (a step 
 constexpr uint32_t kRing = 256;           // bytes per ring
 constexpr uint32_t kChunks = 4;           // 16-byte chunks fetched per top-up (= kPeriod bytes)
 
-// lane LDS layout (byte offsets)
+// Workgroup LDS ("smem"; one flat buffer on the host): the node and block tables at offset 0 -- so that a node record's
+// address is a plain number a record can carry -- then one slice per lane.  Offsets below are relative to a lane's slice.
+constexpr uint32_t kNodeTabOff = 0;       // node records, 8 bytes each (addresses < 512: 9 bits in a record)
+constexpr uint32_t kBlockTabOff = 512;    // block entries, 8 bytes each
+constexpr uint32_t kTablesBytes = 768;    // first lane slice
 constexpr uint32_t kProbs = 0;            // [4][8][3][11] token probabilities
 constexpr uint32_t kXtab = 1056;          // extra-bit probabilities of the six categories, then the sign's 128
 constexpr uint32_t kSignX = 26;           // index of the sign's probability in that table
@@ -88,47 +92,56 @@ constexpr uint8_t kXtabInit[27] = { 159, 165, 145, 173, 148, 140, 176, 155, 140,
 // ---- nodes ----------------------------------------------------------------------------------------------------------
 // 0..10   the token tree (tokens.cc:73-124); node k reads probability k of the current (type, band, context) row
 // 11..36  extra bits: cat1 = 11, cat2 = 12-13, cat3 = 14-16, cat4 = 17-20, cat5 = 21-25, cat6 = 26-36 (node e reads kXtab[e-11])
-// 37      sign
-// 38..40  not decoding: just completed a macroblock / at a macroblock boundary / done with the frame
-enum : uint32_t { N_SIGN = 37, N_MBDONE = 38, N_MB = 39, N_DONE = 40, kNodes = 38 };
-enum : uint32_t { A_NONE = 0, A_SETMAG = 1, A_XBIT = 2, A_EMIT = 3, A_ZERO = 4, A_EOB = 5 };
+// 37..46  the sign, one node per token kind: the record knows the magnitude to add (DCT_1..4: the literal; dct_catN: its
+//         base, the extra bits having been shifted into Lane::mag) and the context the token leaves behind
+// A lane's state is the ADDRESS of its node's record (8 * node); values >= R_MBDONE mean "not decoding".
+enum : uint32_t { kNodes = 47, R_MBDONE = 0x1000, R_MB = 0x1001, R_DONE = 0x1002 };
 // half of a node record = what a decoded 0 / 1 at that node means:
-//   [0,6) next node  [6,14) probability index of the next node  [14] that index is relative to the current row (else to kXtab)
-//   [15,18) literal magnitude  [18,25) constant added to the magnitude when it is emitted  [25,27) context the token leaves
-//   [29,32) action
-constexpr uint32_t half( uint32_t next, uint32_t poff, uint32_t rowrel, uint32_t act, uint32_t k = 0, uint32_t addv = 0, uint32_t c = 0 )
+//   [0,9) address of the next node's record   [9,14) index of the next node's probability   [14] ... in the current row (else in kXtab)
+//   [15] shift the bit into the magnitude   [16] on to the next coefficient position   [17] emit the coefficient   [18] end of block
+//   [19,24) 11 * context the token leaves behind   [24,31) magnitude to add at emission
+constexpr uint32_t H_ROWREL = 1u << 14, H_XS = 1u << 15, H_ADV = 1u << 16, H_EMIT = 1u << 17, H_EOB = 1u << 18;
+constexpr uint32_t half( uint32_t next, uint32_t pk, uint32_t flags, uint32_t ctx = 0, uint32_t addv = 0 )
 {
-  return next | ( poff << 6 ) | ( rowrel << 14 ) | ( k << 15 ) | ( addv << 18 ) | ( c << 25 ) | ( act << 29 );
+  return ( next * 8 ) | ( pk << 9 ) | flags | ( ( ctx * 11 ) << 19 ) | ( addv << 24 );
 }
-constexpr uint32_t tree( uint32_t k ) { return half( k, k, 1, A_NONE ); }                       // on to tree node k
-constexpr uint32_t lit( uint32_t mag, uint32_t ctx ) { return half( N_SIGN, kSignX, 0, A_SETMAG, mag, 0, ctx ); }   // DCT_1..4
-// dct_catN: value = base + N extra bits, base = 2^N + 3 for cat1..5 (start the shift register at 1, add 3), 67 for cat6
-// (start at 0, add 67)
-constexpr uint32_t cat( uint32_t first_node, uint32_t start, uint32_t addv ) { return half( first_node, first_node - 11, 0, A_SETMAG, start, addv, 2 ); }
-constexpr uint32_t xbit( uint32_t e, bool last ) { return last ? half( N_SIGN, kSignX, 0, A_XBIT ) : half( e + 1, e + 1 - 11, 0, A_XBIT ); }
+constexpr uint32_t tree( uint32_t k ) { return half( k, k, H_ROWREL ); }                       // on to tree node k
+constexpr uint32_t sign_node( uint32_t addv )   // DCT_1..4 -> 37..40, dct_cat1..6 (bases 5,7,11,19,35,67) -> 41..46
+{
+  return addv <= 4 ? 36 + addv : ( addv == 5 ? 41 : addv == 7 ? 42 : addv == 11 ? 43 : addv == 19 ? 44 : addv == 35 ? 45 : 46 );
+}
+constexpr uint32_t to_sign( uint32_t addv, uint32_t flags = 0 ) { return half( sign_node( addv ), kSignX, flags ); }
+constexpr uint32_t to_extra( uint32_t e ) { return half( e, e - 11, 0 ); }
 struct NodeTable { V8 n[kNodes]; };
 constexpr NodeTable make_nodes()
 {
   NodeTable t {};
-  t.n[0] = { half( 0, 0, 1, A_EOB ), tree( 1 ) };
-  t.n[1] = { half( 1, 1, 1, A_ZERO ), tree( 2 ) };          // a ZERO token is followed by node 1 of the next position (no EOB check)
-  t.n[2] = { lit( 1, 1 ), tree( 3 ) };
+  t.n[0] = { half( 0, 0, H_EOB ), tree( 1 ) };
+  t.n[1] = { half( 1, 1, H_ROWREL | H_ADV ), tree( 2 ) };   // a ZERO token: node 1 of the next position (no EOB check), context 0
+  t.n[2] = { to_sign( 1 ), tree( 3 ) };
   t.n[3] = { tree( 4 ), tree( 6 ) };
-  t.n[4] = { lit( 2, 2 ), tree( 5 ) };
-  t.n[5] = { lit( 3, 2 ), lit( 4, 2 ) };
+  t.n[4] = { to_sign( 2 ), tree( 5 ) };
+  t.n[5] = { to_sign( 3 ), to_sign( 4 ) };
   t.n[6] = { tree( 7 ), tree( 8 ) };
-  t.n[7] = { cat( 11, 1, 3 ), cat( 12, 1, 3 ) };
+  t.n[7] = { to_extra( 11 ), to_extra( 12 ) };
   t.n[8] = { tree( 9 ), tree( 10 ) };
-  t.n[9] = { cat( 14, 1, 3 ), cat( 17, 1, 3 ) };
-  t.n[10] = { cat( 21, 1, 3 ), cat( 26, 0, 67 ) };
-  for ( uint32_t e = 11; e <= 36; e++ ) {
-    const bool last = e == 11 || e == 13 || e == 16 || e == 20 || e == 25 || e == 36;
-    t.n[e] = { xbit( e, last ), xbit( e, last ) };
+  t.n[9] = { to_extra( 14 ), to_extra( 17 ) };
+  t.n[10] = { to_extra( 21 ), to_extra( 26 ) };
+  const uint32_t first[6] = { 11, 12, 14, 17, 21, 26 }, last[6] = { 11, 13, 16, 20, 25, 36 }, base[6] = { 5, 7, 11, 19, 35, 67 };
+  for ( uint32_t c = 0; c < 6; c++ )
+    for ( uint32_t e = first[c]; e <= last[c]; e++ ) {
+      const uint32_t h = e == last[c] ? to_sign( base[c], H_XS ) : ( to_extra( e + 1 ) | H_XS );
+      t.n[e] = { h, h };
+    }
+  const uint32_t addvs[10] = { 1, 2, 3, 4, 5, 7, 11, 19, 35, 67 };
+  for ( uint32_t k = 0; k < 10; k++ ) {                     // the sign: emit, then the EOB check of the next position
+    const uint32_t h = half( 0, 0, H_ROWREL | H_ADV | H_EMIT, addvs[k] == 1 ? 1 : 2, addvs[k] );
+    t.n[37 + k] = { h, h };
   }
-  t.n[N_SIGN] = { half( 0, 0, 1, A_EMIT ), half( 0, 0, 1, A_EMIT ) };   // then the EOB check of the next position
   return t;
 }
 constexpr NodeTable kNodeTable = make_nodes();
+static_assert( sizeof( NodeTable ) <= kBlockTabOff, "node records must stay below the block table" );
 
 // ---- blocks ---------------------------------------------------------------------------------------------------------
 // parse order within a macroblock (macroblock.cc:480-500): 0 = Y2, 1..16 = Y, 17..20 = U, 21..24 = V.  Per block: where its
@@ -148,14 +161,11 @@ constexpr BlockTable make_blocks()
   return t;
 }
 constexpr BlockTable kBlockTable = make_blocks();
-
-struct Tables { const V8 * nodes; const V8 * blocks; };       // where a workgroup keeps the two tables (LDS on the GPU)
-constexpr uint32_t kTablesBytes = ( sizeof( NodeTable ) + sizeof( BlockTable ) + 15 ) & ~15u;
+static_assert( kBlockTabOff + sizeof( BlockTable ) <= kTablesBytes, "tables overlap the first lane" );
 
 constexpr uint64_t nib( std::initializer_list<unsigned> v ) { uint64_t r = 0; unsigned i = 0; for ( unsigned x : v ) r |= static_cast<uint64_t>( x ) << ( 4 * i++ ); return r; }
-constexpr uint64_t tri( std::initializer_list<unsigned> v ) { uint64_t r = 0; unsigned i = 0; for ( unsigned x : v ) r |= static_cast<uint64_t>( x ) << ( 3 * i++ ); return r; }
 constexpr uint64_t kZigzagNib = nib( { 0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15 } );
-constexpr uint64_t kBandTri = tri( { 0, 1, 2, 3, 6, 4, 5, 6, 6, 6, 6, 6, 6, 6, 6, 7, 0 } );   // coefficient band of position 0..16
+constexpr uint64_t kBandNib = nib( { 0, 1, 2, 3, 6, 4, 5, 6, 6, 6, 6, 6, 6, 6, 6, 7 } );   // coefficient band of position 0..15 (16: 0)
 
 // What a lane needs of its ParseJob at every step, held in registers (the job itself stays in HBM and is only consulted on
 // the rare paths: partition switches, the end of the frame).
@@ -190,10 +200,10 @@ AA_HD inline Chunk16 load16( const AA_GLOBAL uint8_t * p )          // 16-byte a
   Chunk16 c; c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
   return c;
 }
-AA_HD inline void lds_store16( uint8_t * lds, uint32_t off, const Chunk16 & c )
+AA_HD inline void lds_store16( uint8_t * smem, uint32_t off, const Chunk16 & c )
 {
   V16 v; v.x = c.w[0]; v.y = c.w[1]; v.z = c.w[2]; v.w = c.w[3];
-  *reinterpret_cast<V16 *>( lds + off ) = v;
+  *reinterpret_cast<V16 *>( smem + off ) = v;
 }
 // bytes at offsets >= end (absolute offsets at .. at+15) cleared: partitions end anywhere, and past the end a boolean
 // decoder reads zeros (bool_decoder.hh:56-65) -- done once per chunk so that the step does not have to ask
@@ -207,25 +217,28 @@ AA_HD inline Chunk16 mask_past_end( Chunk16 c, uint32_t at, uint32_t end )
   return c;
 }
 
+// All LDS addresses in a Lane are offsets into the workgroup's smem (the lane's slice starts at `base`).
 struct Lane {
-  // boolean decoder of the current partition: 32-bit window, `count` valid bits below the 8 being compared
+  uint32_t base;                  // offset of this lane's slice
+  // boolean decoder of the current partition: 32-bit window; sh = 16 - (valid bits below the 8 being compared)
   uint32_t value, range;
-  int32_t count;
+  int32_t sh;
   uint32_t rpos, rend;            // next stream byte to shift in / end of the partition (offsets into the frame)
   uint32_t wpos;                  // stream ring holds [wpos - kRing, wpos)
   uint32_t mwpos;                 // flag ring holds macroblocks [mwpos - kRing, mwpos)
   uint32_t pend_wpos, pend_mwpos; // what the chunks in flight are for (kNoPend: nothing in flight)
   Chunk16 pend[kChunks], mpend[kChunks];
   // token in progress
-  uint32_t node;                  // node about to be decoded (N_MB / N_DONE: not decoding)
-  uint32_t paddr;                 // LDS offset of its probability
-  uint32_t rowoff, typeoff;       // LDS offsets of the current probability row / of this block type's probabilities
-  uint32_t idx, mag, tinfo, nonzero;   // tinfo: constant to add at emission | context left behind << 7
+  uint32_t rec;                   // address of the record of the node about to be decoded (>= R_MBDONE: not decoding)
+  uint32_t paddr;                 // address of its probability
+  uint32_t rowaddr, typeaddr;     // addresses of the current probability row / of this block type's probabilities
+  uint32_t idx, mag, nonzero;
   // block in progress
-  uint32_t blk, nzsel, blkbit;
+  uint32_t blkaddr;               // address of the BlockTable entry of the block AFTER the current one
+  uint32_t nzsel, blkbit;
   // macroblock in progress
   uint32_t ctxbits;               // non-zero flags: above (this column) bits 0-8, left bits 16-24
-  uint32_t flags, nz_mask, mb_first, coeff_blocks, ytypeoff, yfirst;
+  uint32_t flags, nz_mask, mb_first, coeff_blocks, ytypeaddr, yfirst;
   // position
   uint32_t mi, col, row, part;
   uint32_t steps;
@@ -241,54 +254,54 @@ AA_HD inline void zero_slot( const Frame & J, uint32_t block )
 
 // ---- stream ring ----------------------------------------------------------------------------------------------------
 // synchronous (re)fill of the whole stream ring around rpos: start of a partition
-AA_HD inline void prime_stream( Lane & L, uint8_t * lds, const Frame & J )
+AA_HD inline void prime_stream( Lane & L, uint8_t * smem, const Frame & J )
 {
   const uint32_t base = L.rpos & ~15u;
   for ( uint32_t k = 0; k < kRing / 16; k++ ) {
     const uint32_t at = base + 16 * k;
     Chunk16 c; c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;
     if ( at < J.data_padded ) c = load16( J.data + at );
-    lds_store16( lds, kStream + ( at & ( kRing - 1 ) ), mask_past_end( c, at, L.rend ) );
+    lds_store16( smem, L.base + kStream + ( at & ( kRing - 1 ) ), mask_past_end( c, at, L.rend ) );
   }
   L.wpos = base + kRing;
   L.pend_wpos = kNoPend;
 }
 
 // decoder of partition `p` at its first bit (BoolDecoder ctor, bool_decoder.hh:45-54)
-AA_HD inline void start_partition( Lane & L, uint8_t * lds, const Frame & J, uint32_t p )
+AA_HD inline void start_partition( Lane & L, uint8_t * smem, const Frame & J, uint32_t p )
 {
   L.part = p;
   L.rpos = J.job->fp.part_off[p];
   L.rend = J.job->fp.part_off[p] + J.job->fp.part_size[p];
-  prime_stream( L, lds, J );
+  prime_stream( L, smem, J );
   uint32_t v = 0;
-  for ( int k = 0; k < 4; k++ ) { v = ( v << 8 ) | lds[kStream + ( L.rpos & ( kRing - 1 ) )]; L.rpos++; }
-  L.value = v; L.count = 24; L.range = 255;
+  for ( int k = 0; k < 4; k++ ) { v = ( v << 8 ) | smem[L.base + kStream + ( L.rpos & ( kRing - 1 ) )]; L.rpos++; }
+  L.value = v; L.sh = -8; L.range = 255;
 }
 
-AA_HD inline void switch_partition( Lane & L, uint8_t * lds, const Frame & J, uint32_t p )
+AA_HD inline void switch_partition( Lane & L, uint8_t * smem, const Frame & J, uint32_t p )
 {
-  uint32_t * s = reinterpret_cast<uint32_t *>( lds + kPart + 16 * L.part );
-  s[0] = L.value; s[1] = L.range | ( static_cast<uint32_t>( L.count ) << 8 ); s[2] = L.rpos; s[3] = 1;
-  const uint32_t * t = reinterpret_cast<const uint32_t *>( lds + kPart + 16 * p );
-  if ( !t[3] ) { start_partition( L, lds, J, p ); return; }
+  uint32_t * s = reinterpret_cast<uint32_t *>( smem + L.base + kPart + 16 * L.part );
+  s[0] = L.value; s[1] = L.range | ( static_cast<uint32_t>( L.sh + 64 ) << 8 ); s[2] = L.rpos; s[3] = 1;
+  const uint32_t * t = reinterpret_cast<const uint32_t *>( smem + L.base + kPart + 16 * p );
+  if ( !t[3] ) { start_partition( L, smem, J, p ); return; }
   L.part = p;
-  L.value = t[0]; L.range = t[1] & 255u; L.count = static_cast<int32_t>( t[1] >> 8 ); L.rpos = t[2];
+  L.value = t[0]; L.range = t[1] & 255u; L.sh = static_cast<int32_t>( t[1] >> 8 ) - 64; L.rpos = t[2];
   L.rend = J.job->fp.part_off[p] + J.job->fp.part_size[p];
-  prime_stream( L, lds, J );
+  prime_stream( L, smem, J );
 }
 
 // ---- every kPeriod steps, all lanes together: land the chunks requested a period ago, request the next ---------------
-AA_HD inline void top_up( Lane & L, uint8_t * lds, const Frame & J )
+AA_HD inline void top_up( Lane & L, uint8_t * smem, const Frame & J )
 {
-  if ( L.node == N_DONE ) return;
+  if ( L.rec == R_DONE ) return;
   if ( L.pend_wpos == L.wpos ) {
     for ( uint32_t k = 0; k < kChunks; k++ )
-      lds_store16( lds, kStream + ( ( L.wpos + 16 * k ) & ( kRing - 1 ) ), mask_past_end( L.pend[k], L.wpos + 16 * k, L.rend ) );
+      lds_store16( smem, L.base + kStream + ( ( L.wpos + 16 * k ) & ( kRing - 1 ) ), mask_past_end( L.pend[k], L.wpos + 16 * k, L.rend ) );
     L.wpos += 16 * kChunks;
   }
   if ( L.pend_mwpos == L.mwpos ) {
-    for ( uint32_t k = 0; k < kChunks; k++ ) lds_store16( lds, kMeta + ( ( L.mwpos + 16 * k ) & ( kRing - 1 ) ), L.mpend[k] );
+    for ( uint32_t k = 0; k < kChunks; k++ ) lds_store16( smem, L.base + kMeta + ( ( L.mwpos + 16 * k ) & ( kRing - 1 ) ), L.mpend[k] );
     L.mwpos += 16 * kChunks;
   }
   L.pend_wpos = L.pend_mwpos = kNoPend;
@@ -316,13 +329,17 @@ AA_HD inline void top_up( Lane & L, uint8_t * lds, const Frame & J )
 // ---- block / macroblock transitions ----------------------------------------------------------------------------------
 #if defined( __HIP_DEVICE_COMPILE__ )
 #define AA_ANY( x ) ( __any( x ) != 0 )        // wave-uniform: does any lane ...
+#define AA_UBFE( v, off, width ) __builtin_amdgcn_ubfe( ( v ), ( off ), ( width ) )
+// The workgroup's dynamic LDS starts at LDS address 0 (the kernel has no static LDS), so an offset into smem IS the LDS
+// address: form the pointer from the number and spare the hot loop one "add the base symbol" per access.
+template <class T> __device__ inline __attribute__( ( address_space( 3 ) ) ) T * lds_at( uint8_t *, uint32_t off )
+{
+  return (__attribute__( ( address_space( 3 ) ) ) T *) static_cast<uintptr_t>( off );
+}
 #else
 #define AA_ANY( x ) ( x )
-#endif
-#if defined( __clang__ )
-#define AA_SELECT( c ) __builtin_unpredictable( c )   // keep `c ? a : b` a select: lanes disagree, there is nothing to predict
-#else
-#define AA_SELECT( c ) ( c )
+#define AA_UBFE( v, off, width ) ( ( ( v ) >> ( off ) ) & ( ( 1u << ( width ) ) - 1u ) )
+template <class T> inline T * lds_at( uint8_t * smem, uint32_t off ) { return reinterpret_cast<T *>( smem + off ); }
 #endif
 
 AA_HD inline void store_mb( const Frame & J, uint32_t mi, uint32_t nz_mask, uint32_t coeff_index, uint32_t flags )
@@ -333,31 +350,33 @@ AA_HD inline void store_mb( const Frame & J, uint32_t mi, uint32_t nz_mask, uint
   mb->flags = static_cast<uint8_t>( flags );
 }
 
-// Make block `L.blk` (its BlockTable entry in `e`) the current one: contexts from the non-zero flags, first probability row.
-AA_HD inline void setup_block( Lane & L, const V8 e )
+// Make block `blk` of the macroblock the current one: contexts from the non-zero flags, first probability row.
+AA_HD inline void setup_block( Lane & L, const uint8_t * smem, uint32_t blk )
 {
+  const V8 e = *reinterpret_cast<const V8 *>( smem + kBlockTabOff + 8 * blk );
   const uint32_t a = e.x & 255u, l = ( e.x >> 8 ) & 255u, sel = ( e.x >> 16 ) & 255u;
+  L.blkaddr = kBlockTabOff + 8 * ( blk + 1 );
   L.nzsel = e.y;
   L.blkbit = 1u << ( e.x >> 24 );
   const uint32_t ctx = ( ( L.ctxbits >> a ) & 1u ) + ( ( L.ctxbits >> l ) & 1u );
-  L.typeoff = sel == 0 ? L.ytypeoff : ( sel == 1 ? kProbs + UV * 264u : kProbs + Y2 * 264u );
+  L.typeaddr = sel == 0 ? L.ytypeaddr : L.base + kProbs + ( sel == 1 ? UV : Y2 ) * 264u;
   L.idx = sel == 0 ? L.yfirst : 0u;                         // Y blocks after a Y2 start at position 1 (tokens.cc:61)
-  L.rowoff = L.typeoff + L.idx * 33u + ctx * 11u;           // band of position 0 / 1 is 0 / 1
-  L.node = 0; L.paddr = L.rowoff;
-  L.nonzero = 0;
+  L.rowaddr = L.typeaddr + L.idx * 33u + ctx * 11u;         // band of position 0 / 1 is 0 / 1
+  L.rec = 0; L.paddr = L.rowaddr;
+  L.nonzero = 0; L.mag = 0;
 }
 
-// The slow path, for lanes at a macroblock boundary (node N_MBDONE: the step just completed one; N_MB: waiting for flags):
+// The slow path, for lanes at a macroblock boundary (R_MBDONE: the step just completed one; R_MB: waiting for flags):
 // take macroblocks until one has tokens (skipped ones are settled on the spot), the flag ring runs dry (try again later)
 // or the frame ends.  Everything rare lives here: row ends, partition switches, the end of the frame.
-AA_HD inline void macroblock_boundary( Lane & L, uint8_t * lds, const Tables & T, const Frame & J )
+AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J )
 {
-  uint16_t * const above = reinterpret_cast<uint16_t *>( lds + kAbove );
-  if ( L.node == N_MBDONE ) { L.mi++; L.col++; L.node = N_MB; }
+  uint16_t * const above = reinterpret_cast<uint16_t *>( smem + L.base + kAbove );
+  if ( L.rec == R_MBDONE ) { L.mi++; L.col++; L.rec = R_MB; }
   if ( ++L.steps > J.max_steps ) {             // cannot happen for any input; if it does the frame is reported, not hung on
     AA_GLOBAL FrameSummary * sum = (AA_GLOBAL FrameSummary *) J.job->summary;
     sum->num_coeff_blocks = L.coeff_blocks; sum->steps = 0xFFFFFFFFu;
-    L.node = N_DONE;
+    L.rec = R_DONE;
     return;
   }
   for ( ;; ) {
@@ -365,24 +384,23 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * lds, const Tables & T
       AA_GLOBAL FrameSummary * sum = (AA_GLOBAL FrameSummary *) J.job->summary;
       sum->num_coeff_blocks = L.coeff_blocks;
       sum->steps = L.steps;
-      L.node = N_DONE;
+      L.rec = R_DONE;
       return;
     }
     if ( L.mi >= L.mwpos ) return;                          // flags not here yet (only a long run of skipped macroblocks gets ahead of the ring)
     if ( L.col == J.mbw ) {
       L.col = 0; L.row++; L.ctxbits = 0;
-      if ( J.nparts > 1 ) switch_partition( L, lds, J, L.row % J.nparts );
+      if ( J.nparts > 1 ) switch_partition( L, smem, J, L.row % J.nparts );
     }
-    const uint32_t flags = lds[kMeta + ( L.mi & ( kRing - 1 ) )];
+    const uint32_t flags = smem[L.base + kMeta + ( L.mi & ( kRing - 1 ) )];
     const uint32_t has_y2 = flags & AA_MB_HAS_Y2;
     L.ctxbits = ( L.ctxbits & 0x01FF0000u ) | above[L.col];
     L.mb_first = L.coeff_blocks;
     if ( !( flags & AA_MB_SKIP ) ) {
       L.flags = flags; L.nz_mask = 0;
-      L.ytypeoff = kProbs + ( has_y2 ? Y_AFTER_Y2 : Y_WITHOUT_Y2 ) * 264u;
+      L.ytypeaddr = L.base + kProbs + ( has_y2 ? Y_AFTER_Y2 : Y_WITHOUT_Y2 ) * 264u;
       L.yfirst = has_y2 ? 1u : 0u;
-      L.blk = has_y2 ? 0u : 1u;
-      setup_block( L, T.blocks[L.blk] );
+      setup_block( L, smem, has_y2 ? 0u : 1u );
       return;
     }
     L.ctxbits &= has_y2 ? 0u : 0x01000100u;                 // a non-coded Y2 leaves its chain untouched (frame.cc:255-269)
@@ -392,27 +410,29 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * lds, const Tables & T
   }
 }
 
-AA_HD inline bool at_boundary( const Lane & L ) { return L.node == N_MBDONE || L.node == N_MB; }
+AA_HD inline bool at_boundary( const Lane & L ) { return L.rec == R_MBDONE || L.rec == R_MB; }
 
 // ---- one step: decode one bool (lanes with a node to decode; the others sit it out) -------------------------------------
-// Straight-line code: everything the bit can mean is computed and selected, the only predicated regions are stores.
-AA_HD inline void step( Lane & L, uint8_t * lds, const Tables & T, const Frame & J )
+// Straight-line code: what the bit means comes out of the node's record as bit fields and is applied with arithmetic;
+// the only predicated regions are the stores.  A lone wave gets one issue slot every 4 cycles whatever the instruction, so
+// every instruction saved here is 4 cycles per bool.
+// -> (wave-uniform) some lane has completed a macroblock: leave the hot loop
+AA_HD inline bool step( Lane & L, uint8_t * smem, const Frame & J )
 {
-  if ( L.node >= N_MBDONE ) return;
+  if ( L.rec >= R_MBDONE ) return false;
   L.steps++;
 
   // the LDS reads of a step; all addresses were known at the end of the previous one
-  const uint32_t prob = lds[L.paddr];
-  const uint32_t raw = lds[kStream + ( L.rpos & ( kRing - 1 ) )];
-  const V8 rec = T.nodes[L.node];
-  const V8 nextblk = T.blocks[L.blk + 1];
+  const uint32_t prob = *lds_at<const uint8_t>( smem, L.paddr );
+  const uint32_t raw = *lds_at<const uint8_t>( smem, L.base + kStream + ( L.rpos & ( kRing - 1 ) ) );
+  const V8 rec = *lds_at<const V8>( smem, L.rec );
+  const V8 nextblk = *lds_at<const V8>( smem, L.blkaddr );
 
-  // top the window up by one byte whenever one fits: a decode shifts out at most 7 bits, so the 8 bits being compared are
-  // always real (count >= 0) and the refill is never on the critical path
-  // (mask arithmetic rather than a conditional: the compiler would otherwise branch around the ring read and wait for it there)
-  const uint32_t room = static_cast<uint32_t>( ( L.count - 17 ) >> 31 );        // all ones iff count <= 16
-  L.value |= ( raw << ( ( 16 - L.count ) & 31 ) ) & room;
-  L.count += static_cast<int32_t>( 8u & room );
+  // top the window up by one byte whenever one fits (sh >= 0): a decode shifts out at most 7 bits, so the 8 bits being
+  // compared are always real and the refill is never on the critical path.  Mask arithmetic, no condition.
+  const uint32_t room = ~static_cast<uint32_t>( L.sh >> 31 );
+  L.value |= ( raw << ( L.sh & 31 ) ) & room;
+  L.sh -= static_cast<int32_t>( 8u & room );
   L.rpos -= room;
 
   // BoolDecoder::get (bool_decoder.hh:67-107)
@@ -424,46 +444,38 @@ AA_HD inline void step( Lane & L, uint8_t * lds, const Tables & T, const Frame &
   const int shift = __builtin_clz( range ) - 24;
   L.range = range << shift;
   L.value = value << shift;
-  L.count -= shift;
+  L.sh += shift;
 
   // what the node says this bit means
   const uint32_t h = bit ? rec.y : rec.x;
-  const uint32_t act = h >> 29;
-  const bool setm = act == A_SETMAG, emit = act == A_EMIT, zero = act == A_ZERO;
-  const uint32_t shifted = 2 * L.mag + ( bit ? 1u : 0u );
-  const uint32_t kept = AA_SELECT( act == A_XBIT ) ? shifted : L.mag;
-  const uint32_t mag = AA_SELECT( setm ) ? ( h >> 15 ) & 7u : kept;
-  const uint32_t tinfo = AA_SELECT( setm ) ? ( h >> 18 ) & 0x1FFu : L.tinfo;
-  L.mag = mag; L.tinfo = tinfo;
-  if ( emit ) {                                 // the sign: the token is complete (tokens.cc:126-133)
-    const int32_t m = static_cast<int32_t>( mag + ( tinfo & 127u ) );
+  const uint32_t xs = AA_UBFE( h, 15, 1 );
+  const uint32_t mag = ( L.mag << xs ) | ( ( bit ? 1u : 0u ) & xs );    // extra bits shift in; everything else leaves it alone
+  L.mag = mag;
+  if ( h & H_EMIT ) {                           // the sign: the token is complete (tokens.cc:126-133)
+    const int32_t m = static_cast<int32_t>( mag + AA_UBFE( h, 24, 7 ) );
     const uint32_t zz = static_cast<uint32_t>( kZigzagNib >> ( L.idx * 4 ) ) & 15u;
     J.coeffs[static_cast<size_t>( L.coeff_blocks ) * 16 + zz] = static_cast<int16_t>( bit ? -m : m );
+    L.mag = 0; L.nonzero = 1;
   }
-  const uint32_t nonzero = L.nonzero | ( emit ? 1u : 0u );
-  const bool adv = emit || zero;                // on to the next coefficient position
-  const uint32_t idx = L.idx + ( adv ? 1u : 0u );
-  const uint32_t ctx = zero ? 0u : tinfo >> 7;
-  const uint32_t band = static_cast<uint32_t>( kBandTri >> ( idx * 3 ) ) & 7u;
-  const uint32_t rowoff = adv ? L.typeoff + band * 33u + ctx * 11u : L.rowoff;
-  const uint32_t node = h & 63u;
-  const uint32_t paddr = ( ( h >> 14 ) & 1u ? rowoff : kXtab ) + ( ( h >> 6 ) & 255u );
-  const bool bend = act == A_EOB || ( adv && idx == 16 );
+  const uint32_t adv = AA_UBFE( h, 16, 1 );     // on to the next coefficient position?
+  const uint32_t idx = L.idx + adv;
+  const uint32_t band = static_cast<uint32_t>( kBandNib >> ( ( idx * 4 ) & 63 ) ) & 15u;
+  const uint32_t rowaddr = adv ? L.typeaddr + band * 33u + AA_UBFE( h, 19, 5 ) : L.rowaddr;
+  const uint32_t paddr = ( ( h & H_ROWREL ) ? rowaddr : L.base + kXtab ) + AA_UBFE( h, 9, 5 );
+  const bool bend = ( h & H_EOB ) || idx == 16;
+  L.idx = idx; L.rowaddr = rowaddr; L.paddr = paddr; L.rec = h & 511u;
 
-  if ( !AA_ANY( bend ) ) {                      // (wave-uniform) nobody ends a block in this step
-    L.nonzero = nonzero; L.idx = idx; L.rowoff = rowoff; L.node = node; L.paddr = paddr;
-    return;
-  }
+  if ( !AA_ANY( bend ) ) return false;          // (wave-uniform) nobody ends a block in this step
+
   // ---- end of a block (applied to the lanes with `bend`) ----
-  const uint32_t ctxbits = nonzero ? L.ctxbits | L.nzsel : L.ctxbits & ~L.nzsel;
-  const bool commit = bend && nonzero;
+  const uint32_t ctxbits = L.nonzero ? L.ctxbits | L.nzsel : L.ctxbits & ~L.nzsel;
+  const bool commit = bend && L.nonzero;
   const uint32_t coeff_blocks = L.coeff_blocks + ( commit ? 1u : 0u );
   if ( commit ) zero_slot( J, coeff_blocks );
   const uint32_t nz_mask = commit ? L.nz_mask | L.blkbit : L.nz_mask;
-  const uint32_t blk = L.blk + 1;
-  const bool mbdone = bend && blk == 25;
+  const bool mbdone = bend && L.blkaddr == kBlockTabOff + 8 * 25;
   if ( mbdone ) {                               // the macroblock is complete: its record, its column's flags
-    reinterpret_cast<uint16_t *>( lds + kAbove )[L.col] = static_cast<uint16_t>( ctxbits );
+    *lds_at<uint16_t>( smem, L.base + kAbove + 2 * L.col ) = static_cast<uint16_t>( ctxbits );
     uint32_t flags = L.flags;
     flags |= nz_mask ? AA_MB_HAS_NONZERO : ( ( flags & AA_MB_HAS_Y2 ) ? AA_MB_LF_SKIP_INNER : 0u );
     store_mb( J, L.mi, nz_mask, L.mb_first, flags );
@@ -471,40 +483,55 @@ AA_HD inline void step( Lane & L, uint8_t * lds, const Tables & T, const Frame &
   // the block after it (never a Y2)
   const uint32_t a = nextblk.x & 255u, l = ( nextblk.x >> 8 ) & 255u, uv = ( nextblk.x >> 16 ) & 255u;
   const uint32_t nctx = ( ( ctxbits >> a ) & 1u ) + ( ( ctxbits >> l ) & 1u );
-  const uint32_t ntypeoff = uv ? kProbs + UV * 264u : L.ytypeoff;
+  const uint32_t ntypeaddr = uv ? L.base + kProbs + UV * 264u : L.ytypeaddr;
   const uint32_t nidx = uv ? 0u : L.yfirst;
-  const uint32_t nrowoff = ntypeoff + nidx * 33u + nctx * 11u;
+  const uint32_t nrowaddr = ntypeaddr + nidx * 33u + nctx * 11u;
   L.coeff_blocks = coeff_blocks; L.nz_mask = nz_mask;
   L.ctxbits = bend ? ctxbits : L.ctxbits;
-  L.blk = bend ? blk : L.blk;
+  L.blkaddr = bend ? L.blkaddr + 8 : L.blkaddr;
   L.nzsel = bend ? nextblk.y : L.nzsel;
   L.blkbit = bend ? 1u << ( nextblk.x >> 24 ) : L.blkbit;
-  L.typeoff = bend ? ntypeoff : L.typeoff;
-  L.nonzero = bend ? 0u : nonzero;
-  L.idx = bend ? nidx : idx;
-  L.rowoff = bend ? nrowoff : rowoff;
-  L.node = bend ? ( mbdone ? static_cast<uint32_t>( N_MBDONE ) : 0u ) : node;
-  L.paddr = bend ? nrowoff : paddr;
+  L.typeaddr = bend ? ntypeaddr : L.typeaddr;
+  L.nonzero = bend ? 0u : L.nonzero;
+  L.mag = bend ? 0u : L.mag;
+  L.idx = bend ? nidx : L.idx;
+  L.rowaddr = bend ? nrowaddr : L.rowaddr;
+  L.rec = bend ? ( mbdone ? static_cast<uint32_t>( R_MBDONE ) : 0u ) : L.rec;
+  L.paddr = bend ? nrowaddr : L.paddr;
+  return AA_ANY( mbdone );
 }
 
 // One period of a wave: kPeriod steps, leaving the hot loop whenever a lane has reached a macroblock boundary.
-AA_HD inline void run_period( Lane & L, uint8_t * lds, const Tables & T, const Frame & J )
+AA_HD inline void run_period( Lane & L, uint8_t * smem, const Frame & J )
 {
   uint32_t it = 0;
   while ( it < kPeriod ) {
     if ( AA_ANY( at_boundary( L ) ) ) {
-      if ( at_boundary( L ) ) macroblock_boundary( L, lds, T, J );
+      if ( at_boundary( L ) ) macroblock_boundary( L, smem, J );
       it++;                                                 // (a lane waiting for flags must not spin the period away)
-      if ( !AA_ANY( L.node < N_MBDONE ) ) break;            // nobody has anything to decode
+      if ( !AA_ANY( L.rec < R_MBDONE ) ) break;             // nobody has anything to decode
     }
-    do { step( L, lds, T, J ); it++; } while ( it < kPeriod && !AA_ANY( at_boundary( L ) ) );
+    bool leave;
+    do { leave = step( L, smem, J ); it++; } while ( it < kPeriod && !leave );
   }
 }
 
 // ---- a lane's life ---------------------------------------------------------------------------------------------------
-AA_HD inline void begin_frame( Lane & L, uint8_t * lds, const Frame & J )
+// the node and block tables, once per workgroup: word k of kTablesBytes / 4 (the caller spreads k over its threads)
+AA_HD inline uint32_t table_word( uint32_t k )
+{
+  const uint32_t * n = reinterpret_cast<const uint32_t *>( &kNodeTable );
+  const uint32_t * b = reinterpret_cast<const uint32_t *>( &kBlockTable );
+  if ( k < sizeof( NodeTable ) / 4 ) return n[k];
+  if ( k >= kBlockTabOff / 4 && k < ( kBlockTabOff + sizeof( BlockTable ) ) / 4 ) return b[k - kBlockTabOff / 4];
+  return 0;
+}
+
+AA_HD inline void begin_frame( Lane & L, uint8_t * smem, uint32_t base, const Frame & J )
 {
   // lane LDS: probabilities, constants, zeroed above-row flags / partition save area
+  L.base = base;
+  uint8_t * lds = smem + base;
   const AA_GLOBAL uint32_t * src = (const AA_GLOBAL uint32_t *) &J.job->fp.coeff_probs[0][0][0][0];
   uint32_t * dst = reinterpret_cast<uint32_t *>( lds + kProbs );
   for ( uint32_t k = 0; k < 1056 / 4; k++ ) dst[k] = src[k];
@@ -512,20 +539,21 @@ AA_HD inline void begin_frame( Lane & L, uint8_t * lds, const Frame & J )
   for ( uint32_t k = 0; k < 128 / 4; k++ ) reinterpret_cast<uint32_t *>( lds + kPart )[k] = 0;
   for ( uint32_t k = 0; k < J.mbw; k++ ) reinterpret_cast<uint16_t *>( lds + kAbove )[k] = 0;
   L.mi = 0; L.col = 0; L.row = 0; L.ctxbits = 0; L.coeff_blocks = 0; L.steps = 0;
-  L.flags = L.nz_mask = L.mb_first = L.ytypeoff = L.yfirst = 0;
-  L.blk = L.idx = L.typeoff = L.rowoff = L.nonzero = L.tinfo = L.nzsel = L.blkbit = 0;
-  L.paddr = kXtab; L.mag = 0;
+  L.flags = L.nz_mask = L.mb_first = L.yfirst = 0;
+  L.idx = L.nonzero = L.nzsel = L.blkbit = L.mag = 0;
+  L.ytypeaddr = L.typeaddr = L.rowaddr = L.paddr = base;
+  L.blkaddr = kBlockTabOff;
   zero_slot( J, 0 );
-  start_partition( L, lds, J, 0 );
+  start_partition( L, smem, J, 0 );
   // flag ring: macroblocks [0, kRing)
   for ( uint32_t k = 0; k < kRing / 16; k++ ) {
     Chunk16 c; c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;
     if ( 16 * k < J.flags_padded ) c = load16( J.mbflags + 16 * k );
-    lds_store16( lds, kMeta + 16 * k, c );
+    lds_store16( smem, base + kMeta + 16 * k, c );
   }
   L.mwpos = kRing;
   L.pend_mwpos = kNoPend;
-  L.node = N_MB;
+  L.rec = R_MB;
 }
 
 } // namespace tok

@@ -75,19 +75,20 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
   }
   // ---- k_parse_tokens ----
   {
-    std::vector<uint8_t> lds_store( aa::tok::lane_lds_bytes( J.fp.mbw ) + 16 );
-    uint8_t * lds = reinterpret_cast<uint8_t *>( ( reinterpret_cast<uintptr_t>( lds_store.data() ) + 15 ) & ~uintptr_t( 15 ) );
-    std::memset( lds, 0xA5, aa::tok::lane_lds_bytes( J.fp.mbw ) );
+    const uint32_t bytes = aa::tok::kTablesBytes + aa::tok::lane_lds_bytes( J.fp.mbw );
+    std::vector<uint8_t> store( bytes + 16 );
+    uint8_t * smem = reinterpret_cast<uint8_t *>( ( reinterpret_cast<uintptr_t>( store.data() ) + 15 ) & ~uintptr_t( 15 ) );
+    std::memset( smem, 0xA5, bytes );
+    for ( uint32_t k = 0; k < aa::tok::kTablesBytes / 4; k++ ) reinterpret_cast<uint32_t *>( smem )[k] = aa::tok::table_word( k );
     aa::tok::Lane L;
     std::memset( &L, 0xA5, sizeof L );
     aa::tok::Frame F = aa::tok::frame_of( &J );
-    aa::tok::Tables T { aa::tok::kNodeTable.n, aa::tok::kBlockTable.b };
-    L.node = aa::tok::N_DONE; L.pend_wpos = L.pend_mwpos = aa::tok::kNoPend;
-    aa::tok::begin_frame( L, lds, F );
+    L.rec = aa::tok::R_DONE; L.pend_wpos = L.pend_mwpos = aa::tok::kNoPend;
+    aa::tok::begin_frame( L, smem, aa::tok::kTablesBytes, F );
     for ( ;; ) {
-      aa::tok::top_up( L, lds, F );
-      if ( L.node == aa::tok::N_DONE ) break;
-      aa::tok::run_period( L, lds, T, F );
+      aa::tok::top_up( L, smem, F );
+      if ( L.rec == aa::tok::R_DONE ) break;
+      aa::tok::run_period( L, smem, F );
     }
   }
   hdr->num_coeff_blocks = sum.num_coeff_blocks;
