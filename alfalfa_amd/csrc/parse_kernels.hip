@@ -25,12 +25,14 @@ namespace {
 
 using aa::ParseJob;
 
-__global__ __launch_bounds__( 64 ) void k_parse_mb_headers( const ParseJob * jobs, int n, int lanes )
+// `order`: which job each slot of the launch takes -- the host sorts the frames of a batch by the length of their chains so
+// that the lanes of a wave finish together (a wave lasts as long as its longest lane)
+__global__ __launch_bounds__( 64 ) void k_parse_mb_headers( const ParseJob * jobs, const uint32_t * order, int n, int lanes )
 {
   const int lane = threadIdx.x;
-  const int j = blockIdx.x * lanes + lane;
-  if ( lane >= lanes || j >= n ) return;
-  const ParseJob & J = jobs[j];
+  const int slot = blockIdx.x * lanes + lane;
+  if ( lane >= lanes || slot >= n ) return;
+  const ParseJob & J = jobs[order[slot]];
   if ( J.nmb == 0 ) return;                      // a frame the host header pre-pass rejected
   const aa::FrameParams & fp = J.fp;
   aa::BoolReader32 bd;
@@ -70,12 +72,13 @@ __global__ __launch_bounds__( 256 ) void k_segment_fixup( const ParseJob * jobs,
   }
 }
 
-__global__ __launch_bounds__( 64 ) void k_parse_tokens( const ParseJob * jobs, int n, int lanes, uint32_t lane_bytes )
+__global__ __launch_bounds__( 64 ) void k_parse_tokens( const ParseJob * jobs, const uint32_t * order, int n, int lanes, uint32_t lane_bytes )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t smem[];
   const int lane = threadIdx.x;
-  const int j = blockIdx.x * lanes + lane;
-  const bool active = lane < lanes && j < n && jobs[j < n ? j : 0].nmb != 0;
+  const int slot = blockIdx.x * lanes + lane;
+  const int j = static_cast<int>( order[lane < lanes && slot < n ? slot : 0] );
+  const bool active = lane < lanes && slot < n && jobs[j].nmb != 0;
   for ( uint32_t k = lane; k < aa::tok::kTablesBytes / 4; k += 64 ) reinterpret_cast<uint32_t *>( smem )[k] = aa::tok::table_word( k );
   __syncthreads();
   aa::tok::Lane L;
@@ -105,10 +108,10 @@ static int parse_lanes()
   return lanes;
 }
 
-int launch_parse_mb_headers( const ParseJob * jobs, int n, void * stream )
+int launch_parse_mb_headers( const ParseJob * jobs, const uint32_t * order, int n, void * stream )
 {
   const int lanes = parse_lanes();
-  hipLaunchKernelGGL( k_parse_mb_headers, dim3( ( n + lanes - 1 ) / lanes ), dim3( 64 ), 0, static_cast<hipStream_t>( stream ), jobs, n, lanes );
+  hipLaunchKernelGGL( k_parse_mb_headers, dim3( ( n + lanes - 1 ) / lanes ), dim3( 64 ), 0, static_cast<hipStream_t>( stream ), jobs, order, n, lanes );
   return static_cast<int>( hipGetLastError() );
 }
 
@@ -118,14 +121,14 @@ int launch_segment_fixup( const ParseJob * jobs, const aa_seg_stream * streams, 
   return static_cast<int>( hipGetLastError() );
 }
 
-int launch_parse_tokens( const ParseJob * jobs, int n, int max_mbw, void * stream )
+int launch_parse_tokens( const ParseJob * jobs, const uint32_t * order, int n, int max_mbw, void * stream )
 {
   const uint32_t lane_bytes = tok::lane_lds_bytes( static_cast<uint32_t>( max_mbw ) );
   int lanes = parse_lanes();
   if ( static_cast<uint32_t>( lanes ) * lane_bytes + tok::kTablesBytes > 65536u ) lanes = static_cast<int>( ( 65536u - tok::kTablesBytes ) / lane_bytes );
   if ( lanes < 1 ) return static_cast<int>( hipErrorInvalidValue );
   hipLaunchKernelGGL( k_parse_tokens, dim3( ( n + lanes - 1 ) / lanes ), dim3( 64 ), static_cast<size_t>( lanes ) * lane_bytes + tok::kTablesBytes,
-                      static_cast<hipStream_t>( stream ), jobs, n, lanes, lane_bytes );
+                      static_cast<hipStream_t>( stream ), jobs, order, n, lanes, lane_bytes );
   return static_cast<int>( hipGetLastError() );
 }
 

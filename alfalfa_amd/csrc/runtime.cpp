@@ -625,6 +625,16 @@ aa_status aa_ctx_sync( aa_ctx * ctx )
   HIP_TRY( hipStreamSynchronize( ctx->compute ) );
   return check_watchdog( ctx );
 }
+aa_status aa_ctx_memory( aa_ctx * ctx, size_t * free_bytes, size_t * total_bytes )
+{
+  if ( !ctx ) return fail( AA_ERR_ARGUMENT, "null ctx" );
+  if ( aa_status st = set_device( ctx ) ) return st;
+  size_t f = 0, t = 0;
+  HIP_TRY( hipMemGetInfo( &f, &t ) );
+  if ( free_bytes ) *free_bytes = f;
+  if ( total_bytes ) *total_bytes = t;
+  return AA_OK;
+}
 aa_status aa_ctx_set_schedule( aa_ctx * ctx, int schedule )
 {
   if ( !ctx || ( schedule != AA_SCHEDULE_ROWS && schedule != AA_SCHEDULE_DIAGONAL ) ) return fail( AA_ERR_ARGUMENT, "aa_ctx_set_schedule: bad argument" );
@@ -846,7 +856,7 @@ aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int
   const size_t jobs_bytes = align_up( size_t( n ) * sizeof( aa::ParseJob ) );
   const size_t dframes_bytes = align_up( size_t( n ) * sizeof( aa_dev_frame ) );
   const size_t sums_bytes = align_up( size_t( n ) * sizeof( aa::FrameSummary ) );
-  const size_t seg_bytes = align_up( size_t( n ) * ( sizeof( aa_seg_stream ) + sizeof( uint32_t ) ) );
+  const size_t seg_bytes = align_up( size_t( n ) * ( sizeof( aa_seg_stream ) + 2 * sizeof( uint32_t ) ) );   // + the launch order
   size_t off = jobs_bytes + dframes_bytes + sums_bytes + seg_bytes;
   std::map<aa_stream *, std::vector<int>> by_stream;
   std::vector<aa_stream *> stream_order;
@@ -939,6 +949,13 @@ aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int
     for ( int i : by_stream[s] ) if ( items[i].status == AA_OK ) { seg_order[n_seg_order++] = static_cast<uint32_t>( i ) | ( items[i].seg_reset ? 0x80000000u : 0u ); ss.count++; }
   }
 
+  // launch order: longest chains first (the compressed size is the length of a token chain, near enough), so that the lanes
+  // of a wave finish together and the long waves start first
+  uint32_t * launch_order = seg_order + n;
+  for ( int i = 0; i < n; i++ ) launch_order[i] = static_cast<uint32_t>( i );
+  std::stable_sort( launch_order, launch_order + n, [&]( uint32_t a, uint32_t b ) { return items[a].size > items[b].size; } );
+  const uint32_t * launch_order_dev = reinterpret_cast<const uint32_t *>( b->dev + ( reinterpret_cast<uint8_t *>( launch_order ) - b->host ) );
+
   // ---- device half: arena to HBM on the copy stream, then the three parse kernels on one of the parse streams ----
   HIP_TRY( hipEventCreateWithFlags( &b->done, hipEventDisableTiming ) );
   HIP_TRY( hipMemcpyAsync( b->dev, b->host, off, hipMemcpyHostToDevice, ctx->copy ) );
@@ -949,7 +966,7 @@ aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int
   const aa::ParseJob * jobs_dev = reinterpret_cast<const aa::ParseJob *>( b->dev );
   {
     LaunchTimer t( ctx, 3, ps );
-    if ( int e = aa::launch_parse_mb_headers( jobs_dev, n, ps ) ) return hip_fail( static_cast<hipError_t>( e ), "k_parse_mb_headers" );
+    if ( int e = aa::launch_parse_mb_headers( jobs_dev, launch_order_dev, n, ps ) ) return hip_fail( static_cast<hipError_t>( e ), "k_parse_mb_headers" );
   }
   if ( n_seg_streams ) {
     if ( ctx->last_seg_batch ) HIP_TRY( hipStreamWaitEvent( ps, ctx->last_seg_batch, 0 ) );
@@ -962,7 +979,7 @@ aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int
   }
   {
     LaunchTimer t( ctx, 4, ps );
-    if ( int e = aa::launch_parse_tokens( jobs_dev, n, max_mbw, ps ) ) return hip_fail( static_cast<hipError_t>( e ), "k_parse_tokens" );
+    if ( int e = aa::launch_parse_tokens( jobs_dev, launch_order_dev, n, max_mbw, ps ) ) return hip_fail( static_cast<hipError_t>( e ), "k_parse_tokens" );
   }
   for ( int i = 0; i < n; i++ ) if ( items[i].status == AA_OK ) ctx->stats.parsed_macroblocks += jobs_host[i].nmb;
   HIP_TRY( hipMemcpyAsync( b->host + b->summaries_off, b->dev + b->summaries_off, size_t( n ) * sizeof( aa::FrameSummary ), hipMemcpyDeviceToHost, ps ) );

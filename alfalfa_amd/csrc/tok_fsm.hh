@@ -67,9 +67,11 @@ struct alignas( 16 ) ParseJob {
 
 namespace tok {
 
-constexpr uint32_t kPeriod = 64;          // steps between ring top-ups (a step consumes at most one stream byte / one flag)
-constexpr uint32_t kRing = 256;           // bytes per ring
+constexpr uint32_t kPeriod = 64;          // steps between ring top-ups (a step consumes at most one stream byte)
+constexpr uint32_t kRing = 256;           // bytes in the stream ring
 constexpr uint32_t kChunks = 4;           // 16-byte chunks fetched per top-up (= kPeriod bytes)
+constexpr uint32_t kMetaRing = 128;       // macroblock flags in the flag ring
+constexpr uint32_t kMetaChunks = 2;       // 16-flag chunks fetched per top-up (only runs of skipped macroblocks use more: they wait)
 
 // Workgroup LDS ("smem"; one flat buffer on the host): the node and block tables at offset 0 -- so that a node record's
 // address is a plain number a record can carry -- then one slice per lane.  Offsets below are relative to a lane's slice.
@@ -79,11 +81,11 @@ constexpr uint32_t kTablesBytes = 768;    // first lane slice
 constexpr uint32_t kProbs = 0;            // [4][8][3][11] token probabilities
 constexpr uint32_t kXtab = 1056;          // extra-bit probabilities of the six categories, then the sign's 128
 constexpr uint32_t kSignX = 26;           // index of the sign's probability in that table
-constexpr uint32_t kStream = 1280;        // stream ring
+constexpr uint32_t kStream = 1088;        // stream ring
 constexpr uint32_t kMeta = kStream + kRing;
-constexpr uint32_t kPart = kMeta + kRing; // 8 saved partition decoders x 16 bytes
+constexpr uint32_t kPart = kMeta + kMetaRing;   // 8 saved partition decoders x 16 bytes
 constexpr uint32_t kAbove = kPart + 128;  // uint16 per macroblock column
-AA_HD constexpr uint32_t lane_lds_bytes( uint32_t mbw ) { return ( kAbove + 2 * mbw + 255 ) & ~255u; }
+AA_HD constexpr uint32_t lane_lds_bytes( uint32_t mbw ) { return ( kAbove + 2 * mbw + 15 ) & ~15u; }
 
 // dct_cat probabilities (tokens.cc:36-48) laid out back to back: cat1 @0, cat2 @1, cat3 @3, cat4 @6, cat5 @10, cat6 @15, sign @26
 constexpr uint8_t kXtabInit[27] = { 159, 165, 145, 173, 148, 140, 176, 155, 140, 135, 180, 157, 141, 134, 130,
@@ -225,9 +227,9 @@ struct Lane {
   int32_t sh;
   uint32_t rpos, rend;            // next stream byte to shift in / end of the partition (offsets into the frame)
   uint32_t wpos;                  // stream ring holds [wpos - kRing, wpos)
-  uint32_t mwpos;                 // flag ring holds macroblocks [mwpos - kRing, mwpos)
+  uint32_t mwpos;                 // flag ring holds macroblocks [mwpos - kMetaRing, mwpos)
   uint32_t pend_wpos, pend_mwpos; // what the chunks in flight are for (kNoPend: nothing in flight)
-  Chunk16 pend[kChunks], mpend[kChunks];
+  Chunk16 pend[kChunks], mpend[kMetaChunks];
   // token in progress
   uint32_t rec;                   // address of the record of the node about to be decoded (>= R_MBDONE: not decoding)
   uint32_t paddr;                 // address of its probability
@@ -301,8 +303,8 @@ AA_HD inline void top_up( Lane & L, uint8_t * smem, const Frame & J )
     L.wpos += 16 * kChunks;
   }
   if ( L.pend_mwpos == L.mwpos ) {
-    for ( uint32_t k = 0; k < kChunks; k++ ) lds_store16( smem, L.base + kMeta + ( ( L.mwpos + 16 * k ) & ( kRing - 1 ) ), L.mpend[k] );
-    L.mwpos += 16 * kChunks;
+    for ( uint32_t k = 0; k < kMetaChunks; k++ ) lds_store16( smem, L.base + kMeta + ( ( L.mwpos + 16 * k ) & ( kMetaRing - 1 ) ), L.mpend[k] );
+    L.mwpos += 16 * kMetaChunks;
   }
   L.pend_wpos = L.pend_mwpos = kNoPend;
   // a request may be written a period from now iff the ring then still has room: lead <= kRing - 16*kChunks now
@@ -315,8 +317,8 @@ AA_HD inline void top_up( Lane & L, uint8_t * smem, const Frame & J )
     }
     L.pend_wpos = L.wpos;
   }
-  if ( L.mwpos - L.mi <= kRing - 16 * kChunks ) {
-    for ( uint32_t k = 0; k < kChunks; k++ ) {
+  if ( L.mwpos - L.mi <= kMetaRing - 16 * kMetaChunks ) {
+    for ( uint32_t k = 0; k < kMetaChunks; k++ ) {
       const uint32_t at = L.mwpos + 16 * k;
       Chunk16 c; c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;
       if ( at < J.flags_padded ) c = load16( J.mbflags + at );
@@ -392,7 +394,7 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
       L.col = 0; L.row++; L.ctxbits = 0;
       if ( J.nparts > 1 ) switch_partition( L, smem, J, L.row % J.nparts );
     }
-    const uint32_t flags = smem[L.base + kMeta + ( L.mi & ( kRing - 1 ) )];
+    const uint32_t flags = smem[L.base + kMeta + ( L.mi & ( kMetaRing - 1 ) )];
     const uint32_t has_y2 = flags & AA_MB_HAS_Y2;
     L.ctxbits = ( L.ctxbits & 0x01FF0000u ) | above[L.col];
     L.mb_first = L.coeff_blocks;
@@ -545,13 +547,13 @@ AA_HD inline void begin_frame( Lane & L, uint8_t * smem, uint32_t base, const Fr
   L.blkaddr = kBlockTabOff;
   zero_slot( J, 0 );
   start_partition( L, smem, J, 0 );
-  // flag ring: macroblocks [0, kRing)
-  for ( uint32_t k = 0; k < kRing / 16; k++ ) {
+  // flag ring: macroblocks [0, kMetaRing)
+  for ( uint32_t k = 0; k < kMetaRing / 16; k++ ) {
     Chunk16 c; c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;
     if ( 16 * k < J.flags_padded ) c = load16( J.mbflags + 16 * k );
     lds_store16( smem, base + kMeta + 16 * k, c );
   }
-  L.mwpos = kRing;
+  L.mwpos = kMetaRing;
   L.pend_mwpos = kNoPend;
   L.rec = R_MB;
 }

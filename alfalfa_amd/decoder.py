@@ -94,6 +94,12 @@ class Context:
     def sync(self):
         capi.check(self.L.aa_ctx_sync(self.h))
 
+    def memory(self):
+        """(free, total) bytes of this device's HBM right now."""
+        f, t = C.c_size_t(), C.c_size_t()
+        capi.check(self.L.aa_ctx_memory(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
     def set_schedule(self, name):
         """"rows" (default): row-pipelined persistent kernels; "diagonal": one launch per anti-diagonal."""
         capi.check(self.L.aa_ctx_set_schedule(self.h, {"rows": 0, "diagonal": 1}[name]))

@@ -139,6 +139,8 @@ typedef struct aa_stream aa_stream;
 aa_status aa_ctx_create( int device, aa_ctx ** out );
 void aa_ctx_destroy( aa_ctx * ctx );
 aa_status aa_ctx_sync( aa_ctx * ctx );               /* waits for copy + compute streams */
+/* HBM of the context's device: bytes free / total right now (hipMemGetInfo).  Either pointer may be NULL. */
+aa_status aa_ctx_memory( aa_ctx * ctx, size_t * free_bytes, size_t * total_bytes );
 /* Launch schedule of the dependency-ordered kernels (intra prediction, loop filter):
  *   AA_SCHEDULE_ROWS (default)  row-pipelined persistent kernels, rows ordered in-launch by ticket + progress words
  *   AA_SCHEDULE_DIAGONAL        one launch per 2:1 anti-diagonal (kernel boundary = synchronisation); for A/B runs

@@ -137,7 +137,6 @@ def test_bad_frame_in_a_batch(gpu_ctx):
 def test_long_stream_holds_memory_flat(gpu_ctx):
     """2000 frames through one decoder with aa_stream_release_before trailing by a few frames: HBM use stays flat
     (records and rasters are recycled; RasterHandle semantics of raster_handle.cc:113-122)."""
-    import torch
     w, h, frames = golden_frames("cif_q60_lf40s5")
     dec = aa.Decoder(gpu_ctx, w, h)
     want = GOLDEN["cif_q60_lf40s5"]["raster_sha256"]
@@ -156,6 +155,5 @@ def test_long_stream_holds_memory_flat(gpu_ctx):
         assert sha256(dec.raster_bytes(n - 1)) == want[len(frames) - 1]
         dec.release_before(n - 1)
         if rep % 25 == 24:
-            free, _total = torch.cuda.mem_get_info(0)
-            used.append(free)
+            used.append(gpu_ctx.memory()[0])
     assert max(used[1:]) - min(used[1:]) <= 64 << 20, used
