@@ -22,6 +22,15 @@ struct aa_dev_frame {
   uint32_t pad;
 };
 
+// The raster planes of one frame job.  A job's records are final when the frame is parsed, but WHICH rasters it writes and
+// predicts from is decided when it is handed to reconstruction (References bookkeeping, frame.cc:271-307): frames that are
+// parsed far ahead of their decode -- the device parser keeps several batches in flight -- hold no raster until then.
+struct aa_raster_binding {
+  aa_dev_frame * job;
+  uint8_t * cur[3];
+  const uint8_t * ref[3][3];     // last, golden, altref
+};
+
 #define AA_MAX_XCD 16
 
 // In-launch ordering state of the row-pipelined kernels; zeroed (hipMemsetAsync) before every such launch.
@@ -66,4 +75,5 @@ int launch_recon_intra4( const aa_frame_list & list, int n_groups, int mbh_max, 
 int launch_loopfilter_rows4( const aa_frame_list & list, int n_groups, int mbh_max, int mbw_max, aa_sync_ws * ws, uint8_t * boundary, int n_xcd, void * stream );
 // out16[x] += number of workgroups (of `blocks`) that ran on XCD x
 int launch_probe_xcds( int * out16, int blocks, void * stream );
+int launch_bind_rasters( const aa_raster_binding * b, int n, void * stream );
 }

@@ -1439,7 +1439,23 @@ __global__ void k_probe_xcds( int * out )
   if ( threadIdx.x == 0 ) atomicAdd( &out[xcc_id() & 15], 1 );
 }
 
+// Raster planes of n frame jobs, decided on the host when the frames are handed to reconstruction: out, last, golden, altref.
+__global__ void k_bind_rasters( const aa_raster_binding * b, int n )
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i >= n ) return;
+  aa_dev_frame * f = b[i].job;
+  for ( int p = 0; p < 3; p++ ) f->cur[p] = b[i].cur[p];
+  for ( int r = 1; r < 4; r++ ) for ( int p = 0; p < 3; p++ ) f->ref[r][p] = b[i].ref[r - 1][p];
+}
+
 } // namespace
+
+int launch_bind_rasters( const aa_raster_binding * b, int n, void * stream )
+{
+  hipLaunchKernelGGL( k_bind_rasters, dim3( ( n + 63 ) / 64 ), dim3( 64 ), 0, static_cast<hipStream_t>( stream ), b, n );
+  return static_cast<int>( hipGetLastError() );
+}
 
 int launch_recon_inter( const aa_frame_list & list, int n, unsigned max_mbs, bool split_only, void * stream )
 {

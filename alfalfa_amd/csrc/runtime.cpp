@@ -36,6 +36,11 @@ namespace {
 
 thread_local std::string g_last_error;
 
+// The entropy-decode kernels are long (a chain per lane, seconds) and must run BESIDE reconstruction and beside each other.
+// HIP spreads streams over few hardware queues by default (4), and commands of one queue run in order: with five streams a
+// decode launch can end up queued behind a parse kernel.  Ask for more queues before the runtime starts.
+struct RuntimeEnv { RuntimeEnv() { setenv( "GPU_MAX_HW_QUEUES", "8", 0 ); } } g_runtime_env;
+
 aa_status fail( aa_status code, const std::string & msg ) { g_last_error = msg; return code; }
 aa_status hip_fail( hipError_t e, const char * what )
 {
@@ -92,6 +97,7 @@ struct FrameRec {
   uint8_t * rec_block = nullptr;           // device-parsed frame: its record block in HBM
   size_t rec_bytes = 0;
   bool records_released = false;
+  bool placed = false;                     // raster slot + References bookkeeping done (at the first decode submission)
 };
 
 } // namespace
@@ -105,7 +111,11 @@ struct aa_ctx {
   std::atomic<int> refs { 1 };   // the context handle + one per stream: freed by whoever drops the last (bindings may finalise in any order)
   // device-side entropy decode: submit calls rotate over a few HIP streams so that the parse of one batch runs beside the
   // parse of the next and beside reconstruction (a parse is a few thousand latency-bound chains, not a chip-filling kernel)
+  struct BindBuf { aa_raster_binding * host = nullptr, * dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
+  BindBuf bind_bufs[4];
+  int next_bind_buf = 0;
   hipStream_t parse_streams[3] = { nullptr, nullptr, nullptr };
+  int prio_low = 0;
   int next_parse_stream = 0;
   hipEvent_t last_seg_batch = nullptr;  // segment-map passes of consecutive batches must run in order
   // Device pieces given back while kernels that read them may still be queued: they become reusable once an event recorded
@@ -380,24 +390,30 @@ uint8_t * pinned_get( aa_ctx * ctx, size_t bytes, size_t * got )
   return p;
 }
 
-// References bookkeeping of one appended frame: output slot, the rasters it predicts from, then Frame::copy_to on slot ids
-// (frame.cc:271-307).  Fills the reconstruction job record `job` (host copy) except the record pointers.
-aa_status place_frame( aa_stream * s, FrameRec & rec, aa_dev_frame * job )
+// Per-frame constants of the reconstruction job record (host copy); the raster planes are bound later (bind_frame).
+void fill_job( const FrameRec & rec, aa_dev_frame * job )
 {
+  const aa_frame_header & h = rec.hdr;
+  std::memset( job, 0, sizeof *job );
+  std::memcpy( job->quant, h.quant, sizeof job->quant );
+  job->mbw = h.mb_width; job->mbh = h.mb_height;
+  job->key_frame = h.key_frame; job->loop_filter_level = h.loop_filter_level;
+  job->sharpness = h.sharpness_level; job->has_intra = h.has_intra_mb;
+}
+
+// References bookkeeping of frame `fi`, done when it is first handed to reconstruction (frames of a stream are submitted in
+// order): output slot, the rasters it predicts from, then Frame::copy_to on slot ids (frame.cc:271-307).
+aa_status bind_frame( aa_stream * s, int fi, aa_raster_binding * out )
+{
+  FrameRec & rec = s->frames[fi];
   const aa_frame_header & h = rec.hdr;
   int out_slot;
   if ( aa_status st = alloc_slot( s, &out_slot ) ) return st;
   retain( s, out_slot );   // the frame's own handle (RasterHandle returned to the caller)
   rec.out_slot = out_slot;
-  std::memset( job, 0, sizeof *job );
-  for ( int p = 0; p < 3; p++ ) job->cur[p] = slot_plane( s, out_slot, p );
-  for ( int r = 0; r < 3; r++ ) for ( int p = 0; p < 3; p++ ) job->ref[r + 1][p] = slot_plane( s, s->cur_ref_slot[r], p );
-  std::memcpy( job->quant, h.quant, sizeof job->quant );
-  job->mbw = h.mb_width; job->mbh = h.mb_height;
-  job->key_frame = h.key_frame; job->loop_filter_level = h.loop_filter_level;
-  job->sharpness = h.sharpness_level; job->has_intra = h.has_intra_mb;
-
-  const int fi = static_cast<int>( s->frames.size() );
+  out->job = const_cast<aa_dev_frame *>( rec.dev_job );
+  for ( int p = 0; p < 3; p++ ) out->cur[p] = slot_plane( s, out_slot, p );
+  for ( int r = 0; r < 3; r++ ) for ( int p = 0; p < 3; p++ ) out->ref[r][p] = slot_plane( s, s->cur_ref_slot[r], p );
   enum { LAST = 0, GOLDEN = 1, ALT = 2 };
   if ( h.key_frame ) { for ( int i = 0; i < 3; i++ ) set_ref( s, i, out_slot, fi ); }
   else {
@@ -410,6 +426,41 @@ aa_status place_frame( aa_stream * s, FrameRec & rec, aa_dev_frame * job )
     if ( h.refresh_last ) set_ref( s, LAST, out_slot, fi );
   }
   for ( int i = 0; i < 3; i++ ) rec.ref_after[i] = s->cur_ref_frame[i];
+  rec.placed = true;
+  if ( !rec.handle_held ) release( s, out_slot );   // the caller let go of this frame before it was decoded: only references keep its raster
+  return AA_OK;
+}
+
+// Bind the rasters of the frames of a decode submission that have none yet: one small upload + one tiny kernel, in front of
+// the reconstruction kernels on the compute stream.
+aa_status bind_batch( aa_ctx * ctx, aa_stream * const * streams, int n, const int * frame_index )
+{
+  int need = 0;
+  for ( int i = 0; i < n; i++ ) if ( !streams[i]->frames[frame_index[i]].placed ) need++;
+  if ( !need ) return AA_OK;
+  aa_ctx::BindBuf & bb = ctx->bind_bufs[ctx->next_bind_buf];
+  ctx->next_bind_buf = ( ctx->next_bind_buf + 1 ) % 4;
+  if ( bb.busy ) { HIP_TRY( hipEventSynchronize( bb.done ) ); bb.busy = false; }
+  if ( bb.cap < static_cast<size_t>( need ) ) {
+    if ( bb.host ) (void) hipHostFree( bb.host );
+    if ( bb.dev ) (void) hipFree( bb.dev );
+    bb.host = nullptr; bb.dev = nullptr; bb.cap = 0;
+    const size_t cap = std::max<size_t>( 512, size_t( need ) * 2 );
+    HIP_TRY( hipHostMalloc( reinterpret_cast<void **>( &bb.host ), cap * sizeof( aa_raster_binding ), hipHostMallocDefault ) );
+    HIP_TRY( hipMalloc( reinterpret_cast<void **>( &bb.dev ), cap * sizeof( aa_raster_binding ) ) );
+    bb.cap = cap;
+  }
+  if ( !bb.done ) HIP_TRY( hipEventCreateWithFlags( &bb.done, hipEventDisableTiming ) );
+  int k = 0;
+  for ( int i = 0; i < n; i++ ) {
+    if ( streams[i]->frames[frame_index[i]].placed ) continue;
+    if ( aa_status st = bind_frame( streams[i], frame_index[i], &bb.host[k] ) ) return st;
+    k++;
+  }
+  HIP_TRY( hipMemcpyAsync( bb.dev, bb.host, size_t( k ) * sizeof( aa_raster_binding ), hipMemcpyHostToDevice, ctx->compute ) );
+  if ( int e = aa::launch_bind_rasters( bb.dev, k, ctx->compute ) ) return hip_fail( static_cast<hipError_t>( e ), "k_bind_rasters" );
+  HIP_TRY( hipEventRecord( bb.done, ctx->compute ) );
+  bb.busy = true;
   return AA_OK;
 }
 
@@ -542,10 +593,17 @@ aa_status aa_ctx_create( int device, aa_ctx ** out )
   std::unique_ptr<aa_ctx> ctx( new aa_ctx );
   ctx->device = device;
   HIP_TRY( hipSetDevice( device ) );
-  HIP_TRY( hipStreamCreateWithFlags( &ctx->compute, hipStreamNonBlocking ) );
+  {
+    // reconstruction is short and latency-critical, the entropy decode long and patient: the compute stream gets the
+    // highest priority the device offers, the parse streams the lowest
+    int lo = 0, hi = 0;
+    HIP_TRY( hipDeviceGetStreamPriorityRange( &lo, &hi ) );
+    ctx->prio_low = lo;
+    HIP_TRY( hipStreamCreateWithPriority( &ctx->compute, hipStreamNonBlocking, hi ) );
+  }
   HIP_TRY( hipStreamCreateWithFlags( &ctx->copy, hipStreamNonBlocking ) );
   HIP_TRY( hipEventCreateWithFlags( &ctx->upload_done, hipEventDisableTiming ) );
-  for ( auto & ps : ctx->parse_streams ) HIP_TRY( hipStreamCreateWithFlags( &ps, hipStreamNonBlocking ) );
+  for ( auto & ps : ctx->parse_streams ) HIP_TRY( hipStreamCreateWithPriority( &ps, hipStreamNonBlocking, ctx->prio_low ) );
   if ( const char * e = std::getenv( "ALFALFA_AMD_SCHEDULE" ) ) ctx->schedule = std::string( e ) == "diagonal" ? 1 : 0;
   // The row-pipelined kernels keep every unit on one XCD (per-XCD ticket queues indexed by the hardware XCC_ID): find
   // out which XCC ids workgroups of this device really land on.  They must be 0..n-1, each reached by a modest grid.
@@ -584,6 +642,7 @@ static void ctx_free( aa_ctx * ctx )
   drain_profile( ctx );
   for ( auto e : ctx->free_events ) (void) hipEventDestroy( e );
   (void) hipEventDestroy( ctx->upload_done );
+  for ( auto & bb : ctx->bind_bufs ) { if ( bb.host ) (void) hipHostFree( bb.host ); if ( bb.dev ) (void) hipFree( bb.dev ); if ( bb.done ) (void) hipEventDestroy( bb.done ); }
   if ( ctx->ws ) (void) hipFree( ctx->ws );
   if ( ctx->boundary ) (void) hipFree( ctx->boundary );
   for ( auto & pc : ctx->pinned_pool ) (void) hipHostFree( pc.first );
@@ -742,7 +801,7 @@ aa_status aa_stream_parse( aa_stream * s, const uint8_t * data, size_t size, int
     for ( size_t i = 0; i < nmb; i++ ) if ( mbs[i].y_mode == 9 /* SPLITMV */ ) { rec.has_split = true; break; }
 
   // raster slots: output + the References this frame predicts from; then Frame::copy_to on slot ids
-  if ( aa_status st = place_frame( s, rec, job ) ) return st;
+  fill_job( rec, job );
   job->mbs = reinterpret_cast<const aa_mb_info *>( c->dev + off + job_bytes );
   job->intra_rows = reinterpret_cast<const unsigned long long *>( c->dev + off + job_bytes + mb_bytes );
   job->coeffs = reinterpret_cast<const int16_t *>( c->dev + off + job_bytes + mb_bytes + rows_bytes );
@@ -836,7 +895,7 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
 
   aa_dev_frame * job = &dframes_host[item];
   rec.hdr.has_intra_mb = 1;              // until the device parser has counted: the row masks say which macroblocks are intra
-  if ( aa_status st = place_frame( s, rec, job ) ) { it.error = g_last_error; dev_free( ctx, rec.rec_block, rec.rec_bytes ); return st; }
+  fill_job( rec, job );
   job->mbs = J.mbs; job->intra_rows = J.intra_rows; job->coeffs = J.coeffs;
   rec.host_job = job;
   rec.dev_job = reinterpret_cast<const aa_dev_frame *>( b->dev + ( reinterpret_cast<uint8_t *>( job ) - b->host ) );
@@ -1060,6 +1119,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
     if ( streams[i]->frames[frame_index[i]].records_released ) return fail( AA_ERR_LOGIC, "aa_decode_batch: frame records were released" );
     if ( aa_status st = resolve_summary( streams[i], streams[i]->frames[frame_index[i]] ) ) return st;
   }
+  if ( aa_status st = bind_batch( ctx, streams, n, frame_index ) ) return st;
   // frames count as submitted only once every launch of the batch has been queued (a failed launch must not leave them
   // looking decoded)
   struct Advance { aa_stream * const * streams; int n; bool ok = false; ~Advance() { if ( ok ) for ( int i = 0; i < n; i++ ) streams[i]->next_submit++; } } advance { streams, n };
@@ -1202,7 +1262,7 @@ aa_status aa_stream_release_before( aa_stream * s, int first_kept )
   const int n = std::min<int>( first_kept, static_cast<int>( s->frames.size() ) );
   for ( int i = s->first_live; i < n; i++ ) {
     FrameRec & f = s->frames[i];
-    if ( f.handle_held ) { f.handle_held = false; release( s, f.out_slot ); }
+    if ( f.handle_held ) { f.handle_held = false; if ( f.placed ) release( s, f.out_slot ); }
     if ( i < s->next_submit ) release_records( s, f, true );       // decoded: nothing will read its records again once queued kernels ran
     std::vector<uint8_t>().swap( f.intra_diagonals );
   }
