@@ -37,9 +37,9 @@ namespace {
 thread_local std::string g_last_error;
 
 // The entropy-decode kernels are long (a chain per lane, seconds) and must run BESIDE reconstruction and beside each other.
-// HIP spreads streams over few hardware queues by default (4), and commands of one queue run in order: with five streams a
-// decode launch can end up queued behind a parse kernel.  Ask for more queues before the runtime starts.
-struct RuntimeEnv { RuntimeEnv() { setenv( "GPU_MAX_HW_QUEUES", "8", 0 ); } } g_runtime_env;
+// HIP spreads streams over few hardware queues by default (4), and commands of one queue run in order: with more streams
+// than queues a decode launch can end up queued behind a parse kernel.  Ask for more queues before the runtime starts.
+struct RuntimeEnv { RuntimeEnv() { setenv( "GPU_MAX_HW_QUEUES", "16", 0 ); } } g_runtime_env;
 
 aa_status fail( aa_status code, const std::string & msg ) { g_last_error = msg; return code; }
 aa_status hip_fail( hipError_t e, const char * what )
@@ -74,12 +74,13 @@ struct Batch {
   size_t summaries_off = 0;
 };
 
+// A raster: three padded planes in one piece of the context's device pool.  The piece goes back to the pool when the last
+// holder lets go (RasterHandle semantics, raster_handle.cc:113-122) -- rasters are pooled per GPU, not per stream, so a stream
+// that is idle between two groups of pictures holds one raster (its last reference), not a private stock.
 struct Slot {
-  uint8_t * dev = nullptr;
+  uint8_t * dev = nullptr;    // null: a free entry of the stream's slot table
   int refs = 0;               // References + frame handles holding this raster
-  bool owns = false;          // first slot of a block of kSlotBlock rasters allocated with one hipMalloc
 };
-constexpr int kSlotBlock = 4;
 
 struct FrameRec {
   aa_frame_header hdr;
@@ -114,7 +115,8 @@ struct aa_ctx {
   struct BindBuf { aa_raster_binding * host = nullptr, * dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
   BindBuf bind_bufs[4];
   int next_bind_buf = 0;
-  hipStream_t parse_streams[3] = { nullptr, nullptr, nullptr };
+  static constexpr int kParseStreams = 12;
+  hipStream_t parse_streams[kParseStreams] = {};
   int prio_low = 0;
   int next_parse_stream = 0;
   hipEvent_t last_seg_batch = nullptr;  // segment-map passes of consecutive batches must run in order
@@ -241,17 +243,21 @@ void dev_free( aa_ctx * ctx, uint8_t * p, size_t bytes, bool deferred = false )
 
 aa_status alloc_slot( aa_stream * s, int * out )
 {
-  for ( size_t i = 0; i < s->slots.size(); i++ ) if ( s->slots[i].refs == 0 ) { *out = static_cast<int>( i ); return AA_OK; }
-  // rasters are allocated four at a time: allocation calls serialise in the driver, and parser threads of many streams
-  // call this concurrently
-  uint8_t * block = nullptr;
-  if ( aa_status st = dev_alloc( s->ctx, s->slot_bytes * kSlotBlock, &block ) ) return st;
+  uint8_t * piece = nullptr;
+  if ( aa_status st = dev_alloc( s->ctx, s->slot_bytes, &piece ) ) return st;
+  for ( size_t i = 0; i < s->slots.size(); i++ ) if ( !s->slots[i].dev ) { s->slots[i].dev = piece; s->slots[i].refs = 0; *out = static_cast<int>( i ); return AA_OK; }
+  Slot sl; sl.dev = piece;
   *out = static_cast<int>( s->slots.size() );
-  for ( int k = 0; k < kSlotBlock; k++ ) { Slot sl; sl.dev = block + s->slot_bytes * k; sl.owns = k == 0; s->slots.push_back( sl ); }
+  s->slots.push_back( sl );
   return AA_OK;
 }
 void retain( aa_stream * s, int slot ) { if ( slot >= 0 ) s->slots[slot].refs++; }
-void release( aa_stream * s, int slot ) { if ( slot >= 0 ) s->slots[slot].refs--; }
+void release( aa_stream * s, int slot )
+{
+  if ( slot < 0 ) return;
+  Slot & sl = s->slots[slot];
+  if ( --sl.refs == 0 ) { dev_free( s->ctx, sl.dev, s->slot_bytes, true ); sl.dev = nullptr; }   // (kernels already queued may still read it)
+}
 void set_ref( aa_stream * s, int which, int slot, int frame )
 {
   retain( s, slot ); release( s, s->cur_ref_slot[which] );
@@ -734,7 +740,7 @@ aa_status aa_stream_create( aa_ctx * ctx, uint16_t width, uint16_t height, aa_st
   int slot;
   if ( aa_status st = alloc_slot( s.get(), &slot ) ) return st;
   if ( hipError_t e = hipMemsetAsync( s->slots[slot].dev, 0, s->slot_bytes, ctx->compute ) ) {
-    dev_free( ctx, s->slots[slot].dev, s->slot_bytes * kSlotBlock );
+    dev_free( ctx, s->slots[slot].dev, s->slot_bytes );
     return hip_fail( e, "hipMemsetAsync (blank reference raster)" );
   }
   for ( int i = 0; i < 3; i++ ) { s->cur_ref_slot[i] = -1; s->cur_ref_frame[i] = -1; }
@@ -754,7 +760,7 @@ void aa_stream_destroy( aa_stream * s )
     dev_free( s->ctx, c.dev, c.dev_bytes );
   }
   for ( auto & f : s->frames ) release_records( s, f, false );
-  for ( auto & sl : s->slots ) if ( sl.owns ) dev_free( s->ctx, sl.dev, s->slot_bytes * kSlotBlock );
+  for ( auto & sl : s->slots ) if ( sl.dev ) dev_free( s->ctx, sl.dev, s->slot_bytes );
   dev_free( s->ctx, s->dev_segmap, size_t( s->parser.mb_width() ) * s->parser.mb_height() );
   aa_ctx * ctx = s->ctx;
   delete s;
@@ -990,7 +996,7 @@ aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int
   uint32_t * seg_order = reinterpret_cast<uint32_t *>( seg_streams + n );
   int n_seg_streams = 0; uint32_t n_seg_order = 0;
   hipStream_t ps = ctx->parse_streams[ctx->next_parse_stream];
-  ctx->next_parse_stream = ( ctx->next_parse_stream + 1 ) % 3;
+  ctx->next_parse_stream = ( ctx->next_parse_stream + 1 ) % aa_ctx::kParseStreams;
   for ( aa_stream * s : stream_order ) {
     bool any = false;
     for ( int i : by_stream[s] ) if ( items[i].status == AA_OK && items[i].seg_enabled ) any = true;

@@ -59,7 +59,8 @@ def parse_args():
     ap.add_argument("--config", default="1080p_inter_lf")
     ap.add_argument("--streams", type=int, default=480, help="independent streams per GPU")
     ap.add_argument("--frames", type=int, default=12, help="frames per stream per step")
-    ap.add_argument("--depth", type=int, default=2, help="steps whose entropy decode may be in flight ahead of reconstruction")
+    ap.add_argument("--key-ahead", type=int, default=7, help="steps by which KEY frames are handed to the GPU parser ahead of reconstruction")
+    ap.add_argument("--depth", type=int, default=4, help="steps by which inter frames are handed to the GPU parser ahead of reconstruction")
     ap.add_argument("--threads", type=int, default=0, help="host workers of the header pre-pass (0: cores / local ranks)")
     ap.add_argument("--schedule", default="rows", choices=["rows", "diagonal"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -149,50 +150,65 @@ def main():
         if not agree:
             raise SystemExit("entry-state hand-off mismatch across ranks")
 
-    # ---- the end-to-end pipeline over a set of long-running decoders ----
+    # ---- the end-to-end pipeline ----
+    # A step's S groups of pictures are S independent decode jobs (ExCamera chunks: one Decoder each, xc-decode-bundle).  The
+    # entropy decode of a frame is ONE serial chain on ONE GPU lane, so what matters is how many chains are in flight; and a key
+    # frame's chain is ~2.6x longer than an inter frame's.  The scheduler therefore hands key frames to the GPU `key_ahead`
+    # steps before their group is reconstructed and inter frames only `depth` steps before (they would otherwise sit in HBM
+    # waiting for their key frame).  R = key_ahead decoder sets rotate, so that the key frame of group g + R can be submitted
+    # to a decoder whose group g is done.
     class Pipeline:
-        def __init__(self, stream_list):
-            self.decs = [aa.Decoder(ctx, width, height) for _ in stream_list]
+        def __init__(self, stream_list, key_ahead, depth):
             self.n = len(stream_list)
-            # stream-major: frames of one stream are consecutive (a worker takes a whole stream)
-            self.prepared = ctx.prepare_frames([(d, fr) for d, st in zip(self.decs, stream_list) for fr in st])
-            self.submitted = 0          # steps handed to the GPU parser
-            self.decoded = 0            # steps whose reconstruction has been queued
+            self.K, self.D = max(1, key_ahead), max(1, min(depth, key_ahead))
+            self.R = self.K
+            self.sets = [[aa.Decoder(ctx, width, height) for _ in stream_list] for _ in range(self.R)]
+            self.key_prep = [ctx.prepare_frames([(d, st[0]) for d, st in zip(ds, stream_list)]) for ds in self.sets]
+            # stream-major: the inter frames of one stream are consecutive (a host worker takes a whole stream)
+            self.inter_prep = [ctx.prepare_frames([(d, fr) for d, st in zip(ds, stream_list) for fr in st[1:]]) for ds in self.sets]
+            self.keys = self.inters = self.decoded = 0      # groups handed to the GPU parser (key / inter frames), groups reconstructed
             self.host_s = 0.0
+            self.done_t = []
 
-        def submit(self):
+        def _submit(self, prep):
             t = time.perf_counter()
-            ctx.submit_prepared(self.prepared, threads)
+            ctx.submit_prepared(prep, threads)
             self.host_s += time.perf_counter() - t
-            self.submitted += 1
 
         def decode(self, release=True):
-            base = self.decoded * F
+            g = self.decoded
+            ds, base = self.sets[g % self.R], (g // self.R) * F
             for f in range(F):
-                ctx.decode_batch(self.decs, [base + f] * self.n)
+                ctx.decode_batch(ds, [base + f] * self.n)
             self.decoded += 1
-            if release:                 # this step's frames are consumed; the next step starts on a key frame
-                for d in self.decs:
+            if release:                 # this group's frames are consumed
+                for d in ds:
                     d.release_before(base + F)
+            self.done_t.append(time.perf_counter())
 
-        def run(self, steps, depth):
-            """`steps` whole steps, the entropy decode of up to `depth` steps in flight ahead of reconstruction."""
+        def run(self, steps):
+            """`steps` whole steps, from an empty pipeline to an empty pipeline."""
             target = self.decoded + steps
             while self.decoded < target:
-                while self.submitted < min(target, self.decoded + depth):
-                    self.submit()
+                while self.keys < min(target, self.decoded + self.K):
+                    self._submit(self.key_prep[self.keys % self.R]); self.keys += 1
+                while self.inters < min(target, self.decoded + self.D, self.keys):
+                    self._submit(self.inter_prep[self.inters % self.R]); self.inters += 1
                 self.decode()
 
-    pipe = Pipeline(streams)
-    depth = max(1, args.depth)
-    pipe.run(args.warmup, depth)
+    pipe = Pipeline(streams, args.key_ahead, args.depth)
+    pipe.run(args.warmup)
     barrier()
-    pipe.host_s = 0.0
+    pipe.host_s = 0.0; pipe.done_t = []
     t0 = time.perf_counter()
-    pipe.run(args.steps, depth)
+    pipe.run(args.steps)
     ctx.sync()
     elapsed = time.perf_counter() - t0
     host_submit_s = pipe.host_s / max(1, args.steps)
+    # steady state inside the timed region: the median interval between reconstruction hand-overs (host side, i.e. when the
+    # parse a step waited for was done) -- the timed region itself also pays for filling and draining the pipeline
+    gaps = sorted(b - a for a, b in zip(pipe.done_t, pipe.done_t[1:]))
+    steady_ms = gaps[len(gaps) // 2] * 1e3 if gaps else None
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -204,17 +220,19 @@ def main():
 
     # ---- per-kernel timing of one more (un-pipelined) step: HIP events on the streams the kernels run on ----
     ctx.profile(True); ctx.kernel_stats(reset=True)
+    g = pipe.decoded
     t0 = time.perf_counter()
-    pipe.submit()
+    pipe._submit(pipe.key_prep[g % pipe.R]); pipe._submit(pipe.inter_prep[g % pipe.R]); pipe.keys += 1; pipe.inters += 1
     ctx.sync()
     t_parse_alone = time.perf_counter() - t0
     pipe.decode(release=False)
     ctx.sync()
     kstats = ctx.kernel_stats(reset=True); ctx.profile(False)
-    verify_decs, verify_base = pipe.decs, (pipe.decoded - 1) * F
+    verify_decs, verify_base = pipe.sets[g % pipe.R], (g // pipe.R) * F
 
     launches_per_step = {"recon_inter": max(1, kstats["recon_inter_launches"]), "recon_intra": max(1, kstats["recon_intra_launches"]),
-                         "loopfilter": max(1, kstats["loopfilter_launches"]), "parse_tokens": 1, "parse_headers": 1}
+                         "loopfilter": max(1, kstats["loopfilter_launches"]), "parse_tokens": max(1, kstats["parse_launches"]),
+                         "parse_headers": max(1, kstats["parse_launches"])}
     units = {"recon_inter": S * (F - 1) * mbs_per_frame if not args.config.endswith("_intra") else 0, "recon_intra": S * F * mbs_per_frame,
              "loopfilter": S * F * mbs_per_frame, "parse_tokens": S * F * mbs_per_frame, "parse_headers": S * F * mbs_per_frame}
     traffic = pmc_traffic(args.config) or {}
@@ -272,10 +290,10 @@ def main():
 
         def replay():
             for f in range(F):
-                ctx.decode_batch(pipe.decs, [verify_base + f] * S)
-            for d in pipe.decs:
+                ctx.decode_batch(verify_decs, [verify_base + f] * S)
+            for d in verify_decs:
                 d.rewind_to(verify_base)
-        for d in pipe.decs:
+        for d in verify_decs:
             d.rewind_to(verify_base)
         replay(); ctx.sync()
         t0 = time.perf_counter()
@@ -285,7 +303,8 @@ def main():
         dt = (time.perf_counter() - t0) / reps
         device_half = {"value": round(mbs_per_step / dt, 1), "unit": "macroblocks/s", "ms_per_step": round(dt * 1e3, 3),
                        "note": "reconstruction + loop filter only, parsed records resident in HBM (round-1 metric)"}
-    del pipe
+    pipe_K, pipe_D = pipe.K, pipe.D
+    del pipe, verify_decs
 
     # ---- small batches: the reference's actual callers (one stream, one 8-chunk ExCamera bundle), end to end ----
     small = {}
@@ -293,11 +312,11 @@ def main():
         for n in [int(x) for x in args.small_batches.split(",") if x]:
             if n >= S:
                 continue
-            p = Pipeline(streams[:n])
-            p.run(1, depth); ctx.sync()
-            reps = 3
+            p = Pipeline(streams[:n], args.key_ahead, args.depth)
+            p.run(2); ctx.sync()
+            reps = max(4, args.key_ahead)
             t0 = time.perf_counter()
-            p.run(reps, depth); ctx.sync()
+            p.run(reps); ctx.sync()
             dt = (time.perf_counter() - t0) / reps
             # the same streams through the host parser path (aa_stream_decode: one host core per stream, no batching)
             d1 = aa.Decoder(ctx, width, height)
@@ -362,9 +381,11 @@ def main():
                                    % (args.config, S, width, height, F, shape, cfg[3], cfg[4]),
                        "streams_per_gpu": S, "frames_per_stream": F, "macroblocks_per_step_per_gpu": mbs_per_step,
                        "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective",
-                       "schedule": args.schedule, "pipeline_depth": depth, "host_threads": threads},
+                       "schedule": args.schedule, "key_frames_ahead": pipe_K, "inter_frames_ahead": pipe_D, "host_threads": threads},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "kernels": roofs, "device_half": device_half,
+            "steady_state": None if steady_ms is None else {"ms_per_step": round(steady_ms, 3), "value": round(world * mbs_per_step / (steady_ms * 1e-3), 1),
+                                                            "note": "median interval between steps inside the timed region; `value` itself also pays for filling and draining the pipeline"},
             "stages": {"host_prepass_and_staging_s_per_step": round(host_submit_s, 4),
                        "entropy_decode_alone_s_per_step": round(t_parse_alone, 4),
                        "note": "entropy_decode_alone = one step's submit -> parse finished with nothing else on the GPU (a latency: the longest chain, a key frame)"},
