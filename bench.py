@@ -8,9 +8,12 @@ filtered rasters in HBM:
     H2D     the compressed frames themselves (~36 B/macroblock instead of ~360 B of parsed records)
     GPU     BoolDecoder entropy decode: macroblock headers + tokens, one lane per (stream, frame)   [k_parse_*]
     GPU     reconstruction + loop filter + reference update                                        [k_recon_*, k_loopfilter_*]
-Steps are pipelined (`--depth`: the parse of the next step(s) runs beside the reconstruction of this one); frames are
-released as they are consumed, so memory is a ring.  `value` is that end-to-end rate.  The reconstruction-only rate
-with parsed records already resident in HBM (last round's number) is reported beside it as `device_half`.
+Steps are pipelined: a frame's entropy decode is one serial chain on one GPU lane (seconds for a 1080p frame), so the rate
+comes from the number of chains in flight.  Key frames are handed to the GPU parser `--key-ahead` steps before their group
+is reconstructed, inter frames `--depth` steps before; frames are released as they are consumed, so memory is a ring.  The
+timed region runs K steps from an EMPTY pipeline to an EMPTY pipeline (it pays for filling and draining); `value` is that
+end-to-end rate, `steady_state` the rate between fill and drain.  The reconstruction-only rate with parsed records
+already resident in HBM (last round's number) is reported beside it as `device_half`.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -197,7 +200,8 @@ def main():
                 self.decode()
 
     pipe = Pipeline(streams, args.key_ahead, args.depth)
-    pipe.run(args.warmup)
+    pipe.run(pipe.R)                    # priming (untimed, before the warm-up): every decoder set once, so that first-touch
+    pipe.run(args.warmup)               # allocations of the pools (hipMalloc / hipHostMalloc) are not what the steps measure
     barrier()
     pipe.host_s = 0.0; pipe.done_t = []
     t0 = time.perf_counter()
