@@ -91,8 +91,17 @@ SYMBOLS = [
     ("aa_stream_download", C.c_int, [_P, C.c_int, _P, _P, _P]),
     ("aa_stream_raster_device", C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     ("aa_stream_references", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("aa_stream_reference_slots", C.c_int, [_P, C.POINTER(C.c_int)]),
     ("aa_stream_import_reference", C.c_int, [_P, _P, _P, _P]),
     ("aa_stream_import_reference_host", C.c_int, [_P, _P, _P, _P]),
+    ("aa_parser_state_hash", C.c_int, [_P, C.POINTER(C.c_uint64)]), ("aa_stream_state_hash", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("aa_stream_raster_hash", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64)]),
+    ("aa_stream_decoder_hash", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("aa_stream_minihash", C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    ("aa_stream_release_frame", C.c_int, [_P, C.c_int]),
+    ("aa_stream_set_references", C.c_int, [_P, C.POINTER(_P * 3), C.POINTER(C.c_int)]),
+    ("aa_stream_reference_device", C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    ("aa_stream_reference_download", C.c_int, [_P, C.c_int, _P, _P, _P]),
     ("aa_raster_geometry", None, [C.c_uint16, C.c_uint16, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("aa_ctx_profile", C.c_int, [_P, C.c_int]), ("aa_ctx_kernel_stats", C.c_int, [_P, C.POINTER(KernelStats), C.c_int]),
 ]

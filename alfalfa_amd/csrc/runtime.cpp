@@ -80,6 +80,8 @@ struct Batch {
 struct Slot {
   uint8_t * dev = nullptr;    // null: a free entry of the stream's slot table
   int refs = 0;               // References + frame handles holding this raster
+  bool hash_valid = false;    // HashCachedRaster: the hash is computed once per raster (raster_handle.cc:196-206)
+  uint64_t hash = 0;
 };
 
 struct FrameRec {
@@ -245,7 +247,7 @@ aa_status alloc_slot( aa_stream * s, int * out )
 {
   uint8_t * piece = nullptr;
   if ( aa_status st = dev_alloc( s->ctx, s->slot_bytes, &piece ) ) return st;
-  for ( size_t i = 0; i < s->slots.size(); i++ ) if ( !s->slots[i].dev ) { s->slots[i].dev = piece; s->slots[i].refs = 0; *out = static_cast<int>( i ); return AA_OK; }
+  for ( size_t i = 0; i < s->slots.size(); i++ ) if ( !s->slots[i].dev ) { s->slots[i] = Slot(); s->slots[i].dev = piece; *out = static_cast<int>( i ); return AA_OK; }
   Slot sl; sl.dev = piece;
   *out = static_cast<int>( s->slots.size() );
   s->slots.push_back( sl );
@@ -1332,6 +1334,13 @@ aa_status aa_stream_references( const aa_stream * s, int * last, int * golden, i
   return AA_OK;
 }
 
+aa_status aa_stream_reference_slots( const aa_stream * s, int slots[3] )
+{
+  if ( !s || !slots ) return fail( AA_ERR_ARGUMENT, "null argument" );
+  for ( int i = 0; i < 3; i++ ) slots[i] = s->cur_ref_slot[i];
+  return AA_OK;
+}
+
 aa_status aa_stream_export_raster( aa_stream * s, int fi, void * y, void * u, void * v )
 {
   if ( !s || fi < 0 || fi >= static_cast<int>( s->frames.size() ) || !y || !u || !v ) return fail( AA_ERR_ARGUMENT, "aa_stream_export_raster: bad argument" );
@@ -1442,6 +1451,158 @@ aa_status aa_stream_import_reference_host( aa_stream * s, const uint8_t * y, con
   if ( !s || !y || !u || !v ) return fail( AA_ERR_ARGUMENT, "null argument" );
   const void * src[3] = { y, u, v };
   return import_common( s, src, hipMemcpyHostToDevice );
+}
+
+/* ---------------- hashes: boost::hash_combine / hash_range as the reference uses them (pre-1.81 formula) ---------------- */
+namespace {
+inline void hcombine( uint64_t & seed, uint64_t v ) { seed ^= v + 0x9e3779b9ull + ( seed << 6 ) + ( seed >> 2 ); }
+inline void hrange_u8( uint64_t & seed, const uint8_t * p, size_t n ) { for ( size_t i = 0; i < n; i++ ) hcombine( seed, p[i] ); }
+inline void hrange_i8( uint64_t & seed, const int8_t * p, size_t n ) { for ( size_t i = 0; i < n; i++ ) hcombine( seed, static_cast<uint64_t>( static_cast<int64_t>( p[i] ) ) ); }
+
+// DecoderState::hash (decoder.cc:266-281) with ProbabilityTables::hash (probability_tables.cc:36-57), Segmentation::hash
+// (decoder.cc:379-394; the map is sized by the frame's PIXEL dimensions, decoder.cc:238) and FilterAdjustments::hash
+// (decoder.cc:331-340 -- whose second range runs from mode_adjustments.begin() to REF_adjustments.end(), i.e. is empty: the
+// mode adjustments are not hashed; kept as is).
+uint64_t state_hash( const aa::Parser & ps )
+{
+  const aa::ProbTables & t = ps.probs();
+  uint64_t ph = 0;
+  hrange_u8( ph, &t.coeff[0][0][0][0], 1056 ); hrange_u8( ph, t.y_mode, 4 ); hrange_u8( ph, t.uv_mode, 3 ); hrange_u8( ph, &t.mv[0][0], 38 );
+  uint64_t h = 0;
+  hcombine( h, ps.width() ); hcombine( h, ps.height() ); hcombine( h, ph );
+  const aa::SegmentationState & sg = ps.segmentation();
+  if ( sg.enabled ) {
+    uint64_t sh = 0;
+    hcombine( sh, sg.absolute ? 1 : 0 );
+    hrange_i8( sh, sg.quant, 4 ); hrange_i8( sh, sg.lf, 4 );
+    const unsigned w = ps.width(), hgt = ps.height(), mbw = ps.mb_width(), mbh = ps.mb_height();
+    for ( unsigned r = 0; r < hgt; r++ ) for ( unsigned c = 0; c < w; c++ ) hcombine( sh, ( r < mbh && c < mbw ) ? sg.map[size_t( r ) * mbw + c] : 3 );
+    hcombine( h, sh );
+  }
+  const aa::FilterAdjustState & fa = ps.filter_adjustments();
+  if ( fa.enabled ) { uint64_t fh = 0; hrange_i8( fh, fa.ref, 4 ); hcombine( h, fh ); }
+  return h;
+}
+
+// BaseRaster::raw_hash (raster.cc:52-61) of a raster slot; the recurrence is serial, so the planes come to the host
+aa_status slot_hash( aa_stream * s, int slot, uint64_t * out )
+{
+  Slot & sl = s->slots[slot];
+  if ( !sl.hash_valid ) {
+    HIP_TRY( hipStreamSynchronize( s->ctx->compute ) );
+    if ( aa_status st = check_watchdog( s->ctx ) ) return st;
+    std::vector<uint8_t> host( s->plane_bytes[0] + 2 * s->plane_bytes[1] );
+    HIP_TRY( hipMemcpy( host.data(), sl.dev, host.size(), hipMemcpyDeviceToHost ) );
+    uint64_t h = 0;
+    hrange_u8( h, host.data(), host.size() );
+    sl.hash = h; sl.hash_valid = true;
+  }
+  *out = sl.hash;
+  return AA_OK;
+}
+} // namespace
+
+aa_status aa_parser_state_hash( const aa_parser * p, uint64_t * out )
+{
+  if ( !p || !out ) return fail( AA_ERR_ARGUMENT, "null argument" );
+  *out = state_hash( p->impl );
+  return AA_OK;
+}
+aa_status aa_stream_state_hash( aa_stream * s, uint64_t * out )
+{
+  if ( !s || !out ) return fail( AA_ERR_ARGUMENT, "null argument" );
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  if ( aa_status st = segmap_to_host( s ) ) return st;
+  *out = state_hash( s->parser );
+  return AA_OK;
+}
+aa_status aa_stream_raster_hash( aa_stream * s, int fi, uint64_t * out )
+{
+  if ( !s || !out || fi < 0 || fi >= static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_ARGUMENT, "aa_stream_raster_hash: bad argument" );
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  const FrameRec & r = s->frames[fi];
+  if ( fi >= s->next_submit || !r.placed ) return fail( AA_ERR_LOGIC, "aa_stream_raster_hash: frame not decoded yet" );
+  if ( !r.handle_held ) return fail( AA_ERR_LOGIC, "aa_stream_raster_hash: frame was released" );
+  return slot_hash( s, r.out_slot, out );
+}
+/* DecoderHash (decoder.cc:143-153,482-490): state, last, golden, alternative; everything parsed must have been submitted */
+aa_status aa_stream_decoder_hash( aa_stream * s, uint64_t parts[4], uint64_t * whole )
+{
+  if ( !s ) return fail( AA_ERR_ARGUMENT, "null stream" );
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  if ( s->next_submit != static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_LOGIC, "aa_stream_decoder_hash: parsed frames are still waiting to be decoded" );
+  if ( aa_status st = segmap_to_host( s ) ) return st;
+  uint64_t h[4];
+  h[0] = state_hash( s->parser );
+  for ( int i = 0; i < 3; i++ ) if ( aa_status st = slot_hash( s, s->cur_ref_slot[i], &h[1 + i] ) ) return st;
+  if ( parts ) std::memcpy( parts, h, sizeof h );
+  if ( whole ) { uint64_t w = 0; for ( int i = 0; i < 4; i++ ) hcombine( w, h[i] ); *whole = w; }
+  return AA_OK;
+}
+aa_status aa_stream_minihash( aa_stream * s, uint32_t * out )
+{
+  if ( !out ) return fail( AA_ERR_ARGUMENT, "null argument" );
+  uint64_t w = 0;
+  if ( aa_status st = aa_stream_decoder_hash( s, nullptr, &w ) ) return st;
+  *out = static_cast<uint32_t>( w );
+  return AA_OK;
+}
+
+/* One frame's raster handle and records (what a dying RasterHandle gives back, raster_handle.cc:113-122) */
+aa_status aa_stream_release_frame( aa_stream * s, int fi )
+{
+  if ( !s || fi < 0 || fi >= static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_ARGUMENT, "aa_stream_release_frame: bad frame index" );
+  FrameRec & f = s->frames[fi];
+  if ( f.handle_held ) { f.handle_held = false; if ( f.placed ) release( s, f.out_slot ); }
+  if ( fi < s->next_submit ) release_records( s, f, true );
+  std::vector<uint8_t>().swap( f.intra_diagonals );
+  while ( s->first_live < static_cast<int>( s->frames.size() ) && s->frames[s->first_live].records_released && !s->frames[s->first_live].handle_held ) s->first_live++;
+  return AA_OK;
+}
+
+/* References( last, golden, alternative ): Decoder( DecoderState, References ) (decoder.cc:43-46).  planes[i] = Y, U, V of
+ * reference i, in HBM (is_host[i] == 0) or on the host; references whose Y pointers are equal become one raster here too. */
+aa_status aa_stream_set_references( aa_stream * s, const void * const planes[3][3], const int is_host[3] )
+{
+  if ( !s || !planes || !is_host ) return fail( AA_ERR_ARGUMENT, "null argument" );
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  if ( s->next_submit != static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_LOGIC, "aa_stream_set_references: parsed frames are still waiting to be decoded" );
+  int slot[3] = { -1, -1, -1 };
+  bool any_host = false;
+  for ( int i = 0; i < 3; i++ ) {
+    for ( int p = 0; p < 3; p++ ) if ( !planes[i][p] ) return fail( AA_ERR_ARGUMENT, "aa_stream_set_references: null plane" );
+    for ( int k = 0; k < i; k++ ) if ( planes[k][0] == planes[i][0] && is_host[k] == is_host[i] ) slot[i] = slot[k];
+    if ( slot[i] >= 0 ) continue;
+    if ( aa_status st = alloc_slot( s, &slot[i] ) ) return st;
+    retain( s, slot[i] );                      // (held while the three are being set up)
+    for ( int p = 0; p < 3; p++ )
+      HIP_TRY( hipMemcpyAsync( slot_plane( s, slot[i], p ), planes[i][p], s->plane_bytes[p], is_host[i] ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s->ctx->compute ) );
+    any_host = any_host || is_host[i];
+  }
+  if ( any_host ) HIP_TRY( hipStreamSynchronize( s->ctx->compute ) );       // the caller's host planes may go away
+  for ( int i = 0; i < 3; i++ ) set_ref( s, i, slot[i], -1 );
+  for ( int i = 0; i < 3; i++ ) { bool first = true; for ( int k = 0; k < i; k++ ) if ( slot[k] == slot[i] ) first = false; if ( first ) release( s, slot[i] ); }
+  return AA_OK;
+}
+/* Device planes of References::last / golden / alternative as they stand (which: 0, 1, 2) */
+aa_status aa_stream_reference_device( aa_stream * s, int which, void ** y, void ** u, void ** v )
+{
+  if ( !s || which < 0 || which > 2 ) return fail( AA_ERR_ARGUMENT, "aa_stream_reference_device: bad argument" );
+  const int slot = s->cur_ref_slot[which];
+  if ( y ) *y = slot_plane( s, slot, 0 );
+  if ( u ) *u = slot_plane( s, slot, 1 );
+  if ( v ) *v = slot_plane( s, slot, 2 );
+  return AA_OK;
+}
+aa_status aa_stream_reference_download( aa_stream * s, int which, uint8_t * y, uint8_t * u, uint8_t * v )
+{
+  if ( !s || which < 0 || which > 2 ) return fail( AA_ERR_ARGUMENT, "aa_stream_reference_download: bad argument" );
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  HIP_TRY( hipStreamSynchronize( s->ctx->compute ) );
+  if ( aa_status st = check_watchdog( s->ctx ) ) return st;
+  uint8_t * dst[3] = { y, u, v };
+  for ( int p = 0; p < 3; p++ ) if ( dst[p] ) HIP_TRY( hipMemcpy( dst[p], slot_plane( s, s->cur_ref_slot[which], p ), s->plane_bytes[p], hipMemcpyDeviceToHost ) );
+  return AA_OK;
 }
 
 } // extern "C"

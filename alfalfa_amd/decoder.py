@@ -60,6 +60,12 @@ class Parser:
     def deserialize_state(self, blob):
         capi.check(self.L.aa_parser_deserialize_state(self.h, blob, len(blob)))
 
+    def state_hash(self):
+        """DecoderState::hash (decoder.cc:266-281)."""
+        h = C.c_uint64()
+        capi.check(self.L.aa_parser_state_hash(self.h, C.byref(h)))
+        return h.value
+
     def probs(self):
         out = (C.c_uint8 * 1101)()
         capi.check(self.L.aa_parser_get_probs(self.h, out))
@@ -200,6 +206,25 @@ class Decoder:
 
     def rewind(self):
         capi.check(self.L.aa_stream_rewind(self.h))
+
+    def decoder_hash(self):
+        """DecoderHash (decoder.cc:143-153): ([state, last, golden, alternative], hash of the four)."""
+        parts, whole = (C.c_uint64 * 4)(), C.c_uint64()
+        capi.check(self.L.aa_stream_decoder_hash(self.h, parts, C.byref(whole)))
+        return list(parts), whole.value
+
+    def minihash(self):
+        h = C.c_uint32()
+        capi.check(self.L.aa_stream_minihash(self.h, C.byref(h)))
+        return h.value
+
+    def raster_hash(self, frame_index):
+        h = C.c_uint64()
+        capi.check(self.L.aa_stream_raster_hash(self.h, frame_index, C.byref(h)))
+        return h.value
+
+    def release_frame(self, frame_index):
+        capi.check(self.L.aa_stream_release_frame(self.h, frame_index))
 
     def rewind_to(self, frame_index):
         capi.check(self.L.aa_stream_rewind_to(self.h, frame_index))

@@ -211,6 +211,10 @@ aa_status aa_stream_download( aa_stream * s, int frame_index, uint8_t * y, uint8
 aa_status aa_stream_raster_device( aa_stream * s, int frame_index, void ** y, void ** u, void ** v );
 /* References::last/golden/alternative after the most recently SUBMITTED frame: frame indices (-1 = initial blank). */
 aa_status aa_stream_references( const aa_stream * s, int * last, int * golden, int * alternate );
+/* Identity of the three reference rasters as they stand now (all frames handed to aa_decode_batch so far applied): equal
+ * numbers = the same raster; a number stays the same for as long as that raster is a reference.  Lets a binding keep ONE
+ * handle per raster across frames, also for rasters no frame produced (the blank initial one, imported ones). */
+aa_status aa_stream_reference_slots( const aa_stream * s, int slots[3] );
 /* Replace all three references by a raster given as device planes (e.g. received by an RCCL broadcast over xGMI):
  * the entry-state hand-off of xc-decode-bundle (decoder.cc:171-175, References(EncoderStateDeserializer&)). */
 aa_status aa_stream_import_reference( aa_stream * s, const void * y_dev, const void * u_dev, const void * v_dev );
@@ -228,10 +232,30 @@ aa_status aa_stream_import_state( aa_stream * s, const uint8_t * buf, size_t siz
 /* The whole decoder as the reference writes it to a `.state` file: Decoder::serialize / Decoder::deserialize
  * (decoder.cc:54-81) = DecoderState + References (the LAST raster only; golden and alternative alias it after loading,
  * decoder.cc:171-197).  Files written by the reference's xc-enc -O / read by vp8decode -s and xc-decode-bundle load here
- * and vice versa.  Everything parsed must have been submitted; serialize waits for the device.  buf == NULL: size query.
- * (Decoder::minihash, boost::hash_combine based, is not provided.) */
+ * and vice versa.  Everything parsed must have been submitted; serialize waits for the device.  buf == NULL: size query. */
 aa_status aa_stream_serialize( aa_stream * s, uint8_t * buf, size_t capacity, size_t * size );
 aa_status aa_stream_deserialize( aa_stream * s, const uint8_t * buf, size_t size );
+
+/* Hashes as the reference computes them (boost::hash_combine / hash_range, the pre-1.81 formula, over 64-bit size_t):
+ *   DecoderState::hash (decoder.cc:266-281), BaseRaster::raw_hash of a decoded frame (raster.cc:52-61; computed on the host
+ *   from a copy of the planes -- the recurrence is serial -- and cached per raster like HashCachedRaster),
+ *   DecoderHash = {state, last, golden, alternative} and its hash (decoder.cc:143-153,482-490),
+ *   Decoder::minihash = low 32 bits (decoder.cc:516-529): what xc-decode-bundle checks against IVF header bytes 28-31. */
+aa_status aa_parser_state_hash( const aa_parser * p, uint64_t * out );
+aa_status aa_stream_state_hash( aa_stream * s, uint64_t * out );
+aa_status aa_stream_raster_hash( aa_stream * s, int frame_index, uint64_t * out );
+aa_status aa_stream_decoder_hash( aa_stream * s, uint64_t parts[4], uint64_t * whole );
+aa_status aa_stream_minihash( aa_stream * s, uint32_t * out );
+/* Give back ONE frame: its raster handle (the raster lives on while a reference points at it) and, once decoded, its
+ * parsed records -- what the destructor of the last RasterHandle of a frame does in the reference (raster_handle.cc:113-122). */
+aa_status aa_stream_release_frame( aa_stream * s, int frame_index );
+/* References{ last, golden, alternative } (Decoder( DecoderState, References ), decoder.cc:43-46): planes[i] = Y, U, V of
+ * reference i, in HBM (is_host[i] == 0) or in host memory; references given by the same Y pointer become one raster.
+ * aa_stream_reference_device / _download: the current References of a stream (which: 0 last, 1 golden, 2 alternative),
+ * also before any frame (the blank raster) or after an import. */
+aa_status aa_stream_set_references( aa_stream * s, const void * const planes[3][3], const int is_host[3] );
+aa_status aa_stream_reference_device( aa_stream * s, int which, void ** y, void ** u, void ** v );
+aa_status aa_stream_reference_download( aa_stream * s, int which, uint8_t * y, uint8_t * u, uint8_t * v );
 
 /* Padded plane geometry for a display size (VP8Raster ctor, prediction.cc:94-97). */
 void aa_raster_geometry( uint16_t width, uint16_t height, uint32_t * padded_width, uint32_t * padded_height );

@@ -16,8 +16,11 @@
 //   FileDescriptor (write only), YUV4MPEGHeader, YUV4MPEGFrameWriter  -- what vp8decode / xc-decode-bundle write with
 //                                                                      (util/file_descriptor.hh, input/yuv4mpeg.{hh,cc})
 //   Decoder::get_frame_outputs  -- NOT in the reference: one frame of each of N decoders as one GPU batch step
+//   DecoderState / ProbabilityTables / Segmentation / FilterAdjustments  public fields, ==, hash(), serialize / deserialize
+//               (decoder/decoder.hh:57-225);  Decoder( DecoderState, References ), get_state(), ==, get_hash(), minihash(),
+//               minihash_match()  (decoder.hh:244-300; hashes = boost::hash_combine, pre-1.81 formula)
 // What is NOT mirrored (host-side plumbing outside the hot path): Frame<> object graphs
-// (parse_frame<F>/decode_frame<F> are replaced by get_frame_output), boost-based hash()/minihash.
+// (decompress_frame / parse_frame<F> / decode_frame<F> are replaced by get_frame_output), MutableRasterHandle.
 //   EncoderStateSerializer / EncoderStateDeserializer, Decoder / FramePlayer / FilePlayer ::serialize, ::deserialize
 //               -- the reference's `.state` files, byte-compatible    (decoder/enc_state_serializer.hh, decoder.cc:48-81)
 //
@@ -25,16 +28,22 @@
 // names into the global namespace (drop-in for code written against the reference headers).
 #pragma once
 
+#include <cassert>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <memory>
+#include <new>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <utility>
 #include <vector>
+
+#include <unistd.h>
 
 extern "C" {
 #include "../alfalfa_amd.h"
@@ -86,20 +95,35 @@ inline void check( const aa_status s )
   }
 }
 
-// ---------------------------------------------------------------- Optional
+// ---------------------------------------------------------------- Optional (util/optional.hh: same members; storage in place)
 template <class T>
 class Optional
 {
   bool initialized_ = false;
-  T value_ {};
+  typename std::aligned_storage<sizeof( T ), alignof( T )>::type storage_;
+  T * ptr() { return reinterpret_cast<T *>( &storage_ ); }
+  const T * ptr() const { return reinterpret_cast<const T *>( &storage_ ); }
+  void destroy() { if ( initialized_ ) { ptr()->~T(); initialized_ = false; } }
 public:
-  Optional() = default;
-  Optional( const T & v ) : initialized_( true ), value_( v ) {}
-  Optional( const bool init, const T & v ) : initialized_( init ), value_( init ? v : T() ) {}
+  Optional() {}
+  Optional( T && other ) : initialized_( true ) { new ( &storage_ ) T( std::move( other ) ); }
+  Optional( const T & other ) : initialized_( true ) { new ( &storage_ ) T( other ); }
+  template <typename... Targs>
+  Optional( const bool is_present, Targs &&... args ) : initialized_( is_present ) { if ( initialized_ ) new ( &storage_ ) T( std::forward<Targs>( args )... ); }
+  Optional( Optional<T> && other ) : initialized_( other.initialized_ ) { if ( initialized_ ) new ( &storage_ ) T( std::move( *other.ptr() ) ); }
+  Optional( const Optional<T> & other ) : initialized_( other.initialized_ ) { if ( initialized_ ) new ( &storage_ ) T( *other.ptr() ); }
+  ~Optional() { destroy(); }
+  template <typename... Targs>
+  void initialize( Targs &&... args ) { destroy(); new ( &storage_ ) T( std::forward<Targs>( args )... ); initialized_ = true; }
+  const Optional & operator=( Optional<T> && other ) { if ( this != &other ) { destroy(); if ( other.initialized_ ) { new ( &storage_ ) T( std::move( *other.ptr() ) ); initialized_ = true; } } return *this; }
+  const Optional & operator=( const Optional<T> & other ) { if ( this != &other ) { destroy(); if ( other.initialized_ ) { new ( &storage_ ) T( *other.ptr() ); initialized_ = true; } } return *this; }
+  bool operator==( const Optional<T> & other ) const { return initialized_ ? ( other.initialized_ && get() == other.get() ) : !other.initialized_; }
+  bool operator!=( const Optional<T> & other ) const { return !operator==( other ); }
   bool initialized() const { return initialized_; }
-  const T & get() const { if ( !initialized_ ) throw std::runtime_error( "attempt to get uninitialized Optional" ); return value_; }
-  const T & get_or( const T & fallback ) const { return initialized_ ? value_ : fallback; }
-  void clear() { initialized_ = false; value_ = T(); }
+  const T & get() const { if ( !initialized_ ) throw std::runtime_error( "attempt to get uninitialized Optional" ); return *ptr(); }
+  T & get() { if ( !initialized_ ) throw std::runtime_error( "attempt to get uninitialized Optional" ); return *ptr(); }
+  const T & get_or( const T & fallback ) const { return initialized_ ? *ptr() : fallback; }
+  void clear() { destroy(); }
 };
 template <class T> Optional<T> make_optional( const bool init, const T & v ) { return Optional<T>( init, v ); }
 
@@ -273,18 +297,31 @@ struct StreamOwner     // shared by a Decoder and every RasterHandle it handed o
 struct RasterState
 {
   std::shared_ptr<StreamOwner> owner;
-  int frame_index;                         // -1: the blank initial reference
-  std::unique_ptr<VP8Raster> host;         // filled on first get()
+  int frame_index;                         // >= 0: the raster decoded frame `frame_index` produced; -1: a snapshot (blank / imported reference)
+  std::unique_ptr<VP8Raster> host;         // filled on first get() (snapshots: at creation)
+  ~RasterState() { if ( owner && frame_index >= 0 ) (void) aa_stream_release_frame( owner->stream, frame_index ); }   // raster_handle.cc:113-122
 };
+inline void hash_combine( size_t & seed, const size_t v ) { seed ^= v + 0x9e3779b9 + ( seed << 6 ) + ( seed >> 2 ); }   // boost < 1.81
 }
 
 class RasterHandle
 {
   std::shared_ptr<detail::RasterState> state_;
+  friend class Decoder;
 public:
   RasterHandle() = default;
   RasterHandle( std::shared_ptr<detail::StreamOwner> owner, const int frame_index )
     : state_( std::make_shared<detail::RasterState>() ) { state_->owner = std::move( owner ); state_->frame_index = frame_index; }
+  // a snapshot of References::last / golden / alternative (which = 0, 1, 2) as they stand: blank or imported rasters that no
+  // decoded frame of this decoder produced
+  static RasterHandle snapshot( std::shared_ptr<detail::StreamOwner> owner, const int which )
+  {
+    RasterHandle h( owner, -1 );
+    auto r = std::unique_ptr<VP8Raster>( new VP8Raster( owner->width, owner->height ) );
+    check( aa_stream_reference_download( owner->stream, which, &r->Y().at( 0, 0 ), &r->U().at( 0, 0 ), &r->V().at( 0, 0 ) ) );
+    h.state_->host = std::move( r );
+    return h;
+  }
   // lazy D2H: the raster stays in HBM until somebody looks at the pixels (raster_handle.hh:100-106 `get()`)
   const VP8Raster & get() const
   {
@@ -299,13 +336,37 @@ public:
   }
   operator const VP8Raster & () const { return get(); }
   int frame_index() const { return state_ ? state_->frame_index : -1; }
-  bool operator==( const RasterHandle & o ) const { return get() == o.get(); }
+  const std::shared_ptr<detail::StreamOwner> & owner() const { if ( !state_ ) throw LogicError(); return state_->owner; }
+  // HashCachedRaster::hash = BaseRaster::raw_hash (raster.cc:52-61, raster_handle.cc:196-206)
+  size_t hash() const
+  {
+    if ( !state_ ) throw LogicError();
+    if ( state_->frame_index >= 0 ) { uint64_t h = 0; check( aa_stream_raster_hash( state_->owner->stream, state_->frame_index, &h ) ); return h; }
+    const VP8Raster & r = get();
+    size_t h = 0;
+    for ( const Plane * p : { &r.Y(), &r.U(), &r.V() } ) for ( const uint8_t v : *p ) detail::hash_combine( h, v );
+    return h;
+  }
+  bool operator==( const RasterHandle & o ) const { return hash() == o.hash(); }      // raster_handle.cc:184-194: by hash
   bool operator!=( const RasterHandle & o ) const { return !operator==( o ); }
 };
+
+enum reference_frame { CURRENT_FRAME, LAST_FRAME, GOLDEN_FRAME, ALTREF_FRAME };     // modemv_data.hh
 
 struct References
 {
   RasterHandle last, golden, alternative;
+  const VP8Raster & at( const reference_frame reference_id ) const
+  {
+    switch ( reference_id ) {
+    case LAST_FRAME: return last;
+    case GOLDEN_FRAME: return golden;
+    case ALTREF_FRAME: return alternative;
+    default: throw LogicError();
+    }
+  }
+  bool operator==( const References & o ) const { return last == o.last && golden == o.golden && alternative == o.alternative; }
+  bool operator!=( const References & o ) const { return !operator==( o ); }
 };
 
 // ---------------------------------------------------------------- decoder state files (decoder/enc_state_serializer.hh:58-179)
@@ -343,19 +404,232 @@ public:
   static T build( F f, Ps... ps ) { EncoderStateDeserializer idata( f ); return T::deserialize( idata, ps... ); }     // enc_state_serializer.hh:125-128
 };
 
+// ---------------------------------------------------------------- DecoderState and what it is made of (decoder/decoder.hh:57-225)
+// Plain values with the reference's field names.  hash() / serialize() / deserialize() go through the C ABI (a scratch
+// aa_parser loaded with the value), so they are the product's code, not a second implementation.
+struct ProbabilityTables
+{
+  uint8_t coeff_probs[4][8][3][11];
+  uint8_t y_mode_probs[4], uv_mode_probs[3], motion_vector_probs[2][19];
+  ProbabilityTables() { std::memset( this, 0, sizeof *this ); }
+  bool operator==( const ProbabilityTables & o ) const { return std::memcmp( this, &o, sizeof *this ) == 0; }
+  bool operator!=( const ProbabilityTables & o ) const { return !operator==( o ); }
+};
+struct FilterAdjustments
+{
+  int8_t loopfilter_ref_adjustments[4] = { 0, 0, 0, 0 }, loopfilter_mode_adjustments[4] = { 0, 0, 0, 0 };
+  bool operator==( const FilterAdjustments & o ) const
+  { return std::memcmp( loopfilter_ref_adjustments, o.loopfilter_ref_adjustments, 4 ) == 0 && std::memcmp( loopfilter_mode_adjustments, o.loopfilter_mode_adjustments, 4 ) == 0; }
+};
+struct SegmentationMap       // TwoD<uint8_t> of the macroblocks (the reference sizes its map by PIXEL dimensions and uses this corner)
+{
+  unsigned width_ = 0, height_ = 0;
+  std::vector<uint8_t> storage_;
+  SegmentationMap() = default;
+  SegmentationMap( const unsigned w, const unsigned h, const uint8_t v ) : width_( w ), height_( h ), storage_( size_t( w ) * h, v ) {}
+  uint8_t & at( const unsigned column, const unsigned row ) { return storage_.at( size_t( row ) * width_ + column ); }
+  const uint8_t & at( const unsigned column, const unsigned row ) const { return storage_.at( size_t( row ) * width_ + column ); }
+  unsigned width() const { return width_; }
+  unsigned height() const { return height_; }
+  bool operator==( const SegmentationMap & o ) const { return width_ == o.width_ && height_ == o.height_ && storage_ == o.storage_; }
+};
+struct Segmentation
+{
+  bool absolute_segment_adjustments = false;
+  int8_t segment_quantizer_adjustments[4] = { 0, 0, 0, 0 }, segment_filter_adjustments[4] = { 0, 0, 0, 0 };
+  SegmentationMap map;
+  Segmentation() = default;
+  Segmentation( const unsigned mb_width, const unsigned mb_height ) : map( mb_width, mb_height, 3 ) {}
+  bool operator==( const Segmentation & o ) const
+  {
+    return absolute_segment_adjustments == o.absolute_segment_adjustments && map == o.map
+           && std::memcmp( segment_quantizer_adjustments, o.segment_quantizer_adjustments, 4 ) == 0
+           && std::memcmp( segment_filter_adjustments, o.segment_filter_adjustments, 4 ) == 0;
+  }
+};
+
+struct DecoderState
+{
+  uint16_t width, height;
+  ProbabilityTables probability_tables;
+  Optional<Segmentation> segmentation;
+  Optional<FilterAdjustments> filter_adjustments;
+
+  DecoderState( const unsigned s_width, const unsigned s_height )          // defaults of a fresh decoder (decoder.cc:226-232)
+    : width( s_width ), height( s_height )
+  {
+    aa_parser * p = nullptr;
+    check( aa_parser_create( width, height, &p ) );
+    std::vector<uint8_t> blob( aa_parser_state_size( p ) );
+    const aa_status st = aa_parser_export_state( p, blob.data(), blob.size() );
+    aa_parser_destroy( p );
+    check( st );
+    *this = from_blob( blob );
+  }
+  bool operator==( const DecoderState & o ) const
+  {
+    return width == o.width && height == o.height && probability_tables == o.probability_tables
+           && segmentation == o.segmentation && filter_adjustments == o.filter_adjustments;
+  }
+  bool operator!=( const DecoderState & o ) const { return !operator==( o ); }
+
+  // the C ABI's flat form (aa_parser_export_state / aa_stream_export_state): "AAST" u16 version, width, height, 1101
+  // probabilities, segmentation {enabled, absolute, quant[4], lf[4]}, filter adjustments {enabled, ref[4], mode[4]}, map
+  std::vector<uint8_t> to_blob() const
+  {
+    const unsigned mbw = ( width + 15u ) / 16u, mbh = ( height + 15u ) / 16u;
+    std::vector<uint8_t> b( 4 + 6 + 1101 + 10 + 9 + size_t( mbw ) * mbh, 0 );
+    uint8_t * o = b.data();
+    std::memcpy( o, "AAST", 4 ); o += 4;
+    const uint16_t hdr[3] = { 1, width, height };
+    std::memcpy( o, hdr, 6 ); o += 6;
+    std::memcpy( o, probability_tables.coeff_probs, 1056 ); std::memcpy( o + 1056, probability_tables.y_mode_probs, 4 );
+    std::memcpy( o + 1060, probability_tables.uv_mode_probs, 3 ); std::memcpy( o + 1063, probability_tables.motion_vector_probs, 38 ); o += 1101;
+    if ( segmentation.initialized() ) {
+      const Segmentation & sg = segmentation.get();
+      o[0] = 1; o[1] = sg.absolute_segment_adjustments; std::memcpy( o + 2, sg.segment_quantizer_adjustments, 4 ); std::memcpy( o + 6, sg.segment_filter_adjustments, 4 );
+    }
+    o += 10;
+    if ( filter_adjustments.initialized() ) {
+      o[0] = 1; std::memcpy( o + 1, filter_adjustments.get().loopfilter_ref_adjustments, 4 ); std::memcpy( o + 5, filter_adjustments.get().loopfilter_mode_adjustments, 4 );
+    }
+    o += 9;
+    if ( segmentation.initialized() && segmentation.get().map.width() == mbw && segmentation.get().map.height() == mbh )
+      std::memcpy( o, segmentation.get().map.storage_.data(), size_t( mbw ) * mbh );
+    else std::memset( o, 3, size_t( mbw ) * mbh );
+    return b;
+  }
+  static DecoderState from_blob( const std::vector<uint8_t> & b )
+  {
+    if ( b.size() < 4 + 6 + 1101 + 19 || std::memcmp( b.data(), "AAST", 4 ) != 0 ) throw Invalid( "decoder state: not a state blob" );
+    uint16_t hdr[3];
+    std::memcpy( hdr, b.data() + 4, 6 );
+    DecoderState st( hdr[1], hdr[2], 0 );
+    const unsigned mbw = ( st.width + 15u ) / 16u, mbh = ( st.height + 15u ) / 16u;
+    if ( b.size() != 4 + 6 + 1101 + 19 + size_t( mbw ) * mbh ) throw Invalid( "decoder state: blob size" );
+    const uint8_t * i = b.data() + 10;
+    std::memcpy( st.probability_tables.coeff_probs, i, 1056 ); std::memcpy( st.probability_tables.y_mode_probs, i + 1056, 4 );
+    std::memcpy( st.probability_tables.uv_mode_probs, i + 1060, 3 ); std::memcpy( st.probability_tables.motion_vector_probs, i + 1063, 38 ); i += 1101;
+    if ( i[0] ) {
+      Segmentation sg( mbw, mbh );
+      sg.absolute_segment_adjustments = i[1]; std::memcpy( sg.segment_quantizer_adjustments, i + 2, 4 ); std::memcpy( sg.segment_filter_adjustments, i + 6, 4 );
+      std::memcpy( sg.map.storage_.data(), i + 19, size_t( mbw ) * mbh );
+      st.segmentation.initialize( std::move( sg ) );
+    }
+    i += 10;
+    if ( i[0] ) {
+      FilterAdjustments fa;
+      std::memcpy( fa.loopfilter_ref_adjustments, i + 1, 4 ); std::memcpy( fa.loopfilter_mode_adjustments, i + 5, 4 );
+      st.filter_adjustments.initialize( fa );
+    }
+    return st;
+  }
+  size_t hash() const                                            // DecoderState::hash, decoder.cc:266-281
+  {
+    ScratchParser p( *this );
+    uint64_t h = 0;
+    check( aa_parser_state_hash( p.p, &h ) );
+    return h;
+  }
+  size_t serialize( EncoderStateSerializer & odata ) const;      // decoder.cc:283-313 (defined below the serializer)
+  static DecoderState deserialize( EncoderStateDeserializer & idata );   // decoder.cc:315-330: the whole input is one DECODER_STATE
+private:
+  DecoderState( const uint16_t w, const uint16_t h, int ) : width( w ), height( h ) {}
+  struct ScratchParser
+  {
+    aa_parser * p = nullptr;
+    explicit ScratchParser( const DecoderState & st )
+    {
+      check( aa_parser_create( st.width, st.height, &p ) );
+      const std::vector<uint8_t> b = st.to_blob();
+      const aa_status s = aa_parser_import_state( p, b.data(), b.size() );
+      if ( s != AA_OK ) { aa_parser_destroy( p ); check( s ); }
+    }
+    ~ScratchParser() { aa_parser_destroy( p ); }
+    ScratchParser( const ScratchParser & ) = delete;
+    ScratchParser & operator=( const ScratchParser & ) = delete;
+  };
+};
+
+class DecoderHash                                                 // decoder.hh:227-242, decoder.cc:149-153,482-514
+{
+  size_t state_hash_, last_hash_, golden_hash_, alt_hash_;
+public:
+  DecoderHash( const size_t state_hash, const size_t last_hash, const size_t golden_hash, const size_t alt_hash )
+    : state_hash_( state_hash ), last_hash_( last_hash ), golden_hash_( golden_hash ), alt_hash_( alt_hash ) {}
+  size_t hash() const
+  {
+    size_t h = 0;
+    detail::hash_combine( h, state_hash_ ); detail::hash_combine( h, last_hash_ ); detail::hash_combine( h, golden_hash_ ); detail::hash_combine( h, alt_hash_ );
+    return h;
+  }
+  std::string str() const
+  {
+    char buf[160];
+    std::snprintf( buf, sizeof buf, "%zx (%zx_%zx_%zx_%zx)", hash(), state_hash_, last_hash_, golden_hash_, alt_hash_ );
+    return buf;
+  }
+  bool operator==( const DecoderHash & o ) const { return state_hash_ == o.state_hash_ && last_hash_ == o.last_hash_ && golden_hash_ == o.golden_hash_ && alt_hash_ == o.alt_hash_; }
+  bool operator!=( const DecoderHash & o ) const { return !operator==( o ); }
+};
+
 class Decoder
 {
   std::shared_ptr<detail::StreamOwner> owner_;
-  std::vector<RasterHandle> handles_;      // frame index -> handle (so References can name earlier frames)
-  RasterHandle handle_for( const int frame_index ) const
+  // Handles of the frames the stream's References currently name, and snapshots for rasters no frame of this decoder
+  // produced (blank, imported).  Everything else lives exactly as long as the caller keeps its RasterHandle.
+  RasterHandle refs_[3];
+  int ref_slot_[3] = { -1, -1, -1 };       // identity of the raster each of them is (aa_stream_reference_slots)
+  void sync_references( const RasterHandle * fresh )
   {
-    if ( frame_index < 0 ) return RasterHandle( owner_, -1 );
-    return handles_.at( frame_index );
+    int idx[3] = { -1, -1, -1 }, slot[3] = { -1, -1, -1 };
+    check( aa_stream_references( owner_->stream, &idx[0], &idx[1], &idx[2] ) );
+    check( aa_stream_reference_slots( owner_->stream, slot ) );
+    RasterHandle next[3];
+    for ( int i = 0; i < 3; i++ ) {
+      for ( int k = 0; k < i && !next[i].state_; k++ ) if ( slot[k] == slot[i] ) next[i] = next[k];
+      for ( int k = 0; k < 3 && !next[i].state_; k++ ) if ( refs_[k].state_ && ref_slot_[k] == slot[i] ) next[i] = refs_[k];   // still the same raster
+      if ( !next[i].state_ && fresh && idx[i] >= 0 && fresh->frame_index() == idx[i] ) next[i] = *fresh;
+      if ( !next[i].state_ ) next[i] = RasterHandle::snapshot( owner_, i );     // blank / imported: no frame of ours made it
+    }
+    for ( int i = 0; i < 3; i++ ) { refs_[i] = next[i]; ref_slot_[i] = slot[i]; }
+  }
+  std::pair<bool, RasterHandle> adopt( const int index, const bool shown )
+  {
+    RasterHandle h( owner_, index );
+    sync_references( &h );
+    return std::make_pair( shown, h );
   }
 public:
   Decoder( const uint16_t width, const uint16_t height ) : Decoder( GpuContext::process_default(), width, height ) {}
   Decoder( std::shared_ptr<GpuContext> ctx, const uint16_t width, const uint16_t height )
-    : owner_( std::make_shared<detail::StreamOwner>( std::move( ctx ), width, height ) ) {}
+    : owner_( std::make_shared<detail::StreamOwner>( std::move( ctx ), width, height ) ) { sync_references( nullptr ); }
+  // Decoder( DecoderState, References ) (decoder.cc:43-46): continue from a state somebody else reached
+  Decoder( const DecoderState & state, const References & references ) : Decoder( GpuContext::process_default(), state, references ) {}
+  Decoder( std::shared_ptr<GpuContext> ctx, const DecoderState & state, const References & references )
+    : owner_( std::make_shared<detail::StreamOwner>( std::move( ctx ), state.width, state.height ) )
+  {
+    const std::vector<uint8_t> blob = state.to_blob();
+    check( aa_stream_import_state( owner_->stream, blob.data(), blob.size() ) );
+    const RasterHandle * in[3] = { &references.last, &references.golden, &references.alternative };
+    const void * planes[3][3];
+    int is_host[3];
+    for ( int i = 0; i < 3; i++ ) {
+      const RasterHandle & h = *in[i];
+      const VP8Raster * host = nullptr;
+      if ( h.frame_index() >= 0 && h.owner()->ctx == owner_->ctx ) {      // stays in HBM: device-to-device
+        void * y, * u, * v;
+        check( aa_stream_raster_device( h.owner()->stream, h.frame_index(), &y, &u, &v ) );
+        planes[i][0] = y; planes[i][1] = u; planes[i][2] = v; is_host[i] = 0;
+      } else {
+        host = &h.get();
+        if ( host->display_width() != state.width || host->display_height() != state.height ) throw Invalid( "reference raster size differs from the decoder state's" );
+        planes[i][0] = &host->Y().at( 0, 0 ); planes[i][1] = &host->U().at( 0, 0 ); planes[i][2] = &host->V().at( 0, 0 ); is_host[i] = 1;
+      }
+    }
+    check( aa_stream_set_references( owner_->stream, planes, is_host ) );
+    sync_references( nullptr );
+  }
 
   uint16_t get_width() const { return owner_->width; }
   uint16_t get_height() const { return owner_->height; }
@@ -365,9 +639,7 @@ public:
   {
     int index = -1, shown = 0;
     check( aa_stream_decode( owner_->stream, compressed_frame.buffer(), compressed_frame.size(), &index, &shown ) );
-    if ( static_cast<int>( handles_.size() ) <= index ) handles_.resize( index + 1 );
-    handles_[index] = RasterHandle( owner_, index );
-    return std::make_pair( shown != 0, handles_[index] );
+    return adopt( index, shown != 0 );
   }
   // N independent decoders, one frame each, as ONE batch step on the GPU (aa_decode_batch): what fills the chip when an
   // ExCamera bundle or a set of streams is decoded (the reference loops over its decoders one after the other).
@@ -384,12 +656,7 @@ public:
     }
     check( aa_decode_batch( decoders[0]->owner_->ctx->get(), streams.data(), static_cast<int>( streams.size() ), index.data() ) );
     std::vector<std::pair<bool, RasterHandle>> out;
-    for ( size_t i = 0; i < decoders.size(); i++ ) {
-      Decoder & d = *decoders[i];
-      if ( static_cast<int>( d.handles_.size() ) <= index[i] ) d.handles_.resize( index[i] + 1 );
-      d.handles_[index[i]] = RasterHandle( d.owner_, index[i] );
-      out.emplace_back( shown[i] != 0, d.handles_[index[i]] );
-    }
+    for ( size_t i = 0; i < decoders.size(); i++ ) out.push_back( decoders[i]->adopt( index[i], shown[i] != 0 ) );
     return out;
   }
   Optional<RasterHandle> parse_and_decode_frame( const Chunk & compressed_frame )   // decoder.cc:137-141
@@ -397,14 +664,26 @@ public:
     const std::pair<bool, RasterHandle> out = get_frame_output( compressed_frame );
     return make_optional( out.first, out.second );
   }
-  References get_references() const
-  {
-    int l = -1, g = -1, a = -1;
-    check( aa_stream_references( owner_->stream, &l, &g, &a ) );
-    return References { handle_for( l ), handle_for( g ), handle_for( a ) };
-  }
-  const VP8Raster & example_raster() const { example_ = get_references().last; return example_.get(); }
+  References get_references() const { return References { refs_[0], refs_[1], refs_[2] }; }
+  const VP8Raster & example_raster() const { return refs_[0].get(); }
   aa_stream * native_handle() const { return owner_->stream; }
+
+  DecoderState get_state() const
+  {
+    std::vector<uint8_t> blob( aa_stream_state_size( owner_->stream ) );
+    check( aa_stream_export_state( owner_->stream, blob.data(), blob.size() ) );
+    return DecoderState::from_blob( blob );
+  }
+  DecoderHash get_hash() const                                    // decoder.cc:143-147
+  {
+    uint64_t parts[4];
+    check( aa_stream_decoder_hash( owner_->stream, parts, nullptr ) );
+    return DecoderHash( parts[0], parts[1], parts[2], parts[3] );
+  }
+  uint32_t minihash() const { return static_cast<uint32_t>( get_hash().hash() ); }                  // decoder.cc:516-519
+  bool minihash_match( const uint32_t other_minihash ) const { return other_minihash == 0 || minihash() == other_minihash; }   // :522-529
+  bool operator==( const Decoder & o ) const { return get_state() == o.get_state() && get_references() == o.get_references(); }   // decoder.cc:155-158
+  bool operator!=( const Decoder & o ) const { return !operator==( o ); }
 
   // Decoder::serialize (decoder.cc:54-69): DecoderState + the LAST reference raster, in the reference's wire format
   size_t serialize( EncoderStateSerializer & odata ) const
@@ -424,11 +703,36 @@ public:
     if ( b.size() < 14 || b[0] != 11 || b[5] != 4 ) throw Invalid( "decoder state: not a serialized Decoder" );
     Decoder d( std::move( ctx ), static_cast<uint16_t>( b[10] | ( b[11] << 8 ) ), static_cast<uint16_t>( b[12] | ( b[13] << 8 ) ) );
     check( aa_stream_deserialize( d.owner_->stream, b.data(), b.size() ) );
+    for ( RasterHandle & r : d.refs_ ) r = RasterHandle();
+    d.sync_references( nullptr );           // golden and alternative alias the loaded LAST raster (decoder.cc:171-175)
     return d;
   }
-private:
-  mutable RasterHandle example_;
 };
+
+inline size_t DecoderState::serialize( EncoderStateSerializer & odata ) const
+{
+  ScratchParser p( *this );
+  size_t n = 0;
+  check( aa_parser_serialize_state( p.p, nullptr, 0, &n ) );
+  std::vector<uint8_t> bytes( n );
+  check( aa_parser_serialize_state( p.p, bytes.data(), bytes.size(), &n ) );
+  odata.append( bytes );
+  return n;
+}
+inline DecoderState DecoderState::deserialize( EncoderStateDeserializer & idata )
+{
+  const std::vector<uint8_t> & b = idata.data();
+  if ( b.size() < 9 || b[0] != 4 ) throw Invalid( "decoder state: expected DECODER_STATE" );
+  const uint16_t w = static_cast<uint16_t>( b[5] | ( b[6] << 8 ) ), h = static_cast<uint16_t>( b[7] | ( b[8] << 8 ) );
+  aa_parser * p = nullptr;
+  check( aa_parser_create( w, h, &p ) );
+  aa_status st = aa_parser_deserialize_state( p, b.data(), b.size() );
+  std::vector<uint8_t> blob( aa_parser_state_size( p ) );
+  if ( st == AA_OK ) st = aa_parser_export_state( p, blob.data(), blob.size() );
+  aa_parser_destroy( p );
+  check( st );
+  return from_blob( blob );
+}
 
 class FramePlayer
 {
@@ -469,7 +773,7 @@ class FilePlayer : public FramePlayer
   {
     if ( file_.fourcc() != "VP80" ) throw Unsupported( "not a VP8 file" );
     if ( file_.width() != decoder_.get_width() || file_.height() != decoder_.get_height() ) throw Unsupported( "state vs. file dimension mismatch" );
-    // the reference also checks Decoder::minihash against the IVF header here; minihash (boost::hash_combine) is not provided
+    if ( !decoder_.minihash_match( file_.expected_decoder_minihash() ) ) throw Invalid( "Decoder state / IVF mismatch" );   // player.cc:118-121
   }
 public:
   explicit FilePlayer( const std::string & filename ) : FilePlayer( filename, IVF( filename ) ) {}
@@ -489,25 +793,39 @@ public:
 
 using Player = FilePlayer;
 
+inline std::ostream & operator<<( std::ostream & out, const FramePlayer & player ) { return out << player.current_decoder().get_hash().str(); }   // player.cc:75-78
+
 // ---------------------------------------------------------------- output side of the front-ends (util/file_descriptor.hh, input/yuv4mpeg.{hh,cc})
-class FileDescriptor       // the subset vp8decode / xc-decode-bundle use: wrap a FILE* or an fd, write strings and chunks
+class FileDescriptor       // the subset vp8decode / xc-decode-bundle use (util/file_descriptor.hh:44-160): an owned fd, unbuffered writes
 {
-  FILE * file_ = nullptr;
-  bool owned_ = false;
+  int fd_ = -1;
+  unsigned int write_count_ = 0;
+  void write_all( const void * data, size_t n )
+  {
+    const char * p = static_cast<const char *>( data );
+    while ( n ) {
+      const ssize_t w = ::write( fd_, p, n );
+      if ( w <= 0 ) throw std::runtime_error( "write: failed" );
+      p += w; n -= static_cast<size_t>( w ); write_count_++;
+    }
+  }
 public:
   FileDescriptor() = default;
-  explicit FileDescriptor( FILE * f ) : file_( f ), owned_( true ) { if ( !f ) throw std::runtime_error( "fopen: cannot open file" ); }
-  explicit FileDescriptor( const int fd ) : file_( fd == 1 ? stdout : fd == 2 ? stderr : fdopen( fd, "wb" ) ), owned_( fd > 2 ) { if ( !file_ ) throw std::runtime_error( "fdopen failed" ); }
-  FileDescriptor( FileDescriptor && o ) noexcept : file_( o.file_ ), owned_( o.owned_ ) { o.file_ = nullptr; o.owned_ = false; }
-  FileDescriptor & operator=( FileDescriptor && o ) noexcept { if ( this != &o ) { close(); file_ = o.file_; owned_ = o.owned_; o.file_ = nullptr; o.owned_ = false; } return *this; }
+  FileDescriptor( FILE * file ) : fd_( file ? ( std::fseek( file, 0, SEEK_SET ), ::dup( fileno( file ) ) ) : -1 )   // (the FILE keeps its own descriptor)
+  { if ( fd_ < 0 ) throw std::runtime_error( "fopen: cannot open file" ); }
+  FileDescriptor( const int s_fd ) : fd_( s_fd ) {}
+  FileDescriptor( FileDescriptor && o ) noexcept : fd_( o.fd_ ), write_count_( o.write_count_ ) { o.fd_ = -1; }
+  FileDescriptor & operator=( FileDescriptor && o ) noexcept { if ( this != &o ) { close(); fd_ = o.fd_; write_count_ = o.write_count_; o.fd_ = -1; } return *this; }
   FileDescriptor( const FileDescriptor & ) = delete;
   FileDescriptor & operator=( const FileDescriptor & ) = delete;
   ~FileDescriptor() { close(); }
-  void close() { if ( file_ && owned_ ) std::fclose( file_ ); file_ = nullptr; }
-  bool valid() const { return file_ != nullptr; }
-  long tell() const { return std::ftell( file_ ); }
-  void write( const std::string & s ) { if ( !s.empty() && std::fwrite( s.data(), s.size(), 1, file_ ) != 1 ) throw std::runtime_error( "fwrite returned short write" ); }
-  void write( const Chunk & c ) { if ( c.size() && std::fwrite( c.buffer(), c.size(), 1, file_ ) != 1 ) throw std::runtime_error( "fwrite returned short write" ); }
+  void close() { if ( fd_ > 2 ) (void) ::close( fd_ ); fd_ = -1; }
+  const int & fd_num() const { return fd_; }
+  bool valid() const { return fd_ >= 0; }
+  long tell() const { return static_cast<long>( ::lseek( fd_, 0, SEEK_CUR ) ); }
+  unsigned int write_count() const { return write_count_; }
+  void write( const std::string & s ) { if ( s.empty() ) throw std::runtime_error( "nothing to write" ); write_all( s.data(), s.size() ); }
+  void write( const Chunk & c ) { if ( c.size() ) write_all( c.buffer(), c.size() ); }
 };
 
 struct YUV4MPEGHeader      // yuv4mpeg.hh:40-65; header text yuv4mpeg.cc:85-128
@@ -553,4 +871,7 @@ using alfalfa_amd::Player; using alfalfa_amd::RasterHandle; using alfalfa_amd::R
 using alfalfa_amd::VP8Raster; using alfalfa_amd::print_exception;
 using alfalfa_amd::FileDescriptor; using alfalfa_amd::YUV4MPEGHeader; using alfalfa_amd::YUV4MPEGFrameWriter;
 using alfalfa_amd::EncoderStateSerializer; using alfalfa_amd::EncoderStateDeserializer;
+using alfalfa_amd::DecoderState; using alfalfa_amd::ProbabilityTables; using alfalfa_amd::Segmentation; using alfalfa_amd::FilterAdjustments;
+using alfalfa_amd::DecoderHash; using alfalfa_amd::make_optional;
+using alfalfa_amd::CURRENT_FRAME; using alfalfa_amd::LAST_FRAME; using alfalfa_amd::GOLDEN_FRAME; using alfalfa_amd::ALTREF_FRAME;
 #endif

@@ -1,0 +1,139 @@
+"""The drop-in boundary, tested with the reference's OWN callers: src/tests/decode-to-stdout.cc (its golden-test driver),
+frontend/vp8decode.cc and frontend/decode-bundle.cc are compiled UNMODIFIED -- read from /root/reference at build time,
+never copied -- against include/alfalfa_amd/compat/ (headers with the reference's names), -Wall -Wextra -Werror, and
+linked to the MI355X library.  Builds happen where the reference is (this container; __graft_entry__.build() too); the
+binaries travel to the GPU box under tests/cpp/_build/ like the other built artefacts."""
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, GOLDEN_DIR, ROOT
+from test_cpp_mirror import _write_ivf, y4m_payload
+
+REF = "/root/reference/src"
+BUILD = os.path.join(ROOT, "tests", "cpp", "_build", "ref_callers")
+CALLERS = {"decode-to-stdout": "tests/decode-to-stdout.cc", "vp8decode": "frontend/vp8decode.cc", "xc-decode-bundle": "frontend/decode-bundle.cc"}
+
+
+def build_callers():
+    """-> {name: path}.  Rebuilds where the reference sources are; otherwise uses what was built before."""
+    from alfalfa_amd import build as b
+    b.build()
+    os.makedirs(BUILD, exist_ok=True)
+    libdir = os.path.dirname(b.LIB)
+    out = {}
+    for name, rel in CALLERS.items():
+        exe, src = os.path.join(BUILD, name), os.path.join(REF, rel)
+        if os.path.exists(src):
+            hdr = os.path.join(ROOT, "include", "alfalfa_amd", "alfalfa.hh")
+            if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(hdr), os.path.getmtime(b.LIB)):
+                subprocess.run(["g++", "-std=c++14", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include", "alfalfa_amd", "compat"),
+                                src, "-o", exe, "-L" + libdir, "-lalfalfa_amd", "-Wl,-rpath," + libdir], check=True)
+        if os.path.exists(exe):
+            out[name] = exe
+    return out
+
+
+def build_state_check():
+    from test_cpp_mirror import build_exe
+    return build_exe(os.path.join(ROOT, "tests", "cpp", "decoder_state_check.cc"), "decoder_state_check")
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference sources are not on this box")
+def test_reference_callers_compile_unmodified_and_fail_loudly_without_gpu():
+    from alfalfa_amd import capi
+    exes = build_callers()
+    assert sorted(exes) == sorted(CALLERS)
+    build_state_check()
+    if capi.device_count() == 0:
+        r = subprocess.run([exes["decode-to-stdout"], os.path.join(GOLDEN_DIR, "qcif_q30.ivf")], capture_output=True)
+        assert r.returncode != 0 and b"no HIP device" in r.stderr and r.stdout == b""
+
+
+def _need(exes, name):
+    if name not in exes:
+        pytest.skip("%s was not built (build where /root/reference exists)" % name)
+    return exes[name]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_reference_decode_to_stdout_on_our_library(name):
+    """The reference's own golden test (src/tests/decoding.test: sha1sum of `decode-to-stdout FILE`), its own driver."""
+    exe = _need(build_callers(), "decode-to-stdout")
+    r = subprocess.run([exe, os.path.join(GOLDEN_DIR, name + ".ivf")], capture_output=True, check=True)
+    assert hashlib.sha1(r.stdout).hexdigest() == GOLDEN[name]["display_sha1"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["qcif_q30_lf24", "w200_q40_lf63s7", "synth_175x143_s3"])
+def test_reference_vp8decode_on_our_library(tmp_path, name):
+    exe = _need(build_callers(), "vp8decode")
+    out = tmp_path / "o.y4m"
+    subprocess.run([exe, "-o", str(out), os.path.join(GOLDEN_DIR, name + ".ivf")], check=True)
+    assert hashlib.sha1(y4m_payload(out.read_bytes(), name)).hexdigest() == GOLDEN[name]["display_sha1"]
+
+
+@pytest.mark.gpu
+def test_reference_vp8decode_resumes_from_a_state_file_written_by_the_reference(tmp_path):
+    from conftest import golden_frames
+    exe = _need(build_callers(), "vp8decode")
+    name, n = "qcif_q30_lf24", 3
+    _, _, frames = golden_frames(name)
+    cont, rest, whole = str(tmp_path / "cont.ivf"), str(tmp_path / "rest.y4m"), str(tmp_path / "whole.y4m")
+    _write_ivf(cont, name, frames[n:])
+    subprocess.run([exe, "-o", whole, os.path.join(GOLDEN_DIR, name + ".ivf")], check=True)
+    subprocess.run([exe, "-s", os.path.join(GOLDEN_DIR, "%s_f%d.state" % (name, n)), "-o", rest, cont], check=True)
+    full, tail = y4m_payload(open(whole, "rb").read(), name), y4m_payload(open(rest, "rb").read(), name)
+    frame = len(full) // sum(GOLDEN[name]["shown"])
+    assert tail == full[sum(GOLDEN[name]["shown"][:n]) * frame:]
+
+
+@pytest.mark.gpu
+def test_reference_decode_bundle_on_our_library_checks_minihash(tmp_path):
+    """xc-decode-bundle: pieces named on stdin, one video on stdout; every piece's IVF header carries the minihash the decoder
+    must be in when it starts (decode-bundle.cc:82-87) -- the reference's values, from tests/golden/hash_golden.json."""
+    import json
+    import struct
+    from conftest import golden_frames
+    exe = _need(build_callers(), "xc-decode-bundle")
+    hashes = json.load(open(os.path.join(GOLDEN_DIR, "hash_golden.json")))
+    name = "w200_q40_lf63s7"
+    _, _, frames = golden_frames(name)
+    cuts = [(0, 3), (3, 4), (4, len(frames))]
+    paths = []
+    for a, b in cuts:
+        p = str(tmp_path / ("piece_%d.ivf" % a))
+        _write_ivf(p, name, frames[a:b])
+        if a:                                    # expected entry state = the reference's minihash after frame a-1
+            data = bytearray(open(p, "rb").read())
+            struct.pack_into("<I", data, 28, hashes[name]["minihash"][a - 1])
+            open(p, "wb").write(data)
+        paths.append(p)
+    r = subprocess.run([exe], input=("\n".join(paths) + "\n").encode(), capture_output=True)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert hashlib.sha1(y4m_payload(r.stdout, name)).hexdigest() == GOLDEN[name]["display_sha1"]
+    # a wrong entry hash is refused
+    data = bytearray(open(paths[1], "rb").read())
+    struct.pack_into("<I", data, 28, hashes[name]["minihash"][cuts[1][0] - 1] ^ 0x10)
+    open(paths[1], "wb").write(data)
+    r = subprocess.run([exe], input=("\n".join(paths) + "\n").encode(), capture_output=True)
+    assert r.returncode != 0 and b"Hash mismatch" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["synth_96x80_s1", "synth_175x143_s3", "cif_q60_lf40s5"])
+def test_decoder_state_members_and_flat_memory(name):
+    """Decoder( DecoderState, References ), get_state(), ==, get_hash(), minihash(), wire-format round trips; then ~2000
+    frames through FilePlayer with every RasterHandle dying right away: HBM stays flat."""
+    import json
+    exe = build_state_check()
+    frames = GOLDEN[name]["frames"]
+    loops = 2000 // frames if name == "cif_q60_lf40s5" else 0
+    r = subprocess.run([exe, os.path.join(GOLDEN_DIR, name + ".ivf"), str(loops)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    hashes = json.load(open(os.path.join(GOLDEN_DIR, "hash_golden.json")))[name]
+    first = r.stdout.splitlines()[0].split()
+    assert int(first[1], 16) == hashes["minihash"][-1] and int(first[3], 16) == hashes["state"][-1]
