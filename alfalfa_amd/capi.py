@@ -77,7 +77,7 @@ SYMBOLS = [
     ("aa_stream_export_raster", C.c_int, [_P, C.c_int, _P, _P, _P]),
     ("aa_ctx_create", C.c_int, [C.c_int, C.POINTER(_P)]), ("aa_ctx_destroy", None, [_P]), ("aa_ctx_sync", C.c_int, [_P]),
     ("aa_ctx_memory", C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
-    ("aa_ctx_set_schedule", C.c_int, [_P, C.c_int]), ("aa_ctx_compute_stream", _P, [_P]), ("aa_ctx_copy_stream", _P, [_P]),
+    ("aa_ctx_set_schedule", C.c_int, [_P, C.c_int]), ("aa_ctx_clear_error", C.c_int, [_P]), ("aa_ctx_compute_stream", _P, [_P]), ("aa_ctx_copy_stream", _P, [_P]),
     ("aa_stream_create", C.c_int, [_P, C.c_uint16, C.c_uint16, C.POINTER(_P)]), ("aa_stream_destroy", None, [_P]),
     ("aa_stream_parse", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(FrameHeader)]),
     ("aa_stream_upload", C.c_int, [_P]), ("aa_stream_release_staging", C.c_int, [_P]),

@@ -717,7 +717,8 @@ __device__ __forceinline__ uint32_t bigpred_x4( const int mode, const uint32_t a
   return out;
 }
 
-__device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, const int group, const int row, const int mbh_max, aa_sync_ws * ws, Intra4Lds & L )
+__device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, const int group, const int row, const int mbh_max, aa_sync_ws * ws, Intra4Lds & L,
+                                                  const int home_xcc )
 {
   const int lane = threadIdx.x, slot = lane >> 4, l = lane & 15;
   Intra4Slot & S = L.slot[slot];
@@ -769,7 +770,11 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
         __builtin_amdgcn_s_sleep( 4 );
         if ( on && seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
         ++spins;
-        if ( ( spins & 1023 ) == 0 && __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
+        if ( ( spins & 1023 ) == 0 ) {
+          if ( __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
+          // the hand-off is only coherent inside the XCD the ticket was taken on: a wave that finds itself elsewhere says so
+          if ( xcc_id() != home_xcc ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 4 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( home_xcc << 16 ) | xcc_id(); } break; }
+        }
         if ( spins > ( 1 << 21 ) ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 1 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( need << 16 ) | ( seen & 0xFFFF ); } break; }
       }
     }
@@ -885,7 +890,7 @@ __global__ __launch_bounds__( kLanes ) void k_recon_intra4( const aa_frame_list 
     const int t = take_ticket( ws, xcc, &s_ticket, threadIdx.x );
     const int mine = xcc < n_groups ? ( n_groups - xcc + n_xcd - 1 ) / n_xcd : 0;     // groups of this XCD: xcc, xcc + n_xcd, ...
     if ( t >= mine * mbh_max ) return;
-    recon_intra4_row( list, ( t % mine ) * n_xcd + xcc, t / mine, mbh_max, ws, L );    // ROW-major: see take_ticket
+    recon_intra4_row( list, ( t % mine ) * n_xcd + xcc, t / mine, mbh_max, ws, L, xcc );    // ROW-major: see take_ticket
   }
 }
 
@@ -1439,6 +1444,18 @@ __global__ void k_probe_xcds( int * out )
   if ( threadIdx.x == 0 ) atomicAdd( &out[xcc_id() & 15], 1 );
 }
 
+// After a row-pipelined launch: every queue must have handed out all of its rows.  A queue whose XCD received no workgroup
+// (placement is not promised by HIP) would otherwise leave its units silently unprocessed.
+__global__ void k_check_tickets( aa_sync_ws * ws, const int n_groups, const int mbh_max, const int n_xcd )
+{
+  if ( threadIdx.x != 0 || blockIdx.x != 0 ) return;
+  for ( int x = 0; x < n_xcd; x++ ) {
+    const int mine = x < n_groups ? ( n_groups - x + n_xcd - 1 ) / n_xcd : 0;
+    const int t = __hip_atomic_load( &ws->ticket[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    if ( t < mine * mbh_max && atomicCAS( &ws->error, 0, 5 ) == 0 ) { ws->where[0] = x; ws->where[1] = t; ws->where[2] = mine * mbh_max; }
+  }
+}
+
 // Raster planes of n frame jobs, decided on the host when the frames are handed to reconstruction: out, last, golden, altref.
 __global__ void k_bind_rasters( const aa_raster_binding * b, int n )
 {
@@ -1497,11 +1514,13 @@ static unsigned test_lds_pad()
 int launch_loopfilter_rows4( const aa_frame_list & list, int n_groups, int mbh_max, int mbw_max, aa_sync_ws * ws, uint8_t * boundary, int n_xcd, void * stream )
 {
   hipLaunchKernelGGL( k_loopfilter_rows4, dim3( n_xcd * ( ( n_groups + n_xcd - 1 ) / n_xcd ) * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n_groups, mbh_max, mbw_max, ws, boundary, n_xcd, lf_debug_bits() );
+  hipLaunchKernelGGL( k_check_tickets, dim3( 1 ), dim3( 64 ), 0, static_cast<hipStream_t>( stream ), ws, n_groups, mbh_max, n_xcd );
   return static_cast<int>( hipGetLastError() );
 }
 int launch_recon_intra4( const aa_frame_list & list, int n_groups, int mbh_max, aa_sync_ws * ws, int n_xcd, void * stream )
 {
   hipLaunchKernelGGL( k_recon_intra4, dim3( n_xcd * ( ( n_groups + n_xcd - 1 ) / n_xcd ) * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n_groups, mbh_max, ws, n_xcd );
+  hipLaunchKernelGGL( k_check_tickets, dim3( 1 ), dim3( 64 ), 0, static_cast<hipStream_t>( stream ), ws, n_groups, mbh_max, n_xcd );
   return static_cast<int>( hipGetLastError() );
 }
 int launch_probe_xcds( int * out16, int blocks, void * stream )

@@ -630,6 +630,9 @@ aa_status aa_ctx_create( int device, aa_ctx ** out )
     if ( n_xcd == 0 ) return fail( AA_ERR_HIP, "XCD probe kernel did not run" );
     for ( int x = 0; x < n_xcd; x++ ) ctx->xcd_share[x] = h[x];
     ctx->n_xcd = n_xcd;
+    // The row-pipelined schedule wants every XCD to get its share of a launch's workgroups (the observed round-robin).  If this
+    // device spreads them unevenly (CU masks, partition modes), fall back to the schedule whose ordering is kernel boundaries.
+    for ( int x = 0; x < n_xcd; x++ ) if ( h[x] * n_xcd * 2 < 2048 ) ctx->schedule = 1;
   }
   *out = ctx.release();
   return AA_OK;
@@ -664,6 +667,12 @@ static aa_status check_watchdog( aa_ctx * ctx )
   int err = 0;
   HIP_TRY( hipMemcpy( &err, &ctx->ws->error, sizeof err, hipMemcpyDeviceToHost ) );
   if ( err == 3 ) return fail( AA_ERR_HIP, "row-pipelined kernel: a workgroup ran on an XCD outside the probed set (output is not valid)" );
+  if ( err == 5 ) {
+    int hdr[4] = {};
+    (void) hipMemcpy( hdr, ctx->ws, sizeof hdr, hipMemcpyDeviceToHost );
+    return fail( AA_ERR_HIP, "row-pipelined kernel: XCD " + std::to_string( hdr[1] ) + " handed out " + std::to_string( hdr[2] ) + " of its " + std::to_string( hdr[3] )
+                               + " macroblock rows: no workgroup of the launch ran there (output is not valid); use the diagonal schedule on this device" );
+  }
   if ( err == 4 ) {
     int hdr[4] = {};
     (void) hipMemcpy( hdr, ctx->ws, sizeof hdr, hipMemcpyDeviceToHost );
@@ -700,6 +709,16 @@ aa_status aa_ctx_memory( aa_ctx * ctx, size_t * free_bytes, size_t * total_bytes
   HIP_TRY( hipMemGetInfo( &f, &t ) );
   if ( free_bytes ) *free_bytes = f;
   if ( total_bytes ) *total_bytes = t;
+  return AA_OK;
+}
+/* The sticky error word of the row-pipelined kernels (a bounded wait expired, a wave found itself on another XCD, a queue
+ * was not drained) makes every later row-pipelined launch give up early.  Once it has been reported, this clears it. */
+aa_status aa_ctx_clear_error( aa_ctx * ctx )
+{
+  if ( !ctx ) return fail( AA_ERR_ARGUMENT, "null ctx" );
+  if ( aa_status st = set_device( ctx ) ) return st;
+  HIP_TRY( hipStreamSynchronize( ctx->compute ) );
+  if ( ctx->ws ) HIP_TRY( hipMemset( ctx->ws, 0, AA_SYNC_WS_ZERO_FROM ) );
   return AA_OK;
 }
 aa_status aa_ctx_set_schedule( aa_ctx * ctx, int schedule )

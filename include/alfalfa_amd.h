@@ -148,6 +148,10 @@ aa_status aa_ctx_memory( aa_ctx * ctx, size_t * free_bytes, size_t * total_bytes
 #define AA_SCHEDULE_ROWS 0
 #define AA_SCHEDULE_DIAGONAL 1
 aa_status aa_ctx_set_schedule( aa_ctx * ctx, int schedule );
+/* The row-pipelined kernels keep a sticky error word (a bounded in-launch wait expired, a wave migrated between XCDs, a
+ * ticket queue was not drained): once set, aa_ctx_sync / downloads report AA_ERR_HIP and later launches give up early.
+ * After the caller has dealt with it (e.g. switched to AA_SCHEDULE_DIAGONAL), this clears the word. */
+aa_status aa_ctx_clear_error( aa_ctx * ctx );
 /* hipStream_t handles as opaque pointers (to order foreign work, e.g. an RCCL broadcast, against ours) */
 void * aa_ctx_compute_stream( aa_ctx * ctx );
 void * aa_ctx_copy_stream( aa_ctx * ctx );
