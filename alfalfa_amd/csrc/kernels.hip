@@ -136,10 +136,10 @@ struct alignas( 16 ) InterLds {     // ~5 KB: 32 single-wave workgroups fit one 
   ResidualLds r;
   alignas( 16 ) uint8_t pred[384];   // Y 16x16 | U 8x8 | V 8x8, each row-major
   union {
-    struct {                         // SPLITMV: 24 units of 4x4, byte-at-a-time
-      uint8_t win[24 * 81];          // 9x9 reference windows
-      uint8_t im[24 * 36];           // first-pass output
-      int16_t unit[24][4];           // per unit {sx-2, sy-2, mx, my}
+    struct {                         // SPLITMV: 24 units of 4x4 with their own vectors
+      uint32_t sw[24][9][3];         // 9-row reference windows: 12 bytes per row (aligned dwords; the window starts at byte sx & 3)
+      uint32_t st[24][4][3];         // first-pass output TRANSPOSED: per unit and column, 9 rows in 12 bytes
+      int16_t unit[24][6];           // per unit {sx-2, sy-2, mx, my, byte offset of the window in its row, inside the plane}
     };
     struct {                         // whole-MB vector: reference windows as dword rows, first-pass output stored
       uint32_t wy[21][6], wc[2][13][4];   // TRANSPOSED (column-major) so that the vertical pass also reads 12
@@ -241,8 +241,9 @@ __device__ __forceinline__ void recon_inter_body( const aa_dev_frame & f, const 
     }
     __syncthreads();
   } else {
-    // 16 luma + 4+4 chroma 4x4 units, each with its own vector; all units go through both filter passes
-    // (fraction 0 = identity taps, bit-identical to a copy).
+    // 16 luma + 4+4 chroma 4x4 units, each with its own vector (macroblock.cc:553-601, prediction.cc:813-971); all units go
+    // through both filter passes (fraction 0 = a copy).  Same packed arithmetic as the whole-vector path: a task makes 4
+    // outputs from 12 source bytes (sixtap_x4), 9 first-pass tasks and 4 second-pass tasks per unit.
     if ( lane < 24 ) {
       int mvx, mvy, x0, y0;
       if ( lane < 16 ) {
@@ -254,32 +255,48 @@ __device__ __forceinline__ void recon_inter_body( const aa_dev_frame & f, const 
         mvy = chroma_mv( mb.u.mv[i0][1] + mb.u.mv[i0 + 1][1] + mb.u.mv[i0 + 4][1] + mb.u.mv[i0 + 5][1] );
         x0 = col * 8 + ( b & 1 ) * 4; y0 = row * 8 + ( b >> 1 ) * 4;
       }
-      L.unit[lane][0] = static_cast<int16_t>( x0 + ( mvx >> 3 ) - 2 ); L.unit[lane][1] = static_cast<int16_t>( y0 + ( mvy >> 3 ) - 2 );
+      const int sx = x0 + ( mvx >> 3 ) - 2, sy = y0 + ( mvy >> 3 ) - 2;
+      const int w = lane < 16 ? pw : cw, h = lane < 16 ? ph : ch;
+      const bool in = sx >= 0 && sy >= 0 && ( sx & ~3 ) + 12 <= w && sy + 9 <= h;
+      L.unit[lane][0] = static_cast<int16_t>( sx ); L.unit[lane][1] = static_cast<int16_t>( sy );
       L.unit[lane][2] = static_cast<int16_t>( mvx & 7 ); L.unit[lane][3] = static_cast<int16_t>( mvy & 7 );
+      L.unit[lane][4] = static_cast<int16_t>( in ? ( sx & 3 ) : 0 ); L.unit[lane][5] = in;
     }
     __syncthreads();
-    for ( int i = lane; i < 24 * 81; i += kLanes ) {
-      const int u = i / 81, e = i % 81, r = e / 9, c = e % 9;
+    for ( int i = lane; i < 24 * 27; i += kLanes ) {          // window rows as aligned dwords (coordinate clamping outside the plane)
+      const int u = i / 27, e = i % 27, r = e / 3, d = e % 3;
       const uint8_t * plane = u < 16 ? ref[0] : ( u < 20 ? ref[1] : ref[2] );
       const int w = u < 16 ? pw : cw, h = u < 16 ? ph : ch;
-      L.win[i] = plane[static_cast<size_t>( clampi( L.unit[u][1] + r, 0, h - 1 ) ) * w + clampi( L.unit[u][0] + c, 0, w - 1 )];
+      const int sx = L.unit[u][0], sy = L.unit[u][1];
+      uint32_t v;
+      if ( L.unit[u][5] ) v = *reinterpret_cast<const uint32_t *>( plane + static_cast<size_t>( sy + r ) * w + ( sx & ~3 ) + d * 4 );
+      else {
+        const uint8_t * line = plane + static_cast<size_t>( clampi( sy + r, 0, h - 1 ) ) * w;
+        v = 0;
+        for ( int k = 0; k < 4; k++ ) v |= static_cast<uint32_t>( line[clampi( sx + d * 4 + k, 0, w - 1 )] ) << ( 8 * k );
+      }
+      L.sw[u][r][d] = v;
     }
     __syncthreads();
-    for ( int i = lane; i < 24 * 36; i += kLanes ) {
-      const int u = i / 36, e = i % 36, r = e >> 2, c = e & 3;
-      int t[6]; load_taps( L.unit[u][2], t );
-      const uint8_t * p = L.win + u * 81 + r * 9 + c;
-      L.im[i] = static_cast<uint8_t>( sixtap( p[0], p[1], p[2], p[3], p[4], p[5], t[0], t[1], t[2], t[3], t[4], t[5] ) );
+    for ( int t = lane; t < 24 * 9; t += kLanes ) {           // first pass: unit u, row r -> 4 bytes, stored transposed
+      const int u = t / 9, r = t % 9, fx = L.unit[u][2];
+      uint32_t t0, t1;
+      pack_taps( fx, t0, t1 );
+      const uint32_t o4 = sixtap_x4( L.sw[u][r][0], L.sw[u][r][1], L.sw[u][r][2], L.unit[u][4], fx, t0, t1 );
+      uint8_t * tb = reinterpret_cast<uint8_t *>( &L.st[u][0][0] ) + r;
+      tb[0] = static_cast<uint8_t>( o4 ); tb[12] = static_cast<uint8_t>( o4 >> 8 ); tb[24] = static_cast<uint8_t>( o4 >> 16 ); tb[36] = static_cast<uint8_t>( o4 >> 24 );
     }
     __syncthreads();
-    for ( int i = lane; i < 24 * 16; i += kLanes ) {
-      const int u = i >> 4, e = i & 15, r = e >> 2, c = e & 3;
-      int t[6]; load_taps( L.unit[u][3], t );
-      const uint8_t * p = L.im + u * 36 + r * 4 + c;
-      const int v = sixtap( p[0], p[4], p[8], p[12], p[16], p[20], t[0], t[1], t[2], t[3], t[4], t[5] );
-      // scatter into the MB-shaped prediction buffer
-      if ( u < 16 ) L.pred[( ( u >> 2 ) * 4 + r ) * 16 + ( u & 3 ) * 4 + c] = static_cast<uint8_t>( v );
-      else { const int b = ( u - 16 ) & 3; L.pred[256 + ( u >= 20 ? 64 : 0 ) + ( ( b >> 1 ) * 4 + r ) * 8 + ( b & 1 ) * 4 + c] = static_cast<uint8_t>( v ); }
+    for ( int t = lane; t < 24 * 4; t += kLanes ) {           // second pass: unit u, column c -> rows 0..3
+      const int u = t >> 2, c = t & 3, fy = L.unit[u][3];
+      uint32_t t0, t1;
+      pack_taps( fy, t0, t1 );
+      const uint32_t o4 = sixtap_x4( L.st[u][c][0], L.st[u][c][1], L.st[u][c][2], 0, fy, t0, t1 );
+      uint8_t * pb;
+      int stride;
+      if ( u < 16 ) { pb = L.pred + ( ( u >> 2 ) * 4 ) * 16 + ( u & 3 ) * 4 + c; stride = 16; }
+      else { const int b = ( u - 16 ) & 3; pb = L.pred + 256 + ( u >= 20 ? 64 : 0 ) + ( ( b >> 1 ) * 4 ) * 8 + ( b & 1 ) * 4 + c; stride = 8; }
+      pb[0] = static_cast<uint8_t>( o4 ); pb[stride] = static_cast<uint8_t>( o4 >> 8 ); pb[2 * stride] = static_cast<uint8_t>( o4 >> 16 ); pb[3 * stride] = static_cast<uint8_t>( o4 >> 24 );
     }
     __syncthreads();
   }

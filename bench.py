@@ -95,7 +95,8 @@ def main():
     threads = args.threads or max(1, (os.cpu_count() or 1) // max(1, local_world))
     # stream ids are disjoint across ranks; their CONTENT is drawn from a pool of 120 synthetic videos so that the one-off
     # generation cost (reference encoder, cached on disk) stays bounded on an 8-GPU node
-    seeds = [100 + (g - 100) % 120 for g in sharding.stream_ids(rank, world, S)]
+    pool = 24 if workload.CONFIGS[args.config][2] == "synth" else 120     # (the pure-Python stream writer is slow)
+    seeds = [100 + (g - 100) % pool for g in sharding.stream_ids(rank, world, S)]
     t0 = time.time()
     paths = workload.make_streams(args.config, F, seeds)
     t_gen = time.time() - t0

@@ -87,3 +87,19 @@ def test_720p_configs_every_frame(gpu_ctx, config, frames):
             gpu_ctx.decode_batch([dec], [idx[i]])
             ora.decode(f)
             assert dec.raster_bytes(idx[i]) == ora.raster_bytes(), (config, seed, i)
+
+
+def test_realistic_inter_workload_streams(gpu_ctx):
+    """The "realistic inter" workload of bench.py --config 1080p_inter_lf_subpel (quarter-pel vectors, ~15 % SPLITMV, golden /
+    altref, four partitions) at CIF size, every frame, both parse paths, against the oracle."""
+    import workload
+    for seed in (100, 101, 102, 103):
+        w, h, fr = aa.read_ivf(workload.make_stream("cif_inter_lf_subpel", 8, seed))
+        ora, a, b = vo.OracleDecoder(w, h), aa.Decoder(gpu_ctx, w, h), aa.Decoder(gpu_ctx, w, h)
+        idx = gpu_ctx.submit_frames([(a, f) for f in fr])
+        for i, f in enumerate(fr):
+            gpu_ctx.decode_batch([a], [idx[i]])
+            _, fi = b.get_frame_output(f)
+            ora.decode(f)
+            assert a.raster_bytes(idx[i]) == ora.raster_bytes(), (seed, i, "GPU parser")
+            assert b.raster_bytes(fi) == ora.raster_bytes(), (seed, i, "host parser")

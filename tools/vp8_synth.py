@@ -538,6 +538,25 @@ def feature_stream(width, height, seed, nframes=8):
     return s
 
 
+def perf_stream(width, height, seed, nframes=12):
+    """The benchmark's "realistic inter" workload (bench.py --config 1080p_inter_lf_subpel): 1 key + nframes-1 inter frames,
+    high entropy, loop filter 24, four DCT partitions; inter macroblocks ~97 %, of which ~15 % SPLITMV, ~45 % NEWMV with
+    quarter-pel vectors (7 of 8 have a fractional part), the rest NEAREST / NEAR / ZERO; LAST / GOLDEN / ALTREF all in use,
+    golden and altref refreshed now and then.  The reference encoder emits none of this (full-pel vectors, LAST only, no
+    SPLITMV, one partition: SURVEY.md 8c)."""
+    s = SynthStream(width, height, seed)
+    rng = random.Random(seed * 104729 + 7)
+    s.frame(key=True, lf_level=24, sharpness=0, q_index=20, log2_parts=2, skip_prob=40, density=0.5, intra_bpred=0.5)
+    modes = [NEARESTMV] * 4 + [NEARMV] * 2 + [ZEROMV] * 2 + [NEWMV] * 9 + [SPLITMV] * 3
+    for i in range(1, nframes):
+        s.frame(key=False, show=True, lf_level=24, sharpness=0, q_index=20, log2_parts=2, skip_prob=60, density=0.45,
+                prob_inter=248, prob_last=150, prob_golden=128, inter_modes=modes, intra_bpred=0.3, mv_range=24,
+                refresh_golden=i % 5 == 0, refresh_alt=i % 7 == 0, copy_golden=0, copy_alt=0,
+                sign_bias_golden=False, sign_bias_alt=i % 2 == 0, refresh_last=True, mv_prob_updates=2 if i == 1 else 0,
+                refresh_entropy=True, coeff_updates=4 if i == 1 else 0)
+    return s
+
+
 if __name__ == "__main__":
     import argparse
     from ivf_io import write_ivf

@@ -22,6 +22,10 @@ CONFIGS = {
     "720p_inter": (1280, 720, "low", 30, 24, 0),
     "1080p_inter_lf": (1920, 1080, "high", 20, 24, 0),
     "1080p_inter_lf_lowentropy": (1920, 1080, "low", 40, 24, 0),
+    # not from the reference encoder (which only emits full-pel LAST-reference vectors): tools/vp8_synth.perf_stream --
+    # quarter-pel vectors, ~15 % SPLITMV, golden / altref, four partitions
+    "1080p_inter_lf_subpel": (1920, 1080, "synth", 20, 24, 0),
+    "cif_inter_lf_subpel": (352, 288, "synth", 20, 24, 0),
     "cif_inter_lf": (352, 288, "high", 20, 24, 0),          # small stand-in for quick checks
     "1440p_inter_lf": (2560, 1440, "high", 20, 24, 0),      # bigger than any bench config: parity test only
     # geometry probes for tools/row_kernel_probe.py: one MB row (no cross-row waits) / one MB column (pure hand-off chain)
@@ -73,6 +77,12 @@ def _generate(config, frames, seed, path, lock):
     w, h, ent, qi, lf, sharp = CONFIGS[config]
     if os.path.exists(path):
         return path
+    if ent == "synth":                                       # our own bitstream writer, no encoder involved
+        import vp8_synth
+        st = vp8_synth.perf_stream(w, h, seed, frames)
+        write_ivf(path + ".tmp", w, h, st.frames)
+        os.replace(path + ".tmp", path)
+        return path
     if not have_reference_tools():
         raise RuntimeError("oracle/_ref/xc-enc is missing: build it with `make -C oracle ref` where /root/reference exists")
     with tempfile.TemporaryDirectory() as td:
@@ -100,6 +110,19 @@ def _generate(config, frames, seed, path, lock):
 
 def make_streams(config, frames, seeds, workers=None):
     workers = workers or min(len(seeds), os.cpu_count() or 1, 64)
+    if CONFIGS[config][2] == "synth":       # pure-Python writer: processes, not threads; distinct seeds once each
+        todo = sorted({s for s in seeds if not os.path.exists(os.path.join(cache_dir(), "%s_f%d_s%d.ivf" % (config, frames, s)))})
+        if todo:
+            procs = []
+            for s in todo:
+                procs.append(subprocess.Popen([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import workload; workload.make_stream(%r, %d, %d)"
+                                               % (os.path.join(ROOT, "tools"), config, frames, s)]))
+                while sum(p.poll() is None for p in procs) >= workers:
+                    import time
+                    time.sleep(0.05)
+            for p in procs:
+                if p.wait():
+                    raise RuntimeError("stream generation failed")
     with ThreadPoolExecutor(max_workers=workers) as ex:
         return list(ex.map(lambda s: make_stream(config, frames, s), seeds))
 
