@@ -47,7 +47,7 @@ class KernelStats(C.Structure):
                 ("recon_inter_launches", C.c_uint64), ("recon_intra_launches", C.c_uint64),
                 ("loopfilter_launches", C.c_uint64), ("macroblocks", C.c_uint64),
                 ("parse_headers_ms", C.c_double), ("parse_tokens_ms", C.c_double), ("parse_launches", C.c_uint64),
-                ("parsed_macroblocks", C.c_uint64)]
+                ("parsed_macroblocks", C.c_uint64), ("recon_split_ms", C.c_double), ("recon_split_launches", C.c_uint64)]
 
 
 class AlfalfaError(RuntimeError):
@@ -89,6 +89,8 @@ SYMBOLS = [
     ("aa_stream_frame_count", C.c_int, [_P]), ("aa_stream_release_before", C.c_int, [_P, C.c_int]),
     ("aa_stream_rewind", C.c_int, [_P]), ("aa_stream_rewind_to", C.c_int, [_P, C.c_int]),
     ("aa_stream_download", C.c_int, [_P, C.c_int, _P, _P, _P]),
+    ("aa_pinned_alloc", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]), ("aa_pinned_free", None, [_P]),
+    ("aa_stream_download_async", C.c_int, [_P, C.c_int, _P, _P, _P]), ("aa_stream_download_wait", C.c_int, [_P]),
     ("aa_stream_raster_device", C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     ("aa_stream_references", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("aa_stream_reference_slots", C.c_int, [_P, C.POINTER(C.c_int)]),

@@ -304,7 +304,8 @@ void drain_profile( aa_ctx * ctx )
       else if ( t.kind == 1 ) { ctx->stats.recon_intra_ms += ms; ctx->stats.recon_intra_launches++; }
       else if ( t.kind == 2 ) { ctx->stats.loopfilter_ms += ms; ctx->stats.loopfilter_launches++; }
       else if ( t.kind == 3 ) { ctx->stats.parse_headers_ms += ms; ctx->stats.parse_launches++; }
-      else ctx->stats.parse_tokens_ms += ms;
+      else if ( t.kind == 4 ) ctx->stats.parse_tokens_ms += ms;
+      else { ctx->stats.recon_split_ms += ms; ctx->stats.recon_split_launches++; }
     }
     ctx->free_events.push_back( t.a ); ctx->free_events.push_back( t.b );
   }
@@ -1186,7 +1187,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
     if ( aa_status st = check( e, "k_recon_inter4" ) ) return st;
     if ( any_split ) {
       e = for_each_list( inter_jobs, [&]( const aa_frame_list & l, int cnt ) {
-        LaunchTimer t( ctx, 0 ); return aa::launch_recon_inter( l, cnt, max_mbs, true, ctx->compute ); } );
+        LaunchTimer t( ctx, 5 ); return aa::launch_recon_inter( l, cnt, max_mbs, true, ctx->compute ); } );
       if ( aa_status st = check( e, "k_recon_inter" ) ) return st;
     }
   }
@@ -1330,6 +1331,42 @@ aa_status aa_stream_download( aa_stream * s, int fi, uint8_t * y, uint8_t * u, u
   uint8_t * dst[3] = { y, u, v };
   for ( int p = 0; p < 3; p++ ) if ( dst[p] ) HIP_TRY( hipMemcpy( dst[p], slot_plane( s, r.out_slot, p ), s->plane_bytes[p], hipMemcpyDeviceToHost ) );
   return AA_OK;
+}
+
+/* Pinned host memory for asynchronous downloads (hipHostMalloc) */
+aa_status aa_pinned_alloc( aa_ctx * ctx, size_t bytes, void ** out )
+{
+  if ( !ctx || !out || !bytes ) return fail( AA_ERR_ARGUMENT, "aa_pinned_alloc: bad argument" );
+  if ( aa_status st = set_device( ctx ) ) return st;
+  HIP_TRY( hipHostMalloc( out, bytes, hipHostMallocDefault ) );
+  return AA_OK;
+}
+void aa_pinned_free( void * p ) { if ( p ) (void) hipHostFree( p ); }
+
+/* Shown frames on their way out without stalling the decoder: the copy is queued on the COPY stream behind everything the
+ * compute stream holds now; the planes (pinned memory) are valid after aa_ctx_sync or aa_stream_download_wait. */
+aa_status aa_stream_download_async( aa_stream * s, int fi, uint8_t * y, uint8_t * u, uint8_t * v )
+{
+  if ( !s || fi < 0 || fi >= static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_ARGUMENT, "aa_stream_download_async: bad frame index" );
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  const FrameRec & r = s->frames[fi];
+  if ( !r.handle_held ) return fail( AA_ERR_LOGIC, "aa_stream_download_async: frame was released" );
+  if ( fi >= s->next_submit || !r.placed ) return fail( AA_ERR_LOGIC, "aa_stream_download_async: frame not decoded yet" );
+  aa_ctx * ctx = s->ctx;
+  hipEvent_t e = get_event( ctx );
+  HIP_TRY( hipEventRecord( e, ctx->compute ) );
+  HIP_TRY( hipStreamWaitEvent( ctx->copy, e, 0 ) );
+  ctx->free_events.push_back( e );
+  uint8_t * dst[3] = { y, u, v };
+  for ( int p = 0; p < 3; p++ ) if ( dst[p] ) HIP_TRY( hipMemcpyAsync( dst[p], slot_plane( s, r.out_slot, p ), s->plane_bytes[p], hipMemcpyDeviceToHost, ctx->copy ) );
+  return AA_OK;
+}
+aa_status aa_stream_download_wait( aa_stream * s )
+{
+  if ( !s ) return fail( AA_ERR_ARGUMENT, "null stream" );
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  HIP_TRY( hipStreamSynchronize( s->ctx->copy ) );
+  return check_watchdog( s->ctx );
 }
 
 aa_status aa_stream_raster_device( aa_stream * s, int fi, void ** y, void ** u, void ** v )

@@ -38,10 +38,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 # algorithmic bytes per macroblock, SURVEY.md 8(d): descriptor 80 + dense coefficients 800 + reference read 384
 # + reconstruction write 384 (k_recon_inter) ; loop filter read+write 768 (k_loopfilter); the entropy decode reads the
 # compressed macroblock and writes the descriptor + dense coefficients that the survey's model has the reconstruction read
-BYTES_PER_MB = {"recon_inter": 80 + 800 + 384 + 384, "recon_intra": 80 + 800 + 384, "loopfilter": 768, "parse_tokens": 80 + 800,
-                "parse_headers": 80}
+BYTES_PER_MB = {"recon_inter": 80 + 800 + 384 + 384, "recon_split": 80 + 800 + 384 + 384, "recon_intra": 80 + 800 + 384, "loopfilter": 768,
+                "parse_tokens": 80 + 800, "parse_headers": 80}
 PATH_BYTES_PER_MB = 2416       # inter + deblock, whole path
-KERNEL_NAMES = {"recon_inter": "k_recon_inter4", "recon_intra": "k_recon_intra4", "loopfilter": "k_loopfilter_rows4",
+KERNEL_NAMES = {"recon_inter": "k_recon_inter4", "recon_split": "k_recon_inter", "recon_intra": "k_recon_intra4", "loopfilter": "k_loopfilter_rows4",
                 "parse_tokens": "k_parse_tokens", "parse_headers": "k_parse_mb_headers"}
 
 
@@ -235,10 +235,20 @@ def main():
     kstats = ctx.kernel_stats(reset=True); ctx.profile(False)
     verify_decs, verify_base = pipe.sets[g % pipe.R], (g // pipe.R) * F
 
-    launches_per_step = {"recon_inter": max(1, kstats["recon_inter_launches"]), "recon_intra": max(1, kstats["recon_intra_launches"]),
+    # macroblocks of the profiled step by kind (the records are in HBM: ask them)
+    split_mbs = whole_mbs = intra_mbs = 0
+    for i in sorted({sd: k for k, sd in enumerate(seeds)}.values()):        # one decoder per distinct stream, scaled up
+        mult = seeds.count(seeds[i])
+        for f in range(F):
+            _, mb, _ = verify_decs[i].read_records(verify_base + f)
+            inter = (mb["flags"] & 4) != 0
+            sp = int((inter & (mb["y_mode"] == 9)).sum())
+            split_mbs += mult * sp; whole_mbs += mult * (int(inter.sum()) - sp); intra_mbs += mult * int((~inter).sum())
+    launches_per_step = {"recon_inter": max(1, kstats["recon_inter_launches"]), "recon_split": max(1, kstats["recon_split_launches"]),
+                         "recon_intra": max(1, kstats["recon_intra_launches"]),
                          "loopfilter": max(1, kstats["loopfilter_launches"]), "parse_tokens": max(1, kstats["parse_launches"]),
                          "parse_headers": max(1, kstats["parse_launches"])}
-    units = {"recon_inter": S * (F - 1) * mbs_per_frame if not args.config.endswith("_intra") else 0, "recon_intra": S * F * mbs_per_frame,
+    units = {"recon_inter": whole_mbs, "recon_split": split_mbs, "recon_intra": intra_mbs,
              "loopfilter": S * F * mbs_per_frame, "parse_tokens": S * F * mbs_per_frame, "parse_headers": S * F * mbs_per_frame}
     traffic = pmc_traffic(args.config) or {}
 

@@ -211,6 +211,13 @@ aa_status aa_stream_rewind_to( aa_stream * s, int frame_index );
 /* Output raster of a decoded frame (VP8Raster: three padded planes, stride = padded width, raster.hh:54-56).
  * Synchronises with the compute stream, then D2H.  Any pointer may be NULL. */
 aa_status aa_stream_download( aa_stream * s, int frame_index, uint8_t * y, uint8_t * u, uint8_t * v );
+/* The same without stalling the decoder (what a player that shows frames while decoding the next ones wants, player.cc:134-144):
+ * the copy is queued on the context's COPY stream behind the work the compute stream holds at the time of the call and the
+ * call returns; the planes -- pinned memory, aa_pinned_alloc -- are valid after aa_stream_download_wait (or aa_ctx_sync). */
+aa_status aa_pinned_alloc( aa_ctx * ctx, size_t bytes, void ** out );
+void aa_pinned_free( void * p );
+aa_status aa_stream_download_async( aa_stream * s, int frame_index, uint8_t * y, uint8_t * u, uint8_t * v );
+aa_status aa_stream_download_wait( aa_stream * s );
 /* Device pointers of a frame's planes (valid while the frame's raster is alive). */
 aa_status aa_stream_raster_device( aa_stream * s, int frame_index, void ** y, void ** u, void ** v );
 /* References::last/golden/alternative after the most recently SUBMITTED frame: frame indices (-1 = initial blank). */
@@ -273,6 +280,8 @@ typedef struct aa_kernel_stats {
   double parse_headers_ms, parse_tokens_ms;                  /* device-side entropy decode: k_parse_mb_headers, k_parse_tokens */
   uint64_t parse_launches;                                   /* aa_submit_frames calls timed */
   uint64_t parsed_macroblocks;                               /* MBs handed to the device parser */
+  double recon_split_ms;                                     /* k_recon_inter on SPLITMV macroblocks (recon_inter_ms: k_recon_inter4 only) */
+  uint64_t recon_split_launches;
 } aa_kernel_stats;
 aa_status aa_ctx_profile( aa_ctx * ctx, int enable );
 aa_status aa_ctx_kernel_stats( aa_ctx * ctx, aa_kernel_stats * out, int reset );

@@ -793,6 +793,29 @@ public:
 
 using Player = FilePlayer;
 
+// ---------------------------------------------------------------- input/frame_input.hh, input/ivf_reader.{hh,cc}
+class FrameInput
+{
+public:
+  virtual Optional<RasterHandle> get_next_frame() = 0;
+  virtual uint16_t display_width() = 0;
+  virtual uint16_t display_height() = 0;
+  virtual ~FrameInput() = default;
+};
+class IVFReader : public FrameInput       // ivf_reader.cc:36-46: the shown frames of a file, one after the other
+{
+  FilePlayer player_;
+public:
+  explicit IVFReader( const std::string & filename ) : player_( filename ) {}
+  Optional<RasterHandle> get_next_frame() override
+  {
+    if ( player_.eof() ) return Optional<RasterHandle>();
+    return Optional<RasterHandle>( true, player_.advance() );
+  }
+  uint16_t display_width() override { return player_.width(); }
+  uint16_t display_height() override { return player_.height(); }
+};
+
 inline std::ostream & operator<<( std::ostream & out, const FramePlayer & player ) { return out << player.current_decoder().get_hash().str(); }   // player.cc:75-78
 
 // ---------------------------------------------------------------- output side of the front-ends (util/file_descriptor.hh, input/yuv4mpeg.{hh,cc})
@@ -872,6 +895,6 @@ using alfalfa_amd::VP8Raster; using alfalfa_amd::print_exception;
 using alfalfa_amd::FileDescriptor; using alfalfa_amd::YUV4MPEGHeader; using alfalfa_amd::YUV4MPEGFrameWriter;
 using alfalfa_amd::EncoderStateSerializer; using alfalfa_amd::EncoderStateDeserializer;
 using alfalfa_amd::DecoderState; using alfalfa_amd::ProbabilityTables; using alfalfa_amd::Segmentation; using alfalfa_amd::FilterAdjustments;
-using alfalfa_amd::DecoderHash; using alfalfa_amd::make_optional;
+using alfalfa_amd::DecoderHash; using alfalfa_amd::make_optional; using alfalfa_amd::FrameInput; using alfalfa_amd::IVFReader;
 using alfalfa_amd::CURRENT_FRAME; using alfalfa_amd::LAST_FRAME; using alfalfa_amd::GOLDEN_FRAME; using alfalfa_amd::ALTREF_FRAME;
 #endif

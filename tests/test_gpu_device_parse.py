@@ -157,3 +157,25 @@ def test_long_stream_holds_memory_flat(gpu_ctx):
         if rep % 25 == 24:
             used.append(gpu_ctx.memory()[0])
     assert max(used[1:]) - min(used[1:]) <= 64 << 20, used
+
+
+def test_async_download_into_pinned_memory(gpu_ctx):
+    """aa_stream_download_async: shown frames leave on the copy stream while the next frames are being decoded."""
+    import ctypes as C
+    from alfalfa_amd import capi
+    L = capi.lib()
+    name = "cif_q60_lf40s5"
+    w, h, frames = golden_frames(name)
+    dec = aa.Decoder(gpu_ctx, w, h)
+    ysz, usz, vsz = dec.plane_sizes()
+    bufs = []
+    for fr in frames:
+        p = C.c_void_p()
+        capi.check(L.aa_pinned_alloc(gpu_ctx.h, ysz + usz + vsz, C.byref(p)))
+        bufs.append(p)
+        _, fi = dec.get_frame_output(fr)
+        capi.check(L.aa_stream_download_async(dec.h, fi, C.c_void_p(p.value), C.c_void_p(p.value + ysz), C.c_void_p(p.value + ysz + usz)))
+    capi.check(L.aa_stream_download_wait(dec.h))
+    for i, p in enumerate(bufs):
+        assert sha256(C.string_at(p.value, ysz + usz + vsz)) == GOLDEN[name]["raster_sha256"][i], i
+        L.aa_pinned_free(p)
