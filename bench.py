@@ -398,7 +398,7 @@ def main():
                        "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective",
                        "schedule": args.schedule, "key_frames_ahead": pipe_K, "inter_frames_ahead": pipe_D, "host_threads": threads},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
-            "kernels": roofs, "device_half": device_half,
+            "kernels": roofs, "units_per_step": units, "launches_per_step": launches_per_step, "device_half": device_half,
             "steady_state": None if steady_ms is None else {"ms_per_step": round(steady_ms, 3), "value": round(world * mbs_per_step / (steady_ms * 1e-3), 1),
                                                             "note": "median interval between steps inside the timed region; `value` itself also pays for filling and draining the pipeline"},
             "stages": {"host_prepass_and_staging_s_per_step": round(host_submit_s, 4),
