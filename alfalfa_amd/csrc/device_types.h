@@ -60,7 +60,7 @@ struct ParseJob;   // tok_fsm.hh
 // order[slot] = job index: the host sorts the frames of a batch by chain length so that the lanes of a wave finish together
 int launch_parse_mb_headers( const ParseJob * jobs, const uint32_t * order, int n, void * stream );
 int launch_segment_fixup( const ParseJob * jobs, const aa_seg_stream * streams, int n_streams, const uint32_t * order, void * stream );
-int launch_parse_tokens( const ParseJob * jobs, const uint32_t * order, int n, int max_mbw, void * stream );
+int launch_parse_tokens( const ParseJob * jobs, const uint32_t * order, int n, int max_mbw, int max_nparts, void * stream );
 // whole-vector inter macroblocks, four per wave
 int launch_recon_inter4( const aa_frame_list & list, int n, unsigned max_mbs, void * stream );
 // one inter macroblock per wave; split_only: only SPLITMV macroblocks (the rest is launch_recon_inter4's)

@@ -121,9 +121,9 @@ int launch_segment_fixup( const ParseJob * jobs, const aa_seg_stream * streams, 
   return static_cast<int>( hipGetLastError() );
 }
 
-int launch_parse_tokens( const ParseJob * jobs, const uint32_t * order, int n, int max_mbw, void * stream )
+int launch_parse_tokens( const ParseJob * jobs, const uint32_t * order, int n, int max_mbw, int max_nparts, void * stream )
 {
-  const uint32_t lane_bytes = tok::lane_lds_bytes( static_cast<uint32_t>( max_mbw ) );
+  const uint32_t lane_bytes = tok::lane_lds_bytes( static_cast<uint32_t>( max_mbw ), max_nparts > 1 );
   int lanes = parse_lanes();
   if ( static_cast<uint32_t>( lanes ) * lane_bytes + tok::kTablesBytes > 65536u ) lanes = static_cast<int>( ( 65536u - tok::kTablesBytes ) / lane_bytes );
   if ( lanes < 1 ) return static_cast<int>( hipErrorInvalidValue );

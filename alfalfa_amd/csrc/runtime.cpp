@@ -997,10 +997,10 @@ aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int
     }
   }
   aa_status first_error = AA_OK; std::string first_message;
-  int appended = 0, max_mbw = 0;
+  int appended = 0, max_mbw = 0, max_nparts = 1;
   for ( int i = 0; i < n; i++ ) {
     if ( frame_index_out ) frame_index_out[i] = items[i].frame_index;
-    if ( items[i].status == AA_OK ) { appended++; max_mbw = std::max<int>( max_mbw, jobs_host[i].fp.mbw ); }
+    if ( items[i].status == AA_OK ) { appended++; max_mbw = std::max<int>( max_mbw, jobs_host[i].fp.mbw ); max_nparts = std::max<int>( max_nparts, jobs_host[i].fp.nparts ); }
     else {
       jobs_host[i].nmb = 0;                        // the kernels skip it
       if ( first_error == AA_OK ) { first_error = items[i].status; first_message = items[i].error; }
@@ -1066,7 +1066,7 @@ aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int
   }
   {
     LaunchTimer t( ctx, 4, ps );
-    if ( int e = aa::launch_parse_tokens( jobs_dev, launch_order_dev, n, max_mbw, ps ) ) return hip_fail( static_cast<hipError_t>( e ), "k_parse_tokens" );
+    if ( int e = aa::launch_parse_tokens( jobs_dev, launch_order_dev, n, max_mbw, max_nparts, ps ) ) return hip_fail( static_cast<hipError_t>( e ), "k_parse_tokens" );
   }
   for ( int i = 0; i < n; i++ ) if ( items[i].status == AA_OK ) ctx->stats.parsed_macroblocks += jobs_host[i].nmb;
   HIP_TRY( hipMemcpyAsync( b->host + b->summaries_off, b->dev + b->summaries_off, size_t( n ) * sizeof( aa::FrameSummary ), hipMemcpyDeviceToHost, ps ) );

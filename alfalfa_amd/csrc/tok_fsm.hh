@@ -70,22 +70,25 @@ namespace tok {
 constexpr uint32_t kPeriod = 64;          // steps between ring top-ups (a step consumes at most one stream byte)
 constexpr uint32_t kRing = 256;           // bytes in the stream ring
 constexpr uint32_t kChunks = 4;           // 16-byte chunks fetched per top-up (= kPeriod bytes)
-constexpr uint32_t kMetaRing = 128;       // macroblock flags in the flag ring
+constexpr uint32_t kMetaRing = 64;        // macroblock flags in the flag ring
 constexpr uint32_t kMetaChunks = 2;       // 16-flag chunks fetched per top-up (only runs of skipped macroblocks use more: they wait)
 
-// Workgroup LDS ("smem"; one flat buffer on the host): the node and block tables at offset 0 -- so that a node record's
-// address is a plain number a record can carry -- then one slice per lane.  Offsets below are relative to a lane's slice.
+// Workgroup LDS ("smem"; one flat buffer on the host): the node and block tables and the constant probabilities at offset
+// 0 -- so that a node record's address is a plain number a record can carry -- then one slice per lane.  The number of
+// chains a CU holds is what LDS is left (160 KB / slice), so a slice carries nothing that could be shared or left out.
 constexpr uint32_t kNodeTabOff = 0;       // node records, 8 bytes each (addresses < 512: 9 bits in a record)
 constexpr uint32_t kBlockTabOff = 512;    // block entries, 8 bytes each
-constexpr uint32_t kTablesBytes = 768;    // first lane slice
-constexpr uint32_t kProbs = 0;            // [4][8][3][11] token probabilities
-constexpr uint32_t kXtab = 1056;          // extra-bit probabilities of the six categories, then the sign's 128
+constexpr uint32_t kXtab = 720;           // extra-bit probabilities of the six categories, then the sign's 128 (absolute address)
 constexpr uint32_t kSignX = 26;           // index of the sign's probability in that table
-constexpr uint32_t kStream = 1088;        // stream ring
+constexpr uint32_t kTablesBytes = 768;    // first lane slice
+// offsets relative to a lane's slice:
+constexpr uint32_t kProbs = 0;            // [4][8][3][11] token probabilities
+constexpr uint32_t kStream = 1056;        // stream ring
 constexpr uint32_t kMeta = kStream + kRing;
-constexpr uint32_t kPart = kMeta + kMetaRing;   // 8 saved partition decoders x 16 bytes
-constexpr uint32_t kAbove = kPart + 128;  // uint16 per macroblock column
-AA_HD constexpr uint32_t lane_lds_bytes( uint32_t mbw ) { return ( kAbove + 2 * mbw + 15 ) & ~15u; }
+constexpr uint32_t kAbove = kMeta + kMetaRing;  // uint16 per macroblock column
+// then, only for frames with more than one token partition: 8 saved partition decoders x 16 bytes
+AA_HD constexpr uint32_t part_off( uint32_t mbw ) { return ( kAbove + 2 * mbw + 15 ) & ~15u; }
+AA_HD constexpr uint32_t lane_lds_bytes( uint32_t mbw, bool multi_partition ) { return part_off( mbw ) + ( multi_partition ? 128u : 0u ); }
 
 // dct_cat probabilities (tokens.cc:36-48) laid out back to back: cat1 @0, cat2 @1, cat3 @3, cat4 @6, cat5 @10, cat6 @15, sign @26
 constexpr uint8_t kXtabInit[27] = { 159, 165, 145, 173, 148, 140, 176, 155, 140, 135, 180, 157, 141, 134, 130,
@@ -163,7 +166,7 @@ constexpr BlockTable make_blocks()
   return t;
 }
 constexpr BlockTable kBlockTable = make_blocks();
-static_assert( kBlockTabOff + sizeof( BlockTable ) <= kTablesBytes, "tables overlap the first lane" );
+static_assert( kBlockTabOff + sizeof( BlockTable ) <= kXtab && kXtab + 28 <= kTablesBytes, "tables overlap" );
 
 constexpr uint64_t nib( std::initializer_list<unsigned> v ) { uint64_t r = 0; unsigned i = 0; for ( unsigned x : v ) r |= static_cast<uint64_t>( x ) << ( 4 * i++ ); return r; }
 constexpr uint64_t kZigzagNib = nib( { 0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15 } );
@@ -241,16 +244,17 @@ struct Lane {
   // macroblock in progress
   uint32_t ctxbits;               // non-zero flags: above (this column) bits 0-8, left bits 16-24
   uint32_t flags, nz_mask, mb_first, coeff_blocks, ytypeaddr, yfirst;
+  AA_GLOBAL int16_t * blk;        // the coefficient block being filled = Frame::coeffs + 16 * coeff_blocks
   // position
   uint32_t mi, col, row, part;
   uint32_t steps;
 };
 constexpr uint32_t kNoPend = 0xFFFFFFFFu;
 
-AA_HD inline void zero_slot( const Frame & J, uint32_t block )
+AA_HD inline void zero_slot( AA_GLOBAL int16_t * block )
 {
   V16 z; z.x = z.y = z.z = z.w = 0;
-  AA_GLOBAL V16 * p = (AA_GLOBAL V16 *) ( J.coeffs + static_cast<size_t>( block ) * 16 );
+  AA_GLOBAL V16 * p = (AA_GLOBAL V16 *) block;
   p[0] = z; p[1] = z;
 }
 
@@ -283,9 +287,10 @@ AA_HD inline void start_partition( Lane & L, uint8_t * smem, const Frame & J, ui
 
 AA_HD inline void switch_partition( Lane & L, uint8_t * smem, const Frame & J, uint32_t p )
 {
-  uint32_t * s = reinterpret_cast<uint32_t *>( smem + L.base + kPart + 16 * L.part );
+  const uint32_t save = L.base + part_off( J.mbw );
+  uint32_t * s = reinterpret_cast<uint32_t *>( smem + save + 16 * L.part );
   s[0] = L.value; s[1] = L.range | ( static_cast<uint32_t>( L.sh + 64 ) << 8 ); s[2] = L.rpos; s[3] = 1;
-  const uint32_t * t = reinterpret_cast<const uint32_t *>( smem + L.base + kPart + 16 * p );
+  const uint32_t * t = reinterpret_cast<const uint32_t *>( smem + save + 16 * p );
   if ( !t[3] ) { start_partition( L, smem, J, p ); return; }
   L.part = p;
   L.value = t[0]; L.range = t[1] & 255u; L.sh = static_cast<int32_t>( t[1] >> 8 ) - 64; L.rpos = t[2];
@@ -330,7 +335,8 @@ AA_HD inline void top_up( Lane & L, uint8_t * smem, const Frame & J )
 
 // ---- block / macroblock transitions ----------------------------------------------------------------------------------
 #if defined( __HIP_DEVICE_COMPILE__ )
-#define AA_ANY( x ) ( __any( x ) != 0 )        // wave-uniform: does any lane ...
+#define AA_ANY( x ) ( __builtin_amdgcn_ballot_w64( x ) != 0 )        // wave-uniform: does any lane ...
+#define AA_MUL24( a, b ) __umul24( ( a ), ( b ) )
 #define AA_UBFE( v, off, width ) __builtin_amdgcn_ubfe( ( v ), ( off ), ( width ) )
 // The workgroup's dynamic LDS starts at LDS address 0 (the kernel has no static LDS), so an offset into smem IS the LDS
 // address: form the pointer from the number and spare the hot loop one "add the base symbol" per access.
@@ -340,6 +346,7 @@ template <class T> __device__ inline __attribute__( ( address_space( 3 ) ) ) T *
 }
 #else
 #define AA_ANY( x ) ( x )
+#define AA_MUL24( a, b ) ( ( a ) * ( b ) )
 #define AA_UBFE( v, off, width ) ( ( ( v ) >> ( off ) ) & ( ( 1u << ( width ) ) - 1u ) )
 template <class T> inline T * lds_at( uint8_t * smem, uint32_t off ) { return reinterpret_cast<T *>( smem + off ); }
 #endif
@@ -375,7 +382,7 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
 {
   uint16_t * const above = reinterpret_cast<uint16_t *>( smem + L.base + kAbove );
   if ( L.rec == R_MBDONE ) { L.mi++; L.col++; L.rec = R_MB; }
-  if ( ++L.steps > J.max_steps ) {             // cannot happen for any input; if it does the frame is reported, not hung on
+  if ( L.steps > J.max_steps ) {             // cannot happen for any input; if it does the frame is reported, not hung on
     AA_GLOBAL FrameSummary * sum = (AA_GLOBAL FrameSummary *) J.job->summary;
     sum->num_coeff_blocks = L.coeff_blocks; sum->steps = 0xFFFFFFFFu;
     L.rec = R_DONE;
@@ -418,89 +425,80 @@ AA_HD inline bool at_boundary( const Lane & L ) { return L.rec == R_MBDONE || L.
 // Straight-line code: what the bit means comes out of the node's record as bit fields and is applied with arithmetic;
 // the only predicated regions are the stores.  A lone wave gets one issue slot every 4 cycles whatever the instruction, so
 // every instruction saved here is 4 cycles per bool.
-// -> (wave-uniform) some lane has completed a macroblock: leave the hot loop
-AA_HD inline bool step( Lane & L, uint8_t * smem, const Frame & J )
+AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
 {
-  if ( L.rec >= R_MBDONE ) return false;
-  L.steps++;
+  if ( L.rec < R_MBDONE ) {
+    // the LDS reads of a step; all addresses were known at the end of the previous one
+    const uint32_t prob = *lds_at<const uint8_t>( smem, L.paddr );
+    const uint32_t raw = *lds_at<const uint8_t>( smem, L.base + kStream + ( L.rpos & ( kRing - 1 ) ) );
+    const V8 rec = *lds_at<const V8>( smem, L.rec );
+    const V8 nextblk = *lds_at<const V8>( smem, L.blkaddr );
 
-  // the LDS reads of a step; all addresses were known at the end of the previous one
-  const uint32_t prob = *lds_at<const uint8_t>( smem, L.paddr );
-  const uint32_t raw = *lds_at<const uint8_t>( smem, L.base + kStream + ( L.rpos & ( kRing - 1 ) ) );
-  const V8 rec = *lds_at<const V8>( smem, L.rec );
-  const V8 nextblk = *lds_at<const V8>( smem, L.blkaddr );
+    // top the window up by one byte whenever one fits (sh >= 0): a decode shifts out at most 7 bits, so the 8 bits being
+    // compared are always real and the refill is never on the critical path.  Mask arithmetic, no condition.
+    const uint32_t room = ~static_cast<uint32_t>( L.sh >> 31 );
+    L.value |= ( raw << ( L.sh & 31 ) ) & room;
+    L.sh -= static_cast<int32_t>( 8u & room );
+    L.rpos -= room;
 
-  // top the window up by one byte whenever one fits (sh >= 0): a decode shifts out at most 7 bits, so the 8 bits being
-  // compared are always real and the refill is never on the critical path.  Mask arithmetic, no condition.
-  const uint32_t room = ~static_cast<uint32_t>( L.sh >> 31 );
-  L.value |= ( raw << ( L.sh & 31 ) ) & room;
-  L.sh -= static_cast<int32_t>( 8u & room );
-  L.rpos -= room;
+    // BoolDecoder::get (bool_decoder.hh:67-107)
+    const uint32_t split = ( AA_MUL24( L.range - 1, prob ) + 256u ) >> 8;   // = 1 + (((range - 1) * prob) >> 8)
+    const uint32_t bigsplit = split << 24;
+    const bool bit = L.value >= bigsplit;
+    const uint32_t range = bit ? L.range - split : split;
+    const uint32_t value = bit ? L.value - bigsplit : L.value;
+    const int shift = __builtin_clz( range ) - 24;
+    L.range = range << shift;
+    L.value = value << shift;
+    L.sh += shift;
 
-  // BoolDecoder::get (bool_decoder.hh:67-107)
-  const uint32_t split = ( ( L.range - 1 ) * prob + 256u ) >> 8;        // = 1 + (((range - 1) * prob) >> 8)
-  const uint32_t bigsplit = split << 24;
-  const bool bit = L.value >= bigsplit;
-  const uint32_t range = bit ? L.range - split : split;
-  const uint32_t value = bit ? L.value - bigsplit : L.value;
-  const int shift = __builtin_clz( range ) - 24;
-  L.range = range << shift;
-  L.value = value << shift;
-  L.sh += shift;
+    // what the node says this bit means
+    const uint32_t h = bit ? rec.y : rec.x;
+    const uint32_t xs = AA_UBFE( h, 15, 1 );
+    const uint32_t mag = ( L.mag << xs ) | ( ( bit ? 1u : 0u ) & xs );    // extra bits shift in; everything else leaves it alone
+    L.mag = mag;
+    if ( h & H_EMIT ) {                           // the sign: the token is complete (tokens.cc:126-133)
+      const int32_t m = static_cast<int32_t>( mag + AA_UBFE( h, 24, 7 ) );
+      const uint32_t zz = static_cast<uint32_t>( kZigzagNib >> ( L.idx * 4 ) ) & 15u;
+      L.blk[zz] = static_cast<int16_t>( bit ? -m : m );
+      L.mag = 0; L.nonzero = 1;
+    }
+    const uint32_t adv = AA_UBFE( h, 16, 1 );     // on to the next coefficient position?
+    const uint32_t idx = L.idx + adv;
+    const uint32_t band = static_cast<uint32_t>( kBandNib >> ( ( idx * 4 ) & 63 ) ) & 15u;
+    const uint32_t rowaddr = adv ? L.typeaddr + band * 33u + AA_UBFE( h, 19, 5 ) : L.rowaddr;
+    const uint32_t paddr = ( ( h & H_ROWREL ) ? rowaddr : kXtab ) + AA_UBFE( h, 9, 5 );
+    const bool bend = ( ( h & H_EOB ) | ( idx & 16u ) ) != 0;            // an EOB token, or position 16 reached
+    L.idx = idx; L.rowaddr = rowaddr; L.paddr = paddr; L.rec = h & 511u;
 
-  // what the node says this bit means
-  const uint32_t h = bit ? rec.y : rec.x;
-  const uint32_t xs = AA_UBFE( h, 15, 1 );
-  const uint32_t mag = ( L.mag << xs ) | ( ( bit ? 1u : 0u ) & xs );    // extra bits shift in; everything else leaves it alone
-  L.mag = mag;
-  if ( h & H_EMIT ) {                           // the sign: the token is complete (tokens.cc:126-133)
-    const int32_t m = static_cast<int32_t>( mag + AA_UBFE( h, 24, 7 ) );
-    const uint32_t zz = static_cast<uint32_t>( kZigzagNib >> ( L.idx * 4 ) ) & 15u;
-    J.coeffs[static_cast<size_t>( L.coeff_blocks ) * 16 + zz] = static_cast<int16_t>( bit ? -m : m );
-    L.mag = 0; L.nonzero = 1;
+    // ---- end of a block: a predicated region (exec mask; skipped when no lane of the wave is there), its results land
+    // in the lane's registers directly ----
+    {
+      if ( bend ) {
+        const uint32_t ctxbits = L.nonzero ? L.ctxbits | L.nzsel : L.ctxbits & ~L.nzsel;
+        if ( L.nonzero ) { L.coeff_blocks++; L.blk += 16; zero_slot( L.blk ); L.nz_mask |= L.blkbit; }
+        const bool mbdone = L.blkaddr == kBlockTabOff + 8 * 25;
+        if ( mbdone ) {                           // the macroblock is complete: its record, its column's flags
+          *lds_at<uint16_t>( smem, L.base + kAbove + 2 * L.col ) = static_cast<uint16_t>( ctxbits );
+          uint32_t flags = L.flags;
+          flags |= L.nz_mask ? AA_MB_HAS_NONZERO : ( ( flags & AA_MB_HAS_Y2 ) ? AA_MB_LF_SKIP_INNER : 0u );
+          store_mb( J, L.mi, L.nz_mask, L.mb_first, flags );
+        }
+        // the block after it (never a Y2)
+        const uint32_t a = nextblk.x & 255u, l = ( nextblk.x >> 8 ) & 255u, uv = ( nextblk.x >> 16 ) & 255u;
+        const uint32_t nctx = ( ( ctxbits >> a ) & 1u ) + ( ( ctxbits >> l ) & 1u );
+        L.typeaddr = uv ? L.base + kProbs + UV * 264u : L.ytypeaddr;
+        L.idx = uv ? 0u : L.yfirst;
+        L.rowaddr = L.paddr = L.typeaddr + L.idx * 33u + nctx * 11u;
+        L.ctxbits = ctxbits;
+        L.blkaddr += 8;
+        L.nzsel = nextblk.y;
+        L.blkbit = 1u << ( nextblk.x >> 24 );
+        L.nonzero = 0; L.mag = 0;
+        L.rec = mbdone ? static_cast<uint32_t>( R_MBDONE ) : 0u;
+      }
+    }
   }
-  const uint32_t adv = AA_UBFE( h, 16, 1 );     // on to the next coefficient position?
-  const uint32_t idx = L.idx + adv;
-  const uint32_t band = static_cast<uint32_t>( kBandNib >> ( ( idx * 4 ) & 63 ) ) & 15u;
-  const uint32_t rowaddr = adv ? L.typeaddr + band * 33u + AA_UBFE( h, 19, 5 ) : L.rowaddr;
-  const uint32_t paddr = ( ( h & H_ROWREL ) ? rowaddr : L.base + kXtab ) + AA_UBFE( h, 9, 5 );
-  const bool bend = ( h & H_EOB ) || idx == 16;
-  L.idx = idx; L.rowaddr = rowaddr; L.paddr = paddr; L.rec = h & 511u;
-
-  if ( !AA_ANY( bend ) ) return false;          // (wave-uniform) nobody ends a block in this step
-
-  // ---- end of a block (applied to the lanes with `bend`) ----
-  const uint32_t ctxbits = L.nonzero ? L.ctxbits | L.nzsel : L.ctxbits & ~L.nzsel;
-  const bool commit = bend && L.nonzero;
-  const uint32_t coeff_blocks = L.coeff_blocks + ( commit ? 1u : 0u );
-  if ( commit ) zero_slot( J, coeff_blocks );
-  const uint32_t nz_mask = commit ? L.nz_mask | L.blkbit : L.nz_mask;
-  const bool mbdone = bend && L.blkaddr == kBlockTabOff + 8 * 25;
-  if ( mbdone ) {                               // the macroblock is complete: its record, its column's flags
-    *lds_at<uint16_t>( smem, L.base + kAbove + 2 * L.col ) = static_cast<uint16_t>( ctxbits );
-    uint32_t flags = L.flags;
-    flags |= nz_mask ? AA_MB_HAS_NONZERO : ( ( flags & AA_MB_HAS_Y2 ) ? AA_MB_LF_SKIP_INNER : 0u );
-    store_mb( J, L.mi, nz_mask, L.mb_first, flags );
-  }
-  // the block after it (never a Y2)
-  const uint32_t a = nextblk.x & 255u, l = ( nextblk.x >> 8 ) & 255u, uv = ( nextblk.x >> 16 ) & 255u;
-  const uint32_t nctx = ( ( ctxbits >> a ) & 1u ) + ( ( ctxbits >> l ) & 1u );
-  const uint32_t ntypeaddr = uv ? L.base + kProbs + UV * 264u : L.ytypeaddr;
-  const uint32_t nidx = uv ? 0u : L.yfirst;
-  const uint32_t nrowaddr = ntypeaddr + nidx * 33u + nctx * 11u;
-  L.coeff_blocks = coeff_blocks; L.nz_mask = nz_mask;
-  L.ctxbits = bend ? ctxbits : L.ctxbits;
-  L.blkaddr = bend ? L.blkaddr + 8 : L.blkaddr;
-  L.nzsel = bend ? nextblk.y : L.nzsel;
-  L.blkbit = bend ? 1u << ( nextblk.x >> 24 ) : L.blkbit;
-  L.typeaddr = bend ? ntypeaddr : L.typeaddr;
-  L.nonzero = bend ? 0u : L.nonzero;
-  L.mag = bend ? 0u : L.mag;
-  L.idx = bend ? nidx : L.idx;
-  L.rowaddr = bend ? nrowaddr : L.rowaddr;
-  L.rec = bend ? ( mbdone ? static_cast<uint32_t>( R_MBDONE ) : 0u ) : L.rec;
-  L.paddr = bend ? nrowaddr : L.paddr;
-  return AA_ANY( mbdone );
 }
 
 // One period of a wave: kPeriod steps, leaving the hot loop whenever a lane has reached a macroblock boundary.
@@ -513,9 +511,10 @@ AA_HD inline void run_period( Lane & L, uint8_t * smem, const Frame & J )
       it++;                                                 // (a lane waiting for flags must not spin the period away)
       if ( !AA_ANY( L.rec < R_MBDONE ) ) break;             // nobody has anything to decode
     }
-    bool leave;
-    do { leave = step( L, smem, J ); it++; } while ( it < kPeriod && !leave );
+    // leave the hot loop when a lane has completed a macroblock (asked by ALL lanes, outside the predicated step: wave-uniform)
+    do { step( L, smem, J ); it++; } while ( it < kPeriod && !AA_ANY( L.rec == R_MBDONE ) );
   }
+  if ( L.rec != R_DONE ) L.steps += it;                     // (an upper bound: the iterations a lane sat out count too)
 }
 
 // ---- a lane's life ---------------------------------------------------------------------------------------------------
@@ -526,6 +525,11 @@ AA_HD inline uint32_t table_word( uint32_t k )
   const uint32_t * b = reinterpret_cast<const uint32_t *>( &kBlockTable );
   if ( k < sizeof( NodeTable ) / 4 ) return n[k];
   if ( k >= kBlockTabOff / 4 && k < ( kBlockTabOff + sizeof( BlockTable ) ) / 4 ) return b[k - kBlockTabOff / 4];
+  if ( k >= kXtab / 4 && k < kXtab / 4 + 7 ) {
+    uint32_t w = 0;
+    for ( uint32_t i = 0; i < 4; i++ ) { const uint32_t at = 4 * ( k - kXtab / 4 ) + i; w |= ( at < 27 ? static_cast<uint32_t>( kXtabInit[at] ) : 0u ) << ( 8 * i ); }
+    return w;
+  }
   return 0;
 }
 
@@ -537,15 +541,15 @@ AA_HD inline void begin_frame( Lane & L, uint8_t * smem, uint32_t base, const Fr
   const AA_GLOBAL uint32_t * src = (const AA_GLOBAL uint32_t *) &J.job->fp.coeff_probs[0][0][0][0];
   uint32_t * dst = reinterpret_cast<uint32_t *>( lds + kProbs );
   for ( uint32_t k = 0; k < 1056 / 4; k++ ) dst[k] = src[k];
-  for ( uint32_t k = 0; k < 27; k++ ) lds[kXtab + k] = kXtabInit[k];
-  for ( uint32_t k = 0; k < 128 / 4; k++ ) reinterpret_cast<uint32_t *>( lds + kPart )[k] = 0;
+  if ( J.nparts > 1 ) for ( uint32_t k = 0; k < 128 / 4; k++ ) reinterpret_cast<uint32_t *>( lds + part_off( J.mbw ) )[k] = 0;
   for ( uint32_t k = 0; k < J.mbw; k++ ) reinterpret_cast<uint16_t *>( lds + kAbove )[k] = 0;
   L.mi = 0; L.col = 0; L.row = 0; L.ctxbits = 0; L.coeff_blocks = 0; L.steps = 0;
   L.flags = L.nz_mask = L.mb_first = L.yfirst = 0;
   L.idx = L.nonzero = L.nzsel = L.blkbit = L.mag = 0;
   L.ytypeaddr = L.typeaddr = L.rowaddr = L.paddr = base;
   L.blkaddr = kBlockTabOff;
-  zero_slot( J, 0 );
+  L.blk = J.coeffs;
+  zero_slot( L.blk );
   start_partition( L, smem, J, 0 );
   // flag ring: macroblocks [0, kMetaRing)
   for ( uint32_t k = 0; k < kMetaRing / 16; k++ ) {

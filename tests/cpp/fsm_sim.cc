@@ -75,7 +75,7 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
   }
   // ---- k_parse_tokens ----
   {
-    const uint32_t bytes = aa::tok::kTablesBytes + aa::tok::lane_lds_bytes( J.fp.mbw );
+    const uint32_t bytes = aa::tok::kTablesBytes + aa::tok::lane_lds_bytes( J.fp.mbw, J.fp.nparts > 1 );
     std::vector<uint8_t> store( bytes + 16 );
     uint8_t * smem = reinterpret_cast<uint8_t *>( ( reinterpret_cast<uintptr_t>( store.data() ) + 15 ) & ~uintptr_t( 15 ) );
     std::memset( smem, 0xA5, bytes );
