@@ -165,7 +165,9 @@ def main():
         def __init__(self, stream_list, key_ahead, depth):
             self.n = len(stream_list)
             self.K, self.D = max(1, key_ahead), max(1, min(depth, key_ahead))
-            self.R = self.K
+            # a decoder takes its frames in order (key g, inter g, key g + R, ...): key g + R can be handed over once the
+            # inter frames of group g have been, which happens D steps before g is reconstructed -> K - D + 1 sets suffice
+            self.R = self.K - self.D + 1
             self.sets = [[aa.Decoder(ctx, width, height) for _ in stream_list] for _ in range(self.R)]
             self.key_prep = [ctx.prepare_frames([(d, st[0]) for d, st in zip(ds, stream_list)]) for ds in self.sets]
             # stream-major: the inter frames of one stream are consecutive (a host worker takes a whole stream)
@@ -194,14 +196,17 @@ def main():
             """`steps` whole steps, from an empty pipeline to an empty pipeline."""
             target = self.decoded + steps
             while self.decoded < target:
-                while self.keys < min(target, self.decoded + self.K):
-                    self._submit(self.key_prep[self.keys % self.R]); self.keys += 1
-                while self.inters < min(target, self.decoded + self.D, self.keys):
-                    self._submit(self.inter_prep[self.inters % self.R]); self.inters += 1
+                while True:
+                    if self.keys < min(target, self.decoded + self.K, self.inters + self.R):
+                        self._submit(self.key_prep[self.keys % self.R]); self.keys += 1
+                    elif self.inters < min(target, self.decoded + self.D, self.keys):
+                        self._submit(self.inter_prep[self.inters % self.R]); self.inters += 1
+                    else:
+                        break
                 self.decode()
 
     pipe = Pipeline(streams, args.key_ahead, args.depth)
-    pipe.run(pipe.R)                    # priming (untimed, before the warm-up): every decoder set once, so that first-touch
+    pipe.run(max(pipe.R, pipe.K))       # priming (untimed, before the warm-up): every decoder set once, so that first-touch
     pipe.run(args.warmup)               # allocations of the pools (hipMalloc / hipHostMalloc) are not what the steps measure
     barrier()
     pipe.host_s = 0.0; pipe.done_t = []
@@ -209,6 +214,7 @@ def main():
     pipe.run(args.steps)
     ctx.sync()
     elapsed = time.perf_counter() - t0
+    hbm_free, hbm_total = ctx.memory()
     host_submit_s = pipe.host_s / max(1, args.steps)
     # steady state inside the timed region: the median interval between reconstruction hand-overs (host side, i.e. when the
     # parse a step waited for was done) -- the timed region itself also pays for filling and draining the pipeline
@@ -318,7 +324,7 @@ def main():
         dt = (time.perf_counter() - t0) / reps
         device_half = {"value": round(mbs_per_step / dt, 1), "unit": "macroblocks/s", "ms_per_step": round(dt * 1e3, 3),
                        "note": "reconstruction + loop filter only, parsed records resident in HBM (round-1 metric)"}
-    pipe_K, pipe_D = pipe.K, pipe.D
+    pipe_K, pipe_D, pipe_R = pipe.K, pipe.D, pipe.R
     del pipe, verify_decs
 
     # ---- small batches: the reference's actual callers (one stream, one 8-chunk ExCamera bundle), end to end ----
@@ -329,7 +335,7 @@ def main():
                 continue
             p = Pipeline(streams[:n], args.key_ahead, args.depth)
             p.run(2); ctx.sync()
-            reps = max(4, args.key_ahead)
+            reps = max(4, p.K)
             t0 = time.perf_counter()
             p.run(reps); ctx.sync()
             dt = (time.perf_counter() - t0) / reps
@@ -396,7 +402,8 @@ def main():
                                    % (args.config, S, width, height, F, shape, cfg[3], cfg[4]),
                        "streams_per_gpu": S, "frames_per_stream": F, "macroblocks_per_step_per_gpu": mbs_per_step,
                        "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective",
-                       "schedule": args.schedule, "key_frames_ahead": pipe_K, "inter_frames_ahead": pipe_D, "host_threads": threads},
+                       "schedule": args.schedule, "key_frames_ahead": pipe_K, "inter_frames_ahead": pipe_D, "decoder_sets": pipe_R, "host_threads": threads,
+                       "hbm_in_use_after_timed_region_gb": round((hbm_total - hbm_free) / 1e9, 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "kernels": roofs, "units_per_step": units, "launches_per_step": launches_per_step, "device_half": device_half,
             "steady_state": None if steady_ms is None else {"ms_per_step": round(steady_ms, 3), "value": round(world * mbs_per_step / (steady_ms * 1e-3), 1),
