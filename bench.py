@@ -186,10 +186,10 @@ def main():
             ds, base = self.sets[g % self.R], (g // self.R) * F
             for f in range(F):
                 ctx.decode_batch(ds, [base + f] * self.n)
+                if release:             # this frame is consumed: its records go back to the pool once the kernels queued so far
+                    for d in ds:        # have run, its raster when nothing refers to it any more (RasterHandle semantics)
+                        d.release_before(base + f + 1)
             self.decoded += 1
-            if release:                 # this group's frames are consumed
-                for d in ds:
-                    d.release_before(base + F)
             self.done_t.append(time.perf_counter())
 
         def run(self, steps):
@@ -205,7 +205,21 @@ def main():
                         break
                 self.decode()
 
-    pipe = Pipeline(streams, args.key_ahead, args.depth)
+    # HBM holds what is in flight: the records of K + 1 key-frame groups and D + 1 inter-frame groups (worst-case sized: 25
+    # coefficient blocks per macroblock), and the rasters the decoder sets refer to.  Clamp the look-ahead to what fits.
+    rec_bytes = mbs_per_frame * 80 + (25 * mbs_per_frame + 1) * 32 + 2 * mbs_per_frame + 4096
+    raster_bytes = sum(aa.Decoder(ctx, width, height).plane_sizes())
+    budget = 0.92 * ctx.memory()[0]
+    K, D = max(1, args.key_ahead), max(1, min(args.depth, args.key_ahead))
+
+    def need(k, d):
+        return S * ((k + 1) * rec_bytes + (d + 0.6) * (F - 1) * rec_bytes + (3 * (k - d + 1) + 2) * raster_bytes)
+    while need(K, D) > budget and (K > D or D > 1):
+        if K > D:
+            K -= 1
+        else:
+            D -= 1; K = D
+    pipe = Pipeline(streams, K, D)
     pipe.run(max(pipe.R, pipe.K))       # priming (untimed, before the warm-up): every decoder set once, so that first-touch
     pipe.run(args.warmup)               # allocations of the pools (hipMalloc / hipHostMalloc) are not what the steps measure
     barrier()
