@@ -47,7 +47,8 @@ class KernelStats(C.Structure):
                 ("recon_inter_launches", C.c_uint64), ("recon_intra_launches", C.c_uint64),
                 ("loopfilter_launches", C.c_uint64), ("macroblocks", C.c_uint64),
                 ("parse_headers_ms", C.c_double), ("parse_tokens_ms", C.c_double), ("parse_launches", C.c_uint64),
-                ("parsed_macroblocks", C.c_uint64), ("recon_split_ms", C.c_double), ("recon_split_launches", C.c_uint64)]
+                ("parsed_macroblocks", C.c_uint64), ("recon_split_ms", C.c_double), ("recon_split_launches", C.c_uint64),
+                ("pool_waits", C.c_uint64), ("pool_wait_ms", C.c_double), ("parse_wait_ms", C.c_double)]
 
 
 class AlfalfaError(RuntimeError):

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -230,7 +231,10 @@ aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out )
     // out of HBM: what was released but may still be read by queued kernels comes back once they have run
     (void) hipGetLastError();
     if ( attempt == 2 || ctx->pending_free.empty() ) return hip_fail( e, "hipMalloc (frame store)" );
+    const auto t0 = std::chrono::steady_clock::now();
     collect_pending( ctx, true );
+    ctx->stats.pool_waits++;
+    ctx->stats.pool_wait_ms += std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count();
   }
   return fail( AA_ERR_HIP, "device allocation failed" );
 }
@@ -1082,7 +1086,12 @@ static aa_status resolve_summary( aa_stream * s, FrameRec & r )
   if ( !r.summary_pending ) return AA_OK;
   Batch * b = r.batch;
   if ( !b ) return fail( AA_ERR_LOGIC, "frame records were released before the frame was decoded" );
-  if ( !b->done_seen ) { HIP_TRY( hipEventSynchronize( b->done ) ); b->done_seen = true; }
+  if ( !b->done_seen ) {
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY( hipEventSynchronize( b->done ) );
+    b->done_seen = true;
+    s->ctx->stats.parse_wait_ms += std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count();
+  }
   const aa::FrameSummary & sum = reinterpret_cast<const aa::FrameSummary *>( b->host + b->summaries_off )[r.batch_item];
   if ( sum.steps == 0xFFFFFFFFu ) return fail( AA_ERR_HIP, "device parser: a token lane exceeded the step bound of its frame size (records are not valid)" );
   r.hdr.num_coeff_blocks = sum.num_coeff_blocks;

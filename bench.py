@@ -69,6 +69,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-device-half", action="store_true")
+    ap.add_argument("--profile-timed", action="store_true", help="HIP-event timing of every kernel INSIDE the timed region too (diagnostics)")
     ap.add_argument("--small-batches", default="1,8,64", help="stream counts for the small-batch end-to-end figures ('' = skip)")
     return ap.parse_args()
 
@@ -224,11 +225,20 @@ def main():
     pipe.run(args.warmup)               # allocations of the pools (hipMalloc / hipHostMalloc) are not what the steps measure
     barrier()
     pipe.host_s = 0.0; pipe.done_t = []
+    ctx.kernel_stats(reset=True)
+    if args.profile_timed:
+        ctx.profile(True)
     t0 = time.perf_counter()
     pipe.run(args.steps)
     ctx.sync()
     elapsed = time.perf_counter() - t0
     hbm_free, hbm_total = ctx.memory()
+    tstats = ctx.kernel_stats(reset=True); ctx.profile(False)
+    timed_region = {"step_done_at_ms": [round((t - t0) * 1e3) for t in pipe.done_t],
+                    "host_waited_for_parse_ms_per_step": round(tstats["parse_wait_ms"] / args.steps, 2),
+                    "pool_waits": tstats["pool_waits"], "pool_wait_ms_per_step": round(tstats["pool_wait_ms"] / args.steps, 2)}
+    if args.profile_timed:
+        timed_region["kernel_ms_per_step"] = {k: round(v / args.steps, 2) for k, v in tstats.items() if k.endswith("_ms") and "wait" not in k}
     host_submit_s = pipe.host_s / max(1, args.steps)
     # steady state inside the timed region: the median interval between reconstruction hand-overs (host side, i.e. when the
     # parse a step waited for was done) -- the timed region itself also pays for filling and draining the pipeline
@@ -425,7 +435,7 @@ def main():
             "stages": {"host_prepass_and_staging_s_per_step": round(host_submit_s, 4),
                        "entropy_decode_alone_s_per_step": round(t_parse_alone, 4),
                        "note": "entropy_decode_alone = one step's submit -> parse finished with nothing else on the GPU (a latency: the longest chain, a key frame)"},
-            "small_batches": small,
+            "timed_region": timed_region, "small_batches": small,
             "host": {"parser_mb_per_s_per_core": round(parser_only, 1), "stream_generation_s": round(t_gen, 1)},
             "kernel_stats": kstats, "verified_bit_exact_vs_reference": verified, "entry_state_handoff": handoff,
         }

@@ -282,6 +282,10 @@ typedef struct aa_kernel_stats {
   uint64_t parsed_macroblocks;                               /* MBs handed to the device parser */
   double recon_split_ms;                                     /* k_recon_inter on SPLITMV macroblocks (recon_inter_ms: k_recon_inter4 only) */
   uint64_t recon_split_launches;
+  /* where the host stood still (always counted, profile on or off): waiting for released HBM pieces to come back because
+   * hipMalloc was out of memory; waiting in aa_decode_batch for the device parser to finish the frames asked for */
+  uint64_t pool_waits;
+  double pool_wait_ms, parse_wait_ms;
 } aa_kernel_stats;
 aa_status aa_ctx_profile( aa_ctx * ctx, int enable );
 aa_status aa_ctx_kernel_stats( aa_ctx * ctx, aa_kernel_stats * out, int reset );
