@@ -85,6 +85,8 @@ SYMBOLS = [
     ("aa_decode_batch", C.c_int, [_P, C.POINTER(_P), C.c_int, C.POINTER(C.c_int)]),
     ("aa_stream_decode", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("aa_submit_frames", C.c_int, [_P, C.POINTER(FrameIn), C.c_int, C.POINTER(C.c_int), C.c_int]),
+    ("aa_submit_frames_ex", C.c_int, [_P, C.POINTER(FrameIn), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_uint]),
+    ("aa_launch_tokens", C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
     ("aa_stream_frame_header", C.c_int, [_P, C.c_int, C.POINTER(FrameHeader)]),
     ("aa_stream_read_records", C.c_int, [_P, C.c_int, _P, _P, C.c_size_t]),
     ("aa_stream_frame_count", C.c_int, [_P]), ("aa_stream_release_before", C.c_int, [_P, C.c_int]),

@@ -73,6 +73,16 @@ struct Batch {
   hipEvent_t done = nullptr;                 // parse kernels finished and the summaries are back in `host`
   bool done_seen = false;
   size_t summaries_off = 0;
+  // Two-phase form (AA_SUBMIT_DEFER_TOKENS): the macroblock-header kernel has been queued, the token kernel has not -- the
+  // coefficient blocks (9/10 of a frame's records) are only allocated when it is (aa_launch_tokens, or the first call that
+  // needs the frame's records).
+  bool tokens_pending = false;
+  size_t head_bytes = 0;                     // parse jobs + reconstruction job records at the start of the arena
+  const uint32_t * launch_order_dev = nullptr;
+  int max_mbw = 0, max_nparts = 1;
+  hipStream_t ps = nullptr;
+  struct Item { aa_stream * s; int frame; bool live; };
+  std::vector<Item> items;                   // [n]; live: accepted and not released since
 };
 
 // A raster: three padded planes in one piece of the context's device pool.  The piece goes back to the pool when the last
@@ -98,8 +108,10 @@ struct FrameRec {
   Batch * batch = nullptr;                 // device-parsed frame: its submit call ...
   int batch_item = -1;                     // ... and its index there
   bool summary_pending = false;            // counts (intra macroblocks, coefficient blocks, SPLITMV) not yet read back from the device parser
-  uint8_t * rec_block = nullptr;           // device-parsed frame: its record block in HBM
+  uint8_t * rec_block = nullptr;           // device-parsed frame: macroblock records, intra row masks, flags in HBM ...
   size_t rec_bytes = 0;
+  uint8_t * coeff_block = nullptr;         // ... and its coefficient blocks (worst-case sized: 25 per macroblock + 1)
+  size_t coeff_bytes = 0;
   bool records_released = false;
   bool placed = false;                     // raster slot + References bookkeeping done (at the first decode submission)
 };
@@ -123,6 +135,7 @@ struct aa_ctx {
   int prio_low = 0;
   int next_parse_stream = 0;
   hipEvent_t last_seg_batch = nullptr;  // segment-map passes of consecutive batches must run in order
+  std::vector<Batch *> deferred;        // batches whose token kernel has not been launched yet, oldest first
   // Device pieces given back while kernels that read them may still be queued: they become reusable once an event recorded
   // on the compute stream after the release has fired ("epochs": one event per group of releases, recorded lazily).
   struct PendingFree { uint8_t * p; size_t bytes; uint64_t epoch; };
@@ -362,10 +375,13 @@ void release_records( aa_stream * s, FrameRec & f, bool deferred )
   f.records_released = true;
   aa_ctx * ctx = s->ctx;
   if ( f.rec_block ) { dev_free( ctx, f.rec_block, f.rec_bytes, deferred ); f.rec_block = nullptr; }
+  if ( f.coeff_block ) { dev_free( ctx, f.coeff_block, f.coeff_bytes, deferred ); f.coeff_block = nullptr; }
   if ( Batch * b = f.batch ) {
     bool last;
     { std::lock_guard<std::mutex> g( ctx->pool_mu ); last = --b->live == 0; }
+    if ( f.batch_item >= 0 && f.batch_item < static_cast<int>( b->items.size() ) ) b->items[f.batch_item].live = false;
     if ( last ) {
+      if ( b->tokens_pending ) ctx->deferred.erase( std::remove( ctx->deferred.begin(), ctx->deferred.end(), b ), ctx->deferred.end() );
       if ( !b->done_seen ) (void) hipEventSynchronize( b->done );     // never parsed-and-forgotten while kernels still write
       (void) hipEventDestroy( b->done );
       { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); }
@@ -894,7 +910,7 @@ struct SubmitItem {
 };
 
 // one frame of one stream: header pre-pass on the host, compressed bytes into the pinned arena, record block + raster slot
-aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_host, aa_dev_frame * dframes_host )
+aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_host, aa_dev_frame * dframes_host, bool defer_tokens )
 {
   aa_stream * s = it.s;
   aa_ctx * ctx = s->ctx;
@@ -911,9 +927,11 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
   const size_t rows_bytes = align_up( words_per_row * J.fp.mbh * sizeof( unsigned long long ) );
   const uint32_t flags_padded = ( nmb + 15u ) & ~15u;
   const size_t flags_bytes = align_up( flags_padded );
-  const size_t coeff_bytes = align_up( ( size_t( nmb ) * 25 + 1 ) * 32 );
-  rec.rec_bytes = mb_bytes + rows_bytes + flags_bytes + coeff_bytes;
+  rec.rec_bytes = mb_bytes + rows_bytes + flags_bytes;
+  rec.coeff_bytes = align_up( ( size_t( nmb ) * 25 + 1 ) * 32 );
   if ( aa_status st = dev_alloc( ctx, rec.rec_bytes, &rec.rec_block ) ) { it.error = g_last_error; return st; }
+  if ( !defer_tokens )
+    if ( aa_status st = dev_alloc( ctx, rec.coeff_bytes, &rec.coeff_block ) ) { dev_free( ctx, rec.rec_block, rec.rec_bytes ); it.error = g_last_error; return st; }
   uint8_t * blk = rec.rec_block;
 
   J.data = b->dev + it.data_off;
@@ -922,7 +940,7 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
   J.mbs = reinterpret_cast<aa_mb_info *>( blk );
   J.intra_rows = reinterpret_cast<unsigned long long *>( blk + mb_bytes );
   J.mbflags = blk + mb_bytes + rows_bytes;
-  J.coeffs = reinterpret_cast<int16_t *>( blk + mb_bytes + rows_bytes + flags_bytes );
+  J.coeffs = reinterpret_cast<int16_t *>( rec.coeff_block );       // (null until aa_launch_tokens in the two-phase form)
   J.summary = reinterpret_cast<aa::FrameSummary *>( b->dev + b->summaries_off ) + item;
 
   aa_dev_frame * job = &dframes_host[item];
@@ -938,9 +956,65 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
 }
 } // namespace
 
+namespace {
+// second phase of a batch: coefficient blocks, patched jobs to HBM, the token kernel, summaries back
+aa_status launch_tokens_of( aa_ctx * ctx, Batch * b )
+{
+  if ( !b->tokens_pending ) return AA_OK;
+  aa::ParseJob * jobs_host = reinterpret_cast<aa::ParseJob *>( b->host );
+  aa_dev_frame * dframes_host = reinterpret_cast<aa_dev_frame *>( b->host + align_up( size_t( b->n ) * sizeof( aa::ParseJob ) ) );
+  for ( int i = 0; i < b->n; i++ ) {               // all the coefficient blocks, or nothing launched (the call can be repeated)
+    Batch::Item & it = b->items[i];
+    if ( !it.live ) continue;
+    FrameRec & r = it.s->frames[it.frame];
+    if ( !r.coeff_block ) if ( aa_status st = dev_alloc( ctx, r.coeff_bytes, &r.coeff_block ) ) return st;
+  }
+  b->tokens_pending = false;
+  ctx->deferred.erase( std::remove( ctx->deferred.begin(), ctx->deferred.end(), b ), ctx->deferred.end() );
+  for ( int i = 0; i < b->n; i++ ) {
+    Batch::Item & it = b->items[i];
+    if ( !it.live ) { jobs_host[i].nmb = 0; continue; }           // rejected by the pre-pass, or released since: the kernel skips it
+    FrameRec & r = it.s->frames[it.frame];
+    jobs_host[i].coeffs = reinterpret_cast<int16_t *>( r.coeff_block );
+    dframes_host[i].coeffs = jobs_host[i].coeffs;
+    ctx->stats.parsed_macroblocks += jobs_host[i].nmb;
+  }
+  hipStream_t ps = b->ps;
+  HIP_TRY( hipMemcpyAsync( b->dev, b->host, b->head_bytes, hipMemcpyHostToDevice, ps ) );     // behind the header kernel on its stream
+  {
+    LaunchTimer t( ctx, 4, ps );
+    if ( int e = aa::launch_parse_tokens( reinterpret_cast<const aa::ParseJob *>( b->dev ), b->launch_order_dev, b->n, b->max_mbw, b->max_nparts, ps ) )
+      return hip_fail( static_cast<hipError_t>( e ), "k_parse_tokens" );
+  }
+  HIP_TRY( hipMemcpyAsync( b->host + b->summaries_off, b->dev + b->summaries_off, size_t( b->n ) * sizeof( aa::FrameSummary ), hipMemcpyDeviceToHost, ps ) );
+  HIP_TRY( hipEventRecord( b->done, ps ) );
+  b->done_seen = false;
+  return AA_OK;
+}
+} // namespace
+
+aa_status aa_launch_tokens( aa_ctx * ctx, int max_batches, int * launched_out )
+{
+  if ( !ctx ) return fail( AA_ERR_ARGUMENT, "aa_launch_tokens: null context" );
+  if ( aa_status st = set_device( ctx ) ) return st;
+  int launched = 0;
+  while ( !ctx->deferred.empty() && ( max_batches <= 0 || launched < max_batches ) ) {
+    if ( aa_status st = launch_tokens_of( ctx, ctx->deferred.front() ) ) return st;
+    launched++;
+  }
+  if ( launched_out ) *launched_out = launched;
+  return AA_OK;
+}
+
 aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int * frame_index_out, int threads )
 {
+  return aa_submit_frames_ex( ctx, frames, n, frame_index_out, threads, 0 );
+}
+
+aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, int * frame_index_out, int threads, unsigned flags )
+{
   if ( !ctx || !frames || n <= 0 ) return fail( AA_ERR_ARGUMENT, "aa_submit_frames: bad argument" );
+  const bool defer_tokens = ( flags & AA_SUBMIT_DEFER_TOKENS ) != 0;
   if ( aa_status st = set_device( ctx ) ) return st;
   std::vector<SubmitItem> items( n );
   // arena layout: parse jobs | reconstruction job records | summaries | segment-pass lists | compressed frames
@@ -986,7 +1060,7 @@ aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int
         for ( int i : by_stream[stream_order[k]] ) {
           SubmitItem & it = items[i];
           if ( broken ) { it.status = AA_ERR_LOGIC; it.error = "an earlier frame of this stream in the same call failed"; continue; }
-          it.status = submit_one( b.get(), it, i, jobs_host, dframes_host );
+          it.status = submit_one( b.get(), it, i, jobs_host, dframes_host, defer_tokens );
           if ( it.status != AA_OK ) broken = true;
         }
       }
@@ -1016,6 +1090,10 @@ aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int
     return fail( first_error, first_message );
   }
   b->live = appended;
+  b->items.resize( n );
+  for ( int i = 0; i < n; i++ ) b->items[i] = { items[i].s, items[i].frame_index, items[i].status == AA_OK };
+  b->head_bytes = jobs_bytes + dframes_bytes;
+  b->max_mbw = max_mbw; b->max_nparts = max_nparts;
 
   // ---- segment-map pass lists (only streams that use segmentation in this batch) ----
   aa_seg_stream * seg_streams = reinterpret_cast<aa_seg_stream *>( b->host + jobs_bytes + dframes_bytes + sums_bytes );
@@ -1068,14 +1146,12 @@ aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int
     if ( !ctx->last_seg_batch ) HIP_TRY( hipEventCreateWithFlags( &ctx->last_seg_batch, hipEventDisableTiming ) );
     HIP_TRY( hipEventRecord( ctx->last_seg_batch, ps ) );
   }
-  {
-    LaunchTimer t( ctx, 4, ps );
-    if ( int e = aa::launch_parse_tokens( jobs_dev, launch_order_dev, n, max_mbw, max_nparts, ps ) ) return hip_fail( static_cast<hipError_t>( e ), "k_parse_tokens" );
-  }
-  for ( int i = 0; i < n; i++ ) if ( items[i].status == AA_OK ) ctx->stats.parsed_macroblocks += jobs_host[i].nmb;
-  HIP_TRY( hipMemcpyAsync( b->host + b->summaries_off, b->dev + b->summaries_off, size_t( n ) * sizeof( aa::FrameSummary ), hipMemcpyDeviceToHost, ps ) );
-  HIP_TRY( hipEventRecord( b->done, ps ) );
-  b.release();
+  b->ps = ps; b->launch_order_dev = launch_order_dev;
+  b->tokens_pending = true;
+  HIP_TRY( hipEventRecord( b->done, ps ) );        // (the header kernel; recorded again behind the token kernel)
+  ctx->deferred.push_back( b.get() );
+  Batch * raw = b.release();
+  if ( !defer_tokens ) if ( aa_status st = launch_tokens_of( ctx, raw ) ) return st;
   if ( first_error != AA_OK ) return fail( first_error, first_message );
   return AA_OK;
 }
@@ -1086,6 +1162,7 @@ static aa_status resolve_summary( aa_stream * s, FrameRec & r )
   if ( !r.summary_pending ) return AA_OK;
   Batch * b = r.batch;
   if ( !b ) return fail( AA_ERR_LOGIC, "frame records were released before the frame was decoded" );
+  if ( b->tokens_pending ) if ( aa_status st = launch_tokens_of( s->ctx, b ) ) return st;      // two-phase submit, second phase not asked for yet
   if ( !b->done_seen ) {
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY( hipEventSynchronize( b->done ) );

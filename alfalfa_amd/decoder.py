@@ -121,11 +121,11 @@ class Context:
     def compute_stream(self):
         return self.L.aa_ctx_compute_stream(self.h)
 
-    def submit_frames(self, pairs, threads=0):
+    def submit_frames(self, pairs, threads=0, defer_tokens=False):
         """Device-side entropy decode (aa_submit_frames): pairs = [(decoder, frame bytes), ...], frames of one decoder in
         stream order.  Host: frame-header pre-pass only; the macroblock headers and tokens are parsed on the GPU.
         -> frame index of every pair in its stream."""
-        return self.submit_prepared(self.prepare_frames(pairs), threads)
+        return self.submit_prepared(self.prepare_frames(pairs), threads, defer_tokens)
 
     def prepare_frames(self, pairs):
         """The ctypes argument block of submit_frames, reusable across calls with the same (decoder, bytes) pairs."""
@@ -135,10 +135,17 @@ class Context:
             arr[i].stream, arr[i].data, arr[i].size = d.h.value, fr, len(fr)
         return arr, (C.c_int * n)(), [fr for _, fr in pairs]      # (keeps the byte strings alive)
 
-    def submit_prepared(self, prepared, threads=0):
+    def submit_prepared(self, prepared, threads=0, defer_tokens=False):
+        """defer_tokens: two-phase form (AA_SUBMIT_DEFER_TOKENS) -- macroblock headers now, tokens at launch_tokens()."""
         arr, out, _keep = prepared
-        capi.check(self.L.aa_submit_frames(self.h, arr, len(arr), out, threads))
+        capi.check(self.L.aa_submit_frames_ex(self.h, arr, len(arr), out, threads, 1 if defer_tokens else 0))
         return list(out)
+
+    def launch_tokens(self, max_batches=0):
+        """Second phase of the oldest `max_batches` deferred batches (0: all) -> how many were launched."""
+        n = C.c_int()
+        capi.check(self.L.aa_launch_tokens(self.h, max_batches, C.byref(n)))
+        return n.value
 
     def decode_batch(self, decoders, frame_indices):
         n = len(decoders)

@@ -62,8 +62,9 @@ def parse_args():
     ap.add_argument("--config", default="1080p_inter_lf")
     ap.add_argument("--streams", type=int, default=480, help="independent streams per GPU")
     ap.add_argument("--frames", type=int, default=12, help="frames per stream per step")
-    ap.add_argument("--key-ahead", type=int, default=7, help="steps by which KEY frames are handed to the GPU parser ahead of reconstruction")
+    ap.add_argument("--key-ahead", type=int, default=10, help="steps by which KEY frames are handed to the GPU parser ahead of reconstruction")
     ap.add_argument("--depth", type=int, default=4, help="steps by which inter frames are handed to the GPU parser ahead of reconstruction")
+    ap.add_argument("--header-ahead", type=int, default=1, help="steps by which the macroblock-header pass of inter frames runs ahead of their token pass (two-phase submit)")
     ap.add_argument("--threads", type=int, default=0, help="host workers of the header pre-pass (0: cores / local ranks)")
     ap.add_argument("--schedule", default="rows", choices=["rows", "diagonal"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -163,8 +164,10 @@ def main():
     # waiting for their key frame).  R = key_ahead decoder sets rotate, so that the key frame of group g + R can be submitted
     # to a decoder whose group g is done.
     class Pipeline:
-        def __init__(self, stream_list, key_ahead, depth):
+        def __init__(self, stream_list, key_ahead, depth, header_ahead=0):
             self.n = len(stream_list)
+            self.H = max(0, header_ahead)
+            self.inter_h = 0
             self.K, self.D = max(1, key_ahead), max(1, min(depth, key_ahead))
             # a decoder takes its frames in order (key g, inter g, key g + R, ...): key g + R can be handed over once the
             # inter frames of group g have been, which happens D steps before g is reconstructed -> K - D + 1 sets suffice
@@ -177,9 +180,9 @@ def main():
             self.host_s = 0.0
             self.done_t = []
 
-        def _submit(self, prep):
+        def _submit(self, prep, defer_tokens=False):
             t = time.perf_counter()
-            ctx.submit_prepared(prep, threads)
+            ctx.submit_prepared(prep, threads, defer_tokens)
             self.host_s += time.perf_counter() - t
 
         def decode(self, release=True):
@@ -198,10 +201,14 @@ def main():
             target = self.decoded + steps
             while self.decoded < target:
                 while True:
-                    if self.keys < min(target, self.decoded + self.K, self.inters + self.R):
+                    # inter frames in two phases: header pre-pass + upload + macroblock-header kernel H steps before the
+                    # token kernel is launched (only then are the coefficient blocks, 9/10 of the records, allocated)
+                    if self.keys < min(target, self.decoded + self.K, self.inter_h + self.R):
                         self._submit(self.key_prep[self.keys % self.R]); self.keys += 1
-                    elif self.inters < min(target, self.decoded + self.D, self.keys):
-                        self._submit(self.inter_prep[self.inters % self.R]); self.inters += 1
+                    elif self.inter_h < min(target, self.decoded + self.D + self.H, self.keys):
+                        self._submit(self.inter_prep[self.inter_h % self.R], defer_tokens=True); self.inter_h += 1
+                    elif self.inters < min(target, self.decoded + self.D, self.inter_h):
+                        ctx.launch_tokens(1); self.inters += 1
                     else:
                         break
                 self.decode()
@@ -214,13 +221,14 @@ def main():
     K, D = max(1, args.key_ahead), max(1, min(args.depth, args.key_ahead))
 
     def need(k, d):
-        return S * ((k + 1) * rec_bytes + (d + 0.6) * (F - 1) * rec_bytes + (3 * (k - d + 1) + 2) * raster_bytes)
+        return S * ((k + 1) * rec_bytes + (d + 0.6) * (F - 1) * rec_bytes + (3 * (k - d + 1) + 2) * raster_bytes
+                    + args.header_ahead * (F - 1) * (mbs_per_frame * 84 + compressed_bytes / (S * F)))
     while need(K, D) > budget and (K > D or D > 1):
         if K > D:
             K -= 1
         else:
             D -= 1; K = D
-    pipe = Pipeline(streams, K, D)
+    pipe = Pipeline(streams, K, D, args.header_ahead)
     pipe.run(max(pipe.R, pipe.K))       # priming (untimed, before the warm-up): every decoder set once, so that first-touch
     pipe.run(args.warmup)               # allocations of the pools (hipMalloc / hipHostMalloc) are not what the steps measure
     barrier()
@@ -257,7 +265,7 @@ def main():
     ctx.profile(True); ctx.kernel_stats(reset=True)
     g = pipe.decoded
     t0 = time.perf_counter()
-    pipe._submit(pipe.key_prep[g % pipe.R]); pipe._submit(pipe.inter_prep[g % pipe.R]); pipe.keys += 1; pipe.inters += 1
+    pipe._submit(pipe.key_prep[g % pipe.R]); pipe._submit(pipe.inter_prep[g % pipe.R]); pipe.keys += 1; pipe.inter_h += 1; pipe.inters += 1
     ctx.sync()
     t_parse_alone = time.perf_counter() - t0
     pipe.decode(release=False)
@@ -357,7 +365,7 @@ def main():
         for n in [int(x) for x in args.small_batches.split(",") if x]:
             if n >= S:
                 continue
-            p = Pipeline(streams[:n], args.key_ahead, args.depth)
+            p = Pipeline(streams[:n], pipe_K, pipe_D, args.header_ahead)
             p.run(2); ctx.sync()
             reps = max(4, p.K)
             t0 = time.perf_counter()
@@ -426,7 +434,7 @@ def main():
                                    % (args.config, S, width, height, F, shape, cfg[3], cfg[4]),
                        "streams_per_gpu": S, "frames_per_stream": F, "macroblocks_per_step_per_gpu": mbs_per_step,
                        "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective",
-                       "schedule": args.schedule, "key_frames_ahead": pipe_K, "inter_frames_ahead": pipe_D, "decoder_sets": pipe_R, "host_threads": threads,
+                       "schedule": args.schedule, "key_frames_ahead": pipe_K, "inter_frames_ahead": pipe_D, "inter_headers_ahead_of_tokens": args.header_ahead, "decoder_sets": pipe_R, "host_threads": threads,
                        "hbm_in_use_after_timed_region_gb": round((hbm_total - hbm_free) / 1e9, 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "kernels": roofs, "units_per_step": units, "launches_per_step": launches_per_step, "device_half": device_half,

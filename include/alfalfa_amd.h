@@ -190,6 +190,14 @@ aa_status aa_stream_decode( aa_stream * s, const uint8_t * data, size_t size, in
  * returned (same classes as aa_stream_parse). */
 typedef struct aa_frame_in { aa_stream * stream; const uint8_t * data; size_t size; } aa_frame_in;
 aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int * frame_index_out, int threads );
+/* Two-phase form, for callers that pipeline many batches and are bound by HBM: with AA_SUBMIT_DEFER_TOKENS the call does the
+ * header pre-pass, the upload and the macroblock-header kernel (first partition) and allocates only the macroblock records;
+ * the token kernel (DCT partitions) and the coefficient blocks -- 9/10 of a frame's records, worst-case sized -- wait for
+ * aa_launch_tokens, which takes the oldest `max_batches` deferred batches (<= 0: all).  Anything that needs a deferred
+ * frame's records (aa_decode_batch, aa_stream_frame_header, aa_stream_read_records) launches its batch's tokens itself. */
+#define AA_SUBMIT_DEFER_TOKENS 1u
+aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, int * frame_index_out, int threads, unsigned flags );
+aa_status aa_launch_tokens( aa_ctx * ctx, int max_batches, int * launched_out );
 /* Header of an appended frame.  For device-parsed frames the counts (num_coeff_blocks, num_intra_mbs, has_intra_mb) are known
  * only once the parse has run: this call waits for it. */
 aa_status aa_stream_frame_header( aa_stream * s, int frame_index, aa_frame_header * out );

@@ -179,3 +179,49 @@ def test_async_download_into_pinned_memory(gpu_ctx):
     for i, p in enumerate(bufs):
         assert sha256(C.string_at(p.value, ysz + usz + vsz)) == GOLDEN[name]["raster_sha256"][i], i
         L.aa_pinned_free(p)
+
+
+def test_two_phase_submit(gpu_ctx):
+    """AA_SUBMIT_DEFER_TOKENS: macroblock headers at submit, tokens (and the coefficient blocks) at aa_launch_tokens -- or at
+    the first call that needs the records.  Deferred and one-shot batches interleave; frames may be released in between."""
+    import vp8_synth
+    w, h, frames = golden_frames("cif_q60_lf40s5")
+    want = GOLDEN["cif_q60_lf40s5"]["raster_sha256"]
+    syn = vp8_synth.feature_stream(175, 143, 219, 6).frames
+    a, b, c = aa.Decoder(gpu_ctx, w, h), aa.Decoder(gpu_ctx, w, h), aa.Decoder(gpu_ctx, 175, 143)
+    host, hsyn = aa.Parser(w, h), aa.Parser(175, 143)
+    free0 = gpu_ctx.memory()[0]
+    ia = gpu_ctx.submit_frames([(a, fr) for fr in frames[:4]], defer_tokens=True)          # batch 1 (deferred)
+    ic = gpu_ctx.submit_frames([(c, fr) for fr in syn], defer_tokens=True)                 # batch 2 (deferred)
+    ib = gpu_ctx.submit_frames([(b, fr) for fr in frames[:4]])                             # batch 3 (one shot)
+    assert ia == [0, 1, 2, 3] and ib == [0, 1, 2, 3]
+    assert gpu_ctx.launch_tokens(1) == 1                                                   # batch 1
+    for f in range(4):
+        want_rec = host.parse(frames[f])
+        assert_records_equal(a.read_records(f), want_rec, "deferred frame %d" % f)
+        assert_records_equal(b.read_records(f), want_rec, "one-shot frame %d" % f)
+        gpu_ctx.decode_batch([a, b], [f, f])
+        assert sha256(a.raster_bytes(f)) == want[f] and sha256(b.raster_bytes(f)) == want[f]
+    # batch 2 was never launched explicitly: the first use of its records does it
+    ora = vo.OracleDecoder(175, 143)
+    for f, fr in enumerate(syn):
+        if f == 0:
+            assert_records_equal(c.read_records(0), hsyn.parse(fr), "implicit launch")
+        else:
+            hsyn.parse(fr)
+        gpu_ctx.decode_batch([c], [f])
+        ora.decode(fr)
+        assert c.raster_bytes(f) == ora.raster_bytes(), f
+    assert gpu_ctx.launch_tokens(0) == 0
+    # a deferred batch whose frames go away before the second phase
+    d = aa.Decoder(gpu_ctx, w, h)
+    gpu_ctx.submit_frames([(d, fr) for fr in frames[:3]], defer_tokens=True)
+    del d
+    assert gpu_ctx.launch_tokens(0) == 0
+    # ... and the stream carries on after a deferred batch like after any other
+    ia2 = gpu_ctx.submit_frames([(a, fr) for fr in frames[4:8]], defer_tokens=True)
+    assert ia2 == [4, 5, 6, 7]
+    for f in ia2:
+        gpu_ctx.decode_batch([a], [f])
+        assert sha256(a.raster_bytes(f)) == want[f]
+    assert free0 > 0
