@@ -330,6 +330,8 @@ __device__ __forceinline__ void recon_inter_body( const aa_dev_frame & f, const 
 // grid.x = macroblock (XCD-aware order), grid.y = frame in batch
 __global__ __launch_bounds__( kLanes ) void k_recon_inter( const aa_frame_list list, const unsigned max_mbs, const int split_only )
 {
+  __builtin_amdgcn_s_setprio( 3 );      // reconstruction shares the SIMDs with seconds-long entropy-decode waves: win the issue arbitration
+
   __shared__ InterLds L;
   recon_inter_body( *list.f[blockIdx.y], blockIdx.x, max_mbs, L, split_only != 0 );
 }
@@ -499,6 +501,10 @@ __global__ __launch_bounds__( kLanes ) void k_recon_intra( const aa_frame_list l
 //     lands on each XCD (the grid has n_xcd x the work of the fullest queue; with the observed round-robin placement
 //     block b -> XCD b % 8 every workgroup takes exactly one ticket).
 // Every spin is bounded; on expiry the kernel records an error code and carries on (the host reports AA_ERR_HIP).
+// Bound of a hand-off wait.  The wait cannot deadlock (see above) but the workgroup waited for may be slow: reconstruction
+// runs beside thousands of entropy-decode waves that hold their SIMDs for seconds.  The bound is therefore far beyond any
+// delay load can cause (minutes of spinning); it exists so that a broken hand-off ends in an error, never in a hung GPU.
+constexpr int kMaxSpins = 1 << 26;
 __device__ __forceinline__ int xcc_id() { return static_cast<int>( __builtin_amdgcn_s_getreg( 20 | ( 0 << 6 ) | ( 3 << 11 ) ) ); }   // HW_REG_XCC_ID[3:0]
 
 __device__ __forceinline__ int take_ticket( aa_sync_ws * ws, const int xcc, int * slot, const int lane )
@@ -792,7 +798,7 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
           // the hand-off is only coherent inside the XCD the ticket was taken on: a wave that finds itself elsewhere says so
           if ( xcc_id() != home_xcc ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 4 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( home_xcc << 16 ) | xcc_id(); } break; }
         }
-        if ( spins > ( 1 << 21 ) ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 1 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( need << 16 ) | ( seen & 0xFFFF ); } break; }
+        if ( spins > kMaxSpins ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 1 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( need << 16 ) | ( seen & 0xFFFF ); } break; }
       }
     }
     const int x0 = col * 16, cx0 = col * 8;
@@ -889,6 +895,8 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
 
 __global__ __launch_bounds__( kLanes ) void k_recon_intra4( const aa_frame_list list, const int n_groups, const int mbh_max, aa_sync_ws * ws, const int n_xcd )
 {
+  __builtin_amdgcn_s_setprio( 3 );      // reconstruction shares the SIMDs with seconds-long entropy-decode waves: win the issue arbitration
+
   __shared__ Intra4Lds L;
   __shared__ int s_ticket;
   for ( int i = threadIdx.x; i < 160; i += kLanes ) {       // (mode, pixel) -> three tile offsets, above-right flags, kind
@@ -1153,6 +1161,8 @@ __device__ __forceinline__ void recon_inter4_body( const aa_dev_frame & f, const
 // grid.x = quad of macroblocks (XCD-aware order), grid.y = frame in batch
 __global__ __launch_bounds__( kLanes ) void k_recon_inter4( const aa_frame_list list, const unsigned max_quads )
 {
+  __builtin_amdgcn_s_setprio( 3 );      // reconstruction shares the SIMDs with seconds-long entropy-decode waves: win the issue arbitration
+
   __shared__ Inter4Lds L;
   recon_inter4_body( *list.f[blockIdx.y], blockIdx.x, max_quads, L );
 }
@@ -1356,7 +1366,7 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
             // under queue oversubscription) says so instead of waiting for the watchdog
             if ( xcc_id() != home_xcc ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 4 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( home_xcc << 16 ) | xcc_id(); } break; }
           }
-          if ( spins > ( 1 << 21 ) ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 2 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( need << 16 ) | ( seen & 0xFFFF ); } break; }
+          if ( spins > kMaxSpins ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 2 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( need << 16 ) | ( seen & 0xFFFF ); } break; }
         }
         // rows -4..-1: the boundary line the row above left for this macroblock (sc1: bypass L1, served by the XCD's L2)
         if ( frame_on && l < 8 && !( dbg & 8 ) ) {
@@ -1450,6 +1460,8 @@ __device__ __forceinline__ void loopfilter_rows4_body( const aa_frame_list & lis
 __global__ __launch_bounds__( kLanes ) __attribute__( ( amdgpu_waves_per_eu( 2 ) ) ) void k_loopfilter_rows4( const aa_frame_list list, const int n_groups, const int mbh_max, const int mbw_max, aa_sync_ws * ws, uint8_t * bnd,
                                                                  const int n_xcd, const int dbg )
 {
+  __builtin_amdgcn_s_setprio( 3 );      // reconstruction shares the SIMDs with seconds-long entropy-decode waves: win the issue arbitration
+
   __shared__ LfStripLds S;
   __shared__ int s_ticket;
   loopfilter_rows4_body( list, n_groups, mbh_max, mbw_max, ws, bnd, n_xcd, S, s_ticket, dbg );

@@ -29,6 +29,8 @@ using aa::ParseJob;
 // that the lanes of a wave finish together (a wave lasts as long as its longest lane)
 __global__ __launch_bounds__( 64 ) void k_parse_mb_headers( const ParseJob * jobs, const uint32_t * order, int n, int lanes )
 {
+  __builtin_amdgcn_s_setprio( 2 );      // short chains the long token chains wait for: ahead of them at the issue arbiter
+
   const int lane = threadIdx.x;
   const int slot = blockIdx.x * lanes + lane;
   if ( lane >= lanes || slot >= n ) return;

@@ -178,6 +178,7 @@ def main():
             self.inter_prep = [ctx.prepare_frames([(d, fr) for d, st in zip(ds, stream_list) for fr in st[1:]]) for ds in self.sets]
             self.keys = self.inters = self.decoded = 0      # groups handed to the GPU parser (key / inter frames), groups reconstructed
             self.host_s = 0.0
+            self.t_launch = self.t_decode = self.t_release = 0.0      # host time in aa_launch_tokens / aa_decode_batch / releases
             self.done_t = []
 
         def _submit(self, prep, defer_tokens=False):
@@ -189,10 +190,13 @@ def main():
             g = self.decoded
             ds, base = self.sets[g % self.R], (g // self.R) * F
             for f in range(F):
+                t = time.perf_counter()
                 ctx.decode_batch(ds, [base + f] * self.n)
+                t1 = time.perf_counter(); self.t_decode += t1 - t
                 if release:             # this frame is consumed: its records go back to the pool once the kernels queued so far
                     for d in ds:        # have run, its raster when nothing refers to it any more (RasterHandle semantics)
                         d.release_before(base + f + 1)
+                    self.t_release += time.perf_counter() - t1
             self.decoded += 1
             self.done_t.append(time.perf_counter())
 
@@ -208,7 +212,9 @@ def main():
                     elif self.inter_h < min(target, self.decoded + self.D + self.H, self.keys):
                         self._submit(self.inter_prep[self.inter_h % self.R], defer_tokens=True); self.inter_h += 1
                     elif self.inters < min(target, self.decoded + self.D, self.inter_h):
+                        t = time.perf_counter()
                         ctx.launch_tokens(1); self.inters += 1
+                        self.t_launch += time.perf_counter() - t
                     else:
                         break
                 self.decode()
@@ -232,7 +238,7 @@ def main():
     pipe.run(max(pipe.R, pipe.K))       # priming (untimed, before the warm-up): every decoder set once, so that first-touch
     pipe.run(args.warmup)               # allocations of the pools (hipMalloc / hipHostMalloc) are not what the steps measure
     barrier()
-    pipe.host_s = 0.0; pipe.done_t = []
+    pipe.host_s = pipe.t_launch = pipe.t_decode = pipe.t_release = 0.0; pipe.done_t = []
     ctx.kernel_stats(reset=True)
     if args.profile_timed:
         ctx.profile(True)
@@ -243,6 +249,9 @@ def main():
     hbm_free, hbm_total = ctx.memory()
     tstats = ctx.kernel_stats(reset=True); ctx.profile(False)
     timed_region = {"step_done_at_ms": [round((t - t0) * 1e3) for t in pipe.done_t],
+                    "host_ms_per_step": {"submit": round(pipe.host_s / args.steps * 1e3, 1), "launch_tokens": round(pipe.t_launch / args.steps * 1e3, 1),
+                                         "decode_batch_calls_incl_wait_for_parse": round(pipe.t_decode / args.steps * 1e3, 1),
+                                         "release": round(pipe.t_release / args.steps * 1e3, 1)},
                     "host_waited_for_parse_ms_per_step": round(tstats["parse_wait_ms"] / args.steps, 2),
                     "pool_waits": tstats["pool_waits"], "pool_wait_ms_per_step": round(tstats["pool_wait_ms"] / args.steps, 2)}
     if args.profile_timed:
