@@ -62,9 +62,9 @@ def parse_args():
     ap.add_argument("--config", default="1080p_inter_lf")
     ap.add_argument("--streams", type=int, default=480, help="independent streams per GPU")
     ap.add_argument("--frames", type=int, default=12, help="frames per stream per step")
-    ap.add_argument("--key-ahead", type=int, default=10, help="steps by which KEY frames are handed to the GPU parser ahead of reconstruction")
+    ap.add_argument("--key-ahead", type=int, default=9, help="steps by which KEY frames are handed to the GPU parser ahead of reconstruction")
     ap.add_argument("--depth", type=int, default=4, help="steps by which inter frames are handed to the GPU parser ahead of reconstruction")
-    ap.add_argument("--header-ahead", type=int, default=1, help="steps by which the macroblock-header pass of inter frames runs ahead of their token pass (two-phase submit)")
+    ap.add_argument("--header-ahead", type=int, default=0, help="steps by which the macroblock-header pass of inter frames runs ahead of their token pass (two-phase submit)")
     ap.add_argument("--threads", type=int, default=0, help="host workers of the header pre-pass (0: cores / local ranks)")
     ap.add_argument("--schedule", default="rows", choices=["rows", "diagonal"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -261,8 +261,15 @@ def main():
     # parse a step waited for was done) -- the timed region itself also pays for filling and draining the pipeline
     gaps = sorted(b - a for a, b in zip(pipe.done_t, pipe.done_t[1:]))
     steady_ms = gaps[len(gaps) // 2] * 1e3 if gaps else None
+    per_rank = None
     if dist is not None:
         import torch
+        mine = torch.tensor([elapsed, pipe.host_s / max(1, args.steps), tstats["parse_wait_ms"] / max(1, args.steps) * 1e-3, float(threads)],
+                            dtype=torch.float64, device="cuda")
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"rank": r, "elapsed_s": round(float(v[0]), 4), "host_prepass_and_staging_s_per_step": round(float(v[1]), 4),
+                     "host_waited_for_parse_s_per_step": round(float(v[2]), 4), "host_threads": int(v[3])} for r, v in enumerate(every)]
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -452,7 +459,7 @@ def main():
             "stages": {"host_prepass_and_staging_s_per_step": round(host_submit_s, 4),
                        "entropy_decode_alone_s_per_step": round(t_parse_alone, 4),
                        "note": "entropy_decode_alone = one step's submit -> parse finished with nothing else on the GPU (a latency: the longest chain, a key frame)"},
-            "timed_region": timed_region, "small_batches": small,
+            "timed_region": timed_region, "per_rank": per_rank, "small_batches": small,
             "host": {"parser_mb_per_s_per_core": round(parser_only, 1), "stream_generation_s": round(t_gen, 1)},
             "kernel_stats": kstats, "verified_bit_exact_vs_reference": verified, "entry_state_handoff": handoff,
         }

@@ -62,7 +62,7 @@ def main():
             db = os.path.join(d, name + "_results.db")
             if not os.path.exists(db):
                 continue
-            for k, v in sorted(per_kernel(db).items()):
+            for k, v in sorted(per_kernel(db).items()):  # noqa
                 for pn, vals in sorted(v.items()):
                     vs = [x[0] for x in vals]
                     out.append("%s %s %s launches %d avg %.4g max %.4g avg_dur_us %.1f" % (name, k, pn, len(vs), sum(vs) / len(vs), max(vs), sum(x[1] for x in vals) / len(vals) / 1e3))
@@ -78,7 +78,8 @@ def main():
             f = tot[k]["FETCH_SIZE"][0] * 1024 / (steps_f * units[k]); w = tot[k]["WRITE_SIZE"][0] * 1024 / (steps_w * units[k])
             t[k] = round(2 * f + w, 1)
             out.append("| %s | %d | %.0f | %.0f | %.0f | %.0f | %d | %.2f |" % (k, units[k], f, w, f + w, 2 * f + w, alg[k], (2 * f + w) / alg[k]))
-        traffic[cfg] = t
+        if t:
+            traffic[cfg] = t
         open(os.path.join(ROOT, "profiles", "%s_%s.md" % (tag, cfg)), "w").write("\n".join(out) + "\n")
         print("wrote profiles/%s_%s.md" % (tag, cfg))
     json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
