@@ -18,6 +18,8 @@
 // events -- macroblock / row boundaries -- then stall few neighbours) and spread over as many SIMDs as there are chains.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device_types.h"
 #include "tok_fsm.hh"
 
@@ -100,19 +102,49 @@ __global__ __launch_bounds__( 64 ) void k_parse_tokens( const ParseJob * jobs, c
 
 namespace aa {
 
-static int parse_lanes()
+// ALFALFA_AMD_PARSE_LANES=n: n token lanes per workgroup, whatever that does to occupancy (experiments); 0 / unset: chosen
+// per launch by token_launch_shape().
+static int parse_lanes_env()
 {
   static const int lanes = [] {
     const char * e = getenv( "ALFALFA_AMD_PARSE_LANES" );
-    const int v = e ? atoi( e ) : 16;
-    return v < 1 ? 1 : ( v > 64 ? 64 : v );
+    const int v = e ? atoi( e ) : 0;
+    return v < 0 ? 0 : ( v > 64 ? 64 : v );
   }();
   return lanes;
+}
+static int header_lanes() { const int v = parse_lanes_env(); return v ? v : 16; }
+
+// Token workgroups live for seconds and a CU holds as many as its LDS takes, so the LDS they leave is all that the
+// reconstruction kernels (milliseconds, launched on the high-priority stream) can start in while a parse is running: with the
+// LDS fully booked, reconstruction only advances as fast as token workgroups retire.  Shape the launch so that a CU full of
+// token workgroups still has `kLdsReserve` bytes free on every CU (a loop-filter workgroup: 18.7 KB, two inter-prediction
+// workgroups: 2 x 11 KB): n workgroups of `lanes` lanes per CU, their LDS request padded so that an (n + 1)-th does not fit.
+// (A step costs the wave the same whatever its width, but the rarer paths -- a coefficient emitted, a block or macroblock ended
+// -- run whenever ANY lane needs them: beyond ~24 lanes a wave spends most steps in them.)
+constexpr uint32_t kLdsPerCu = 160u * 1024u, kLdsReserve = 24u * 1024u, kLdsGranule = 512u, kMaxLanes = 24u;
+struct TokenShape { int lanes; uint32_t lds; };
+static TokenShape token_launch_shape( uint32_t lane_bytes )
+{
+  TokenShape best { 0, 0 };
+  int best_total = 0;
+  for ( uint32_t n = 1; n <= 16; n++ ) {
+    const uint32_t maxp = std::min<uint32_t>( 65536u, ( kLdsPerCu - kLdsReserve ) / n / kLdsGranule * kLdsGranule );
+    if ( maxp < tok::kTablesBytes + lane_bytes ) break;
+    const int lanes = static_cast<int>( std::min<uint32_t>( kMaxLanes, ( maxp - tok::kTablesBytes ) / lane_bytes ) );
+    const uint32_t need = ( static_cast<uint32_t>( lanes ) * lane_bytes + tok::kTablesBytes + kLdsGranule - 1 ) / kLdsGranule * kLdsGranule;
+    const uint32_t excl = ( kLdsPerCu / ( n + 1 ) / kLdsGranule + 1 ) * kLdsGranule;      // smallest request of which n + 1 do not fit
+    const uint32_t p = std::max( need, excl );
+    if ( p > maxp ) continue;
+    const int total = static_cast<int>( n ) * lanes;
+    if ( total >= best_total ) { best_total = total; best = { lanes, p }; }                // ties: more, narrower workgroups (n ascending)
+  }
+  return best;
 }
 
 int launch_parse_mb_headers( const ParseJob * jobs, const uint32_t * order, int n, void * stream )
 {
-  const int lanes = parse_lanes();
+  const int lanes = header_lanes();
   hipLaunchKernelGGL( k_parse_mb_headers, dim3( ( n + lanes - 1 ) / lanes ), dim3( 64 ), 0, static_cast<hipStream_t>( stream ), jobs, order, n, lanes );
   return static_cast<int>( hipGetLastError() );
 }
@@ -126,11 +158,17 @@ int launch_segment_fixup( const ParseJob * jobs, const aa_seg_stream * streams, 
 int launch_parse_tokens( const ParseJob * jobs, const uint32_t * order, int n, int max_mbw, int max_nparts, void * stream )
 {
   const uint32_t lane_bytes = tok::lane_lds_bytes( static_cast<uint32_t>( max_mbw ), max_nparts > 1 );
-  int lanes = parse_lanes();
-  if ( static_cast<uint32_t>( lanes ) * lane_bytes + tok::kTablesBytes > 65536u ) lanes = static_cast<int>( ( 65536u - tok::kTablesBytes ) / lane_bytes );
+  int lanes = parse_lanes_env();
+  uint32_t lds = 0;
+  if ( lanes ) {
+    if ( static_cast<uint32_t>( lanes ) * lane_bytes + tok::kTablesBytes > 65536u ) lanes = static_cast<int>( ( 65536u - tok::kTablesBytes ) / lane_bytes );
+    lds = static_cast<uint32_t>( lanes ) * lane_bytes + tok::kTablesBytes;
+  } else {
+    const TokenShape sh = token_launch_shape( lane_bytes );
+    lanes = sh.lanes; lds = sh.lds;
+  }
   if ( lanes < 1 ) return static_cast<int>( hipErrorInvalidValue );
-  hipLaunchKernelGGL( k_parse_tokens, dim3( ( n + lanes - 1 ) / lanes ), dim3( 64 ), static_cast<size_t>( lanes ) * lane_bytes + tok::kTablesBytes,
-                      static_cast<hipStream_t>( stream ), jobs, order, n, lanes, lane_bytes );
+  hipLaunchKernelGGL( k_parse_tokens, dim3( ( n + lanes - 1 ) / lanes ), dim3( 64 ), lds, static_cast<hipStream_t>( stream ), jobs, order, n, lanes, lane_bytes );
   return static_cast<int>( hipGetLastError() );
 }
 
