@@ -122,7 +122,10 @@ static int header_lanes() { const int v = parse_lanes_env(); return v ? v : 16; 
 // workgroups: 2 x 11 KB): n workgroups of `lanes` lanes per CU, their LDS request padded so that an (n + 1)-th does not fit.
 // (A step costs the wave the same whatever its width, but the rarer paths -- a coefficient emitted, a block or macroblock ended
 // -- run whenever ANY lane needs them: beyond ~24 lanes a wave spends most steps in them.)
-constexpr uint32_t kLdsPerCu = 160u * 1024u, kLdsReserve = 24u * 1024u, kLdsGranule = 512u, kMaxLanes = 24u;
+constexpr uint32_t kLdsPerCu = 160u * 1024u, kLdsGranule = 512u;
+static uint32_t env_u32( const char * name, uint32_t dflt ) { const char * e = getenv( name ); return e ? static_cast<uint32_t>( atoi( e ) ) : dflt; }
+static const uint32_t kLdsReserve = env_u32( "ALFALFA_AMD_LDS_RESERVE_KB", 24u ) * 1024u;      // (the two knobs: experiments)
+static const uint32_t kMaxLanes = std::max( 1u, std::min( 64u, env_u32( "ALFALFA_AMD_MAX_LANES", 24u ) ) );
 struct TokenShape { int lanes; uint32_t lds; };
 static TokenShape token_launch_shape( uint32_t lane_bytes )
 {
