@@ -40,7 +40,7 @@ thread_local std::string g_last_error;
 // The entropy-decode kernels are long (a chain per lane, seconds) and must run BESIDE reconstruction and beside each other.
 // HIP spreads streams over few hardware queues by default (4), and commands of one queue run in order: with more streams
 // than queues a decode launch can end up queued behind a parse kernel.  Ask for more queues before the runtime starts.
-struct RuntimeEnv { RuntimeEnv() { setenv( "GPU_MAX_HW_QUEUES", "16", 0 ); } } g_runtime_env;
+struct RuntimeEnv { RuntimeEnv() { setenv( "GPU_MAX_HW_QUEUES", "24", 0 ); } } g_runtime_env;
 
 aa_status fail( aa_status code, const std::string & msg ) { g_last_error = msg; return code; }
 aa_status hip_fail( hipError_t e, const char * what )
@@ -81,6 +81,7 @@ struct Batch {
   const uint32_t * launch_order_dev = nullptr;
   int max_mbw = 0, max_nparts = 1;
   hipStream_t ps = nullptr;
+  int parse_stream_index = 0;
   struct Item { aa_stream * s; int frame; bool live; };
   std::vector<Item> items;                   // [n]; live: accepted and not released since
 };
@@ -130,8 +131,13 @@ struct aa_ctx {
   struct BindBuf { aa_raster_binding * host = nullptr, * dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
   BindBuf bind_bufs[4];
   int next_bind_buf = 0;
-  static constexpr int kParseStreams = 12;
-  hipStream_t parse_streams[kParseStreams] = {};
+  // A parse batch holds its stream for as long as its longest chain (seconds for a key frame): a batch queued behind another
+  // one on the same stream starts that much later.  Hence one stream per batch that can be in flight, and a batch goes to a
+  // stream that has nothing queued (pick_parse_stream).
+  static constexpr int kMaxParseStreams = 20;
+  int n_parse_streams = 16;
+  std::vector<hipStream_t> parse_streams;
+  std::vector<hipEvent_t> parse_idle;    // recorded behind the last operation queued on the stream
   int prio_low = 0;
   int next_parse_stream = 0;
   hipEvent_t last_seg_batch = nullptr;  // segment-map passes of consecutive batches must run in order
@@ -632,7 +638,11 @@ aa_status aa_ctx_create( int device, aa_ctx ** out )
   }
   HIP_TRY( hipStreamCreateWithFlags( &ctx->copy, hipStreamNonBlocking ) );
   HIP_TRY( hipEventCreateWithFlags( &ctx->upload_done, hipEventDisableTiming ) );
+  if ( const char * e = getenv( "ALFALFA_AMD_PARSE_STREAMS" ) ) ctx->n_parse_streams = std::max( 1, std::min( aa_ctx::kMaxParseStreams, atoi( e ) ) );
+  ctx->parse_streams.assign( ctx->n_parse_streams, nullptr );
+  ctx->parse_idle.assign( ctx->n_parse_streams, nullptr );
   for ( auto & ps : ctx->parse_streams ) HIP_TRY( hipStreamCreateWithPriority( &ps, hipStreamNonBlocking, ctx->prio_low ) );
+  for ( auto & e : ctx->parse_idle ) HIP_TRY( hipEventCreateWithFlags( &e, hipEventDisableTiming ) );
   if ( const char * e = std::getenv( "ALFALFA_AMD_SCHEDULE" ) ) ctx->schedule = std::string( e ) == "diagonal" ? 1 : 0;
   // The row-pipelined kernels keep every unit on one XCD (per-XCD ticket queues indexed by the hardware XCC_ID): find
   // out which XCC ids workgroups of this device really land on.  They must be 0..n-1, each reached by a modest grid.
@@ -669,6 +679,7 @@ static void ctx_free( aa_ctx * ctx )
   (void) hipSetDevice( ctx->device );
   (void) hipStreamSynchronize( ctx->compute ); (void) hipStreamSynchronize( ctx->copy );
   for ( auto ps : ctx->parse_streams ) if ( ps ) { (void) hipStreamSynchronize( ps ); (void) hipStreamDestroy( ps ); }
+  for ( auto e : ctx->parse_idle ) if ( e ) (void) hipEventDestroy( e );
   for ( auto & ee : ctx->epoch_events ) (void) hipEventDestroy( ee.second );
   if ( ctx->last_seg_batch ) (void) hipEventDestroy( ctx->last_seg_batch );
   drain_profile( ctx );
@@ -988,6 +999,7 @@ aa_status launch_tokens_of( aa_ctx * ctx, Batch * b )
   }
   HIP_TRY( hipMemcpyAsync( b->host + b->summaries_off, b->dev + b->summaries_off, size_t( b->n ) * sizeof( aa::FrameSummary ), hipMemcpyDeviceToHost, ps ) );
   HIP_TRY( hipEventRecord( b->done, ps ) );
+  HIP_TRY( hipEventRecord( ctx->parse_idle[b->parse_stream_index], ps ) );
   b->done_seen = false;
   return AA_OK;
 }
@@ -1099,8 +1111,16 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   aa_seg_stream * seg_streams = reinterpret_cast<aa_seg_stream *>( b->host + jobs_bytes + dframes_bytes + sums_bytes );
   uint32_t * seg_order = reinterpret_cast<uint32_t *>( seg_streams + n );
   int n_seg_streams = 0; uint32_t n_seg_order = 0;
-  hipStream_t ps = ctx->parse_streams[ctx->next_parse_stream];
-  ctx->next_parse_stream = ( ctx->next_parse_stream + 1 ) % aa_ctx::kParseStreams;
+  // a stream with nothing queued if there is one (else the next in turn: the batch waits behind that stream's work)
+  int pick = ctx->next_parse_stream;
+  for ( int k = 0; k < ctx->n_parse_streams; k++ ) {
+    const int c = ( ctx->next_parse_stream + k ) % ctx->n_parse_streams;
+    if ( hipEventQuery( ctx->parse_idle[c] ) == hipSuccess ) { pick = c; break; }
+  }
+  (void) hipGetLastError();
+  ctx->next_parse_stream = ( pick + 1 ) % ctx->n_parse_streams;
+  b->parse_stream_index = pick;
+  hipStream_t ps = ctx->parse_streams[pick];
   for ( aa_stream * s : stream_order ) {
     bool any = false;
     for ( int i : by_stream[s] ) if ( items[i].status == AA_OK && items[i].seg_enabled ) any = true;
@@ -1149,6 +1169,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   b->ps = ps; b->launch_order_dev = launch_order_dev;
   b->tokens_pending = true;
   HIP_TRY( hipEventRecord( b->done, ps ) );        // (the header kernel; recorded again behind the token kernel)
+  HIP_TRY( hipEventRecord( ctx->parse_idle[pick], ps ) );
   ctx->deferred.push_back( b.get() );
   Batch * raw = b.release();
   if ( !defer_tokens ) if ( aa_status st = launch_tokens_of( ctx, raw ) ) return st;
