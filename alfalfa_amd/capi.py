@@ -48,7 +48,8 @@ class KernelStats(C.Structure):
                 ("loopfilter_launches", C.c_uint64), ("macroblocks", C.c_uint64),
                 ("parse_headers_ms", C.c_double), ("parse_tokens_ms", C.c_double), ("parse_launches", C.c_uint64),
                 ("parsed_macroblocks", C.c_uint64), ("recon_split_ms", C.c_double), ("recon_split_launches", C.c_uint64),
-                ("pool_waits", C.c_uint64), ("pool_wait_ms", C.c_double), ("parse_wait_ms", C.c_double)]
+                ("pool_waits", C.c_uint64), ("pool_wait_ms", C.c_double), ("parse_wait_ms", C.c_double),
+                ("bind_wait_ms", C.c_double), ("alloc_ms", C.c_double), ("slab_mallocs", C.c_uint64)]
 
 
 class AlfalfaError(RuntimeError):

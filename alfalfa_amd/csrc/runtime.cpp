@@ -229,6 +229,8 @@ aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out )
 {
   bytes = align_up( bytes );
   std::lock_guard<std::mutex> g( ctx->pool_mu );
+  struct Clock { aa_ctx * c; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                 ~Clock() { c->stats.alloc_ms += std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count(); } } clock { ctx };
   for ( int attempt = 0; attempt < 3; attempt++ ) {
     auto it = ctx->dev_free.find( bytes );
     if ( it != ctx->dev_free.end() && !it->second.empty() ) { *out = it->second.back(); it->second.pop_back(); return AA_OK; }
@@ -236,11 +238,13 @@ aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out )
     hipError_t e;
     if ( bytes > kSlabBytes / 2 ) {                 // big pieces get their own allocation (still recycled through the free list)
       e = hipMalloc( reinterpret_cast<void **>( out ), bytes );
+      ctx->stats.slab_mallocs++;
       if ( e == hipSuccess ) { ctx->dev_slabs.push_back( *out ); return AA_OK; }
     } else {
       if ( ctx->cur_slab && ctx->slab_used + bytes <= kSlabBytes ) { *out = ctx->cur_slab + ctx->slab_used; ctx->slab_used += bytes; return AA_OK; }
       uint8_t * slab = nullptr;
       e = hipMalloc( reinterpret_cast<void **>( &slab ), kSlabBytes );
+      ctx->stats.slab_mallocs++;
       if ( e == hipSuccess ) {
         ctx->dev_slabs.push_back( slab ); ctx->cur_slab = slab; ctx->slab_used = bytes;
         *out = slab;
@@ -475,7 +479,12 @@ aa_status bind_batch( aa_ctx * ctx, aa_stream * const * streams, int n, const in
   if ( !need ) return AA_OK;
   aa_ctx::BindBuf & bb = ctx->bind_bufs[ctx->next_bind_buf];
   ctx->next_bind_buf = ( ctx->next_bind_buf + 1 ) % 4;
-  if ( bb.busy ) { HIP_TRY( hipEventSynchronize( bb.done ) ); bb.busy = false; }
+  if ( bb.busy ) {
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY( hipEventSynchronize( bb.done ) );
+    bb.busy = false;
+    ctx->stats.bind_wait_ms += std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count();
+  }
   if ( bb.cap < static_cast<size_t>( need ) ) {
     if ( bb.host ) (void) hipHostFree( bb.host );
     if ( bb.dev ) (void) hipFree( bb.dev );

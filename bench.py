@@ -253,6 +253,8 @@ def main():
                                          "decode_batch_calls_incl_wait_for_parse": round(pipe.t_decode / args.steps * 1e3, 1),
                                          "release": round(pipe.t_release / args.steps * 1e3, 1)},
                     "host_waited_for_parse_ms_per_step": round(tstats["parse_wait_ms"] / args.steps, 2),
+                    "host_waited_for_compute_stream_ms_per_step": round(tstats["bind_wait_ms"] / args.steps, 2),
+                    "host_in_pool_allocator_ms_per_step": round(tstats["alloc_ms"] / args.steps, 2), "slab_mallocs": tstats["slab_mallocs"],
                     "pool_waits": tstats["pool_waits"], "pool_wait_ms_per_step": round(tstats["pool_wait_ms"] / args.steps, 2)}
     if args.profile_timed:
         timed_region["kernel_ms_per_step"] = {k: round(v / args.steps, 2) for k, v in tstats.items() if k.endswith("_ms") and "wait" not in k}

@@ -7,7 +7,7 @@ for item in $1; do
 import json
 l=[x for x in open("gpurun_out/rep_$name.log") if x.startswith("{")]
 if l:
-    j=json.loads(l[-1]); t=j["timed_region"]; print("$name value %.1fM" % (j["value"]/1e6), "mem", j["config"]["hbm_in_use_after_timed_region_gb"], "decode-call", t["host_ms_per_step"]["decode_batch_calls_incl_wait_for_parse"], "parse-wait", t["host_waited_for_parse_ms_per_step"], t["step_done_at_ms"])
+    j=json.loads(l[-1]); t=j["timed_region"]; print("$name value %.1fM" % (j["value"]/1e6), "mem", j["config"]["hbm_in_use_after_timed_region_gb"], "decode-call", t["host_ms_per_step"]["decode_batch_calls_incl_wait_for_parse"], "parse-wait", t["host_waited_for_parse_ms_per_step"], "compute-wait", t["host_waited_for_compute_stream_ms_per_step"], "alloc", t["host_in_pool_allocator_ms_per_step"], t["slab_mallocs"], t["step_done_at_ms"])
 else: print("$name failed", open("gpurun_out/rep_$name.log").read()[-800:])
 PY
 done
