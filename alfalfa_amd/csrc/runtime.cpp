@@ -73,10 +73,12 @@ struct Batch {
   hipEvent_t done = nullptr;                 // parse kernels finished and the summaries are back in `host`
   bool done_seen = false;
   size_t summaries_off = 0;
+  uint8_t * host_dev = nullptr;              // `host` as the device sees it (the parse kernels write the summaries there)
   // Two-phase form (AA_SUBMIT_DEFER_TOKENS): the macroblock-header kernel has been queued, the token kernel has not -- the
   // coefficient blocks (9/10 of a frame's records) are only allocated when it is (aa_launch_tokens, or the first call that
   // needs the frame's records).
   bool tokens_pending = false;
+  bool patch_jobs = false;                   // the jobs in HBM lack the coefficient pointers (two-phase form)
   size_t head_bytes = 0;                     // parse jobs + reconstruction job records at the start of the arena
   const uint32_t * launch_order_dev = nullptr;
   int max_mbw = 0, max_nparts = 1;
@@ -487,11 +489,12 @@ aa_status bind_batch( aa_ctx * ctx, aa_stream * const * streams, int n, const in
   }
   if ( bb.cap < static_cast<size_t>( need ) ) {
     if ( bb.host ) (void) hipHostFree( bb.host );
-    if ( bb.dev ) (void) hipFree( bb.dev );
     bb.host = nullptr; bb.dev = nullptr; bb.cap = 0;
     const size_t cap = std::max<size_t>( 512, size_t( need ) * 2 );
+    // pinned and mapped: the patch kernel reads the bindings over the bus.  (No copy engine on the reconstruction path: a small
+    // copy queues behind whatever the engine holds, and that can be a copy ordered behind a seconds-long parse kernel.)
     HIP_TRY( hipHostMalloc( reinterpret_cast<void **>( &bb.host ), cap * sizeof( aa_raster_binding ), hipHostMallocDefault ) );
-    HIP_TRY( hipMalloc( reinterpret_cast<void **>( &bb.dev ), cap * sizeof( aa_raster_binding ) ) );
+    HIP_TRY( hipHostGetDevicePointer( reinterpret_cast<void **>( &bb.dev ), bb.host, 0 ) );
     bb.cap = cap;
   }
   if ( !bb.done ) HIP_TRY( hipEventCreateWithFlags( &bb.done, hipEventDisableTiming ) );
@@ -501,7 +504,6 @@ aa_status bind_batch( aa_ctx * ctx, aa_stream * const * streams, int n, const in
     if ( aa_status st = bind_frame( streams[i], frame_index[i], &bb.host[k] ) ) return st;
     k++;
   }
-  HIP_TRY( hipMemcpyAsync( bb.dev, bb.host, size_t( k ) * sizeof( aa_raster_binding ), hipMemcpyHostToDevice, ctx->compute ) );
   if ( int e = aa::launch_bind_rasters( bb.dev, k, ctx->compute ) ) return hip_fail( static_cast<hipError_t>( e ), "k_bind_rasters" );
   HIP_TRY( hipEventRecord( bb.done, ctx->compute ) );
   bb.busy = true;
@@ -694,7 +696,7 @@ static void ctx_free( aa_ctx * ctx )
   drain_profile( ctx );
   for ( auto e : ctx->free_events ) (void) hipEventDestroy( e );
   (void) hipEventDestroy( ctx->upload_done );
-  for ( auto & bb : ctx->bind_bufs ) { if ( bb.host ) (void) hipHostFree( bb.host ); if ( bb.dev ) (void) hipFree( bb.dev ); if ( bb.done ) (void) hipEventDestroy( bb.done ); }
+  for ( auto & bb : ctx->bind_bufs ) { if ( bb.host ) (void) hipHostFree( bb.host ); if ( bb.done ) (void) hipEventDestroy( bb.done ); }
   if ( ctx->ws ) (void) hipFree( ctx->ws );
   if ( ctx->boundary ) (void) hipFree( ctx->boundary );
   for ( auto & pc : ctx->pinned_pool ) (void) hipHostFree( pc.first );
@@ -961,7 +963,7 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
   J.intra_rows = reinterpret_cast<unsigned long long *>( blk + mb_bytes );
   J.mbflags = blk + mb_bytes + rows_bytes;
   J.coeffs = reinterpret_cast<int16_t *>( rec.coeff_block );       // (null until aa_launch_tokens in the two-phase form)
-  J.summary = reinterpret_cast<aa::FrameSummary *>( b->dev + b->summaries_off ) + item;
+  J.summary = reinterpret_cast<aa::FrameSummary *>( b->host_dev + b->summaries_off ) + item;     // pinned + mapped: no copy back
 
   aa_dev_frame * job = &dframes_host[item];
   rec.hdr.has_intra_mb = 1;              // until the device parser has counted: the row masks say which macroblocks are intra
@@ -1000,13 +1002,12 @@ aa_status launch_tokens_of( aa_ctx * ctx, Batch * b )
     ctx->stats.parsed_macroblocks += jobs_host[i].nmb;
   }
   hipStream_t ps = b->ps;
-  HIP_TRY( hipMemcpyAsync( b->dev, b->host, b->head_bytes, hipMemcpyHostToDevice, ps ) );     // behind the header kernel on its stream
+  if ( b->patch_jobs ) HIP_TRY( hipMemcpyAsync( b->dev, b->host, b->head_bytes, hipMemcpyHostToDevice, ps ) );     // (behind the header kernel on its stream)
   {
     LaunchTimer t( ctx, 4, ps );
     if ( int e = aa::launch_parse_tokens( reinterpret_cast<const aa::ParseJob *>( b->dev ), b->launch_order_dev, b->n, b->max_mbw, b->max_nparts, ps ) )
       return hip_fail( static_cast<hipError_t>( e ), "k_parse_tokens" );
   }
-  HIP_TRY( hipMemcpyAsync( b->host + b->summaries_off, b->dev + b->summaries_off, size_t( b->n ) * sizeof( aa::FrameSummary ), hipMemcpyDeviceToHost, ps ) );
   HIP_TRY( hipEventRecord( b->done, ps ) );
   HIP_TRY( hipEventRecord( ctx->parse_idle[b->parse_stream_index], ps ) );
   b->done_seen = false;
@@ -1065,6 +1066,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   b->dev_bytes = arena;
   if ( aa_status st = dev_alloc( ctx, arena, &b->dev ) ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); return st; }
   b->n = n; b->summaries_off = jobs_bytes + dframes_bytes;
+  HIP_TRY( hipHostGetDevicePointer( reinterpret_cast<void **>( &b->host_dev ), b->host, 0 ) );
   aa::ParseJob * jobs_host = reinterpret_cast<aa::ParseJob *>( b->host );
   aa_dev_frame * dframes_host = reinterpret_cast<aa_dev_frame *>( b->host + jobs_bytes );
   std::memset( b->host, 0, jobs_bytes + dframes_bytes + sums_bytes + seg_bytes );
@@ -1176,7 +1178,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
     HIP_TRY( hipEventRecord( ctx->last_seg_batch, ps ) );
   }
   b->ps = ps; b->launch_order_dev = launch_order_dev;
-  b->tokens_pending = true;
+  b->tokens_pending = true; b->patch_jobs = defer_tokens;
   HIP_TRY( hipEventRecord( b->done, ps ) );        // (the header kernel; recorded again behind the token kernel)
   HIP_TRY( hipEventRecord( ctx->parse_idle[pick], ps ) );
   ctx->deferred.push_back( b.get() );
