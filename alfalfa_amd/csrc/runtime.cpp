@@ -40,7 +40,7 @@ thread_local std::string g_last_error;
 // The entropy-decode kernels are long (a chain per lane, seconds) and must run BESIDE reconstruction and beside each other.
 // HIP spreads streams over few hardware queues by default (4), and commands of one queue run in order: with more streams
 // than queues a decode launch can end up queued behind a parse kernel.  Ask for more queues before the runtime starts.
-struct RuntimeEnv { RuntimeEnv() { setenv( "GPU_MAX_HW_QUEUES", "24", 0 ); } } g_runtime_env;
+struct RuntimeEnv { RuntimeEnv() { setenv( "GPU_MAX_HW_QUEUES", "16", 0 ); } } g_runtime_env;
 
 aa_status fail( aa_status code, const std::string & msg ) { g_last_error = msg; return code; }
 aa_status hip_fail( hipError_t e, const char * what )
@@ -137,7 +137,7 @@ struct aa_ctx {
   // one on the same stream starts that much later.  Hence one stream per batch that can be in flight, and a batch goes to a
   // stream that has nothing queued (pick_parse_stream).
   static constexpr int kMaxParseStreams = 20;
-  int n_parse_streams = 16;
+  int n_parse_streams = 12;             // + compute + copy: within the 16 hardware queues asked for above
   std::vector<hipStream_t> parse_streams;
   std::vector<hipEvent_t> parse_idle;    // recorded behind the last operation queued on the stream
   int prio_low = 0;

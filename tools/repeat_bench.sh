@@ -1,8 +1,8 @@
-# bench.py at the driver's settings under a few launch-shape settings: bash tools/repeat_bench.sh "name:ENV=V,ENV=V name2:..."
+# bench.py at the driver's settings under a few settings: bash tools/repeat_bench.sh "name:ENV=V,ENV=V[:bench flags with + for space] name2:..."
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 for item in $1; do
-  name=${item%%:*}; envs=$(echo ${item#*:} | tr ',' ' ')
-  env $envs timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-verify --small-batches= --no-device-half $2 > gpurun_out/rep_$name.log 2>&1
+  name=${item%%:*}; rest=${item#*:}; envs=$(echo ${rest%%:*} | tr ',' ' '); flags=""; case "$rest" in *:*) flags=$(echo ${rest#*:} | tr '+' ' ');; esac
+  env $envs timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-verify --small-batches= --no-device-half $flags > gpurun_out/rep_$name.log 2>&1
   python - <<PY
 import json
 l=[x for x in open("gpurun_out/rep_$name.log") if x.startswith("{")]
