@@ -116,15 +116,16 @@ static int parse_lanes_env()
 static int header_lanes() { const int v = parse_lanes_env(); return v ? v : 16; }
 
 // Token workgroups live for seconds and a CU holds as many as its LDS takes, so the LDS they leave is all that the
-// reconstruction kernels (milliseconds, launched on the high-priority stream) can start in while a parse is running: with the
-// LDS fully booked, reconstruction only advances as fast as token workgroups retire.  Shape the launch so that a CU full of
-// token workgroups still has `kLdsReserve` bytes free on every CU (a loop-filter workgroup: 18.7 KB, two inter-prediction
-// workgroups: 2 x 11 KB): n workgroups of `lanes` lanes per CU, their LDS request padded so that an (n + 1)-th does not fit.
+// reconstruction kernels (milliseconds, launched on the high-priority stream) can start in while a parse is running.  The
+// launch shape -- n workgroups of `lanes` lanes per CU -- is chosen for the most lanes per CU with `kLdsReserve` bytes left
+// free on every CU: the LDS request is padded so that an (n + 1)-th workgroup does not fit.  Measured on the benchmark
+// (profiles/r02_pipeline_experiments.md) the reserve buys nothing -- a pipelined run leaves ~30 % of the token slots empty at any
+// time, reconstruction runs there -- so it defaults to 0; ALFALFA_AMD_LDS_RESERVE_KB=24 keeps a loop-filter workgroup's worth.
 // (A step costs the wave the same whatever its width, but the rarer paths -- a coefficient emitted, a block or macroblock ended
 // -- run whenever ANY lane needs them: beyond ~24 lanes a wave spends most steps in them.)
 constexpr uint32_t kLdsPerCu = 160u * 1024u, kLdsGranule = 512u;
 static uint32_t env_u32( const char * name, uint32_t dflt ) { const char * e = getenv( name ); return e ? static_cast<uint32_t>( atoi( e ) ) : dflt; }
-static const uint32_t kLdsReserve = env_u32( "ALFALFA_AMD_LDS_RESERVE_KB", 24u ) * 1024u;      // (the two knobs: experiments)
+static const uint32_t kLdsReserve = env_u32( "ALFALFA_AMD_LDS_RESERVE_KB", 0u ) * 1024u;      // (the two knobs: experiments)
 static const uint32_t kMaxLanes = std::max( 1u, std::min( 64u, env_u32( "ALFALFA_AMD_MAX_LANES", 24u ) ) );
 struct TokenShape { int lanes; uint32_t lds; };
 static TokenShape token_launch_shape( uint32_t lane_bytes )

@@ -131,7 +131,8 @@ struct aa_ctx {
   // device-side entropy decode: submit calls rotate over a few HIP streams so that the parse of one batch runs beside the
   // parse of the next and beside reconstruction (a parse is a few thousand latency-bound chains, not a chip-filling kernel)
   struct BindBuf { aa_raster_binding * host = nullptr, * dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
-  BindBuf bind_bufs[4];
+  static constexpr int kBindBufs = 16;      // aa_decode_batch calls the host may run ahead of the compute stream
+  BindBuf bind_bufs[kBindBufs];
   int next_bind_buf = 0;
   // A parse batch holds its stream for as long as its longest chain (seconds for a key frame): a batch queued behind another
   // one on the same stream starts that much later.  Hence one stream per batch that can be in flight, and a batch goes to a
@@ -480,7 +481,7 @@ aa_status bind_batch( aa_ctx * ctx, aa_stream * const * streams, int n, const in
   for ( int i = 0; i < n; i++ ) if ( !streams[i]->frames[frame_index[i]].placed ) need++;
   if ( !need ) return AA_OK;
   aa_ctx::BindBuf & bb = ctx->bind_bufs[ctx->next_bind_buf];
-  ctx->next_bind_buf = ( ctx->next_bind_buf + 1 ) % 4;
+  ctx->next_bind_buf = ( ctx->next_bind_buf + 1 ) % aa_ctx::kBindBufs;
   if ( bb.busy ) {
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY( hipEventSynchronize( bb.done ) );

@@ -294,7 +294,7 @@ typedef struct aa_kernel_stats {
    * hipMalloc was out of memory; waiting in aa_decode_batch for the device parser to finish the frames asked for */
   uint64_t pool_waits;
   double pool_wait_ms, parse_wait_ms;
-  double bind_wait_ms;      /* aa_decode_batch waiting for one of its (four) raster-binding buffers: the compute stream is that far behind */
+  double bind_wait_ms;      /* aa_decode_batch waiting for one of its (16) raster-binding buffers: the compute stream is that far behind */
   double alloc_ms;          /* host time inside the device pool allocator (hipMalloc of new slabs included) */
   uint64_t slab_mallocs;    /* hipMalloc calls of the pool */
 } aa_kernel_stats;
