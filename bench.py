@@ -62,7 +62,7 @@ def parse_args():
     ap.add_argument("--config", default="1080p_inter_lf")
     ap.add_argument("--streams", type=int, default=480, help="independent streams per GPU")
     ap.add_argument("--frames", type=int, default=12, help="frames per stream per step")
-    ap.add_argument("--key-ahead", type=int, default=9, help="steps by which KEY frames are handed to the GPU parser ahead of reconstruction")
+    ap.add_argument("--key-ahead", type=int, default=8, help="steps by which KEY frames are handed to the GPU parser ahead of reconstruction")
     ap.add_argument("--depth", type=int, default=4, help="steps by which inter frames are handed to the GPU parser ahead of reconstruction")
     ap.add_argument("--header-ahead", type=int, default=0, help="steps by which the macroblock-header pass of inter frames runs ahead of their token pass (two-phase submit)")
     ap.add_argument("--threads", type=int, default=0, help="host workers of the header pre-pass (0: cores / local ranks)")
