@@ -164,6 +164,8 @@ struct aa_ctx {
   std::vector<uint8_t *> dev_slabs;
   uint8_t * cur_slab = nullptr;
   size_t slab_used = 0;
+  size_t pool_bytes = 0;                  // HBM the pool has taken from HIP so far
+  size_t pool_soft_limit = ~size_t( 0 );  // beyond this the pool waits for released pieces rather than grow (aa_ctx_create: 7/8 of what was free)
   std::map<size_t, std::vector<uint8_t *>> dev_free;
   uint8_t * boundary = nullptr; // loop filter: hand-off lines between macroblock rows (transient within a launch)
   size_t boundary_bytes = 0;
@@ -234,25 +236,33 @@ aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out )
   std::lock_guard<std::mutex> g( ctx->pool_mu );
   struct Clock { aa_ctx * c; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
                  ~Clock() { c->stats.alloc_ms += std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count(); } } clock { ctx };
+  int soft_waits = 0;
   for ( int attempt = 0; attempt < 3; attempt++ ) {
     auto it = ctx->dev_free.find( bytes );
     if ( it != ctx->dev_free.end() && !it->second.empty() ) { *out = it->second.back(); it->second.pop_back(); return AA_OK; }
     if ( attempt == 0 && !ctx->pending_free.empty() ) { collect_pending( ctx, false ); continue; }
+    const bool big = bytes > kSlabBytes / 2;         // big pieces get their own allocation (still recycled through the free list)
+    if ( !big && ctx->cur_slab && ctx->slab_used + bytes <= kSlabBytes ) { *out = ctx->cur_slab + ctx->slab_used; ctx->slab_used += bytes; return AA_OK; }
+    // The pool is about to grow.  Past the soft limit, pieces that were released but may still be read by queued kernels are
+    // waited for instead (they come back as the compute stream advances): the pool must not creep up to the last byte of HBM.
+    const size_t grow = big ? bytes : kSlabBytes;
+    if ( ctx->pool_bytes + grow > ctx->pool_soft_limit && !ctx->pending_free.empty() && soft_waits < 64 ) {
+      const auto t0 = std::chrono::steady_clock::now();
+      collect_pending( ctx, true );
+      ctx->stats.pool_waits++;
+      ctx->stats.pool_wait_ms += std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count();
+      soft_waits++; attempt = 0;
+      continue;
+    }
     hipError_t e;
-    if ( bytes > kSlabBytes / 2 ) {                 // big pieces get their own allocation (still recycled through the free list)
-      e = hipMalloc( reinterpret_cast<void **>( out ), bytes );
-      ctx->stats.slab_mallocs++;
-      if ( e == hipSuccess ) { ctx->dev_slabs.push_back( *out ); return AA_OK; }
-    } else {
-      if ( ctx->cur_slab && ctx->slab_used + bytes <= kSlabBytes ) { *out = ctx->cur_slab + ctx->slab_used; ctx->slab_used += bytes; return AA_OK; }
-      uint8_t * slab = nullptr;
-      e = hipMalloc( reinterpret_cast<void **>( &slab ), kSlabBytes );
-      ctx->stats.slab_mallocs++;
-      if ( e == hipSuccess ) {
-        ctx->dev_slabs.push_back( slab ); ctx->cur_slab = slab; ctx->slab_used = bytes;
-        *out = slab;
-        return AA_OK;
-      }
+    uint8_t * piece = nullptr;
+    e = hipMalloc( reinterpret_cast<void **>( &piece ), grow );
+    ctx->stats.slab_mallocs++;
+    if ( e == hipSuccess ) {
+      ctx->dev_slabs.push_back( piece ); ctx->pool_bytes += grow;
+      if ( !big ) { ctx->cur_slab = piece; ctx->slab_used = bytes; }
+      *out = piece;
+      return AA_OK;
     }
     // out of HBM: what was released but may still be read by queued kernels comes back once they have run
     (void) hipGetLastError();
@@ -650,6 +660,11 @@ aa_status aa_ctx_create( int device, aa_ctx ** out )
   }
   HIP_TRY( hipStreamCreateWithFlags( &ctx->copy, hipStreamNonBlocking ) );
   HIP_TRY( hipEventCreateWithFlags( &ctx->upload_done, hipEventDisableTiming ) );
+  {
+    size_t free_b = 0, total_b = 0;
+    if ( hipMemGetInfo( &free_b, &total_b ) == hipSuccess && free_b ) ctx->pool_soft_limit = free_b / 8 * 7;
+    (void) hipGetLastError();
+  }
   if ( const char * e = getenv( "ALFALFA_AMD_PARSE_STREAMS" ) ) ctx->n_parse_streams = std::max( 1, std::min( aa_ctx::kMaxParseStreams, atoi( e ) ) );
   ctx->parse_streams.assign( ctx->n_parse_streams, nullptr );
   ctx->parse_idle.assign( ctx->n_parse_streams, nullptr );
