@@ -105,6 +105,18 @@ def test_device_algorithm_matches_host_parser_on_truncated_frames(name):
     check_stream(w, h, truncated(frames))
 
 
+def test_device_algorithm_on_long_runs_of_skipped_macroblocks():
+    """A token lane learns about macroblocks through a 64-entry flag ring topped up every 64 steps; skipped macroblocks take no
+    steps, so long runs of them outrun the ring and the lane has to wait for it (tok::macroblock_boundary)."""
+    import vp8_synth
+    for w, h, seed, density in ((1920, 48, 31, 0.0), (1920, 48, 32, 0.004), (640, 360, 33, 0.002), (4096, 16, 34, 0.0)):
+        s = vp8_synth.SynthStream(w, h, seed)
+        s.frame(key=True, q_index=30, skip_prob=3, density=density, skip_rate=1.0, intra_bpred=0.2)
+        for k in range(3):
+            s.frame(key=False, q_index=30, skip_prob=2 + k, density=density, skip_rate=1.0, log2_parts=k % 3, lf_level=8)
+        check_stream(w, h, s.frames)
+
+
 def test_device_algorithm_on_extreme_geometries():
     import vp8_synth
     for w, h, seed in ((16, 4096, 901), (4096, 16, 902), (24, 1000, 903), (2000, 32, 904)):

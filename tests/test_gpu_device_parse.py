@@ -226,3 +226,15 @@ def test_two_phase_submit(gpu_ctx):
         gpu_ctx.decode_batch([a], [f])
         assert sha256(a.raster_bytes(f)) == want[f]
     assert free0 > 0
+
+
+def test_gpu_parser_on_long_runs_of_skipped_macroblocks(gpu_ctx):
+    """Skipped macroblocks take no decode steps, so long runs of them outrun the token lane's 64-entry flag ring and the lane
+    waits for the next top-up (tok::macroblock_boundary) -- frames that are (almost) entirely skipped, single and multi-partition."""
+    import vp8_synth
+    for w, h, seed, density in ((1920, 48, 31, 0.0), (1920, 48, 32, 0.004), (640, 360, 33, 0.002), (4096, 16, 34, 0.0)):
+        s = vp8_synth.SynthStream(w, h, seed)
+        s.frame(key=True, q_index=30, skip_prob=3, density=density, skip_rate=1.0, intra_bpred=0.2)
+        for k in range(3):
+            s.frame(key=False, q_index=30, skip_prob=2 + k, density=density, skip_rate=1.0, log2_parts=k % 3, lf_level=8)
+        check_stream(gpu_ctx, w, h, s.frames)

@@ -303,7 +303,8 @@ class SynthStream:
               segmentation=None, lf_deltas=None, refresh_entropy=True, coeff_updates=0, skip_prob=None,
               density=0.3, big_coeffs=False, prob_inter=200, prob_last=128, prob_golden=128, inter_modes=None,
               intra_bpred=0.3, mv_range=40, refresh_golden=False, refresh_alt=False, copy_golden=0, copy_alt=0,
-              sign_bias_golden=False, sign_bias_alt=False, refresh_last=True, update_mode_probs=False, mv_prob_updates=0):
+              sign_bias_golden=False, sign_bias_alt=False, refresh_last=True, update_mode_probs=False, mv_prob_updates=0,
+              skip_rate=0.8):
         rng = self.rng
         mbw, mbh = self.mbw, self.mbh
         e = BoolEncoder()
@@ -384,7 +385,7 @@ class SynthStream:
                     any_nz = any(any(c) for c in coeffs)
                 mb.skip = False
                 if skip_prob is not None:
-                    mb.skip = (not any_nz) and rng.random() < 0.8
+                    mb.skip = (not any_nz) and rng.random() < skip_rate
                     e.put(1 if mb.skip else 0, skip_prob)
                 mb.coeffs = coeffs
                 if not key:
