@@ -1497,6 +1497,41 @@ __global__ void k_bind_rasters( const aa_raster_binding * b, int n )
 
 } // namespace
 
+// ---- SSIM windows of the encoder's loop-filter search (util/ssim.cc:57-71 -> libx264 pixel_ssim_wxh) -------
+// One thread per 8x8 window (windows step by 4): the sums over its 64 pixel pairs, then x264's ssim_end1 in single precision
+// -- integer arithmetic up to the four factors, two multiplications and one correctly rounded division, nothing a contraction
+// could fuse -- so the value is the one the plain-C algorithm produces (oracle/ssim_x264.c).  The host adds the windows up in
+// x264's order (floats, four at a time, row by row): the order is part of the result.
+__global__ __launch_bounds__( 256 ) void k_ssim_windows( const uint8_t * a, const uint8_t * b, int width, int w4, int h4, float * out )
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;       // window (x, y): pixels [4x, 4x+8) x [4y, 4y+8)
+  if ( x >= w4 - 1 || y >= h4 - 1 ) return;
+  uint32_t s1 = 0, s2 = 0, ss = 0, s12 = 0;
+  for ( int r = 0; r < 8; r++ ) {
+    const size_t off = static_cast<size_t>( 4 * y + r ) * width + 4 * x;
+    const uint32_t * ra = reinterpret_cast<const uint32_t *>( a + off ), * rb = reinterpret_cast<const uint32_t *>( b + off );
+    const uint32_t wa[2] = { ra[0], ra[1] }, wb[2] = { rb[0], rb[1] };
+    for ( int k = 0; k < 8; k++ ) {
+      const uint32_t p = ( wa[k >> 2] >> ( 8 * ( k & 3 ) ) ) & 255u, q = ( wb[k >> 2] >> ( 8 * ( k & 3 ) ) ) & 255u;
+      s1 += p; s2 += q; ss += p * p + q * q; s12 += p * q;
+    }
+  }
+  const int i1 = static_cast<int>( s1 ), i2 = static_cast<int>( s2 ), iss = static_cast<int>( ss ), i12 = static_cast<int>( s12 );
+  const int c1 = 416, c2 = 235963;               // (int)(.01*.01*255*255*64 + .5), (int)(.03*.03*255*255*64*63 + .5)
+  const int vars = iss * 64 - i1 * i1 - i2 * i2, covar = i12 * 64 - i1 * i2;
+  const float num = __fmul_rn( static_cast<float>( 2 * i1 * i2 + c1 ), static_cast<float>( 2 * covar + c2 ) );
+  const float den = __fmul_rn( static_cast<float>( i1 * i1 + i2 * i2 + c1 ), static_cast<float>( vars + c2 ) );
+  out[static_cast<size_t>( y ) * ( w4 - 1 ) + x] = __fdiv_rn( num, den );
+}
+
+int launch_ssim_windows( const uint8_t * a, const uint8_t * b, int width, int height, float * out, void * stream )
+{
+  const int w4 = width >> 2, h4 = height >> 2;
+  if ( w4 < 2 || h4 < 2 ) return static_cast<int>( hipErrorInvalidValue );
+  hipLaunchKernelGGL( k_ssim_windows, dim3( ( w4 - 1 + 255 ) / 256, h4 - 1 ), dim3( 256 ), 0, static_cast<hipStream_t>( stream ), a, b, width, w4, h4, out );
+  return static_cast<int>( hipGetLastError() );
+}
+
 int launch_bind_rasters( const aa_raster_binding * b, int n, void * stream )
 {
   hipLaunchKernelGGL( k_bind_rasters, dim3( ( n + 63 ) / 64 ), dim3( 64 ), 0, static_cast<hipStream_t>( stream ), b, n );

@@ -1774,6 +1774,91 @@ aa_status aa_stream_set_references( aa_stream * s, const void * const planes[3][
   for ( int i = 0; i < 3; i++ ) { bool first = true; for ( int k = 0; k < i; k++ ) if ( slot[k] == slot[i] ) first = false; if ( first ) release( s, slot[i] ); }
   return AA_OK;
 }
+/* Encoder feedback, the loop-filter level search of Encoder::apply_best_loopfilter_settings
+ * (encoder.cc:459-516): the frame as serialised with ANY level is reconstructed once per candidate level on a scratch copy of
+ * the decoder (state + references; the stream itself is untouched), filtered with the candidate level and zero mode / reference
+ * adjustments (`filter_adjustments.reset( frame.header() )` after the adjustments were zeroed, encoder.cc:464-470), and scored
+ * with BaseRaster::quality = x264's SSIM of the padded luma planes (util/raster.cc:63-66, util/ssim.cc:57-71).  All candidates
+ * are independent frames: ONE aa_decode_batch.  Selection as in the reference: levels in ascending order, the first one that
+ * does not improve on the best so far ends the search (encoder.cc:489-503). */
+aa_status aa_stream_lf_search( aa_stream * s, const uint8_t * data, size_t size, const uint8_t * original_luma,
+                               int level_lo, int level_hi, int * best_level, double * best_ssim, double * ssim_out, uint8_t * rasters_out )
+{
+  if ( !s || !data || !original_luma ) return fail( AA_ERR_ARGUMENT, "aa_stream_lf_search: null argument" );
+  if ( level_lo < 0 || level_hi > 63 || level_lo > level_hi ) return fail( AA_ERR_ARGUMENT, "aa_stream_lf_search: levels must be 0 <= lo <= hi <= 63" );
+  aa_ctx * ctx = s->ctx;
+  if ( aa_status st = set_device( ctx ) ) return st;
+  if ( s->next_submit != static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_LOGIC, "aa_stream_lf_search: parsed frames are still waiting to be decoded" );
+  if ( aa_status st = segmap_to_host( s ) ) return st;
+  const int n = level_hi - level_lo + 1;
+  std::vector<aa_stream *> cand( n, nullptr );
+  std::vector<int> fis( n, -1 );
+  struct Cleanup { std::vector<aa_stream *> & v; uint8_t * orig = nullptr; float * win = nullptr;
+                   ~Cleanup() { for ( aa_stream * c : v ) if ( c ) aa_stream_destroy( c ); if ( orig ) (void) hipFree( orig ); if ( win ) (void) hipFree( win ); } } cleanup { cand };
+  const void * planes[3][3]; const int on_device[3] = { 0, 0, 0 };
+  for ( int r = 0; r < 3; r++ ) for ( int p = 0; p < 3; p++ ) planes[r][p] = slot_plane( s, s->cur_ref_slot[r], p );
+  const size_t job_bytes = align_up( sizeof( aa_dev_frame ) );
+  for ( int i = 0; i < n; i++ ) {
+    const int level = level_lo + i;
+    if ( aa_status st = aa_stream_create( ctx, s->parser.width(), s->parser.height(), &cand[i] ) ) return st;
+    aa_stream * c = cand[i];
+    c->parser = s->parser;                                               // DecoderState as it stands before this frame
+    if ( aa_status st = aa_stream_set_references( c, planes, on_device ) ) return st;
+    if ( aa_status st = aa_stream_parse( c, data, size, &fis[i], nullptr ) ) return st;
+    FrameRec & r = c->frames[fis[i]];
+    // the candidate's header: this level, adjustments present and zero.  Per macroblock: the segment's level (frame.cc:144-166)
+    // clamped to 0..63 (macroblock.cc:611-623), nothing added (loopfilter.cc:59-79 with zero adjustments).
+    const aa::SegmentationState & seg = c->parser.segmentation();
+    uint8_t seg_level[4];
+    for ( int k = 0; k < 4; k++ ) {
+      const int v = seg.enabled ? seg.lf[k] + ( seg.absolute ? 0 : level ) : level;
+      seg_level[k] = static_cast<uint8_t>( v <= 0 ? 0 : ( v > 63 ? 63 : v ) );
+    }
+    aa_mb_info * mbs = reinterpret_cast<aa_mb_info *>( reinterpret_cast<uint8_t *>( r.host_job ) + job_bytes );
+    for ( unsigned m = 0; m < r.hdr.num_macroblocks; m++ ) mbs[m].lf_level = level ? seg_level[mbs[m].segment_id & 3] : 0;
+    r.hdr.loop_filter_level = static_cast<uint8_t>( level );
+    r.host_job->loop_filter_level = static_cast<uint8_t>( level );
+  }
+  if ( aa_status st = aa_decode_batch( ctx, cand.data(), n, fis.data() ) ) return st;
+
+  // quality of every candidate against the original: per-window terms on the device, x264's summation order on the host
+  const int pw = s->pw, ph = s->ph, w4 = pw >> 2, h4 = ph >> 2;
+  const size_t windows = size_t( w4 - 1 ) * ( h4 - 1 );
+  HIP_TRY( hipMalloc( reinterpret_cast<void **>( &cleanup.orig ), s->plane_bytes[0] ) );
+  HIP_TRY( hipMalloc( reinterpret_cast<void **>( &cleanup.win ), windows * n * sizeof( float ) ) );
+  HIP_TRY( hipMemcpyAsync( cleanup.orig, original_luma, s->plane_bytes[0], hipMemcpyHostToDevice, ctx->compute ) );
+  for ( int i = 0; i < n; i++ ) {
+    const FrameRec & r = cand[i]->frames[fis[i]];
+    if ( const int e = aa::launch_ssim_windows( slot_plane( cand[i], r.out_slot, 0 ), cleanup.orig, pw, ph, cleanup.win + windows * i, ctx->compute ) )
+      return hip_fail( static_cast<hipError_t>( e ), "k_ssim_windows" );
+  }
+  std::vector<float> win( windows * n );
+  HIP_TRY( hipMemcpyAsync( win.data(), cleanup.win, win.size() * sizeof( float ), hipMemcpyDeviceToHost, ctx->compute ) );
+  HIP_TRY( hipStreamSynchronize( ctx->compute ) );
+  if ( aa_status st = check_watchdog( ctx ) ) return st;
+  int best = level_lo; double best_q = -1.0; bool searching = true;
+  for ( int i = 0; i < n; i++ ) {
+    float total = 0.0f;                                                  // pixel_ssim_wxh: floats, four windows at a time, row by row
+    for ( int y = 0; y < h4 - 1; y++ )
+      for ( int x = 0; x < w4 - 1; x += 4 ) {
+        float part = 0.0f;
+        for ( int k = x; k < std::min( x + 4, w4 - 1 ); k++ ) part += win[windows * i + size_t( y ) * ( w4 - 1 ) + k];
+        total += part;
+      }
+    const double q = static_cast<double>( total ) / static_cast<double>( windows );
+    if ( ssim_out ) ssim_out[i] = q;
+    if ( searching ) { if ( q > best_q ) { best_q = q; best = level_lo + i; } else searching = false; }
+  }
+  if ( best_level ) *best_level = best;
+  if ( best_ssim ) *best_ssim = best_q;
+  if ( rasters_out )
+    for ( int i = 0; i < n; i++ ) {
+      uint8_t * dst = rasters_out + size_t( i ) * ( s->plane_bytes[0] + 2 * s->plane_bytes[1] );
+      if ( aa_status st = aa_stream_download( cand[i], fis[i], dst, dst + s->plane_bytes[0], dst + s->plane_bytes[0] + s->plane_bytes[1] ) ) return st;
+    }
+  return AA_OK;
+}
+
 /* Device planes of References::last / golden / alternative as they stand (which: 0, 1, 2) */
 aa_status aa_stream_reference_device( aa_stream * s, int which, void ** y, void ** u, void ** v )
 {

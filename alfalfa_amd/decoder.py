@@ -236,6 +236,20 @@ class Decoder:
     def rewind_to(self, frame_index):
         capi.check(self.L.aa_stream_rewind_to(self.h, frame_index))
 
+    def lf_search(self, frame_bytes, original_luma, level_lo, level_hi, want_rasters=False):
+        """Encoder::apply_best_loopfilter_settings (encoder.cc:459-516) as one batch: -> (best level, its SSIM, [SSIM of every
+        candidate], [raster bytes of every candidate] or None).  original_luma: padded_height x padded_width uint8."""
+        n = level_hi - level_lo + 1
+        orig = np.ascontiguousarray(original_luma, dtype=np.uint8)
+        assert orig.shape == (self.padded_height, self.padded_width), orig.shape
+        best, q = C.c_int(), C.c_double()
+        qs = (C.c_double * n)()
+        rb = sum(self.plane_sizes())
+        rasters = np.empty(n * rb, np.uint8) if want_rasters else None
+        capi.check(self.L.aa_stream_lf_search(self.h, frame_bytes, len(frame_bytes), orig.ctypes.data_as(C.c_void_p), level_lo, level_hi,
+                                              C.byref(best), C.byref(q), qs, rasters.ctypes.data_as(C.c_void_p) if want_rasters else None))
+        return best.value, q.value, list(qs), ([rasters[i * rb:(i + 1) * rb].tobytes() for i in range(n)] if want_rasters else None)
+
     def release_before(self, first_kept):
         capi.check(self.L.aa_stream_release_before(self.h, first_kept))
 

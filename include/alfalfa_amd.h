@@ -279,6 +279,19 @@ aa_status aa_stream_reference_download( aa_stream * s, int which, uint8_t * y, u
 /* Padded plane geometry for a display size (VP8Raster ctor, prediction.cc:94-97). */
 void aa_raster_geometry( uint16_t width, uint16_t height, uint32_t * padded_width, uint32_t * padded_height );
 
+/* Encoder feedback.  The reference update of Encoder::write_frame (encoder.cc:146-170: frame.decode +
+ * frame.loopfilter + copy_to) IS aa_stream_decode of the frame it has just serialised.  What the encoder does BEFORE it knows
+ * the loop-filter level -- Encoder::apply_best_loopfilter_settings (encoder.cc:459-516): filter a copy of the reconstruction
+ * with every candidate level, score it against the original, keep the best -- is this call: `data` = the frame serialised
+ * with any provisional level, `original_luma` = the original's padded luma plane (padded width x padded height, stride =
+ * padded width: BaseRaster::Y(), util/raster.hh:54-60), candidates level_lo..level_hi (0..63; the reference tries 0..63 on
+ * the first frame and last-1..last+1 afterwards, encoder.cc:477-487).  The stream's own state and references are not touched.
+ * -> best_level / best_ssim by the reference's rule (ascending levels, stop at the first that does not improve);
+ * ssim_out[level_hi - level_lo + 1] (optional): every candidate's score; rasters_out (optional, host): every candidate's
+ * filtered raster, Y U V planes back to back. */
+aa_status aa_stream_lf_search( aa_stream * s, const uint8_t * data, size_t size, const uint8_t * original_luma,
+                               int level_lo, int level_hi, int * best_level, double * best_ssim, double * ssim_out, uint8_t * rasters_out );
+
 /* Per-kernel timing of the device half, measured with HIP events on the compute stream.
  * enable=1 brackets every kernel launch with events (serialises nothing beyond event records). */
 typedef struct aa_kernel_stats {

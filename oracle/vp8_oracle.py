@@ -60,6 +60,10 @@ def lib():
         L.vp8o_get_probs.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
         L.vp8o_get_frame_info.argtypes = [C.c_void_p, C.POINTER(FrameInfo)]
         L.vp8o_set_phases.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_ssim_plane.restype = C.c_double
+        L.oracle_ssim_plane.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_ssim_window.restype = C.c_float
+        L.oracle_ssim_window.argtypes = [C.c_int] * 4
         assert C.sizeof(MB) == MB_DTYPE.itemsize, (C.sizeof(MB), MB_DTYPE.itemsize)
         _lib = L
     return _lib
@@ -116,6 +120,12 @@ class OracleDecoder:
 
     def set_phases(self, mask):
         self.L.vp8o_set_phases(self.h, mask)
+
+
+def ssim_plane(a, b, width, height):
+    """x264's pixel_ssim_wxh / count over two planes (bytes, stride = width) as restated in oracle/ssim_x264.c."""
+    assert len(a) == len(b) == width * height
+    return lib().oracle_ssim_plane(bytes(a), bytes(b), width, height, None)
 
 
 def read_ivf(path_or_bytes):

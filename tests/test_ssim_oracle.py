@@ -1,0 +1,54 @@
+"""oracle/ssim_x264.c (the quality measure of the encoder's loop-filter search; PARITY UNPINNED: libx264 is not in
+this image) against an independent numpy derivation of the same published algorithm -- block sums by reshaping, window sums
+by slicing, single-precision arithmetic and x264's accumulation order -- and against the properties SSIM has."""
+import numpy as np
+import pytest
+
+import vp8_oracle as vo
+
+
+def ssim_numpy(a, b):
+    h, w = a.shape
+    w4, h4 = w // 4, h // 4
+    A = a[:h4 * 4, :w4 * 4].astype(np.int64).reshape(h4, 4, w4, 4)
+    B = b[:h4 * 4, :w4 * 4].astype(np.int64).reshape(h4, 4, w4, 4)
+    s1, s2 = A.sum(axis=(1, 3)), B.sum(axis=(1, 3))
+    ss, s12 = (A * A + B * B).sum(axis=(1, 3)), (A * B).sum(axis=(1, 3))
+
+    def win(t):          # 2x2 blocks -> one 8x8 window
+        return t[:-1, :-1] + t[:-1, 1:] + t[1:, :-1] + t[1:, 1:]
+    s1, s2, ss, s12 = win(s1), win(s2), win(ss), win(s12)
+    c1, c2 = 416, 235963
+    var, cov = ss * 64 - s1 * s1 - s2 * s2, s12 * 64 - s1 * s2
+    f = np.float32
+    v = (f(1) * (2 * s1 * s2 + c1).astype(f)) * (2 * cov + c2).astype(f) / ((s1 * s1 + s2 * s2 + c1).astype(f) * (var + c2).astype(f))
+    assert v.dtype == np.float32
+    total = f(0)
+    for y in range(h4 - 1):
+        for x in range(0, w4 - 1, 4):
+            part = f(0)
+            for k in range(x, min(x + 4, w4 - 1)):
+                part = f(part + v[y, k])
+            total = f(total + part)
+    return float(total) / ((h4 - 1) * (w4 - 1))
+
+
+@pytest.mark.parametrize("w,h,seed", [(48, 64, 1), (176, 144, 2), (32, 16, 3), (200, 56, 4), (8, 8, 5)])
+def test_oracle_ssim_equals_the_numpy_derivation(w, h, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    for noise in (0, 1, 6, 40, 255):
+        b = np.clip(a.astype(int) + rng.integers(-noise, noise + 1, a.shape), 0, 255).astype(np.uint8)
+        got = vo.ssim_plane(a.tobytes(), b.tobytes(), w, h)
+        assert got == ssim_numpy(a, b), (w, h, noise)
+        assert got == vo.ssim_plane(b.tobytes(), a.tobytes(), w, h)            # symmetric
+        assert -1.0 <= got <= 1.0 + 1e-6
+        if noise == 0:
+            assert abs(got - 1.0) < 1e-6
+
+
+def test_oracle_ssim_orders_distortions():
+    rng = np.random.default_rng(9)
+    a = rng.integers(0, 256, (96, 128), dtype=np.uint8)
+    qs = [vo.ssim_plane(a.tobytes(), np.clip(a.astype(int) + rng.integers(-n, n + 1, a.shape), 0, 255).astype(np.uint8).tobytes(), 128, 96) for n in (1, 4, 16, 64)]
+    assert qs == sorted(qs, reverse=True) and qs[0] > 0.99 and qs[-1] < 0.9
