@@ -77,5 +77,7 @@ int launch_loopfilter_rows4( const aa_frame_list & list, int n_groups, int mbh_m
 int launch_probe_xcds( int * out16, int blocks, void * stream );
 int launch_bind_rasters( const aa_raster_binding * b, int n, void * stream );
 // per-window SSIM terms of two planes (stride = width; width a multiple of 8): (height/4 - 1) x (width/4 - 1) floats
+// dst = src with lf_level := byte `segment_id` of `levels` (records are 80 bytes, 16-byte aligned)
+int launch_lf_relevel( const aa_mb_info * src, aa_mb_info * dst, unsigned nmb, uint32_t levels, void * stream );
 int launch_ssim_windows( const uint8_t * a, const uint8_t * b, int width, int height, float * out, void * stream );
 }

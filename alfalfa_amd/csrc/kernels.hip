@@ -1524,6 +1524,28 @@ __global__ __launch_bounds__( 256 ) void k_ssim_windows( const uint8_t * a, cons
   out[static_cast<size_t>( y ) * ( w4 - 1 ) + x] = __fdiv_rn( num, den );
 }
 
+// Macroblock records of a loop-filter candidate: the frame's records with the per-macroblock level replaced by the candidate's
+// (by segment; zero mode / reference adjustments: encoder.cc:464-470, loopfilter.cc:59-79).  levels = four bytes, one per segment.
+__global__ __launch_bounds__( 256 ) void k_lf_relevel( const aa_mb_info * src, aa_mb_info * dst, unsigned nmb, uint32_t levels )
+{
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ( i >= nmb ) return;
+  const uint4 * s = reinterpret_cast<const uint4 *>( src + i );
+  uint4 * d = reinterpret_cast<uint4 *>( dst + i );
+  uint4 head = s[0];                                              // y_mode uv_mode ref_frame segment_id | flags lf_level ...
+  const uint32_t seg = ( head.x >> 24 ) & 3u;
+  head.y = ( head.y & 0xFFFF00FFu ) | ( ( ( levels >> ( 8 * seg ) ) & 255u ) << 8 );
+  d[0] = head;
+  for ( int k = 1; k < 5; k++ ) d[k] = s[k];
+}
+static_assert( sizeof( aa_mb_info ) == 80, "k_lf_relevel copies five 16-byte pieces" );
+
+int launch_lf_relevel( const aa_mb_info * src, aa_mb_info * dst, unsigned nmb, uint32_t levels, void * stream )
+{
+  hipLaunchKernelGGL( k_lf_relevel, dim3( ( nmb + 255 ) / 256 ), dim3( 256 ), 0, static_cast<hipStream_t>( stream ), src, dst, nmb, levels );
+  return static_cast<int>( hipGetLastError() );
+}
+
 int launch_ssim_windows( const uint8_t * a, const uint8_t * b, int width, int height, float * out, void * stream )
 {
   const int w4 = width >> 2, h4 = height >> 2;

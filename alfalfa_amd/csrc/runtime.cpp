@@ -1258,6 +1258,42 @@ aa_status aa_stream_read_records( aa_stream * s, int fi, aa_mb_info * mb_out, in
   return AA_OK;
 }
 
+namespace {
+// Row-pipelined loop filter over a set of frames: four frames of ONE geometry per wave.  Bucket by geometry, pad every bucket
+// to a multiple of four with null frames (slot 0 of a group is never null), split at group boundaries when a list is full.
+aa_status launch_lf_rows( aa_ctx * ctx, std::vector<std::pair<uint32_t, const aa_dev_frame *>> & keyed, bool same_geometry, int max_mbh, int max_mbw )
+{
+  if ( !same_geometry ) std::stable_sort( keyed.begin(), keyed.end(), []( const auto & a, const auto & b ) { return a.first < b.first; } );
+  aa_frame_list list;
+  int filled = 0;
+  auto launch = [&]() -> aa_status {
+    if ( !filled ) return AA_OK;
+    for ( int k = filled; k < AA_MAX_BATCH; k++ ) list.f[k] = nullptr;
+    if ( aa_status st = zero_ws( ctx, ctx->ws, filled / 4, max_mbh ) ) return st;
+    const size_t need = size_t( filled ) * max_mbh * max_mbw * 128;
+    if ( need > ctx->boundary_bytes ) {
+      HIP_TRY( hipStreamSynchronize( ctx->compute ) );
+      if ( ctx->boundary ) (void) hipFree( ctx->boundary );
+      ctx->boundary = nullptr; ctx->boundary_bytes = 0;
+      HIP_TRY( hipMalloc( reinterpret_cast<void **>( &ctx->boundary ), need ) );
+      ctx->boundary_bytes = need;
+    }
+    LaunchTimer t( ctx, 2 );
+    if ( const int e = aa::launch_loopfilter_rows4( list, filled / 4, max_mbh, max_mbw, ctx->ws, ctx->boundary, ctx->n_xcd, ctx->compute ) ) return hip_fail( static_cast<hipError_t>( e ), "k_loopfilter_rows4" );
+    filled = 0;
+    return AA_OK;
+  };
+  for ( size_t i = 0; i < keyed.size(); ) {
+    size_t j = i;
+    while ( j < keyed.size() && j - i < 4 && keyed[j].first == keyed[i].first ) j++;
+    for ( size_t k = 0; k < 4; k++ ) list.f[filled++] = i + k < j ? keyed[i + k].second : nullptr;
+    i = j;
+    if ( filled + 4 > AA_MAX_BATCH ) if ( aa_status st = launch() ) return st;
+  }
+  return launch();
+}
+} // namespace
+
 aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, const int * frame_index )
 {
   if ( !ctx || !streams || !frame_index || n <= 0 ) return fail( AA_ERR_ARGUMENT, "aa_decode_batch: bad argument" );
@@ -1339,40 +1375,11 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
       LaunchTimer t( ctx, 1 );
       if ( const int e = aa::launch_recon_intra4( list, groups, max_mbh, ctx->ws, ctx->n_xcd, ctx->compute ) ) return hip_fail( static_cast<hipError_t>( e ), "k_recon_intra4" );
     }
-    // loop filter: four frames of ONE geometry per wave.  Bucket by geometry, pad every bucket to a multiple of four
-    // with null frames (slot 0 of a group is never null), split at group boundaries when a list is full.
     if ( !lf_jobs.empty() ) {
       std::vector<std::pair<uint32_t, const aa_dev_frame *>> keyed;
       keyed.reserve( lf_geometry.size() );
       for ( size_t i = 0; i < lf_jobs.size(); i++ ) keyed.emplace_back( lf_geometry[i], lf_jobs[i] );
-      if ( !same_geometry ) std::stable_sort( keyed.begin(), keyed.end(), []( const auto & a, const auto & b ) { return a.first < b.first; } );
-      aa_frame_list list;
-      int filled = 0;
-      auto launch = [&]() -> aa_status {
-        if ( !filled ) return AA_OK;
-        for ( int k = filled; k < AA_MAX_BATCH; k++ ) list.f[k] = nullptr;
-        if ( aa_status st = zero_ws( ctx, ctx->ws, filled / 4, max_mbh ) ) return st;
-        const size_t need = size_t( filled ) * max_mbh * max_mbw * 128;
-        if ( need > ctx->boundary_bytes ) {
-          HIP_TRY( hipStreamSynchronize( ctx->compute ) );
-          if ( ctx->boundary ) (void) hipFree( ctx->boundary );
-          ctx->boundary = nullptr; ctx->boundary_bytes = 0;
-          HIP_TRY( hipMalloc( reinterpret_cast<void **>( &ctx->boundary ), need ) );
-          ctx->boundary_bytes = need;
-        }
-        LaunchTimer t( ctx, 2 );
-        if ( const int e = aa::launch_loopfilter_rows4( list, filled / 4, max_mbh, max_mbw, ctx->ws, ctx->boundary, ctx->n_xcd, ctx->compute ) ) return hip_fail( static_cast<hipError_t>( e ), "k_loopfilter_rows4" );
-        filled = 0;
-        return AA_OK;
-      };
-      for ( size_t i = 0; i < keyed.size(); ) {
-        size_t j = i;
-        while ( j < keyed.size() && j - i < 4 && keyed[j].first == keyed[i].first ) j++;
-        for ( size_t k = 0; k < 4; k++ ) list.f[filled++] = i + k < j ? keyed[i + k].second : nullptr;
-        i = j;
-        if ( filled + 4 > AA_MAX_BATCH ) if ( aa_status st = launch() ) return st;
-      }
-      if ( aa_status st = launch() ) return st;
+      if ( aa_status st = launch_lf_rows( ctx, keyed, same_geometry, max_mbh, max_mbw ) ) return st;
     }
     advance.ok = true;
     return AA_OK;
@@ -1774,15 +1781,41 @@ aa_status aa_stream_set_references( aa_stream * s, const void * const planes[3][
   for ( int i = 0; i < 3; i++ ) { bool first = true; for ( int k = 0; k < i; k++ ) if ( slot[k] == slot[i] ) first = false; if ( first ) release( s, slot[i] ); }
   return AA_OK;
 }
-/* Encoder feedback (SURVEY 8f.4), the loop-filter level search of Encoder::apply_best_loopfilter_settings
- * (encoder.cc:459-516): the frame as serialised with ANY level is reconstructed once per candidate level on a scratch copy of
- * the decoder (state + references; the stream itself is untouched), filtered with the candidate level and zero mode / reference
- * adjustments (`filter_adjustments.reset( frame.header() )` after the adjustments were zeroed, encoder.cc:464-470), and scored
- * with BaseRaster::quality = x264's SSIM of the padded luma planes (util/raster.cc:63-66, util/ssim.cc:57-71).  All candidates
- * are independent frames: ONE aa_decode_batch.  Selection as in the reference: levels in ascending order, the first one that
- * does not improve on the best so far ends the search (encoder.cc:489-503). */
-aa_status aa_stream_lf_search( aa_stream * s, const uint8_t * data, size_t size, const uint8_t * original_luma,
-                               int level_lo, int level_hi, int * best_level, double * best_ssim, double * ssim_out, uint8_t * rasters_out )
+namespace {
+// x264's pixel_ssim_wxh over per-window terms (floats, four windows at a time, row by row) / count, for n candidates; then the
+// reference's choice: ascending levels, the first one that does not improve on the best so far ends the search.
+void score_candidates( const std::vector<float> & win, int n, int w4, int h4, int level_lo, int * best_level, double * best_ssim, double * ssim_out )
+{
+  const size_t windows = size_t( w4 - 1 ) * ( h4 - 1 );
+  int best = level_lo; double best_q = -1.0; bool searching = true;
+  for ( int i = 0; i < n; i++ ) {
+    float total = 0.0f;
+    for ( int y = 0; y < h4 - 1; y++ )
+      for ( int x = 0; x < w4 - 1; x += 4 ) {
+        float part = 0.0f;
+        for ( int k = x; k < std::min( x + 4, w4 - 1 ); k++ ) part += win[windows * i + size_t( y ) * ( w4 - 1 ) + k];
+        total += part;
+      }
+    const double q = static_cast<double>( total ) / static_cast<double>( windows );
+    if ( ssim_out ) ssim_out[i] = q;
+    if ( searching ) { if ( q > best_q ) { best_q = q; best = level_lo + i; } else searching = false; }
+  }
+  if ( best_level ) *best_level = best;
+  if ( best_ssim ) *best_ssim = best_q;
+}
+uint32_t segment_levels( const aa::SegmentationState & seg, int level )      // frame.cc:144-166 + the clamp of macroblock.cc:611-623
+{
+  uint32_t word = 0;
+  for ( int k = 0; k < 4; k++ ) {
+    const int v = level ? ( seg.enabled ? seg.lf[k] + ( seg.absolute ? 0 : level ) : level ) : 0;
+    word |= static_cast<uint32_t>( v <= 0 ? 0 : ( v > 63 ? 63 : v ) ) << ( 8 * k );
+  }
+  return word;
+}
+} // namespace
+
+static aa_status lf_search_by_decoders( aa_stream * s, const uint8_t * data, size_t size, const uint8_t * original_luma,
+                                        int level_lo, int level_hi, int * best_level, double * best_ssim, double * ssim_out, uint8_t * rasters_out )
 {
   if ( !s || !data || !original_luma ) return fail( AA_ERR_ARGUMENT, "aa_stream_lf_search: null argument" );
   if ( level_lo < 0 || level_hi > 63 || level_lo > level_hi ) return fail( AA_ERR_ARGUMENT, "aa_stream_lf_search: levels must be 0 <= lo <= hi <= 63" );
@@ -1808,14 +1841,9 @@ aa_status aa_stream_lf_search( aa_stream * s, const uint8_t * data, size_t size,
     FrameRec & r = c->frames[fis[i]];
     // the candidate's header: this level, adjustments present and zero.  Per macroblock: the segment's level (frame.cc:144-166)
     // clamped to 0..63 (macroblock.cc:611-623), nothing added (loopfilter.cc:59-79 with zero adjustments).
-    const aa::SegmentationState & seg = c->parser.segmentation();
-    uint8_t seg_level[4];
-    for ( int k = 0; k < 4; k++ ) {
-      const int v = seg.enabled ? seg.lf[k] + ( seg.absolute ? 0 : level ) : level;
-      seg_level[k] = static_cast<uint8_t>( v <= 0 ? 0 : ( v > 63 ? 63 : v ) );
-    }
+    const uint32_t seg_level = segment_levels( c->parser.segmentation(), level );
     aa_mb_info * mbs = reinterpret_cast<aa_mb_info *>( reinterpret_cast<uint8_t *>( r.host_job ) + job_bytes );
-    for ( unsigned m = 0; m < r.hdr.num_macroblocks; m++ ) mbs[m].lf_level = level ? seg_level[mbs[m].segment_id & 3] : 0;
+    for ( unsigned m = 0; m < r.hdr.num_macroblocks; m++ ) mbs[m].lf_level = static_cast<uint8_t>( ( seg_level >> ( 8 * ( mbs[m].segment_id & 3 ) ) ) & 255u );
     r.hdr.loop_filter_level = static_cast<uint8_t>( level );
     r.host_job->loop_filter_level = static_cast<uint8_t>( level );
   }
@@ -1836,26 +1864,99 @@ aa_status aa_stream_lf_search( aa_stream * s, const uint8_t * data, size_t size,
   HIP_TRY( hipMemcpyAsync( win.data(), cleanup.win, win.size() * sizeof( float ), hipMemcpyDeviceToHost, ctx->compute ) );
   HIP_TRY( hipStreamSynchronize( ctx->compute ) );
   if ( aa_status st = check_watchdog( ctx ) ) return st;
-  int best = level_lo; double best_q = -1.0; bool searching = true;
-  for ( int i = 0; i < n; i++ ) {
-    float total = 0.0f;                                                  // pixel_ssim_wxh: floats, four windows at a time, row by row
-    for ( int y = 0; y < h4 - 1; y++ )
-      for ( int x = 0; x < w4 - 1; x += 4 ) {
-        float part = 0.0f;
-        for ( int k = x; k < std::min( x + 4, w4 - 1 ); k++ ) part += win[windows * i + size_t( y ) * ( w4 - 1 ) + k];
-        total += part;
-      }
-    const double q = static_cast<double>( total ) / static_cast<double>( windows );
-    if ( ssim_out ) ssim_out[i] = q;
-    if ( searching ) { if ( q > best_q ) { best_q = q; best = level_lo + i; } else searching = false; }
-  }
-  if ( best_level ) *best_level = best;
-  if ( best_ssim ) *best_ssim = best_q;
+  score_candidates( win, n, w4, h4, level_lo, best_level, best_ssim, ssim_out );
   if ( rasters_out )
     for ( int i = 0; i < n; i++ ) {
       uint8_t * dst = rasters_out + size_t( i ) * ( s->plane_bytes[0] + 2 * s->plane_bytes[1] );
       if ( aa_status st = aa_stream_download( cand[i], fis[i], dst, dst + s->plane_bytes[0], dst + s->plane_bytes[0] + s->plane_bytes[1] ) ) return st;
     }
+  return AA_OK;
+}
+
+/* Encoder feedback (SURVEY 8f.4), the loop-filter level search of Encoder::apply_best_loopfilter_settings
+ * (encoder.cc:459-516): the frame as serialised with ANY level is parsed and reconstructed ONCE, unfiltered, on a scratch copy
+ * of the decoder (state + references; the stream itself is untouched).  Every candidate level then is an independent frame
+ * for the loop filter: a copy of the unfiltered raster, the macroblock records with the candidate's per-segment level and zero
+ * mode / reference adjustments (`filter_adjustments.reset( frame.header() )` after the adjustments were zeroed,
+ * encoder.cc:464-470) -- ONE k_loopfilter_rows4 launch over all candidates -- scored with BaseRaster::quality = x264's SSIM of
+ * the padded luma planes (util/raster.cc:63-66, util/ssim.cc:57-71).  Selection as in the reference: levels in ascending
+ * order, the first one that does not improve on the best so far ends the search (encoder.cc:489-503).
+ * (With the diagonal schedule -- no row-pipelined filter -- every candidate is decoded by a scratch decoder of its own.) */
+aa_status aa_stream_lf_search( aa_stream * s, const uint8_t * data, size_t size, const uint8_t * original_luma,
+                               int level_lo, int level_hi, int * best_level, double * best_ssim, double * ssim_out, uint8_t * rasters_out )
+{
+  if ( !s || !data || !original_luma ) return fail( AA_ERR_ARGUMENT, "aa_stream_lf_search: null argument" );
+  if ( level_lo < 0 || level_hi > 63 || level_lo > level_hi ) return fail( AA_ERR_ARGUMENT, "aa_stream_lf_search: levels must be 0 <= lo <= hi <= 63" );
+  aa_ctx * ctx = s->ctx;
+  if ( aa_status st = set_device( ctx ) ) return st;
+  if ( s->next_submit != static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_LOGIC, "aa_stream_lf_search: parsed frames are still waiting to be decoded" );
+  if ( ctx->schedule != 0 ) return lf_search_by_decoders( s, data, size, original_luma, level_lo, level_hi, best_level, best_ssim, ssim_out, rasters_out );
+  if ( aa_status st = segmap_to_host( s ) ) return st;
+  const int n = level_hi - level_lo + 1;
+
+  // ---- the unfiltered reconstruction, on a scratch decoder ----
+  aa_stream * x = nullptr;
+  struct Cleanup { aa_ctx * ctx; aa_stream *& x; uint8_t * dev = nullptr;
+                   ~Cleanup() { (void) hipStreamSynchronize( ctx->compute ); if ( x ) aa_stream_destroy( x ); if ( dev ) (void) hipFree( dev ); } } cleanup { ctx, x };
+  if ( aa_status st = aa_stream_create( ctx, s->parser.width(), s->parser.height(), &x ) ) return st;
+  x->parser = s->parser;                                                 // DecoderState as it stands before this frame
+  const void * planes[3][3]; const int on_device[3] = { 0, 0, 0 };
+  for ( int r = 0; r < 3; r++ ) for ( int p = 0; p < 3; p++ ) planes[r][p] = slot_plane( s, s->cur_ref_slot[r], p );
+  if ( aa_status st = aa_stream_set_references( x, planes, on_device ) ) return st;
+  int fx = -1;
+  if ( aa_status st = aa_stream_parse( x, data, size, &fx, nullptr ) ) return st;
+  {
+    FrameRec & r = x->frames[fx];
+    r.hdr.loop_filter_level = 0; r.host_job->loop_filter_level = 0;      // Frame::decode only (frame.cc:208-250)
+  }
+  if ( aa_status st = aa_decode_batch( ctx, &x, 1, &fx ) ) return st;
+  const FrameRec & rx = x->frames[fx];
+  const aa_dev_frame job_x = *rx.host_job;
+  const unsigned nmb = rx.hdr.num_macroblocks;
+  const uint8_t * unfiltered = slot_plane( x, rx.out_slot, 0 );
+  const size_t raster_bytes = s->plane_bytes[0] + 2 * s->plane_bytes[1];
+
+  // ---- per candidate: raster | macroblock records | job; then the original and the SSIM terms ----
+  const size_t mb_bytes = align_up( size_t( nmb ) * sizeof( aa_mb_info ) ), job_bytes = align_up( sizeof( aa_dev_frame ) );
+  const size_t per = align_up( raster_bytes ) + mb_bytes + job_bytes;
+  const int pw = s->pw, ph = s->ph, w4 = pw >> 2, h4 = ph >> 2;
+  const size_t windows = size_t( w4 - 1 ) * ( h4 - 1 );
+  const size_t orig_off = per * n, win_off = orig_off + align_up( s->plane_bytes[0] );
+  HIP_TRY( hipMalloc( reinterpret_cast<void **>( &cleanup.dev ), win_off + windows * n * sizeof( float ) ) );
+  uint8_t * base = cleanup.dev;
+  std::vector<aa_dev_frame> jobs( n );
+  std::vector<std::pair<uint32_t, const aa_dev_frame *>> keyed;
+  std::vector<const uint8_t *> luma( n );
+  for ( int i = 0; i < n; i++ ) {
+    const int level = level_lo + i;
+    uint8_t * raster = base + per * i;
+    aa_mb_info * mbs = reinterpret_cast<aa_mb_info *>( raster + align_up( raster_bytes ) );
+    aa_dev_frame * job_dev = reinterpret_cast<aa_dev_frame *>( reinterpret_cast<uint8_t *>( mbs ) + mb_bytes );
+    luma[i] = level ? raster : unfiltered;                               // level 0: Frame::loopfilter does nothing (frame.cc:144)
+    if ( !level ) continue;
+    HIP_TRY( hipMemcpyAsync( raster, unfiltered, raster_bytes, hipMemcpyDeviceToDevice, ctx->compute ) );
+    if ( const int e = aa::launch_lf_relevel( job_x.mbs, mbs, nmb, segment_levels( x->parser.segmentation(), level ), ctx->compute ) )
+      return hip_fail( static_cast<hipError_t>( e ), "k_lf_relevel" );
+    jobs[i] = job_x;
+    jobs[i].cur[0] = raster; jobs[i].cur[1] = raster + s->plane_bytes[0]; jobs[i].cur[2] = raster + s->plane_bytes[0] + s->plane_bytes[1];
+    jobs[i].mbs = mbs;
+    jobs[i].loop_filter_level = static_cast<uint8_t>( level );
+    HIP_TRY( hipMemcpyAsync( job_dev, &jobs[i], sizeof( aa_dev_frame ), hipMemcpyHostToDevice, ctx->compute ) );
+    keyed.emplace_back( ( static_cast<uint32_t>( rx.hdr.mb_width ) << 16 ) | rx.hdr.mb_height, job_dev );
+  }
+  if ( !keyed.empty() ) if ( aa_status st = launch_lf_rows( ctx, keyed, true, rx.hdr.mb_height, rx.hdr.mb_width ) ) return st;
+  uint8_t * orig_dev = base + orig_off;
+  float * win_dev = reinterpret_cast<float *>( base + win_off );
+  HIP_TRY( hipMemcpyAsync( orig_dev, original_luma, s->plane_bytes[0], hipMemcpyHostToDevice, ctx->compute ) );
+  for ( int i = 0; i < n; i++ )
+    if ( const int e = aa::launch_ssim_windows( luma[i], orig_dev, pw, ph, win_dev + windows * i, ctx->compute ) ) return hip_fail( static_cast<hipError_t>( e ), "k_ssim_windows" );
+  std::vector<float> win( windows * n );
+  HIP_TRY( hipMemcpyAsync( win.data(), win_dev, win.size() * sizeof( float ), hipMemcpyDeviceToHost, ctx->compute ) );
+  HIP_TRY( hipStreamSynchronize( ctx->compute ) );
+  if ( aa_status st = check_watchdog( ctx ) ) return st;
+  score_candidates( win, n, w4, h4, level_lo, best_level, best_ssim, ssim_out );
+  if ( rasters_out )
+    for ( int i = 0; i < n; i++ ) HIP_TRY( hipMemcpy( rasters_out + raster_bytes * i, luma[i], raster_bytes, hipMemcpyDeviceToHost ) );
   return AA_OK;
 }
 

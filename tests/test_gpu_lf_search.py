@@ -69,6 +69,15 @@ def test_lf_search_matches_the_oracle(gpu_ctx, w, h, seed, lo, hi, provisional, 
     assert dec.raster_bytes(fi) == rasters[best - lo]
 
 
+def test_lf_search_with_the_diagonal_schedule(gpu_ctx):
+    """Without the row-pipelined filter every candidate is decoded by a scratch decoder of its own: same results."""
+    gpu_ctx.set_schedule("diagonal")
+    try:
+        test_lf_search_matches_the_oracle(gpu_ctx, 175, 143, 65, 30, 33, 12, 2, None)
+    finally:
+        gpu_ctx.set_schedule("rows")
+
+
 def test_lf_search_argument_errors(gpu_ctx):
     w, h = 64, 64
     frames = variant(w, h, 70, 10, None, None, 0)
