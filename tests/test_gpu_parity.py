@@ -200,3 +200,16 @@ def test_hip_matches_oracle_on_large_and_extreme_geometries(gpu_ctx):
             assert ora.decode(fr) == shown
             got, want = dec.raster_bytes(fi), ora.raster_bytes()
             assert got == want, "%dx%d frame %d: %s" % (w, h, i, first_diff(got, want, dec.padded_width, dec.padded_height))
+
+
+def test_first_allocation_of_a_context_is_a_big_piece():
+    """Device pool: a raster above 128 MiB gets an allocation of its own.  When that is the FIRST allocation of a context, the
+    next ordinary request must still open a slab (round-1 bug: it was carved out of a slab that did not exist)."""
+    ctx = aa.Context(0)
+    big = aa.Decoder(ctx, 12000, 8000)            # 96 M luma pixels: one raster = 144 MB
+    w, h, frames = golden_frames("qcif_q30_lf24")
+    small = aa.Decoder(ctx, w, h)
+    for i, fr in enumerate(frames[:4]):
+        _, fi = small.get_frame_output(fr)
+        assert sha256(small.raster_bytes(fi)) == GOLDEN["qcif_q30_lf24"]["raster_sha256"][i]
+    del big, small
