@@ -30,6 +30,10 @@ import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
 
+# The pipeline runs 14 HIP streams side by side; HIP multiplexes streams over GPU_MAX_HW_QUEUES (default 4) hardware queues and
+# reads the variable when the runtime starts -- which, with torch.distributed, is before libalfalfa_amd.so is loaded.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
