@@ -88,6 +88,7 @@ SYMBOLS = [
     ("aa_submit_frames", C.c_int, [_P, C.POINTER(FrameIn), C.c_int, C.POINTER(C.c_int), C.c_int]),
     ("aa_submit_frames_ex", C.c_int, [_P, C.POINTER(FrameIn), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_uint]),
     ("aa_launch_tokens", C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
+    ("aa_ssim_host", C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     ("aa_stream_lf_search", C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.c_void_p]),
     ("aa_stream_frame_header", C.c_int, [_P, C.c_int, C.POINTER(FrameHeader)]),

@@ -1814,6 +1814,44 @@ uint32_t segment_levels( const aa::SegmentationState & seg, int level )      // 
 }
 } // namespace
 
+/* BaseRaster::quality on HOST planes (util/raster.cc:63-66 -> util/ssim.cc:57-71 -> libx264's pixel_ssim_wxh): the same
+ * measure aa_stream_lf_search computes on the device, for callers that hold rasters in host memory (VP8Raster::quality in the
+ * shim).  Plain host arithmetic -- the reference does this on the CPU too. */
+aa_status aa_ssim_host( const uint8_t * a, const uint8_t * b, int width, int height, double * out )
+{
+  if ( !a || !b || !out || width < 8 || height < 8 ) return fail( AA_ERR_ARGUMENT, "aa_ssim_host: null plane or a plane smaller than one 8x8 window" );
+  const int w4 = width >> 2, h4 = height >> 2;
+  // sums over every 4x4 block: pixels of a, pixels of b, squares of both, products
+  std::vector<int> blocks( size_t( w4 ) * h4 * 4 );
+  for ( int by = 0; by < h4; by++ )
+    for ( int bx = 0; bx < w4; bx++ ) {
+      int s1 = 0, s2 = 0, ss = 0, s12 = 0;
+      for ( int y = 0; y < 4; y++ ) {
+        const uint8_t * pa = a + size_t( 4 * by + y ) * width + 4 * bx, * pb = b + size_t( 4 * by + y ) * width + 4 * bx;
+        for ( int x = 0; x < 4; x++ ) { const int p = pa[x], q = pb[x]; s1 += p; s2 += q; ss += p * p + q * q; s12 += p * q; }
+      }
+      int * t = &blocks[( size_t( by ) * w4 + bx ) * 4];
+      t[0] = s1; t[1] = s2; t[2] = ss; t[3] = s12;
+    }
+  // one term per 8x8 window (2x2 blocks, windows step by 4 pixels), in single precision as x264's ssim_end1
+  std::vector<float> win( size_t( w4 - 1 ) * ( h4 - 1 ) );
+  for ( int y = 0; y < h4 - 1; y++ )
+    for ( int x = 0; x < w4 - 1; x++ ) {
+      int v[4];
+      for ( int k = 0; k < 4; k++ )
+        v[k] = blocks[( size_t( y ) * w4 + x ) * 4 + k] + blocks[( size_t( y ) * w4 + x + 1 ) * 4 + k]
+               + blocks[( size_t( y + 1 ) * w4 + x ) * 4 + k] + blocks[( size_t( y + 1 ) * w4 + x + 1 ) * 4 + k];
+      const int c1 = 416, c2 = 235963;           // (int)(.01*.01*255*255*64 + .5), (int)(.03*.03*255*255*64*63 + .5)
+      const int vars = v[2] * 64 - v[0] * v[0] - v[1] * v[1], covar = v[3] * 64 - v[0] * v[1];
+      const float num = static_cast<float>( 2 * v[0] * v[1] + c1 ) * static_cast<float>( 2 * covar + c2 );
+      const float den = static_cast<float>( v[0] * v[0] + v[1] * v[1] + c1 ) * static_cast<float>( vars + c2 );
+      win[size_t( y ) * ( w4 - 1 ) + x] = num / den;
+    }
+  score_candidates( win, 1, w4, h4, 0, nullptr, nullptr, out );
+  return AA_OK;
+}
+
+
 static aa_status lf_search_by_decoders( aa_stream * s, const uint8_t * data, size_t size, const uint8_t * original_luma,
                                         int level_lo, int level_hi, int * best_level, double * best_ssim, double * ssim_out, uint8_t * rasters_out )
 {

@@ -292,6 +292,9 @@ void aa_raster_geometry( uint16_t width, uint16_t height, uint32_t * padded_widt
 aa_status aa_stream_lf_search( aa_stream * s, const uint8_t * data, size_t size, const uint8_t * original_luma,
                                int level_lo, int level_hi, int * best_level, double * best_ssim, double * ssim_out, uint8_t * rasters_out );
 
+/* BaseRaster::quality (util/raster.cc:63-66: x264's SSIM of two planes, stride = width) for planes in HOST memory. */
+aa_status aa_ssim_host( const uint8_t * a, const uint8_t * b, int width, int height, double * out );
+
 /* Per-kernel timing of the device half, measured with HIP events on the compute stream.
  * enable=1 brackets every kernel launch with events (serialises nothing beyond event records). */
 typedef struct aa_kernel_stats {

@@ -221,6 +221,15 @@ public:
   bool operator==( const Plane & o ) const { return width_ == o.width_ && height_ == o.height_ && storage_ == o.storage_; }
 };
 
+// util/ssim.hh:31 -- the reference calls into libx264 (pixel_ssim_wxh over the whole plane, stride = width, / count)
+inline double ssim( const Plane & image, const Plane & other_image )
+{
+  if ( image.width() != other_image.width() || image.height() != other_image.height() ) throw std::invalid_argument( "ssim: planes of different size" );
+  double q = 0;
+  check( aa_ssim_host( &image.at( 0, 0 ), &other_image.at( 0, 0 ), static_cast<int>( image.width() ), static_cast<int>( image.height() ), &q ) );
+  return q;
+}
+
 class VP8Raster
 {
   uint16_t display_width_, display_height_, width_, height_;
@@ -245,6 +254,12 @@ public:
   uint16_t chroma_display_height() const { return ( 1 + display_height_ ) / 2; }
   bool operator==( const VP8Raster & o ) const { return Y_ == o.Y_ && U_ == o.U_ && V_ == o.V_; }
   bool operator!=( const VP8Raster & o ) const { return !operator==( o ); }
+  double quality( const VP8Raster & other ) const { return ssim( Y(), other.Y() ); }        // raster.cc:63-66: SSIM of the luma planes
+  void copy_from( const VP8Raster & other )                                                  // raster.cc:78-83
+  {
+    if ( width_ != other.width_ || height_ != other.height_ ) throw std::invalid_argument( "copy_from: rasters of different size" );
+    Y_ = other.Y_; U_ = other.U_; V_ = other.V_;
+  }
   std::vector<Chunk> display_rectangle_as_planar() const     // raster.cc:85-104
   {
     std::vector<Chunk> ret;
@@ -644,6 +659,17 @@ public:
   // N independent decoders, one frame each, as ONE batch step on the GPU (aa_decode_batch): what fills the chip when an
   // ExCamera bundle or a set of streams is decoded (the reference loops over its decoders one after the other).
   // All decoders must live on the same GpuContext.  Returns (shown, raster) per decoder.
+  // The loop-filter level search of Encoder::apply_best_loopfilter_settings (encoder.cc:459-516) for the frame an encoder is
+  // about to write (serialised with any provisional level): candidates level_lo..level_hi filtered and scored against `original`
+  // as ONE GPU batch; this decoder is not advanced.  -> { best level, its SSIM } by the reference's rule.
+  std::pair<uint8_t, double> search_loopfilter_level( const Chunk & frame, const VP8Raster & original, const uint8_t level_lo, const uint8_t level_hi )
+  {
+    if ( original.width() != VP8Raster( owner_->width, owner_->height ).width() ) throw std::invalid_argument( "search_loopfilter_level: original of another size" );
+    int best = 0; double q = 0;
+    check( aa_stream_lf_search( owner_->stream, frame.buffer(), frame.size(), &original.Y().at( 0, 0 ), level_lo, level_hi, &best, &q, nullptr, nullptr ) );
+    return { static_cast<uint8_t>( best ), q };
+  }
+
   static std::vector<std::pair<bool, RasterHandle>> get_frame_outputs( const std::vector<Decoder *> & decoders, const std::vector<Chunk> & frames )
   {
     if ( decoders.size() != frames.size() || decoders.empty() ) throw std::invalid_argument( "get_frame_outputs: one frame per decoder" );

@@ -132,3 +132,26 @@ def test_ivf_to_y4m_resumes_from_a_state_file_written_by_the_reference(tmp_path)
     shown_before = sum(GOLDEN[name]["shown"][:n])
     frame = len(full) // sum(GOLDEN[name]["shown"])
     assert tail == full[shown_before * frame:]
+
+
+@pytest.mark.parametrize("w,h,seed", [(176, 144, 5), (175, 143, 6), (1920, 1080, 7)])
+def test_raster_quality_in_the_shim_equals_the_oracle(w, h, seed):
+    """VP8Raster::quality / ssim() / copy_from of the shim (host code, no GPU): the program's pseudo-random rasters are rebuilt
+    here and scored by the oracle's restatement of x264's SSIM."""
+    import numpy as np
+    import vp8_oracle as vo
+    exe = build_exe(os.path.join(ROOT, "tests", "cpp", "raster_quality_check.cc"), "raster_quality_check")
+    got = [float(x) for x in subprocess.run([exe, str(w), str(h), str(seed)], check=True, capture_output=True, text=True).stdout.split()]
+    pw, ph = (w + 15) // 16 * 16, (h + 15) // 16 * 16
+    state = [seed]
+
+    def lcg():
+        state[0] = (state[0] * 1664525 + 1013904223) & 0xFFFFFFFF
+        return state[0] >> 8
+    a = np.array([lcg() & 255 for _ in range(pw * ph)], np.uint8)
+    want = [vo.ssim_plane(a.tobytes(), a.tobytes(), pw, ph)]
+    for amp in (2, 9, 60):
+        b = np.clip(a.astype(int) + np.array([lcg() % (2 * amp + 1) - amp for _ in range(pw * ph)]), 0, 255).astype(np.uint8)
+        q = vo.ssim_plane(a.tobytes(), b.tobytes(), pw, ph)
+        want += [q, q]
+    assert got == want

@@ -52,3 +52,21 @@ def test_oracle_ssim_orders_distortions():
     a = rng.integers(0, 256, (96, 128), dtype=np.uint8)
     qs = [vo.ssim_plane(a.tobytes(), np.clip(a.astype(int) + rng.integers(-n, n + 1, a.shape), 0, 255).astype(np.uint8).tobytes(), 128, 96) for n in (1, 4, 16, 64)]
     assert qs == sorted(qs, reverse=True) and qs[0] > 0.99 and qs[-1] < 0.9
+
+
+def test_product_host_ssim_equals_the_oracle():
+    """aa_ssim_host (VP8Raster::quality of the shim; the summation half is shared with aa_stream_lf_search) against the
+    oracle's restatement, bit for bit."""
+    import ctypes as C
+    from alfalfa_amd import capi
+    L = capi.lib()
+    rng = np.random.default_rng(11)
+    for w, h in ((48, 64), (176, 144), (1920, 1088), (8, 8), (200, 56), (36, 20)):
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        for noise in (0, 3, 30):
+            b = np.clip(a.astype(int) + rng.integers(-noise, noise + 1, a.shape), 0, 255).astype(np.uint8)
+            out = C.c_double()
+            capi.check(L.aa_ssim_host(a.tobytes(), b.tobytes(), w, h, C.byref(out)))
+            assert out.value == vo.ssim_plane(a.tobytes(), b.tobytes(), w, h), (w, h, noise)
+    with pytest.raises(capi.AlfalfaError):
+        capi.check(L.aa_ssim_host(b"\0" * 16, b"\0" * 16, 4, 4, C.byref(C.c_double())))
