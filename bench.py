@@ -230,7 +230,7 @@ def main():
     # coefficient blocks per macroblock), and the rasters the decoder sets refer to.  Clamp the look-ahead to what fits.
     rec_bytes = mbs_per_frame * 80 + (25 * mbs_per_frame + 1) * 32 + 2 * mbs_per_frame + 4096
     raster_bytes = sum(aa.Decoder(ctx, width, height).plane_sizes())
-    budget = 0.85 * ctx.memory()[0]
+    budget = 0.9 * ctx.memory()[0]
     K, D = max(1, args.key_ahead), max(1, min(args.depth, args.key_ahead))
 
     def need(k, d):
