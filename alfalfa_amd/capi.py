@@ -12,7 +12,7 @@ from . import build as _build
 
 AA_OK = 0
 ERR_NAMES = {-1: "Invalid", -2: "Unsupported", -3: "LogicError", -4: "OutOfRange", -5: "HipError",
-             -6: "NoDevice", -7: "BadArgument"}
+             -6: "NoDevice", -7: "BadArgument", -8: "NoMemory"}
 
 AA_MB_HAS_NONZERO, AA_MB_HAS_Y2, AA_MB_INTER, AA_MB_SKIP, AA_MB_LF_SKIP_INNER = 1, 2, 4, 8, 16
 
@@ -49,7 +49,16 @@ class KernelStats(C.Structure):
                 ("parse_headers_ms", C.c_double), ("parse_tokens_ms", C.c_double), ("parse_launches", C.c_uint64),
                 ("parsed_macroblocks", C.c_uint64), ("recon_split_ms", C.c_double), ("recon_split_launches", C.c_uint64),
                 ("pool_waits", C.c_uint64), ("pool_wait_ms", C.c_double), ("parse_wait_ms", C.c_double),
-                ("bind_wait_ms", C.c_double), ("alloc_ms", C.c_double), ("slab_mallocs", C.c_uint64)]
+                ("bind_wait_ms", C.c_double), ("alloc_ms", C.c_double), ("slab_mallocs", C.c_uint64),
+                ("token_steps", C.c_uint64), ("token_frames", C.c_uint64), ("worker_launches", C.c_uint64), ("worker_wgs", C.c_uint64),
+                ("worker_retires", C.c_uint64), ("heap_grows", C.c_uint64), ("heap_mapped_bytes", C.c_uint64), ("nomem_retries", C.c_uint64)]
+
+
+class CtxInfo(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("memory_limit_bytes", "pool_bytes", "heap_mapped_bytes", "heap_limit_bytes", "heap_used_bytes",
+                                          "pinned_host_bytes")] + [
+        (n, C.c_uint32) for n in ("heap_is_virtual", "token_lanes_per_workgroup", "token_workgroups_capacity", "token_workgroups_alive",
+                                  "token_lane_lds_bytes", "token_workgroup_lds_bytes", "jobs_waiting", "compute_units")]
 
 
 class AlfalfaError(RuntimeError):
@@ -79,6 +88,7 @@ SYMBOLS = [
     ("aa_stream_export_raster", C.c_int, [_P, C.c_int, _P, _P, _P]),
     ("aa_ctx_create", C.c_int, [C.c_int, C.POINTER(_P)]), ("aa_ctx_destroy", None, [_P]), ("aa_ctx_sync", C.c_int, [_P]),
     ("aa_ctx_memory", C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("aa_ctx_set_memory_limit", C.c_int, [_P, C.c_size_t]), ("aa_ctx_get_info", C.c_int, [_P, C.POINTER(CtxInfo)]),
     ("aa_ctx_set_schedule", C.c_int, [_P, C.c_int]), ("aa_ctx_clear_error", C.c_int, [_P]), ("aa_ctx_compute_stream", _P, [_P]), ("aa_ctx_copy_stream", _P, [_P]),
     ("aa_stream_create", C.c_int, [_P, C.c_uint16, C.c_uint16, C.POINTER(_P)]), ("aa_stream_destroy", None, [_P]),
     ("aa_stream_parse", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(FrameHeader)]),

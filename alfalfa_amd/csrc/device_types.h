@@ -52,15 +52,33 @@ struct aa_frame_list {
 // at all-3 with that frame), map = the stream's persistent segment map in HBM (mb_width*mb_height bytes)
 struct aa_seg_stream { uint8_t * map; uint32_t first, count; };
 
+// Counters of the device-side job queue / coefficient pool / worker grids as one kernel thread saw them, in pinned host memory
+#define AA_MAX_WORKER_GRIDS 16
+struct aa_tok_mirror {
+  uint32_t seq;                // the mirror kernel's number (written last)
+  uint32_t q_head, q_publish, q_reserve;
+  int32_t pool_avail;
+  uint32_t pool_starving;
+  uint32_t exited[AA_MAX_WORKER_GRIDS];
+};
+
 // kernels.hip / parse_kernels.hip launchers (plain C++ signatures so runtime.cpp needs no HIP kernel syntax)
 namespace aa {
 struct ParseJob;   // tok_fsm.hh
+struct TokQueue; struct CoeffPool; struct Heap;
 // device-side entropy decode of n frames (jobs resident in HBM): macroblock headers, then (streams with segmentation only)
 // the segment-map pass, then tokens
 // order[slot] = job index: the host sorts the frames of a batch by chain length so that the lanes of a wave finish together
 int launch_parse_mb_headers( const ParseJob * jobs, const uint32_t * order, int n, void * stream );
 int launch_segment_fixup( const ParseJob * jobs, const aa_seg_stream * streams, int n_streams, const uint32_t * order, void * stream );
-int launch_parse_tokens( const ParseJob * jobs, const uint32_t * order, int n, int max_mbw, int max_nparts, void * stream );
+// token workers (tok_fsm.hh, parse_kernels.hip): lanes that take frames from a queue in HBM
+void token_worker_shape( uint32_t lane_bytes, int n_cus, int * lanes_out, uint32_t * lds_out, int * wgs_per_cu_out );
+int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap & heap, uint32_t * exited, const uint32_t * retire, uint32_t gen,
+                          int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, void * stream );
+int launch_enqueue_jobs( TokQueue * q, unsigned long long * slots, const ParseJob * jobs, const uint32_t * order, int n, void * stream );
+int launch_pool_push_range( const Heap & heap, uint32_t first, uint32_t count, void * stream );
+int launch_pool_free_lists( const Heap & heap, const uint32_t * const * lists, int n, void * stream );
+int launch_mirror_counters( const TokQueue * q, const CoeffPool * pool, const uint32_t * exited, int n_grids, aa_tok_mirror * out, uint32_t seq, void * stream );
 // whole-vector inter macroblocks, four per wave
 int launch_recon_inter4( const aa_frame_list & list, int n, unsigned max_mbs, void * stream );
 // one inter macroblock per wave; split_only: only SPLITMV macroblocks (the rest is launch_recon_inter4's)

@@ -76,26 +76,163 @@ __global__ __launch_bounds__( 256 ) void k_segment_fixup( const ParseJob * jobs,
   }
 }
 
-__global__ __launch_bounds__( 64 ) void k_parse_tokens( const ParseJob * jobs, const uint32_t * order, int n, int lanes, uint32_t lane_bytes )
+// ---- token workers ----------------------------------------------------------------------------------------------------
+// A workgroup = one wave; `lanes` of its threads are token lanes.  A lane without a frame takes the next job of the queue; a
+// wave leaves when none of its lanes has a frame and the queue has nothing for them (or its grid was told to retire: the
+// host wants the stream the grid was launched on).  Work arriving later is picked up by the lanes that become free -- or by a
+// grid the host launches when too few workgroups are alive (runtime.cpp, ensure_workers).
+struct WorkerArgs {
+  aa::TokQueue * q;
+  unsigned long long * slots;             // q->mask + 1 job pointers
+  aa::Heap heap;
+  uint32_t * exited;                      // this grid's count of workgroups that have left (HBM)
+  const uint32_t * retire;                // grids of this slot up to generation *retire take no new jobs (pinned host memory, mapped)
+  uint32_t gen;                           // this grid's generation
+  int lanes;
+  uint32_t lane_bytes;
+};
+
+// up to `want` tickets for this wave (called by ONE lane): -> first ticket in *base, how many as the result
+__device__ inline uint32_t queue_take( aa::TokQueue * q, uint32_t want, uint32_t * base )
+{
+  uint32_t h = AA_AT_LOAD( &q->head );
+  for ( int tries = 0; tries < 16; tries++ ) {
+    const uint32_t avail = AA_AT_LOAD( &q->publish ) - h;
+    if ( static_cast<int32_t>( avail ) <= 0 ) return 0;
+    const uint32_t n = want < avail ? want : avail;
+    uint32_t expect = h;
+    if ( __hip_atomic_compare_exchange_strong( &q->head, &expect, h + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) { *base = h; return n; }
+    h = expect;
+  }
+  return 0;                               // (contended: the next period tries again)
+}
+
+__global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t smem[];
   const int lane = threadIdx.x;
-  const int slot = blockIdx.x * lanes + lane;
-  const int j = static_cast<int>( order[lane < lanes && slot < n ? slot : 0] );
-  const bool active = lane < lanes && slot < n && jobs[j].nmb != 0;
   for ( uint32_t k = lane; k < aa::tok::kTablesBytes / 4; k += 64 ) reinterpret_cast<uint32_t *>( smem )[k] = aa::tok::table_word( k );
   __syncthreads();
   aa::tok::Lane L;
-  aa::tok::Frame F = aa::tok::frame_of( &jobs[active ? j : 0] );
+  aa::tok::Frame F {};
   L.rec = aa::tok::R_DONE;
-  L.base = aa::tok::kTablesBytes;
+  L.base = aa::tok::kTablesBytes + static_cast<uint32_t>( lane ) * a.lane_bytes;
   L.pend_wpos = L.pend_mwpos = aa::tok::kNoPend;
-  if ( active ) aa::tok::begin_frame( L, smem, aa::tok::kTablesBytes + static_cast<uint32_t>( lane ) * lane_bytes, F );
+  L.steps = 0;
+  const bool is_lane = lane < a.lanes;
+  uint32_t backoff = 0;
   for ( ;; ) {
+    const bool idle = is_lane && L.rec == aa::tok::R_DONE;
+    const unsigned long long idle_mask = __ballot( idle );
+    bool looked = false, retired = false;
+    if ( idle_mask ) {
+      if ( backoff ) backoff--;
+      else {
+        looked = true;
+        const int first = __ffsll( static_cast<long long>( idle_mask ) ) - 1;
+        uint32_t base = 0, got = 0;
+        if ( lane == first ) {
+          if ( __hip_atomic_load( a.retire, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM ) >= a.gen ) got = 0xFFFFFFFFu;
+          else got = queue_take( a.q, static_cast<uint32_t>( __popcll( idle_mask ) ), &base );
+        }
+        base = __shfl( base, first ); got = __shfl( got, first );
+        if ( got == 0xFFFFFFFFu ) { retired = true; got = 0; }
+        const uint32_t rank = static_cast<uint32_t>( __popcll( idle_mask & ( ( 1ull << lane ) - 1ull ) ) );
+        const bool mine = idle && rank < got;
+        if ( got ) {
+          // the slot, the job, the compressed frame, the header kernel's flags: written by other agents / other XCDs, and
+          // this CU may hold stale lines of the recycled memory they live in
+          __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "agent" );
+          if ( mine ) {
+            const aa::ParseJob * job = reinterpret_cast<const aa::ParseJob *>( AA_AT_LOAD( &a.slots[( base + rank ) & a.q->mask] ) );
+            F = aa::tok::frame_of( job );
+            if ( F.nmb == 0 ) { L.rec = aa::tok::R_DONE; }                        // (never queued; belt and braces)
+            else aa::tok::begin_frame( L, smem, L.base, F );
+          }
+        } else backoff = 3;               // nothing there: the busy lanes of this wave should not pay for a look every period
+      }
+    }
+    const bool active = is_lane && L.rec != aa::tok::R_DONE;
+    if ( !__any( active ) ) {
+      if ( looked ) break;                // no lane has a frame and there was nothing to take (or the grid retires)
+      if ( retired ) break;
+      backoff = 0;
+      continue;
+    }
     if ( active ) aa::tok::top_up( L, smem, F );
-    if ( !__any( L.rec != aa::tok::R_DONE ) ) break;
-    aa::tok::run_period( L, smem, F );
+    aa::tok::run_period( L, smem, F, a.heap );
   }
+  if ( lane == 0 ) AA_AT_ADD( a.exited, 1u );
+}
+
+// jobs[order[i]] -> the queue, in this order (longest chains first).  Frames the host pre-pass rejected (nmb == 0) go in too:
+// the lane that draws one drops it.
+__global__ __launch_bounds__( 64 ) void k_enqueue_jobs( aa::TokQueue * q, unsigned long long * slots, const ParseJob * jobs, const uint32_t * order, int n )
+{
+  __shared__ uint32_t s_base;
+  if ( threadIdx.x == 0 ) s_base = AA_AT_ADD( &q->reserve, static_cast<uint32_t>( n ) );
+  __syncthreads();
+  const uint32_t base = s_base, mask = q->mask;
+  for ( int i = threadIdx.x; i < n; i += 64 ) AA_AT_STORE( &slots[( base + i ) & mask], reinterpret_cast<unsigned long long>( &jobs[order[i]] ) );
+  __syncthreads();
+  if ( threadIdx.x == 0 ) {
+    __builtin_amdgcn_fence( __ATOMIC_RELEASE, "agent" );
+    asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );                 // (one wave: this waits for every lane's stores)
+    while ( AA_AT_LOAD( &q->publish ) != base ) __builtin_amdgcn_s_sleep( 8 );     // in order (earlier reservers are running)
+    AA_AT_STORE( &q->publish, base + static_cast<uint32_t>( n ) );
+  }
+}
+
+// One wave returns chunk numbers to the pool: thread t brings n_mine of them (ids, or first, first + 1, ...).  ONE reservation
+// and ONE publication per wave -- threads of a wave must never wait for each other's publication (lock step).
+__device__ inline void pool_push_wave( const aa::Heap & H, const AA_GLOBAL uint32_t * ids, uint32_t first, uint32_t n_mine )
+{
+  __shared__ uint32_t s_off[65];
+  __shared__ uint32_t s_pbase;
+  s_off[threadIdx.x + 1] = n_mine;
+  __syncthreads();
+  if ( threadIdx.x == 0 ) {
+    s_off[0] = 0;
+    for ( int i = 1; i <= 64; i++ ) s_off[i] += s_off[i - 1];
+    s_pbase = s_off[64] ? AA_AT_ADD( &H.pool->reserve, s_off[64] ) : 0u;
+  }
+  __syncthreads();
+  const uint32_t b = s_pbase + s_off[threadIdx.x], mask = H.pool->mask, total = s_off[64];
+  for ( uint32_t i = 0; i < n_mine; i++ ) AA_AT_STORE( &H.ring[( b + i ) & mask], ids ? ids[i] : first + i );
+  __syncthreads();
+  if ( threadIdx.x == 0 && total ) {
+    __builtin_amdgcn_fence( __ATOMIC_RELEASE, "agent" );
+    asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+    while ( AA_AT_LOAD( &H.pool->publish ) != s_pbase ) __builtin_amdgcn_s_sleep( 8 );
+    AA_AT_STORE( &H.pool->publish, s_pbase + total );
+    AA_AT_ADD_REL( &H.pool->avail, static_cast<int32_t>( total ) );
+  }
+}
+// chunks [first, first + count) of newly mapped heap -> the pool
+__global__ __launch_bounds__( 64 ) void k_pool_push_range( aa::Heap heap, uint32_t first, uint32_t count )
+{
+  const uint32_t per = ( count + 63u ) / 64u, lo = threadIdx.x * per;
+  const uint32_t mine = lo >= count ? 0u : ( count - lo < per ? count - lo : per );
+  pool_push_wave( heap, nullptr, first + lo, mine );
+}
+// the chunks of released frames -> the pool: lists[i][0] = count, then the chunk numbers
+struct FreeLists { const uint32_t * l[AA_MAX_BATCH]; };
+__global__ __launch_bounds__( 64 ) void k_pool_free_lists( aa::Heap heap, const FreeLists lists, int n )
+{
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const AA_GLOBAL uint32_t * l = ( i < n && lists.l[i] ) ? (const AA_GLOBAL uint32_t *) lists.l[i] : nullptr;
+  pool_push_wave( heap, l ? l + 1 : nullptr, 0, l ? l[0] : 0u );
+}
+// the counters the host steers by, gathered by ONE thread into pinned host memory (a single writer: no torn or reordered view)
+__global__ void k_mirror_counters( const aa::TokQueue * q, const aa::CoeffPool * pool, const uint32_t * exited, int n_grids, aa_tok_mirror * out, uint32_t seq )
+{
+  if ( threadIdx.x || blockIdx.x ) return;
+  out->q_head = AA_AT_LOAD( &q->head ); out->q_publish = AA_AT_LOAD( &q->publish ); out->q_reserve = AA_AT_LOAD( &q->reserve );
+  if ( pool ) { out->pool_avail = AA_AT_LOAD( &pool->avail ); out->pool_starving = AA_AT_LOAD( &pool->starving ); }
+  for ( int g = 0; g < n_grids; g++ ) out->exited[g] = AA_AT_LOAD( &exited[g] );
+  __builtin_amdgcn_fence( __ATOMIC_RELEASE, "" );
+  asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+  __hip_atomic_store( &out->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
 }
 
 } // namespace
@@ -159,9 +296,9 @@ int launch_segment_fixup( const ParseJob * jobs, const aa_seg_stream * streams, 
   return static_cast<int>( hipGetLastError() );
 }
 
-int launch_parse_tokens( const ParseJob * jobs, const uint32_t * order, int n, int max_mbw, int max_nparts, void * stream )
+// Shape of a worker grid for slices of `lane_bytes`: lanes per workgroup, LDS request, workgroups the GPU holds at once
+void token_worker_shape( uint32_t lane_bytes, int n_cus, int * lanes_out, uint32_t * lds_out, int * wgs_per_cu_out )
 {
-  const uint32_t lane_bytes = tok::lane_lds_bytes( static_cast<uint32_t>( max_mbw ), max_nparts > 1 );
   int lanes = parse_lanes_env();
   uint32_t lds = 0;
   if ( lanes ) {
@@ -171,8 +308,48 @@ int launch_parse_tokens( const ParseJob * jobs, const uint32_t * order, int n, i
     const TokenShape sh = token_launch_shape( lane_bytes );
     lanes = sh.lanes; lds = sh.lds;
   }
-  if ( lanes < 1 ) return static_cast<int>( hipErrorInvalidValue );
-  hipLaunchKernelGGL( k_parse_tokens, dim3( ( n + lanes - 1 ) / lanes ), dim3( 64 ), lds, static_cast<hipStream_t>( stream ), jobs, order, n, lanes, lane_bytes );
+  (void) n_cus;
+  *lanes_out = lanes; *lds_out = lds;
+  *wgs_per_cu_out = lds ? static_cast<int>( ( kLdsPerCu - kLdsReserve ) / lds ) : 0;
+}
+
+int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap & heap, uint32_t * exited, const uint32_t * retire, uint32_t gen,
+                          int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, void * stream )
+{
+  if ( lanes < 1 || wgs < 1 ) return static_cast<int>( hipErrorInvalidValue );
+  WorkerArgs a;
+  a.q = q; a.slots = slots; a.heap = heap; a.exited = exited; a.retire = retire; a.gen = gen; a.lanes = lanes; a.lane_bytes = lane_bytes;
+  hipLaunchKernelGGL( k_token_workers, dim3( wgs ), dim3( 64 ), lds, static_cast<hipStream_t>( stream ), a );
+  return static_cast<int>( hipGetLastError() );
+}
+
+int launch_enqueue_jobs( TokQueue * q, unsigned long long * slots, const ParseJob * jobs, const uint32_t * order, int n, void * stream )
+{
+  hipLaunchKernelGGL( k_enqueue_jobs, dim3( 1 ), dim3( 64 ), 0, static_cast<hipStream_t>( stream ), q, slots, jobs, order, n );
+  return static_cast<int>( hipGetLastError() );
+}
+
+int launch_pool_push_range( const Heap & heap, uint32_t first, uint32_t count, void * stream )
+{
+  hipLaunchKernelGGL( k_pool_push_range, dim3( 1 ), dim3( 64 ), 0, static_cast<hipStream_t>( stream ), heap, first, count );
+  return static_cast<int>( hipGetLastError() );
+}
+
+int launch_pool_free_lists( const Heap & heap, const uint32_t * const * lists, int n, void * stream )
+{
+  for ( int base = 0; base < n; base += AA_MAX_BATCH ) {
+    FreeLists fl;
+    const int cnt = std::min( AA_MAX_BATCH, n - base );
+    for ( int i = 0; i < AA_MAX_BATCH; i++ ) fl.l[i] = i < cnt ? lists[base + i] : nullptr;
+    hipLaunchKernelGGL( k_pool_free_lists, dim3( ( cnt + 63 ) / 64 ), dim3( 64 ), 0, static_cast<hipStream_t>( stream ), heap, fl, cnt );
+    if ( hipError_t e = hipGetLastError() ) return static_cast<int>( e );
+  }
+  return 0;
+}
+
+int launch_mirror_counters( const TokQueue * q, const CoeffPool * pool, const uint32_t * exited, int n_grids, aa_tok_mirror * out, uint32_t seq, void * stream )
+{
+  hipLaunchKernelGGL( k_mirror_counters, dim3( 1 ), dim3( 64 ), 0, static_cast<hipStream_t>( stream ), q, pool, exited, n_grids, out, seq );
   return static_cast<int>( hipGetLastError() );
 }
 

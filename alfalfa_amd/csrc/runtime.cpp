@@ -28,6 +28,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include "../../include/alfalfa_amd.h"
 #include "device_types.h"
 #include "parser.hh"
@@ -70,8 +72,7 @@ struct Batch {
   uint8_t * host = nullptr, * dev = nullptr;
   size_t host_bytes = 0, dev_bytes = 0;
   int n = 0, live = 0;
-  hipEvent_t done = nullptr;                 // parse kernels finished and the summaries are back in `host`
-  bool done_seen = false;
+  hipEvent_t hdr_done = nullptr;             // macroblock-header kernel (+ segment pass, + the hand-over to the job queue) finished
   size_t summaries_off = 0;
   uint8_t * host_dev = nullptr;              // `host` as the device sees it (the parse kernels write the summaries there)
   // Two-phase form (AA_SUBMIT_DEFER_TOKENS): the macroblock-header kernel has been queued, the token kernel has not -- the
@@ -111,10 +112,14 @@ struct FrameRec {
   Batch * batch = nullptr;                 // device-parsed frame: its submit call ...
   int batch_item = -1;                     // ... and its index there
   bool summary_pending = false;            // counts (intra macroblocks, coefficient blocks, SPLITMV) not yet read back from the device parser
-  uint8_t * rec_block = nullptr;           // device-parsed frame: macroblock records, intra row masks, flags in HBM ...
+  uint8_t * rec_block = nullptr;           // device-parsed frame: macroblock records, intra row masks, flags, chunk list in HBM
   size_t rec_bytes = 0;
-  uint8_t * coeff_block = nullptr;         // ... and its coefficient blocks (worst-case sized: 25 per macroblock + 1)
-  size_t coeff_bytes = 0;
+  const uint32_t * chunk_list = nullptr;   // ... the list of coefficient chunks its token lane took (in rec_block; [0] = count)
+  volatile aa::FrameSummary * summary = nullptr;   // in the batch's pinned arena: the token lane's last word lands here
+  const aa::ParseJob * parse_job = nullptr;        // in the batch's device arena
+  bool enqueued = false;                   // handed to the job queue (a token lane may be writing its records)
+  uint32_t est_chunks = 0;                 // coefficient chunks accounted for this frame (an estimate until the parse is over)
+  bool chunks_returned = false;            // the frame was handed back for lack of memory and its chunks are in the pool again
   bool records_released = false;
   bool placed = false;                     // raster slot + References bookkeeping done (at the first decode submission)
 };
@@ -144,14 +149,52 @@ struct aa_ctx {
   int prio_low = 0;
   int next_parse_stream = 0;
   hipEvent_t last_seg_batch = nullptr;  // segment-map passes of consecutive batches must run in order
-  std::vector<Batch *> deferred;        // batches whose token kernel has not been launched yet, oldest first
+  std::vector<Batch *> deferred;        // batches whose frames have not been handed to the job queue yet, oldest first
+  // ---- token workers: job queue, coefficient heap, worker grids (tok_fsm.hh) ----
+  struct Tok {
+    bool ready = false;
+    hipStream_t util = nullptr;          // mirror kernel, heap pushes: never behind anything long
+    // job queue
+    aa::TokQueue * q = nullptr;
+    unsigned long long * slots = nullptr;
+    uint32_t q_slots = 1u << 18;
+    uint64_t jobs_enqueued = 0;          // tickets the host has scheduled (a ticket = one frame, rejected ones included)
+    std::vector<volatile aa::FrameSummary *> inflight;   // frames handed to the queue and not yet seen done
+    uint32_t * one_dev = nullptr;        // a zero in HBM: the `order` of a one-job hand-over
+    // coefficient heap: ONE virtual range, physical memory mapped as the frames need it
+    uint8_t * heap = nullptr;
+    size_t heap_va = 0, heap_mapped = 0, heap_limit = 0, grow_bytes = size_t( 1 ) << 30;
+    bool vmm = false;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    aa::CoeffPool * pool = nullptr;
+    uint32_t * ring = nullptr;
+    int64_t chunks_committed = 0;        // chunks frames hold (parsed: what they took) or are expected to take (in flight: estimate)
+    double blocks_per_mb = 25.0;         // running estimate of what a macroblock stores (starts at the worst case)
+    uint32_t seen_starving = 0;
+    std::vector<const uint32_t *> pending_lists;   // chunk lists of released frames, not yet handed to k_pool_free_lists
+    // worker grids: slot g = worker stream g; counters are cumulative over the grids a slot has run
+    static constexpr int kSlots = 6;
+    struct Slot { hipStream_t st = nullptr; uint32_t launched = 0, gen = 0; bool queued_behind_retiring = false; } slot[kSlots];
+    uint32_t * exited_dev = nullptr;     // [AA_MAX_WORKER_GRIDS] in HBM
+    uint32_t * retire_host = nullptr, * retire_dev = nullptr;     // [AA_MAX_WORKER_GRIDS]: grids of generation <= this take no more jobs
+    aa_tok_mirror * mirror_host = nullptr, * mirror_dev = nullptr;
+    uint32_t mirror_seq = 0;
+    uint32_t lane_bytes = 0, lds = 0;
+    int lanes = 0, cap_wgs = 0, n_cus = 0;
+  } tok;
   // Device pieces given back while kernels that read them may still be queued: they become reusable once an event recorded
   // on the compute stream after the release has fired ("epochs": one event per group of releases, recorded lazily).
   struct PendingFree { uint8_t * p; size_t bytes; uint64_t epoch; };
   std::vector<PendingFree> pending_free;
-  std::vector<std::pair<uint64_t, hipEvent_t>> epoch_events;   // closed epochs, oldest first
+  struct Epoch { uint64_t id; hipEvent_t compute, copy; };   // copy: null unless downloads were queued on the copy stream
+  std::vector<Epoch> epoch_events;      // closed epochs, oldest first
   uint64_t open_epoch = 1;
   bool open_epoch_used = false;
+  // Between the first raster binding of an aa_decode_batch call and its last launch no epoch may be closed: a raster that
+  // bind_frame releases (an old reference, an output nobody holds) is still read or written by kernels that are not queued
+  // yet, and an event recorded now would sit in FRONT of them on the compute stream.
+  int binding_depth = 0;
+  bool copy_reads_rasters = false;      // aa_stream_download_async queued copies since the last epoch was closed
   bool profile = false;
   int schedule = 0;            // 0: row-pipelined persistent kernels (default), 1: one launch per 2:1 anti-diagonal
   int n_xcd = 1;               // XCDs workgroups land on (probed at creation); row kernels keep a unit on one XCD
@@ -165,7 +208,9 @@ struct aa_ctx {
   uint8_t * cur_slab = nullptr;
   size_t slab_used = 0;
   size_t pool_bytes = 0;                  // HBM the pool has taken from HIP so far
-  size_t pool_soft_limit = ~size_t( 0 );  // beyond this the pool waits for released pieces rather than grow (aa_ctx_create: 7/8 of what was free)
+  size_t pool_soft_limit = ~size_t( 0 );  // beyond this (slabs + mapped coefficient heap) the pool waits for released pieces rather than grow
+                                          // (aa_ctx_create: 7/8 of what was free; aa_ctx_set_memory_limit)
+  size_t pinned_bytes = 0;                // pinned host memory the context has taken (arenas, staging chunks, binding buffers)
   std::map<size_t, std::vector<uint8_t *>> dev_free;
   uint8_t * boundary = nullptr; // loop filter: hand-off lines between macroblock rows (transient within a launch)
   size_t boundary_bytes = 0;
@@ -202,23 +247,44 @@ constexpr size_t kSlabBytes = size_t( 256 ) << 20;
 
 // pool_mu held.  Close the open epoch if anything was released in it (one event on the compute stream covers every launch made
 // before now, hence every launch made before those releases), then hand pieces of fired epochs to the free lists.
+void flush_chunk_frees( aa_ctx * ctx );     // (below)
 void collect_pending( aa_ctx * ctx, bool wait_oldest )
 {
-  if ( ctx->open_epoch_used ) {
-    hipEvent_t e = nullptr;
-    if ( hipEventCreateWithFlags( &e, hipEventDisableTiming ) == hipSuccess && hipEventRecord( e, ctx->compute ) == hipSuccess ) {
-      ctx->epoch_events.emplace_back( ctx->open_epoch, e );
-      ctx->open_epoch++; ctx->open_epoch_used = false;
-    } else if ( e ) (void) hipEventDestroy( e );
+  if ( ctx->open_epoch_used && ctx->binding_depth == 0 ) {
+    flush_chunk_frees( ctx );           // (coefficient chunks of released frames go back behind the kernels that read them)
+    hipEvent_t e = nullptr, c = nullptr;
+    bool ok = hipEventCreateWithFlags( &e, hipEventDisableTiming ) == hipSuccess && hipEventRecord( e, ctx->compute ) == hipSuccess;
+    // asynchronous downloads read rasters on the COPY stream: a released raster is reusable only when those copies are done too
+    if ( ok && ctx->copy_reads_rasters )
+      ok = hipEventCreateWithFlags( &c, hipEventDisableTiming ) == hipSuccess && hipEventRecord( c, ctx->copy ) == hipSuccess;
+    if ( ok ) {
+      ctx->epoch_events.push_back( { ctx->open_epoch, e, c } );
+      ctx->open_epoch++; ctx->open_epoch_used = false; ctx->copy_reads_rasters = false;
+    } else {
+      // no event to be had: the epoch is closed by waiting for both streams instead (never left open for good)
+      if ( e ) (void) hipEventDestroy( e );
+      if ( c ) (void) hipEventDestroy( c );
+      (void) hipGetLastError();
+      if ( hipStreamSynchronize( ctx->compute ) == hipSuccess && hipStreamSynchronize( ctx->copy ) == hipSuccess ) {
+        ctx->epoch_events.push_back( { ctx->open_epoch, nullptr, nullptr } );
+        ctx->open_epoch++; ctx->open_epoch_used = false; ctx->copy_reads_rasters = false;
+      }
+    }
   }
   uint64_t fired = 0;
   while ( !ctx->epoch_events.empty() ) {
-    hipEvent_t e = ctx->epoch_events.front().second;
-    hipError_t q = hipEventQuery( e );
-    if ( q != hipSuccess && wait_oldest ) { q = hipEventSynchronize( e ); wait_oldest = false; }
-    if ( q != hipSuccess ) break;
-    fired = ctx->epoch_events.front().first;
-    (void) hipEventDestroy( e );
+    aa_ctx::Epoch & ep = ctx->epoch_events.front();
+    bool done = true;
+    for ( hipEvent_t * e : { &ep.compute, &ep.copy } ) {
+      if ( !*e ) continue;
+      hipError_t q = hipEventQuery( *e );
+      if ( q != hipSuccess && wait_oldest ) q = hipEventSynchronize( *e );
+      if ( q != hipSuccess ) { done = false; break; }
+      (void) hipEventDestroy( *e ); *e = nullptr;
+    }
+    wait_oldest = false;
+    if ( !done ) { (void) hipGetLastError(); break; }
+    fired = ep.id;
     ctx->epoch_events.erase( ctx->epoch_events.begin() );
   }
   if ( !fired ) return;
@@ -246,7 +312,7 @@ aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out )
     // The pool is about to grow.  Past the soft limit, pieces that were released but may still be read by queued kernels are
     // waited for instead (they come back as the compute stream advances): the pool must not creep up to the last byte of HBM.
     const size_t grow = big ? bytes : kSlabBytes;
-    if ( ctx->pool_bytes + grow > ctx->pool_soft_limit && !ctx->pending_free.empty() && soft_waits < 64 ) {
+    if ( ctx->pool_bytes + ctx->tok.heap_mapped + grow > ctx->pool_soft_limit && !ctx->pending_free.empty() && soft_waits < 64 ) {
       const auto t0 = std::chrono::steady_clock::now();
       collect_pending( ctx, true );
       ctx->stats.pool_waits++;
@@ -321,7 +387,7 @@ aa_status reserve( aa_stream * s, size_t bytes, Chunk ** out )
       auto & pool = s->ctx->pinned_pool;
       for ( size_t i = 0; i < pool.size(); i++ ) if ( pool[i].second == c.capacity ) { c.host = pool[i].first; pool[i] = pool.back(); pool.pop_back(); break; }
     }
-    if ( !c.host ) HIP_TRY( hipHostMalloc( reinterpret_cast<void **>( &c.host ), c.capacity, hipHostMallocDefault ) );
+    if ( !c.host ) { HIP_TRY( hipHostMalloc( reinterpret_cast<void **>( &c.host ), c.capacity, hipHostMallocDefault ) ); std::lock_guard<std::mutex> g( s->ctx->pool_mu ); s->ctx->pinned_bytes += c.capacity; }
     c.pinned_bytes = c.dev_bytes = c.capacity;
     if ( aa_status st = dev_alloc( s->ctx, c.capacity, &c.dev ) ) { std::lock_guard<std::mutex> g( s->ctx->pool_mu ); s->ctx->pinned_pool.emplace_back( c.host, c.pinned_bytes ); return st; }
     s->chunks.push_back( c );
@@ -378,6 +444,248 @@ struct LaunchTimer {     // events on the stream the kernel is launched on
   ~LaunchTimer() { if ( ctx->profile ) { hipEvent_t b = get_event( ctx ); (void) hipEventRecord( b, st ); ctx->pending.push_back( { a, b, kind } ); if ( ctx->pending.size() >= 8192 ) drain_profile( ctx ); } }
 };
 
+
+// ---------------- token workers: job queue, coefficient heap, worker grids ----------------
+inline double now_ms() { return std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now().time_since_epoch() ).count(); }
+inline aa::Heap heap_of( const aa_ctx * ctx )
+{
+  aa::Heap h;
+  h.base = (AA_GLOBAL int16_t *) ctx->tok.heap; h.pool = (AA_GLOBAL aa::CoeffPool *) ctx->tok.pool; h.ring = (AA_GLOBAL uint32_t *) ctx->tok.ring;
+  return h;
+}
+constexpr size_t kChunkBytesHeap = size_t( aa::kChunkBlocks ) * 32;
+
+// pool_mu held.  Chunk lists of released frames -> one kernel on the COMPUTE stream: behind every reconstruction kernel that
+// may still read those coefficients, in front of the event that lets the lists' own memory (the frames' record blocks) go.
+void flush_chunk_frees( aa_ctx * ctx )
+{
+  auto & T = ctx->tok;
+  if ( T.pending_lists.empty() ) return;
+  if ( aa::launch_pool_free_lists( heap_of( ctx ), T.pending_lists.data(), static_cast<int>( T.pending_lists.size() ), ctx->compute ) == 0 ) T.pending_lists.clear();
+  else (void) hipGetLastError();          // (kept: tried again at the next epoch)
+}
+
+aa_status tok_refresh_mirror( aa_ctx * ctx )
+{
+  auto & T = ctx->tok;
+  T.mirror_seq++;
+  if ( int e = aa::launch_mirror_counters( T.q, T.pool, T.exited_dev, aa_ctx::Tok::kSlots, T.mirror_dev, T.mirror_seq, T.util ) )
+    return hip_fail( static_cast<hipError_t>( e ), "k_mirror_counters" );
+  HIP_TRY( hipStreamSynchronize( T.util ) );
+  return AA_OK;
+}
+
+// Map more of the heap until `want_mapped` bytes are there (or the memory limit / the reserved range says no).
+aa_status tok_grow_heap( aa_ctx * ctx, size_t want_mapped )
+{
+  auto & T = ctx->tok;
+  if ( !T.vmm ) return AA_OK;
+  want_mapped = std::min( ( want_mapped + T.grow_bytes - 1 ) / T.grow_bytes * T.grow_bytes, T.heap_va );
+  while ( T.heap_mapped < want_mapped ) {
+    { std::lock_guard<std::mutex> g( ctx->pool_mu ); if ( ctx->pool_bytes + T.heap_mapped + T.grow_bytes > ctx->pool_soft_limit ) break; }
+    hipMemAllocationProp prop {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = ctx->device;
+    hipMemGenericAllocationHandle_t h;
+    if ( hipMemCreate( &h, T.grow_bytes, &prop, 0 ) != hipSuccess ) { (void) hipGetLastError(); break; }
+    uint8_t * at = T.heap + T.heap_mapped;
+    if ( hipMemMap( at, T.grow_bytes, 0, h, 0 ) != hipSuccess ) { (void) hipGetLastError(); (void) hipMemRelease( h ); break; }
+    hipMemAccessDesc acc {};
+    acc.location.type = hipMemLocationTypeDevice; acc.location.id = ctx->device; acc.flags = hipMemAccessFlagsProtReadWrite;
+    if ( hipMemSetAccess( at, T.grow_bytes, &acc, 1 ) != hipSuccess ) { (void) hipGetLastError(); (void) hipMemUnmap( at, T.grow_bytes ); (void) hipMemRelease( h ); break; }
+    T.handles.push_back( h );
+    if ( int e = aa::launch_pool_push_range( heap_of( ctx ), static_cast<uint32_t>( T.heap_mapped / kChunkBytesHeap ), static_cast<uint32_t>( T.grow_bytes / kChunkBytesHeap ), T.util ) )
+      return hip_fail( static_cast<hipError_t>( e ), "k_pool_push_range" );
+    T.heap_mapped += T.grow_bytes;
+    ctx->stats.heap_grows++;
+  }
+  return AA_OK;
+}
+
+aa_status tok_init( aa_ctx * ctx )
+{
+  auto & T = ctx->tok;
+  if ( T.ready ) return AA_OK;
+  hipDeviceProp_t prop;
+  HIP_TRY( hipGetDeviceProperties( &prop, ctx->device ) );
+  T.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+  HIP_TRY( hipStreamCreateWithFlags( &T.util, hipStreamNonBlocking ) );
+  for ( auto & sl : T.slot ) HIP_TRY( hipStreamCreateWithPriority( &sl.st, hipStreamNonBlocking, ctx->prio_low ) );
+  // the job queue
+  HIP_TRY( hipMalloc( reinterpret_cast<void **>( &T.q ), 256 ) );
+  { aa::TokQueue hq {}; hq.mask = T.q_slots - 1; HIP_TRY( hipMemcpy( T.q, &hq, sizeof hq, hipMemcpyHostToDevice ) ); }
+  HIP_TRY( hipMalloc( reinterpret_cast<void **>( &T.slots ), size_t( T.q_slots ) * 8 ) );
+  HIP_TRY( hipMemset( T.slots, 0, size_t( T.q_slots ) * 8 ) );
+  HIP_TRY( hipMalloc( reinterpret_cast<void **>( &T.one_dev ), 256 ) );
+  HIP_TRY( hipMemset( T.one_dev, 0, 256 ) );
+  HIP_TRY( hipMalloc( reinterpret_cast<void **>( &T.exited_dev ), sizeof( uint32_t ) * AA_MAX_WORKER_GRIDS ) );
+  HIP_TRY( hipMemset( T.exited_dev, 0, sizeof( uint32_t ) * AA_MAX_WORKER_GRIDS ) );
+  HIP_TRY( hipHostMalloc( reinterpret_cast<void **>( &T.retire_host ), sizeof( uint32_t ) * AA_MAX_WORKER_GRIDS, hipHostMallocDefault ) );
+  std::memset( T.retire_host, 0, sizeof( uint32_t ) * AA_MAX_WORKER_GRIDS );
+  HIP_TRY( hipHostGetDevicePointer( reinterpret_cast<void **>( &T.retire_dev ), T.retire_host, 0 ) );
+  HIP_TRY( hipHostMalloc( reinterpret_cast<void **>( &T.mirror_host ), sizeof( aa_tok_mirror ), hipHostMallocDefault ) );
+  std::memset( T.mirror_host, 0, sizeof( aa_tok_mirror ) );
+  HIP_TRY( hipHostGetDevicePointer( reinterpret_cast<void **>( &T.mirror_dev ), T.mirror_host, 0 ) );
+  // the coefficient heap: a block index is 32 bits and a block 32 bytes -> at most 128 GiB; by default at most 3/4 of what the
+  // context may use.  Virtual range now, memory as the frames need it.
+  const size_t cap = size_t( 120 ) << 30;
+  if ( !T.heap_limit ) T.heap_limit = ctx->pool_soft_limit == ~size_t( 0 ) ? ( size_t( 16 ) << 30 ) : ctx->pool_soft_limit / 4 * 3;
+  T.heap_limit = std::max( T.grow_bytes, std::min( cap, T.heap_limit ) / T.grow_bytes * T.grow_bytes );
+  const char * no_vmm = std::getenv( "ALFALFA_AMD_NO_VMM" );
+  if ( !( no_vmm && atoi( no_vmm ) ) ) {
+    void * va = nullptr;
+    if ( hipMemAddressReserve( &va, T.heap_limit, T.grow_bytes, nullptr, 0 ) == hipSuccess && va ) { T.heap = static_cast<uint8_t *>( va ); T.heap_va = T.heap_limit; T.vmm = true; }
+    else (void) hipGetLastError();
+  }
+  if ( !T.vmm ) {
+    // no virtual memory management on this runtime: one fixed piece (a quarter of the limit unless the caller set one)
+    size_t fixed = std::max( T.grow_bytes, T.heap_limit / 4 / T.grow_bytes * T.grow_bytes );
+    if ( const char * e = std::getenv( "ALFALFA_AMD_HEAP_GB" ) ) fixed = std::max<size_t>( 1, static_cast<size_t>( atoi( e ) ) ) << 30;
+    HIP_TRY( hipMalloc( reinterpret_cast<void **>( &T.heap ), fixed ) );
+    T.heap_va = fixed;
+  }
+  uint32_t entries = 1;
+  while ( size_t( entries ) * kChunkBytesHeap < T.heap_va ) entries <<= 1;
+  uint8_t * pr = nullptr;
+  HIP_TRY( hipMalloc( reinterpret_cast<void **>( &pr ), 256 + size_t( entries ) * 4 ) );
+  HIP_TRY( hipMemset( pr, 0, 256 + size_t( entries ) * 4 ) );
+  T.pool = reinterpret_cast<aa::CoeffPool *>( pr ); T.ring = reinterpret_cast<uint32_t *>( pr + 256 );
+  { aa::CoeffPool hp {}; hp.mask = entries - 1; HIP_TRY( hipMemcpy( T.pool, &hp, sizeof hp, hipMemcpyHostToDevice ) ); }
+  if ( !T.vmm ) {
+    if ( int e = aa::launch_pool_push_range( heap_of( ctx ), 0, static_cast<uint32_t>( T.heap_va / kChunkBytesHeap ), T.util ) ) return hip_fail( static_cast<hipError_t>( e ), "k_pool_push_range" );
+    T.heap_mapped = T.heap_va;
+    { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pool_bytes += T.heap_va; }      // (counts against the memory limit like a slab)
+  }
+  T.ready = true;
+  return AA_OK;
+}
+
+void tok_free( aa_ctx * ctx )
+{
+  auto & T = ctx->tok;
+  if ( T.util ) { (void) hipStreamSynchronize( T.util ); }
+  for ( auto & sl : T.slot ) if ( sl.st ) { (void) hipStreamSynchronize( sl.st ); (void) hipStreamDestroy( sl.st ); sl.st = nullptr; }
+  if ( T.util ) { (void) hipStreamDestroy( T.util ); T.util = nullptr; }
+  if ( T.vmm ) {
+    if ( T.heap_mapped ) (void) hipMemUnmap( T.heap, T.heap_mapped );
+    for ( auto h : T.handles ) (void) hipMemRelease( h );
+    if ( T.heap ) (void) hipMemAddressFree( T.heap, T.heap_va );
+  } else if ( T.heap ) (void) hipFree( T.heap );
+  if ( T.pool ) (void) hipFree( T.pool );
+  if ( T.q ) (void) hipFree( T.q );
+  if ( T.slots ) (void) hipFree( T.slots );
+  if ( T.one_dev ) (void) hipFree( T.one_dev );
+  if ( T.exited_dev ) (void) hipFree( T.exited_dev );
+  if ( T.retire_host ) (void) hipHostFree( T.retire_host );
+  if ( T.mirror_host ) (void) hipHostFree( T.mirror_host );
+  T = aa_ctx::Tok {};
+}
+
+// Launch worker workgroups if jobs are waiting and fewer workgroups are alive than the GPU holds (the mirror must be fresh).
+// `after`: the grid starts behind this event (the hand-over of the jobs it is launched for).
+aa_status tok_launch_workers( aa_ctx * ctx, hipEvent_t after )
+{
+  auto & T = ctx->tok;
+  const aa_tok_mirror & M = *T.mirror_host;
+  const int32_t queued = static_cast<int32_t>( static_cast<uint32_t>( T.jobs_enqueued ) - M.q_head );
+  if ( queued <= 0 || T.lanes < 1 ) return AA_OK;
+  int alive[aa_ctx::Tok::kSlots], alive_total = 0;
+  for ( int g = 0; g < aa_ctx::Tok::kSlots; g++ ) {
+    alive[g] = static_cast<int>( T.slot[g].launched - M.exited[g] );
+    if ( alive[g] == 0 ) T.slot[g].queued_behind_retiring = false;
+    alive_total += alive[g];
+  }
+  const int room = T.cap_wgs - alive_total;
+  if ( room <= 0 ) return AA_OK;
+  const int want = std::min( room, ( queued + T.lanes - 1 ) / T.lanes );
+  int g = -1;
+  for ( int k = 0; k < aa_ctx::Tok::kSlots; k++ ) if ( alive[k] == 0 ) { g = k; break; }
+  if ( g < 0 ) {
+    // every worker stream still has a grid with workgroups alive (remnants that keep taking jobs would hold their stream for
+    // good): the smallest one retires -- its lanes finish the frames they have and take no more -- and the new grid queues behind it
+    for ( int k = 0; k < aa_ctx::Tok::kSlots; k++ )
+      if ( !T.slot[k].queued_behind_retiring && ( g < 0 || alive[k] < alive[g] ) ) g = k;
+    if ( g < 0 || alive[g] * 4 > T.cap_wgs ) return AA_OK;              // (nothing small enough to give up: the alive ones keep working)
+    __atomic_store_n( &T.retire_host[g], T.slot[g].gen, __ATOMIC_RELEASE );
+    T.slot[g].queued_behind_retiring = true;
+    ctx->stats.worker_retires++;
+  }
+  auto & sl = T.slot[g];
+  sl.gen++;
+  if ( after ) HIP_TRY( hipStreamWaitEvent( sl.st, after, 0 ) );
+  if ( int e = aa::launch_token_workers( T.q, T.slots, heap_of( ctx ), T.exited_dev + g, T.retire_dev + g, sl.gen, want, T.lanes, T.lane_bytes, T.lds, sl.st ) )
+    return hip_fail( static_cast<hipError_t>( e ), "k_token_workers" );
+  sl.launched += static_cast<uint32_t>( want );
+  ctx->stats.worker_launches++; ctx->stats.worker_wgs += static_cast<uint64_t>( want );
+  return AA_OK;
+}
+
+// What a waiting host does every few milliseconds: look at the device's counters, map more heap when lanes starve, make sure
+// workgroups exist for the jobs that wait.
+aa_status tok_service( aa_ctx * ctx, hipEvent_t after = nullptr )
+{
+  auto & T = ctx->tok;
+  if ( !T.ready ) return AA_OK;
+  if ( aa_status st = tok_refresh_mirror( ctx ) ) return st;
+  if ( T.mirror_host->pool_starving != T.seen_starving ) {
+    T.seen_starving = T.mirror_host->pool_starving;
+    if ( aa_status st = tok_grow_heap( ctx, T.heap_mapped + T.grow_bytes ) ) return st;
+  }
+  return tok_launch_workers( ctx, after );
+}
+
+// the token lane's `done` word of one frame (pinned host memory the lane writes last)
+aa_status tok_wait_done( aa_ctx * ctx, volatile aa::FrameSummary * sum )
+{
+  if ( sum->done ) return AA_OK;
+  const double t0 = now_ms();
+  double last = t0 - 1e9;
+  int spins = 0;
+  while ( !sum->done ) {
+    const double t = now_ms();
+    if ( t - last > 2.0 ) { if ( aa_status st = tok_service( ctx ) ) return st; last = t; }
+    if ( t - t0 > 300000.0 ) return fail( AA_ERR_HIP, "device parser: a frame handed to the token workers was not finished within 300 s" );
+    if ( ++spins > 64 ) usleep( 50 );
+  }
+  ctx->stats.parse_wait_ms += now_ms() - t0;
+  return AA_OK;
+}
+
+// every frame handed to the queue so far is through
+aa_status tok_quiesce( aa_ctx * ctx )
+{
+  auto & T = ctx->tok;
+  for ( volatile aa::FrameSummary * sum : T.inflight ) if ( aa_status st = tok_wait_done( ctx, sum ) ) return st;
+  T.inflight.clear();
+  return AA_OK;
+}
+void tok_prune_inflight( aa_ctx * ctx )
+{
+  auto & v = ctx->tok.inflight;
+  if ( v.size() < 65536 ) return;
+  size_t keep = 0;
+  for ( auto p : v ) if ( !p->done ) v[keep++] = p;
+  v.resize( keep );
+}
+
+// The slice of LDS a token lane needs depends on the widest frame (its above-row flags) and on whether frames have several DCT
+// partitions.  Grids with smaller slices cannot run such frames, so the size only ever grows -- and before it does, the queue
+// is drained and the grids are gone.
+aa_status tok_set_lane_bytes( aa_ctx * ctx, uint32_t need )
+{
+  auto & T = ctx->tok;
+  if ( need <= T.lane_bytes ) return AA_OK;
+  if ( T.lane_bytes ) {
+    if ( aa_status st = tok_quiesce( ctx ) ) return st;
+    for ( auto & sl : T.slot ) HIP_TRY( hipStreamSynchronize( sl.st ) );
+  }
+  T.lane_bytes = ( need + 15u ) & ~15u;
+  int per_cu = 0;
+  aa::token_worker_shape( T.lane_bytes, T.n_cus, &T.lanes, &T.lds, &per_cu );
+  if ( T.lanes < 1 || per_cu < 1 ) return fail( AA_ERR_UNSUPPORTED, "device parser: a token lane for frames this wide does not fit a workgroup's LDS" );
+  T.cap_wgs = per_cu * T.n_cus;
+  return AA_OK;
+}
+
 } // namespace
 
 static uint8_t * slot_plane( aa_stream * s, int slot, int plane )
@@ -395,23 +703,32 @@ namespace {
 void release_records( aa_stream * s, FrameRec & f, bool deferred )
 {
   if ( f.records_released ) return;
-  f.records_released = true;
   aa_ctx * ctx = s->ctx;
-  if ( f.rec_block ) { dev_free( ctx, f.rec_block, f.rec_bytes, deferred ); f.rec_block = nullptr; }
-  if ( f.coeff_block ) { dev_free( ctx, f.coeff_block, f.coeff_bytes, deferred ); f.coeff_block = nullptr; }
+  // a token lane may still be writing this frame's records (callers release decoded frames: then this is over already)
+  bool parsed = false;
+  if ( f.enqueued && f.summary ) parsed = tok_wait_done( ctx, f.summary ) == AA_OK;
+  f.records_released = true;
+  if ( f.rec_block ) {
+    // the coefficient chunks the frame took go back to the pool on the device, by a kernel that reads the list out of the
+    // record block: the block itself is recycled only behind that kernel (always through an epoch, never at once)
+    const bool has_chunks = parsed && f.chunk_list && !f.chunks_returned;
+    if ( has_chunks ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->tok.pending_lists.push_back( f.chunk_list ); }
+    dev_free( ctx, f.rec_block, f.rec_bytes, deferred || has_chunks );
+    f.rec_block = nullptr; f.chunk_list = nullptr;
+    ctx->tok.chunks_committed -= f.est_chunks; f.est_chunks = 0;
+  }
   if ( Batch * b = f.batch ) {
     bool last;
     { std::lock_guard<std::mutex> g( ctx->pool_mu ); last = --b->live == 0; }
     if ( f.batch_item >= 0 && f.batch_item < static_cast<int>( b->items.size() ) ) b->items[f.batch_item].live = false;
     if ( last ) {
       if ( b->tokens_pending ) ctx->deferred.erase( std::remove( ctx->deferred.begin(), ctx->deferred.end(), b ), ctx->deferred.end() );
-      if ( !b->done_seen ) (void) hipEventSynchronize( b->done );     // never parsed-and-forgotten while kernels still write
-      (void) hipEventDestroy( b->done );
+      if ( b->hdr_done ) { (void) hipEventSynchronize( b->hdr_done ); (void) hipEventDestroy( b->hdr_done ); }   // never forgotten while kernels still read the arena
       { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); }
       dev_free( ctx, b->dev, b->dev_bytes, deferred );
       delete b;
     }
-    f.batch = nullptr;
+    f.batch = nullptr; f.summary = nullptr; f.parse_job = nullptr;
   }
   if ( f.chunk >= 0 && f.chunk < static_cast<int>( s->chunks.size() ) ) {
     Chunk & c = s->chunks[f.chunk];
@@ -439,6 +756,7 @@ uint8_t * pinned_get( aa_ctx * ctx, size_t bytes, size_t * got )
   uint8_t * p = nullptr;
   if ( hipHostMalloc( reinterpret_cast<void **>( &p ), bytes, hipHostMallocDefault ) != hipSuccess ) return nullptr;
   *got = bytes;
+  { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_bytes += bytes; }
   return p;
 }
 
@@ -704,10 +1022,11 @@ void aa_ctx_destroy( aa_ctx * ctx )
 static void ctx_free( aa_ctx * ctx )
 {
   (void) hipSetDevice( ctx->device );
+  (void) tok_quiesce( ctx );
   (void) hipStreamSynchronize( ctx->compute ); (void) hipStreamSynchronize( ctx->copy );
   for ( auto ps : ctx->parse_streams ) if ( ps ) { (void) hipStreamSynchronize( ps ); (void) hipStreamDestroy( ps ); }
   for ( auto e : ctx->parse_idle ) if ( e ) (void) hipEventDestroy( e );
-  for ( auto & ee : ctx->epoch_events ) (void) hipEventDestroy( ee.second );
+  for ( auto & ee : ctx->epoch_events ) { if ( ee.compute ) (void) hipEventDestroy( ee.compute ); if ( ee.copy ) (void) hipEventDestroy( ee.copy ); }
   if ( ctx->last_seg_batch ) (void) hipEventDestroy( ctx->last_seg_batch );
   drain_profile( ctx );
   for ( auto e : ctx->free_events ) (void) hipEventDestroy( e );
@@ -715,6 +1034,7 @@ static void ctx_free( aa_ctx * ctx )
   for ( auto & bb : ctx->bind_bufs ) { if ( bb.host ) (void) hipHostFree( bb.host ); if ( bb.done ) (void) hipEventDestroy( bb.done ); }
   if ( ctx->ws ) (void) hipFree( ctx->ws );
   if ( ctx->boundary ) (void) hipFree( ctx->boundary );
+  tok_free( ctx );
   for ( auto & pc : ctx->pinned_pool ) (void) hipHostFree( pc.first );
   for ( uint8_t * slab : ctx->dev_slabs ) (void) hipFree( slab );
   (void) hipStreamDestroy( ctx->compute ); (void) hipStreamDestroy( ctx->copy );
@@ -757,6 +1077,7 @@ aa_status aa_ctx_sync( aa_ctx * ctx )
   if ( aa_status st = set_device( ctx ) ) return st;
   HIP_TRY( hipStreamSynchronize( ctx->copy ) );
   for ( auto ps : ctx->parse_streams ) HIP_TRY( hipStreamSynchronize( ps ) );
+  if ( aa_status st = tok_quiesce( ctx ) ) return st;       // every frame handed to the token workers is parsed
   HIP_TRY( hipStreamSynchronize( ctx->compute ) );
   return check_watchdog( ctx );
 }
@@ -768,6 +1089,40 @@ aa_status aa_ctx_memory( aa_ctx * ctx, size_t * free_bytes, size_t * total_bytes
   HIP_TRY( hipMemGetInfo( &f, &t ) );
   if ( free_bytes ) *free_bytes = f;
   if ( total_bytes ) *total_bytes = t;
+  return AA_OK;
+}
+aa_status aa_ctx_set_memory_limit( aa_ctx * ctx, size_t bytes )
+{
+  if ( !ctx || !bytes ) return fail( AA_ERR_ARGUMENT, "aa_ctx_set_memory_limit: bad argument" );
+  std::lock_guard<std::mutex> g( ctx->pool_mu );
+  ctx->pool_soft_limit = bytes;
+  if ( !ctx->tok.ready ) ctx->tok.heap_limit = 0;      // (the heap's virtual size follows the limit when it is set up)
+  return AA_OK;
+}
+aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
+{
+  if ( !ctx || !out ) return fail( AA_ERR_ARGUMENT, "null argument" );
+  if ( aa_status st = set_device( ctx ) ) return st;
+  std::memset( out, 0, sizeof *out );
+  auto & T = ctx->tok;
+  {
+    std::lock_guard<std::mutex> g( ctx->pool_mu );
+    out->memory_limit_bytes = ctx->pool_soft_limit; out->pool_bytes = ctx->pool_bytes; out->pinned_host_bytes = ctx->pinned_bytes;
+  }
+  out->heap_mapped_bytes = T.heap_mapped; out->heap_limit_bytes = T.heap_va;
+  out->heap_used_bytes = static_cast<uint64_t>( std::max<int64_t>( 0, T.chunks_committed ) ) * kChunkBytesHeap;
+  out->heap_is_virtual = T.vmm ? 1u : 0u;
+  out->token_lanes_per_workgroup = static_cast<uint32_t>( T.lanes ); out->token_workgroups_capacity = static_cast<uint32_t>( T.cap_wgs );
+  out->token_lane_lds_bytes = T.lane_bytes; out->token_workgroup_lds_bytes = T.lds;
+  out->compute_units = static_cast<uint32_t>( T.n_cus );
+  if ( T.ready ) {
+    if ( aa_status st = tok_refresh_mirror( ctx ) ) return st;
+    uint32_t alive = 0;
+    for ( int g = 0; g < aa_ctx::Tok::kSlots; g++ ) alive += T.slot[g].launched - T.mirror_host->exited[g];
+    out->token_workgroups_alive = alive;
+    const int32_t waiting = static_cast<int32_t>( static_cast<uint32_t>( T.jobs_enqueued ) - T.mirror_host->q_head );
+    out->jobs_waiting = waiting > 0 ? static_cast<uint32_t>( waiting ) : 0u;
+  }
   return AA_OK;
 }
 /* The sticky error word of the row-pipelined kernels (a bounded wait expired, a wave found itself on another XCD, a queue
@@ -801,6 +1156,7 @@ aa_status aa_ctx_kernel_stats( aa_ctx * ctx, aa_kernel_stats * out, int reset )
   HIP_TRY( hipStreamSynchronize( ctx->compute ) );
   for ( auto ps : ctx->parse_streams ) HIP_TRY( hipStreamSynchronize( ps ) );
   drain_profile( ctx );
+  ctx->stats.heap_mapped_bytes = ctx->tok.heap_mapped;
   *out = ctx->stats;
   if ( reset ) ctx->stats = aa_kernel_stats {};
   return AA_OK;
@@ -835,11 +1191,13 @@ void aa_stream_destroy( aa_stream * s )
   (void) hipSetDevice( s->ctx->device );
   (void) hipStreamSynchronize( s->ctx->compute ); (void) hipStreamSynchronize( s->ctx->copy );
   for ( auto ps : s->ctx->parse_streams ) (void) hipStreamSynchronize( ps );
+  // records first (a frame-store chunk goes back to the pools with its last frame), then whatever chunk is left -- the tail
+  // that was still being filled, chunks no frame ever landed in -- each piece exactly once
+  for ( auto & f : s->frames ) release_records( s, f, true );      // (waits for a token lane still on the frame; chunk lists go through an epoch)
   for ( auto & c : s->chunks ) {
-    if ( c.host ) { std::lock_guard<std::mutex> g( s->ctx->pool_mu ); s->ctx->pinned_pool.emplace_back( c.host, c.pinned_bytes ); }
-    dev_free( s->ctx, c.dev, c.dev_bytes );
+    if ( c.host ) { std::lock_guard<std::mutex> g( s->ctx->pool_mu ); s->ctx->pinned_pool.emplace_back( c.host, c.pinned_bytes ); c.host = nullptr; }
+    if ( c.dev ) { dev_free( s->ctx, c.dev, c.dev_bytes ); c.dev = nullptr; }
   }
-  for ( auto & f : s->frames ) release_records( s, f, false );
   for ( auto & sl : s->slots ) if ( sl.dev ) dev_free( s->ctx, sl.dev, s->slot_bytes );
   dev_free( s->ctx, s->dev_segmap, size_t( s->parser.mb_width() ) * s->parser.mb_height() );
   aa_ctx * ctx = s->ctx;
@@ -948,7 +1306,7 @@ struct SubmitItem {
 };
 
 // one frame of one stream: header pre-pass on the host, compressed bytes into the pinned arena, record block + raster slot
-aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_host, aa_dev_frame * dframes_host, bool defer_tokens )
+aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_host, aa_dev_frame * dframes_host )
 {
   aa_stream * s = it.s;
   aa_ctx * ctx = s->ctx;
@@ -965,11 +1323,9 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
   const size_t rows_bytes = align_up( words_per_row * J.fp.mbh * sizeof( unsigned long long ) );
   const uint32_t flags_padded = ( nmb + 15u ) & ~15u;
   const size_t flags_bytes = align_up( flags_padded );
-  rec.rec_bytes = mb_bytes + rows_bytes + flags_bytes;
-  rec.coeff_bytes = align_up( ( size_t( nmb ) * 25 + 1 ) * 32 );
+  const size_t list_bytes = align_up( size_t( aa::chunk_list_entries( nmb ) ) * sizeof( uint32_t ) );
+  rec.rec_bytes = mb_bytes + rows_bytes + flags_bytes + list_bytes;
   if ( aa_status st = dev_alloc( ctx, rec.rec_bytes, &rec.rec_block ) ) { it.error = g_last_error; return st; }
-  if ( !defer_tokens )
-    if ( aa_status st = dev_alloc( ctx, rec.coeff_bytes, &rec.coeff_block ) ) { dev_free( ctx, rec.rec_block, rec.rec_bytes ); it.error = g_last_error; return st; }
   uint8_t * blk = rec.rec_block;
 
   J.data = b->dev + it.data_off;
@@ -978,13 +1334,17 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
   J.mbs = reinterpret_cast<aa_mb_info *>( blk );
   J.intra_rows = reinterpret_cast<unsigned long long *>( blk + mb_bytes );
   J.mbflags = blk + mb_bytes + rows_bytes;
-  J.coeffs = reinterpret_cast<int16_t *>( rec.coeff_block );       // (null until aa_launch_tokens in the two-phase form)
+  J.chunk_list = reinterpret_cast<uint32_t *>( blk + mb_bytes + rows_bytes + flags_bytes );
   J.summary = reinterpret_cast<aa::FrameSummary *>( b->host_dev + b->summaries_off ) + item;     // pinned + mapped: no copy back
+  rec.chunk_list = J.chunk_list;
+  rec.summary = reinterpret_cast<volatile aa::FrameSummary *>( b->host + b->summaries_off ) + item;
+  rec.parse_job = reinterpret_cast<const aa::ParseJob *>( b->dev ) + item;
 
   aa_dev_frame * job = &dframes_host[item];
   rec.hdr.has_intra_mb = 1;              // until the device parser has counted: the row masks say which macroblocks are intra
   fill_job( rec, job );
-  job->mbs = J.mbs; job->intra_rows = J.intra_rows; job->coeffs = J.coeffs;
+  job->mbs = J.mbs; job->intra_rows = J.intra_rows;
+  job->coeffs = reinterpret_cast<const int16_t *>( ctx->tok.heap );     // coeff_index of a device-parsed macroblock = its first block's index in the heap
   rec.host_job = job;
   rec.dev_job = reinterpret_cast<const aa_dev_frame *>( b->dev + ( reinterpret_cast<uint8_t *>( job ) - b->host ) );
   rec.batch = b; rec.batch_item = item; rec.summary_pending = true;
@@ -995,39 +1355,45 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
 } // namespace
 
 namespace {
-// second phase of a batch: coefficient blocks, patched jobs to HBM, the token kernel, summaries back
+// second phase of a batch: its frames go to the job queue of the token workers (behind the macroblock-header kernel on the
+// batch's stream), the heap is grown for what they are expected to store, workgroups are launched if too few are alive
 aa_status launch_tokens_of( aa_ctx * ctx, Batch * b )
 {
   if ( !b->tokens_pending ) return AA_OK;
+  auto & T = ctx->tok;
   aa::ParseJob * jobs_host = reinterpret_cast<aa::ParseJob *>( b->host );
-  aa_dev_frame * dframes_host = reinterpret_cast<aa_dev_frame *>( b->host + align_up( size_t( b->n ) * sizeof( aa::ParseJob ) ) );
-  for ( int i = 0; i < b->n; i++ ) {               // all the coefficient blocks, or nothing launched (the call can be repeated)
-    Batch::Item & it = b->items[i];
-    if ( !it.live ) continue;
-    FrameRec & r = it.s->frames[it.frame];
-    if ( !r.coeff_block ) if ( aa_status st = dev_alloc( ctx, r.coeff_bytes, &r.coeff_block ) ) return st;
+  // the ring of job slots must not wrap onto jobs that have not been taken
+  if ( static_cast<uint32_t>( T.jobs_enqueued ) - T.mirror_host->q_head + static_cast<uint32_t>( b->n ) + 4096u > T.q_slots ) {
+    if ( aa_status st = tok_refresh_mirror( ctx ) ) return st;
+    if ( static_cast<uint32_t>( T.jobs_enqueued ) - T.mirror_host->q_head + static_cast<uint32_t>( b->n ) + 4096u > T.q_slots )
+      if ( aa_status st = tok_quiesce( ctx ) ) return st;
   }
   b->tokens_pending = false;
   ctx->deferred.erase( std::remove( ctx->deferred.begin(), ctx->deferred.end(), b ), ctx->deferred.end() );
+  bool dropped = false;
+  tok_prune_inflight( ctx );
   for ( int i = 0; i < b->n; i++ ) {
     Batch::Item & it = b->items[i];
-    if ( !it.live ) { jobs_host[i].nmb = 0; continue; }           // rejected by the pre-pass, or released since: the kernel skips it
+    if ( !it.live ) { if ( jobs_host[i].nmb ) { jobs_host[i].nmb = 0; dropped = true; } continue; }   // rejected by the pre-pass, or released since: the lane that draws it drops it
     FrameRec & r = it.s->frames[it.frame];
-    jobs_host[i].coeffs = reinterpret_cast<int16_t *>( r.coeff_block );
-    dframes_host[i].coeffs = jobs_host[i].coeffs;
+    r.enqueued = true;
+    // what the frame is expected to store, in chunks (the running average of what macroblocks have stored so far, a margin, and
+    // the chunk its lane will be filling when it ends)
+    const double blocks = static_cast<double>( jobs_host[i].nmb ) * std::min( 25.0, T.blocks_per_mb * 1.15 );
+    r.est_chunks = static_cast<uint32_t>( blocks / ( aa::kChunkBlocks - aa::kMbBlocks ) ) + 1u;
+    T.chunks_committed += r.est_chunks;
+    T.inflight.push_back( r.summary );
     ctx->stats.parsed_macroblocks += jobs_host[i].nmb;
   }
+  if ( aa_status st = tok_grow_heap( ctx, static_cast<size_t>( std::max<int64_t>( 0, T.chunks_committed ) ) * kChunkBytesHeap ) ) return st;
   hipStream_t ps = b->ps;
-  if ( b->patch_jobs ) HIP_TRY( hipMemcpyAsync( b->dev, b->host, b->head_bytes, hipMemcpyHostToDevice, ps ) );     // (behind the header kernel on its stream)
-  {
-    LaunchTimer t( ctx, 4, ps );
-    if ( int e = aa::launch_parse_tokens( reinterpret_cast<const aa::ParseJob *>( b->dev ), b->launch_order_dev, b->n, b->max_mbw, b->max_nparts, ps ) )
-      return hip_fail( static_cast<hipError_t>( e ), "k_parse_tokens" );
-  }
-  HIP_TRY( hipEventRecord( b->done, ps ) );
+  if ( b->patch_jobs && dropped ) HIP_TRY( hipMemcpyAsync( b->dev, b->host, b->head_bytes, hipMemcpyHostToDevice, ps ) );     // (behind the header kernel on its stream)
+  if ( int e = aa::launch_enqueue_jobs( T.q, T.slots, reinterpret_cast<const aa::ParseJob *>( b->dev ), b->launch_order_dev, b->n, ps ) )
+    return hip_fail( static_cast<hipError_t>( e ), "k_enqueue_jobs" );
+  T.jobs_enqueued += static_cast<uint64_t>( b->n );
+  HIP_TRY( hipEventRecord( b->hdr_done, ps ) );
   HIP_TRY( hipEventRecord( ctx->parse_idle[b->parse_stream_index], ps ) );
-  b->done_seen = false;
-  return AA_OK;
+  return tok_service( ctx, b->hdr_done );
 }
 } // namespace
 
@@ -1054,6 +1420,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   if ( !ctx || !frames || n <= 0 ) return fail( AA_ERR_ARGUMENT, "aa_submit_frames: bad argument" );
   const bool defer_tokens = ( flags & AA_SUBMIT_DEFER_TOKENS ) != 0;
   if ( aa_status st = set_device( ctx ) ) return st;
+  if ( aa_status st = tok_init( ctx ) ) return st;
   std::vector<SubmitItem> items( n );
   // arena layout: parse jobs | reconstruction job records | summaries | segment-pass lists | compressed frames
   const size_t jobs_bytes = align_up( size_t( n ) * sizeof( aa::ParseJob ) );
@@ -1082,7 +1449,11 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   b->dev_bytes = arena;
   if ( aa_status st = dev_alloc( ctx, arena, &b->dev ) ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); return st; }
   b->n = n; b->summaries_off = jobs_bytes + dframes_bytes;
-  HIP_TRY( hipHostGetDevicePointer( reinterpret_cast<void **>( &b->host_dev ), b->host, 0 ) );
+  if ( hipError_t e = hipHostGetDevicePointer( reinterpret_cast<void **>( &b->host_dev ), b->host, 0 ) ) {
+    { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); }
+    dev_free( ctx, b->dev, b->dev_bytes );
+    return hip_fail( e, "hipHostGetDevicePointer (batch arena)" );
+  }
   aa::ParseJob * jobs_host = reinterpret_cast<aa::ParseJob *>( b->host );
   aa_dev_frame * dframes_host = reinterpret_cast<aa_dev_frame *>( b->host + jobs_bytes );
   std::memset( b->host, 0, jobs_bytes + dframes_bytes + sums_bytes + seg_bytes );
@@ -1099,7 +1470,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
         for ( int i : by_stream[stream_order[k]] ) {
           SubmitItem & it = items[i];
           if ( broken ) { it.status = AA_ERR_LOGIC; it.error = "an earlier frame of this stream in the same call failed"; continue; }
-          it.status = submit_one( b.get(), it, i, jobs_host, dframes_host, defer_tokens );
+          it.status = submit_one( b.get(), it, i, jobs_host, dframes_host );
           if ( it.status != AA_OK ) broken = true;
         }
       }
@@ -1133,9 +1504,24 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   for ( int i = 0; i < n; i++ ) b->items[i] = { items[i].s, items[i].frame_index, items[i].status == AA_OK };
   b->head_bytes = jobs_bytes + dframes_bytes;
   b->max_mbw = max_mbw; b->max_nparts = max_nparts;
+  // From here on the frames that were appended point at the batch.  If anything below fails they are given back one by one
+  // (the last one frees the batch): no frame is left with a dangling batch, nothing leaks; the frames themselves stay in
+  // their streams as frames whose records are gone (decoding them reports that).
+  struct Abandon {
+    aa_ctx * ctx; Batch * b; bool armed = true;
+    ~Abandon() {
+      if ( !armed ) return;
+      const std::string keep = g_last_error;
+      std::vector<Batch::Item> its = b->items;              // (the batch dies with its last frame)
+      for ( auto & it : its ) if ( it.live ) release_records( it.s, it.s->frames[it.frame], true );
+      g_last_error = keep;
+    }
+  } abandon { ctx, b.release() };
+  Batch * const raw = abandon.b;
+  if ( aa_status st = tok_set_lane_bytes( ctx, aa::tok::lane_lds_bytes( static_cast<uint32_t>( max_mbw ), max_nparts > 1 ) ) ) return st;
 
   // ---- segment-map pass lists (only streams that use segmentation in this batch) ----
-  aa_seg_stream * seg_streams = reinterpret_cast<aa_seg_stream *>( b->host + jobs_bytes + dframes_bytes + sums_bytes );
+  aa_seg_stream * seg_streams = reinterpret_cast<aa_seg_stream *>( raw->host + jobs_bytes + dframes_bytes + sums_bytes );
   uint32_t * seg_order = reinterpret_cast<uint32_t *>( seg_streams + n );
   int n_seg_streams = 0; uint32_t n_seg_order = 0;
   // a stream with nothing queued if there is one (else the next in turn: the batch waits behind that stream's work)
@@ -1146,7 +1532,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   }
   (void) hipGetLastError();
   ctx->next_parse_stream = ( pick + 1 ) % ctx->n_parse_streams;
-  b->parse_stream_index = pick;
+  raw->parse_stream_index = pick;
   hipStream_t ps = ctx->parse_streams[pick];
   for ( aa_stream * s : stream_order ) {
     bool any = false;
@@ -1170,35 +1556,35 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   uint32_t * launch_order = seg_order + n;
   for ( int i = 0; i < n; i++ ) launch_order[i] = static_cast<uint32_t>( i );
   std::stable_sort( launch_order, launch_order + n, [&]( uint32_t a, uint32_t b ) { return items[a].size > items[b].size; } );
-  const uint32_t * launch_order_dev = reinterpret_cast<const uint32_t *>( b->dev + ( reinterpret_cast<uint8_t *>( launch_order ) - b->host ) );
+  const uint32_t * launch_order_dev = reinterpret_cast<const uint32_t *>( raw->dev + ( reinterpret_cast<uint8_t *>( launch_order ) - raw->host ) );
 
-  // ---- device half: arena to HBM on the copy stream, then the three parse kernels on one of the parse streams ----
-  HIP_TRY( hipEventCreateWithFlags( &b->done, hipEventDisableTiming ) );
-  HIP_TRY( hipMemcpyAsync( b->dev, b->host, off, hipMemcpyHostToDevice, ctx->copy ) );
+  // ---- device half: arena to HBM on the copy stream, then the header kernels on one of the parse streams ----
+  HIP_TRY( hipEventCreateWithFlags( &raw->hdr_done, hipEventDisableTiming ) );
+  HIP_TRY( hipMemcpyAsync( raw->dev, raw->host, off, hipMemcpyHostToDevice, ctx->copy ) );
   hipEvent_t up = get_event( ctx );
   HIP_TRY( hipEventRecord( up, ctx->copy ) );
   HIP_TRY( hipStreamWaitEvent( ps, up, 0 ) );
   ctx->free_events.push_back( up );
-  const aa::ParseJob * jobs_dev = reinterpret_cast<const aa::ParseJob *>( b->dev );
+  const aa::ParseJob * jobs_dev = reinterpret_cast<const aa::ParseJob *>( raw->dev );
   {
     LaunchTimer t( ctx, 3, ps );
     if ( int e = aa::launch_parse_mb_headers( jobs_dev, launch_order_dev, n, ps ) ) return hip_fail( static_cast<hipError_t>( e ), "k_parse_mb_headers" );
   }
   if ( n_seg_streams ) {
     if ( ctx->last_seg_batch ) HIP_TRY( hipStreamWaitEvent( ps, ctx->last_seg_batch, 0 ) );
-    const uint8_t * segs_dev = b->dev + jobs_bytes + dframes_bytes + sums_bytes;
+    const uint8_t * segs_dev = raw->dev + jobs_bytes + dframes_bytes + sums_bytes;
     if ( int e = aa::launch_segment_fixup( jobs_dev, reinterpret_cast<const aa_seg_stream *>( segs_dev ), n_seg_streams,
                                            reinterpret_cast<const uint32_t *>( segs_dev + size_t( n ) * sizeof( aa_seg_stream ) ), ps ) )
       return hip_fail( static_cast<hipError_t>( e ), "k_segment_fixup" );
     if ( !ctx->last_seg_batch ) HIP_TRY( hipEventCreateWithFlags( &ctx->last_seg_batch, hipEventDisableTiming ) );
     HIP_TRY( hipEventRecord( ctx->last_seg_batch, ps ) );
   }
-  b->ps = ps; b->launch_order_dev = launch_order_dev;
-  b->tokens_pending = true; b->patch_jobs = defer_tokens;
-  HIP_TRY( hipEventRecord( b->done, ps ) );        // (the header kernel; recorded again behind the token kernel)
+  raw->ps = ps; raw->launch_order_dev = launch_order_dev;
+  raw->tokens_pending = true; raw->patch_jobs = defer_tokens;
+  HIP_TRY( hipEventRecord( raw->hdr_done, ps ) );  // (the header kernels; recorded again behind the hand-over to the job queue)
   HIP_TRY( hipEventRecord( ctx->parse_idle[pick], ps ) );
-  ctx->deferred.push_back( b.get() );
-  Batch * raw = b.release();
+  ctx->deferred.push_back( raw );
+  abandon.armed = false;                           // the batch is on the books: from here on a failure leaves a consistent state
   if ( !defer_tokens ) if ( aa_status st = launch_tokens_of( ctx, raw ) ) return st;
   if ( first_error != AA_OK ) return fail( first_error, first_message );
   return AA_OK;
@@ -1208,24 +1594,62 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
 static aa_status resolve_summary( aa_stream * s, FrameRec & r )
 {
   if ( !r.summary_pending ) return AA_OK;
+  aa_ctx * ctx = s->ctx;
+  auto & T = ctx->tok;
   Batch * b = r.batch;
-  if ( !b ) return fail( AA_ERR_LOGIC, "frame records were released before the frame was decoded" );
-  if ( b->tokens_pending ) if ( aa_status st = launch_tokens_of( s->ctx, b ) ) return st;      // two-phase submit, second phase not asked for yet
-  if ( !b->done_seen ) {
-    const auto t0 = std::chrono::steady_clock::now();
-    HIP_TRY( hipEventSynchronize( b->done ) );
-    b->done_seen = true;
-    s->ctx->stats.parse_wait_ms += std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count();
+  if ( !b || !r.summary ) return fail( AA_ERR_LOGIC, "frame records were released before the frame was decoded" );
+  if ( b->tokens_pending ) if ( aa_status st = launch_tokens_of( ctx, b ) ) return st;      // two-phase submit, second phase not asked for yet
+  volatile aa::FrameSummary * sum = r.summary;
+  for ( int attempt = 0; ; attempt++ ) {
+    if ( aa_status st = tok_wait_done( ctx, sum ) ) return st;
+    if ( sum->status != aa::TOK_NO_MEMORY ) break;
+    // The coefficient pool ran dry under this frame's lane and nothing came back in time: the lane handed the frame back.  Its
+    // chunks are returned, room is made (more heap if the memory limit allows it, else by letting everything else in flight
+    // finish) and the frame goes to the queue again -- its macroblock headers are parsed already.
+    ctx->stats.nomem_retries++;
+    const uint32_t worst = static_cast<uint32_t>( ( 25ull * r.hdr.num_macroblocks ) / ( aa::kChunkBlocks - aa::kMbBlocks ) ) + 2u;
+    if ( !r.chunks_returned ) {
+      {
+        std::lock_guard<std::mutex> g( ctx->pool_mu );
+        T.pending_lists.push_back( r.chunk_list );
+        flush_chunk_frees( ctx );
+        if ( !T.pending_lists.empty() ) return fail( AA_ERR_HIP, "k_pool_free_lists could not be launched" );
+      }
+      HIP_TRY( hipStreamSynchronize( ctx->compute ) );
+      r.chunks_returned = true;
+      T.chunks_committed -= r.est_chunks; r.est_chunks = 0;
+    }
+    if ( aa_status st = tok_grow_heap( ctx, T.heap_mapped + static_cast<size_t>( worst ) * kChunkBytesHeap ) ) return st;
+    if ( aa_status st = tok_refresh_mirror( ctx ) ) return st;
+    if ( T.mirror_host->pool_avail < static_cast<int32_t>( worst ) ) {
+      if ( aa_status st = tok_quiesce( ctx ) ) return st;
+      if ( aa_status st = tok_refresh_mirror( ctx ) ) return st;
+    }
+    if ( attempt >= 2 || T.mirror_host->pool_avail < static_cast<int32_t>( worst ) )
+      return fail( AA_ERR_NO_MEMORY, "device parser: the coefficient heap is exhausted (" + std::to_string( T.heap_mapped >> 20 ) + " MiB mapped, "
+                                     + std::to_string( T.mirror_host->pool_avail ) + " chunks free, this frame may need " + std::to_string( worst )
+                                     + "): release decoded frames (aa_stream_release_before) or raise the limit (aa_ctx_set_memory_limit); the call can be repeated" );
+    sum->status = 0; sum->done = 0; sum->num_chunks = 0;
+    r.chunks_returned = false;
+    r.est_chunks = worst; T.chunks_committed += worst;
+    __atomic_thread_fence( __ATOMIC_SEQ_CST );
+    if ( int e = aa::launch_enqueue_jobs( T.q, T.slots, r.parse_job, T.one_dev, 1, T.util ) ) return hip_fail( static_cast<hipError_t>( e ), "k_enqueue_jobs" );
+    T.jobs_enqueued += 1;
+    T.inflight.push_back( sum );
+    if ( aa_status st = tok_service( ctx ) ) return st;
   }
-  const aa::FrameSummary & sum = reinterpret_cast<const aa::FrameSummary *>( b->host + b->summaries_off )[r.batch_item];
-  if ( sum.steps == 0xFFFFFFFFu ) return fail( AA_ERR_HIP, "device parser: a token lane exceeded the step bound of its frame size (records are not valid)" );
-  r.hdr.num_coeff_blocks = sum.num_coeff_blocks;
-  r.hdr.num_intra_mbs = sum.num_intra_mbs;
-  r.hdr.has_intra_mb = sum.num_intra_mbs != 0;
-  r.has_split = sum.has_split != 0;
+  if ( sum->status == aa::TOK_STEP_BOUND ) return fail( AA_ERR_HIP, "device parser: a token lane exceeded the step bound of its frame size (records are not valid)" );
+  r.hdr.num_coeff_blocks = sum->num_coeff_blocks;
+  r.hdr.num_intra_mbs = sum->num_intra_mbs;
+  r.hdr.has_intra_mb = sum->num_intra_mbs != 0;
+  r.has_split = sum->has_split != 0;
   r.intra_diagonals.assign( r.hdr.mb_width + 2 * ( r.hdr.mb_height - 1 ), r.hdr.has_intra_mb ? 1 : 0 );   // diagonal schedule: all of them
+  // the books: what the frame really took; what macroblocks store on this content (feeds the estimate of later frames)
+  T.chunks_committed += static_cast<int64_t>( sum->num_chunks ) - static_cast<int64_t>( r.est_chunks );
+  r.est_chunks = sum->num_chunks;
+  if ( r.hdr.num_macroblocks ) T.blocks_per_mb += 0.02 * ( static_cast<double>( sum->num_coeff_blocks ) / r.hdr.num_macroblocks - T.blocks_per_mb );
+  ctx->stats.token_steps += sum->steps; ctx->stats.token_frames++;
   r.summary_pending = false;
-  (void) s;
   return AA_OK;
 }
 
@@ -1250,11 +1674,41 @@ aa_status aa_stream_read_records( aa_stream * s, int fi, aa_mb_info * mb_out, in
   HIP_TRY( hipStreamSynchronize( s->ctx->copy ) );
   aa_dev_frame job;
   HIP_TRY( hipMemcpy( &job, r.dev_job, sizeof job, hipMemcpyDeviceToHost ) );
-  if ( mb_out ) HIP_TRY( hipMemcpy( mb_out, job.mbs, size_t( r.hdr.num_macroblocks ) * sizeof( aa_mb_info ), hipMemcpyDeviceToHost ) );
-  if ( coeff_out ) {
-    if ( coeff_capacity_blocks < r.hdr.num_coeff_blocks ) return fail( AA_ERR_ARGUMENT, "aa_stream_read_records: coefficient buffer too small" );
-    HIP_TRY( hipMemcpy( coeff_out, job.coeffs, size_t( r.hdr.num_coeff_blocks ) * 32, hipMemcpyDeviceToHost ) );
+  if ( coeff_out && coeff_capacity_blocks < r.hdr.num_coeff_blocks ) return fail( AA_ERR_ARGUMENT, "aa_stream_read_records: coefficient buffer too small" );
+  if ( !r.chunk_list ) {                     // host-parsed: the blocks follow each other in the frame-store chunk
+    if ( mb_out ) HIP_TRY( hipMemcpy( mb_out, job.mbs, size_t( r.hdr.num_macroblocks ) * sizeof( aa_mb_info ), hipMemcpyDeviceToHost ) );
+    if ( coeff_out ) HIP_TRY( hipMemcpy( coeff_out, job.coeffs, size_t( r.hdr.num_coeff_blocks ) * 32, hipMemcpyDeviceToHost ) );
+    return AA_OK;
   }
+  // device-parsed: the blocks sit in chunks of the coefficient heap and coeff_index is a heap index.  The caller gets the
+  // frame's own view -- blocks back to back in parse order, coeff_index counted from the frame's first block -- which is
+  // what the host parser produces.
+  std::vector<aa_mb_info> mbs( r.hdr.num_macroblocks );
+  HIP_TRY( hipMemcpy( mbs.data(), job.mbs, mbs.size() * sizeof( aa_mb_info ), hipMemcpyDeviceToHost ) );
+  std::vector<uint32_t> list( size_t( r.est_chunks ) + 1 );
+  HIP_TRY( hipMemcpy( list.data(), r.chunk_list, list.size() * sizeof( uint32_t ), hipMemcpyDeviceToHost ) );
+  if ( list[0] != r.est_chunks ) return fail( AA_ERR_LOGIC, "aa_stream_read_records: chunk list disagrees with the parse summary" );
+  std::map<uint32_t, std::vector<uint8_t>> chunk;
+  if ( coeff_out )
+    for ( uint32_t k = 0; k < list[0]; k++ ) {
+      auto & v = chunk[list[1 + k]];
+      v.resize( kChunkBytesHeap );
+      HIP_TRY( hipMemcpy( v.data(), s->ctx->tok.heap + size_t( list[1 + k] ) * kChunkBytesHeap, kChunkBytesHeap, hipMemcpyDeviceToHost ) );
+    }
+  uint32_t running = 0;
+  for ( auto & mb : mbs ) {
+    const uint32_t nblk = static_cast<uint32_t>( __builtin_popcount( mb.nz_mask ) );
+    if ( nblk && coeff_out ) {
+      auto it = chunk.find( mb.coeff_index / aa::kChunkBlocks );
+      if ( it == chunk.end() || mb.coeff_index % aa::kChunkBlocks + nblk > aa::kChunkBlocks || running + nblk > r.hdr.num_coeff_blocks )
+        return fail( AA_ERR_LOGIC, "aa_stream_read_records: a macroblock's coefficients lie outside the frame's chunks" );
+      std::memcpy( coeff_out + size_t( running ) * 16, it->second.data() + size_t( mb.coeff_index % aa::kChunkBlocks ) * 32, size_t( nblk ) * 32 );
+    }
+    mb.coeff_index = running;
+    running += nblk;
+  }
+  if ( running != r.hdr.num_coeff_blocks ) return fail( AA_ERR_LOGIC, "aa_stream_read_records: non-zero masks disagree with the parse summary" );
+  if ( mb_out ) std::memcpy( mb_out, mbs.data(), mbs.size() * sizeof( aa_mb_info ) );
   return AA_OK;
 }
 
@@ -1317,6 +1771,11 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
     if ( streams[i]->frames[frame_index[i]].records_released ) return fail( AA_ERR_LOGIC, "aa_decode_batch: frame records were released" );
     if ( aa_status st = resolve_summary( streams[i], streams[i]->frames[frame_index[i]] ) ) return st;
   }
+  // rasters released while binding (old references, outputs nobody holds) must not be recycled before this call's kernels
+  // are queued: no release epoch is closed until then
+  struct BindGuard { aa_ctx * c;
+                     explicit BindGuard( aa_ctx * x ) : c( x ) { std::lock_guard<std::mutex> g( c->pool_mu ); c->binding_depth++; }
+                     ~BindGuard() { std::lock_guard<std::mutex> g( c->pool_mu ); c->binding_depth--; } } bind_guard( ctx );
   if ( aa_status st = bind_batch( ctx, streams, n, frame_index ) ) return st;
   // frames count as submitted only once every launch of the batch has been queued (a failed launch must not leave them
   // looking decoded)
@@ -1499,6 +1958,8 @@ aa_status aa_stream_download_async( aa_stream * s, int fi, uint8_t * y, uint8_t 
   HIP_TRY( hipStreamWaitEvent( ctx->copy, e, 0 ) );
   ctx->free_events.push_back( e );
   uint8_t * dst[3] = { y, u, v };
+  // the raster may be released before the copy has run: the epoch that frees it waits for the copy stream as well
+  { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->copy_reads_rasters = true; }
   for ( int p = 0; p < 3; p++ ) if ( dst[p] ) HIP_TRY( hipMemcpyAsync( dst[p], slot_plane( s, r.out_slot, p ), s->plane_bytes[p], hipMemcpyDeviceToHost, ctx->copy ) );
   return AA_OK;
 }

@@ -26,6 +26,17 @@
 //   HBM   the frame's compressed bytes, flags[mi] from the header kernel (in), coefficient blocks + nz_mask / coeff_index /
 //         flags of every macroblock record (out, fire-and-forget stores)
 // Shared by the lanes of a workgroup (LDS, read-only): the node records and the per-block constants.
+//
+// Where the coefficient blocks go.  A frame stores only its non-zero 4x4 blocks, and how many those are is known when the
+// parse is over -- so a lane does not get a worst-case sized piece (25 blocks per macroblock: 6.5 MB per 1080p frame, of
+// which video uses a fraction) but draws CHUNKS of kChunkBlocks blocks from a pool shared by the whole GPU (CoeffPool: a
+// ring of free chunk numbers) whenever the chunk it is filling cannot take another macroblock.  All chunks are pieces of ONE
+// heap, so a macroblock's coeff_index is simply the index of its first block in that heap and the reconstruction kernels
+// address it as before (heap base + 16 * index).  The chunks a frame took are listed in the frame's records (chunk_list) and
+// go back to the ring, on the device, when the frame's records are released.
+//
+// Who runs a frame.  Lanes are WORKERS (k_token_workers): a lane that has finished its frame takes the next ParseJob from a
+// queue in HBM (TokQueue) at once, so a wave does not wait for its longest lane and a launch not for its longest wave.
 #pragma once
 #include <initializer_list>
 
@@ -45,11 +56,68 @@ struct alignas( 8 ) V8 { uint32_t x, y; };
 #define AA_GLOBAL
 #endif
 
-struct FrameSummary {           // written by the device parser, read by the host once the parse event has fired
+// Written by the device parser into pinned host memory the GPU has mapped; the host polls `done` (the token lane's last
+// store, behind a system-scope release: everything the frame's parse wrote to HBM is visible to kernels launched after the
+// host has seen it).
+struct FrameSummary {
   uint32_t num_coeff_blocks;
-  uint32_t num_intra_mbs;
-  uint32_t has_split;
-  uint32_t steps;               // steps of the token lane (diagnostics); 0xFFFFFFFF: the lane hit its step bound
+  uint32_t num_intra_mbs;       // (header kernel)
+  uint32_t has_split;           // (header kernel)
+  uint32_t steps;               // steps of the token lane (an upper bound on the bools it decoded)
+  uint32_t num_chunks;          // coefficient chunks the frame took (= chunk_list[0])
+  uint32_t status;              // TOK_OK ...
+  uint32_t done;                // 1: the token lane is through with this frame
+  uint32_t pad;
+};
+enum : uint32_t { TOK_OK = 0, TOK_STEP_BOUND = 1, TOK_NO_MEMORY = 2 };
+
+// ---- atomics: agent scope on the GPU (coherent across the XCDs' L2s); the host simulation runs one lane at a time ----
+#if defined( __HIP_DEVICE_COMPILE__ )
+#define AA_AT_ADD( p, v ) __hip_atomic_fetch_add( ( p ), ( v ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT )
+#define AA_AT_ADD_ACQ( p, v ) __hip_atomic_fetch_add( ( p ), ( v ), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT )
+#define AA_AT_ADD_REL( p, v ) __hip_atomic_fetch_add( ( p ), ( v ), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT )
+#define AA_AT_LOAD( p ) __hip_atomic_load( ( p ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT )
+#define AA_AT_STORE( p, v ) __hip_atomic_store( ( p ), ( v ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT )
+#define AA_NOW() wall_clock64()                        /* constant 100 MHz */
+#else
+template <class T, class V> AA_HD inline T aa_host_add( T * p, V v ) { const T old = *p; *p = static_cast<T>( old + static_cast<T>( v ) ); return old; }
+#define AA_AT_ADD( p, v ) aa::aa_host_add( ( p ), ( v ) )
+#define AA_AT_ADD_ACQ( p, v ) aa::aa_host_add( ( p ), ( v ) )
+#define AA_AT_ADD_REL( p, v ) aa::aa_host_add( ( p ), ( v ) )
+#define AA_AT_LOAD( p ) ( *( p ) )
+#define AA_AT_STORE( p, v ) ( *( p ) = ( v ) )
+AA_HD inline unsigned long long aa_host_clock() { static unsigned long long t = 0; return t += 1000; }
+#define AA_NOW() aa::aa_host_clock()                  /* the simulation's clock: 10 us per look */
+#endif
+
+// Free coefficient chunks of the GPU: a ring of chunk numbers + a semaphore.  Consumers are token lanes (pool_take), producers
+// the kernels that return the chunks of released frames or add the chunks of newly mapped heap (pool_push).  The ring has at
+// least as many entries as there are chunks, so a producer never overwrites an entry that has not been handed out.
+struct CoeffPool {
+  int32_t avail;                // published entries nobody has claimed yet (claimed first, then a ticket is drawn)
+  uint32_t head;                // next ticket
+  uint32_t reserve, publish;    // producers: entries reserved / entries visible
+  uint32_t mask;                // ring entries - 1 (a power of two)
+  uint32_t starving;            // lanes that found the pool empty (events; the host grows the heap when it moves)
+  uint32_t pad[2];
+};
+constexpr uint32_t kChunkBlocks = 2048;               // 64 KB
+constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
+constexpr uint32_t kMbBlocks = 26;                    // what must be left in a chunk when a macroblock starts: 25 blocks + the pre-zeroed next one
+AA_HD constexpr uint32_t chunk_list_entries( uint32_t nmb ) { return 2u + ( 25u * nmb + ( kChunkBlocks - kMbBlocks ) ) / ( kChunkBlocks - kMbBlocks + 1u ); }
+
+// Jobs waiting for a token lane: slots[ticket & mask] = the ParseJob; tickets below `publish` are ready, `head` is the next
+// one to take.  Producers (k_enqueue_jobs) reserve a range, fill it, publish in order.  The host keeps fewer jobs in flight
+// than the ring has slots.
+struct TokQueue {
+  uint32_t head, reserve, publish, mask;
+};
+
+// What every worker lane of a GPU shares (kernel arguments: uniform)
+struct Heap {
+  AA_GLOBAL int16_t * base;     // the coefficient heap: block i at base + 16 * i
+  AA_GLOBAL CoeffPool * pool;
+  AA_GLOBAL uint32_t * ring;
 };
 
 // One frame to parse on the device.  Built by the host header pre-pass, resident in HBM.
@@ -59,7 +127,7 @@ struct alignas( 16 ) ParseJob {
   uint32_t size, data_padded;   // data_padded: multiple of 16, >= size
   uint32_t nmb, flags_padded;   // flags_padded: multiple of 16, >= nmb
   aa_mb_info * mbs;
-  int16_t * coeffs;             // 25 * nmb + 1 blocks of 16
+  uint32_t * chunk_list;        // [chunk_list_entries( nmb )]: [0] = how many coefficient chunks the frame took, then their numbers
   unsigned long long * intra_rows;
   uint8_t * mbflags;            // [flags_padded]: INTER | HAS_Y2 | SKIP of every macroblock, header kernel -> token kernel
   FrameSummary * summary;
@@ -67,11 +135,17 @@ struct alignas( 16 ) ParseJob {
 
 namespace tok {
 
-constexpr uint32_t kPeriod = 64;          // steps between ring top-ups (a step consumes at most one stream byte)
-constexpr uint32_t kRing = 256;           // bytes in the stream ring
-constexpr uint32_t kChunks = 4;           // 16-byte chunks fetched per top-up (= kPeriod bytes)
-constexpr uint32_t kMetaRing = 64;        // macroblock flags in the flag ring
-constexpr uint32_t kMetaChunks = 2;       // 16-flag chunks fetched per top-up (only runs of skipped macroblocks use more: they wait)
+// Ring sizes.  Invariant of the stream ring: lead = wpos - rpos >= kPeriod at every top-up (a period consumes at most kPeriod
+// bytes).  A top-up asks for kPeriod more bytes iff lead <= kRing - kPeriod (they land a period later, when the bytes they
+// replace have been read); otherwise lead > kRing - kPeriod >= 2 * kPeriod leaves >= kPeriod after the period.  So
+// kRing >= 3 * kPeriod is enough -- 128 bytes of LDS per lane with a period of 32 steps (it was 256 / 64: the slice is what
+// bounds the number of chains a CU holds).
+constexpr uint32_t kPeriod = 32;          // steps between ring top-ups (a step consumes at most one stream byte)
+constexpr uint32_t kRing = 128;           // bytes in the stream ring
+constexpr uint32_t kChunks = 2;           // 16-byte chunks fetched per top-up (= kPeriod bytes)
+constexpr uint32_t kMetaRing = 32;        // macroblock flags in the flag ring
+constexpr uint32_t kMetaChunks = 1;       // 16-flag chunks fetched per top-up (only runs of skipped macroblocks use more: they wait)
+static_assert( kRing >= 3 * kPeriod && 16 * kChunks == kPeriod && ( kRing & ( kRing - 1 ) ) == 0, "stream ring invariant" );
 
 // Workgroup LDS ("smem"; one flat buffer on the host): the node and block tables and the constant probabilities at offset
 // 0 -- so that a node record's address is a plain number a record can carry -- then one slice per lane.  The number of
@@ -179,7 +253,7 @@ struct Frame {
   const AA_GLOBAL uint8_t * data;
   const AA_GLOBAL uint8_t * mbflags;
   AA_GLOBAL aa_mb_info * mbs;
-  AA_GLOBAL int16_t * coeffs;
+  AA_GLOBAL uint32_t * chunk_list;
   uint32_t data_padded, flags_padded, nmb, mbw, nparts;
   uint32_t max_steps;           // no frame of this size can take more steps: a lane that gets there stops (never a hung GPU)
 };
@@ -188,7 +262,7 @@ AA_HD inline Frame frame_of( const ParseJob * job )
   Frame F;
   F.job = (const AA_GLOBAL ParseJob *) job;
   F.data = (const AA_GLOBAL uint8_t *) job->data; F.mbflags = (const AA_GLOBAL uint8_t *) job->mbflags;
-  F.mbs = (AA_GLOBAL aa_mb_info *) job->mbs; F.coeffs = (AA_GLOBAL int16_t *) job->coeffs;
+  F.mbs = (AA_GLOBAL aa_mb_info *) job->mbs; F.chunk_list = (AA_GLOBAL uint32_t *) job->chunk_list;
   // per macroblock at most 25 blocks x 16 tokens x (11 tree nodes + 11 extra bits + sign), plus boundary steps
   const uint64_t bound = static_cast<uint64_t>( job->nmb ) * ( 25u * 16u * 23u + 4u ) + 4096u;
   F.max_steps = bound > 0xFFFFFFF0ull ? 0xFFFFFFF0u : static_cast<uint32_t>( bound );
@@ -244,7 +318,11 @@ struct Lane {
   // macroblock in progress
   uint32_t ctxbits;               // non-zero flags: above (this column) bits 0-8, left bits 16-24
   uint32_t flags, nz_mask, mb_first, coeff_blocks, ytypeaddr, yfirst;
-  AA_GLOBAL int16_t * blk;        // the coefficient block being filled = Frame::coeffs + 16 * coeff_blocks
+  AA_GLOBAL int16_t * blk;        // the coefficient block being filled = Heap::base + 16 * blk_index (zeroed in advance)
+  uint32_t blk_index;             // its index in the heap
+  uint32_t blk_left;              // blocks left in the chunk being filled, the current one included (0: no chunk yet)
+  uint32_t nchunks;               // chunks taken so far
+  unsigned long long mem_since;   // waiting for a chunk since (0: not waiting)
   // position
   uint32_t mi, col, row, part;
   uint32_t steps;
@@ -256,6 +334,28 @@ AA_HD inline void zero_slot( AA_GLOBAL int16_t * block )
   V16 z; z.x = z.y = z.z = z.w = 0;
   AA_GLOBAL V16 * p = (AA_GLOBAL V16 *) block;
   p[0] = z; p[1] = z;
+}
+
+// ---- coefficient chunks ---------------------------------------------------------------------------------------------
+// -> a free chunk's number, or kNoChunk when the pool is empty right now
+AA_HD inline uint32_t pool_take( const Heap & H )
+{
+  // claim first (the semaphore counts published entries), then draw the ticket: a ticket is only ever drawn for an entry
+  // that is there.  The acquire pairs with the producers' release: the entry's value is visible.
+  const int32_t old = AA_AT_ADD_ACQ( &H.pool->avail, -1 );
+  if ( old <= 0 ) { AA_AT_ADD( &H.pool->avail, 1 ); return kNoChunk; }
+  const uint32_t t = AA_AT_ADD( &H.pool->head, 1u );
+  return AA_AT_LOAD( &H.ring[t & H.pool->mask] );
+}
+// producers (one thread per call): n chunk numbers ids[0..n) (or first, first+1, ... when ids is null) go back to the ring
+AA_HD inline void pool_push( const Heap & H, const AA_GLOBAL uint32_t * ids, uint32_t first, uint32_t n )
+{
+  if ( !n ) return;
+  const uint32_t b = AA_AT_ADD( &H.pool->reserve, n );
+  for ( uint32_t i = 0; i < n; i++ ) AA_AT_STORE( &H.ring[( b + i ) & H.pool->mask], ids ? ids[i] : first + i );
+  while ( AA_AT_LOAD( &H.pool->publish ) != b ) {}          // in order (whoever reserved before us is running: it reserved)
+  AA_AT_STORE( &H.pool->publish, b + n );
+  AA_AT_ADD_REL( &H.pool->avail, static_cast<int32_t>( n ) );
 }
 
 // ---- stream ring ----------------------------------------------------------------------------------------------------
@@ -378,22 +478,39 @@ AA_HD inline void setup_block( Lane & L, const uint8_t * smem, uint32_t blk )
 // The slow path, for lanes at a macroblock boundary (R_MBDONE: the step just completed one; R_MB: waiting for flags):
 // take macroblocks until one has tokens (skipped ones are settled on the spot), the flag ring runs dry (try again later)
 // or the frame ends.  Everything rare lives here: row ends, partition switches, the end of the frame.
-AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J )
+// The lane is through with its frame: counts to the host, the chunk list closed, then -- behind a release that makes every
+// record and coefficient this lane stored visible to the whole device -- the `done` word the host polls.
+AA_HD inline void finish_frame( Lane & L, const Frame & J, uint32_t status )
+{
+  J.chunk_list[0] = L.nchunks;
+  AA_GLOBAL FrameSummary * sum = (AA_GLOBAL FrameSummary *) J.job->summary;
+  sum->num_coeff_blocks = L.coeff_blocks;
+  sum->steps = L.steps;
+  sum->num_chunks = L.nchunks;
+  sum->status = status;
+#if defined( __HIP_DEVICE_COMPILE__ )
+  __builtin_amdgcn_fence( __ATOMIC_RELEASE, "" );               // system scope: HBM stores written back, host stores ordered
+  asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );            // (the compiler may drop the wait behind the write-back)
+  __hip_atomic_store( &sum->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+#else
+  sum->done = 1u;
+#endif
+  L.rec = R_DONE;
+}
+
+constexpr unsigned long long kMemWaitTicks = 200000000ull;      // 2 s of the 100 MHz clock: then the frame is handed back (TOK_NO_MEMORY)
+
+AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J, const Heap & H )
 {
   uint16_t * const above = reinterpret_cast<uint16_t *>( smem + L.base + kAbove );
   if ( L.rec == R_MBDONE ) { L.mi++; L.col++; L.rec = R_MB; }
   if ( L.steps > J.max_steps ) {             // cannot happen for any input; if it does the frame is reported, not hung on
-    AA_GLOBAL FrameSummary * sum = (AA_GLOBAL FrameSummary *) J.job->summary;
-    sum->num_coeff_blocks = L.coeff_blocks; sum->steps = 0xFFFFFFFFu;
-    L.rec = R_DONE;
+    finish_frame( L, J, TOK_STEP_BOUND );
     return;
   }
   for ( ;; ) {
     if ( L.mi == J.nmb ) {
-      AA_GLOBAL FrameSummary * sum = (AA_GLOBAL FrameSummary *) J.job->summary;
-      sum->num_coeff_blocks = L.coeff_blocks;
-      sum->steps = L.steps;
-      L.rec = R_DONE;
+      finish_frame( L, J, TOK_OK );
       return;
     }
     if ( L.mi >= L.mwpos ) return;                          // flags not here yet (only a long run of skipped macroblocks gets ahead of the ring)
@@ -404,8 +521,27 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
     const uint32_t flags = smem[L.base + kMeta + ( L.mi & ( kMetaRing - 1 ) )];
     const uint32_t has_y2 = flags & AA_MB_HAS_Y2;
     L.ctxbits = ( L.ctxbits & 0x01FF0000u ) | above[L.col];
-    L.mb_first = L.coeff_blocks;
     if ( !( flags & AA_MB_SKIP ) ) {
+      if ( L.blk_left < kMbBlocks ) {                       // the chunk cannot take a whole macroblock: on to a new one
+        const uint32_t c = pool_take( H );
+        if ( c == kNoChunk ) {
+          // nothing free right now: this lane sits the steps out and asks again at the next boundary pass (its wave-mates keep
+          // decoding).  The host maps more heap when it sees lanes starve; if nothing comes for kMemWaitTicks the frame is
+          // handed back unfinished and the host runs it again when memory has been released.
+          const unsigned long long now = AA_NOW();
+          if ( !L.mem_since ) { L.mem_since = now | 1ull; AA_AT_ADD( &H.pool->starving, 1u ); }
+          else if ( now - L.mem_since > kMemWaitTicks ) finish_frame( L, J, TOK_NO_MEMORY );
+          return;
+        }
+        L.mem_since = 0;
+        J.chunk_list[1 + L.nchunks] = c;
+        L.nchunks++;
+        L.blk_index = c * kChunkBlocks;
+        L.blk = H.base + static_cast<size_t>( L.blk_index ) * 16;
+        L.blk_left = kChunkBlocks;
+        zero_slot( L.blk );
+      }
+      L.mb_first = L.blk_index;
       L.flags = flags; L.nz_mask = 0;
       L.ytypeaddr = L.base + kProbs + ( has_y2 ? Y_AFTER_Y2 : Y_WITHOUT_Y2 ) * 264u;
       L.yfirst = has_y2 ? 1u : 0u;
@@ -414,7 +550,7 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
     }
     L.ctxbits &= has_y2 ? 0u : 0x01000100u;                 // a non-coded Y2 leaves its chain untouched (frame.cc:255-269)
     above[L.col] = static_cast<uint16_t>( L.ctxbits );
-    store_mb( J, L.mi, 0, L.mb_first, flags | ( has_y2 ? AA_MB_LF_SKIP_INNER : 0u ) );
+    store_mb( J, L.mi, 0, L.blk_index, flags | ( has_y2 ? AA_MB_LF_SKIP_INNER : 0u ) );
     L.mi++; L.col++;
   }
 }
@@ -476,7 +612,7 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
     {
       if ( bend ) {
         const uint32_t ctxbits = L.nonzero ? L.ctxbits | L.nzsel : L.ctxbits & ~L.nzsel;
-        if ( L.nonzero ) { L.coeff_blocks++; L.blk += 16; zero_slot( L.blk ); L.nz_mask |= L.blkbit; }
+        if ( L.nonzero ) { L.coeff_blocks++; L.blk += 16; L.blk_index++; L.blk_left--; zero_slot( L.blk ); L.nz_mask |= L.blkbit; }
         const bool mbdone = L.blkaddr == kBlockTabOff + 8 * 25;
         if ( mbdone ) {                           // the macroblock is complete: its record, its column's flags
           *lds_at<uint16_t>( smem, L.base + kAbove + 2 * L.col ) = static_cast<uint16_t>( ctxbits );
@@ -502,12 +638,12 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
 }
 
 // One period of a wave: kPeriod steps, leaving the hot loop whenever a lane has reached a macroblock boundary.
-AA_HD inline void run_period( Lane & L, uint8_t * smem, const Frame & J )
+AA_HD inline void run_period( Lane & L, uint8_t * smem, const Frame & J, const Heap & H )
 {
   uint32_t it = 0;
   while ( it < kPeriod ) {
     if ( AA_ANY( at_boundary( L ) ) ) {
-      if ( at_boundary( L ) ) macroblock_boundary( L, smem, J );
+      if ( at_boundary( L ) ) macroblock_boundary( L, smem, J, H );
       it++;                                                 // (a lane waiting for flags must not spin the period away)
       if ( !AA_ANY( L.rec < R_MBDONE ) ) break;             // nobody has anything to decode
     }
@@ -548,8 +684,7 @@ AA_HD inline void begin_frame( Lane & L, uint8_t * smem, uint32_t base, const Fr
   L.idx = L.nonzero = L.nzsel = L.blkbit = L.mag = 0;
   L.ytypeaddr = L.typeaddr = L.rowaddr = L.paddr = base;
   L.blkaddr = kBlockTabOff;
-  L.blk = J.coeffs;
-  zero_slot( L.blk );
+  L.blk = nullptr; L.blk_index = 0; L.blk_left = 0; L.nchunks = 0; L.mem_since = 0;     // the first coded macroblock takes the first chunk
   start_partition( L, smem, J, 0 );
   // flag ring: macroblocks [0, kMetaRing)
   for ( uint32_t k = 0; k < kMetaRing / 16; k++ ) {

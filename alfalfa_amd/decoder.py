@@ -106,6 +106,16 @@ class Context:
         capi.check(self.L.aa_ctx_memory(self.h, C.byref(f), C.byref(t)))
         return f.value, t.value
 
+    def set_memory_limit(self, nbytes):
+        """HBM the context may take for its pools (default: 7/8 of what was free at creation)."""
+        capi.check(self.L.aa_ctx_set_memory_limit(self.h, int(nbytes)))
+
+    def info(self):
+        """What the context holds right now (aa_ctx_info): memory by kind, token-worker shape and occupancy."""
+        st = capi.CtxInfo()
+        capi.check(self.L.aa_ctx_get_info(self.h, C.byref(st)))
+        return {n: getattr(st, n) for n, _ in capi.CtxInfo._fields_}
+
     def set_schedule(self, name):
         """"rows" (default): row-pipelined persistent kernels; "diagonal": one launch per anti-diagonal."""
         capi.check(self.L.aa_ctx_set_schedule(self.h, {"rows": 0, "diagonal": 1}[name]))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 2
+#define AA_ABI_VERSION 3
 
 typedef enum aa_status {
   AA_OK = 0,
@@ -36,7 +36,8 @@ typedef enum aa_status {
   AA_ERR_OUT_OF_RANGE = -4, /* reference: std::out_of_range from Chunk bounds       chunk.hh:54-59     */
   AA_ERR_HIP = -5,          /* HIP runtime failure (message has hipGetErrorString)                      */
   AA_ERR_NO_DEVICE = -6,    /* no HIP device / kernels missing: the device path NEVER falls back to CPU */
-  AA_ERR_ARGUMENT = -7
+  AA_ERR_ARGUMENT = -7,
+  AA_ERR_NO_MEMORY = -8     /* HBM: the memory limit of the context leaves no room (the message says what to release); the call can be repeated */
 } aa_status;
 
 /* Message of the last failing call on this thread ("" if none). */
@@ -152,6 +153,24 @@ aa_status aa_ctx_set_schedule( aa_ctx * ctx, int schedule );
  * ticket queue was not drained): once set, aa_ctx_sync / downloads report AA_ERR_HIP and later launches give up early.
  * After the caller has dealt with it (e.g. switched to AA_SCHEDULE_DIAGONAL), this clears the word. */
 aa_status aa_ctx_clear_error( aa_ctx * ctx );
+/* HBM the context may take for its pools (frame records, rasters, the coefficient heap of the device parser): by default 7/8 of
+ * what was free when it was created; a caller that shares the GPU sets less.  Memory is taken as frames need it, up to this. */
+aa_status aa_ctx_set_memory_limit( aa_ctx * ctx, size_t bytes );
+/* What the context holds right now (the memory budget of a deployment: one context per GPU, one process per GPU). */
+typedef struct aa_ctx_info {
+  uint64_t memory_limit_bytes;       /* aa_ctx_set_memory_limit */
+  uint64_t pool_bytes;               /* HBM taken for frame records, rasters, batch arenas (slabs, recycled) */
+  uint64_t heap_mapped_bytes;        /* HBM mapped into the coefficient heap of the device parser */
+  uint64_t heap_limit_bytes;         /* its virtual size */
+  uint64_t heap_used_bytes;          /* chunks frames hold or are expected to take */
+  uint64_t pinned_host_bytes;        /* pinned host memory (batch arenas, staging chunks) */
+  uint32_t heap_is_virtual;          /* 1: grown on demand (hipMemMap); 0: one fixed allocation (no virtual memory management) */
+  uint32_t token_lanes_per_workgroup, token_workgroups_capacity, token_workgroups_alive;
+  uint32_t token_lane_lds_bytes, token_workgroup_lds_bytes;
+  uint32_t jobs_waiting;             /* frames in the token workers' queue that no lane has taken */
+  uint32_t compute_units;
+} aa_ctx_info;
+aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out );
 /* hipStream_t handles as opaque pointers (to order foreign work, e.g. an RCCL broadcast, against ours) */
 void * aa_ctx_compute_stream( aa_ctx * ctx );
 void * aa_ctx_copy_stream( aa_ctx * ctx );
@@ -313,6 +332,14 @@ typedef struct aa_kernel_stats {
   double bind_wait_ms;      /* aa_decode_batch waiting for one of its (16) raster-binding buffers: the compute stream is that far behind */
   double alloc_ms;          /* host time inside the device pool allocator (hipMalloc of new slabs included) */
   uint64_t slab_mallocs;    /* hipMalloc calls of the pool */
+  /* token workers (device-side entropy decode) */
+  uint64_t token_steps;     /* decode steps of the frames whose parse has been waited for (an upper bound on the bools decoded) */
+  uint64_t token_frames;
+  uint64_t worker_launches, worker_wgs;   /* worker grids launched / workgroups in them */
+  uint64_t worker_retires;  /* grids told to finish so that their stream could take a new grid */
+  uint64_t heap_grows;      /* pieces of memory mapped into the coefficient heap */
+  uint64_t heap_mapped_bytes;
+  uint64_t nomem_retries;   /* frames a lane handed back because the coefficient pool was empty, run again */
 } aa_kernel_stats;
 aa_status aa_ctx_profile( aa_ctx * ctx, int enable );
 aa_status aa_ctx_kernel_stats( aa_ctx * ctx, aa_kernel_stats * out, int reset );

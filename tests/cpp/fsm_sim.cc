@@ -4,6 +4,8 @@
 //   g++ -shared fsm_sim.cc ../../alfalfa_amd/csrc/parser.cpp
 // It follows parse_kernels.hip statement for statement: header pre-pass (Parser::parse_header, the real product code),
 // k_parse_mb_headers' loop, k_segment_fixup's loop, k_parse_tokens' loop.
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -15,6 +17,8 @@
 namespace {
 struct Sim {
   aa::Parser parser;
+  uint32_t pool_chunks = 0;        // coefficient chunks the pool offers per frame (0: plenty)
+  uint32_t last_status = 0, last_chunks = 0;
   std::vector<uint8_t> segmap;     // the stream's persistent segment map as the device keeps it
   Sim( uint16_t w, uint16_t h ) : parser( w, h ), segmap( size_t( parser.mb_width() ) * parser.mb_height(), 3 ) {}
 };
@@ -44,7 +48,20 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
   J.nmb = nmb; J.flags_padded = ( nmb + 15 ) & ~15u;
   J.mbflags = static_cast<uint8_t *>( aligned( J.flags_padded ) );
   J.mbs = static_cast<aa_mb_info *>( aligned( nmb * sizeof( aa_mb_info ) ) );
-  J.coeffs = static_cast<int16_t *>( aligned( ( size_t( nmb ) * 25 + 1 ) * 32 ) );
+  J.chunk_list = static_cast<uint32_t *>( aligned( size_t( aa::chunk_list_entries( nmb ) ) * 4 ) );
+  // the coefficient heap as the runtime sets it up: chunks handed out through the pool's ring -- here in an order that is
+  // neither ascending nor contiguous, and with `pool_chunks` of them only (0: as many as the worst case needs)
+  const uint32_t worst_chunks = aa::chunk_list_entries( nmb ) - 1;
+  const uint32_t heap_chunks = worst_chunks + 3;
+  const uint32_t avail_chunks = S.pool_chunks ? S.pool_chunks : heap_chunks;
+  int16_t * heap_mem = static_cast<int16_t *>( aligned( size_t( heap_chunks ) * aa::kChunkBlocks * 32 ) );
+  uint32_t ring_entries = 1; while ( ring_entries < heap_chunks ) ring_entries <<= 1;
+  std::vector<uint32_t> ring( ring_entries, 0xDEADBEEFu );
+  aa::CoeffPool pool; std::memset( &pool, 0, sizeof pool ); pool.mask = ring_entries - 1;
+  aa::Heap H; H.base = heap_mem; H.pool = &pool; H.ring = ring.data();
+  uint32_t stride = 1;
+  for ( uint32_t c : { 7u, 11u, 13u, 5u, 3u } ) if ( heap_chunks % c ) { stride = c; break; }       // (coprime: a permutation)
+  for ( uint32_t k = 0; k < avail_chunks && k < heap_chunks; k++ ) aa::tok::pool_push( H, nullptr, ( k * stride + 2u ) % heap_chunks, 1 );
   const unsigned words_per_row = ( J.fp.mbw + 63 ) / 64;
   J.intra_rows = static_cast<unsigned long long *>( aligned( size_t( words_per_row ) * J.fp.mbh * 8 ) );
   aa::FrameSummary sum; std::memset( &sum, 0, sizeof sum );
@@ -88,22 +105,46 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
     for ( ;; ) {
       aa::tok::top_up( L, smem, F );
       if ( L.rec == aa::tok::R_DONE ) break;
-      aa::tok::run_period( L, smem, F );
+      aa::tok::run_period( L, smem, F, H );
     }
   }
+  S.last_status = sum.status; S.last_chunks = sum.num_chunks;
+  int bad = 0;
+  if ( !sum.done || J.chunk_list[0] != sum.num_chunks ) bad = 1;
+  if ( getenv( "FSM_SIM_DEBUG" ) ) fprintf( stderr, "done %u list0 %u chunks %u avail %d of %u status %u blocks %u\n", sum.done, J.chunk_list[0], sum.num_chunks, pool.avail, avail_chunks, sum.status, sum.num_coeff_blocks );
+  // every chunk number distinct and one the pool handed out; chunks not taken are still in the pool
+  for ( uint32_t k = 0; k < sum.num_chunks; k++ ) for ( uint32_t j = 0; j < k; j++ ) if ( J.chunk_list[1 + k] == J.chunk_list[1 + j] ) bad = 1;
+  if ( pool.avail + static_cast<int32_t>( sum.num_chunks ) != static_cast<int32_t>( std::min( avail_chunks, heap_chunks ) ) ) bad = 1;
   hdr->num_coeff_blocks = sum.num_coeff_blocks;
   hdr->num_intra_mbs = sum.num_intra_mbs;
   hdr->has_intra_mb = sum.num_intra_mbs != 0;
   if ( steps ) *steps = sum.steps;
   std::memcpy( mbs, J.mbs, nmb * sizeof( aa_mb_info ) );
-  std::memcpy( coeffs, J.coeffs, size_t( sum.num_coeff_blocks ) * 32 );
+  // the frame's own view of its coefficients (what aa_stream_read_records gives): blocks back to back in parse order,
+  // coeff_index counted from the frame's first block; every macroblock's blocks must lie inside one of the frame's chunks
+  if ( sum.status == aa::TOK_OK ) {
+    uint32_t running = 0;
+    for ( uint32_t mi = 0; mi < nmb; mi++ ) {
+      const uint32_t nblk = static_cast<uint32_t>( __builtin_popcount( mbs[mi].nz_mask ) );
+      if ( nblk ) {
+        const uint32_t c = mbs[mi].coeff_index / aa::kChunkBlocks, o = mbs[mi].coeff_index % aa::kChunkBlocks;
+        bool mine = false;
+        for ( uint32_t k = 0; k < sum.num_chunks; k++ ) if ( J.chunk_list[1 + k] == c ) mine = true;
+        if ( !mine || o + nblk > aa::kChunkBlocks || running + nblk > sum.num_coeff_blocks ) { bad = 1; break; }
+        std::memcpy( coeffs + size_t( running ) * 16, heap_mem + size_t( mbs[mi].coeff_index ) * 16, size_t( nblk ) * 32 );
+      }
+      mbs[mi].coeff_index = running;
+      running += nblk;
+    }
+    if ( running != sum.num_coeff_blocks ) bad = 1;
+  }
   // the intra row masks must say what the records say
-  int bad = 0;
   for ( unsigned row = 0; row < J.fp.mbh; row++ ) for ( unsigned col = 0; col < J.fp.mbw; col++ ) {
     const bool bit = ( J.intra_rows[row * words_per_row + ( col >> 6 )] >> ( col & 63 ) ) & 1;
     if ( bit != !( J.mbs[row * J.fp.mbw + col].flags & AA_MB_INTER ) ) bad = 1;
   }
-  free( dev_data ); free( J.mbflags ); free( J.mbs ); free( J.coeffs ); free( J.intra_rows );
+  free( dev_data ); free( J.mbflags ); free( J.mbs ); free( J.chunk_list ); free( heap_mem ); free( J.intra_rows );
+  if ( sum.status != aa::TOK_OK ) return 200 + static_cast<int>( sum.status );
   return bad ? 100 : 0;
 }
 
@@ -124,6 +165,11 @@ int fsm_sim_handover_check( const uint8_t * data, size_t size, int n, int look )
   }
   return bad;
 }
+
+// the pool offers only `chunks` coefficient chunks to the next frames (0: plenty) -> a frame that needs more is handed back
+// with TOK_NO_MEMORY (fsm_sim_frame returns 202)
+void fsm_sim_set_pool_chunks( void * handle, uint32_t chunks ) { static_cast<Sim *>( handle )->pool_chunks = chunks; }
+uint32_t fsm_sim_last_chunks( void * handle ) { return static_cast<Sim *>( handle )->last_chunks; }
 
 // persistent state for comparison with the host parser's
 void fsm_sim_segmap( void * handle, uint8_t * out ) { Sim & S = *static_cast<Sim *>( handle ); std::memcpy( out, S.segmap.data(), S.segmap.size() ); }

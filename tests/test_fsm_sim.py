@@ -33,6 +33,9 @@ def sim_lib():
     L.fsm_sim_segmap.argtypes = [C.c_void_p, C.c_void_p]
     L.fsm_sim_probs.argtypes = [C.c_void_p, C.c_void_p]
     L.fsm_sim_handover_check.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int]
+    L.fsm_sim_set_pool_chunks.argtypes = [C.c_void_p, C.c_uint32]
+    L.fsm_sim_last_chunks.argtypes = [C.c_void_p]
+    L.fsm_sim_last_chunks.restype = C.c_uint32
     return L
 
 
@@ -48,10 +51,10 @@ class Sim:
     def __del__(self):
         self.L.fsm_sim_destroy(self.h)
 
-    def frame(self, data):
+    def frame(self, data, expect=0):
         hdr, steps = capi.FrameHeader(), C.c_uint32()
         rc = self.L.fsm_sim_frame(self.h, data, len(data), C.byref(hdr), self.mb.ctypes.data, self.cf.ctypes.data, C.byref(steps))
-        assert rc == 0, rc
+        assert rc == expect, rc
         h = hdr.as_dict()
         return h, self.mb.copy(), self.cf[:h["num_coeff_blocks"] * 16].copy(), steps.value
 
@@ -139,3 +142,25 @@ def test_device_algorithm_on_a_1080p_bench_stream():
     if not workload.have_reference_tools():
         pytest.skip("oracle/_ref (stream generator) not built")
     check_stream(*aa.read_ivf(workload.make_stream("1080p_inter_lf", 3, 105)))
+
+
+def test_coefficient_pool_runs_dry_and_the_frame_is_handed_back():
+    """A token lane draws 64-KB chunks of the coefficient heap as it goes.  With fewer chunks in the pool than a frame needs the
+    lane waits, then hands the frame back (TOK_NO_MEMORY: fsm_sim_frame -> 202) instead of hanging; with exactly as many as the
+    frame took the parse goes through, and a frame takes only what its non-zero blocks need (far less than 25 per macroblock)."""
+    w, h, frames = golden_frames("cif_q60_lf40s5")
+    host, sim = aa.Parser(w, h), Sim(w, h)
+    hh, hmb, hcf = host.parse(frames[0])
+    sh, smb, scf, _ = sim.frame(frames[0])
+    took = sim.L.fsm_sim_last_chunks(sim.h)
+    nmb = sim.mbw * sim.mbh
+    assert took >= 1 and took == -(-hh["num_coeff_blocks"] // 2048) or took == -(-hh["num_coeff_blocks"] // 2048) + 1, (took, hh["num_coeff_blocks"])
+    assert took * 2048 < 25 * nmb or hh["num_coeff_blocks"] > 20 * nmb          # demand-sized, not worst-case sized
+    sim2 = Sim(w, h)
+    sim2.L.fsm_sim_set_pool_chunks(sim2.h, max(0, took - 1) or 10 ** 6)
+    if took > 1:
+        sim2.frame(frames[0], expect=202)
+    sim3 = Sim(w, h)
+    sim3.L.fsm_sim_set_pool_chunks(sim3.h, took)
+    h3, mb3, cf3, _ = sim3.frame(frames[0])
+    assert h3 == hh and (cf3 == hcf.reshape(-1)).all()
