@@ -252,35 +252,31 @@ static int parse_lanes_env()
 }
 static int header_lanes() { const int v = parse_lanes_env(); return v ? v : 16; }
 
-// Token workgroups live for seconds and a CU holds as many as its LDS takes, so the LDS they leave is all that the
-// reconstruction kernels (milliseconds, launched on the high-priority stream) can start in while a parse is running.  The
-// launch shape -- n workgroups of `lanes` lanes per CU -- is chosen for the most lanes per CU with `kLdsReserve` bytes left
-// free on every CU: the LDS request is padded so that an (n + 1)-th workgroup does not fit.  Measured on the benchmark
-// (profiles/r02_pipeline_experiments.md) the reserve buys nothing -- a pipelined run leaves ~30 % of the token slots empty at any
-// time, reconstruction runs there -- so it defaults to 0; ALFALFA_AMD_LDS_RESERVE_KB=24 keeps a loop-filter workgroup's worth.
-// (A step costs the wave the same whatever its width, but the rarer paths -- a coefficient emitted, a block or macroblock ended
-// -- run whenever ANY lane needs them: beyond ~24 lanes a wave spends most steps in them.)
+// Token workgroups stay for as long as there is work, and what they leave of a CU -- LDS, registers -- is all the reconstruction
+// kernels (milliseconds each, on the high-priority stream) ever get.  The shape is therefore chosen for the reconstruction
+// kernels' sake as much as for the lanes':
+//   * `n` workgroups (waves) per CU, default 4 = ONE per SIMD: a worker wave holds 208 VGPRs, so a SIMD with one of them keeps
+//     304 free -- room for a loop-filter wave (256) or two intra waves; with two worker waves on a SIMD only k_recon_inter4 fits;
+//   * each workgroup asks for just over 1 / (n + 1) of the CU's LDS, so that an (n + 1)-th does not fit and n of them leave
+//     160 KB - n * request to the other kernels (n = 4: 30 KB, a loop-filter workgroup's 19 KB and an inter workgroup's 11 KB);
+//   * lanes per workgroup = what that request holds (26 at 1216 bytes per lane).  A step costs a wave the same whatever its
+//     width, but the rarer paths -- a block ended, a macroblock ended -- run whenever ANY lane needs them: wider waves step
+//     slower (measured in round 2: 16 lanes per wave with 6 waves per CU was the best shape when nothing else had to fit).
+// ALFALFA_AMD_WGS_PER_CU / ALFALFA_AMD_MAX_LANES: experiments.
 constexpr uint32_t kLdsPerCu = 160u * 1024u, kLdsGranule = 512u;
 static uint32_t env_u32( const char * name, uint32_t dflt ) { const char * e = getenv( name ); return e ? static_cast<uint32_t>( atoi( e ) ) : dflt; }
-static const uint32_t kLdsReserve = env_u32( "ALFALFA_AMD_LDS_RESERVE_KB", 0u ) * 1024u;      // (the two knobs: experiments)
-static const uint32_t kMaxLanes = std::max( 1u, std::min( 64u, env_u32( "ALFALFA_AMD_MAX_LANES", 24u ) ) );
-struct TokenShape { int lanes; uint32_t lds; };
+static const uint32_t kWgsPerCu = std::max( 1u, std::min( 16u, env_u32( "ALFALFA_AMD_WGS_PER_CU", 4u ) ) );
+static const uint32_t kMaxLanes = std::max( 1u, std::min( 64u, env_u32( "ALFALFA_AMD_MAX_LANES", 32u ) ) );
+struct TokenShape { int lanes; uint32_t lds; int per_cu; };
 static TokenShape token_launch_shape( uint32_t lane_bytes )
 {
-  TokenShape best { 0, 0 };
-  int best_total = 0;
-  for ( uint32_t n = 1; n <= 16; n++ ) {
-    const uint32_t maxp = std::min<uint32_t>( 65536u, ( kLdsPerCu - kLdsReserve ) / n / kLdsGranule * kLdsGranule );
-    if ( maxp < tok::kTablesBytes + lane_bytes ) break;
-    const int lanes = static_cast<int>( std::min<uint32_t>( kMaxLanes, ( maxp - tok::kTablesBytes ) / lane_bytes ) );
-    const uint32_t need = ( static_cast<uint32_t>( lanes ) * lane_bytes + tok::kTablesBytes + kLdsGranule - 1 ) / kLdsGranule * kLdsGranule;
-    const uint32_t excl = ( kLdsPerCu / ( n + 1 ) / kLdsGranule + 1 ) * kLdsGranule;      // smallest request of which n + 1 do not fit
-    const uint32_t p = std::max( need, excl );
-    if ( p > maxp ) continue;
-    const int total = static_cast<int>( n ) * lanes;
-    if ( total >= best_total ) { best_total = total; best = { lanes, p }; }                // ties: more, narrower workgroups (n ascending)
+  for ( uint32_t n = kWgsPerCu; n >= 1; n-- ) {
+    const uint32_t request = std::min( 65536u, ( kLdsPerCu / ( n + 1 ) / kLdsGranule + 1 ) * kLdsGranule );      // smallest request of which n + 1 do not fit
+    if ( request < tok::kTablesBytes + lane_bytes || request * n > kLdsPerCu ) continue;
+    const int lanes = static_cast<int>( std::min<uint32_t>( kMaxLanes, ( request - tok::kTablesBytes ) / lane_bytes ) );
+    return { lanes, request, static_cast<int>( n ) };
   }
-  return best;
+  return { 0, 0, 0 };
 }
 
 int launch_parse_mb_headers( const ParseJob * jobs, const uint32_t * order, int n, void * stream )
@@ -310,7 +306,7 @@ void token_worker_shape( uint32_t lane_bytes, int n_cus, int * lanes_out, uint32
   }
   (void) n_cus;
   *lanes_out = lanes; *lds_out = lds;
-  *wgs_per_cu_out = lds ? static_cast<int>( ( kLdsPerCu - kLdsReserve ) / lds ) : 0;
+  *wgs_per_cu_out = lds ? static_cast<int>( kLdsPerCu / lds ) : 0;
 }
 
 int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap & heap, uint32_t * exited, const uint32_t * retire, uint32_t gen,

@@ -528,18 +528,19 @@ aa_status tok_init( aa_ctx * ctx )
   // the coefficient heap: a block index is 32 bits and a block 32 bytes -> at most 128 GiB; by default at most 3/4 of what the
   // context may use.  Virtual range now, memory as the frames need it.
   const size_t cap = size_t( 120 ) << 30;
+  if ( const char * e = std::getenv( "ALFALFA_AMD_HEAP_GROW_MB" ) ) T.grow_bytes = std::max<size_t>( 2, static_cast<size_t>( atoi( e ) ) ) << 20;     // (tests: small pieces)
+  if ( const char * e = std::getenv( "ALFALFA_AMD_HEAP_LIMIT_MB" ) ) T.heap_limit = std::max<size_t>( 2, static_cast<size_t>( atoi( e ) ) ) << 20;
   if ( !T.heap_limit ) T.heap_limit = ctx->pool_soft_limit == ~size_t( 0 ) ? ( size_t( 16 ) << 30 ) : ctx->pool_soft_limit / 4 * 3;
   T.heap_limit = std::max( T.grow_bytes, std::min( cap, T.heap_limit ) / T.grow_bytes * T.grow_bytes );
   const char * no_vmm = std::getenv( "ALFALFA_AMD_NO_VMM" );
   if ( !( no_vmm && atoi( no_vmm ) ) ) {
     void * va = nullptr;
-    if ( hipMemAddressReserve( &va, T.heap_limit, T.grow_bytes, nullptr, 0 ) == hipSuccess && va ) { T.heap = static_cast<uint8_t *>( va ); T.heap_va = T.heap_limit; T.vmm = true; }
+    if ( hipMemAddressReserve( &va, T.heap_limit, 0, nullptr, 0 ) == hipSuccess && va ) { T.heap = static_cast<uint8_t *>( va ); T.heap_va = T.heap_limit; T.vmm = true; }
     else (void) hipGetLastError();
   }
   if ( !T.vmm ) {
     // no virtual memory management on this runtime: one fixed piece (a quarter of the limit unless the caller set one)
-    size_t fixed = std::max( T.grow_bytes, T.heap_limit / 4 / T.grow_bytes * T.grow_bytes );
-    if ( const char * e = std::getenv( "ALFALFA_AMD_HEAP_GB" ) ) fixed = std::max<size_t>( 1, static_cast<size_t>( atoi( e ) ) ) << 30;
+    size_t fixed = std::getenv( "ALFALFA_AMD_HEAP_LIMIT_MB" ) ? T.heap_limit : std::max( T.grow_bytes, T.heap_limit / 4 / T.grow_bytes * T.grow_bytes );
     HIP_TRY( hipMalloc( reinterpret_cast<void **>( &T.heap ), fixed ) );
     T.heap_va = fixed;
   }
@@ -612,6 +613,7 @@ aa_status tok_launch_workers( aa_ctx * ctx, hipEvent_t after )
   auto & sl = T.slot[g];
   sl.gen++;
   if ( after ) HIP_TRY( hipStreamWaitEvent( sl.st, after, 0 ) );
+  LaunchTimer timer( ctx, 4, sl.st );
   if ( int e = aa::launch_token_workers( T.q, T.slots, heap_of( ctx ), T.exited_dev + g, T.retire_dev + g, sl.gen, want, T.lanes, T.lane_bytes, T.lds, sl.st ) )
     return hip_fail( static_cast<hipError_t>( e ), "k_token_workers" );
   sl.launched += static_cast<uint32_t>( want );
@@ -633,6 +635,11 @@ aa_status tok_service( aa_ctx * ctx, hipEvent_t after = nullptr )
   return tok_launch_workers( ctx, after );
 }
 
+inline double parse_timeout_ms()
+{
+  static const double ms = [] { const char * e = std::getenv( "ALFALFA_AMD_PARSE_TIMEOUT_S" ); const double s = e ? atof( e ) : 0.0; return ( s > 0 ? s : 300.0 ) * 1000.0; }();
+  return ms;
+}
 // the token lane's `done` word of one frame (pinned host memory the lane writes last)
 aa_status tok_wait_done( aa_ctx * ctx, volatile aa::FrameSummary * sum )
 {
@@ -643,7 +650,7 @@ aa_status tok_wait_done( aa_ctx * ctx, volatile aa::FrameSummary * sum )
   while ( !sum->done ) {
     const double t = now_ms();
     if ( t - last > 2.0 ) { if ( aa_status st = tok_service( ctx ) ) return st; last = t; }
-    if ( t - t0 > 300000.0 ) return fail( AA_ERR_HIP, "device parser: a frame handed to the token workers was not finished within 300 s" );
+    if ( t - t0 > parse_timeout_ms() ) return fail( AA_ERR_HIP, "device parser: a frame handed to the token workers was not finished in time (ALFALFA_AMD_PARSE_TIMEOUT_S, default 300)" );
     if ( ++spins > 64 ) usleep( 50 );
   }
   ctx->stats.parse_wait_ms += now_ms() - t0;
@@ -667,9 +674,9 @@ void tok_prune_inflight( aa_ctx * ctx )
   v.resize( keep );
 }
 
-// The slice of LDS a token lane needs depends on the widest frame (its above-row flags) and on whether frames have several DCT
-// partitions.  Grids with smaller slices cannot run such frames, so the size only ever grows -- and before it does, the queue
-// is drained and the grids are gone.
+// The slice of LDS a token lane needs depends only on whether frames have several DCT partitions (the saved decoders of the
+// other partitions).  Grids with the smaller slice cannot run such frames, so the size only ever grows -- and before it does,
+// the queue is drained and the grids are gone.
 aa_status tok_set_lane_bytes( aa_ctx * ctx, uint32_t need )
 {
   auto & T = ctx->tok;
@@ -1078,6 +1085,7 @@ aa_status aa_ctx_sync( aa_ctx * ctx )
   HIP_TRY( hipStreamSynchronize( ctx->copy ) );
   for ( auto ps : ctx->parse_streams ) HIP_TRY( hipStreamSynchronize( ps ) );
   if ( aa_status st = tok_quiesce( ctx ) ) return st;       // every frame handed to the token workers is parsed
+  { std::lock_guard<std::mutex> g( ctx->pool_mu ); flush_chunk_frees( ctx ); }     // coefficient chunks of released frames are back in the pool
   HIP_TRY( hipStreamSynchronize( ctx->compute ) );
   return check_watchdog( ctx );
 }
@@ -1324,7 +1332,8 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
   const uint32_t flags_padded = ( nmb + 15u ) & ~15u;
   const size_t flags_bytes = align_up( flags_padded );
   const size_t list_bytes = align_up( size_t( aa::chunk_list_entries( nmb ) ) * sizeof( uint32_t ) );
-  rec.rec_bytes = mb_bytes + rows_bytes + flags_bytes + list_bytes;
+  const size_t above_bytes = align_up( size_t( aa::tok::above_entries( J.fp.mbw ) ) * sizeof( uint16_t ) );
+  rec.rec_bytes = mb_bytes + rows_bytes + flags_bytes + list_bytes + above_bytes;
   if ( aa_status st = dev_alloc( ctx, rec.rec_bytes, &rec.rec_block ) ) { it.error = g_last_error; return st; }
   uint8_t * blk = rec.rec_block;
 
@@ -1335,6 +1344,7 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
   J.intra_rows = reinterpret_cast<unsigned long long *>( blk + mb_bytes );
   J.mbflags = blk + mb_bytes + rows_bytes;
   J.chunk_list = reinterpret_cast<uint32_t *>( blk + mb_bytes + rows_bytes + flags_bytes );
+  J.above = reinterpret_cast<uint16_t *>( blk + mb_bytes + rows_bytes + flags_bytes + list_bytes );
   J.summary = reinterpret_cast<aa::FrameSummary *>( b->host_dev + b->summaries_off ) + item;     // pinned + mapped: no copy back
   rec.chunk_list = J.chunk_list;
   rec.summary = reinterpret_cast<volatile aa::FrameSummary *>( b->host + b->summaries_off ) + item;
@@ -1518,7 +1528,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
     }
   } abandon { ctx, b.release() };
   Batch * const raw = abandon.b;
-  if ( aa_status st = tok_set_lane_bytes( ctx, aa::tok::lane_lds_bytes( static_cast<uint32_t>( max_mbw ), max_nparts > 1 ) ) ) return st;
+  if ( aa_status st = tok_set_lane_bytes( ctx, aa::tok::lane_lds_bytes( max_nparts > 1 ) ) ) return st;
 
   // ---- segment-map pass lists (only streams that use segmentation in this batch) ----
   aa_seg_stream * seg_streams = reinterpret_cast<aa_seg_stream *>( raw->host + jobs_bytes + dframes_bytes + sums_bytes );
@@ -1608,17 +1618,14 @@ static aa_status resolve_summary( aa_stream * s, FrameRec & r )
     // finish) and the frame goes to the queue again -- its macroblock headers are parsed already.
     ctx->stats.nomem_retries++;
     const uint32_t worst = static_cast<uint32_t>( ( 25ull * r.hdr.num_macroblocks ) / ( aa::kChunkBlocks - aa::kMbBlocks ) ) + 2u;
-    if ( !r.chunks_returned ) {
-      {
-        std::lock_guard<std::mutex> g( ctx->pool_mu );
-        T.pending_lists.push_back( r.chunk_list );
-        flush_chunk_frees( ctx );
-        if ( !T.pending_lists.empty() ) return fail( AA_ERR_HIP, "k_pool_free_lists could not be launched" );
-      }
-      HIP_TRY( hipStreamSynchronize( ctx->compute ) );
-      r.chunks_returned = true;
-      T.chunks_committed -= r.est_chunks; r.est_chunks = 0;
+    {
+      std::lock_guard<std::mutex> g( ctx->pool_mu );
+      if ( !r.chunks_returned ) T.pending_lists.push_back( r.chunk_list );
+      flush_chunk_frees( ctx );                     // (and the chunks of everything the caller has released since)
+      if ( !T.pending_lists.empty() ) return fail( AA_ERR_HIP, "k_pool_free_lists could not be launched" );
     }
+    HIP_TRY( hipStreamSynchronize( ctx->compute ) );
+    if ( !r.chunks_returned ) { r.chunks_returned = true; T.chunks_committed -= r.est_chunks; r.est_chunks = 0; }
     if ( aa_status st = tok_grow_heap( ctx, T.heap_mapped + static_cast<size_t>( worst ) * kChunkBytesHeap ) ) return st;
     if ( aa_status st = tok_refresh_mirror( ctx ) ) return st;
     if ( T.mirror_host->pool_avail < static_cast<int32_t>( worst ) ) {
@@ -1767,6 +1774,9 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
     if ( fi != s->next_submit ) return fail( AA_ERR_LOGIC, "aa_decode_batch: frames of a stream must be submitted in order" );
   }
   for ( int i = 0; i < n; i++ ) if ( aa_status st = aa_stream_upload( streams[i] ) ) return st;
+  // coefficient chunks of the frames released since the last call go back to the pool (behind the kernels that read them:
+  // those were queued before the release)
+  { std::lock_guard<std::mutex> g( ctx->pool_mu ); flush_chunk_frees( ctx ); }
   for ( int i = 0; i < n; i++ ) {
     if ( streams[i]->frames[frame_index[i]].records_released ) return fail( AA_ERR_LOGIC, "aa_decode_batch: frame records were released" );
     if ( aa_status st = resolve_summary( streams[i], streams[i]->frames[frame_index[i]] ) ) return st;

@@ -46,7 +46,7 @@ BYTES_PER_MB = {"recon_inter": 80 + 800 + 384 + 384, "recon_split": 80 + 800 + 3
                 "parse_tokens": 80 + 800, "parse_headers": 80}
 PATH_BYTES_PER_MB = 2416       # inter + deblock, whole path
 KERNEL_NAMES = {"recon_inter": "k_recon_inter4", "recon_split": "k_recon_inter", "recon_intra": "k_recon_intra4", "loopfilter": "k_loopfilter_rows4",
-                "parse_tokens": "k_parse_tokens", "parse_headers": "k_parse_mb_headers"}
+                "parse_tokens": "k_token_workers", "parse_headers": "k_parse_mb_headers"}
 
 
 def pmc_traffic(config):
@@ -66,8 +66,9 @@ def parse_args():
     ap.add_argument("--config", default="1080p_inter_lf")
     ap.add_argument("--streams", type=int, default=480, help="independent streams per GPU")
     ap.add_argument("--frames", type=int, default=12, help="frames per stream per step")
-    ap.add_argument("--key-ahead", type=int, default=8, help="steps by which KEY frames are handed to the GPU parser ahead of reconstruction")
-    ap.add_argument("--depth", type=int, default=4, help="steps by which inter frames are handed to the GPU parser ahead of reconstruction")
+    ap.add_argument("--key-ahead", type=int, default=12, help="steps by which KEY frames are handed to the GPU parser ahead of reconstruction (clamped to what the HBM budget holds)")
+    ap.add_argument("--depth", type=int, default=6, help="steps by which inter frames are handed to the GPU parser ahead of reconstruction (clamped likewise)")
+    ap.add_argument("--hbm-gb", type=float, default=150.0, help="HBM the decoder context may use on each GPU (aa_ctx_set_memory_limit); the look-ahead is planned inside it")
     ap.add_argument("--header-ahead", type=int, default=0, help="steps by which the macroblock-header pass of inter frames runs ahead of their token pass (two-phase submit)")
     ap.add_argument("--threads", type=int, default=0, help="host workers of the header pre-pass (0: cores / local ranks)")
     ap.add_argument("--schedule", default="rows", choices=["rows", "diagonal"])
@@ -116,6 +117,8 @@ def main():
 
     ctx = aa.Context(local_rank)
     ctx.set_schedule(args.schedule)
+    hbm_budget = min(args.hbm_gb * 1e9, 0.9 * ctx.memory()[0])
+    ctx.set_memory_limit(int(hbm_budget))
 
     def barrier():
         ctx.sync()
@@ -226,15 +229,35 @@ def main():
                         break
                 self.decode()
 
-    # HBM holds what is in flight: the records of K + 1 key-frame groups and D + 1 inter-frame groups (worst-case sized: 25
-    # coefficient blocks per macroblock), and the rasters the decoder sets refer to.  Clamp the look-ahead to what fits.
-    rec_bytes = mbs_per_frame * 80 + (25 * mbs_per_frame + 1) * 32 + 2 * mbs_per_frame + 4096
+    # ---- calibration: what ONE lone chain costs, and what frames of this content really store ----
+    # (a) a key frame parsed with nothing else on the GPU: its wall time / its decode steps = the latency of one step of one
+    #     lane, the unit of the entropy decode's own roof (lanes / step latency);
+    # (b) coefficient blocks per key / inter frame of a few streams -> bytes a frame in flight holds (records + the chunks its
+    #     lane drew: demand-sized, not 25 blocks per macroblock).
+    cal = [aa.Decoder(ctx, width, height) for _ in range(min(4, S))]
+    ctx.kernel_stats(reset=True)
+    t0 = time.perf_counter()
+    ctx.submit_frames([(cal[0], streams[0][0])], threads)
+    key_hdr = cal[0].frame_header(0)                     # waits for the parse
+    t_lone_key = time.perf_counter() - t0
+    lone_steps = ctx.kernel_stats(reset=True)["token_steps"]
+    ctx.submit_frames([(d, st[0]) for d, st in zip(cal[1:], streams[1:])] + [(d, fr) for d, st in zip(cal, streams) for fr in st[1:]], threads)
+    key_blocks = max([key_hdr["num_coeff_blocks"]] + [d.frame_header(0)["num_coeff_blocks"] for d in cal[1:]])
+    inter_blocks = max(d.frame_header(f)["num_coeff_blocks"] for d in cal for f in range(1, F)) if F > 1 else key_blocks
+    ctx.sync()
+    step_latency_us = t_lone_key / max(1, lone_steps) * 1e6
+    del cal
+    rec_fixed = mbs_per_frame * 84 + 4096 + 2 * 65536          # macroblock records + flags + lists; two partly filled 64-KB chunks
+    key_bytes, inter_bytes = rec_fixed + key_blocks * 32, rec_fixed + inter_blocks * 32
     raster_bytes = sum(aa.Decoder(ctx, width, height).plane_sizes())
-    budget = 0.9 * ctx.memory()[0]
+    info0 = ctx.info()
+    budget = hbm_budget - 2e9                                   # (arenas of the compressed frames, row-kernel work space)
     K, D = max(1, args.key_ahead), max(1, min(args.depth, args.key_ahead))
 
+    # HBM holds what is in flight: K + 1 groups of key frames, D + 0.6 groups of inter frames (frames being parsed hold part of
+    # what they will), the rasters the decoder sets refer to.  Clamp the look-ahead to what fits.
     def need(k, d):
-        return S * ((k + 1) * rec_bytes + (d + 0.6) * (F - 1) * rec_bytes + (3 * (k - d + 1) + 2) * raster_bytes
+        return S * ((k + 1) * key_bytes + (d + 0.6) * (F - 1) * inter_bytes + (3 * (k - d + 1) + 2) * raster_bytes
                     + args.header_ahead * (F - 1) * (mbs_per_frame * 84 + compressed_bytes / (S * F)))
     while need(K, D) > budget and (K > D or D > 1):
         if K > D:
@@ -255,6 +278,7 @@ def main():
     elapsed = time.perf_counter() - t0
     hbm_free, hbm_total = ctx.memory()
     tstats = ctx.kernel_stats(reset=True); ctx.profile(False)
+    info = ctx.info()
     timed_region = {"step_done_at_ms": [round((t - t0) * 1e3) for t in pipe.done_t],
                     "host_ms_per_step": {"submit": round(pipe.host_s / args.steps * 1e3, 1), "launch_tokens": round(pipe.t_launch / args.steps * 1e3, 1),
                                          "decode_batch_calls_incl_wait_for_parse": round(pipe.t_decode / args.steps * 1e3, 1),
@@ -262,14 +286,30 @@ def main():
                     "host_waited_for_parse_ms_per_step": round(tstats["parse_wait_ms"] / args.steps, 2),
                     "host_waited_for_compute_stream_ms_per_step": round(tstats["bind_wait_ms"] / args.steps, 2),
                     "host_in_pool_allocator_ms_per_step": round(tstats["alloc_ms"] / args.steps, 2), "slab_mallocs": tstats["slab_mallocs"],
+                    "heap_grows": tstats["heap_grows"], "frames_handed_back_for_lack_of_memory": tstats["nomem_retries"],
+                    "worker_grids_launched": tstats["worker_launches"], "worker_workgroups_launched": tstats["worker_wgs"], "worker_grids_retired": tstats["worker_retires"],
                     "pool_waits": tstats["pool_waits"], "pool_wait_ms_per_step": round(tstats["pool_wait_ms"] / args.steps, 2)}
+    # the entropy decode against ITS roof: a lane decodes one bool per step, a step takes what it takes (measured on a lone chain),
+    # the GPU holds `lanes` chains -> lanes / step latency bools per second at best
+    lanes_total = info["token_lanes_per_workgroup"] * info["token_workgroups_capacity"]
+    bools = tstats["token_steps"]
+    lanes_roof = {"lanes": lanes_total, "lanes_per_workgroup": info["token_lanes_per_workgroup"], "workgroups_per_cu": info["token_workgroups_capacity"] // max(1, info["compute_units"]),
+                  "lane_lds_bytes": info["token_lane_lds_bytes"], "workgroup_lds_bytes": info["token_workgroup_lds_bytes"],
+                  "step_latency_us_lone_chain": round(step_latency_us, 4),
+                  "roof_bools_per_s": round(lanes_total / (step_latency_us * 1e-6)), "sustained_bools_per_s": round(bools / elapsed),
+                  "frac": round(bools / elapsed / (lanes_total / (step_latency_us * 1e-6)), 4), "bools_per_step": round(bools / args.steps),
+                  "note": "decode steps of the frames parsed in the timed region (an upper bound on bools) over the timed region's wall time; step latency = lone key frame submit->parsed / its steps"}
+    memory = {"limit_gb": round(info["memory_limit_bytes"] / 1e9, 1), "pool_gb": round(info["pool_bytes"] / 1e9, 2), "coefficient_heap_mapped_gb": round(info["heap_mapped_bytes"] / 1e9, 2),
+              "hbm_taken_by_the_context_gb": round((info["pool_bytes"] + (info["heap_mapped_bytes"] if info["heap_is_virtual"] else 0)) / 1e9, 2),
+              "pinned_host_gb": round(info["pinned_host_bytes"] / 1e9, 2), "heap_is_virtual": bool(info["heap_is_virtual"]),
+              "hbm_in_use_on_device_gb": round((hbm_total - hbm_free) / 1e9, 1),
+              "planned": {"key_frame_bytes": key_bytes, "inter_frame_bytes": inter_bytes, "key_blocks_per_mb": round(key_blocks / mbs_per_frame, 2), "inter_blocks_per_mb": round(inter_blocks / mbs_per_frame, 2)}}
     if args.profile_timed:
         timed_region["kernel_ms_per_step"] = {k: round(v / args.steps, 2) for k, v in tstats.items() if k.endswith("_ms") and "wait" not in k}
     host_submit_s = pipe.host_s / max(1, args.steps)
-    # steady state inside the timed region: the median interval between reconstruction hand-overs (host side, i.e. when the
+    # between fill and drain: the MEAN interval between reconstruction hand-overs after the first one (host side, i.e. when the
     # parse a step waited for was done) -- the timed region itself also pays for filling and draining the pipeline
-    gaps = sorted(b - a for a, b in zip(pipe.done_t, pipe.done_t[1:]))
-    steady_ms = gaps[len(gaps) // 2] * 1e3 if gaps else None
+    steady_ms = (pipe.done_t[-1] - pipe.done_t[0]) / (len(pipe.done_t) - 1) * 1e3 if len(pipe.done_t) > 1 else None
     per_rank = None
     if dist is not None:
         import torch
@@ -309,7 +349,7 @@ def main():
             split_mbs += mult * sp; whole_mbs += mult * (int(inter.sum()) - sp); intra_mbs += mult * int((~inter).sum())
     launches_per_step = {"recon_inter": max(1, kstats["recon_inter_launches"]), "recon_split": max(1, kstats["recon_split_launches"]),
                          "recon_intra": max(1, kstats["recon_intra_launches"]),
-                         "loopfilter": max(1, kstats["loopfilter_launches"]), "parse_tokens": max(1, kstats["parse_launches"]),
+                         "loopfilter": max(1, kstats["loopfilter_launches"]), "parse_tokens": max(1, kstats["worker_launches"]),
                          "parse_headers": max(1, kstats["parse_launches"])}
     units = {"recon_inter": whole_mbs, "recon_split": split_mbs, "recon_intra": intra_mbs,
              "loopfilter": S * F * mbs_per_frame, "parse_tokens": S * F * mbs_per_frame, "parse_headers": S * F * mbs_per_frame}
@@ -330,8 +370,12 @@ def main():
     roofs = {k: roof(k) for k in BYTES_PER_MB}
     dom = max((k for k in roofs if roofs[k]), key=lambda k: kstats[k + "_ms"])
     roofline = dict(roofs[dom])
-    roofline["note"] = ("dominant kernel by time; k_parse_tokens is a latency-bound serial arithmetic decode per lane (one bool per ~100 cycles), "
-                        "HBM is the nominal roof the contract prices against, not what binds it")
+    roofline["note"] = ("dominant kernel by time, from the un-pipelined profile step (its worker grids overlap: one for the key frames, one for the inter frames). "
+                        "k_token_workers is a latency-bound serial arithmetic decode per lane; HBM is the nominal roof the contract prices against, "
+                        "what binds it is lanes / step latency: see entropy_decode_roof")
+    roofline["sustained_in_timed_region"] = {"achieved": round(BYTES_PER_MB["parse_tokens"] * value / world / 1e9, 2), "unit": "GB/s",
+                                             "frac": round(BYTES_PER_MB["parse_tokens"] * value / world / (HBM_PEAK_GBS * 1e9), 5),
+                                             "note": "algorithmic bytes of the entropy decode (880 per macroblock) x the end-to-end rate: the workers are resident for the whole timed region"}
     roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this config)" if traffic else None
     roofline["path_frac_of_hbm_peak"] = round(value / world * PATH_BYTES_PER_MB / (HBM_PEAK_GBS * 1e9), 5)
 
@@ -460,11 +504,12 @@ def main():
                        "streams_per_gpu": S, "frames_per_stream": F, "macroblocks_per_step_per_gpu": mbs_per_step,
                        "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective",
                        "schedule": args.schedule, "key_frames_ahead": pipe_K, "inter_frames_ahead": pipe_D, "inter_headers_ahead_of_tokens": args.header_ahead, "decoder_sets": pipe_R, "host_threads": threads,
-                       "hbm_in_use_after_timed_region_gb": round((hbm_total - hbm_free) / 1e9, 1)},
+                       "hbm_budget_gb": round(hbm_budget / 1e9, 1), "hbm_taken_by_the_context_gb": memory["hbm_taken_by_the_context_gb"]},
+            "memory": memory, "entropy_decode_roof": lanes_roof,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "kernels": roofs, "units_per_step": units, "launches_per_step": launches_per_step, "device_half": device_half,
             "steady_state": None if steady_ms is None else {"ms_per_step": round(steady_ms, 3), "value": round(world * mbs_per_step / (steady_ms * 1e-3), 1),
-                                                            "note": "median interval between steps inside the timed region; `value` itself also pays for filling and draining the pipeline"},
+                                                            "note": "mean interval between step hand-overs after the first one (the series is timed_region.step_done_at_ms); `value` itself also pays for filling and draining the pipeline"},
             "stages": {"host_prepass_and_staging_s_per_step": round(host_submit_s, 4),
                        "entropy_decode_alone_s_per_step": round(t_parse_alone, 4),
                        "note": "entropy_decode_alone = one step's submit -> parse finished with nothing else on the GPU (a latency: the longest chain, a key frame)"},

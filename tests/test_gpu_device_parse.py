@@ -238,3 +238,64 @@ def test_gpu_parser_on_long_runs_of_skipped_macroblocks(gpu_ctx):
         for k in range(3):
             s.frame(key=False, q_index=30, skip_prob=2 + k, density=density, skip_rate=1.0, log2_parts=k % 3, lf_level=8)
         check_stream(gpu_ctx, w, h, s.frames)
+
+
+def test_context_info_and_demand_sized_coefficient_storage(gpu_ctx):
+    """aa_ctx_get_info: the token workers' shape and what the context holds.  A frame's coefficients take what its non-zero
+    blocks need (64-KB chunks of one heap), not 25 blocks per macroblock."""
+    w, h, frames = golden_frames("cif_q60_lf40s5")
+    dec = aa.Decoder(gpu_ctx, w, h)
+    gpu_ctx.submit_frames([(dec, fr) for fr in frames[:3]])
+    hdrs = [dec.frame_header(i) for i in range(3)]
+    info = gpu_ctx.info()
+    assert info["token_lanes_per_workgroup"] >= 1 and info["token_workgroups_capacity"] >= info["compute_units"] >= 1
+    assert info["token_lane_lds_bytes"] in (1216, 1344) and info["heap_mapped_bytes"] > 0 and info["heap_limit_bytes"] >= info["heap_mapped_bytes"]
+    nmb = hdrs[0]["num_macroblocks"]
+    used_chunks = info["heap_used_bytes"] // 65536
+    assert used_chunks >= 3                                                     # (other tests' frames may be alive too)
+    assert sum(-(-hd["num_coeff_blocks"] // 2048) for hd in hdrs) <= used_chunks
+    assert max(hd["num_coeff_blocks"] for hd in hdrs) < 25 * nmb
+    for i in range(3):
+        gpu_ctx.decode_batch([dec], [i])
+    assert sha256(dec.raster_bytes(2)) == GOLDEN["cif_q60_lf40s5"]["raster_sha256"][2]
+
+
+@pytest.mark.parametrize("vmm", [True, False])
+def test_coefficient_heap_runs_out_and_frames_are_run_again(vmm, monkeypatch):
+    """A heap far too small for what is submitted (8 MB = 128 chunks, 60 CIF key frames want more): lanes wait, hand their frames
+    back (TOK_NO_MEMORY), the runtime runs them again as memory comes back -- and says AA_ERR_NO_MEMORY (repeatable) when the
+    caller has to release frames first.  Every raster still equals the reference's.  Both heap kinds: mapped on demand
+    (hipMemMap) and one fixed allocation."""
+    monkeypatch.setenv("ALFALFA_AMD_HEAP_GROW_MB", "2")
+    monkeypatch.setenv("ALFALFA_AMD_HEAP_LIMIT_MB", "8")
+    if not vmm:
+        monkeypatch.setenv("ALFALFA_AMD_NO_VMM", "1")
+    ctx = aa.Context(0)
+    name = "cif_q60_lf40s5"
+    w, h, frames = golden_frames(name)
+    decs = [aa.Decoder(ctx, w, h) for _ in range(60)]
+    ctx.submit_frames([(d, frames[0]) for d in decs] + [(d, frames[1]) for d in decs])
+    assert bool(ctx.info()["heap_is_virtual"]) == vmm
+    refused = 0
+    for f in range(2):
+        for k, d in enumerate(decs):
+            for attempt in range(4):
+                try:
+                    ctx.decode_batch([d], [f])
+                    break
+                except aa.AlfalfaError as e:
+                    assert e.kind == "NoMemory", e
+                    refused += 1
+                    ctx.sync()
+                    for d2 in decs[:k]:                  # what has been decoded can go
+                        d2.release_before(f + 1)
+                    if f == 1:
+                        for d2 in decs:
+                            d2.release_before(1)
+                    ctx.sync()
+            else:
+                raise AssertionError("decode kept being refused")
+            assert sha256(d.raster_bytes(f)) == GOLDEN[name]["raster_sha256"][f], (f, k)
+    st = ctx.kernel_stats()
+    assert st["nomem_retries"] > 0, st
+    assert ctx.info()["heap_mapped_bytes"] <= 8 << 20

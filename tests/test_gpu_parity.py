@@ -213,3 +213,20 @@ def test_first_allocation_of_a_context_is_a_big_piece():
         _, fi = small.get_frame_output(fr)
         assert sha256(small.raster_bytes(fi)) == GOLDEN["qcif_q30_lf24"]["raster_sha256"][i]
     del big, small
+
+
+def test_rasters_released_while_binding_are_not_recycled_inside_the_same_launch(gpu_ctx):
+    """Round-2 review: with an idle compute stream and every handle released after every step, a raster that bind_frame gives
+    back (an old reference) could come out of the pool again as ANOTHER stream's output raster of the same aa_decode_batch --
+    one frame then read a plane another was writing.  Many streams, key / inter / inter ..., release + sync after every step."""
+    name = "qcif_q30_lf24"
+    w, h, frames = golden_frames(name)
+    decs = [aa.Decoder(gpu_ctx, w, h) for _ in range(12)]
+    for f, fr in enumerate(frames[:6]):
+        idx = [d.parse_frame(fr)[0] for d in decs]
+        gpu_ctx.decode_batch(decs, idx)
+        got = [sha256(d.raster_bytes(f)) for d in decs]
+        assert all(g == GOLDEN[name]["raster_sha256"][f] for g in got), (f, [g == GOLDEN[name]["raster_sha256"][f] for g in got])
+        for d in decs:
+            d.release_before(f + 1)
+        gpu_ctx.sync()
