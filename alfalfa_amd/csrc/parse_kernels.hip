@@ -88,18 +88,22 @@ struct WorkerArgs {
   uint32_t * exited;                      // this grid's count of workgroups that have left (HBM)
   const uint32_t * retire;                // grids of this slot up to generation *retire take no new jobs (pinned host memory, mapped)
   uint32_t gen;                           // this grid's generation
+  uint32_t spread;                        // workgroups the GPU holds: a wave takes its share of a short queue, not all it can carry
   int lanes;
   uint32_t lane_bytes;
 };
 
-// up to `want` tickets for this wave (called by ONE lane): -> first ticket in *base, how many as the result
-__device__ inline uint32_t queue_take( aa::TokQueue * q, uint32_t want, uint32_t * base )
+// up to `want` tickets for this wave (called by ONE lane): -> first ticket in *base, how many as the result.  When the queue
+// is short the wave takes only its share (queue length / workgroups the GPU holds, rounded up): a wave steps faster the
+// fewer lanes it carries, and the other workgroups -- alive or about to start -- look at the same queue.
+__device__ inline uint32_t queue_take( aa::TokQueue * q, uint32_t want, uint32_t spread, uint32_t * base )
 {
   uint32_t h = AA_AT_LOAD( &q->head );
   for ( int tries = 0; tries < 16; tries++ ) {
     const uint32_t avail = AA_AT_LOAD( &q->publish ) - h;
     if ( static_cast<int32_t>( avail ) <= 0 ) return 0;
-    const uint32_t n = want < avail ? want : avail;
+    const uint32_t share = ( avail + spread - 1u ) / spread;
+    const uint32_t n = want < share ? want : share;
     uint32_t expect = h;
     if ( __hip_atomic_compare_exchange_strong( &q->head, &expect, h + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) { *base = h; return n; }
     h = expect;
@@ -133,7 +137,7 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
         uint32_t base = 0, got = 0;
         if ( lane == first ) {
           if ( __hip_atomic_load( a.retire, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM ) >= a.gen ) got = 0xFFFFFFFFu;
-          else got = queue_take( a.q, static_cast<uint32_t>( __popcll( idle_mask ) ), &base );
+          else got = queue_take( a.q, static_cast<uint32_t>( __popcll( idle_mask ) ), a.spread, &base );
         }
         base = __shfl( base, first ); got = __shfl( got, first );
         if ( got == 0xFFFFFFFFu ) { retired = true; got = 0; }
@@ -309,12 +313,12 @@ void token_worker_shape( uint32_t lane_bytes, int n_cus, int * lanes_out, uint32
   *wgs_per_cu_out = lds ? static_cast<int>( kLdsPerCu / lds ) : 0;
 }
 
-int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap & heap, uint32_t * exited, const uint32_t * retire, uint32_t gen,
+int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap & heap, uint32_t * exited, const uint32_t * retire, uint32_t gen, uint32_t spread,
                           int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, void * stream )
 {
   if ( lanes < 1 || wgs < 1 ) return static_cast<int>( hipErrorInvalidValue );
   WorkerArgs a;
-  a.q = q; a.slots = slots; a.heap = heap; a.exited = exited; a.retire = retire; a.gen = gen; a.lanes = lanes; a.lane_bytes = lane_bytes;
+  a.q = q; a.slots = slots; a.heap = heap; a.exited = exited; a.retire = retire; a.gen = gen; a.spread = spread ? spread : 1u; a.lanes = lanes; a.lane_bytes = lane_bytes;
   hipLaunchKernelGGL( k_token_workers, dim3( wgs ), dim3( 64 ), lds, static_cast<hipStream_t>( stream ), a );
   return static_cast<int>( hipGetLastError() );
 }

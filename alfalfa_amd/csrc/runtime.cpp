@@ -94,6 +94,7 @@ struct Batch {
 // that is idle between two groups of pictures holds one raster (its last reference), not a private stock.
 struct Slot {
   uint8_t * dev = nullptr;    // null: a free entry of the stream's slot table
+  bool shared = false;        // the context's blank raster of this size (what a new decoder's references point at): not this stream's to free
   int refs = 0;               // References + frame handles holding this raster
   bool hash_valid = false;    // HashCachedRaster: the hash is computed once per raster (raster_handle.cc:196-206)
   uint64_t hash = 0;
@@ -159,7 +160,7 @@ struct aa_ctx {
     unsigned long long * slots = nullptr;
     uint32_t q_slots = 1u << 18;
     uint64_t jobs_enqueued = 0;          // tickets the host has scheduled (a ticket = one frame, rejected ones included)
-    std::vector<volatile aa::FrameSummary *> inflight;   // frames handed to the queue and not yet seen done
+    std::vector<Batch *> inflight;       // batches with frames handed to the queue that may not be through yet (a batch leaves when it dies)
     uint32_t * one_dev = nullptr;        // a zero in HBM: the `order` of a one-job hand-over
     // coefficient heap: ONE virtual range, physical memory mapped as the frames need it
     uint8_t * heap = nullptr;
@@ -169,7 +170,7 @@ struct aa_ctx {
     aa::CoeffPool * pool = nullptr;
     uint32_t * ring = nullptr;
     int64_t chunks_committed = 0;        // chunks frames hold (parsed: what they took) or are expected to take (in flight: estimate)
-    double blocks_per_mb = 25.0;         // running estimate of what a macroblock stores (starts at the worst case)
+    double blocks_per_byte = 1.0;        // running estimate: coefficient blocks a frame stores per byte of its compressed size (never more than 25 per macroblock)
     uint32_t seen_starving = 0;
     std::vector<const uint32_t *> pending_lists;   // chunk lists of released frames, not yet handed to k_pool_free_lists
     // worker grids: slot g = worker stream g; counters are cumulative over the grids a slot has run
@@ -212,6 +213,7 @@ struct aa_ctx {
                                           // (aa_ctx_create: 7/8 of what was free; aa_ctx_set_memory_limit)
   size_t pinned_bytes = 0;                // pinned host memory the context has taken (arenas, staging chunks, binding buffers)
   std::map<size_t, std::vector<uint8_t *>> dev_free;
+  std::map<size_t, uint8_t *> blank;    // References( width, height ): one all-zero raster per raster size, shared by every new decoder (never written)
   uint8_t * boundary = nullptr; // loop filter: hand-off lines between macroblock rows (transient within a launch)
   size_t boundary_bytes = 0;
   aa_sync_ws * ws = nullptr;   // in-launch ordering state of the row-pipelined kernels
@@ -364,7 +366,7 @@ void release( aa_stream * s, int slot )
 {
   if ( slot < 0 ) return;
   Slot & sl = s->slots[slot];
-  if ( --sl.refs == 0 ) { dev_free( s->ctx, sl.dev, s->slot_bytes, true ); sl.dev = nullptr; }   // (kernels already queued may still read it)
+  if ( --sl.refs == 0 ) { if ( !sl.shared ) dev_free( s->ctx, sl.dev, s->slot_bytes, true ); sl.dev = nullptr; sl.shared = false; }   // (kernels already queued may still read it)
 }
 void set_ref( aa_stream * s, int which, int slot, int frame )
 {
@@ -595,9 +597,10 @@ aa_status tok_launch_workers( aa_ctx * ctx, hipEvent_t after )
     if ( alive[g] == 0 ) T.slot[g].queued_behind_retiring = false;
     alive_total += alive[g];
   }
-  const int room = T.cap_wgs - alive_total;
-  if ( room <= 0 ) return AA_OK;
-  const int want = std::min( room, ( queued + T.lanes - 1 ) / T.lanes );
+  // as many workgroups as there are jobs waiting, up to what the GPU holds: when lanes are plentiful a frame gets a wave of its
+  // own (a wave steps faster the fewer lanes it carries); grids already launched for these jobs -- started or not -- count
+  const int want = std::min( T.cap_wgs, queued ) - alive_total;
+  if ( want <= 0 ) return AA_OK;
   int g = -1;
   for ( int k = 0; k < aa_ctx::Tok::kSlots; k++ ) if ( alive[k] == 0 ) { g = k; break; }
   if ( g < 0 ) {
@@ -614,7 +617,7 @@ aa_status tok_launch_workers( aa_ctx * ctx, hipEvent_t after )
   sl.gen++;
   if ( after ) HIP_TRY( hipStreamWaitEvent( sl.st, after, 0 ) );
   LaunchTimer timer( ctx, 4, sl.st );
-  if ( int e = aa::launch_token_workers( T.q, T.slots, heap_of( ctx ), T.exited_dev + g, T.retire_dev + g, sl.gen, want, T.lanes, T.lane_bytes, T.lds, sl.st ) )
+  if ( int e = aa::launch_token_workers( T.q, T.slots, heap_of( ctx ), T.exited_dev + g, T.retire_dev + g, sl.gen, static_cast<uint32_t>( T.cap_wgs ), want, T.lanes, T.lane_bytes, T.lds, sl.st ) )
     return hip_fail( static_cast<hipError_t>( e ), "k_token_workers" );
   sl.launched += static_cast<uint32_t>( want );
   ctx->stats.worker_launches++; ctx->stats.worker_wgs += static_cast<uint64_t>( want );
@@ -658,19 +661,29 @@ aa_status tok_wait_done( aa_ctx * ctx, volatile aa::FrameSummary * sum )
 }
 
 // every frame handed to the queue so far is through
+bool batch_through( const Batch * b )
+{
+  const volatile aa::FrameSummary * sums = reinterpret_cast<const volatile aa::FrameSummary *>( b->host + b->summaries_off );
+  for ( int i = 0; i < b->n; i++ ) if ( b->items[i].live && b->items[i].s->frames[b->items[i].frame].enqueued && !sums[i].done ) return false;
+  return true;
+}
 aa_status tok_quiesce( aa_ctx * ctx )
 {
   auto & T = ctx->tok;
-  for ( volatile aa::FrameSummary * sum : T.inflight ) if ( aa_status st = tok_wait_done( ctx, sum ) ) return st;
+  for ( Batch * b : T.inflight ) {
+    volatile aa::FrameSummary * sums = reinterpret_cast<volatile aa::FrameSummary *>( b->host + b->summaries_off );
+    for ( int i = 0; i < b->n; i++ )
+      if ( b->items[i].live && b->items[i].s->frames[b->items[i].frame].enqueued ) if ( aa_status st = tok_wait_done( ctx, &sums[i] ) ) return st;
+  }
   T.inflight.clear();
   return AA_OK;
 }
 void tok_prune_inflight( aa_ctx * ctx )
 {
   auto & v = ctx->tok.inflight;
-  if ( v.size() < 65536 ) return;
+  if ( v.size() < 64 ) return;
   size_t keep = 0;
-  for ( auto p : v ) if ( !p->done ) v[keep++] = p;
+  for ( Batch * b : v ) if ( !batch_through( b ) ) v[keep++] = b;
   v.resize( keep );
 }
 
@@ -730,6 +743,7 @@ void release_records( aa_stream * s, FrameRec & f, bool deferred )
     if ( f.batch_item >= 0 && f.batch_item < static_cast<int>( b->items.size() ) ) b->items[f.batch_item].live = false;
     if ( last ) {
       if ( b->tokens_pending ) ctx->deferred.erase( std::remove( ctx->deferred.begin(), ctx->deferred.end(), b ), ctx->deferred.end() );
+      ctx->tok.inflight.erase( std::remove( ctx->tok.inflight.begin(), ctx->tok.inflight.end(), b ), ctx->tok.inflight.end() );
       if ( b->hdr_done ) { (void) hipEventSynchronize( b->hdr_done ); (void) hipEventDestroy( b->hdr_done ); }   // never forgotten while kernels still read the arena
       { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); }
       dev_free( ctx, b->dev, b->dev_bytes, deferred );
@@ -1180,13 +1194,22 @@ aa_status aa_stream_create( aa_ctx * ctx, uint16_t width, uint16_t height, aa_st
   s->plane_bytes[0] = size_t( s->pw ) * s->ph;
   s->plane_bytes[1] = s->plane_bytes[2] = size_t( s->pw / 2 ) * ( s->ph / 2 );
   s->slot_bytes = align_up( s->plane_bytes[0] + 2 * s->plane_bytes[1] );
-  // References(width, height): all three references alias one (blank) raster (decoder.cc:161-169)
-  int slot;
-  if ( aa_status st = alloc_slot( s.get(), &slot ) ) return st;
-  if ( hipError_t e = hipMemsetAsync( s->slots[slot].dev, 0, s->slot_bytes, ctx->compute ) ) {
-    dev_free( ctx, s->slots[slot].dev, s->slot_bytes );
-    return hip_fail( e, "hipMemsetAsync (blank reference raster)" );
+  // References(width, height): all three references alias one (blank) raster (decoder.cc:161-169).  Rasters are never written
+  // once they are references, so every decoder of this raster size points at the SAME blank one: a decoder that is created
+  // long before its first key frame is decoded (a chunk waiting in a pipeline) costs no raster.
+  uint8_t * blank = nullptr;
+  {
+    auto it = ctx->blank.find( s->slot_bytes );
+    if ( it != ctx->blank.end() ) blank = it->second;
+    else {
+      if ( aa_status st = dev_alloc( ctx, s->slot_bytes, &blank ) ) return st;
+      if ( hipError_t e = hipMemsetAsync( blank, 0, s->slot_bytes, ctx->compute ) ) { dev_free( ctx, blank, s->slot_bytes ); return hip_fail( e, "hipMemsetAsync (blank reference raster)" ); }
+      ctx->blank[s->slot_bytes] = blank;
+    }
   }
+  Slot sl; sl.dev = blank; sl.shared = true;
+  s->slots.push_back( sl );
+  const int slot = 0;
   for ( int i = 0; i < 3; i++ ) { s->cur_ref_slot[i] = -1; s->cur_ref_frame[i] = -1; }
   for ( int i = 0; i < 3; i++ ) set_ref( s.get(), i, slot, -1 );
   ctx->refs++;
@@ -1196,19 +1219,23 @@ aa_status aa_stream_create( aa_ctx * ctx, uint16_t width, uint16_t height, aa_st
 void aa_stream_destroy( aa_stream * s )
 {
   if ( !s ) return;
-  (void) hipSetDevice( s->ctx->device );
-  (void) hipStreamSynchronize( s->ctx->compute ); (void) hipStreamSynchronize( s->ctx->copy );
-  for ( auto ps : s->ctx->parse_streams ) (void) hipStreamSynchronize( ps );
-  // records first (a frame-store chunk goes back to the pools with its last frame), then whatever chunk is left -- the tail
-  // that was still being filled, chunks no frame ever landed in -- each piece exactly once
-  for ( auto & f : s->frames ) release_records( s, f, true );      // (waits for a token lane still on the frame; chunk lists go through an epoch)
-  for ( auto & c : s->chunks ) {
-    if ( c.host ) { std::lock_guard<std::mutex> g( s->ctx->pool_mu ); s->ctx->pinned_pool.emplace_back( c.host, c.pinned_bytes ); c.host = nullptr; }
-    if ( c.dev ) { dev_free( s->ctx, c.dev, c.dev_bytes ); c.dev = nullptr; }
-  }
-  for ( auto & sl : s->slots ) if ( sl.dev ) dev_free( s->ctx, sl.dev, s->slot_bytes );
-  dev_free( s->ctx, s->dev_segmap, size_t( s->parser.mb_width() ) * s->parser.mb_height() );
   aa_ctx * ctx = s->ctx;
+  (void) hipSetDevice( ctx->device );
+  // Nothing here waits for the reconstruction stream: what queued kernels may still read or write (rasters, records) goes back
+  // to the pools through a release epoch, like everything released while the pipeline runs -- a caller that drops a decoder
+  // per chunk does not stall.  What IS waited for: uploads out of this stream's pinned staging (it is handed to other parses),
+  // token lanes still on its frames (release_records), header kernels of a two-phase batch that was never launched.
+  bool staged = false;
+  for ( auto & c : s->chunks ) if ( c.host && c.uploaded ) staged = true;
+  if ( staged ) (void) hipStreamSynchronize( ctx->copy );
+  for ( auto & f : s->frames ) if ( f.batch && f.batch->hdr_done && !f.enqueued && !f.records_released ) (void) hipEventSynchronize( f.batch->hdr_done );
+  for ( auto & f : s->frames ) release_records( s, f, true );
+  for ( auto & c : s->chunks ) {
+    if ( c.host ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( c.host, c.pinned_bytes ); c.host = nullptr; }
+    if ( c.dev ) { dev_free( ctx, c.dev, c.dev_bytes, true ); c.dev = nullptr; }
+  }
+  for ( auto & sl : s->slots ) if ( sl.dev && !sl.shared ) dev_free( ctx, sl.dev, s->slot_bytes, true );
+  dev_free( ctx, s->dev_segmap, size_t( s->parser.mb_width() ) * s->parser.mb_height(), true );
   delete s;
   if ( --ctx->refs == 0 ) ctx_free( ctx );
 }
@@ -1387,14 +1414,15 @@ aa_status launch_tokens_of( aa_ctx * ctx, Batch * b )
     if ( !it.live ) { if ( jobs_host[i].nmb ) { jobs_host[i].nmb = 0; dropped = true; } continue; }   // rejected by the pre-pass, or released since: the lane that draws it drops it
     FrameRec & r = it.s->frames[it.frame];
     r.enqueued = true;
-    // what the frame is expected to store, in chunks (the running average of what macroblocks have stored so far, a margin, and
-    // the chunk its lane will be filling when it ends)
-    const double blocks = static_cast<double>( jobs_host[i].nmb ) * std::min( 25.0, T.blocks_per_mb * 1.15 );
+    // what the frame is expected to store, in chunks: blocks per compressed byte as frames have turned out so far (the ratio
+    // holds across key and inter frames and quantisers far better than blocks per macroblock), a margin, and the chunk its
+    // lane will be filling when it ends
+    const double blocks = std::min( 25.0 * jobs_host[i].nmb, T.blocks_per_byte * 1.15 * jobs_host[i].size );
     r.est_chunks = static_cast<uint32_t>( blocks / ( aa::kChunkBlocks - aa::kMbBlocks ) ) + 1u;
     T.chunks_committed += r.est_chunks;
-    T.inflight.push_back( r.summary );
     ctx->stats.parsed_macroblocks += jobs_host[i].nmb;
   }
+  if ( std::find( T.inflight.begin(), T.inflight.end(), b ) == T.inflight.end() ) T.inflight.push_back( b );
   if ( aa_status st = tok_grow_heap( ctx, static_cast<size_t>( std::max<int64_t>( 0, T.chunks_committed ) ) * kChunkBytesHeap ) ) return st;
   hipStream_t ps = b->ps;
   if ( b->patch_jobs && dropped ) HIP_TRY( hipMemcpyAsync( b->dev, b->host, b->head_bytes, hipMemcpyHostToDevice, ps ) );     // (behind the header kernel on its stream)
@@ -1642,7 +1670,7 @@ static aa_status resolve_summary( aa_stream * s, FrameRec & r )
     __atomic_thread_fence( __ATOMIC_SEQ_CST );
     if ( int e = aa::launch_enqueue_jobs( T.q, T.slots, r.parse_job, T.one_dev, 1, T.util ) ) return hip_fail( static_cast<hipError_t>( e ), "k_enqueue_jobs" );
     T.jobs_enqueued += 1;
-    T.inflight.push_back( sum );
+    if ( std::find( T.inflight.begin(), T.inflight.end(), b ) == T.inflight.end() ) T.inflight.push_back( b );
     if ( aa_status st = tok_service( ctx ) ) return st;
   }
   if ( sum->status == aa::TOK_STEP_BOUND ) return fail( AA_ERR_HIP, "device parser: a token lane exceeded the step bound of its frame size (records are not valid)" );
@@ -1654,7 +1682,7 @@ static aa_status resolve_summary( aa_stream * s, FrameRec & r )
   // the books: what the frame really took; what macroblocks store on this content (feeds the estimate of later frames)
   T.chunks_committed += static_cast<int64_t>( sum->num_chunks ) - static_cast<int64_t>( r.est_chunks );
   r.est_chunks = sum->num_chunks;
-  if ( r.hdr.num_macroblocks ) T.blocks_per_mb += 0.02 * ( static_cast<double>( sum->num_coeff_blocks ) / r.hdr.num_macroblocks - T.blocks_per_mb );
+  if ( r.hdr.compressed_size ) T.blocks_per_byte += 0.05 * ( static_cast<double>( sum->num_coeff_blocks ) / r.hdr.compressed_size - T.blocks_per_byte );
   ctx->stats.token_steps += sum->steps; ctx->stats.token_frames++;
   r.summary_pending = false;
   return AA_OK;

@@ -22,6 +22,7 @@ Multi-GPU: one process per GPU, independent streams per rank (weak scaling, no d
 traffic is the one-shot entry-state hand-off (shared reference raster broadcast over xGMI) before the timed region.
 """
 import argparse
+import ctypes as C
 import hashlib
 import json
 import os
@@ -174,39 +175,65 @@ def main():
     # waiting for their key frame).  R = key_ahead decoder sets rotate, so that the key frame of group g + R can be submitted
     # to a decoder whose group g is done.
     class Pipeline:
+        """Group g = one group of pictures of every stream = S decoders created when its key frames are handed over (a new
+        Decoder per chunk, as xc-decode-bundle does) and dropped when its last frame has been reconstructed: a decoder waiting
+        for its turn holds no raster (its references point at the context's shared blank one)."""
+
         def __init__(self, stream_list, key_ahead, depth, header_ahead=0):
+            self.streams = stream_list
             self.n = len(stream_list)
             self.H = max(0, header_ahead)
             self.inter_h = 0
             self.K, self.D = max(1, key_ahead), max(1, min(depth, key_ahead))
-            # a decoder takes its frames in order (key g, inter g, key g + R, ...): key g + R can be handed over once the
-            # inter frames of group g have been, which happens D steps before g is reconstructed -> K - D + 1 sets suffice
-            self.R = self.K - self.D + 1
-            self.sets = [[aa.Decoder(ctx, width, height) for _ in stream_list] for _ in range(self.R)]
-            self.key_prep = [ctx.prepare_frames([(d, st[0]) for d, st in zip(ds, stream_list)]) for ds in self.sets]
-            # stream-major: the inter frames of one stream are consecutive (a host worker takes a whole stream)
-            self.inter_prep = [ctx.prepare_frames([(d, fr) for d, st in zip(ds, stream_list) for fr in st[1:]]) for ds in self.sets]
+            self.groups = {}                                # g -> [Decoder]
+            n = self.n
+            # argument blocks, reused: only the decoder handles change from group to group
+            self.key_arr = (aa.capi.FrameIn * n)(); self.key_out = (C.c_int * n)()
+            self.inter_arr = (aa.capi.FrameIn * (n * (F - 1)))(); self.inter_out = (C.c_int * (n * (F - 1)))()
+            for i, st in enumerate(stream_list):
+                self.key_arr[i].data, self.key_arr[i].size = st[0], len(st[0])
+                for k, fr in enumerate(st[1:]):             # stream-major: the inter frames of one stream are consecutive (a host worker takes a whole stream)
+                    e = self.inter_arr[i * (F - 1) + k]
+                    e.data, e.size = fr, len(fr)
             self.keys = self.inters = self.decoded = 0      # groups handed to the GPU parser (key / inter frames), groups reconstructed
             self.host_s = 0.0
             self.t_launch = self.t_decode = self.t_release = 0.0      # host time in aa_launch_tokens / aa_decode_batch / releases
             self.done_t = []
 
-        def _submit(self, prep, defer_tokens=False):
+        def _submit_keys(self, g):
             t = time.perf_counter()
-            ctx.submit_prepared(prep, threads, defer_tokens)
+            ds = self.groups[g] = [aa.Decoder(ctx, width, height) for _ in range(self.n)]
+            for i, d in enumerate(ds):
+                self.key_arr[i].stream = d.h.value
+            ctx.submit_prepared((self.key_arr, self.key_out, None), threads, False)
+            self.host_s += time.perf_counter() - t
+
+        def _submit_inters(self, g, defer_tokens=False):
+            if F < 2:
+                return
+            t = time.perf_counter()
+            for i, d in enumerate(self.groups[g]):
+                h = d.h.value
+                for k in range(F - 1):
+                    self.inter_arr[i * (F - 1) + k].stream = h
+            ctx.submit_prepared((self.inter_arr, self.inter_out, None), threads, defer_tokens)
             self.host_s += time.perf_counter() - t
 
         def decode(self, release=True):
             g = self.decoded
-            ds, base = self.sets[g % self.R], (g // self.R) * F
+            ds = self.groups[g]
             for f in range(F):
                 t = time.perf_counter()
-                ctx.decode_batch(ds, [base + f] * self.n)
+                ctx.decode_batch(ds, [f] * self.n)
                 t1 = time.perf_counter(); self.t_decode += t1 - t
                 if release:             # this frame is consumed: its records go back to the pool once the kernels queued so far
                     for d in ds:        # have run, its raster when nothing refers to it any more (RasterHandle semantics)
-                        d.release_before(base + f + 1)
+                        d.release_before(f + 1)
                     self.t_release += time.perf_counter() - t1
+            if release:
+                t1 = time.perf_counter()
+                del self.groups[g], ds  # the chunk is done: its decoders go (nothing waits for the GPU here)
+                self.t_release += time.perf_counter() - t1
             self.decoded += 1
             self.done_t.append(time.perf_counter())
 
@@ -215,13 +242,15 @@ def main():
             target = self.decoded + steps
             while self.decoded < target:
                 while True:
-                    # inter frames in two phases: header pre-pass + upload + macroblock-header kernel H steps before the
-                    # token kernel is launched (only then are the coefficient blocks, 9/10 of the records, allocated)
-                    if self.keys < min(target, self.decoded + self.K, self.inter_h + self.R):
-                        self._submit(self.key_prep[self.keys % self.R]); self.keys += 1
+                    # inter frames in two phases (optional): header pre-pass + upload + macroblock-header kernel H steps before
+                    # the frames go to the token workers' queue
+                    if self.keys < min(target, self.decoded + self.K):
+                        self._submit_keys(self.keys); self.keys += 1
                     elif self.inter_h < min(target, self.decoded + self.D + self.H, self.keys):
-                        self._submit(self.inter_prep[self.inter_h % self.R], defer_tokens=True); self.inter_h += 1
-                    elif self.inters < min(target, self.decoded + self.D, self.inter_h):
+                        self._submit_inters(self.inter_h, defer_tokens=self.H > 0); self.inter_h += 1
+                        if self.H == 0:
+                            self.inters += 1
+                    elif self.H > 0 and self.inters < min(target, self.decoded + self.D, self.inter_h):
                         t = time.perf_counter()
                         ctx.launch_tokens(1); self.inters += 1
                         self.t_launch += time.perf_counter() - t
@@ -257,7 +286,9 @@ def main():
     # HBM holds what is in flight: K + 1 groups of key frames, D + 0.6 groups of inter frames (frames being parsed hold part of
     # what they will), the rasters the decoder sets refer to.  Clamp the look-ahead to what fits.
     def need(k, d):
-        return S * ((k + 1) * key_bytes + (d + 0.6) * (F - 1) * inter_bytes + (3 * (k - d + 1) + 2) * raster_bytes
+        # frames being parsed hold part of what they will (on average half, for the ~chain latency), parsed ones all of it
+        return S * ((0.5 * k + 1.5) * key_bytes + (0.6 * d + 1.0) * (F - 1) * inter_bytes + 5 * raster_bytes
+                    + (k + d * (F - 1)) * compressed_bytes / (S * F) * 1.1
                     + args.header_ahead * (F - 1) * (mbs_per_frame * 84 + compressed_bytes / (S * F)))
     while need(K, D) > budget and (K > D or D > 1):
         if K > D:
@@ -265,8 +296,8 @@ def main():
         else:
             D -= 1; K = D
     pipe = Pipeline(streams, K, D, args.header_ahead)
-    pipe.run(max(pipe.R, pipe.K))       # priming (untimed, before the warm-up): every decoder set once, so that first-touch
-    pipe.run(args.warmup)               # allocations of the pools (hipMalloc / hipHostMalloc) are not what the steps measure
+    pipe.run(max(2, pipe.K // 2))       # priming (untimed, before the warm-up): the pools and the coefficient heap reach their working
+    pipe.run(args.warmup)               # size, so that first-touch allocations (hipMalloc / hipMemMap / hipHostMalloc) are not what the steps measure
     barrier()
     pipe.host_s = pipe.t_launch = pipe.t_decode = pipe.t_release = 0.0; pipe.done_t = []
     ctx.kernel_stats(reset=True)
@@ -330,13 +361,13 @@ def main():
     ctx.profile(True); ctx.kernel_stats(reset=True)
     g = pipe.decoded
     t0 = time.perf_counter()
-    pipe._submit(pipe.key_prep[g % pipe.R]); pipe._submit(pipe.inter_prep[g % pipe.R]); pipe.keys += 1; pipe.inter_h += 1; pipe.inters += 1
+    pipe._submit_keys(g); pipe._submit_inters(g); pipe.keys += 1; pipe.inter_h += 1; pipe.inters += 1
     ctx.sync()
     t_parse_alone = time.perf_counter() - t0
     pipe.decode(release=False)
     ctx.sync()
     kstats = ctx.kernel_stats(reset=True); ctx.profile(False)
-    verify_decs, verify_base = pipe.sets[g % pipe.R], (g // pipe.R) * F
+    verify_decs, verify_base = pipe.groups[g], 0
 
     # macroblocks of the profiled step by kind (the records are in HBM: ask them)
     split_mbs = whole_mbs = intra_mbs = 0
@@ -425,7 +456,7 @@ def main():
         dt = (time.perf_counter() - t0) / reps
         device_half = {"value": round(mbs_per_step / dt, 1), "unit": "macroblocks/s", "ms_per_step": round(dt * 1e3, 3),
                        "note": "reconstruction + loop filter only, parsed records resident in HBM (round-1 metric)"}
-    pipe_K, pipe_D, pipe_R = pipe.K, pipe.D, pipe.R
+    pipe_K, pipe_D = pipe.K, pipe.D
     del pipe, verify_decs
 
     # ---- small batches: the reference's actual callers (one stream, one 8-chunk ExCamera bundle), end to end ----
@@ -503,7 +534,7 @@ def main():
                                    % (args.config, S, width, height, F, shape, cfg[3], cfg[4]),
                        "streams_per_gpu": S, "frames_per_stream": F, "macroblocks_per_step_per_gpu": mbs_per_step,
                        "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective",
-                       "schedule": args.schedule, "key_frames_ahead": pipe_K, "inter_frames_ahead": pipe_D, "inter_headers_ahead_of_tokens": args.header_ahead, "decoder_sets": pipe_R, "host_threads": threads,
+                       "schedule": args.schedule, "key_frames_ahead": pipe_K, "inter_frames_ahead": pipe_D, "inter_headers_ahead_of_tokens": args.header_ahead, "host_threads": threads,
                        "hbm_budget_gb": round(hbm_budget / 1e9, 1), "hbm_taken_by_the_context_gb": memory["hbm_taken_by_the_context_gb"]},
             "memory": memory, "entropy_decode_roof": lanes_roof,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
