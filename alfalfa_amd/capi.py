@@ -55,10 +55,11 @@ class KernelStats(C.Structure):
 
 
 class CtxInfo(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("memory_limit_bytes", "pool_bytes", "heap_mapped_bytes", "heap_limit_bytes", "heap_used_bytes",
+    _fields_ = [(n, C.c_uint64) for n in ("memory_limit_bytes", "pool_bytes", "pool_free_bytes", "pool_pending_bytes", "heap_mapped_bytes", "heap_limit_bytes", "heap_used_bytes",
                                           "pinned_host_bytes")] + [
         (n, C.c_uint32) for n in ("heap_is_virtual", "token_lanes_per_workgroup", "token_workgroups_capacity", "token_workgroups_alive",
-                                  "token_lane_lds_bytes", "token_workgroup_lds_bytes", "jobs_waiting", "compute_units")]
+                                  "token_lane_lds_bytes", "token_workgroup_lds_bytes", "jobs_waiting", "compute_units")] + [
+        ("heap_free_chunks", C.c_int32), ("lanes_starved", C.c_uint32)]
 
 
 class AlfalfaError(RuntimeError):

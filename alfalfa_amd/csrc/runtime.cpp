@@ -1130,6 +1130,9 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
   {
     std::lock_guard<std::mutex> g( ctx->pool_mu );
     out->memory_limit_bytes = ctx->pool_soft_limit; out->pool_bytes = ctx->pool_bytes; out->pinned_host_bytes = ctx->pinned_bytes;
+    for ( auto & kv : ctx->dev_free ) out->pool_free_bytes += kv.first * kv.second.size();
+    for ( auto & pf : ctx->pending_free ) out->pool_pending_bytes += pf.bytes;
+    if ( ctx->cur_slab ) out->pool_free_bytes += kSlabBytes - ctx->slab_used;
   }
   out->heap_mapped_bytes = T.heap_mapped; out->heap_limit_bytes = T.heap_va;
   out->heap_used_bytes = static_cast<uint64_t>( std::max<int64_t>( 0, T.chunks_committed ) ) * kChunkBytesHeap;
@@ -1139,6 +1142,7 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
   out->compute_units = static_cast<uint32_t>( T.n_cus );
   if ( T.ready ) {
     if ( aa_status st = tok_refresh_mirror( ctx ) ) return st;
+    out->heap_free_chunks = T.mirror_host->pool_avail; out->lanes_starved = T.mirror_host->pool_starving;
     uint32_t alive = 0;
     for ( int g = 0; g < aa_ctx::Tok::kSlots; g++ ) alive += T.slot[g].launched - T.mirror_host->exited[g];
     out->token_workgroups_alive = alive;
@@ -1804,7 +1808,9 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
   for ( int i = 0; i < n; i++ ) if ( aa_status st = aa_stream_upload( streams[i] ) ) return st;
   // coefficient chunks of the frames released since the last call go back to the pool (behind the kernels that read them:
   // those were queued before the release)
-  { std::lock_guard<std::mutex> g( ctx->pool_mu ); flush_chunk_frees( ctx ); }
+  // ... and what was released since then gets its epoch now: reusable as soon as the kernels queued before this call have run
+  // (not whenever some later allocation happens to miss its free list)
+  { std::lock_guard<std::mutex> g( ctx->pool_mu ); collect_pending( ctx, false ); }
   for ( int i = 0; i < n; i++ ) {
     if ( streams[i]->frames[frame_index[i]].records_released ) return fail( AA_ERR_LOGIC, "aa_decode_batch: frame records were released" );
     if ( aa_status st = resolve_summary( streams[i], streams[i]->frames[frame_index[i]] ) ) return st;

@@ -350,8 +350,10 @@ AA_HD inline void zero_slot( AA_GLOBAL int16_t * block )
 AA_HD inline uint32_t pool_take( const Heap & H )
 {
   // claim first (the semaphore counts published entries), then draw the ticket: a ticket is only ever drawn for an entry
-  // that is there.  The acquire pairs with the producers' release: the entry's value is visible.
-  const int32_t old = AA_AT_ADD_ACQ( &H.pool->avail, -1 );
+  // that is there.  No acquire fence: the entry is read with an agent-scope atomic load (it comes from the coherence point,
+  // where the producer's atomic store landed before it raised the semaphore), and the chunk itself is only ever WRITTEN by
+  // this lane -- an acquire here would invalidate the CU's vector cache, and the XCD's L2 lines, once per 64 KB per lane.
+  const int32_t old = AA_AT_ADD( &H.pool->avail, -1 );
   if ( old <= 0 ) { AA_AT_ADD( &H.pool->avail, 1 ); return kNoChunk; }
   const uint32_t t = AA_AT_ADD( &H.pool->head, 1u );
   return AA_AT_LOAD( &H.ring[t & H.pool->mask] );

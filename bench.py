@@ -77,6 +77,7 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-device-half", action="store_true")
     ap.add_argument("--profile-timed", action="store_true", help="HIP-event timing of every kernel INSIDE the timed region too (diagnostics)")
+    ap.add_argument("--trace-memory", action="store_true", help="print the context's memory books after every step of the timed region (stderr)")
     ap.add_argument("--small-batches", default="1,8,64", help="stream counts for the small-batch end-to-end figures ('' = skip)")
     return ap.parse_args()
 
@@ -236,6 +237,11 @@ def main():
                 self.t_release += time.perf_counter() - t1
             self.decoded += 1
             self.done_t.append(time.perf_counter())
+            if args.trace_memory:
+                i = ctx.info()
+                print("step %d: pool %.1f GB (free %.1f, pending %.1f) heap mapped %.1f used %.1f GB free chunks %d starved %d alive wgs %d waiting %d"
+                      % (self.decoded, i["pool_bytes"] / 1e9, i["pool_free_bytes"] / 1e9, i["pool_pending_bytes"] / 1e9, i["heap_mapped_bytes"] / 1e9,
+                         i["heap_used_bytes"] / 1e9, i["heap_free_chunks"], i["lanes_starved"], i["token_workgroups_alive"], i["jobs_waiting"]), file=sys.stderr, flush=True)
 
         def run(self, steps):
             """`steps` whole steps, from an empty pipeline to an empty pipeline."""

@@ -160,6 +160,8 @@ aa_status aa_ctx_set_memory_limit( aa_ctx * ctx, size_t bytes );
 typedef struct aa_ctx_info {
   uint64_t memory_limit_bytes;       /* aa_ctx_set_memory_limit */
   uint64_t pool_bytes;               /* HBM taken for frame records, rasters, batch arenas (slabs, recycled) */
+  uint64_t pool_free_bytes;          /* ... of which in the free lists right now */
+  uint64_t pool_pending_bytes;       /* ... of which released but possibly still read by queued kernels */
   uint64_t heap_mapped_bytes;        /* HBM mapped into the coefficient heap of the device parser */
   uint64_t heap_limit_bytes;         /* its virtual size */
   uint64_t heap_used_bytes;          /* chunks frames hold or are expected to take */
@@ -169,6 +171,8 @@ typedef struct aa_ctx_info {
   uint32_t token_lane_lds_bytes, token_workgroup_lds_bytes;
   uint32_t jobs_waiting;             /* frames in the token workers' queue that no lane has taken */
   uint32_t compute_units;
+  int32_t heap_free_chunks;          /* 64-KB chunks in the coefficient pool */
+  uint32_t lanes_starved;            /* times a token lane found the pool empty (since the context was created) */
 } aa_ctx_info;
 aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out );
 /* hipStream_t handles as opaque pointers (to order foreign work, e.g. an RCCL broadcast, against ours) */
