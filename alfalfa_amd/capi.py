@@ -59,7 +59,7 @@ class CtxInfo(C.Structure):
                                           "pinned_host_bytes")] + [
         (n, C.c_uint32) for n in ("heap_is_virtual", "token_lanes_per_workgroup", "token_workgroups_capacity", "token_workgroups_alive",
                                   "token_lane_lds_bytes", "token_workgroup_lds_bytes", "jobs_waiting", "compute_units")] + [
-        ("heap_free_chunks", C.c_int32), ("lanes_starved", C.c_uint32)]
+        ("heap_free_chunks", C.c_int32), ("lanes_starved", C.c_uint32), ("token_profile", C.c_uint64 * 8)]
 
 
 class AlfalfaError(RuntimeError):

@@ -60,6 +60,9 @@ struct aa_tok_mirror {
   int32_t pool_avail;
   uint32_t pool_starving;
   uint32_t exited[AA_MAX_WORKER_GRIDS];
+  // diagnostics (ALFALFA_AMD_TOKEN_PROFILE=1), summed over the waves that have left, 100 MHz ticks: [0] boundary passes [1] their
+  // number [2] wave steps [3] looking for / starting frames [4] ring top-ups [5] periods [6] lane-periods with a frame [7] periods
+  unsigned long long prof[8];
 };
 
 // kernels.hip / parse_kernels.hip launchers (plain C++ signatures so runtime.cpp needs no HIP kernel syntax)
@@ -74,11 +77,11 @@ int launch_segment_fixup( const ParseJob * jobs, const aa_seg_stream * streams, 
 // token workers (tok_fsm.hh, parse_kernels.hip): lanes that take frames from a queue in HBM
 void token_worker_shape( uint32_t lane_bytes, int n_cus, int * lanes_out, uint32_t * lds_out, int * wgs_per_cu_out );
 int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap & heap, uint32_t * exited, const uint32_t * retire, uint32_t gen, uint32_t spread,
-                          int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, void * stream );
+                          unsigned long long * prof, int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, void * stream );
 int launch_enqueue_jobs( TokQueue * q, unsigned long long * slots, const ParseJob * jobs, const uint32_t * order, int n, void * stream );
 int launch_pool_push_range( const Heap & heap, uint32_t first, uint32_t count, void * stream );
 int launch_pool_free_lists( const Heap & heap, const uint32_t * const * lists, int n, void * stream );
-int launch_mirror_counters( const TokQueue * q, const CoeffPool * pool, const uint32_t * exited, int n_grids, aa_tok_mirror * out, uint32_t seq, void * stream );
+int launch_mirror_counters( const TokQueue * q, const CoeffPool * pool, const uint32_t * exited, int n_grids, const unsigned long long * prof, aa_tok_mirror * out, uint32_t seq, void * stream );
 // whole-vector inter macroblocks, four per wave
 int launch_recon_inter4( const aa_frame_list & list, int n, unsigned max_mbs, void * stream );
 // one inter macroblock per wave; split_only: only SPLITMV macroblocks (the rest is launch_recon_inter4's)

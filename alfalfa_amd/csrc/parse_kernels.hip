@@ -89,17 +89,22 @@ struct WorkerArgs {
   const uint32_t * retire;                // grids of this slot up to generation *retire take no new jobs (pinned host memory, mapped)
   uint32_t gen;                           // this grid's generation
   uint32_t spread;                        // workgroups the GPU holds: a wave takes its share of a short queue, not all it can carry
+  unsigned long long * prof;              // diagnostics (null: off): 8 counters summed over the waves of all grids, see aa_tok_mirror::prof
   int lanes;
   uint32_t lane_bytes;
 };
 
-// up to `want` tickets for this wave (called by ONE lane): -> first ticket in *base, how many as the result.  When the queue
-// is short the wave takes only its share (queue length / workgroups the GPU holds, rounded up): a wave steps faster the
-// fewer lanes it carries, and the other workgroups -- alive or about to start -- look at the same queue.
+// up to `want` tickets for this wave (called by ONE lane): -> first ticket in *base, how many as the result; 0 = the queue is
+// EMPTY (nothing published that is not taken).  Losing the compare-and-swap to another wave is not "empty": hundreds of waves
+// look at the same word when a grid starts, and a wave that gave up then would leave with the queue full (round 3, first
+// version: ~80 of 1024 workgroups survived their first look, the GPU ran at 8 % of its lanes).  So: retry until taken or empty,
+// backing off by a wave-dependent number of cycles.
+// When the queue is short the wave takes only its share (queue length / workgroups the GPU holds, rounded up): a wave steps
+// faster the fewer lanes it carries, and the other workgroups -- alive or about to start -- look at the same queue.
 __device__ inline uint32_t queue_take( aa::TokQueue * q, uint32_t want, uint32_t spread, uint32_t * base )
 {
   uint32_t h = AA_AT_LOAD( &q->head );
-  for ( int tries = 0; tries < 16; tries++ ) {
+  for ( uint32_t tries = 0; ; tries++ ) {
     const uint32_t avail = AA_AT_LOAD( &q->publish ) - h;
     if ( static_cast<int32_t>( avail ) <= 0 ) return 0;
     const uint32_t share = ( avail + spread - 1u ) / spread;
@@ -107,8 +112,11 @@ __device__ inline uint32_t queue_take( aa::TokQueue * q, uint32_t want, uint32_t
     uint32_t expect = h;
     if ( __hip_atomic_compare_exchange_strong( &q->head, &expect, h + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) { *base = h; return n; }
     h = expect;
+    // lost: somebody else moved the head.  Wait a little before the next try, differently per workgroup and per try
+    const uint32_t r = ( blockIdx.x * 2654435761u + tries * 40503u ) >> 27;       // 0..31
+    for ( uint32_t k = 0; k <= ( r & ( tries < 4 ? 3u : tries < 8 ? 15u : 31u ) ); k++ ) __builtin_amdgcn_s_sleep( 16 );
+    if ( tries > 2048 ) h = AA_AT_LOAD( &q->head );
   }
-  return 0;                               // (contended: the next period tries again)
 }
 
 __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
@@ -125,7 +133,12 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
   L.steps = 0;
   const bool is_lane = lane < a.lanes;
   uint32_t backoff = 0;
+  // diagnostics: where a wave's time goes (100 MHz ticks): [0] boundary passes [1] their number [2] steps [3] looking for / starting
+  // frames [4] ring top-ups [5] periods (hot loops + boundary passes) [6] lane-periods with a frame [7] periods
+  unsigned long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  const bool profiling = a.prof != nullptr;
   for ( ;; ) {
+    const unsigned long long t_a = profiling ? wall_clock64() : 0ull;
     const bool idle = is_lane && L.rec == aa::tok::R_DONE;
     const unsigned long long idle_mask = __ballot( idle );
     bool looked = false, retired = false;
@@ -163,10 +176,20 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
       backoff = 0;
       continue;
     }
+    const unsigned long long t_b = profiling ? wall_clock64() : 0ull;
     if ( active ) aa::tok::top_up( L, smem, F );
-    aa::tok::run_period( L, smem, F, a.heap );
+    const unsigned long long t_c = profiling ? wall_clock64() : 0ull;
+    aa::tok::run_period( L, smem, F, a.heap, profiling ? prof : nullptr );
+    if ( profiling ) {
+      const unsigned long long t_d = wall_clock64();
+      prof[3] += t_b - t_a; prof[4] += t_c - t_b; prof[5] += t_d - t_c;
+      prof[6] += static_cast<unsigned long long>( __popcll( __ballot( active ) ) ); prof[7]++;
+    }
   }
-  if ( lane == 0 ) AA_AT_ADD( a.exited, 1u );
+  if ( lane == 0 ) {
+    if ( profiling ) for ( int k = 0; k < 8; k++ ) __hip_atomic_fetch_add( &a.prof[k], prof[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    AA_AT_ADD( a.exited, 1u );
+  }
 }
 
 // jobs[order[i]] -> the queue, in this order (longest chains first).  Frames the host pre-pass rejected (nmb == 0) go in too:
@@ -228,9 +251,10 @@ __global__ __launch_bounds__( 64 ) void k_pool_free_lists( aa::Heap heap, const 
   pool_push_wave( heap, l ? l + 1 : nullptr, 0, l ? l[0] : 0u );
 }
 // the counters the host steers by, gathered by ONE thread into pinned host memory (a single writer: no torn or reordered view)
-__global__ void k_mirror_counters( const aa::TokQueue * q, const aa::CoeffPool * pool, const uint32_t * exited, int n_grids, aa_tok_mirror * out, uint32_t seq )
+__global__ void k_mirror_counters( const aa::TokQueue * q, const aa::CoeffPool * pool, const uint32_t * exited, int n_grids, const unsigned long long * prof, aa_tok_mirror * out, uint32_t seq )
 {
   if ( threadIdx.x || blockIdx.x ) return;
+  if ( prof ) for ( int k = 0; k < 8; k++ ) out->prof[k] = AA_AT_LOAD( &prof[k] );
   out->q_head = AA_AT_LOAD( &q->head ); out->q_publish = AA_AT_LOAD( &q->publish ); out->q_reserve = AA_AT_LOAD( &q->reserve );
   if ( pool ) { out->pool_avail = AA_AT_LOAD( &pool->avail ); out->pool_starving = AA_AT_LOAD( &pool->starving ); }
   for ( int g = 0; g < n_grids; g++ ) out->exited[g] = AA_AT_LOAD( &exited[g] );
@@ -314,11 +338,11 @@ void token_worker_shape( uint32_t lane_bytes, int n_cus, int * lanes_out, uint32
 }
 
 int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap & heap, uint32_t * exited, const uint32_t * retire, uint32_t gen, uint32_t spread,
-                          int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, void * stream )
+                          unsigned long long * prof, int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, void * stream )
 {
   if ( lanes < 1 || wgs < 1 ) return static_cast<int>( hipErrorInvalidValue );
   WorkerArgs a;
-  a.q = q; a.slots = slots; a.heap = heap; a.exited = exited; a.retire = retire; a.gen = gen; a.spread = spread ? spread : 1u; a.lanes = lanes; a.lane_bytes = lane_bytes;
+  a.q = q; a.slots = slots; a.heap = heap; a.exited = exited; a.retire = retire; a.gen = gen; a.spread = spread ? spread : 1u; a.prof = prof; a.lanes = lanes; a.lane_bytes = lane_bytes;
   hipLaunchKernelGGL( k_token_workers, dim3( wgs ), dim3( 64 ), lds, static_cast<hipStream_t>( stream ), a );
   return static_cast<int>( hipGetLastError() );
 }
@@ -347,9 +371,9 @@ int launch_pool_free_lists( const Heap & heap, const uint32_t * const * lists, i
   return 0;
 }
 
-int launch_mirror_counters( const TokQueue * q, const CoeffPool * pool, const uint32_t * exited, int n_grids, aa_tok_mirror * out, uint32_t seq, void * stream )
+int launch_mirror_counters( const TokQueue * q, const CoeffPool * pool, const uint32_t * exited, int n_grids, const unsigned long long * prof, aa_tok_mirror * out, uint32_t seq, void * stream )
 {
-  hipLaunchKernelGGL( k_mirror_counters, dim3( 1 ), dim3( 64 ), 0, static_cast<hipStream_t>( stream ), q, pool, exited, n_grids, out, seq );
+  hipLaunchKernelGGL( k_mirror_counters, dim3( 1 ), dim3( 64 ), 0, static_cast<hipStream_t>( stream ), q, pool, exited, n_grids, prof, out, seq );
   return static_cast<int>( hipGetLastError() );
 }
 

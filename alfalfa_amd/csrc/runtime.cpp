@@ -115,6 +115,7 @@ struct FrameRec {
   bool summary_pending = false;            // counts (intra macroblocks, coefficient blocks, SPLITMV) not yet read back from the device parser
   uint8_t * rec_block = nullptr;           // device-parsed frame: macroblock records, intra row masks, flags, chunk list in HBM
   size_t rec_bytes = 0;
+  bool rec_in_arena = false;               // ... inside the device half of its batch's arena (freed with the batch)
   const uint32_t * chunk_list = nullptr;   // ... the list of coefficient chunks its token lane took (in rec_block; [0] = count)
   volatile aa::FrameSummary * summary = nullptr;   // in the batch's pinned arena: the token lane's last word lands here
   const aa::ParseJob * parse_job = nullptr;        // in the batch's device arena
@@ -144,7 +145,10 @@ struct aa_ctx {
   // one on the same stream starts that much later.  Hence one stream per batch that can be in flight, and a batch goes to a
   // stream that has nothing queued (pick_parse_stream).
   static constexpr int kMaxParseStreams = 20;
-  int n_parse_streams = 12;             // + compute + copy: within the 16 hardware queues asked for above
+  // Hardware queues are few (16 asked for above) and a queue runs its commands in order: a stream that shares a queue with a
+  // worker grid -- which stays for as long as there is work -- would not get a kernel started until that grid leaves.  So the
+  // context keeps to 11 streams: compute, copy, utility, 4 header-parse streams (short kernels now), 4 worker streams.
+  int n_parse_streams = 4;
   std::vector<hipStream_t> parse_streams;
   std::vector<hipEvent_t> parse_idle;    // recorded behind the last operation queued on the stream
   int prio_low = 0;
@@ -174,9 +178,10 @@ struct aa_ctx {
     uint32_t seen_starving = 0;
     std::vector<const uint32_t *> pending_lists;   // chunk lists of released frames, not yet handed to k_pool_free_lists
     // worker grids: slot g = worker stream g; counters are cumulative over the grids a slot has run
-    static constexpr int kSlots = 6;
+    static constexpr int kSlots = 4;
     struct Slot { hipStream_t st = nullptr; uint32_t launched = 0, gen = 0; bool queued_behind_retiring = false; } slot[kSlots];
     uint32_t * exited_dev = nullptr;     // [AA_MAX_WORKER_GRIDS] in HBM
+    unsigned long long * prof_dev = nullptr;   // diagnostics counters (ALFALFA_AMD_TOKEN_PROFILE=1), else null
     uint32_t * retire_host = nullptr, * retire_dev = nullptr;     // [AA_MAX_WORKER_GRIDS]: grids of generation <= this take no more jobs
     aa_tok_mirror * mirror_host = nullptr, * mirror_dev = nullptr;
     uint32_t mirror_seq = 0;
@@ -471,7 +476,7 @@ aa_status tok_refresh_mirror( aa_ctx * ctx )
 {
   auto & T = ctx->tok;
   T.mirror_seq++;
-  if ( int e = aa::launch_mirror_counters( T.q, T.pool, T.exited_dev, aa_ctx::Tok::kSlots, T.mirror_dev, T.mirror_seq, T.util ) )
+  if ( int e = aa::launch_mirror_counters( T.q, T.pool, T.exited_dev, aa_ctx::Tok::kSlots, T.prof_dev, T.mirror_dev, T.mirror_seq, T.util ) )
     return hip_fail( static_cast<hipError_t>( e ), "k_mirror_counters" );
   HIP_TRY( hipStreamSynchronize( T.util ) );
   return AA_OK;
@@ -521,6 +526,10 @@ aa_status tok_init( aa_ctx * ctx )
   HIP_TRY( hipMemset( T.one_dev, 0, 256 ) );
   HIP_TRY( hipMalloc( reinterpret_cast<void **>( &T.exited_dev ), sizeof( uint32_t ) * AA_MAX_WORKER_GRIDS ) );
   HIP_TRY( hipMemset( T.exited_dev, 0, sizeof( uint32_t ) * AA_MAX_WORKER_GRIDS ) );
+  if ( const char * e = std::getenv( "ALFALFA_AMD_TOKEN_PROFILE" ) ) if ( atoi( e ) ) {
+    HIP_TRY( hipMalloc( reinterpret_cast<void **>( &T.prof_dev ), 64 ) );
+    HIP_TRY( hipMemset( T.prof_dev, 0, 64 ) );
+  }
   HIP_TRY( hipHostMalloc( reinterpret_cast<void **>( &T.retire_host ), sizeof( uint32_t ) * AA_MAX_WORKER_GRIDS, hipHostMallocDefault ) );
   std::memset( T.retire_host, 0, sizeof( uint32_t ) * AA_MAX_WORKER_GRIDS );
   HIP_TRY( hipHostGetDevicePointer( reinterpret_cast<void **>( &T.retire_dev ), T.retire_host, 0 ) );
@@ -537,7 +546,9 @@ aa_status tok_init( aa_ctx * ctx )
   const char * no_vmm = std::getenv( "ALFALFA_AMD_NO_VMM" );
   if ( !( no_vmm && atoi( no_vmm ) ) ) {
     void * va = nullptr;
-    if ( hipMemAddressReserve( &va, T.heap_limit, 0, nullptr, 0 ) == hipSuccess && va ) { T.heap = static_cast<uint8_t *>( va ); T.heap_va = T.heap_limit; T.vmm = true; }
+    size_t va_align = 0;
+    if ( const char * e = std::getenv( "ALFALFA_AMD_HEAP_VA_ALIGN_MB" ) ) va_align = static_cast<size_t>( atoi( e ) ) << 20;     // (experiments)
+    if ( hipMemAddressReserve( &va, T.heap_limit, va_align, nullptr, 0 ) == hipSuccess && va ) { T.heap = static_cast<uint8_t *>( va ); T.heap_va = T.heap_limit; T.vmm = true; }
     else (void) hipGetLastError();
   }
   if ( !T.vmm ) {
@@ -578,6 +589,7 @@ void tok_free( aa_ctx * ctx )
   if ( T.slots ) (void) hipFree( T.slots );
   if ( T.one_dev ) (void) hipFree( T.one_dev );
   if ( T.exited_dev ) (void) hipFree( T.exited_dev );
+  if ( T.prof_dev ) (void) hipFree( T.prof_dev );
   if ( T.retire_host ) (void) hipHostFree( T.retire_host );
   if ( T.mirror_host ) (void) hipHostFree( T.mirror_host );
   T = aa_ctx::Tok {};
@@ -617,7 +629,7 @@ aa_status tok_launch_workers( aa_ctx * ctx, hipEvent_t after )
   sl.gen++;
   if ( after ) HIP_TRY( hipStreamWaitEvent( sl.st, after, 0 ) );
   LaunchTimer timer( ctx, 4, sl.st );
-  if ( int e = aa::launch_token_workers( T.q, T.slots, heap_of( ctx ), T.exited_dev + g, T.retire_dev + g, sl.gen, static_cast<uint32_t>( T.cap_wgs ), want, T.lanes, T.lane_bytes, T.lds, sl.st ) )
+  if ( int e = aa::launch_token_workers( T.q, T.slots, heap_of( ctx ), T.exited_dev + g, T.retire_dev + g, sl.gen, static_cast<uint32_t>( T.cap_wgs ), T.prof_dev, want, T.lanes, T.lane_bytes, T.lds, sl.st ) )
     return hip_fail( static_cast<hipError_t>( e ), "k_token_workers" );
   sl.launched += static_cast<uint32_t>( want );
   ctx->stats.worker_launches++; ctx->stats.worker_wgs += static_cast<uint64_t>( want );
@@ -687,9 +699,9 @@ void tok_prune_inflight( aa_ctx * ctx )
   v.resize( keep );
 }
 
-// The slice of LDS a token lane needs depends only on whether frames have several DCT partitions (the saved decoders of the
-// other partitions).  Grids with the smaller slice cannot run such frames, so the size only ever grows -- and before it does,
-// the queue is drained and the grids are gone.
+// The slice of LDS a token lane needs depends on the widest frame (its above-row flags) and on whether frames have several DCT
+// partitions.  Grids with smaller slices cannot run such frames, so the size only ever grows -- and before it does, the queue
+// is drained and the grids are gone.
 aa_status tok_set_lane_bytes( aa_ctx * ctx, uint32_t need )
 {
   auto & T = ctx->tok;
@@ -733,7 +745,7 @@ void release_records( aa_stream * s, FrameRec & f, bool deferred )
     // record block: the block itself is recycled only behind that kernel (always through an epoch, never at once)
     const bool has_chunks = parsed && f.chunk_list && !f.chunks_returned;
     if ( has_chunks ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->tok.pending_lists.push_back( f.chunk_list ); }
-    dev_free( ctx, f.rec_block, f.rec_bytes, deferred || has_chunks );
+    if ( !f.rec_in_arena ) dev_free( ctx, f.rec_block, f.rec_bytes, deferred || has_chunks );
     f.rec_block = nullptr; f.chunk_list = nullptr;
     ctx->tok.chunks_committed -= f.est_chunks; f.est_chunks = 0;
   }
@@ -746,7 +758,7 @@ void release_records( aa_stream * s, FrameRec & f, bool deferred )
       ctx->tok.inflight.erase( std::remove( ctx->tok.inflight.begin(), ctx->tok.inflight.end(), b ), ctx->tok.inflight.end() );
       if ( b->hdr_done ) { (void) hipEventSynchronize( b->hdr_done ); (void) hipEventDestroy( b->hdr_done ); }   // never forgotten while kernels still read the arena
       { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); }
-      dev_free( ctx, b->dev, b->dev_bytes, deferred );
+      dev_free( ctx, b->dev, b->dev_bytes, true );        // (always through an epoch: the chunk lists of its frames are read out of it on the device)
       delete b;
     }
     f.batch = nullptr; f.summary = nullptr; f.parse_job = nullptr;
@@ -1143,6 +1155,7 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
   if ( T.ready ) {
     if ( aa_status st = tok_refresh_mirror( ctx ) ) return st;
     out->heap_free_chunks = T.mirror_host->pool_avail; out->lanes_starved = T.mirror_host->pool_starving;
+    for ( int k = 0; k < 8; k++ ) out->token_profile[k] = T.mirror_host->prof[k];
     uint32_t alive = 0;
     for ( int g = 0; g < aa_ctx::Tok::kSlots; g++ ) alive += T.slot[g].launched - T.mirror_host->exited[g];
     out->token_workgroups_alive = alive;
@@ -1339,6 +1352,7 @@ namespace {
 struct SubmitItem {
   aa_stream * s; const uint8_t * data; size_t size;
   size_t data_off;          // in the batch arena
+  size_t rec_off = 0;       // the frame's record block, in the device half of the arena only
   aa_status status = AA_OK; std::string error;
   int frame_index = -1;
   bool seg_enabled = false, seg_reset = false;
@@ -1363,9 +1377,8 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
   const uint32_t flags_padded = ( nmb + 15u ) & ~15u;
   const size_t flags_bytes = align_up( flags_padded );
   const size_t list_bytes = align_up( size_t( aa::chunk_list_entries( nmb ) ) * sizeof( uint32_t ) );
-  const size_t above_bytes = align_up( size_t( aa::tok::above_entries( J.fp.mbw ) ) * sizeof( uint16_t ) );
-  rec.rec_bytes = mb_bytes + rows_bytes + flags_bytes + list_bytes + above_bytes;
-  if ( aa_status st = dev_alloc( ctx, rec.rec_bytes, &rec.rec_block ) ) { it.error = g_last_error; return st; }
+  rec.rec_bytes = mb_bytes + rows_bytes + flags_bytes + list_bytes;
+  rec.rec_block = b->dev + it.rec_off; rec.rec_in_arena = true;
   uint8_t * blk = rec.rec_block;
 
   J.data = b->dev + it.data_off;
@@ -1375,7 +1388,6 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
   J.intra_rows = reinterpret_cast<unsigned long long *>( blk + mb_bytes );
   J.mbflags = blk + mb_bytes + rows_bytes;
   J.chunk_list = reinterpret_cast<uint32_t *>( blk + mb_bytes + rows_bytes + flags_bytes );
-  J.above = reinterpret_cast<uint16_t *>( blk + mb_bytes + rows_bytes + flags_bytes + list_bytes );
   J.summary = reinterpret_cast<aa::FrameSummary *>( b->host_dev + b->summaries_off ) + item;     // pinned + mapped: no copy back
   rec.chunk_list = J.chunk_list;
   rec.summary = reinterpret_cast<volatile aa::FrameSummary *>( b->host + b->summaries_off ) + item;
@@ -1486,10 +1498,23 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
 
   std::unique_ptr<Batch> b( new Batch );
   const size_t arena = ( off + ( size_t( 16 ) << 20 ) - 1 ) & ~( ( size_t( 16 ) << 20 ) - 1 );
+  // The frames' record blocks (macroblock records, flags, chunk list: written by the parse kernels only) sit behind the mirrored
+  // part in the DEVICE half of the arena: one piece of the pool per call instead of one per frame (thousands of allocator
+  // round trips per call); they go back when the last frame of the call is released.
+  size_t dev_arena = arena;
+  for ( int i = 0; i < n; i++ ) {
+    const aa_stream * s = frames[i].stream;
+    const size_t nmb = size_t( s->parser.mb_width() ) * s->parser.mb_height();
+    const size_t words_per_row = ( s->parser.mb_width() + 63 ) / 64;
+    items[i].rec_off = dev_arena;
+    dev_arena += align_up( nmb * sizeof( aa_mb_info ) ) + align_up( words_per_row * s->parser.mb_height() * sizeof( unsigned long long ) )
+                 + align_up( ( nmb + 15u ) & ~size_t( 15 ) ) + align_up( size_t( aa::chunk_list_entries( static_cast<uint32_t>( nmb ) ) ) * sizeof( uint32_t ) );
+  }
+  dev_arena = ( dev_arena + ( size_t( 16 ) << 20 ) - 1 ) & ~( ( size_t( 16 ) << 20 ) - 1 );
   b->host = pinned_get( ctx, arena, &b->host_bytes );
   if ( !b->host ) return fail( AA_ERR_HIP, "aa_submit_frames: pinned staging allocation failed" );
-  b->dev_bytes = arena;
-  if ( aa_status st = dev_alloc( ctx, arena, &b->dev ) ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); return st; }
+  b->dev_bytes = dev_arena;
+  if ( aa_status st = dev_alloc( ctx, dev_arena, &b->dev ) ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); return st; }
   b->n = n; b->summaries_off = jobs_bytes + dframes_bytes;
   if ( hipError_t e = hipHostGetDevicePointer( reinterpret_cast<void **>( &b->host_dev ), b->host, 0 ) ) {
     { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); }
@@ -1560,7 +1585,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
     }
   } abandon { ctx, b.release() };
   Batch * const raw = abandon.b;
-  if ( aa_status st = tok_set_lane_bytes( ctx, aa::tok::lane_lds_bytes( max_nparts > 1 ) ) ) return st;
+  if ( aa_status st = tok_set_lane_bytes( ctx, aa::tok::lane_lds_bytes( static_cast<uint32_t>( max_mbw ), max_nparts > 1 ) ) ) return st;
 
   // ---- segment-map pass lists (only streams that use segmentation in this batch) ----
   aa_seg_stream * seg_streams = reinterpret_cast<aa_seg_stream *>( raw->host + jobs_bytes + dframes_bytes + sums_bytes );

@@ -128,7 +128,6 @@ struct alignas( 16 ) ParseJob {
   uint32_t nmb, flags_padded;   // flags_padded: multiple of 16, >= nmb
   aa_mb_info * mbs;
   uint32_t * chunk_list;        // [chunk_list_entries( nmb )]: [0] = how many coefficient chunks the frame took, then their numbers
-  uint16_t * above;             // [above_entries( mbw )]: above-row non-zero flags per macroblock column (scratch of the token lane), 16-byte aligned
   unsigned long long * intra_rows;
   uint8_t * mbflags;            // [flags_padded]: INTER | HAS_Y2 | SKIP of every macroblock, header kernel -> token kernel
   FrameSummary * summary;
@@ -160,14 +159,14 @@ constexpr uint32_t kTablesBytes = 768;    // first lane slice
 constexpr uint32_t kProbs = 0;            // [4][8][3][11] token probabilities
 constexpr uint32_t kStream = 1056;        // stream ring
 constexpr uint32_t kMeta = kStream + kRing;
+constexpr uint32_t kAbove = kMeta + kMetaRing;  // uint16 per macroblock column: the above-row non-zero flags
 // then, only for frames with more than one token partition: 8 saved partition decoders x 16 bytes
-constexpr uint32_t kPartSave = kMeta + kMetaRing;
-AA_HD constexpr uint32_t lane_lds_bytes( bool multi_partition ) { return kPartSave + ( multi_partition ? 128u : 0u ); }
-// The above-row non-zero flags (9 bits per macroblock column, read once and written once per macroblock) are NOT in the
-// slice: they live in HBM beside the frame's records (ParseJob::above) and a lane keeps the eight columns it is passing in
-// registers, the next eight on their way (240 bytes of LDS per lane at 1080p bought 15 % more chains per CU).
-constexpr uint32_t kAboveCols = 8;        // columns per 16-byte piece
-AA_HD constexpr uint32_t above_entries( uint32_t mbw ) { return ( mbw + 2 * kAboveCols - 1 ) / kAboveCols * kAboveCols; }   // padded: a prefetch never leaves the array
+AA_HD constexpr uint32_t part_off( uint32_t mbw ) { return ( kAbove + 2 * mbw + 15 ) & ~15u; }
+AA_HD constexpr uint32_t lane_lds_bytes( uint32_t mbw, bool multi_partition ) { return part_off( mbw ) + ( multi_partition ? 128u : 0u ); }
+// (The flags were tried in HBM -- 240 bytes of LDS per lane at 1080p would buy 15 % more chains per CU --, the lane keeping the
+// eight columns it passes in registers.  Measured on MI355X, round 3: every use of those registers costs the wave an
+// s_waitcnt vmcnt(0), i.e. a drain of ALL its outstanding coefficient stores at every macroblock boundary of every lane;
+// steps went from 0.30 to 1.8 us with 26 lanes per wave.  The step must never wait for HBM: the flags stay in LDS.)
 
 // dct_cat probabilities (tokens.cc:36-48) laid out back to back: cat1 @0, cat2 @1, cat3 @3, cat4 @6, cat5 @10, cat6 @15, sign @26
 constexpr uint8_t kXtabInit[27] = { 159, 165, 145, 173, 148, 140, 176, 155, 140, 135, 180, 157, 141, 134, 130,
@@ -259,7 +258,6 @@ struct Frame {
   const AA_GLOBAL uint8_t * mbflags;
   AA_GLOBAL aa_mb_info * mbs;
   AA_GLOBAL uint32_t * chunk_list;
-  AA_GLOBAL uint16_t * above;
   uint32_t data_padded, flags_padded, nmb, mbw, nparts;
   uint32_t max_steps;           // no frame of this size can take more steps: a lane that gets there stops (never a hung GPU)
 };
@@ -269,7 +267,6 @@ AA_HD inline Frame frame_of( const ParseJob * job )
   F.job = (const AA_GLOBAL ParseJob *) job;
   F.data = (const AA_GLOBAL uint8_t *) job->data; F.mbflags = (const AA_GLOBAL uint8_t *) job->mbflags;
   F.mbs = (AA_GLOBAL aa_mb_info *) job->mbs; F.chunk_list = (AA_GLOBAL uint32_t *) job->chunk_list;
-  F.above = (AA_GLOBAL uint16_t *) job->above;
   // per macroblock at most 25 blocks x 16 tokens x (11 tree nodes + 11 extra bits + sign), plus boundary steps
   const uint64_t bound = static_cast<uint64_t>( job->nmb ) * ( 25u * 16u * 23u + 4u ) + 4096u;
   F.max_steps = bound > 0xFFFFFFF0ull ? 0xFFFFFFF0u : static_cast<uint32_t>( bound );
@@ -330,8 +327,6 @@ struct Lane {
   uint32_t blk_left;              // blocks left in the chunk being filled, the current one included (0: no chunk yet)
   uint32_t nchunks;               // chunks taken so far
   unsigned long long mem_since;   // waiting for a chunk since (0: not waiting)
-  Chunk16 abv, abv_nx;            // above-row flags of columns [abv_c0, abv_c0 + 8) and of the eight after them (in flight)
-  uint32_t abv_c0;
   // position
   uint32_t mi, col, row, part;
   uint32_t steps;
@@ -398,7 +393,7 @@ AA_HD inline void start_partition( Lane & L, uint8_t * smem, const Frame & J, ui
 
 AA_HD inline void switch_partition( Lane & L, uint8_t * smem, const Frame & J, uint32_t p )
 {
-  const uint32_t save = L.base + kPartSave;
+  const uint32_t save = L.base + part_off( J.mbw );
   uint32_t * s = reinterpret_cast<uint32_t *>( smem + save + 16 * L.part );
   s[0] = L.value; s[1] = L.range | ( static_cast<uint32_t>( L.sh + 64 ) << 8 ); s[2] = L.rpos; s[3] = 1;
   const uint32_t * t = reinterpret_cast<const uint32_t *>( smem + save + 16 * p );
@@ -489,29 +484,6 @@ AA_HD inline void setup_block( Lane & L, const uint8_t * smem, uint32_t blk )
 // The slow path, for lanes at a macroblock boundary (R_MBDONE: the step just completed one; R_MB: waiting for flags):
 // take macroblocks until one has tokens (skipped ones are settled on the spot), the flag ring runs dry (try again later)
 // or the frame ends.  Everything rare lives here: row ends, partition switches, the end of the frame.
-// The above-row flags of column L.col.  Row 0: zero.  Otherwise out of the 16-byte piece the lane holds: fetched at the start
-// of a row (the one wait per row: the flags were stored a row ago, by this lane), from then on the next piece is asked for as
-// the lane enters a piece -- eight macroblocks before it is needed.  (Stores go straight to HBM: a piece is only ever loaded
-// after every store of the row above has been issued by this same lane, and a wave's memory operations are in order.)
-AA_HD inline uint32_t above_flags( Lane & L, const Frame & J )
-{
-  if ( L.row == 0 ) return 0;
-  const uint32_t c0 = L.col & ~( kAboveCols - 1 );
-  if ( L.col == 0 ) {
-    L.abv = load16( reinterpret_cast<const AA_GLOBAL uint8_t *>( J.above ) );
-    L.abv_nx = load16( reinterpret_cast<const AA_GLOBAL uint8_t *>( J.above + kAboveCols ) );
-    L.abv_c0 = 0;
-  } else if ( c0 != L.abv_c0 ) {
-    L.abv = L.abv_nx;
-    L.abv_nx = load16( reinterpret_cast<const AA_GLOBAL uint8_t *>( J.above + c0 + kAboveCols ) );
-    L.abv_c0 = c0;
-  }
-  const uint32_t k = L.col - c0;
-  const uint32_t w01 = ( k & 2u ) ? L.abv.w[1] : L.abv.w[0], w23 = ( k & 2u ) ? L.abv.w[3] : L.abv.w[2];
-  const uint32_t w = ( k & 4u ) ? w23 : w01;
-  return ( w >> ( ( k & 1u ) * 16u ) ) & 0xFFFFu;
-}
-
 // The lane is through with its frame: counts to the host, the chunk list closed, then -- behind a release that makes every
 // record and coefficient this lane stored visible to the whole device -- the `done` word the host polls.
 AA_HD inline void finish_frame( Lane & L, const Frame & J, uint32_t status )
@@ -536,6 +508,7 @@ constexpr unsigned long long kMemWaitTicks = 200000000ull;      // 2 s of the 10
 
 AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J, const Heap & H )
 {
+  uint16_t * const above = reinterpret_cast<uint16_t *>( smem + L.base + kAbove );
   if ( L.rec == R_MBDONE ) { L.mi++; L.col++; L.rec = R_MB; }
   if ( L.steps > J.max_steps ) {             // cannot happen for any input; if it does the frame is reported, not hung on
     finish_frame( L, J, TOK_STEP_BOUND );
@@ -553,7 +526,7 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
     }
     const uint32_t flags = smem[L.base + kMeta + ( L.mi & ( kMetaRing - 1 ) )];
     const uint32_t has_y2 = flags & AA_MB_HAS_Y2;
-    L.ctxbits = ( L.ctxbits & 0x01FF0000u ) | above_flags( L, J );
+    L.ctxbits = ( L.ctxbits & 0x01FF0000u ) | above[L.col];
     if ( !( flags & AA_MB_SKIP ) ) {
       if ( L.blk_left < kMbBlocks ) {                       // the chunk cannot take a whole macroblock: on to a new one
         const uint32_t c = pool_take( H );
@@ -582,7 +555,7 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
       return;
     }
     L.ctxbits &= has_y2 ? 0u : 0x01000100u;                 // a non-coded Y2 leaves its chain untouched (frame.cc:255-269)
-    J.above[L.col] = static_cast<uint16_t>( L.ctxbits );
+    above[L.col] = static_cast<uint16_t>( L.ctxbits );
     store_mb( J, L.mi, 0, L.blk_index, flags | ( has_y2 ? AA_MB_LF_SKIP_INNER : 0u ) );
     L.mi++; L.col++;
   }
@@ -648,7 +621,7 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
         if ( L.nonzero ) { L.coeff_blocks++; L.blk += 16; L.blk_index++; L.blk_left--; zero_slot( L.blk ); L.nz_mask |= L.blkbit; }
         const bool mbdone = L.blkaddr == kBlockTabOff + 8 * 25;
         if ( mbdone ) {                           // the macroblock is complete: its record, its column's flags
-          J.above[L.col] = static_cast<uint16_t>( ctxbits );
+          *lds_at<uint16_t>( smem, L.base + kAbove + 2 * L.col ) = static_cast<uint16_t>( ctxbits );
           uint32_t flags = L.flags;
           flags |= L.nz_mask ? AA_MB_HAS_NONZERO : ( ( flags & AA_MB_HAS_Y2 ) ? AA_MB_LF_SKIP_INNER : 0u );
           store_mb( J, L.mi, L.nz_mask, L.mb_first, flags );
@@ -671,17 +644,22 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
 }
 
 // One period of a wave: kPeriod steps, leaving the hot loop whenever a lane has reached a macroblock boundary.
-AA_HD inline void run_period( Lane & L, uint8_t * smem, const Frame & J, const Heap & H )
+// `prof` (diagnostics, may be null): [0] += clock ticks spent in boundary passes, [1] += boundary passes, [2] += steps of the wave
+AA_HD inline void run_period( Lane & L, uint8_t * smem, const Frame & J, const Heap & H, unsigned long long * prof = nullptr )
 {
   uint32_t it = 0;
   while ( it < kPeriod ) {
     if ( AA_ANY( at_boundary( L ) ) ) {
+      const unsigned long long tb = prof ? AA_NOW() : 0ull;
       if ( at_boundary( L ) ) macroblock_boundary( L, smem, J, H );
+      if ( prof ) { prof[0] += AA_NOW() - tb; prof[1]++; }
       it++;                                                 // (a lane waiting for flags must not spin the period away)
       if ( !AA_ANY( L.rec < R_MBDONE ) ) break;             // nobody has anything to decode
     }
     // leave the hot loop when a lane has completed a macroblock (asked by ALL lanes, outside the predicated step: wave-uniform)
+    const uint32_t it0 = it;
     do { step( L, smem, J ); it++; } while ( it < kPeriod && !AA_ANY( L.rec == R_MBDONE ) );
+    if ( prof ) prof[2] += it - it0;
   }
   if ( L.rec != R_DONE ) L.steps += it;                     // (an upper bound: the iterations a lane sat out count too)
 }
@@ -710,9 +688,8 @@ AA_HD inline void begin_frame( Lane & L, uint8_t * smem, uint32_t base, const Fr
   const AA_GLOBAL uint32_t * src = (const AA_GLOBAL uint32_t *) &J.job->fp.coeff_probs[0][0][0][0];
   uint32_t * dst = reinterpret_cast<uint32_t *>( lds + kProbs );
   for ( uint32_t k = 0; k < 1056 / 4; k++ ) dst[k] = src[k];
-  if ( J.nparts > 1 ) for ( uint32_t k = 0; k < 128 / 4; k++ ) reinterpret_cast<uint32_t *>( lds + kPartSave )[k] = 0;
-  L.abv_c0 = 0;
-  for ( uint32_t k = 0; k < 4; k++ ) L.abv.w[k] = L.abv_nx.w[k] = 0;      // row 0 has nothing above it
+  if ( J.nparts > 1 ) for ( uint32_t k = 0; k < 128 / 4; k++ ) reinterpret_cast<uint32_t *>( lds + part_off( J.mbw ) )[k] = 0;
+  for ( uint32_t k = 0; k < J.mbw; k++ ) reinterpret_cast<uint16_t *>( lds + kAbove )[k] = 0;
   L.mi = 0; L.col = 0; L.row = 0; L.ctxbits = 0; L.coeff_blocks = 0; L.steps = 0;
   L.flags = L.nz_mask = L.mb_first = L.yfirst = 0;
   L.idx = L.nonzero = L.nzsel = L.blkbit = L.mag = 0;

@@ -114,7 +114,9 @@ class Context:
         """What the context holds right now (aa_ctx_info): memory by kind, token-worker shape and occupancy."""
         st = capi.CtxInfo()
         capi.check(self.L.aa_ctx_get_info(self.h, C.byref(st)))
-        return {n: getattr(st, n) for n, _ in capi.CtxInfo._fields_}
+        d = {n: getattr(st, n) for n, _ in capi.CtxInfo._fields_}
+        d["token_profile"] = list(st.token_profile)
+        return d
 
     def set_schedule(self, name):
         """"rows" (default): row-pipelined persistent kernels; "diagonal": one launch per anti-diagonal."""

@@ -68,7 +68,7 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=480, help="independent streams per GPU")
     ap.add_argument("--frames", type=int, default=12, help="frames per stream per step")
     ap.add_argument("--key-ahead", type=int, default=12, help="steps by which KEY frames are handed to the GPU parser ahead of reconstruction (clamped to what the HBM budget holds)")
-    ap.add_argument("--depth", type=int, default=6, help="steps by which inter frames are handed to the GPU parser ahead of reconstruction (clamped likewise)")
+    ap.add_argument("--depth", type=int, default=8, help="steps by which inter frames are handed to the GPU parser ahead of reconstruction (clamped likewise)")
     ap.add_argument("--hbm-gb", type=float, default=150.0, help="HBM the decoder context may use on each GPU (aa_ctx_set_memory_limit); the look-ahead is planned inside it")
     ap.add_argument("--header-ahead", type=int, default=0, help="steps by which the macroblock-header pass of inter frames runs ahead of their token pass (two-phase submit)")
     ap.add_argument("--threads", type=int, default=0, help="host workers of the header pre-pass (0: cores / local ranks)")
@@ -243,19 +243,36 @@ def main():
                       % (self.decoded, i["pool_bytes"] / 1e9, i["pool_free_bytes"] / 1e9, i["pool_pending_bytes"] / 1e9, i["heap_mapped_bytes"] / 1e9,
                          i["heap_used_bytes"] / 1e9, i["heap_free_chunks"], i["lanes_starved"], i["token_workgroups_alive"], i["jobs_waiting"]), file=sys.stderr, flush=True)
 
+        def _room(self, nbytes):
+            """Is there room in the coefficient heap for frames expected to store `nbytes`?  (Frames in flight are on the context's
+            books with what they are expected to take, parsed ones with what they took.)  Never refuses when nothing is in
+            flight: then waiting would not free anything."""
+            if self.keys == self.decoded:
+                return True
+            i = ctx.info()
+            cap = min(i["heap_limit_bytes"], i["memory_limit_bytes"] - i["pool_bytes"]) if i["heap_limit_bytes"] else i["memory_limit_bytes"] - i["pool_bytes"]
+            return i["heap_used_bytes"] + nbytes <= 0.97 * cap
+
         def run(self, steps):
-            """`steps` whole steps, from an empty pipeline to an empty pipeline."""
+            """`steps` whole steps, from an empty pipeline to an empty pipeline.  Frames go to the GPU parser in the order they
+            are needed, as far ahead as the look-ahead says AND the HBM budget holds: key frames up to K steps before their
+            group is reconstructed (their chains are the long ones), inter frames up to D steps."""
             target = self.decoded + steps
             while self.decoded < target:
                 while True:
-                    # inter frames in two phases (optional): header pre-pass + upload + macroblock-header kernel H steps before
-                    # the frames go to the token workers' queue
-                    if self.keys < min(target, self.decoded + self.K):
-                        self._submit_keys(self.keys); self.keys += 1
-                    elif self.inter_h < min(target, self.decoded + self.D + self.H, self.keys):
+                    can_inter = self.inter_h < min(target, self.decoded + self.D + self.H, self.keys)
+                    can_key = self.keys < min(target, self.decoded + self.K)
+                    # the group about to be reconstructed comes first; otherwise key frames lead (K - D steps ahead of the inter frames)
+                    if can_inter and (self.inter_h == self.decoded or not can_key or self.keys - self.inter_h > self.K - self.D):
+                        if not self._room(self.n * (F - 1) * inter_bytes):
+                            break
                         self._submit_inters(self.inter_h, defer_tokens=self.H > 0); self.inter_h += 1
                         if self.H == 0:
                             self.inters += 1
+                    elif can_key:
+                        if not self._room(self.n * key_bytes):
+                            break
+                        self._submit_keys(self.keys); self.keys += 1
                     elif self.H > 0 and self.inters < min(target, self.decoded + self.D, self.inter_h):
                         t = time.perf_counter()
                         ctx.launch_tokens(1); self.inters += 1
@@ -296,11 +313,7 @@ def main():
         return S * ((0.5 * k + 1.5) * key_bytes + (0.6 * d + 1.0) * (F - 1) * inter_bytes + 5 * raster_bytes
                     + (k + d * (F - 1)) * compressed_bytes / (S * F) * 1.1
                     + args.header_ahead * (F - 1) * (mbs_per_frame * 84 + compressed_bytes / (S * F)))
-    while need(K, D) > budget and (K > D or D > 1):
-        if K > D:
-            K -= 1
-        else:
-            D -= 1; K = D
+    planned_need_gb = round(need(K, D) / 1e9, 1)         # (the look-ahead is bounded by K / D AND, at run time, by what the heap holds)
     pipe = Pipeline(streams, K, D, args.header_ahead)
     pipe.run(max(2, pipe.K // 2))       # priming (untimed, before the warm-up): the pools and the coefficient heap reach their working
     pipe.run(args.warmup)               # size, so that first-touch allocations (hipMalloc / hipMemMap / hipHostMalloc) are not what the steps measure
@@ -541,7 +554,7 @@ def main():
                        "streams_per_gpu": S, "frames_per_stream": F, "macroblocks_per_step_per_gpu": mbs_per_step,
                        "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective",
                        "schedule": args.schedule, "key_frames_ahead": pipe_K, "inter_frames_ahead": pipe_D, "inter_headers_ahead_of_tokens": args.header_ahead, "host_threads": threads,
-                       "hbm_budget_gb": round(hbm_budget / 1e9, 1), "hbm_taken_by_the_context_gb": memory["hbm_taken_by_the_context_gb"]},
+                       "hbm_budget_gb": round(hbm_budget / 1e9, 1), "look_ahead_if_memory_were_free_gb": planned_need_gb, "hbm_taken_by_the_context_gb": memory["hbm_taken_by_the_context_gb"]},
             "memory": memory, "entropy_decode_roof": lanes_roof,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "kernels": roofs, "units_per_step": units, "launches_per_step": launches_per_step, "device_half": device_half,

@@ -173,6 +173,10 @@ typedef struct aa_ctx_info {
   uint32_t compute_units;
   int32_t heap_free_chunks;          /* 64-KB chunks in the coefficient pool */
   uint32_t lanes_starved;            /* times a token lane found the pool empty (since the context was created) */
+  /* diagnostics, ALFALFA_AMD_TOKEN_PROFILE=1 (else zero): where the token workers' waves spent their time, summed over the waves
+   * that have left, in 10-ns ticks: [0] macroblock-boundary passes [1] how many [2] decode steps of waves [3] looking for /
+   * starting frames [4] ring top-ups [5] periods (steps + boundary passes) [6] lane-periods that had a frame [7] periods */
+  uint64_t token_profile[8];
 } aa_ctx_info;
 aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out );
 /* hipStream_t handles as opaque pointers (to order foreign work, e.g. an RCCL broadcast, against ours) */

@@ -49,7 +49,6 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
   J.mbflags = static_cast<uint8_t *>( aligned( J.flags_padded ) );
   J.mbs = static_cast<aa_mb_info *>( aligned( nmb * sizeof( aa_mb_info ) ) );
   J.chunk_list = static_cast<uint32_t *>( aligned( size_t( aa::chunk_list_entries( nmb ) ) * 4 ) );
-  J.above = static_cast<uint16_t *>( aligned( size_t( aa::tok::above_entries( J.fp.mbw ) ) * 2 ) );
   // the coefficient heap as the runtime sets it up: chunks handed out through the pool's ring -- here in an order that is
   // neither ascending nor contiguous, and with `pool_chunks` of them only (0: as many as the worst case needs)
   const uint32_t worst_chunks = aa::chunk_list_entries( nmb ) - 1;
@@ -93,7 +92,7 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
   }
   // ---- k_parse_tokens ----
   {
-    const uint32_t bytes = aa::tok::kTablesBytes + aa::tok::lane_lds_bytes( J.fp.nparts > 1 );
+    const uint32_t bytes = aa::tok::kTablesBytes + aa::tok::lane_lds_bytes( J.fp.mbw, J.fp.nparts > 1 );
     std::vector<uint8_t> store( bytes + 16 );
     uint8_t * smem = reinterpret_cast<uint8_t *>( ( reinterpret_cast<uintptr_t>( store.data() ) + 15 ) & ~uintptr_t( 15 ) );
     std::memset( smem, 0xA5, bytes );
@@ -144,7 +143,7 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
     const bool bit = ( J.intra_rows[row * words_per_row + ( col >> 6 )] >> ( col & 63 ) ) & 1;
     if ( bit != !( J.mbs[row * J.fp.mbw + col].flags & AA_MB_INTER ) ) bad = 1;
   }
-  free( dev_data ); free( J.mbflags ); free( J.mbs ); free( J.chunk_list ); free( J.above ); free( heap_mem ); free( J.intra_rows );
+  free( dev_data ); free( J.mbflags ); free( J.mbs ); free( J.chunk_list ); free( heap_mem ); free( J.intra_rows );
   if ( sum.status != aa::TOK_OK ) return 200 + static_cast<int>( sum.status );
   return bad ? 100 : 0;
 }
