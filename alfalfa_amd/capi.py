@@ -51,7 +51,7 @@ class KernelStats(C.Structure):
                 ("pool_waits", C.c_uint64), ("pool_wait_ms", C.c_double), ("parse_wait_ms", C.c_double),
                 ("bind_wait_ms", C.c_double), ("alloc_ms", C.c_double), ("slab_mallocs", C.c_uint64),
                 ("token_steps", C.c_uint64), ("token_frames", C.c_uint64), ("worker_launches", C.c_uint64), ("worker_wgs", C.c_uint64),
-                ("worker_retires", C.c_uint64), ("heap_grows", C.c_uint64), ("heap_mapped_bytes", C.c_uint64), ("nomem_retries", C.c_uint64)]
+                ("worker_retires", C.c_uint64), ("heap_grows", C.c_uint64), ("heap_mapped_bytes", C.c_uint64), ("nomem_retries", C.c_uint64), ("frames_evicted", C.c_uint64)]
 
 
 class CtxInfo(C.Structure):

@@ -90,6 +90,7 @@ struct WorkerArgs {
   uint32_t gen;                           // this grid's generation
   uint32_t spread;                        // workgroups the GPU holds: a wave takes its share of a short queue, not all it can carry
   unsigned long long * prof;              // diagnostics (null: off): 8 counters summed over the waves of all grids, see aa_tok_mirror::prof
+  unsigned long long linger_ticks;        // a workgroup without work stays this long (100 MHz ticks) before it leaves
   int lanes;
   uint32_t lane_bytes;
 };
@@ -133,6 +134,8 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
   L.steps = 0;
   const bool is_lane = lane < a.lanes;
   uint32_t backoff = 0;
+  unsigned long long idle_since = 0;      // the wave has had no frame since (0: it has one)
+  uint32_t looks = 0;
   // diagnostics: where a wave's time goes (100 MHz ticks): [0] boundary passes [1] their number [2] steps [3] looking for / starting
   // frames [4] ring top-ups [5] periods (hot loops + boundary passes) [6] lane-periods with a frame [7] periods
   unsigned long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -149,7 +152,8 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
         const int first = __ffsll( static_cast<long long>( idle_mask ) ) - 1;
         uint32_t base = 0, got = 0;
         if ( lane == first ) {
-          if ( __hip_atomic_load( a.retire, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM ) >= a.gen ) got = 0xFFFFFFFFu;
+          // (the retire word lives in host memory: a read over the bus -- every 8th look is often enough)
+          if ( ( looks++ & 7u ) == 0 && __hip_atomic_load( a.retire, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM ) >= a.gen ) got = 0xFFFFFFFFu;
           else got = queue_take( a.q, static_cast<uint32_t>( __popcll( idle_mask ) ), a.spread, &base );
         }
         base = __shfl( base, first ); got = __shfl( got, first );
@@ -171,11 +175,20 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
     }
     const bool active = is_lane && L.rec != aa::tok::R_DONE;
     if ( !__any( active ) ) {
-      if ( looked ) break;                // no lane has a frame and there was nothing to take (or the grid retires)
       if ( retired ) break;
+      if ( looked ) {
+        // No lane has a frame and the queue is empty.  The wave does not leave at once: the host hands frames over in bursts,
+        // and a grid whose waves left in the gap between two bursts would have to be launched again -- on a worker stream that a
+        // few long-running leftovers of the old grid may hold for seconds.  It stays, asleep between looks, for `linger`.
+        const unsigned long long now = wall_clock64();
+        if ( !idle_since ) idle_since = now | 1ull;
+        else if ( now - idle_since > a.linger_ticks ) break;
+        for ( int k = 0; k < 16; k++ ) __builtin_amdgcn_s_sleep( 127 );          // ~30 us
+      }
       backoff = 0;
       continue;
     }
+    idle_since = 0;
     const unsigned long long t_b = profiling ? wall_clock64() : 0ull;
     if ( active ) aa::tok::top_up( L, smem, F );
     const unsigned long long t_c = profiling ? wall_clock64() : 0ull;
@@ -338,11 +351,11 @@ void token_worker_shape( uint32_t lane_bytes, int n_cus, int * lanes_out, uint32
 }
 
 int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap & heap, uint32_t * exited, const uint32_t * retire, uint32_t gen, uint32_t spread,
-                          unsigned long long * prof, int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, void * stream )
+                          unsigned long long * prof, unsigned long long linger_ticks, int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, void * stream )
 {
   if ( lanes < 1 || wgs < 1 ) return static_cast<int>( hipErrorInvalidValue );
   WorkerArgs a;
-  a.q = q; a.slots = slots; a.heap = heap; a.exited = exited; a.retire = retire; a.gen = gen; a.spread = spread ? spread : 1u; a.prof = prof; a.lanes = lanes; a.lane_bytes = lane_bytes;
+  a.q = q; a.slots = slots; a.heap = heap; a.exited = exited; a.retire = retire; a.gen = gen; a.spread = spread ? spread : 1u; a.prof = prof; a.linger_ticks = linger_ticks; a.lanes = lanes; a.lane_bytes = lane_bytes;
   hipLaunchKernelGGL( k_token_workers, dim3( wgs ), dim3( 64 ), lds, static_cast<hipStream_t>( stream ), a );
   return static_cast<int>( hipGetLastError() );
 }

@@ -147,7 +147,7 @@ struct aa_ctx {
   static constexpr int kMaxParseStreams = 20;
   // Hardware queues are few (16 asked for above) and a queue runs its commands in order: a stream that shares a queue with a
   // worker grid -- which stays for as long as there is work -- would not get a kernel started until that grid leaves.  So the
-  // context keeps to 11 streams: compute, copy, utility, 4 header-parse streams (short kernels now), 4 worker streams.
+  // context keeps to 15 streams: compute, copy, utility, 4 header-parse streams (short kernels now), 8 worker streams.
   int n_parse_streams = 4;
   std::vector<hipStream_t> parse_streams;
   std::vector<hipEvent_t> parse_idle;    // recorded behind the last operation queued on the stream
@@ -165,6 +165,7 @@ struct aa_ctx {
     uint32_t q_slots = 1u << 18;
     uint64_t jobs_enqueued = 0;          // tickets the host has scheduled (a ticket = one frame, rejected ones included)
     std::vector<Batch *> inflight;       // batches with frames handed to the queue that may not be through yet (a batch leaves when it dies)
+    std::vector<Batch *> batches;        // every live batch whose frames went to the queue, oldest first (eviction walks it from the back)
     uint32_t * one_dev = nullptr;        // a zero in HBM: the `order` of a one-job hand-over
     // coefficient heap: ONE virtual range, physical memory mapped as the frames need it
     uint8_t * heap = nullptr;
@@ -178,8 +179,10 @@ struct aa_ctx {
     uint32_t seen_starving = 0;
     std::vector<const uint32_t *> pending_lists;   // chunk lists of released frames, not yet handed to k_pool_free_lists
     // worker grids: slot g = worker stream g; counters are cumulative over the grids a slot has run
-    static constexpr int kSlots = 4;
-    struct Slot { hipStream_t st = nullptr; uint32_t launched = 0, gen = 0; bool queued_behind_retiring = false; } slot[kSlots];
+    static constexpr int kSlots = 8;
+    struct Slot { hipStream_t st = nullptr; uint32_t launched = 0, gen = 0;
+                  bool queued_behind_retiring = false;      // a grid was told to finish and a new one waits behind it on the stream ...
+                  uint32_t retiring_until = 0; } slot[kSlots];  // ... until the slot's exit count reaches this (the old grid is gone)
     uint32_t * exited_dev = nullptr;     // [AA_MAX_WORKER_GRIDS] in HBM
     unsigned long long * prof_dev = nullptr;   // diagnostics counters (ALFALFA_AMD_TOKEN_PROFILE=1), else null
     uint32_t * retire_host = nullptr, * retire_dev = nullptr;     // [AA_MAX_WORKER_GRIDS]: grids of generation <= this take no more jobs
@@ -187,6 +190,7 @@ struct aa_ctx {
     uint32_t mirror_seq = 0;
     uint32_t lane_bytes = 0, lds = 0;
     int lanes = 0, cap_wgs = 0, n_cus = 0;
+    unsigned long long linger_ticks = 100000000ull;    // 1 s at 100 MHz (ALFALFA_AMD_WORKER_LINGER_MS)
   } tok;
   // Device pieces given back while kernels that read them may still be queued: they become reusable once an event recorded
   // on the compute stream after the release has fired ("epochs": one event per group of releases, recorded lazily).
@@ -526,6 +530,7 @@ aa_status tok_init( aa_ctx * ctx )
   HIP_TRY( hipMemset( T.one_dev, 0, 256 ) );
   HIP_TRY( hipMalloc( reinterpret_cast<void **>( &T.exited_dev ), sizeof( uint32_t ) * AA_MAX_WORKER_GRIDS ) );
   HIP_TRY( hipMemset( T.exited_dev, 0, sizeof( uint32_t ) * AA_MAX_WORKER_GRIDS ) );
+  if ( const char * e = std::getenv( "ALFALFA_AMD_WORKER_LINGER_MS" ) ) T.linger_ticks = static_cast<unsigned long long>( std::max( 0, atoi( e ) ) ) * 100000ull;
   if ( const char * e = std::getenv( "ALFALFA_AMD_TOKEN_PROFILE" ) ) if ( atoi( e ) ) {
     HIP_TRY( hipMalloc( reinterpret_cast<void **>( &T.prof_dev ), 64 ) );
     HIP_TRY( hipMemset( T.prof_dev, 0, 64 ) );
@@ -576,6 +581,7 @@ aa_status tok_init( aa_ctx * ctx )
 void tok_free( aa_ctx * ctx )
 {
   auto & T = ctx->tok;
+  if ( T.retire_host ) for ( int g = 0; g < aa_ctx::Tok::kSlots; g++ ) __atomic_store_n( &T.retire_host[g], 0xFFFFFFFFu, __ATOMIC_RELEASE );   // lingering workgroups leave now
   if ( T.util ) { (void) hipStreamSynchronize( T.util ); }
   for ( auto & sl : T.slot ) if ( sl.st ) { (void) hipStreamSynchronize( sl.st ); (void) hipStreamDestroy( sl.st ); sl.st = nullptr; }
   if ( T.util ) { (void) hipStreamDestroy( T.util ); T.util = nullptr; }
@@ -606,7 +612,7 @@ aa_status tok_launch_workers( aa_ctx * ctx, hipEvent_t after )
   int alive[aa_ctx::Tok::kSlots], alive_total = 0;
   for ( int g = 0; g < aa_ctx::Tok::kSlots; g++ ) {
     alive[g] = static_cast<int>( T.slot[g].launched - M.exited[g] );
-    if ( alive[g] == 0 ) T.slot[g].queued_behind_retiring = false;
+    if ( T.slot[g].queued_behind_retiring && static_cast<int32_t>( M.exited[g] - T.slot[g].retiring_until ) >= 0 ) T.slot[g].queued_behind_retiring = false;
     alive_total += alive[g];
   }
   // as many workgroups as there are jobs waiting, up to what the GPU holds: when lanes are plentiful a frame gets a wave of its
@@ -622,14 +628,14 @@ aa_status tok_launch_workers( aa_ctx * ctx, hipEvent_t after )
       if ( !T.slot[k].queued_behind_retiring && ( g < 0 || alive[k] < alive[g] ) ) g = k;
     if ( g < 0 || alive[g] * 4 > T.cap_wgs ) return AA_OK;              // (nothing small enough to give up: the alive ones keep working)
     __atomic_store_n( &T.retire_host[g], T.slot[g].gen, __ATOMIC_RELEASE );
-    T.slot[g].queued_behind_retiring = true;
+    T.slot[g].queued_behind_retiring = true; T.slot[g].retiring_until = T.slot[g].launched;
     ctx->stats.worker_retires++;
   }
   auto & sl = T.slot[g];
   sl.gen++;
   if ( after ) HIP_TRY( hipStreamWaitEvent( sl.st, after, 0 ) );
   LaunchTimer timer( ctx, 4, sl.st );
-  if ( int e = aa::launch_token_workers( T.q, T.slots, heap_of( ctx ), T.exited_dev + g, T.retire_dev + g, sl.gen, static_cast<uint32_t>( T.cap_wgs ), T.prof_dev, want, T.lanes, T.lane_bytes, T.lds, sl.st ) )
+  if ( int e = aa::launch_token_workers( T.q, T.slots, heap_of( ctx ), T.exited_dev + g, T.retire_dev + g, sl.gen, static_cast<uint32_t>( T.cap_wgs ), T.prof_dev, T.linger_ticks, want, T.lanes, T.lane_bytes, T.lds, sl.st ) )
     return hip_fail( static_cast<hipError_t>( e ), "k_token_workers" );
   sl.launched += static_cast<uint32_t>( want );
   ctx->stats.worker_launches++; ctx->stats.worker_wgs += static_cast<uint64_t>( want );
@@ -756,6 +762,7 @@ void release_records( aa_stream * s, FrameRec & f, bool deferred )
     if ( last ) {
       if ( b->tokens_pending ) ctx->deferred.erase( std::remove( ctx->deferred.begin(), ctx->deferred.end(), b ), ctx->deferred.end() );
       ctx->tok.inflight.erase( std::remove( ctx->tok.inflight.begin(), ctx->tok.inflight.end(), b ), ctx->tok.inflight.end() );
+      ctx->tok.batches.erase( std::remove( ctx->tok.batches.begin(), ctx->tok.batches.end(), b ), ctx->tok.batches.end() );
       if ( b->hdr_done ) { (void) hipEventSynchronize( b->hdr_done ); (void) hipEventDestroy( b->hdr_done ); }   // never forgotten while kernels still read the arena
       { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); }
       dev_free( ctx, b->dev, b->dev_bytes, true );        // (always through an epoch: the chunk lists of its frames are read out of it on the device)
@@ -1439,6 +1446,7 @@ aa_status launch_tokens_of( aa_ctx * ctx, Batch * b )
     ctx->stats.parsed_macroblocks += jobs_host[i].nmb;
   }
   if ( std::find( T.inflight.begin(), T.inflight.end(), b ) == T.inflight.end() ) T.inflight.push_back( b );
+  if ( std::find( T.batches.begin(), T.batches.end(), b ) == T.batches.end() ) T.batches.push_back( b );
   if ( aa_status st = tok_grow_heap( ctx, static_cast<size_t>( std::max<int64_t>( 0, T.chunks_committed ) ) * kChunkBytesHeap ) ) return st;
   hipStream_t ps = b->ps;
   if ( b->patch_jobs && dropped ) HIP_TRY( hipMemcpyAsync( b->dev, b->host, b->head_bytes, hipMemcpyHostToDevice, ps ) );     // (behind the header kernel on its stream)
@@ -1689,7 +1697,34 @@ static aa_status resolve_summary( aa_stream * s, FrameRec & r )
       if ( aa_status st = tok_quiesce( ctx ) ) return st;
       if ( aa_status st = tok_refresh_mirror( ctx ) ) return st;
     }
-    if ( attempt >= 2 || T.mirror_host->pool_avail < static_cast<int32_t>( worst ) )
+    if ( T.mirror_host->pool_avail < static_cast<int32_t>( worst ) ) {
+      // Still not enough: the heap is held by frames that were parsed AHEAD of this one (submitted later, needed later).  They
+      // give their chunks back -- newest first -- and are parsed again when their turn comes: to them it is as if their lane had
+      // handed them back.  Thrashing is slow, but a caller that looks far ahead never gets stuck on the frame it needs now.
+      int32_t have = T.mirror_host->pool_avail;
+      std::lock_guard<std::mutex> g( ctx->pool_mu );
+      for ( auto bi = T.batches.rbegin(); bi != T.batches.rend() && have < static_cast<int32_t>( worst ); ++bi ) {
+        Batch * vb = *bi;
+        volatile aa::FrameSummary * sums = reinterpret_cast<volatile aa::FrameSummary *>( vb->host + vb->summaries_off );
+        for ( int i = vb->n - 1; i >= 0 && have < static_cast<int32_t>( worst ); i-- ) {
+          if ( !vb->items[i].live ) continue;
+          aa_stream * vs = vb->items[i].s;
+          FrameRec & v = vs->frames[vb->items[i].frame];
+          if ( &v == &r || !v.enqueued || v.records_released || v.chunks_returned || !sums[i].done || vb->items[i].frame < vs->next_submit ) continue;
+          T.pending_lists.push_back( v.chunk_list );
+          have += static_cast<int32_t>( sums[i].num_chunks );
+          v.chunks_returned = true; v.summary_pending = true;
+          T.chunks_committed -= v.est_chunks; v.est_chunks = 0;
+          sums[i].status = aa::TOK_NO_MEMORY;
+          ctx->stats.frames_evicted++;
+        }
+      }
+      flush_chunk_frees( ctx );
+      if ( !T.pending_lists.empty() ) return fail( AA_ERR_HIP, "k_pool_free_lists could not be launched" );
+    }
+    HIP_TRY( hipStreamSynchronize( ctx->compute ) );
+    if ( aa_status st = tok_refresh_mirror( ctx ) ) return st;
+    if ( attempt >= 8 || T.mirror_host->pool_avail < static_cast<int32_t>( worst ) )
       return fail( AA_ERR_NO_MEMORY, "device parser: the coefficient heap is exhausted (" + std::to_string( T.heap_mapped >> 20 ) + " MiB mapped, "
                                      + std::to_string( T.mirror_host->pool_avail ) + " chunks free, this frame may need " + std::to_string( worst )
                                      + "): release decoded frames (aa_stream_release_before) or raise the limit (aa_ctx_set_memory_limit); the call can be repeated" );

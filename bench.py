@@ -77,6 +77,8 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-device-half", action="store_true")
     ap.add_argument("--profile-timed", action="store_true", help="HIP-event timing of every kernel INSIDE the timed region too (diagnostics)")
+    ap.add_argument("--overcommit", type=float, default=1.25, help="frames are admitted while what those in flight are EXPECTED to store stays below this x the heap "
+                    "(frames being parsed hold only part of it, and the oldest are released first; a lane that finds the pool empty waits)")
     ap.add_argument("--trace-memory", action="store_true", help="print the context's memory books after every step of the timed region (stderr)")
     ap.add_argument("--small-batches", default="1,8,64", help="stream counts for the small-batch end-to-end figures ('' = skip)")
     return ap.parse_args()
@@ -251,7 +253,7 @@ def main():
                 return True
             i = ctx.info()
             cap = min(i["heap_limit_bytes"], i["memory_limit_bytes"] - i["pool_bytes"]) if i["heap_limit_bytes"] else i["memory_limit_bytes"] - i["pool_bytes"]
-            return i["heap_used_bytes"] + nbytes <= 0.97 * cap
+            return i["heap_used_bytes"] + nbytes <= args.overcommit * cap
 
         def run(self, steps):
             """`steps` whole steps, from an empty pipeline to an empty pipeline.  Frames go to the GPU parser in the order they
@@ -336,7 +338,7 @@ def main():
                     "host_waited_for_parse_ms_per_step": round(tstats["parse_wait_ms"] / args.steps, 2),
                     "host_waited_for_compute_stream_ms_per_step": round(tstats["bind_wait_ms"] / args.steps, 2),
                     "host_in_pool_allocator_ms_per_step": round(tstats["alloc_ms"] / args.steps, 2), "slab_mallocs": tstats["slab_mallocs"],
-                    "heap_grows": tstats["heap_grows"], "frames_handed_back_for_lack_of_memory": tstats["nomem_retries"],
+                    "heap_grows": tstats["heap_grows"], "frames_handed_back_for_lack_of_memory": tstats["nomem_retries"], "frames_evicted": tstats["frames_evicted"],
                     "worker_grids_launched": tstats["worker_launches"], "worker_workgroups_launched": tstats["worker_wgs"], "worker_grids_retired": tstats["worker_retires"],
                     "pool_waits": tstats["pool_waits"], "pool_wait_ms_per_step": round(tstats["pool_wait_ms"] / args.steps, 2)}
     # the entropy decode against ITS roof: a lane decodes one bool per step, a step takes what it takes (measured on a lone chain),

@@ -348,6 +348,7 @@ typedef struct aa_kernel_stats {
   uint64_t heap_grows;      /* pieces of memory mapped into the coefficient heap */
   uint64_t heap_mapped_bytes;
   uint64_t nomem_retries;   /* frames a lane handed back because the coefficient pool was empty, run again */
+  uint64_t frames_evicted;  /* frames parsed ahead of their turn whose chunks were taken back for a frame needed now (parsed again later) */
 } aa_kernel_stats;
 aa_status aa_ctx_profile( aa_ctx * ctx, int enable );
 aa_status aa_ctx_kernel_stats( aa_ctx * ctx, aa_kernel_stats * out, int reset );
