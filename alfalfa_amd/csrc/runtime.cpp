@@ -190,7 +190,7 @@ struct aa_ctx {
     uint32_t mirror_seq = 0;
     uint32_t lane_bytes = 0, lds = 0;
     int lanes = 0, cap_wgs = 0, n_cus = 0;
-    unsigned long long linger_ticks = 100000000ull;    // 1 s at 100 MHz (ALFALFA_AMD_WORKER_LINGER_MS)
+    unsigned long long linger_ticks = 200000000ull;    // 2 s at 100 MHz (ALFALFA_AMD_WORKER_LINGER_MS)
   } tok;
   // Device pieces given back while kernels that read them may still be queued: they become reusable once an event recorded
   // on the compute stream after the release has fired ("epochs": one event per group of releases, recorded lazily).
@@ -618,7 +618,9 @@ aa_status tok_launch_workers( aa_ctx * ctx, hipEvent_t after )
   // as many workgroups as there are jobs waiting, up to what the GPU holds: when lanes are plentiful a frame gets a wave of its
   // own (a wave steps faster the fewer lanes it carries); grids already launched for these jobs -- started or not -- count
   const int want = std::min( T.cap_wgs, queued ) - alive_total;
-  if ( want <= 0 ) return AA_OK;
+  // ... and not in dribs and drabs: a grid takes a worker stream for as long as its last wave lives, so small top-ups use the
+  // streams up.  Waves linger when the queue is empty; a top-up is for when a good part of the GPU's lanes is really gone.
+  if ( want <= 0 || ( alive_total > 0 && want * 4 < T.cap_wgs && want < queued ) ) return AA_OK;
   int g = -1;
   for ( int k = 0; k < aa_ctx::Tok::kSlots; k++ ) if ( alive[k] == 0 ) { g = k; break; }
   if ( g < 0 ) {
@@ -626,7 +628,8 @@ aa_status tok_launch_workers( aa_ctx * ctx, hipEvent_t after )
     // good): the smallest one retires -- its lanes finish the frames they have and take no more -- and the new grid queues behind it
     for ( int k = 0; k < aa_ctx::Tok::kSlots; k++ )
       if ( !T.slot[k].queued_behind_retiring && ( g < 0 || alive[k] < alive[g] ) ) g = k;
-    if ( g < 0 || alive[g] * 4 > T.cap_wgs ) return AA_OK;              // (nothing small enough to give up: the alive ones keep working)
+    // (a retiring grid's lanes stop taking frames: that costs capacity until its last chain ends -- only worth it when half the GPU's lanes are gone)
+    if ( g < 0 || alive[g] * 4 > T.cap_wgs || alive_total * 2 > T.cap_wgs ) return AA_OK;
     __atomic_store_n( &T.retire_host[g], T.slot[g].gen, __ATOMIC_RELEASE );
     T.slot[g].queued_behind_retiring = true; T.slot[g].retiring_until = T.slot[g].launched;
     ctx->stats.worker_retires++;

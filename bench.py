@@ -69,7 +69,7 @@ def parse_args():
     ap.add_argument("--frames", type=int, default=12, help="frames per stream per step")
     ap.add_argument("--key-ahead", type=int, default=12, help="steps by which KEY frames are handed to the GPU parser ahead of reconstruction (clamped to what the HBM budget holds)")
     ap.add_argument("--depth", type=int, default=8, help="steps by which inter frames are handed to the GPU parser ahead of reconstruction (clamped likewise)")
-    ap.add_argument("--hbm-gb", type=float, default=150.0, help="HBM the decoder context may use on each GPU (aa_ctx_set_memory_limit); the look-ahead is planned inside it")
+    ap.add_argument("--hbm-gb", type=float, default=200.0, help="HBM the decoder context may use on each GPU (aa_ctx_set_memory_limit); the look-ahead is planned inside it")
     ap.add_argument("--header-ahead", type=int, default=0, help="steps by which the macroblock-header pass of inter frames runs ahead of their token pass (two-phase submit)")
     ap.add_argument("--threads", type=int, default=0, help="host workers of the header pre-pass (0: cores / local ranks)")
     ap.add_argument("--schedule", default="rows", choices=["rows", "diagonal"])
@@ -77,7 +77,7 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-device-half", action="store_true")
     ap.add_argument("--profile-timed", action="store_true", help="HIP-event timing of every kernel INSIDE the timed region too (diagnostics)")
-    ap.add_argument("--overcommit", type=float, default=1.25, help="frames are admitted while what those in flight are EXPECTED to store stays below this x the heap "
+    ap.add_argument("--overcommit", type=float, default=1.2, help="frames are admitted while what those in flight are EXPECTED to store stays below this x the heap "
                     "(frames being parsed hold only part of it, and the oldest are released first; a lane that finds the pool empty waits)")
     ap.add_argument("--trace-memory", action="store_true", help="print the context's memory books after every step of the timed region (stderr)")
     ap.add_argument("--small-batches", default="1,8,64", help="stream counts for the small-batch end-to-end figures ('' = skip)")
@@ -199,6 +199,7 @@ def main():
                     e = self.inter_arr[i * (F - 1) + k]
                     e.data, e.size = fr, len(fr)
             self.keys = self.inters = self.decoded = 0      # groups handed to the GPU parser (key / inter frames), groups reconstructed
+            self.frames_submitted = 0
             self.host_s = 0.0
             self.t_launch = self.t_decode = self.t_release = 0.0      # host time in aa_launch_tokens / aa_decode_batch / releases
             self.done_t = []
@@ -209,6 +210,7 @@ def main():
             for i, d in enumerate(ds):
                 self.key_arr[i].stream = d.h.value
             ctx.submit_prepared((self.key_arr, self.key_out, None), threads, False)
+            self.frames_submitted += self.n
             self.host_s += time.perf_counter() - t
 
         def _submit_inters(self, g, defer_tokens=False):
@@ -220,6 +222,7 @@ def main():
                 for k in range(F - 1):
                     self.inter_arr[i * (F - 1) + k].stream = h
             ctx.submit_prepared((self.inter_arr, self.inter_out, None), threads, defer_tokens)
+            self.frames_submitted += self.n * (F - 1)
             self.host_s += time.perf_counter() - t
 
         def decode(self, release=True):
@@ -315,7 +318,7 @@ def main():
         return S * ((0.5 * k + 1.5) * key_bytes + (0.6 * d + 1.0) * (F - 1) * inter_bytes + 5 * raster_bytes
                     + (k + d * (F - 1)) * compressed_bytes / (S * F) * 1.1
                     + args.header_ahead * (F - 1) * (mbs_per_frame * 84 + compressed_bytes / (S * F)))
-    planned_need_gb = round(need(K, D) / 1e9, 1)         # (the look-ahead is bounded by K / D AND, at run time, by what the heap holds)
+    planned_need_gb = round(need(K, D) / 1e9, 1)         # (the look-ahead is bounded by K / D AND, at run time, by what the heap holds: _room)
     pipe = Pipeline(streams, K, D, args.header_ahead)
     pipe.run(max(2, pipe.K // 2))       # priming (untimed, before the warm-up): the pools and the coefficient heap reach their working
     pipe.run(args.warmup)               # size, so that first-touch allocations (hipMalloc / hipMemMap / hipHostMalloc) are not what the steps measure
@@ -478,6 +481,7 @@ def main():
         device_half = {"value": round(mbs_per_step / dt, 1), "unit": "macroblocks/s", "ms_per_step": round(dt * 1e3, 3),
                        "note": "reconstruction + loop filter only, parsed records resident in HBM (round-1 metric)"}
     pipe_K, pipe_D = pipe.K, pipe.D
+    mbs_whole_run = (pipe.frames_submitted + min(4, S) * F) * mbs_per_frame       # (+ the calibration frames)
     del pipe, verify_decs
 
     # ---- small batches: the reference's actual callers (one stream, one 8-chunk ExCamera bundle), end to end ----
@@ -557,7 +561,7 @@ def main():
                        "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective",
                        "schedule": args.schedule, "key_frames_ahead": pipe_K, "inter_frames_ahead": pipe_D, "inter_headers_ahead_of_tokens": args.header_ahead, "host_threads": threads,
                        "hbm_budget_gb": round(hbm_budget / 1e9, 1), "look_ahead_if_memory_were_free_gb": planned_need_gb, "hbm_taken_by_the_context_gb": memory["hbm_taken_by_the_context_gb"]},
-            "memory": memory, "entropy_decode_roof": lanes_roof,
+            "memory": memory, "entropy_decode_roof": lanes_roof, "macroblocks_parsed_whole_run": mbs_whole_run,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "kernels": roofs, "units_per_step": units, "launches_per_step": launches_per_step, "device_half": device_half,
             "steady_state": None if steady_ms is None else {"ms_per_step": round(steady_ms, 3), "value": round(world * mbs_per_step / (steady_ms * 1e-3), 1),

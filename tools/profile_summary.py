@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import rocpd_summary  # noqa: E402
 
 KINDS = collections.OrderedDict([("k_recon_inter4", "recon_inter"), ("k_recon_inter(", "recon_split"), ("k_recon_intra4", "recon_intra"),
-                                 ("k_loopfilter_rows4", "loopfilter"), ("k_parse_tokens", "parse_tokens"), ("k_parse_mb_headers", "parse_headers")])
+                                 ("k_loopfilter_rows4", "loopfilter"), ("k_token_workers", "parse_tokens"), ("k_parse_mb_headers", "parse_headers")])
 
 
 def kind_of(name):
@@ -57,6 +57,15 @@ def main():
         out += ["## HIP-event timing inside bench.py of the same run (must agree with the trace)\n", "```",
                 json.dumps({k: (v and {"avg_launch_us": v["avg_launch_us"], "launches_per_step": v["launches_per_step"], "frac_of_hbm_peak": v["frac"]}) for k, v in bench["kernels"].items()}, indent=1), "```", ""]
         tot = collections.defaultdict(dict)
+
+        def bench_of(name):
+            try:
+                return json.loads([l for l in open(os.path.join(d, name + ".log")) if l.startswith("{")][-1])
+            except (OSError, IndexError, ValueError):
+                return {}
+        fetch_bench, write_bench = bench_of("fetch"), bench_of("write")
+        if fetch_bench:
+            units, lps = fetch_bench["units_per_step"], fetch_bench["launches_per_step"]     # (the counter passes run their own, smaller workload)
         out += ["## Counters per launch, summed over the chip\n", "```"]
         for name in ("fetch", "write", "sq"):
             db = os.path.join(d, name + "_results.db")
@@ -74,8 +83,13 @@ def main():
         for k in alg:
             if k not in tot or "FETCH_SIZE" not in tot[k] or "WRITE_SIZE" not in tot[k] or not units.get(k):
                 continue
-            steps_f = tot[k]["FETCH_SIZE"][1] / lps[k]; steps_w = tot[k]["WRITE_SIZE"][1] / lps[k]
-            f = tot[k]["FETCH_SIZE"][0] * 1024 / (steps_f * units[k]); w = tot[k]["WRITE_SIZE"][0] * 1024 / (steps_w * units[k])
+            if k in ("parse_tokens", "parse_headers") and fetch_bench.get("macroblocks_parsed_whole_run"):
+                # worker grids do not come one per step: everything the run's grids moved over everything the run parsed
+                f = tot[k]["FETCH_SIZE"][0] * 1024 / fetch_bench["macroblocks_parsed_whole_run"]
+                w = tot[k]["WRITE_SIZE"][0] * 1024 / write_bench["macroblocks_parsed_whole_run"]
+            else:
+                steps_f = tot[k]["FETCH_SIZE"][1] / lps[k]; steps_w = tot[k]["WRITE_SIZE"][1] / lps[k]
+                f = tot[k]["FETCH_SIZE"][0] * 1024 / (steps_f * units[k]); w = tot[k]["WRITE_SIZE"][0] * 1024 / (steps_w * units[k])
             t[k] = round(2 * f + w, 1)
             out.append("| %s | %d | %.0f | %.0f | %.0f | %.0f | %d | %.2f |" % (k, units[k], f, w, f + w, 2 * f + w, alg[k], (2 * f + w) / alg[k]))
         if t:

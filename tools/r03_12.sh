@@ -1,0 +1,7 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+export ALFALFA_AMD_PARSE_TIMEOUT_S=120
+mkdir -p gpurun_out
+Q="--steps 20 --warmup 3 --small-batches= --no-cpu-baseline --no-verify --no-device-half"
+timeout 300 python bench.py $Q > gpurun_out/r03n_b220.log 2>&1
+timeout 300 python bench.py $Q --hbm-gb 150 > gpurun_out/r03n_b150.log 2>&1
