@@ -423,6 +423,18 @@ def main():
                 "avg_launch_us": round(ms / n * 1e3, 3), "launches_per_step": n, "ms_per_step": round(ms, 3),
                 "algorithmic_bytes_per_launch": round(bytes_per_launch)}
     roofs = {k: roof(k) for k in BYTES_PER_MB}
+    if roofs["parse_tokens"] is None and units["parse_tokens"]:
+        # the worker grids of the timed region were still there (they linger between bursts): no launch, no launch events.  What this
+        # step's frames cost the workers is then the wall time from their hand-over to the last lane's `done` -- ONE residency
+        bytes_per_launch = BYTES_PER_MB["parse_tokens"] * units["parse_tokens"]
+        achieved = bytes_per_launch / t_parse_alone / 1e9
+        tr = traffic.get("parse_tokens")
+        roofs["parse_tokens"] = {"bound": "hbm", "kernel": KERNEL_NAMES["parse_tokens"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None if tr is None else round(tr * units["parse_tokens"]),
+                                 "avg_launch_us": round(t_parse_alone * 1e6, 3), "launches_per_step": 1, "ms_per_step": round(t_parse_alone * 1e3, 3),
+                                 "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                                 "duration_source": "host clock, hand-over -> parsed (the grid was resident before the step: no HIP events around a launch)"}
+        kstats["parse_tokens_ms"] = t_parse_alone * 1e3
     dom = max((k for k in roofs if roofs[k]), key=lambda k: kstats[k + "_ms"])
     roofline = dict(roofs[dom])
     roofline["note"] = ("dominant kernel by time, from the un-pipelined profile step (its worker grids overlap: one for the key frames, one for the inter frames). "
