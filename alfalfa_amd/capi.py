@@ -51,7 +51,7 @@ class KernelStats(C.Structure):
                 ("pool_waits", C.c_uint64), ("pool_wait_ms", C.c_double), ("parse_wait_ms", C.c_double),
                 ("bind_wait_ms", C.c_double), ("alloc_ms", C.c_double), ("slab_mallocs", C.c_uint64),
                 ("token_steps", C.c_uint64), ("token_frames", C.c_uint64), ("worker_launches", C.c_uint64), ("worker_wgs", C.c_uint64),
-                ("worker_retires", C.c_uint64), ("heap_grows", C.c_uint64), ("heap_mapped_bytes", C.c_uint64), ("nomem_retries", C.c_uint64), ("frames_evicted", C.c_uint64)]
+                ("worker_retires", C.c_uint64), ("heap_grows", C.c_uint64), ("heap_mapped_bytes", C.c_uint64), ("nomem_retries", C.c_uint64), ("frames_evicted", C.c_uint64), ("host_routed_frames", C.c_uint64)]
 
 
 class CtxInfo(C.Structure):
@@ -77,7 +77,8 @@ SYMBOLS = [
     ("aa_last_error", C.c_char_p, []), ("aa_abi_version", C.c_int, []), ("aa_device_count", C.c_int, []),
     ("aa_parser_create", C.c_int, [C.c_uint16, C.c_uint16, C.POINTER(_P)]), ("aa_parser_destroy", None, [_P]),
     ("aa_parser_parse", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(FrameHeader), _P, _P]),
-    ("aa_parser_get_probs", C.c_int, [_P, _U8P]),
+    ("aa_parser_get_probs", C.c_int, [_P, _U8P]), ("aa_parser_set_error_concealment", C.c_int, [_P, C.c_int]),
+    ("aa_stream_set_error_concealment", C.c_int, [_P, C.c_int]), ("aa_stream_error_concealment", C.c_int, [_P]),
     ("aa_parser_get_segmentation", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int8), C.POINTER(C.c_int8), _U8P]),
     ("aa_parser_get_filter_adjustments", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int8), C.POINTER(C.c_int8)]),
     ("aa_parser_serialize_state", C.c_int, [_P, _P, C.c_size_t, _P]), ("aa_parser_deserialize_state", C.c_int, [_P, _P, C.c_size_t]),

@@ -65,6 +65,15 @@ public:
   bool segment_map_reset() const { return seg_map_reset_; }
   std::vector<uint8_t> & segment_map() { return seg_.map; }
 
+  // Decoder::set_error_concealment (decoder.hh:298): frames that end early are ACCEPTED instead of rejected
+  // (UncompressedChunk's accept_partial, uncompressed_chunk.cc:34-130): a frame cut inside its first partition keeps what is
+  // there of it and has no DCT data; a frame too short even for its tag becomes an inter frame of no bytes at all; every
+  // decoder reads zeros past the end of what it has.  (That is ALL the reference does: the macroblock-level branches of
+  // macroblock.cc:53-70,345-352,386 depend on BoolDecoder::valid(), and decoder_state.hh:79,120 builds the first partition's
+  // decoder with complete_chunk = "the frame is corrupted", so valid() never turns false on a corrupted frame.)
+  void set_error_concealment( bool on ) { conceal_ = on; }
+  bool error_concealment() const { return conceal_; }
+
   uint16_t width() const { return width_; }
   uint16_t height() const { return height_; }
   unsigned mb_width() const { return mbw_; }
@@ -90,6 +99,7 @@ public:
 private:
   void parse_header_impl( const uint8_t * data, size_t size, aa_frame_header & hdr, FrameParams & fp, class BoolReader & bd );
   bool seg_map_reset_ = false;
+  bool conceal_ = false;
   uint16_t width_, height_;
   unsigned mbw_, mbh_;
   ProbTables probs_;

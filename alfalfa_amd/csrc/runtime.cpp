@@ -924,6 +924,12 @@ aa_status aa_parser_parse( aa_parser * p, const uint8_t * data, size_t size, aa_
   catch ( const aa::ParseError & e ) { return fail( e.code, e.message ); }
   return AA_OK;
 }
+aa_status aa_parser_set_error_concealment( aa_parser * p, int on )
+{
+  if ( !p ) return fail( AA_ERR_ARGUMENT, "null parser" );
+  p->impl.set_error_concealment( on != 0 );
+  return AA_OK;
+}
 static void export_probs( const aa::Parser & ps, uint8_t * out )
 {
   const aa::ProbTables & t = ps.probs();
@@ -1507,6 +1513,51 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   for ( aa_stream * s : stream_order )
     if ( s->next_submit > static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_LOGIC, "aa_submit_frames: stream state is inconsistent" );
 
+  // ---- route: few chains -> the host's cores ----
+  // A GPU lane decodes a bool in ~0.3 us, a host core in ~4 ns: one core is worth ~75 lanes, and a frame on a lane is a chain of
+  // seconds whatever else the GPU does.  The GPU wins by holding 22 000 chains at once; a call with fewer streams than the host
+  // has workers (an ExCamera bundle of 8 chunks, a player's single stream) is through sooner -- and at a higher rate -- when
+  // each stream's frames are parsed by one host worker (Parser::parse, the same records) and uploaded.  Frames of one stream
+  // are serial on a core, so what counts is streams per worker, not frames.
+  {
+    int nt = threads > 0 ? threads : static_cast<int>( std::thread::hardware_concurrency() );
+    nt = std::max( 1, std::min( nt, 256 ) );
+    const char * route_env = std::getenv( "ALFALFA_AMD_ROUTE" );            // "device" / "host": tests and experiments; default: by size
+    const bool force_device = ( flags & AA_SUBMIT_DEVICE ) || ( route_env && route_env[0] == 'd' );
+    const bool force_host = ( flags & AA_SUBMIT_HOST ) || ( route_env && route_env[0] == 'h' );
+    const bool few = static_cast<int>( stream_order.size() ) <= std::min( nt, 96 );
+    if ( !defer_tokens && !force_device && ( force_host || few ) ) {
+      std::atomic<size_t> next { 0 };
+      auto work = [&]() {
+        for ( ;; ) {
+          const size_t k = next.fetch_add( 1 );
+          if ( k >= stream_order.size() ) return;
+          bool broken = false;
+          for ( int i : by_stream[stream_order[k]] ) {
+            SubmitItem & it = items[i];
+            if ( broken ) { it.status = AA_ERR_LOGIC; it.error = "an earlier frame of this stream in the same call failed"; continue; }
+            it.status = aa_stream_parse( it.s, it.data, it.size, &it.frame_index, nullptr );
+            if ( it.status != AA_OK ) { it.error = g_last_error; it.frame_index = -1; broken = true; }
+          }
+        }
+      };
+      const int workers = std::max( 1, std::min<int>( nt, static_cast<int>( stream_order.size() ) ) );
+      if ( workers == 1 ) work();
+      else {
+        std::vector<std::thread> pool;
+        for ( int t = 0; t < workers; t++ ) pool.emplace_back( work );
+        for ( auto & t : pool ) t.join();
+      }
+      ctx->stats.host_routed_frames += static_cast<uint64_t>( n );
+      aa_status first_error = AA_OK; std::string first_message;
+      for ( int i = 0; i < n; i++ ) {
+        if ( frame_index_out ) frame_index_out[i] = items[i].frame_index;
+        if ( items[i].status != AA_OK && first_error == AA_OK ) { first_error = items[i].status; first_message = items[i].error; }
+      }
+      return first_error == AA_OK ? AA_OK : fail( first_error, first_message );
+    }
+  }
+
   std::unique_ptr<Batch> b( new Batch );
   const size_t arena = ( off + ( size_t( 16 ) << 20 ) - 1 ) & ~( ( size_t( 16 ) << 20 ) - 1 );
   // The frames' record blocks (macroblock records, flags, chunk list: written by the parse kernels only) sit behind the mirrored
@@ -1990,6 +2041,14 @@ aa_status aa_stream_decode( aa_stream * s, const uint8_t * data, size_t size, in
 }
 
 int aa_stream_frame_count( const aa_stream * s ) { return s ? static_cast<int>( s->frames.size() ) : 0; }
+
+aa_status aa_stream_set_error_concealment( aa_stream * s, int on )
+{
+  if ( !s ) return fail( AA_ERR_ARGUMENT, "null stream" );
+  s->parser.set_error_concealment( on != 0 );       // (the host parser and the header pre-pass of the device parser: one Parser)
+  return AA_OK;
+}
+int aa_stream_error_concealment( const aa_stream * s ) { return s && s->parser.error_concealment() ? 1 : 0; }
 
 aa_status aa_stream_release_before( aa_stream * s, int first_kept )
 {

@@ -39,6 +39,10 @@ class Parser:
         h = hdr.as_dict()
         return h, self._mb.copy().reshape(self.mbh, self.mbw), self._coeff[:h["num_coeff_blocks"] * 16].copy().reshape(-1, 16)
 
+    def set_error_concealment(self, on):
+        """Decoder::set_error_concealment (decoder.hh:298): accept frames that end early."""
+        capi.check(self.L.aa_parser_set_error_concealment(self.h, int(on)))
+
     def export_state(self):
         """DecoderState as bytes (host half of the entry-state hand-off, decoder.cc:43-46)."""
         n = self.L.aa_parser_state_size(self.h)
@@ -133,11 +137,13 @@ class Context:
     def compute_stream(self):
         return self.L.aa_ctx_compute_stream(self.h)
 
-    def submit_frames(self, pairs, threads=0, defer_tokens=False):
+    ROUTES = {"auto": 0, "device": 2, "host": 4}
+
+    def submit_frames(self, pairs, threads=0, defer_tokens=False, route="auto"):
         """Device-side entropy decode (aa_submit_frames): pairs = [(decoder, frame bytes), ...], frames of one decoder in
         stream order.  Host: frame-header pre-pass only; the macroblock headers and tokens are parsed on the GPU.
         -> frame index of every pair in its stream."""
-        return self.submit_prepared(self.prepare_frames(pairs), threads, defer_tokens)
+        return self.submit_prepared(self.prepare_frames(pairs), threads, defer_tokens, route)
 
     def prepare_frames(self, pairs):
         """The ctypes argument block of submit_frames, reusable across calls with the same (decoder, bytes) pairs."""
@@ -147,10 +153,11 @@ class Context:
             arr[i].stream, arr[i].data, arr[i].size = d.h.value, fr, len(fr)
         return arr, (C.c_int * n)(), [fr for _, fr in pairs]      # (keeps the byte strings alive)
 
-    def submit_prepared(self, prepared, threads=0, defer_tokens=False):
-        """defer_tokens: two-phase form (AA_SUBMIT_DEFER_TOKENS) -- macroblock headers now, tokens at launch_tokens()."""
+    def submit_prepared(self, prepared, threads=0, defer_tokens=False, route="auto"):
+        """defer_tokens: two-phase form (AA_SUBMIT_DEFER_TOKENS) -- macroblock headers now, tokens at launch_tokens().
+        route: "auto" (few streams -> host workers, many -> GPU lanes), "device", "host"."""
         arr, out, _keep = prepared
-        capi.check(self.L.aa_submit_frames_ex(self.h, arr, len(arr), out, threads, 1 if defer_tokens else 0))
+        capi.check(self.L.aa_submit_frames_ex(self.h, arr, len(arr), out, threads, (1 if defer_tokens else 0) | self.ROUTES[route]))
         return list(out)
 
     def launch_tokens(self, max_batches=0):
@@ -179,6 +186,13 @@ class Decoder:
     def __del__(self):
         if getattr(self, "h", None):
             self.L.aa_stream_destroy(self.h); self.h = None
+
+    def set_error_concealment(self, on):
+        """Decoder::set_error_concealment (decoder.hh:298): accept frames that end early (host and GPU parser alike)."""
+        capi.check(self.L.aa_stream_set_error_concealment(self.h, int(on)))
+
+    def error_concealment(self):
+        return bool(self.L.aa_stream_error_concealment(self.h))
 
     # -- two-step form: parse_frame + decode_frame (decoder.cc:89-118) --
     def parse_frame(self, frame_bytes):

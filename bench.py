@@ -294,11 +294,11 @@ def main():
     cal = [aa.Decoder(ctx, width, height) for _ in range(min(4, S))]
     ctx.kernel_stats(reset=True)
     t0 = time.perf_counter()
-    ctx.submit_frames([(cal[0], streams[0][0])], threads)
+    ctx.submit_frames([(cal[0], streams[0][0])], threads, route="device")
     key_hdr = cal[0].frame_header(0)                     # waits for the parse
     t_lone_key = time.perf_counter() - t0
     lone_steps = ctx.kernel_stats(reset=True)["token_steps"]
-    ctx.submit_frames([(d, st[0]) for d, st in zip(cal[1:], streams[1:])] + [(d, fr) for d, st in zip(cal, streams) for fr in st[1:]], threads)
+    ctx.submit_frames([(d, st[0]) for d, st in zip(cal[1:], streams[1:])] + [(d, fr) for d, st in zip(cal, streams) for fr in st[1:]], threads, route="device")
     key_blocks = max([key_hdr["num_coeff_blocks"]] + [d.frame_header(0)["num_coeff_blocks"] for d in cal[1:]])
     inter_blocks = max(d.frame_header(f)["num_coeff_blocks"] for d in cal for f in range(1, F)) if F > 1 else key_blocks
     ctx.sync()

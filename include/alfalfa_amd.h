@@ -113,6 +113,12 @@ void aa_parser_destroy( aa_parser * p );
 aa_status aa_parser_parse( aa_parser * p, const uint8_t * data, size_t size,
                            aa_frame_header * hdr_out, aa_mb_info * mb_out, int16_t * coeff_out );
 
+/* Decoder::set_error_concealment (decoder.hh:298; FramePlayer::set_error_concealment player.hh:72; salsify-receiver.cc:192): a frame
+ * that ends inside its first partition, or before its tag is complete, is ACCEPTED (UncompressedChunk accept_partial,
+ * uncompressed_chunk.cc:34-130) -- what is there of the first partition is used, decoders read zeros past the end, a frame
+ * without a complete tag becomes an inter frame of no bytes -- instead of AA_ERR_INVALID.  Off by default, as in the reference. */
+aa_status aa_parser_set_error_concealment( aa_parser * p, int on );
+
 /* Persistent state (DecoderState, decoder.hh:190-225), flat export for tests / serialisation:
  * probs[1101] = 1056 coefficient, 4 y-mode, 3 uv-mode, 38 mv probabilities. */
 aa_status aa_parser_get_probs( const aa_parser * p, uint8_t probs[1101] );
@@ -223,6 +229,12 @@ aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int
  * aa_launch_tokens, which takes the oldest `max_batches` deferred batches (<= 0: all).  Anything that needs a deferred
  * frame's records (aa_decode_batch, aa_stream_frame_header, aa_stream_read_records) launches its batch's tokens itself. */
 #define AA_SUBMIT_DEFER_TOKENS 1u
+/* Routing.  By default a call whose streams are fewer than the host workers it may use (and at most 96) is parsed on the HOST --
+ * one worker per stream, Parser::parse, records uploaded: the same records, sooner, because a frame on a GPU lane is a chain of
+ * seconds and one core is worth ~75 lanes (an 8-chunk bundle: 4x the rate of the GPU parser) -- and everything larger on the GPU.
+ * AA_SUBMIT_DEVICE / AA_SUBMIT_HOST force one or the other (so does the environment variable ALFALFA_AMD_ROUTE=device|host). */
+#define AA_SUBMIT_DEVICE 2u
+#define AA_SUBMIT_HOST 4u
 aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, int * frame_index_out, int threads, unsigned flags );
 aa_status aa_launch_tokens( aa_ctx * ctx, int max_batches, int * launched_out );
 /* Header of an appended frame.  For device-parsed frames the counts (num_coeff_blocks, num_intra_mbs, has_intra_mb) are known
@@ -231,6 +243,11 @@ aa_status aa_stream_frame_header( aa_stream * s, int frame_index, aa_frame_heade
 /* Test / debug view: a frame's parsed records as they sit in HBM (host- or device-parsed), copied back.  mb_out:
  * mb_width*mb_height records; coeff_out: up to coeff_capacity_blocks blocks of 16 (either may be NULL). */
 aa_status aa_stream_read_records( aa_stream * s, int frame_index, aa_mb_info * mb_out, int16_t * coeff_out, size_t coeff_capacity_blocks );
+
+/* Decoder::set_error_concealment for a stream decoder: applies to aa_stream_parse / aa_stream_decode AND to aa_submit_frames (the
+ * frame tag is read by the host pre-pass; the GPU lanes read zeros past the end of what a frame has, like the host's). */
+aa_status aa_stream_set_error_concealment( aa_stream * s, int on );
+int aa_stream_error_concealment( const aa_stream * s );
 
 /* Number of frames appended so far.  aa_stream_release_before: the caller is done with frames < first_kept -- their raster
  * handles are dropped (a raster lives on while a reference points at it: RasterHandle semantics, raster_handle.cc:113-122)
@@ -349,6 +366,7 @@ typedef struct aa_kernel_stats {
   uint64_t heap_mapped_bytes;
   uint64_t nomem_retries;   /* frames a lane handed back because the coefficient pool was empty, run again */
   uint64_t frames_evicted;  /* frames parsed ahead of their turn whose chunks were taken back for a frame needed now (parsed again later) */
+  uint64_t host_routed_frames; /* frames of aa_submit_frames calls that were parsed by host workers (few streams) */
 } aa_kernel_stats;
 aa_status aa_ctx_profile( aa_ctx * ctx, int enable );
 aa_status aa_ctx_kernel_stats( aa_ctx * ctx, aa_kernel_stats * out, int reset );

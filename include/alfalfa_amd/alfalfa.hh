@@ -693,6 +693,9 @@ public:
   References get_references() const { return References { refs_[0], refs_[1], refs_[2] }; }
   const VP8Raster & example_raster() const { return refs_[0].get(); }
   aa_stream * native_handle() const { return owner_->stream; }
+  // decoder.hh:298-299: frames that end early are accepted instead of thrown at the caller (salsify-receiver.cc:192)
+  void set_error_concealment( const bool val ) { check( aa_stream_set_error_concealment( owner_->stream, val ? 1 : 0 ) ); }
+  bool error_concealment() const { return aa_stream_error_concealment( owner_->stream ) != 0; }
 
   DecoderState get_state() const
   {
@@ -777,6 +780,7 @@ public:
   uint16_t height() const { return height_; }
   const Decoder & current_decoder() const { return decoder_; }
   Decoder & mutable_decoder() { return decoder_; }
+  void set_error_concealment( const bool value ) { decoder_.set_error_concealment( value ); }     // player.hh:72
   References current_references() const { return decoder_.get_references(); }
 };
 

@@ -6,6 +6,7 @@
  *                                        three PADDED planes Y,U,V (16-aligned dims)
  *   ref_decode --display in.ivf out.raw  only shown frames, display rectangle as planar
  *                                        I420 == tests/decode-to-stdout.cc:43-49
+ *   ref_decode --conceal in.ivf out.raw  Decoder::set_error_concealment( true ) (decoder.hh:298) first
  * stdout: one line per frame "frame <n> key=<0|1> shown=<0|1> bytes=<n>".
  * Entry points used: Decoder::get_frame_output (decoder.cc:125-135), IVF (util/ivf.cc). */
 #include <cstdio>
@@ -29,17 +30,23 @@ static void write_plane( FILE * f, const TwoD<uint8_t> & p )
 int main( int argc, char * argv[] )
 {
   try {
-    bool display = false;
+    bool display = false, conceal = false;
     int a = 1;
-    if ( argc > 1 and string( argv[ 1 ] ) == "--display" ) { display = true; a++; }
-    if ( argc - a != 2 ) { cerr << "usage: ref_decode [--display] in.ivf out.raw\n"; return 2; }
+    while ( a < argc and argv[ a ][ 0 ] == '-' ) {
+      if ( string( argv[ a ] ) == "--display" ) display = true;
+      else if ( string( argv[ a ] ) == "--conceal" ) conceal = true;
+      else break;
+      a++;
+    }
+    if ( argc - a != 2 ) { cerr << "usage: ref_decode [--display] [--conceal] in.ivf out.raw\n"; return 2; }
     IVF ivf( argv[ a ] );
     FILE * out = fopen( argv[ a + 1 ], "wb" );
     if ( not out ) { perror( "fopen" ); return 2; }
     Decoder decoder( ivf.width(), ivf.height() );
+    decoder.set_error_concealment( conceal );
     for ( unsigned i = 0; i < ivf.frame_count(); i++ ) {
       const Chunk chunk = ivf.frame( i );
-      const bool key = not ( chunk.octet() & 1 );
+      const bool key = chunk.size() and not ( chunk.octet() & 1 );
       pair<bool, RasterHandle> res = decoder.get_frame_output( chunk );
       const VP8Raster & r = res.second.get();
       if ( display ) {

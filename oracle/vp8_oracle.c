@@ -110,6 +110,7 @@ struct vp8o_decoder {
   vp8o_mb * mbs;
   uint8_t * above_nz;                      /* per MB column: 4 Y, 2 U, 2 V, 1 Y2 = 9 flags */
   int phases;
+  int conceal;                             /* Decoder::set_error_concealment (decoder.hh:298) */
   char err[160];
 };
 
@@ -158,6 +159,8 @@ void vp8o_destroy( vp8o_decoder * d )
   for ( int i = 0; i < 4; i++ ) for ( int p = 0; p < 3; p++ ) free( d->ref[i].plane[p] );
   free( d->seg.map ); free( d->mbs ); free( d->above_nz ); free( d );
 }
+void vp8o_set_error_concealment( vp8o_decoder * d, int on ) { d->conceal = on != 0; }
+
 const char * vp8o_error( const vp8o_decoder * d ) { return d->err; }
 void vp8o_set_phases( vp8o_decoder * d, int mask ) { d->phases = mask; }
 const uint8_t * vp8o_plane( const vp8o_decoder * d, int plane, int * w, int * h )
@@ -759,15 +762,33 @@ int vp8o_decode_frame( vp8o_decoder * d, const uint8_t * data, size_t size, int 
   frame_header * h = &d->hdr;
   d->err[0] = 0;
   /* ---- uncompressed chunk: uncompressed_chunk.cc:34-130 ---- */
-  if ( size < 3 ) return fail( d, VP8O_INVALID, "VP8 frame truncated" );
-  const uint32_t tag = data[0] | ( data[1] << 8 ) | ( (uint32_t) data[2] << 16 );
-  const int key = !( tag & 1 ), version = ( tag >> 1 ) & 7, show = ( tag >> 4 ) & 1;
-  const uint32_t first_len = ( tag >> 5 ) & 0x7FFFF;
-  int experimental = 0;
-  if ( version == 4 || version == 6 ) experimental = 1;
-  else if ( version != 0 ) return fail( d, VP8O_UNSUPPORTED, "VP8 version" );
-  const uint32_t first_off = key ? 10 : 3;
-  if ( size <= (size_t) first_off + first_len ) return fail( d, VP8O_INVALID, "invalid VP8 first partition length" );
+  /* accept_partial (error concealment): a first partition that reaches the end of the frame keeps what there is of it and there
+   * is no DCT data (:82-95); a frame too short for its tag (the reference's Chunk throws out_of_range, :116-127) becomes an inter
+   * frame with an empty first partition.  Nothing else: BoolDecoder::valid() never turns false on such a frame because
+   * decoder_state.hh:79,120 passes "corrupted" as complete_chunk, so the macroblock-level branches of macroblock.cc are dead. */
+  int key = 0, show = 0, experimental = 0, corrupted_frame = 0;
+  uint32_t first_off = 3, first_len = 0;
+  size_t rest_at = size;
+  if ( size >= 1 ) {
+    key = !( data[0] & 1 ); show = ( data[0] >> 4 ) & 1;
+    const int version = ( data[0] >> 1 ) & 7;
+    if ( version == 4 || version == 6 ) experimental = 1;
+    else if ( version != 0 ) return fail( d, VP8O_UNSUPPORTED, "VP8 version" );
+  }
+  if ( size < 3 ) {
+    if ( !d->conceal ) return fail( d, VP8O_INVALID, "VP8 frame truncated" );
+    corrupted_frame = 1;
+  } else {
+    const uint32_t tag = data[0] | ( data[1] << 8 ) | ( (uint32_t) data[2] << 16 );
+    first_len = ( tag >> 5 ) & 0x7FFFF;
+    first_off = key ? 10 : 3;
+    if ( size <= (size_t) first_off + first_len ) {
+      if ( !d->conceal ) return fail( d, VP8O_INVALID, "invalid VP8 first partition length" );
+      if ( size < first_off ) corrupted_frame = 1;
+      else first_len = (uint32_t) ( size - first_off );
+    } else rest_at = (size_t) first_off + first_len;
+  }
+  if ( corrupted_frame ) { key = 0; experimental = 0; first_off = 0; first_len = 0; rest_at = size; }
   if ( key ) {
     if ( data[3] != 0x9d || data[4] != 0x01 || data[5] != 0x2a ) return fail( d, VP8O_INVALID, "did not find key-frame start code" );
     const int fw = ( data[6] | ( data[7] << 8 ) ) & 0x3FFF, hs = data[7] >> 6;
@@ -776,7 +797,7 @@ int vp8o_decode_frame( vp8o_decoder * d, const uint8_t * data, size_t size, int 
     if ( experimental ) return fail( d, VP8O_INVALID, "experimental key frame" );     /* decoder_state.hh:81-83 */
   } else if ( experimental ) return fail( d, VP8O_UNSUPPORTED, "experimental" );      /* decoder.cc:131-133 */
   const uint8_t * first = data + first_off;
-  const uint8_t * rest = first + first_len; size_t rest_len = size - first_off - first_len;
+  const uint8_t * rest = data + rest_at; size_t rest_len = size - rest_at;
 
   booldec bd; bd_init( &bd, first, first_len );
   memset( h, 0, sizeof *h );

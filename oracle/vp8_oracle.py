@@ -58,6 +58,7 @@ def lib():
         L.vp8o_macroblocks.restype = C.POINTER(MB)
         L.vp8o_macroblocks.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.vp8o_get_probs.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+        L.vp8o_set_error_concealment.argtypes = [C.c_void_p, C.c_int]
         L.vp8o_get_frame_info.argtypes = [C.c_void_p, C.POINTER(FrameInfo)]
         L.vp8o_set_phases.argtypes = [C.c_void_p, C.c_int]
         L.oracle_ssim_plane.restype = C.c_double
@@ -84,6 +85,9 @@ class OracleDecoder:
     def __del__(self):
         if getattr(self, "h", None):
             self.L.vp8o_destroy(self.h); self.h = None
+
+    def set_error_concealment(self, on):
+        self.L.vp8o_set_error_concealment(self.h, int(on))
 
     def decode(self, frame_bytes):
         shown = C.c_int(0)
@@ -153,9 +157,10 @@ def ref_available():
     return os.path.exists(os.path.join(REF_DIR, "ref_decode"))
 
 
-def ref_decode(ivf_path, out_path, display=False):
-    """Run the REFERENCE decoder (oracle/_ref/ref_decode). Returns list of (key, shown) per frame."""
-    cmd = [os.path.join(REF_DIR, "ref_decode")] + (["--display"] if display else []) + [ivf_path, out_path]
+def ref_decode(ivf_path, out_path, display=False, conceal=False):
+    """Run the REFERENCE decoder (oracle/_ref/ref_decode). Returns list of (key, shown) per frame.
+    conceal: Decoder::set_error_concealment( true ) first."""
+    cmd = [os.path.join(REF_DIR, "ref_decode")] + (["--display"] if display else []) + (["--conceal"] if conceal else []) + [ivf_path, out_path]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("ref_decode failed: " + r.stderr.strip())

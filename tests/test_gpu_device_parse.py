@@ -13,6 +13,12 @@ from conftest import GOLDEN, golden_frames, sha256
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def device_route(monkeypatch):
+    """These tests are about the GPU parser: small calls would otherwise be routed to host workers (aa_submit_frames, "route")."""
+    monkeypatch.setenv("ALFALFA_AMD_ROUTE", "device")
+
+
 def assert_records_equal(got, want, what):
     gh, gmb, gcf = got
     wh, wmb, wcf = want
@@ -300,3 +306,60 @@ def test_coefficient_heap_runs_out_and_frames_are_run_again(vmm, monkeypatch):
     st = ctx.kernel_stats()
     assert st["nomem_retries"] > 0, st
     assert ctx.info()["heap_mapped_bytes"] <= 8 << 20
+
+
+def test_small_calls_are_routed_to_host_workers_and_give_the_same_records(gpu_ctx, monkeypatch):
+    """aa_submit_frames with few streams: every stream's frames are parsed by one host worker (Parser::parse) instead of a GPU
+    lane each -- same records, same rasters, counted in host_routed_frames; AA_SUBMIT_DEVICE forces the GPU parser."""
+    monkeypatch.delenv("ALFALFA_AMD_ROUTE", raising=False)
+    names = ["qcif_q30_lf24", "cif_q60_lf40s5", "synth_175x143_s3", "w200_q40_lf63s7"]
+    streams = [golden_frames(n) for n in names]
+    nf = min(len(f) for _, _, f in streams)
+    before = gpu_ctx.kernel_stats()["host_routed_frames"]
+    auto = [aa.Decoder(gpu_ctx, w, h) for w, h, _ in streams]
+    dev = [aa.Decoder(gpu_ctx, w, h) for w, h, _ in streams]
+    gpu_ctx.submit_frames([(auto[i], streams[i][2][f]) for i in range(len(names)) for f in range(nf)], threads=4)
+    assert gpu_ctx.kernel_stats()["host_routed_frames"] == before + len(names) * nf
+    gpu_ctx.submit_frames([(dev[i], streams[i][2][f]) for i in range(len(names)) for f in range(nf)], threads=4, route="device")
+    assert gpu_ctx.kernel_stats()["host_routed_frames"] == before + len(names) * nf
+    for i, n in enumerate(names):
+        for f in range(nf):
+            assert_records_equal(auto[i].read_records(f), dev[i].read_records(f), "%s frame %d" % (n, f))
+    for f in range(nf):
+        gpu_ctx.decode_batch(auto, [f] * len(names)); gpu_ctx.decode_batch(dev, [f] * len(names))
+    for i, n in enumerate(names):
+        assert sha256(auto[i].raster_bytes(nf - 1)) == sha256(dev[i].raster_bytes(nf - 1)) == GOLDEN[n]["raster_sha256"][nf - 1], n
+    # a bitstream error stops ITS stream only, on the host route as on the device route
+    w, h, frames = golden_frames("qcif_q30")
+    a, b = aa.Decoder(gpu_ctx, w, h), aa.Decoder(gpu_ctx, w, h)
+    with pytest.raises(aa.AlfalfaError):
+        gpu_ctx.submit_frames([(a, frames[0]), (a, b"\x00\x00"), (a, frames[1]), (b, frames[0]), (b, frames[1])])
+    assert a.frame_count() == 1 and b.frame_count() == 2
+
+
+@pytest.mark.parametrize("name", ["qcif_q30_lf24", "cif_q60_lf40s5"])
+def test_error_concealment_on_the_gpu_parser_and_the_host_parser(gpu_ctx, name):
+    """Decoder::set_error_concealment (decoder.hh:298): frames cut inside the first partition, at its end, or before their tag
+    is complete are accepted -- by the GPU parser (the host pre-pass reads the tag, the lanes read zeros past the end) and by the
+    host parser -- and decode to what the oracle (pinned to the reference built with the flag on, test_parser_vs_oracle.py)
+    produces; without the flag they are refused as before."""
+    from test_parser_vs_oracle import cut_for_concealment
+    w, h, frames = golden_frames(name)
+    cut = cut_for_concealment(frames)
+    plain = aa.Decoder(gpu_ctx, w, h)
+    with pytest.raises(aa.AlfalfaError) as e:
+        gpu_ctx.submit_frames([(plain, cut[0]), (plain, cut[1])])
+    assert e.value.kind == "Invalid" and plain.frame_count() == 1
+    dev, host, ora = aa.Decoder(gpu_ctx, w, h), aa.Decoder(gpu_ctx, w, h), vo.OracleDecoder(w, h)
+    for d in (dev, host, ora):
+        d.set_error_concealment(True)
+    assert dev.error_concealment()
+    idx = gpu_ctx.submit_frames([(dev, fr) for fr in cut])
+    assert idx == list(range(len(cut)))
+    for i, fr in enumerate(cut):
+        gpu_ctx.decode_batch([dev], [i])
+        shown, fi = host.get_frame_output(fr)
+        assert ora.decode(fr) == shown
+        want = ora.raster_bytes()
+        assert dev.raster_bytes(i) == want, "GPU parser, frame %d" % i
+        assert host.raster_bytes(fi) == want, "host parser, frame %d" % i

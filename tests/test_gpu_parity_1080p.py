@@ -44,7 +44,7 @@ def test_every_bench_stream_matches_the_reference_decoder(gpu_ctx, tmp_path):
     for base in range(0, len(seeds), 40):                       # 40 streams at a time: bounded memory, still a batch
         part = list(range(base, min(base + 40, len(seeds))))
         decs = [aa.Decoder(gpu_ctx, 1920, 1080) for _ in part]
-        gpu_ctx.submit_frames([(d, fr) for d, i in zip(decs, part) for fr in streams[i]])        # GPU entropy decode
+        gpu_ctx.submit_frames([(d, fr) for d, i in zip(decs, part) for fr in streams[i]], route="device")        # GPU entropy decode
         for f in range(F):
             gpu_ctx.decode_batch(decs, [f] * len(decs))
         for d, i in zip(decs, part):
@@ -68,7 +68,7 @@ def test_feature_streams_at_1080p(gpu_ctx, seed):
         ora.decode(fr)
         want.append(ora.raster_bytes())
     a, b = aa.Decoder(gpu_ctx, 1920, 1080), aa.Decoder(gpu_ctx, 1920, 1080)
-    idx = gpu_ctx.submit_frames([(a, fr) for fr in frames])
+    idx = gpu_ctx.submit_frames([(a, fr) for fr in frames], route="device")
     for f, fr in enumerate(frames):
         gpu_ctx.decode_batch([a], [idx[f]])
         _, fi = b.get_frame_output(fr)
@@ -82,7 +82,7 @@ def test_720p_configs_every_frame(gpu_ctx, config, frames):
     for seed in (300, 301, 302):
         w, h, fr = aa.read_ivf(workload.make_stream(config, frames, seed))
         ora, dec = vo.OracleDecoder(w, h), aa.Decoder(gpu_ctx, w, h)
-        idx = gpu_ctx.submit_frames([(dec, f) for f in fr])
+        idx = gpu_ctx.submit_frames([(dec, f) for f in fr], route="device")
         for i, f in enumerate(fr):
             gpu_ctx.decode_batch([dec], [idx[i]])
             ora.decode(f)
@@ -96,7 +96,7 @@ def test_realistic_inter_workload_streams(gpu_ctx):
     for seed in (100, 101, 102, 103):
         w, h, fr = aa.read_ivf(workload.make_stream("cif_inter_lf_subpel", 8, seed))
         ora, a, b = vo.OracleDecoder(w, h), aa.Decoder(gpu_ctx, w, h), aa.Decoder(gpu_ctx, w, h)
-        idx = gpu_ctx.submit_frames([(a, f) for f in fr])
+        idx = gpu_ctx.submit_frames([(a, f) for f in fr], route="device")
         for i, f in enumerate(fr):
             gpu_ctx.decode_batch([a], [idx[i]])
             _, fi = b.get_frame_output(f)

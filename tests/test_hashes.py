@@ -31,7 +31,7 @@ def test_decoder_hash_and_minihash_match_the_reference(gpu_ctx, name):
     a, b = aa.Decoder(gpu_ctx, w, h), aa.Decoder(gpu_ctx, w, h)
     for i, fr in enumerate(frames):
         a.get_frame_output(fr)                                   # host parser
-        fi = gpu_ctx.submit_frames([(b, fr)])[0]; gpu_ctx.decode_batch([b], [fi])      # GPU parser
+        fi = gpu_ctx.submit_frames([(b, fr)], route="device")[0]; gpu_ctx.decode_batch([b], [fi])      # GPU parser
         for d in (a, b):
             parts, whole = d.decoder_hash()
             assert parts == [g["state"][i], g["last"][i], g["golden"][i], g["alternative"][i]], (name, i)

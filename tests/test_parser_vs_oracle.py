@@ -84,3 +84,63 @@ def test_truncated_partition_table_is_out_of_range():
     with pytest.raises(aa.AlfalfaError) as e:
         aa.Parser(w, h).parse(cut[0])
     assert e.value.kind == "OutOfRange" and "past end of chunk" in e.value.message
+
+
+def cut_for_concealment(frames):
+    """Frames that only a decoder with error concealment accepts (Decoder::set_error_concealment, decoder.hh:298), in a stream
+    whose other frames are intact -- the state they leave behind matters to what follows:
+      frame 1  cut inside its first partition            -> CORRUPTED_FIRST_PARTITION (uncompressed_chunk.cc:82-95)
+      frame 2  cut exactly where its first partition ends -> the same (`<=`)
+      frame 3  two bytes / frame 4 no bytes / frame 5 one byte -> CORRUPTED_FRAME (:116-127)
+      a key frame (if there is a second one) cut below its 10-byte header -> CORRUPTED_FRAME, decoded as an INTER frame."""
+    out = list(frames)
+
+    def first_end(fr):
+        tag = fr[0] | (fr[1] << 8) | (fr[2] << 16)
+        return (3 if tag & 1 else 10) + ((tag >> 5) & 0x7FFFF)
+    if len(out) > 1:
+        out[1] = out[1][:max(4, first_end(out[1]) // 2)]
+    if len(out) > 2:
+        out[2] = out[2][:first_end(out[2])]
+    if len(out) > 3:
+        out[3] = out[3][:2]
+    if len(out) > 4:
+        out[4] = b""
+    if len(out) > 5:
+        out[5] = out[5][:1]
+    for i in range(6, len(out)):
+        if not out[i][0] & 1:
+            out[i] = out[i][:7]
+            break
+    return out
+
+
+@pytest.mark.parametrize("name", ["qcif_q30_lf24", "w200_q40_lf63s7", "qcif_allkey_q20", "cif_q60_lf40s5"])
+def test_error_concealment_like_the_oracle_and_the_reference(name, tmp_path):
+    """With error concealment on, the product's parser, the oracle and the REFERENCE decoder (built in place, --conceal) agree on
+    every frame of a stream with frames cut short; with it off all of them refuse those frames (Invalid)."""
+    w, h, frames = golden_frames(name)
+    cut = cut_for_concealment(frames)
+    p, d = aa.Parser(w, h), vo.OracleDecoder(w, h)
+    for fr in cut[1:6]:
+        with pytest.raises(aa.AlfalfaError) as e:
+            aa.Parser(w, h).parse(fr if fr else b"\x00"[:0] or b"")       # (a fresh parser: the tag is what is refused)
+        assert e.value.kind in ("Invalid", "BadArgument")
+    p.set_error_concealment(True); d.set_error_concealment(True)
+    rasters = []
+    for i, fr in enumerate(cut):
+        hdr, mb, cf = p.parse(fr if fr else bytes(1)[:0] + b"")
+        d.decode(fr)
+        compare(hdr, mb, cf, d.macroblocks(), d.frame_info())
+        assert (p.probs() == d.probs()).all(), i
+        rasters.append(d.raster_bytes())
+    if vo.ref_available():
+        ivf, raw = str(tmp_path / "c.ivf"), str(tmp_path / "c.raw")
+        vo.write_ivf(ivf, w, h, cut)
+        info = vo.ref_decode(ivf, raw, conceal=True)
+        data = open(raw, "rb").read()
+        fs = len(data) // len(info)
+        got = [data[i * fs:(i + 1) * fs] for i in range(len(cut))]
+        bad = [i for i in range(len(cut)) if got[i] != rasters[i]]
+        assert not bad, "frames %r differ from the reference decoder with error concealment" % bad
+        assert [s for _, s in info] == [int(bool(fr and (fr[0] >> 4) & 1)) for fr in cut]

@@ -34,7 +34,7 @@ def main():
         ctx.profile(True); ctx.kernel_stats(reset=True)
         pairs = [(d, fr) for d, st in zip(decs, streams) for fr in st[a.first:]]
         t0 = time.perf_counter()
-        ctx.submit_frames(pairs)
+        ctx.submit_frames(pairs, route="device")
         t1 = time.perf_counter()
         ctx.sync()
         t2 = time.perf_counter()
