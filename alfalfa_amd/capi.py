@@ -78,6 +78,7 @@ SYMBOLS = [
     ("aa_parser_create", C.c_int, [C.c_uint16, C.c_uint16, C.POINTER(_P)]), ("aa_parser_destroy", None, [_P]),
     ("aa_parser_parse", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(FrameHeader), _P, _P]),
     ("aa_parser_get_probs", C.c_int, [_P, _U8P]), ("aa_parser_set_error_concealment", C.c_int, [_P, C.c_int]),
+    ("aa_parse_frame_tag", C.c_int, [C.c_char_p, C.c_size_t, C.c_uint16, C.c_uint16, C.c_int] + [C.POINTER(C.c_int)] * 4),
     ("aa_stream_set_error_concealment", C.c_int, [_P, C.c_int]), ("aa_stream_error_concealment", C.c_int, [_P]),
     ("aa_parser_get_segmentation", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int8), C.POINTER(C.c_int8), _U8P]),
     ("aa_parser_get_filter_adjustments", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int8), C.POINTER(C.c_int8)]),
@@ -94,6 +95,7 @@ SYMBOLS = [
     ("aa_ctx_set_schedule", C.c_int, [_P, C.c_int]), ("aa_ctx_clear_error", C.c_int, [_P]), ("aa_ctx_compute_stream", _P, [_P]), ("aa_ctx_copy_stream", _P, [_P]),
     ("aa_stream_create", C.c_int, [_P, C.c_uint16, C.c_uint16, C.POINTER(_P)]), ("aa_stream_destroy", None, [_P]),
     ("aa_stream_parse", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(FrameHeader)]),
+    ("aa_stream_append_records", C.c_int, [_P, C.POINTER(FrameHeader), _P, _P, C.POINTER(C.c_int)]),
     ("aa_stream_upload", C.c_int, [_P]), ("aa_stream_release_staging", C.c_int, [_P]),
     ("aa_decode_batch", C.c_int, [_P, C.POINTER(_P), C.c_int, C.POINTER(C.c_int)]),
     ("aa_stream_decode", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

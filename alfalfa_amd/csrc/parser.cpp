@@ -214,6 +214,48 @@ size_t Parser::deserialize_reference( const uint8_t * in, size_t size )
   return r.at;
 }
 
+// UncompressedChunk::UncompressedChunk (uncompressed_chunk.cc:34-130).  With accept_partial (error concealment) two things that
+// otherwise reject the frame are survived instead:
+//   the first partition reaches to or past the end of the frame -> CORRUPTED_FIRST_PARTITION: it is what is left of the frame,
+//     there is no DCT data (:82-95);
+//   the frame is too short for the fields being read (the reference's Chunk throws out_of_range) -> CORRUPTED_FRAME: an inter
+//     frame, version 0, with an EMPTY first partition and no DCT data (:116-127); `show` is whatever byte 0 said, if there is one.
+FrameTag parse_frame_tag( const uint8_t * data, size_t size, uint16_t width, uint16_t height, bool accept_partial )
+{
+  FrameTag t;
+  t.rest_at = size;                            // where the DCT partitions start (size: there are none)
+  bool corrupted_frame = false;
+  if ( size >= 1 ) {
+    t.key = !( data[0] & 1 ); t.show = ( data[0] >> 4 ) & 1;
+    const unsigned version = ( data[0] >> 1 ) & 7;
+    if ( version == 4 || version == 6 ) t.experimental = true;
+    else if ( version != 0 ) throw ParseError( AA_ERR_UNSUPPORTED, "unsupported bitstream: VP8 version of " + std::to_string( version ) );
+  }
+  if ( size < 3 ) {
+    if ( !accept_partial ) throw ParseError( AA_ERR_INVALID, "invalid bitstream: VP8 frame truncated" );
+    corrupted_frame = true;
+  } else {
+    const uint32_t tag = data[0] | ( data[1] << 8 ) | ( static_cast<uint32_t>( data[2] ) << 16 );
+    t.first_len = ( tag >> 5 ) & 0x7FFFF;
+    t.first_off = t.key ? 10 : 3;
+    if ( size <= static_cast<size_t>( t.first_off ) + t.first_len ) {
+      if ( !accept_partial ) throw ParseError( AA_ERR_INVALID, "invalid bitstream: invalid VP8 first partition length" );
+      if ( size < t.first_off ) corrupted_frame = true;          // (frame( offset, size - offset ) is out of range)
+      else { t.first_len = static_cast<uint32_t>( size - t.first_off ); t.corruption = 2; }
+    } else t.rest_at = static_cast<size_t>( t.first_off ) + t.first_len;
+  }
+  if ( corrupted_frame ) { t.key = false; t.experimental = false; t.first_off = 0; t.first_len = 0; t.rest_at = size; t.corruption = 3; }
+  if ( t.key ) {
+    if ( data[3] != 0x9d || data[4] != 0x01 || data[5] != 0x2a )
+      throw ParseError( AA_ERR_INVALID, "invalid bitstream: did not find key-frame start code" );
+    const unsigned fw = ( data[6] | ( data[7] << 8 ) ) & 0x3FFF, hscale = data[7] >> 6;
+    const unsigned fh = ( data[8] | ( data[9] << 8 ) ) & 0x3FFF, vscale = data[9] >> 6;
+    if ( fw != width || fh != height || hscale || vscale )
+      throw ParseError( AA_ERR_UNSUPPORTED, "unsupported bitstream: VP8 upscaling not supported" );
+  }
+  return t;
+}
+
 void Parser::parse_header( const uint8_t * data, size_t size, aa_frame_header & hdr, FrameParams & fp )
 {
   BoolReader bd;
@@ -223,48 +265,13 @@ void Parser::parse_header( const uint8_t * data, size_t size, aa_frame_header & 
 void Parser::parse_header_impl( const uint8_t * data, size_t size, aa_frame_header & hdr, FrameParams & fp, BoolReader & bd )
 {
   // ---- frame tag + partition split: uncompressed_chunk.cc:34-130 ----
-  // With error concealment (accept_partial) two things that otherwise reject the frame are survived instead:
-  //   the first partition reaches to or past the end of the frame -> CORRUPTED_FIRST_PARTITION: it is what is left of the frame,
-  //     there is no DCT data (:82-95);
-  //   the frame is too short for the fields being read (the reference's Chunk throws out_of_range) -> CORRUPTED_FRAME: an inter
-  //     frame, version 0, with an EMPTY first partition and no DCT data (:116-127); `show` is whatever byte 0 said, if there is one.
-  bool key = false, show = false, experimental = false;
-  uint32_t first_off = 3, first_len = 0;
-  size_t rest_at = size;                       // where the DCT partitions start (size: there are none)
-  bool corrupted_frame = false;
-  if ( size >= 1 ) {
-    key = !( data[0] & 1 ); show = ( data[0] >> 4 ) & 1;
-    const unsigned version = ( data[0] >> 1 ) & 7;
-    if ( version == 4 || version == 6 ) experimental = true;
-    else if ( version != 0 ) throw ParseError( AA_ERR_UNSUPPORTED, "unsupported bitstream: VP8 version of " + std::to_string( version ) );
-  }
-  if ( size < 3 ) {
-    if ( !conceal_ ) throw ParseError( AA_ERR_INVALID, "invalid bitstream: VP8 frame truncated" );
-    corrupted_frame = true;
-  } else {
-    const uint32_t tag = data[0] | ( data[1] << 8 ) | ( static_cast<uint32_t>( data[2] ) << 16 );
-    first_len = ( tag >> 5 ) & 0x7FFFF;
-    first_off = key ? 10 : 3;
-    if ( size <= static_cast<size_t>( first_off ) + first_len ) {
-      if ( !conceal_ ) throw ParseError( AA_ERR_INVALID, "invalid bitstream: invalid VP8 first partition length" );
-      if ( size < first_off ) corrupted_frame = true;            // (frame( offset, size - offset ) is out of range)
-      else first_len = static_cast<uint32_t>( size - first_off );
-    } else rest_at = static_cast<size_t>( first_off ) + first_len;
-  }
-  if ( corrupted_frame ) { key = false; experimental = false; first_off = 0; first_len = 0; rest_at = size; }
-  if ( key ) {
-    if ( data[3] != 0x9d || data[4] != 0x01 || data[5] != 0x2a )
-      throw ParseError( AA_ERR_INVALID, "invalid bitstream: did not find key-frame start code" );
-    const unsigned fw = ( data[6] | ( data[7] << 8 ) ) & 0x3FFF, hscale = data[7] >> 6;
-    const unsigned fh = ( data[8] | ( data[9] << 8 ) ) & 0x3FFF, vscale = data[9] >> 6;
-    if ( fw != width_ || fh != height_ || hscale || vscale )
-      throw ParseError( AA_ERR_UNSUPPORTED, "unsupported bitstream: VP8 upscaling not supported" );
-    if ( experimental ) throw ParseError( AA_ERR_INVALID, "invalid bitstream: experimental key frame" );   // decoder_state.hh:81-83
-  } else if ( experimental ) {
-    throw ParseError( AA_ERR_UNSUPPORTED, "unsupported bitstream: experimental" );                         // decoder.cc:131-133
-  }
-  const uint8_t * rest = data + rest_at;
-  const size_t rest_len = size - rest_at;
+  const FrameTag t = parse_frame_tag( data, size, width_, height_, conceal_ );
+  const bool key = t.key, show = t.show;
+  if ( !key && t.experimental ) throw ParseError( AA_ERR_UNSUPPORTED, "unsupported bitstream: experimental" );    // decoder.cc:131-133
+  if ( key && t.experimental ) throw ParseError( AA_ERR_INVALID, "invalid bitstream: experimental key frame" );   // decoder_state.hh:81-83
+  const uint32_t first_off = t.first_off, first_len = t.first_len;
+  const uint8_t * rest = data + t.rest_at;
+  const size_t rest_len = size - t.rest_at;
 
   bd.reset( data + first_off, first_len );
 

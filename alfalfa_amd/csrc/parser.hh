@@ -48,6 +48,15 @@ public:
   ParseError( aa_status c, std::string m ) : code( c ), message( std::move( m ) ) {}
 };
 
+// What the first bytes of a frame say (UncompressedChunk, uncompressed_chunk.cc:34-130)
+struct FrameTag {
+  bool key = false, show = false, experimental = false;
+  int corruption = 0;                 // CorruptionLevel (uncompressed_chunk.hh:40-46): 0 none, 2 CORRUPTED_FIRST_PARTITION, 3 CORRUPTED_FRAME
+  uint32_t first_off = 3, first_len = 0;
+  size_t rest_at = 0;                 // where the DCT partitions start
+};
+FrameTag parse_frame_tag( const uint8_t * data, size_t size, uint16_t width, uint16_t height, bool accept_partial );   // throws ParseError
+
 class Parser
 {
 public:

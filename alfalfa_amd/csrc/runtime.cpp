@@ -924,6 +924,17 @@ aa_status aa_parser_parse( aa_parser * p, const uint8_t * data, size_t size, aa_
   catch ( const aa::ParseError & e ) { return fail( e.code, e.message ); }
   return AA_OK;
 }
+aa_status aa_parse_frame_tag( const uint8_t * data, size_t size, uint16_t width, uint16_t height, int accept_partial,
+                              int * key_frame, int * show_frame, int * experimental, int * corruption_level )
+{
+  if ( !data && size ) return fail( AA_ERR_ARGUMENT, "aa_parse_frame_tag: null data" );
+  try {
+    const aa::FrameTag t = aa::parse_frame_tag( data, size, width, height, accept_partial != 0 );
+    if ( key_frame ) *key_frame = t.key; if ( show_frame ) *show_frame = t.show;
+    if ( experimental ) *experimental = t.experimental; if ( corruption_level ) *corruption_level = t.corruption;
+  } catch ( const aa::ParseError & e ) { return fail( e.code, e.message ); }
+  return AA_OK;
+}
 aa_status aa_parser_set_error_concealment( aa_parser * p, int on )
 {
   if ( !p ) return fail( AA_ERR_ARGUMENT, "null parser" );
@@ -1273,9 +1284,15 @@ void aa_stream_destroy( aa_stream * s )
   if ( --ctx->refs == 0 ) ctx_free( ctx );
 }
 
-aa_status aa_stream_parse( aa_stream * s, const uint8_t * data, size_t size, int * frame_index, aa_frame_header * hdr_out )
+} // extern "C"
+namespace {
+// A frame whose records are produced on the HOST -- by the bitstream parser (aa_stream_parse) or handed in as records
+// (aa_stream_append_records) -- is staged in the stream's pinned chunk (mirrored 1:1 in HBM, uploaded by aa_stream_upload):
+// job record | macroblock records | intra row masks | coefficient blocks.  `fill` writes the header, the macroblock records and
+// the coefficient blocks into the staging area it is given (worst-case sized) or throws aa::ParseError.
+template <class Fill>
+aa_status append_host_frame( aa_stream * s, int * frame_index, aa_frame_header * hdr_out, Fill && fill )
 {
-  if ( !s || !data ) return fail( AA_ERR_ARGUMENT, "aa_stream_parse: null argument" );
   if ( aa_status st = set_device( s->ctx ) ) return st;
   const size_t nmb = size_t( s->parser.mb_width() ) * s->parser.mb_height();
   const size_t job_bytes = align_up( sizeof( aa_dev_frame ) );
@@ -1291,9 +1308,8 @@ aa_status aa_stream_parse( aa_stream * s, const uint8_t * data, size_t size, int
   unsigned long long * intra_rows = reinterpret_cast<unsigned long long *>( c->host + off + job_bytes + mb_bytes );
   int16_t * coeffs = reinterpret_cast<int16_t *>( c->host + off + job_bytes + mb_bytes + rows_bytes );
 
-  if ( aa_status st = segmap_to_host( s ) ) return st;
   FrameRec rec;
-  try { s->parser.parse( data, size, rec.hdr, mbs, coeffs ); }
+  try { fill( rec.hdr, mbs, coeffs ); }
   catch ( const aa::ParseError & e ) { return fail( e.code, e.message ); }
   const aa_frame_header & h = rec.hdr;
   c->used = off + job_bytes + mb_bytes + rows_bytes + align_up( size_t( h.num_coeff_blocks ) * 32 );   // commit what was used
@@ -1312,7 +1328,6 @@ aa_status aa_stream_parse( aa_stream * s, const uint8_t * data, size_t size, int
   if ( !h.key_frame )
     for ( size_t i = 0; i < nmb; i++ ) if ( mbs[i].y_mode == 9 /* SPLITMV */ ) { rec.has_split = true; break; }
 
-  // raster slots: output + the References this frame predicts from; then Frame::copy_to on slot ids
   fill_job( rec, job );
   job->mbs = reinterpret_cast<const aa_mb_info *>( c->dev + off + job_bytes );
   job->intra_rows = reinterpret_cast<const unsigned long long *>( c->dev + off + job_bytes + mb_bytes );
@@ -1326,6 +1341,45 @@ aa_status aa_stream_parse( aa_stream * s, const uint8_t * data, size_t size, int
   if ( frame_index ) *frame_index = fi;
   if ( hdr_out ) *hdr_out = h;
   return AA_OK;
+}
+} // namespace
+extern "C" {
+
+aa_status aa_stream_parse( aa_stream * s, const uint8_t * data, size_t size, int * frame_index, aa_frame_header * hdr_out )
+{
+  if ( !s || !data ) return fail( AA_ERR_ARGUMENT, "aa_stream_parse: null argument" );
+  if ( aa_status st = set_device( s->ctx ) ) return st;
+  if ( aa_status st = segmap_to_host( s ) ) return st;
+  return append_host_frame( s, frame_index, hdr_out, [&]( aa_frame_header & hdr, aa_mb_info * mbs, int16_t * coeffs ) { s->parser.parse( data, size, hdr, mbs, coeffs ); } );
+}
+
+/* A frame given as RECORDS, no bitstream: what Encoder::write_frame has in hand when it updates its references
+ * (encoder.cc:146-160: frame.decode + frame.loopfilter + copy_to on a Frame it holds), and what xc-enc -r replays. */
+aa_status aa_stream_append_records( aa_stream * s, const aa_frame_header * hdr, const aa_mb_info * mbs_in, const int16_t * coeffs_in, int * frame_index )
+{
+  if ( !s || !hdr || !mbs_in ) return fail( AA_ERR_ARGUMENT, "aa_stream_append_records: null argument" );
+  if ( hdr->num_coeff_blocks && !coeffs_in ) return fail( AA_ERR_ARGUMENT, "aa_stream_append_records: coefficient blocks missing" );
+  const size_t nmb = size_t( s->parser.mb_width() ) * s->parser.mb_height();
+  if ( hdr->mb_width != s->parser.mb_width() || hdr->mb_height != s->parser.mb_height() || hdr->num_macroblocks != nmb )
+    return fail( AA_ERR_ARGUMENT, "aa_stream_append_records: the header's macroblock dimensions are not this decoder's" );
+  if ( hdr->num_coeff_blocks > nmb * 25 ) return fail( AA_ERR_ARGUMENT, "aa_stream_append_records: more coefficient blocks than macroblocks can hold" );
+  // every macroblock's blocks must lie inside the array that came with it (the kernels trust coeff_index + popcount( nz_mask ))
+  uint32_t intra = 0;
+  for ( size_t i = 0; i < nmb; i++ ) {
+    const uint32_t nblk = static_cast<uint32_t>( __builtin_popcount( mbs_in[i].nz_mask & 0x1FFFFFFu ) );
+    if ( ( mbs_in[i].nz_mask >> 25 ) || ( nblk && size_t( mbs_in[i].coeff_index ) + nblk > hdr->num_coeff_blocks ) )
+      return fail( AA_ERR_ARGUMENT, "aa_stream_append_records: macroblock " + std::to_string( i ) + " points outside the coefficient blocks" );
+    if ( mbs_in[i].y_mode > 9 || mbs_in[i].uv_mode > 3 || mbs_in[i].ref_frame > 3 || mbs_in[i].segment_id > 3 || mbs_in[i].lf_level > 63 )
+      return fail( AA_ERR_ARGUMENT, "aa_stream_append_records: macroblock " + std::to_string( i ) + " has a field out of range" );
+    if ( !( mbs_in[i].flags & AA_MB_INTER ) ) intra++;
+    else if ( hdr->key_frame ) return fail( AA_ERR_ARGUMENT, "aa_stream_append_records: inter macroblock in a key frame" );
+  }
+  return append_host_frame( s, frame_index, nullptr, [&]( aa_frame_header & h, aa_mb_info * mbs, int16_t * coeffs ) {
+    h = *hdr;
+    h.num_intra_mbs = intra; h.has_intra_mb = intra != 0;
+    std::memcpy( mbs, mbs_in, nmb * sizeof( aa_mb_info ) );
+    if ( hdr->num_coeff_blocks ) std::memcpy( coeffs, coeffs_in, size_t( hdr->num_coeff_blocks ) * 32 );
+  } );
 }
 
 aa_status aa_stream_upload( aa_stream * s )

@@ -200,6 +200,25 @@ class Decoder:
         capi.check(self.L.aa_stream_parse(self.h, frame_bytes, len(frame_bytes), C.byref(fi), C.byref(hdr)))
         return fi.value, hdr.as_dict()
 
+    def append_records(self, header, mb, coeff_blocks):
+        """A frame given as records (aa_stream_append_records): header dict as frame_header() / Parser.parse() return it,
+        macroblock records, coefficient blocks [n, 16] -> frame index.  What an encoder has in hand when it updates its
+        references (Encoder::write_frame, encoder.cc:146-160)."""
+        hdr = FrameHeader()
+        for n, _ in FrameHeader._fields_:
+            if n == "quant":
+                for sgm in range(4):
+                    for k in range(6):
+                        hdr.quant[sgm][k] = header["quant"][sgm][k]
+            else:
+                setattr(hdr, n, header[n])
+        mbs = np.ascontiguousarray(mb, dtype=MB_INFO_DTYPE).reshape(-1)
+        cf = np.ascontiguousarray(coeff_blocks, dtype=np.int16).reshape(-1, 16)
+        hdr.num_coeff_blocks = len(cf)
+        fi = C.c_int()
+        capi.check(self.L.aa_stream_append_records(self.h, C.byref(hdr), mbs.ctypes.data_as(C.c_void_p), cf.ctypes.data_as(C.c_void_p), C.byref(fi)))
+        return fi.value
+
     def upload(self):
         capi.check(self.L.aa_stream_upload(self.h))
 

@@ -118,6 +118,11 @@ aa_status aa_parser_parse( aa_parser * p, const uint8_t * data, size_t size,
  * uncompressed_chunk.cc:34-130) -- what is there of the first partition is used, decoders read zeros past the end, a frame
  * without a complete tag becomes an inter frame of no bytes -- instead of AA_ERR_INVALID.  Off by default, as in the reference. */
 aa_status aa_parser_set_error_concealment( aa_parser * p, int on );
+/* UncompressedChunk( frame, expected_width, expected_height, accept_partial ) (uncompressed_chunk.cc:34-130): what the frame tag
+ * says, with the reference's checks and error classes.  corruption_level: 0 NO_CORRUPTION, 2 CORRUPTED_FIRST_PARTITION,
+ * 3 CORRUPTED_FRAME (uncompressed_chunk.hh:40-46).  Any out pointer may be NULL. */
+aa_status aa_parse_frame_tag( const uint8_t * data, size_t size, uint16_t width, uint16_t height, int accept_partial,
+                              int * key_frame, int * show_frame, int * experimental, int * corruption_level );
 
 /* Persistent state (DecoderState, decoder.hh:190-225), flat export for tests / serialisation:
  * probs[1101] = 1056 coefficient, 4 y-mode, 3 uv-mode, 38 mv probabilities. */
@@ -198,6 +203,13 @@ void aa_stream_destroy( aa_stream * s );
 
 /* Host half: parse frame into pinned staging (no GPU work). Returns the frame's index in *frame_index. */
 aa_status aa_stream_parse( aa_stream * s, const uint8_t * data, size_t size, int * frame_index, aa_frame_header * hdr_out );
+/* Append a frame given as RECORDS -- header (quantiser factors, loop-filter level, reference update flags ...), macroblock records
+ * with their final loop-filter levels, coefficient blocks in parse order -- instead of as a bitstream: the reference update of
+ * Encoder::write_frame (encoder.cc:146-160: frame.decode + frame.loopfilter + copy_to on a Frame the encoder holds) and the replay
+ * of xc-enc -r (frontend/xc-enc.cc:286-300) need no serialise -> parse round trip.  The records are what aa_parser_parse /
+ * aa_stream_read_records produce.  The stream's DecoderState is NOT advanced (it belongs to whoever made the records); the frame
+ * is decoded by aa_decode_batch like any other. */
+aa_status aa_stream_append_records( aa_stream * s, const aa_frame_header * hdr, const aa_mb_info * mbs, const int16_t * coeffs, int * frame_index );
 /* hipMemcpyAsync (copy stream) of every parsed, not yet uploaded frame's records into HBM. */
 aa_status aa_stream_upload( aa_stream * s );
 /* Give the pinned host staging of everything uploaded so far back to the system (the device copy is what decode reads).

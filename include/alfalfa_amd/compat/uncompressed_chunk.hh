@@ -1,0 +1,6 @@
+// Drop-in for the reference's "uncompressed_chunk.hh": see decoder.hh in this directory.  Everything is in alfalfa.hh.
+#pragma once
+#ifndef ALFALFA_AMD_GLOBAL_NAMES
+#define ALFALFA_AMD_GLOBAL_NAMES
+#endif
+#include "../alfalfa.hh"

@@ -363,3 +363,26 @@ def test_error_concealment_on_the_gpu_parser_and_the_host_parser(gpu_ctx, name):
         want = ora.raster_bytes()
         assert dev.raster_bytes(i) == want, "GPU parser, frame %d" % i
         assert host.raster_bytes(fi) == want, "host parser, frame %d" % i
+
+
+def test_frames_given_as_records_decode_like_their_bitstream(gpu_ctx):
+    """aa_stream_append_records: the records one decoder parsed -- on the GPU or on the host -- handed to ANOTHER decoder as
+    records (no bitstream) reconstruct to the same rasters: Encoder::write_frame's reference update without the serialise ->
+    parse round trip (encoder.cc:146-160)."""
+    for name, route in (("cif_q60_lf40s5", "device"), ("synth_175x143_s3", "host"), ("qcif_q30_lf24", "device")):
+        w, h, frames = golden_frames(name)
+        src, dst = aa.Decoder(gpu_ctx, w, h), aa.Decoder(gpu_ctx, w, h)
+        gpu_ctx.submit_frames([(src, fr) for fr in frames], route=route)
+        for i in range(len(frames)):
+            hdr, mb, cf = src.read_records(i)
+            fi = dst.append_records(hdr, mb, cf)
+            assert fi == i
+            gpu_ctx.decode_batch([src], [i]); gpu_ctx.decode_batch([dst], [fi])
+            assert sha256(dst.raster_bytes(fi)) == sha256(src.raster_bytes(i)) == GOLDEN[name]["raster_sha256"][i], (name, i)
+    w, h, frames = golden_frames("qcif_q30")
+    d = aa.Decoder(gpu_ctx, w, h)
+    hdr, mb, cf = aa.Parser(w, h).parse(frames[0])
+    bad = mb.copy(); bad.reshape(-1)[3]["coeff_index"] = 10 ** 6
+    with pytest.raises(aa.AlfalfaError) as e:
+        d.append_records(hdr, bad, cf)
+    assert e.value.kind == "BadArgument"

@@ -137,3 +137,31 @@ def test_decoder_state_members_and_flat_memory(name):
     hashes = json.load(open(os.path.join(GOLDEN_DIR, "hash_golden.json")))[name]
     first = r.stdout.splitlines()[0].split()
     assert int(first[1], 16) == hashes["minihash"][-1] and int(first[3], 16) == hashes["state"][-1]
+
+
+def build_two_step():
+    """tests/cpp/two_step_replay.cc against the compat headers (the reference's header names), like the reference's callers."""
+    from alfalfa_amd import build as b
+    b.build()
+    os.makedirs(BUILD, exist_ok=True)
+    libdir = os.path.dirname(b.LIB)
+    exe, src = os.path.join(BUILD, "two_step_replay"), os.path.join(ROOT, "tests", "cpp", "two_step_replay.cc")
+    hdr = os.path.join(ROOT, "include", "alfalfa_amd", "alfalfa.hh")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(hdr), os.path.getmtime(src), os.path.getmtime(b.LIB)):
+        subprocess.run(["g++", "-std=c++14", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include", "alfalfa_amd", "compat"),
+                        src, "-o", exe, "-L" + libdir, "-lalfalfa_amd", "-Wl,-rpath," + libdir], check=True)
+    return exe
+
+
+def test_two_step_replay_compiles_against_the_compat_headers():
+    build_two_step()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["qcif_q30_lf24", "synth_175x143_s3", "cif_q60_lf40s5"])
+def test_two_step_decode_as_xc_enc_replays_it(name):
+    """UncompressedChunk + Decoder::parse_frame<F> + Decoder::decode_frame (decoder.hh:262-270), the loop of frontend/xc-enc.cc:286-300,
+    and References( MutableRasterHandle && ): same rasters, same decoder hash as the one-step decode."""
+    exe = build_two_step()
+    r = subprocess.run([exe, os.path.join(GOLDEN_DIR, name + ".ivf")], capture_output=True, text=True)
+    assert r.returncode == 0 and "ALL OK" in r.stdout and "MISMATCH" not in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
