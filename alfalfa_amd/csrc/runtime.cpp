@@ -1579,7 +1579,9 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
     const char * route_env = std::getenv( "ALFALFA_AMD_ROUTE" );            // "device" / "host": tests and experiments; default: by size
     const bool force_device = ( flags & AA_SUBMIT_DEVICE ) || ( route_env && route_env[0] == 'd' );
     const bool force_host = ( flags & AA_SUBMIT_HOST ) || ( route_env && route_env[0] == 'h' );
-    const bool few = static_cast<int>( stream_order.size() ) <= std::min( nt, 96 );
+    // measured (round 3, 1080p, 256-core host): 1 stream 0.67 M macroblocks/s on the host route vs 0.14 M on the GPU lanes, 8 streams
+    // 4.8 M vs 2.4 M -- but 64 streams 9.8 M vs 14.9 M (64 workers do not scale on this host's memory system): the bound is 24
+    const bool few = static_cast<int>( stream_order.size() ) <= std::min( nt, 24 );
     if ( !defer_tokens && !force_device && ( force_host || few ) ) {
       std::atomic<size_t> next { 0 };
       auto work = [&]() {

@@ -241,7 +241,7 @@ aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int
  * aa_launch_tokens, which takes the oldest `max_batches` deferred batches (<= 0: all).  Anything that needs a deferred
  * frame's records (aa_decode_batch, aa_stream_frame_header, aa_stream_read_records) launches its batch's tokens itself. */
 #define AA_SUBMIT_DEFER_TOKENS 1u
-/* Routing.  By default a call whose streams are fewer than the host workers it may use (and at most 96) is parsed on the HOST --
+/* Routing.  By default a call whose streams are fewer than the host workers it may use (and at most 24) is parsed on the HOST --
  * one worker per stream, Parser::parse, records uploaded: the same records, sooner, because a frame on a GPU lane is a chain of
  * seconds and one core is worth ~75 lanes (an 8-chunk bundle: 4x the rate of the GPU parser) -- and everything larger on the GPU.
  * AA_SUBMIT_DEVICE / AA_SUBMIT_HOST force one or the other (so does the environment variable ALFALFA_AMD_ROUTE=device|host). */
