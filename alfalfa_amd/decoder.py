@@ -122,6 +122,15 @@ class Context:
         d["token_profile"] = list(st.token_profile)
         return d
 
+    def pinned_alloc(self, nbytes):
+        """Pinned host memory for asynchronous downloads (aa_pinned_alloc) -> address; free with pinned_free."""
+        p = C.c_void_p()
+        capi.check(self.L.aa_pinned_alloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def pinned_free(self, address):
+        self.L.aa_pinned_free(C.c_void_p(address))
+
     def set_schedule(self, name):
         """"rows" (default): row-pipelined persistent kernels; "diagonal": one launch per anti-diagonal."""
         capi.check(self.L.aa_ctx_set_schedule(self.h, {"rows": 0, "diagonal": 1}[name]))
@@ -304,6 +313,14 @@ class Decoder:
         y = np.empty((ph, pw), np.uint8); u = np.empty((ph // 2, pw // 2), np.uint8); v = np.empty((ph // 2, pw // 2), np.uint8)
         capi.check(self.L.aa_stream_download(self.h, frame_index, y.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
         return y, u, v
+
+    def download_async(self, frame_index, y_ptr, u_ptr, v_ptr):
+        """aa_stream_download_async: the frame's planes into PINNED host memory (Context.pinned_alloc), queued on the copy stream
+        behind what the compute stream holds now; valid after Context.download_wait()."""
+        capi.check(self.L.aa_stream_download_async(self.h, frame_index, C.c_void_p(y_ptr), C.c_void_p(u_ptr), C.c_void_p(v_ptr)))
+
+    def download_wait(self):
+        capi.check(self.L.aa_stream_download_wait(self.h))
 
     def raster_bytes(self, frame_index):
         return b"".join(p.tobytes() for p in self.raster(frame_index))

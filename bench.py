@@ -79,6 +79,8 @@ def parse_args():
     ap.add_argument("--profile-timed", action="store_true", help="HIP-event timing of every kernel INSIDE the timed region too (diagnostics)")
     ap.add_argument("--overcommit", type=float, default=1.2, help="frames are admitted while what those in flight are EXPECTED to store stays below this x the heap "
                     "(frames being parsed hold only part of it, and the oldest are released first; a lane that finds the pool empty waits)")
+    ap.add_argument("--deliver", action="store_true", help="every reconstructed frame is also DELIVERED: copied to pinned host memory (aa_stream_download_async, "
+                    "copy stream) while the next frames are decoded -- what vp8decode / xc-decode-bundle do with every shown frame; the timed region then includes PCIe")
     ap.add_argument("--trace-memory", action="store_true", help="print the context's memory books after every step of the timed region (stderr)")
     ap.add_argument("--small-batches", default="1,8,64", help="stream counts for the small-batch end-to-end figures ('' = skip)")
     return ap.parse_args()
@@ -203,6 +205,16 @@ def main():
             self.host_s = 0.0
             self.t_launch = self.t_decode = self.t_release = 0.0      # host time in aa_launch_tokens / aa_decode_batch / releases
             self.done_t = []
+            self.delivered_bytes = 0
+
+        def _deliver(self, ds, f):
+            """Frame f of every decoder of the group -> the pinned ring, behind its reconstruction, beside the next frame's."""
+            slab = deliver_ring[f & 1]
+            ds[0].download_wait()                       # the copies that used this part of the ring before are through (copy stream)
+            for i, d in enumerate(ds):
+                base = slab + i * raster_bytes
+                d.download_async(f, base, base + plane_sizes[0], base + plane_sizes[0] + plane_sizes[1])
+            self.delivered_bytes += len(ds) * raster_bytes
 
         def _submit_keys(self, g):
             t = time.perf_counter()
@@ -232,6 +244,9 @@ def main():
                 t = time.perf_counter()
                 ctx.decode_batch(ds, [f] * self.n)
                 t1 = time.perf_counter(); self.t_decode += t1 - t
+                if deliver_ring and release:
+                    self._deliver(ds, f)
+                    t1 = time.perf_counter()
                 if release:             # this frame is consumed: its records go back to the pool once the kernels queued so far
                     for d in ds:        # have run, its raster when nothing refers to it any more (RasterHandle semantics)
                         d.release_before(f + 1)
@@ -306,7 +321,9 @@ def main():
     del cal
     rec_fixed = mbs_per_frame * 84 + 4096 + 2 * 65536          # macroblock records + flags + lists; two partly filled 64-KB chunks
     key_bytes, inter_bytes = rec_fixed + key_blocks * 32, rec_fixed + inter_blocks * 32
-    raster_bytes = sum(aa.Decoder(ctx, width, height).plane_sizes())
+    plane_sizes = aa.Decoder(ctx, width, height).plane_sizes()
+    raster_bytes = sum(plane_sizes)
+    deliver_ring = [ctx.pinned_alloc(S * raster_bytes) for _ in range(2)] if args.deliver else None
     info0 = ctx.info()
     budget = hbm_budget - 2e9                                   # (arenas of the compressed frames, row-kernel work space)
     K, D = max(1, args.key_ahead), max(1, min(args.depth, args.key_ahead))
@@ -328,9 +345,14 @@ def main():
     if args.profile_timed:
         ctx.profile(True)
     t0 = time.perf_counter()
+    delivered0 = pipe.delivered_bytes
     pipe.run(args.steps)
     ctx.sync()
     elapsed = time.perf_counter() - t0
+    delivery = None
+    if args.deliver:
+        delivery = {"bytes_per_step": (pipe.delivered_bytes - delivered0) // args.steps, "gb_per_s": round((pipe.delivered_bytes - delivered0) / elapsed / 1e9, 2),
+                    "note": "every reconstructed frame copied to pinned host memory on the copy stream inside the timed region (3.13 MB per 1080p frame); `value` of THIS run includes it"}
     hbm_free, hbm_total = ctx.memory()
     tstats = ctx.kernel_stats(reset=True); ctx.profile(False)
     info = ctx.info()
@@ -577,7 +599,7 @@ def main():
                        "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective",
                        "schedule": args.schedule, "key_frames_ahead": pipe_K, "inter_frames_ahead": pipe_D, "inter_headers_ahead_of_tokens": args.header_ahead, "host_threads": threads,
                        "hbm_budget_gb": round(hbm_budget / 1e9, 1), "look_ahead_if_memory_were_free_gb": planned_need_gb, "hbm_taken_by_the_context_gb": memory["hbm_taken_by_the_context_gb"]},
-            "memory": memory, "entropy_decode_roof": lanes_roof, "macroblocks_parsed_whole_run": mbs_whole_run,
+            "memory": memory, "entropy_decode_roof": lanes_roof, "delivery": delivery, "macroblocks_parsed_whole_run": mbs_whole_run,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "kernels": roofs, "units_per_step": units, "launches_per_step": launches_per_step, "device_half": device_half,
             "steady_state": None if steady_ms is None else {"ms_per_step": round(steady_ms, 3), "value": round(world * mbs_per_step / (steady_ms * 1e-3), 1),
