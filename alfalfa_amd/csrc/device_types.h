@@ -31,6 +31,17 @@ struct aa_raster_binding {
   const uint8_t * ref[3][3];     // last, golden, altref
 };
 
+// One device-parsed frame whose coefficients are stored packed (tok_fsm.hh), as it is handed to reconstruction: the expansion
+// pass writes its dense blocks and the macroblocks' coeff_index, and points the job at the dense array.
+struct aa_expand_job {
+  aa_dev_frame * job;
+  aa_mb_info * mbs;
+  const uint32_t * packed_pos;   // [nmb]
+  const uint32_t * chunk_list;   // [0] = count, then chunk numbers
+  int16_t * dense;               // num_coeff_blocks * 16 coefficients
+  uint32_t nmb, num_coeff_blocks;
+};
+
 #define AA_MAX_XCD 16
 
 // In-launch ordering state of the row-pipelined kernels; zeroed (hipMemsetAsync) before every such launch.
@@ -77,7 +88,10 @@ int launch_segment_fixup( const ParseJob * jobs, const aa_seg_stream * streams, 
 // token workers (tok_fsm.hh, parse_kernels.hip): lanes that take frames from a queue in HBM
 void token_worker_shape( uint32_t lane_bytes, int n_cus, int * lanes_out, uint32_t * lds_out, int * wgs_per_cu_out );
 int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap & heap, uint32_t * exited, const uint32_t * retire, uint32_t gen, uint32_t spread,
-                          unsigned long long * prof, unsigned long long linger_ticks, int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, void * stream );
+                          unsigned long long * prof, unsigned long long linger_ticks, int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, bool packed, void * stream );
+// packed coefficients of n frames -> their dense arrays (k_dense_index + k_expand_coeffs); heap = the coefficient heap's base,
+// jobs = host memory the device can read, jobs_hbm = room for a copy of them in HBM
+int launch_expand_coeffs( const int16_t * heap, const aa_expand_job * jobs, aa_expand_job * jobs_hbm, int n, unsigned max_mbs, void * stream );
 int launch_enqueue_jobs( TokQueue * q, unsigned long long * slots, const ParseJob * jobs, const uint32_t * order, int n, void * stream );
 int launch_pool_push_range( const Heap & heap, uint32_t first, uint32_t count, void * stream );
 int launch_pool_free_lists( const Heap & heap, const uint32_t * const * lists, int n, void * stream );

@@ -34,6 +34,7 @@
 #include "device_types.h"
 #include "parser.hh"
 #include "tok_fsm.hh"
+#include "coeff_pack.hh"
 
 namespace {
 
@@ -117,6 +118,8 @@ struct FrameRec {
   size_t rec_bytes = 0;
   bool rec_in_arena = false;               // ... inside the device half of its batch's arena (freed with the batch)
   const uint32_t * chunk_list = nullptr;   // ... the list of coefficient chunks its token lane took (in rec_block; [0] = count)
+  aa_mb_info * dev_mbs = nullptr;          // ... its macroblock records (in rec_block)
+  const uint32_t * packed_pos = nullptr;   // ... packed coefficient storage: where every macroblock's words start (in rec_block); null: dense blocks
   volatile aa::FrameSummary * summary = nullptr;   // in the batch's pinned arena: the token lane's last word lands here
   const aa::ParseJob * parse_job = nullptr;        // in the batch's device arena
   bool enqueued = false;                   // handed to the job queue (a token lane may be writing its records)
@@ -141,6 +144,11 @@ struct aa_ctx {
   static constexpr int kBindBufs = 16;      // aa_decode_batch calls the host may run ahead of the compute stream
   BindBuf bind_bufs[kBindBufs];
   int next_bind_buf = 0;
+  // the expansion jobs of a reconstruction submission (packed coefficient storage), read by k_dense_index / k_expand_coeffs
+  // over the bus like the raster bindings
+  struct ExpandBuf { aa_expand_job * host = nullptr, * dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
+  ExpandBuf expand_bufs[kBindBufs];
+  int next_expand_buf = 0;
   // A parse batch holds its stream for as long as its longest chain (seconds for a key frame): a batch queued behind another
   // one on the same stream starts that much later.  Hence one stream per batch that can be in flight, and a batch goes to a
   // stream that has nothing queued (pick_parse_stream).
@@ -176,6 +184,11 @@ struct aa_ctx {
     uint32_t * ring = nullptr;
     int64_t chunks_committed = 0;        // chunks frames hold (parsed: what they took) or are expected to take (in flight: estimate)
     double blocks_per_byte = 1.0;        // running estimate: coefficient blocks a frame stores per byte of its compressed size (never more than 25 per macroblock)
+    // Packed coefficient storage (tok_fsm.hh): the lanes write a mask word + the non-zero coefficients of a block instead of 16
+    // coefficients; frames are expanded into a transient dense array when they are handed to reconstruction.  One format per
+    // context, fixed when the first frame is submitted (ALFALFA_AMD_PACKED=1 / aa_ctx_set_packed_coefficients).
+    bool packed = false;
+    double words_per_byte = 4.0;         // running estimate for packed frames: 16-bit words stored per compressed byte
     uint32_t seen_starving = 0;
     std::vector<const uint32_t *> pending_lists;   // chunk lists of released frames, not yet handed to k_pool_free_lists
     // worker grids: slot g = worker stream g; counters are cumulative over the grids a slot has run
@@ -307,9 +320,23 @@ void collect_pending( aa_ctx * ctx, bool wait_oldest )
   ctx->pending_free.resize( keep );
 }
 
-aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out )
+// Pieces are recycled through free lists keyed by their exact size.  Streams of one frame size ask for the same few sizes --
+// but a batch arena's size follows the compressed sizes of its frames, and a freed arena of a size nobody asks for again would
+// sit in its list for good (measured, round 3: 130 GB of pool for 45 GB of live pieces).  So pieces that get an allocation
+// of their own (more than half a slab) come in size CLASSES: a sixteenth of the next power of two (at most 6 % over).
+inline size_t pool_size_class( size_t bytes )
 {
   bytes = align_up( bytes );
+  if ( bytes <= kSlabBytes / 2 ) return bytes;
+  size_t p2 = kSlabBytes;
+  while ( p2 < bytes ) p2 <<= 1;
+  const size_t step = p2 / 16;
+  return ( bytes + step - 1 ) / step * step;
+}
+
+aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out )
+{
+  bytes = pool_size_class( bytes );
   std::lock_guard<std::mutex> g( ctx->pool_mu );
   struct Clock { aa_ctx * c; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
                  ~Clock() { c->stats.alloc_ms += std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t0 ).count(); } } clock { ctx };
@@ -356,8 +383,8 @@ void dev_free( aa_ctx * ctx, uint8_t * p, size_t bytes, bool deferred = false )
 {
   if ( !p ) return;
   std::lock_guard<std::mutex> g( ctx->pool_mu );
-  if ( deferred ) { ctx->pending_free.push_back( { p, align_up( bytes ), ctx->open_epoch } ); ctx->open_epoch_used = true; }
-  else ctx->dev_free[align_up( bytes )].push_back( p );
+  if ( deferred ) { ctx->pending_free.push_back( { p, pool_size_class( bytes ), ctx->open_epoch } ); ctx->open_epoch_used = true; }
+  else ctx->dev_free[pool_size_class( bytes )].push_back( p );
 }
 
 aa_status alloc_slot( aa_stream * s, int * out )
@@ -422,6 +449,7 @@ void drain_profile( aa_ctx * ctx )
       else if ( t.kind == 2 ) { ctx->stats.loopfilter_ms += ms; ctx->stats.loopfilter_launches++; }
       else if ( t.kind == 3 ) { ctx->stats.parse_headers_ms += ms; ctx->stats.parse_launches++; }
       else if ( t.kind == 4 ) ctx->stats.parse_tokens_ms += ms;
+      else if ( t.kind == 6 ) { ctx->stats.expand_ms += ms; ctx->stats.expand_launches++; }
       else { ctx->stats.recon_split_ms += ms; ctx->stats.recon_split_launches++; }
     }
     ctx->free_events.push_back( t.a ); ctx->free_events.push_back( t.b );
@@ -598,7 +626,9 @@ void tok_free( aa_ctx * ctx )
   if ( T.prof_dev ) (void) hipFree( T.prof_dev );
   if ( T.retire_host ) (void) hipHostFree( T.retire_host );
   if ( T.mirror_host ) (void) hipHostFree( T.mirror_host );
+  const bool packed = T.packed;
   T = aa_ctx::Tok {};
+  T.packed = packed;
 }
 
 // Launch worker workgroups if jobs are waiting and fewer workgroups are alive than the GPU holds (the mirror must be fresh).
@@ -638,7 +668,7 @@ aa_status tok_launch_workers( aa_ctx * ctx, hipEvent_t after )
   sl.gen++;
   if ( after ) HIP_TRY( hipStreamWaitEvent( sl.st, after, 0 ) );
   LaunchTimer timer( ctx, 4, sl.st );
-  if ( int e = aa::launch_token_workers( T.q, T.slots, heap_of( ctx ), T.exited_dev + g, T.retire_dev + g, sl.gen, static_cast<uint32_t>( T.cap_wgs ), T.prof_dev, T.linger_ticks, want, T.lanes, T.lane_bytes, T.lds, sl.st ) )
+  if ( int e = aa::launch_token_workers( T.q, T.slots, heap_of( ctx ), T.exited_dev + g, T.retire_dev + g, sl.gen, static_cast<uint32_t>( T.cap_wgs ), T.prof_dev, T.linger_ticks, want, T.lanes, T.lane_bytes, T.lds, T.packed, sl.st ) )
     return hip_fail( static_cast<hipError_t>( e ), "k_token_workers" );
   sl.launched += static_cast<uint32_t>( want );
   ctx->stats.worker_launches++; ctx->stats.worker_wgs += static_cast<uint64_t>( want );
@@ -755,7 +785,7 @@ void release_records( aa_stream * s, FrameRec & f, bool deferred )
     const bool has_chunks = parsed && f.chunk_list && !f.chunks_returned;
     if ( has_chunks ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->tok.pending_lists.push_back( f.chunk_list ); }
     if ( !f.rec_in_arena ) dev_free( ctx, f.rec_block, f.rec_bytes, deferred || has_chunks );
-    f.rec_block = nullptr; f.chunk_list = nullptr;
+    f.rec_block = nullptr; f.chunk_list = nullptr; f.packed_pos = nullptr;
     ctx->tok.chunks_committed -= f.est_chunks; f.est_chunks = 0;
   }
   if ( Batch * b = f.batch ) {
@@ -1049,6 +1079,7 @@ aa_status aa_ctx_create( int device, aa_ctx ** out )
   for ( auto & ps : ctx->parse_streams ) HIP_TRY( hipStreamCreateWithPriority( &ps, hipStreamNonBlocking, ctx->prio_low ) );
   for ( auto & e : ctx->parse_idle ) HIP_TRY( hipEventCreateWithFlags( &e, hipEventDisableTiming ) );
   if ( const char * e = std::getenv( "ALFALFA_AMD_SCHEDULE" ) ) ctx->schedule = std::string( e ) == "diagonal" ? 1 : 0;
+  if ( const char * e = std::getenv( "ALFALFA_AMD_PACKED" ) ) ctx->tok.packed = atoi( e ) != 0;
   // The row-pipelined kernels keep every unit on one XCD (per-XCD ticket queues indexed by the hardware XCC_ID): find
   // out which XCC ids workgroups of this device really land on.  They must be 0..n-1, each reached by a modest grid.
   {
@@ -1092,6 +1123,7 @@ static void ctx_free( aa_ctx * ctx )
   for ( auto e : ctx->free_events ) (void) hipEventDestroy( e );
   (void) hipEventDestroy( ctx->upload_done );
   for ( auto & bb : ctx->bind_bufs ) { if ( bb.host ) (void) hipHostFree( bb.host ); if ( bb.done ) (void) hipEventDestroy( bb.done ); }
+  for ( auto & eb : ctx->expand_bufs ) { if ( eb.host ) (void) hipHostFree( eb.host ); if ( eb.done ) (void) hipEventDestroy( eb.done ); }
   if ( ctx->ws ) (void) hipFree( ctx->ws );
   if ( ctx->boundary ) (void) hipFree( ctx->boundary );
   tok_free( ctx );
@@ -1176,6 +1208,7 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
   out->heap_mapped_bytes = T.heap_mapped; out->heap_limit_bytes = T.heap_va;
   out->heap_used_bytes = static_cast<uint64_t>( std::max<int64_t>( 0, T.chunks_committed ) ) * kChunkBytesHeap;
   out->heap_is_virtual = T.vmm ? 1u : 0u;
+  out->packed_coefficients = T.packed ? 1u : 0u;
   out->token_lanes_per_workgroup = static_cast<uint32_t>( T.lanes ); out->token_workgroups_capacity = static_cast<uint32_t>( T.cap_wgs );
   out->token_lane_lds_bytes = T.lane_bytes; out->token_workgroup_lds_bytes = T.lds;
   out->compute_units = static_cast<uint32_t>( T.n_cus );
@@ -1189,6 +1222,13 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
     const int32_t waiting = static_cast<int32_t>( static_cast<uint32_t>( T.jobs_enqueued ) - T.mirror_host->q_head );
     out->jobs_waiting = waiting > 0 ? static_cast<uint32_t>( waiting ) : 0u;
   }
+  return AA_OK;
+}
+aa_status aa_ctx_set_packed_coefficients( aa_ctx * ctx, int on )
+{
+  if ( !ctx ) return fail( AA_ERR_ARGUMENT, "null context" );
+  if ( ctx->tok.ready && ctx->tok.packed != ( on != 0 ) ) return fail( AA_ERR_LOGIC, "aa_ctx_set_packed_coefficients: frames have been submitted to this context already" );
+  ctx->tok.packed = on != 0;
   return AA_OK;
 }
 /* The sticky error word of the row-pipelined kernels (a bounded wait expired, a wave found itself on another XCD, a queue
@@ -1447,7 +1487,8 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
   const uint32_t flags_padded = ( nmb + 15u ) & ~15u;
   const size_t flags_bytes = align_up( flags_padded );
   const size_t list_bytes = align_up( size_t( aa::chunk_list_entries( nmb ) ) * sizeof( uint32_t ) );
-  rec.rec_bytes = mb_bytes + rows_bytes + flags_bytes + list_bytes;
+  const size_t pos_bytes = ctx->tok.packed ? align_up( size_t( nmb ) * sizeof( uint32_t ) ) : 0;
+  rec.rec_bytes = mb_bytes + rows_bytes + flags_bytes + list_bytes + pos_bytes;
   rec.rec_block = b->dev + it.rec_off; rec.rec_in_arena = true;
   uint8_t * blk = rec.rec_block;
 
@@ -1458,6 +1499,8 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
   J.intra_rows = reinterpret_cast<unsigned long long *>( blk + mb_bytes );
   J.mbflags = blk + mb_bytes + rows_bytes;
   J.chunk_list = reinterpret_cast<uint32_t *>( blk + mb_bytes + rows_bytes + flags_bytes );
+  J.packed_pos = pos_bytes ? reinterpret_cast<uint32_t *>( blk + mb_bytes + rows_bytes + flags_bytes + list_bytes ) : nullptr;
+  rec.packed_pos = J.packed_pos; rec.dev_mbs = J.mbs;
   J.summary = reinterpret_cast<aa::FrameSummary *>( b->host_dev + b->summaries_off ) + item;     // pinned + mapped: no copy back
   rec.chunk_list = J.chunk_list;
   rec.summary = reinterpret_cast<volatile aa::FrameSummary *>( b->host + b->summaries_off ) + item;
@@ -1503,8 +1546,13 @@ aa_status launch_tokens_of( aa_ctx * ctx, Batch * b )
     // what the frame is expected to store, in chunks: blocks per compressed byte as frames have turned out so far (the ratio
     // holds across key and inter frames and quantisers far better than blocks per macroblock), a margin, and the chunk its
     // lane will be filling when it ends
-    const double blocks = std::min( 25.0 * jobs_host[i].nmb, T.blocks_per_byte * 1.15 * jobs_host[i].size );
-    r.est_chunks = static_cast<uint32_t>( blocks / ( aa::kChunkBlocks - aa::kMbBlocks ) ) + 1u;
+    if ( T.packed ) {
+      const double words = std::min( double( aa::kMbWords ) * jobs_host[i].nmb, T.words_per_byte * 1.15 * jobs_host[i].size );
+      r.est_chunks = static_cast<uint32_t>( words / ( aa::kChunkWords - aa::kMbWords ) ) + 1u;
+    } else {
+      const double blocks = std::min( 25.0 * jobs_host[i].nmb, T.blocks_per_byte * 1.15 * jobs_host[i].size );
+      r.est_chunks = static_cast<uint32_t>( blocks / ( aa::kChunkBlocks - aa::kMbBlocks ) ) + 1u;
+    }
     T.chunks_committed += r.est_chunks;
     ctx->stats.parsed_macroblocks += jobs_host[i].nmb;
   }
@@ -1626,7 +1674,8 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
     const size_t words_per_row = ( s->parser.mb_width() + 63 ) / 64;
     items[i].rec_off = dev_arena;
     dev_arena += align_up( nmb * sizeof( aa_mb_info ) ) + align_up( words_per_row * s->parser.mb_height() * sizeof( unsigned long long ) )
-                 + align_up( ( nmb + 15u ) & ~size_t( 15 ) ) + align_up( size_t( aa::chunk_list_entries( static_cast<uint32_t>( nmb ) ) ) * sizeof( uint32_t ) );
+                 + align_up( ( nmb + 15u ) & ~size_t( 15 ) ) + align_up( size_t( aa::chunk_list_entries( static_cast<uint32_t>( nmb ) ) ) * sizeof( uint32_t ) )
+                 + ( ctx->tok.packed ? align_up( nmb * sizeof( uint32_t ) ) : 0 );
   }
   dev_arena = ( dev_arena + ( size_t( 16 ) << 20 ) - 1 ) & ~( ( size_t( 16 ) << 20 ) - 1 );
   b->host = pinned_get( ctx, arena, &b->host_bytes );
@@ -1792,7 +1841,7 @@ static aa_status resolve_summary( aa_stream * s, FrameRec & r )
     // chunks are returned, room is made (more heap if the memory limit allows it, else by letting everything else in flight
     // finish) and the frame goes to the queue again -- its macroblock headers are parsed already.
     ctx->stats.nomem_retries++;
-    const uint32_t worst = static_cast<uint32_t>( ( 25ull * r.hdr.num_macroblocks ) / ( aa::kChunkBlocks - aa::kMbBlocks ) ) + 2u;
+    const uint32_t worst = aa::chunk_list_entries( r.hdr.num_macroblocks );      // (what no frame of this size exceeds, in either storage format)
     {
       std::lock_guard<std::mutex> g( ctx->pool_mu );
       if ( !r.chunks_returned ) T.pending_lists.push_back( r.chunk_list );
@@ -1857,6 +1906,8 @@ static aa_status resolve_summary( aa_stream * s, FrameRec & r )
   T.chunks_committed += static_cast<int64_t>( sum->num_chunks ) - static_cast<int64_t>( r.est_chunks );
   r.est_chunks = sum->num_chunks;
   if ( r.hdr.compressed_size ) T.blocks_per_byte += 0.05 * ( static_cast<double>( sum->num_coeff_blocks ) / r.hdr.compressed_size - T.blocks_per_byte );
+  if ( r.hdr.compressed_size && r.packed_pos ) T.words_per_byte += 0.05 * ( static_cast<double>( sum->packed_words ) / r.hdr.compressed_size - T.words_per_byte );
+  if ( r.packed_pos ) { ctx->stats.packed_frames++; ctx->stats.packed_words += sum->packed_words; ctx->stats.packed_blocks += sum->num_coeff_blocks; }
   ctx->stats.token_steps += sum->steps; ctx->stats.token_frames++;
   r.summary_pending = false;
   return AA_OK;
@@ -1897,6 +1948,39 @@ aa_status aa_stream_read_records( aa_stream * s, int fi, aa_mb_info * mb_out, in
   std::vector<uint32_t> list( size_t( r.est_chunks ) + 1 );
   HIP_TRY( hipMemcpy( list.data(), r.chunk_list, list.size() * sizeof( uint32_t ), hipMemcpyDeviceToHost ) );
   if ( list[0] != r.est_chunks ) return fail( AA_ERR_LOGIC, "aa_stream_read_records: chunk list disagrees with the parse summary" );
+  if ( r.packed_pos ) {
+    // packed storage: the frame's words are expanded here as k_dense_index / k_expand_coeffs do it on the device (coeff_pack.hh)
+    std::vector<uint32_t> pos( r.hdr.num_macroblocks );
+    HIP_TRY( hipMemcpy( pos.data(), r.packed_pos, pos.size() * sizeof( uint32_t ), hipMemcpyDeviceToHost ) );
+    std::vector<std::vector<int16_t>> words( list[0] );
+    if ( coeff_out )
+      for ( uint32_t k = 0; k < list[0]; k++ ) {
+        words[k].resize( aa::kChunkWords );
+        HIP_TRY( hipMemcpy( words[k].data(), s->ctx->tok.heap + size_t( list[1 + k] ) * kChunkBytesHeap, kChunkBytesHeap, hipMemcpyDeviceToHost ) );
+      }
+    uint32_t running = 0;
+    for ( size_t mi = 0; mi < mbs.size(); mi++ ) {
+      aa_mb_info & mb = mbs[mi];
+      const uint32_t nblk = aa::pack::blocks_of( mb.nz_mask );
+      if ( nblk && coeff_out ) {
+        const uint32_t ord = pos[mi] >> 15, off = pos[mi] & ( aa::kChunkWords - 1u );
+        if ( ord >= list[0] || running + nblk > r.hdr.num_coeff_blocks )
+          return fail( AA_ERR_LOGIC, "aa_stream_read_records: a macroblock's coefficients lie outside the frame's chunks" );
+        // (a macroblock's words end inside its chunk -- the lane made sure of it; checked block by block all the same)
+        const int16_t * w = words[ord].data() + off, * end = words[ord].data() + aa::kChunkWords;
+        for ( uint32_t b = 0; b < nblk; b++ ) {
+          if ( w >= end || w + aa::pack::block_words( w ) > end ) return fail( AA_ERR_LOGIC, "aa_stream_read_records: packed coefficients run past their chunk" );
+          for ( uint32_t j = 0; j < 16; j++ ) coeff_out[( size_t( running ) + b ) * 16 + j] = aa::pack::value_at( w, j );
+          w += aa::pack::block_words( w );
+        }
+      }
+      mb.coeff_index = running;
+      running += nblk;
+    }
+    if ( running != r.hdr.num_coeff_blocks ) return fail( AA_ERR_LOGIC, "aa_stream_read_records: non-zero masks disagree with the parse summary" );
+    if ( mb_out ) std::memcpy( mb_out, mbs.data(), mbs.size() * sizeof( aa_mb_info ) );
+    return AA_OK;
+  }
   std::map<uint32_t, std::vector<uint8_t>> chunk;
   if ( coeff_out )
     for ( uint32_t k = 0; k < list[0]; k++ ) {
@@ -1957,6 +2041,47 @@ aa_status launch_lf_rows( aa_ctx * ctx, std::vector<std::pair<uint32_t, const aa
 }
 } // namespace
 
+namespace {
+// k_dense_index + k_expand_coeffs for the packed frames of a reconstruction submission (on the compute stream, in front of its
+// reconstruction kernels): every frame's dense blocks into its part of `dense`, its macroblocks' coeff_index, its job's pointer.
+aa_status expand_packed( aa_ctx * ctx, aa_stream * const * streams, const int * frame_index, const std::vector<std::pair<int, size_t>> & frames, uint8_t * piece, size_t dense_off )
+{
+  uint8_t * dense = piece + dense_off;
+  aa_ctx::ExpandBuf & eb = ctx->expand_bufs[ctx->next_expand_buf];
+  ctx->next_expand_buf = ( ctx->next_expand_buf + 1 ) % aa_ctx::kBindBufs;
+  if ( eb.busy ) { HIP_TRY( hipEventSynchronize( eb.done ) ); eb.busy = false; }
+  if ( eb.cap < frames.size() ) {
+    if ( eb.host ) (void) hipHostFree( eb.host );
+    eb.host = nullptr; eb.dev = nullptr; eb.cap = 0;
+    const size_t cap = std::max<size_t>( 512, frames.size() * 2 );
+    HIP_TRY( hipHostMalloc( reinterpret_cast<void **>( &eb.host ), cap * sizeof( aa_expand_job ), hipHostMallocDefault ) );
+    HIP_TRY( hipHostGetDevicePointer( reinterpret_cast<void **>( &eb.dev ), eb.host, 0 ) );
+    eb.cap = cap;
+  }
+  if ( !eb.done ) HIP_TRY( hipEventCreateWithFlags( &eb.done, hipEventDisableTiming ) );
+  unsigned max_mbs = 0;
+  for ( size_t k = 0; k < frames.size(); k++ ) {
+    const FrameRec & r = streams[frames[k].first]->frames[frame_index[frames[k].first]];
+    aa_expand_job & e = eb.host[k];
+    e.job = const_cast<aa_dev_frame *>( r.dev_job );
+    e.mbs = r.dev_mbs;
+    e.packed_pos = r.packed_pos; e.chunk_list = r.chunk_list;
+    e.dense = reinterpret_cast<int16_t *>( dense ) + frames[k].second * 16;
+    e.nmb = r.hdr.num_macroblocks; e.num_coeff_blocks = r.hdr.num_coeff_blocks;
+    max_mbs = std::max<unsigned>( max_mbs, e.nmb );
+  }
+  const int16_t * heap = reinterpret_cast<const int16_t *>( ctx->tok.heap );
+  for ( size_t base = 0; base < frames.size(); base += 32768 ) {          // (grid.y)
+    LaunchTimer t( ctx, 6 );
+    const int cnt = static_cast<int>( std::min<size_t>( 32768, frames.size() - base ) );
+    if ( int e = aa::launch_expand_coeffs( heap, eb.dev + base, reinterpret_cast<aa_expand_job *>( piece ) + base, cnt, max_mbs, ctx->compute ) ) return hip_fail( static_cast<hipError_t>( e ), "k_expand_coeffs" );
+  }
+  HIP_TRY( hipEventRecord( eb.done, ctx->compute ) );
+  eb.busy = true;
+  return AA_OK;
+}
+} // namespace
+
 aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, const int * frame_index )
 {
   if ( !ctx || !streams || !frame_index || n <= 0 ) return fail( AA_ERR_ARGUMENT, "aa_decode_batch: bad argument" );
@@ -1985,12 +2110,37 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
     if ( streams[i]->frames[frame_index[i]].records_released ) return fail( AA_ERR_LOGIC, "aa_decode_batch: frame records were released" );
     if ( aa_status st = resolve_summary( streams[i], streams[i]->frames[frame_index[i]] ) ) return st;
   }
+  // Packed coefficient storage: the frames of this call that were parsed on the device get their dense blocks now -- one
+  // transient piece for the call, written by k_expand_coeffs in front of the reconstruction kernels and given back behind them
+  struct Scratch { aa_ctx * c; uint8_t * p = nullptr; size_t bytes = 0; ~Scratch() { if ( p ) dev_free( c, p, bytes, true ); } } dense { ctx };
+  std::vector<std::pair<int, size_t>> packed_frames;      // (index in the call, first block in the piece)
+  size_t dense_off = 0;
+  {
+    size_t blocks = 0;
+    for ( int i = 0; i < n; i++ ) {
+      const FrameRec & r = streams[i]->frames[frame_index[i]];
+      if ( !r.packed_pos ) continue;
+      packed_frames.emplace_back( i, blocks );
+      blocks += ( size_t( r.hdr.num_coeff_blocks ) + 7 ) & ~size_t( 7 );        // (every frame's array 256-byte aligned)
+    }
+    if ( !packed_frames.empty() ) {
+      // [expansion jobs][dense blocks]; the pool recycles pieces by exact size, so the size is rounded to a few classes (a
+      // power of two up to 16 MiB, then an eighth of the next power of two)
+      dense_off = align_up( packed_frames.size() * sizeof( aa_expand_job ) );
+      size_t want = dense_off + std::max<size_t>( blocks, 8 ) * 32, cls = size_t( 64 ) << 10;
+      while ( cls < want ) cls <<= 1;
+      if ( cls > ( size_t( 16 ) << 20 ) ) { const size_t step = std::max<size_t>( size_t( 16 ) << 20, cls / 8 ); cls = ( want + step - 1 ) / step * step; }
+      dense.bytes = cls;
+      if ( aa_status st = dev_alloc( ctx, dense.bytes, &dense.p ) ) { dense.p = nullptr; return st; }
+    }
+  }
   // rasters released while binding (old references, outputs nobody holds) must not be recycled before this call's kernels
   // are queued: no release epoch is closed until then
   struct BindGuard { aa_ctx * c;
                      explicit BindGuard( aa_ctx * x ) : c( x ) { std::lock_guard<std::mutex> g( c->pool_mu ); c->binding_depth++; }
                      ~BindGuard() { std::lock_guard<std::mutex> g( c->pool_mu ); c->binding_depth--; } } bind_guard( ctx );
   if ( aa_status st = bind_batch( ctx, streams, n, frame_index ) ) return st;
+  if ( !packed_frames.empty() ) if ( aa_status st = expand_packed( ctx, streams, frame_index, packed_frames, dense.p, dense_off ) ) return st;
   // frames count as submitted only once every launch of the batch has been queued (a failed launch must not leave them
   // looking decoded)
   struct Advance { aa_stream * const * streams; int n; bool ok = false; ~Advance() { if ( ok ) for ( int i = 0; i < n; i++ ) streams[i]->next_submit++; } } advance { streams, n };

@@ -35,6 +35,17 @@
 // address it as before (heap base + 16 * index).  The chunks a frame took are listed in the frame's records (chunk_list) and
 // go back to the ring, on the device, when the frame's records are released.
 //
+// Packed coefficients (the second storage format, template parameter PK of the functions below; ALFALFA_AMD_PACKED=1 selects
+// it for a context).  Video leaves 2-4 of a stored block's 16 coefficients non-zero, so a dense block is mostly zeros: 611
+// bytes per 1080p macroblock, which is what bounds how many parsed frames a GPU can hold ahead of reconstruction.  Packed, a
+// stored block is ONE MASK WORD (bit k: zigzag position k holds a coefficient) followed by those coefficients as 16-bit
+// values in zigzag order; a macroblock's blocks follow each other in parse order as before, a macroblock never straddles a
+// chunk, and where it starts is recorded per macroblock (ParseJob::packed_pos).  The lane writes one 16-bit value per
+// coefficient and one mask word per block -- fewer stores and fewer instructions than the dense path, which zeroes 32 bytes
+// ahead of every block.  Reconstruction reads dense blocks: a frame's words are expanded into a transient dense array when
+// the frame is handed to reconstruction (coeff_pack.hh, k_expand_coeffs), macroblock by macroblock, coeff_index being set
+// then.
+//
 // Who runs a frame.  Lanes are WORKERS (k_token_workers): a lane that has finished its frame takes the next ParseJob from a
 // queue in HBM (TokQueue) at once, so a wave does not wait for its longest lane and a launch not for its longest wave.
 #pragma once
@@ -67,7 +78,7 @@ struct FrameSummary {
   uint32_t num_chunks;          // coefficient chunks the frame took (= chunk_list[0])
   uint32_t status;              // TOK_OK ...
   uint32_t done;                // 1: the token lane is through with this frame
-  uint32_t pad;
+  uint32_t packed_words;        // packed storage (see "Packed coefficients"): 16-bit words the frame's coefficients take; 0: stored dense
 };
 enum : uint32_t { TOK_OK = 0, TOK_STEP_BOUND = 1, TOK_NO_MEMORY = 2 };
 
@@ -104,7 +115,12 @@ struct CoeffPool {
 constexpr uint32_t kChunkBlocks = 2048;               // 64 KB
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
 constexpr uint32_t kMbBlocks = 26;                    // what must be left in a chunk when a macroblock starts: 25 blocks + the pre-zeroed next one
-AA_HD constexpr uint32_t chunk_list_entries( uint32_t nmb ) { return 2u + ( 25u * nmb + ( kChunkBlocks - kMbBlocks ) ) / ( kChunkBlocks - kMbBlocks + 1u ); }
+// Packed storage: a chunk is 32768 16-bit words, a macroblock takes at most 25 x (mask word + 16 values)
+constexpr uint32_t kChunkWords = kChunkBlocks * 16u;
+constexpr uint32_t kMbWords = 25u * 17u;
+// entries of a frame's chunk list ([0] = count): a chunk that is left behind holds at least 80 macroblocks' worth of dense
+// blocks ((2048 - 26 + 1) / 25) or 77 of packed words, whatever the content -- one bound for both formats
+AA_HD constexpr uint32_t chunk_list_entries( uint32_t nmb ) { return 2u + ( nmb + 75u ) / 76u; }
 
 // Jobs waiting for a token lane: slots[ticket & mask] = the ParseJob; tickets below `publish` are ready, `head` is the next
 // one to take.  Producers (k_enqueue_jobs) reserve a range, fill it, publish in order.  The host keeps fewer jobs in flight
@@ -128,6 +144,7 @@ struct alignas( 16 ) ParseJob {
   uint32_t nmb, flags_padded;   // flags_padded: multiple of 16, >= nmb
   aa_mb_info * mbs;
   uint32_t * chunk_list;        // [chunk_list_entries( nmb )]: [0] = how many coefficient chunks the frame took, then their numbers
+  uint32_t * packed_pos;        // [nmb], packed storage only: where a macroblock's words start = ordinal of the chunk in chunk_list << 15 | word in the chunk
   unsigned long long * intra_rows;
   uint8_t * mbflags;            // [flags_padded]: INTER | HAS_Y2 | SKIP of every macroblock, header kernel -> token kernel
   FrameSummary * summary;
@@ -258,6 +275,7 @@ struct Frame {
   const AA_GLOBAL uint8_t * mbflags;
   AA_GLOBAL aa_mb_info * mbs;
   AA_GLOBAL uint32_t * chunk_list;
+  AA_GLOBAL uint32_t * packed_pos;
   uint32_t data_padded, flags_padded, nmb, mbw, nparts;
   uint32_t max_steps;           // no frame of this size can take more steps: a lane that gets there stops (never a hung GPU)
 };
@@ -267,6 +285,7 @@ AA_HD inline Frame frame_of( const ParseJob * job )
   F.job = (const AA_GLOBAL ParseJob *) job;
   F.data = (const AA_GLOBAL uint8_t *) job->data; F.mbflags = (const AA_GLOBAL uint8_t *) job->mbflags;
   F.mbs = (AA_GLOBAL aa_mb_info *) job->mbs; F.chunk_list = (AA_GLOBAL uint32_t *) job->chunk_list;
+  F.packed_pos = (AA_GLOBAL uint32_t *) job->packed_pos;
   // per macroblock at most 25 blocks x 16 tokens x (11 tree nodes + 11 extra bits + sign), plus boundary steps
   const uint64_t bound = static_cast<uint64_t>( job->nmb ) * ( 25u * 16u * 23u + 4u ) + 4096u;
   F.max_steps = bound > 0xFFFFFFF0ull ? 0xFFFFFFF0u : static_cast<uint32_t>( bound );
@@ -327,6 +346,10 @@ struct Lane {
   uint32_t blk_left;              // blocks left in the chunk being filled, the current one included (0: no chunk yet)
   uint32_t nchunks;               // chunks taken so far
   unsigned long long mem_since;   // waiting for a chunk since (0: not waiting)
+  // packed storage only (then blk = where the next coefficient value goes, blk_index = first block of the chunk being filled):
+  AA_GLOBAL int16_t * hdr;        // the mask word of the block in progress (written when the block ends non-zero)
+  uint32_t zzmask;                // zigzag positions of the block in progress that hold a coefficient
+  uint32_t words;                 // words used in the chunks left behind
   // position
   uint32_t mi, col, row, part;
   uint32_t steps;
@@ -465,6 +488,15 @@ AA_HD inline void store_mb( const Frame & J, uint32_t mi, uint32_t nz_mask, uint
   mb->flags = static_cast<uint8_t>( flags );
 }
 
+// packed storage: coeff_index belongs to the expansion pass; where the macroblock's words start goes into packed_pos
+AA_HD inline void store_mb_packed( const Frame & J, uint32_t mi, uint32_t nz_mask, uint32_t pos, uint32_t flags )
+{
+  AA_GLOBAL aa_mb_info * mb = J.mbs + mi;
+  mb->nz_mask = nz_mask;
+  mb->flags = static_cast<uint8_t>( flags );
+  J.packed_pos[mi] = pos;
+}
+
 // Make block `blk` of the macroblock the current one: contexts from the non-zero flags, first probability row.
 AA_HD inline void setup_block( Lane & L, const uint8_t * smem, uint32_t blk )
 {
@@ -486,11 +518,14 @@ AA_HD inline void setup_block( Lane & L, const uint8_t * smem, uint32_t blk )
 // or the frame ends.  Everything rare lives here: row ends, partition switches, the end of the frame.
 // The lane is through with its frame: counts to the host, the chunk list closed, then -- behind a release that makes every
 // record and coefficient this lane stored visible to the whole device -- the `done` word the host polls.
-AA_HD inline void finish_frame( Lane & L, const Frame & J, uint32_t status )
+template <bool PK>
+AA_HD inline void finish_frame( Lane & L, const Frame & J, const Heap & H, uint32_t status )
 {
   J.chunk_list[0] = L.nchunks;
   AA_GLOBAL FrameSummary * sum = (AA_GLOBAL FrameSummary *) J.job->summary;
   sum->num_coeff_blocks = L.coeff_blocks;
+  if constexpr ( PK ) sum->packed_words = L.words + ( L.nchunks ? static_cast<uint32_t>( L.hdr - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) ) : 0u );
+  else sum->packed_words = 0;
   sum->steps = L.steps;
   sum->num_chunks = L.nchunks;
   sum->status = status;
@@ -506,17 +541,18 @@ AA_HD inline void finish_frame( Lane & L, const Frame & J, uint32_t status )
 
 constexpr unsigned long long kMemWaitTicks = 200000000ull;      // 2 s of the 100 MHz clock: then the frame is handed back (TOK_NO_MEMORY)
 
+template <bool PK>
 AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J, const Heap & H )
 {
   uint16_t * const above = reinterpret_cast<uint16_t *>( smem + L.base + kAbove );
   if ( L.rec == R_MBDONE ) { L.mi++; L.col++; L.rec = R_MB; }
   if ( L.steps > J.max_steps ) {             // cannot happen for any input; if it does the frame is reported, not hung on
-    finish_frame( L, J, TOK_STEP_BOUND );
+    finish_frame<PK>( L, J, H, TOK_STEP_BOUND );
     return;
   }
   for ( ;; ) {
     if ( L.mi == J.nmb ) {
-      finish_frame( L, J, TOK_OK );
+      finish_frame<PK>( L, J, H, TOK_OK );
       return;
     }
     if ( L.mi >= L.mwpos ) return;                          // flags not here yet (only a long run of skipped macroblocks gets ahead of the ring)
@@ -528,7 +564,9 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
     const uint32_t has_y2 = flags & AA_MB_HAS_Y2;
     L.ctxbits = ( L.ctxbits & 0x01FF0000u ) | above[L.col];
     if ( !( flags & AA_MB_SKIP ) ) {
-      if ( L.blk_left < kMbBlocks ) {                       // the chunk cannot take a whole macroblock: on to a new one
+      // words of the chunk in use (packed storage; hdr = the next free word)
+      const uint32_t used = PK && L.nchunks ? static_cast<uint32_t>( L.hdr - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) ) : 0u;
+      if ( PK ? ( !L.nchunks || used + kMbWords > kChunkWords ) : L.blk_left < kMbBlocks ) {   // the chunk cannot take a whole macroblock: on to a new one
         const uint32_t c = pool_take( H );
         if ( c == kNoChunk ) {
           // nothing free right now: this lane sits the steps out and asks again at the next boundary pass (its wave-mates keep
@@ -536,18 +574,26 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
           // handed back unfinished and the host runs it again when memory has been released.
           const unsigned long long now = AA_NOW();
           if ( !L.mem_since ) { L.mem_since = now | 1ull; AA_AT_ADD( &H.pool->starving, 1u ); }
-          else if ( now - L.mem_since > kMemWaitTicks ) finish_frame( L, J, TOK_NO_MEMORY );
+          else if ( now - L.mem_since > kMemWaitTicks ) finish_frame<PK>( L, J, H, TOK_NO_MEMORY );
           return;
         }
         L.mem_since = 0;
         J.chunk_list[1 + L.nchunks] = c;
         L.nchunks++;
         L.blk_index = c * kChunkBlocks;
-        L.blk = H.base + static_cast<size_t>( L.blk_index ) * 16;
-        L.blk_left = kChunkBlocks;
-        zero_slot( L.blk );
+        if constexpr ( PK ) {
+          L.words += used;
+          L.hdr = H.base + static_cast<size_t>( L.blk_index ) * 16;
+        } else {
+          L.blk = H.base + static_cast<size_t>( L.blk_index ) * 16;
+          L.blk_left = kChunkBlocks;
+          zero_slot( L.blk );
+        }
       }
-      L.mb_first = L.blk_index;
+      if constexpr ( PK ) {
+        L.mb_first = ( ( L.nchunks - 1u ) << 15 ) | static_cast<uint32_t>( L.hdr - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) );
+        L.blk = L.hdr + 1; L.zzmask = 0;
+      } else L.mb_first = L.blk_index;
       L.flags = flags; L.nz_mask = 0;
       L.ytypeaddr = L.base + kProbs + ( has_y2 ? Y_AFTER_Y2 : Y_WITHOUT_Y2 ) * 264u;
       L.yfirst = has_y2 ? 1u : 0u;
@@ -556,7 +602,8 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
     }
     L.ctxbits &= has_y2 ? 0u : 0x01000100u;                 // a non-coded Y2 leaves its chain untouched (frame.cc:255-269)
     above[L.col] = static_cast<uint16_t>( L.ctxbits );
-    store_mb( J, L.mi, 0, L.blk_index, flags | ( has_y2 ? AA_MB_LF_SKIP_INNER : 0u ) );
+    if constexpr ( PK ) store_mb_packed( J, L.mi, 0, 0, flags | ( has_y2 ? AA_MB_LF_SKIP_INNER : 0u ) );
+    else store_mb( J, L.mi, 0, L.blk_index, flags | ( has_y2 ? AA_MB_LF_SKIP_INNER : 0u ) );
     L.mi++; L.col++;
   }
 }
@@ -567,6 +614,7 @@ AA_HD inline bool at_boundary( const Lane & L ) { return L.rec == R_MBDONE || L.
 // Straight-line code: what the bit means comes out of the node's record as bit fields and is applied with arithmetic;
 // the only predicated regions are the stores.  A lone wave gets one issue slot every 4 cycles whatever the instruction, so
 // every instruction saved here is 4 cycles per bool.
+template <bool PK>
 AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
 {
   if ( L.rec < R_MBDONE ) {
@@ -601,9 +649,16 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
     L.mag = mag;
     if ( h & H_EMIT ) {                           // the sign: the token is complete (tokens.cc:126-133)
       const int32_t m = static_cast<int32_t>( mag + AA_UBFE( h, 24, 7 ) );
-      const uint32_t zz = static_cast<uint32_t>( kZigzagNib >> ( L.idx * 4 ) ) & 15u;
-      L.blk[zz] = static_cast<int16_t>( bit ? -m : m );
-      L.mag = 0; L.nonzero = 1;
+      if constexpr ( PK ) {                       // the next value of the block, its zigzag position into the mask
+        *L.blk = static_cast<int16_t>( bit ? -m : m );
+        L.blk += 1;
+        L.zzmask |= 1u << L.idx;
+        L.mag = 0;
+      } else {
+        const uint32_t zz = static_cast<uint32_t>( kZigzagNib >> ( L.idx * 4 ) ) & 15u;
+        L.blk[zz] = static_cast<int16_t>( bit ? -m : m );
+        L.mag = 0; L.nonzero = 1;
+      }
     }
     const uint32_t adv = AA_UBFE( h, 16, 1 );     // on to the next coefficient position?
     const uint32_t idx = L.idx + adv;
@@ -617,14 +672,21 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
     // in the lane's registers directly ----
     {
       if ( bend ) {
-        const uint32_t ctxbits = L.nonzero ? L.ctxbits | L.nzsel : L.ctxbits & ~L.nzsel;
-        if ( L.nonzero ) { L.coeff_blocks++; L.blk += 16; L.blk_index++; L.blk_left--; zero_slot( L.blk ); L.nz_mask |= L.blkbit; }
+        const bool nonzero = PK ? L.zzmask != 0 : L.nonzero != 0;
+        const uint32_t ctxbits = nonzero ? L.ctxbits | L.nzsel : L.ctxbits & ~L.nzsel;
+        if constexpr ( PK ) {
+          // the block's mask into the word kept for it; the word after its last value is kept for the next block
+          if ( nonzero ) { L.coeff_blocks++; *L.hdr = static_cast<int16_t>( L.zzmask ); L.hdr = L.blk; L.blk += 1; L.zzmask = 0; L.nz_mask |= L.blkbit; }
+        } else {
+          if ( nonzero ) { L.coeff_blocks++; L.blk += 16; L.blk_index++; L.blk_left--; zero_slot( L.blk ); L.nz_mask |= L.blkbit; }
+        }
         const bool mbdone = L.blkaddr == kBlockTabOff + 8 * 25;
         if ( mbdone ) {                           // the macroblock is complete: its record, its column's flags
           *lds_at<uint16_t>( smem, L.base + kAbove + 2 * L.col ) = static_cast<uint16_t>( ctxbits );
           uint32_t flags = L.flags;
           flags |= L.nz_mask ? AA_MB_HAS_NONZERO : ( ( flags & AA_MB_HAS_Y2 ) ? AA_MB_LF_SKIP_INNER : 0u );
-          store_mb( J, L.mi, L.nz_mask, L.mb_first, flags );
+          if constexpr ( PK ) store_mb_packed( J, L.mi, L.nz_mask, L.mb_first, flags );
+          else store_mb( J, L.mi, L.nz_mask, L.mb_first, flags );
         }
         // the block after it (never a Y2)
         const uint32_t a = nextblk.x & 255u, l = ( nextblk.x >> 8 ) & 255u, uv = ( nextblk.x >> 16 ) & 255u;
@@ -645,20 +707,21 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
 
 // One period of a wave: kPeriod steps, leaving the hot loop whenever a lane has reached a macroblock boundary.
 // `prof` (diagnostics, may be null): [0] += clock ticks spent in boundary passes, [1] += boundary passes, [2] += steps of the wave
+template <bool PK>
 AA_HD inline void run_period( Lane & L, uint8_t * smem, const Frame & J, const Heap & H, unsigned long long * prof = nullptr )
 {
   uint32_t it = 0;
   while ( it < kPeriod ) {
     if ( AA_ANY( at_boundary( L ) ) ) {
       const unsigned long long tb = prof ? AA_NOW() : 0ull;
-      if ( at_boundary( L ) ) macroblock_boundary( L, smem, J, H );
+      if ( at_boundary( L ) ) macroblock_boundary<PK>( L, smem, J, H );
       if ( prof ) { prof[0] += AA_NOW() - tb; prof[1]++; }
       it++;                                                 // (a lane waiting for flags must not spin the period away)
       if ( !AA_ANY( L.rec < R_MBDONE ) ) break;             // nobody has anything to decode
     }
     // leave the hot loop when a lane has completed a macroblock (asked by ALL lanes, outside the predicated step: wave-uniform)
     const uint32_t it0 = it;
-    do { step( L, smem, J ); it++; } while ( it < kPeriod && !AA_ANY( L.rec == R_MBDONE ) );
+    do { step<PK>( L, smem, J ); it++; } while ( it < kPeriod && !AA_ANY( L.rec == R_MBDONE ) );
     if ( prof ) prof[2] += it - it0;
   }
   if ( L.rec != R_DONE ) L.steps += it;                     // (an upper bound: the iterations a lane sat out count too)
@@ -696,6 +759,7 @@ AA_HD inline void begin_frame( Lane & L, uint8_t * smem, uint32_t base, const Fr
   L.ytypeaddr = L.typeaddr = L.rowaddr = L.paddr = base;
   L.blkaddr = kBlockTabOff;
   L.blk = nullptr; L.blk_index = 0; L.blk_left = 0; L.nchunks = 0; L.mem_since = 0;     // the first coded macroblock takes the first chunk
+  L.hdr = nullptr; L.zzmask = 0; L.words = 0;
   start_partition( L, smem, J, 0 );
   // flag ring: macroblocks [0, kMetaRing)
   for ( uint32_t k = 0; k < kMetaRing / 16; k++ ) {

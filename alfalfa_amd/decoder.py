@@ -114,6 +114,11 @@ class Context:
         """HBM the context may take for its pools (default: 7/8 of what was free at creation)."""
         capi.check(self.L.aa_ctx_set_memory_limit(self.h, int(nbytes)))
 
+    def set_packed_coefficients(self, on=True):
+        """Device-parsed frames store packed coefficients (mask word + non-zero values per block; expanded on the device when
+        a frame is reconstructed) instead of dense blocks.  Before the context's first submit_frames only."""
+        capi.check(self.L.aa_ctx_set_packed_coefficients(self.h, int(bool(on))))
+
     def info(self):
         """What the context holds right now (aa_ctx_info): memory by kind, token-worker shape and occupancy."""
         st = capi.CtxInfo()

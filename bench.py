@@ -79,6 +79,8 @@ def parse_args():
     ap.add_argument("--profile-timed", action="store_true", help="HIP-event timing of every kernel INSIDE the timed region too (diagnostics)")
     ap.add_argument("--overcommit", type=float, default=1.2, help="frames are admitted while what those in flight are EXPECTED to store stays below this x the heap "
                     "(frames being parsed hold only part of it, and the oldest are released first; a lane that finds the pool empty waits)")
+    ap.add_argument("--packed", action="store_true", help="device-parsed frames store PACKED coefficients (aa_ctx_set_packed_coefficients: a mask word + the non-zero "
+                    "values per block, expanded on the device when a frame is reconstructed) instead of dense 32-byte blocks")
     ap.add_argument("--deliver", action="store_true", help="every reconstructed frame is also DELIVERED: copied to pinned host memory (aa_stream_download_async, "
                     "copy stream) while the next frames are decoded -- what vp8decode / xc-decode-bundle do with every shown frame; the timed region then includes PCIe")
     ap.add_argument("--trace-memory", action="store_true", help="print the context's memory books after every step of the timed region (stderr)")
@@ -125,6 +127,8 @@ def main():
     ctx.set_schedule(args.schedule)
     hbm_budget = min(args.hbm_gb * 1e9, 0.9 * ctx.memory()[0])
     ctx.set_memory_limit(int(hbm_budget))
+    if args.packed:
+        ctx.set_packed_coefficients(True)
 
     def barrier():
         ctx.sync()
@@ -312,7 +316,8 @@ def main():
     ctx.submit_frames([(cal[0], streams[0][0])], threads, route="device")
     key_hdr = cal[0].frame_header(0)                     # waits for the parse
     t_lone_key = time.perf_counter() - t0
-    lone_steps = ctx.kernel_stats(reset=True)["token_steps"]
+    lone_stats = ctx.kernel_stats(reset=True)
+    lone_steps = lone_stats["token_steps"]
     ctx.submit_frames([(d, st[0]) for d, st in zip(cal[1:], streams[1:])] + [(d, fr) for d, st in zip(cal, streams) for fr in st[1:]], threads, route="device")
     key_blocks = max([key_hdr["num_coeff_blocks"]] + [d.frame_header(0)["num_coeff_blocks"] for d in cal[1:]])
     inter_blocks = max(d.frame_header(f)["num_coeff_blocks"] for d in cal for f in range(1, F)) if F > 1 else key_blocks
@@ -321,6 +326,17 @@ def main():
     del cal
     rec_fixed = mbs_per_frame * 84 + 4096 + 2 * 65536          # macroblock records + flags + lists; two partly filled 64-KB chunks
     key_bytes, inter_bytes = rec_fixed + key_blocks * 32, rec_fixed + inter_blocks * 32
+    packed_storage = None
+    if args.packed:
+        # bytes a stored block takes, key and inter frames apart (a key frame's blocks are nearly full, an inter frame's hold 2-4 values)
+        rest = ctx.kernel_stats()
+        key_bpb = 2.0 * lone_stats["packed_words"] / max(1, lone_stats["packed_blocks"])
+        rest_keys = len(streams[1:min(4, S)])
+        inter_words = rest["packed_words"] - rest_keys * lone_stats["packed_words"]
+        inter_blks = rest["packed_blocks"] - rest_keys * lone_stats["packed_blocks"]
+        inter_bpb = 2.0 * inter_words / inter_blks if inter_blks > 0 and inter_words > 0 else key_bpb
+        key_bytes, inter_bytes = int(rec_fixed + mbs_per_frame * 4 + key_blocks * key_bpb), int(rec_fixed + mbs_per_frame * 4 + inter_blocks * inter_bpb)
+        packed_storage = {"key_frame_bytes_per_block": round(key_bpb, 2), "inter_frame_bytes_per_block": round(inter_bpb, 2), "dense_bytes_per_block": 32}
     plane_sizes = aa.Decoder(ctx, width, height).plane_sizes()
     raster_bytes = sum(plane_sizes)
     deliver_ring = [ctx.pinned_alloc(S * raster_bytes) for _ in range(2)] if args.deliver else None
@@ -380,6 +396,7 @@ def main():
               "hbm_taken_by_the_context_gb": round((info["pool_bytes"] + (info["heap_mapped_bytes"] if info["heap_is_virtual"] else 0)) / 1e9, 2),
               "pinned_host_gb": round(info["pinned_host_bytes"] / 1e9, 2), "heap_is_virtual": bool(info["heap_is_virtual"]),
               "hbm_in_use_on_device_gb": round((hbm_total - hbm_free) / 1e9, 1),
+              "packed_storage": packed_storage,
               "planned": {"key_frame_bytes": key_bytes, "inter_frame_bytes": inter_bytes, "key_blocks_per_mb": round(key_blocks / mbs_per_frame, 2), "inter_blocks_per_mb": round(inter_blocks / mbs_per_frame, 2)}}
     if args.profile_timed:
         timed_region["kernel_ms_per_step"] = {k: round(v / args.steps, 2) for k, v in tstats.items() if k.endswith("_ms") and "wait" not in k}
@@ -598,7 +615,8 @@ def main():
                        "streams_per_gpu": S, "frames_per_stream": F, "macroblocks_per_step_per_gpu": mbs_per_step,
                        "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective",
                        "schedule": args.schedule, "key_frames_ahead": pipe_K, "inter_frames_ahead": pipe_D, "inter_headers_ahead_of_tokens": args.header_ahead, "host_threads": threads,
-                       "hbm_budget_gb": round(hbm_budget / 1e9, 1), "look_ahead_if_memory_were_free_gb": planned_need_gb, "hbm_taken_by_the_context_gb": memory["hbm_taken_by_the_context_gb"]},
+                       "hbm_budget_gb": round(hbm_budget / 1e9, 1), "look_ahead_if_memory_were_free_gb": planned_need_gb, "hbm_taken_by_the_context_gb": memory["hbm_taken_by_the_context_gb"],
+                       "coefficient_storage": "packed" if args.packed else "dense"},
             "memory": memory, "entropy_decode_roof": lanes_roof, "delivery": delivery, "macroblocks_parsed_whole_run": mbs_whole_run,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "kernels": roofs, "units_per_step": units, "launches_per_step": launches_per_step, "device_half": device_half,

@@ -188,8 +188,17 @@ typedef struct aa_ctx_info {
    * that have left, in 10-ns ticks: [0] macroblock-boundary passes [1] how many [2] decode steps of waves [3] looking for /
    * starting frames [4] ring top-ups [5] periods (steps + boundary passes) [6] lane-periods that had a frame [7] periods */
   uint64_t token_profile[8];
+  uint32_t packed_coefficients;      /* 1: device-parsed frames store packed coefficients (aa_ctx_set_packed_coefficients) */
+  uint32_t reserved0;
 } aa_ctx_info;
 aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out );
+/* How the device parser stores a frame's coefficients until the frame is reconstructed.  0 (default): dense, 32 bytes per
+ * non-zero 4x4 block.  1: packed -- one mask word + the block's non-zero coefficients (about a third of the memory on video
+ * content, and fewer stores for the token lanes); aa_decode_batch expands the frames it is given into a transient dense array
+ * on the device before reconstructing them.  Results are identical.  The choice is per context and can only be made before
+ * the context's first aa_submit_frames call (AA_ERR_LOGIC afterwards); the environment variable ALFALFA_AMD_PACKED=1 makes
+ * packed the default. */
+aa_status aa_ctx_set_packed_coefficients( aa_ctx * ctx, int on );
 /* hipStream_t handles as opaque pointers (to order foreign work, e.g. an RCCL broadcast, against ours) */
 void * aa_ctx_compute_stream( aa_ctx * ctx );
 void * aa_ctx_copy_stream( aa_ctx * ctx );
@@ -379,6 +388,10 @@ typedef struct aa_kernel_stats {
   uint64_t nomem_retries;   /* frames a lane handed back because the coefficient pool was empty, run again */
   uint64_t frames_evicted;  /* frames parsed ahead of their turn whose chunks were taken back for a frame needed now (parsed again later) */
   uint64_t host_routed_frames; /* frames of aa_submit_frames calls that were parsed by host workers (few streams) */
+  /* packed coefficient storage (aa_ctx_set_packed_coefficients) */
+  double expand_ms;         /* k_dense_index + k_expand_coeffs (profile on) */
+  uint64_t expand_launches;
+  uint64_t packed_frames, packed_words, packed_blocks;   /* frames stored packed, the 16-bit words they took, the dense blocks they stand for */
 } aa_kernel_stats;
 aa_status aa_ctx_profile( aa_ctx * ctx, int enable );
 aa_status aa_ctx_kernel_stats( aa_ctx * ctx, aa_kernel_stats * out, int reset );

@@ -13,12 +13,14 @@
 #include "../../alfalfa_amd/csrc/bool_reader.hh"
 #include "../../alfalfa_amd/csrc/parser.hh"
 #include "../../alfalfa_amd/csrc/tok_fsm.hh"
+#include "../../alfalfa_amd/csrc/coeff_pack.hh"
 
 namespace {
 struct Sim {
   aa::Parser parser;
   uint32_t pool_chunks = 0;        // coefficient chunks the pool offers per frame (0: plenty)
-  uint32_t last_status = 0, last_chunks = 0;
+  bool packed = false;             // the lanes store packed coefficients (tok_fsm.hh), expanded below as k_dense_index / k_expand_coeffs do
+  uint32_t last_status = 0, last_chunks = 0, last_words = 0;
   std::vector<uint8_t> segmap;     // the stream's persistent segment map as the device keeps it
   Sim( uint16_t w, uint16_t h ) : parser( w, h ), segmap( size_t( parser.mb_width() ) * parser.mb_height(), 3 ) {}
 };
@@ -49,6 +51,7 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
   J.mbflags = static_cast<uint8_t *>( aligned( J.flags_padded ) );
   J.mbs = static_cast<aa_mb_info *>( aligned( nmb * sizeof( aa_mb_info ) ) );
   J.chunk_list = static_cast<uint32_t *>( aligned( size_t( aa::chunk_list_entries( nmb ) ) * 4 ) );
+  J.packed_pos = S.packed ? static_cast<uint32_t *>( aligned( size_t( nmb ) * 4 ) ) : nullptr;
   // the coefficient heap as the runtime sets it up: chunks handed out through the pool's ring -- here in an order that is
   // neither ascending nor contiguous, and with `pool_chunks` of them only (0: as many as the worst case needs)
   const uint32_t worst_chunks = aa::chunk_list_entries( nmb ) - 1;
@@ -105,10 +108,11 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
     for ( ;; ) {
       aa::tok::top_up( L, smem, F );
       if ( L.rec == aa::tok::R_DONE ) break;
-      aa::tok::run_period( L, smem, F, H );
+      if ( S.packed ) aa::tok::run_period<true>( L, smem, F, H );
+      else aa::tok::run_period<false>( L, smem, F, H );
     }
   }
-  S.last_status = sum.status; S.last_chunks = sum.num_chunks;
+  S.last_status = sum.status; S.last_chunks = sum.num_chunks; S.last_words = sum.packed_words;
   int bad = 0;
   if ( !sum.done || J.chunk_list[0] != sum.num_chunks ) bad = 1;
   if ( getenv( "FSM_SIM_DEBUG" ) ) fprintf( stderr, "done %u list0 %u chunks %u avail %d of %u status %u blocks %u\n", sum.done, J.chunk_list[0], sum.num_chunks, pool.avail, avail_chunks, sum.status, sum.num_coeff_blocks );
@@ -122,7 +126,35 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
   std::memcpy( mbs, J.mbs, nmb * sizeof( aa_mb_info ) );
   // the frame's own view of its coefficients (what aa_stream_read_records gives): blocks back to back in parse order,
   // coeff_index counted from the frame's first block; every macroblock's blocks must lie inside one of the frame's chunks
-  if ( sum.status == aa::TOK_OK ) {
+  if ( sum.status == aa::TOK_OK && S.packed ) {
+    // k_dense_index: coeff_index = blocks stored before the macroblock; k_expand_coeffs: every macroblock's words -> dense blocks
+    uint32_t running = 0, words = 0;
+    for ( uint32_t mi = 0; mi < nmb; mi++ ) {
+      const uint32_t nblk = aa::pack::blocks_of( mbs[mi].nz_mask );
+      mbs[mi].coeff_index = running;
+      if ( nblk ) {
+        const uint32_t pos = J.packed_pos[mi], ord = pos >> 15, off = pos & ( aa::kChunkWords - 1u );
+        if ( ord >= sum.num_chunks || running + nblk > sum.num_coeff_blocks ) { bad = 1; break; }
+        const int16_t * w = heap_mem + aa::pack::word_offset( pos, J.chunk_list );
+        // 16 lanes, one raster position each, as the kernel does it
+        const int16_t * wb = w;
+        for ( uint32_t b = 0; b < nblk; b++ ) {
+          for ( uint32_t j = 0; j < 16; j++ ) coeffs[( size_t( running ) + b ) * 16 + j] = aa::pack::value_at( wb, j );
+          wb += aa::pack::block_words( wb );
+        }
+        // ... and the host-side form (aa_stream_read_records) must say the same
+        std::vector<int16_t> again( size_t( nblk ) * 16 );
+        const uint32_t used = aa::pack::expand_macroblock( w, mbs[mi].nz_mask, again.data() );
+        if ( used != static_cast<uint32_t>( wb - w ) || std::memcmp( again.data(), coeffs + size_t( running ) * 16, again.size() * 2 ) ) bad = 1;
+        if ( off + used > aa::kChunkWords ) bad = 1;          // a macroblock never straddles a chunk
+        words += used;
+      }
+      running += nblk;
+    }
+    if ( running != sum.num_coeff_blocks ) bad = 1;
+    // the lane's word count: what the macroblocks took + what was left unused at the end of the chunks it moved on from
+    if ( sum.packed_words < words || sum.packed_words > words + sum.num_chunks * aa::kMbWords ) bad = 1;
+  } else if ( sum.status == aa::TOK_OK ) {
     uint32_t running = 0;
     for ( uint32_t mi = 0; mi < nmb; mi++ ) {
       const uint32_t nblk = static_cast<uint32_t>( __builtin_popcount( mbs[mi].nz_mask ) );
@@ -137,13 +169,14 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
       running += nblk;
     }
     if ( running != sum.num_coeff_blocks ) bad = 1;
+    if ( sum.packed_words ) bad = 1;
   }
   // the intra row masks must say what the records say
   for ( unsigned row = 0; row < J.fp.mbh; row++ ) for ( unsigned col = 0; col < J.fp.mbw; col++ ) {
     const bool bit = ( J.intra_rows[row * words_per_row + ( col >> 6 )] >> ( col & 63 ) ) & 1;
     if ( bit != !( J.mbs[row * J.fp.mbw + col].flags & AA_MB_INTER ) ) bad = 1;
   }
-  free( dev_data ); free( J.mbflags ); free( J.mbs ); free( J.chunk_list ); free( heap_mem ); free( J.intra_rows );
+  free( dev_data ); free( J.mbflags ); free( J.mbs ); free( J.chunk_list ); free( J.packed_pos ); free( heap_mem ); free( J.intra_rows );
   if ( sum.status != aa::TOK_OK ) return 200 + static_cast<int>( sum.status );
   return bad ? 100 : 0;
 }
@@ -170,6 +203,9 @@ int fsm_sim_handover_check( const uint8_t * data, size_t size, int n, int look )
 // with TOK_NO_MEMORY (fsm_sim_frame returns 202)
 void fsm_sim_set_pool_chunks( void * handle, uint32_t chunks ) { static_cast<Sim *>( handle )->pool_chunks = chunks; }
 uint32_t fsm_sim_last_chunks( void * handle ) { return static_cast<Sim *>( handle )->last_chunks; }
+// the lanes store packed coefficients from the next frame on (expanded before they are returned)
+void fsm_sim_set_packed( void * handle, int on ) { static_cast<Sim *>( handle )->packed = on != 0; }
+uint32_t fsm_sim_last_words( void * handle ) { return static_cast<Sim *>( handle )->last_words; }
 
 // persistent state for comparison with the host parser's
 void fsm_sim_segmap( void * handle, uint8_t * out ) { Sim & S = *static_cast<Sim *>( handle ); std::memcpy( out, S.segmap.data(), S.segmap.size() ); }

@@ -21,7 +21,7 @@ CSRC = os.path.join(ROOT, "alfalfa_amd", "csrc")
 
 def sim_lib():
     srcs = [os.path.join(ROOT, "tests", "cpp", "fsm_sim.cc"), os.path.join(CSRC, "parser.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("tok_fsm.hh", "parse_common.hh", "parser.hh", "bool_reader.hh")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("tok_fsm.hh", "coeff_pack.hh", "parse_common.hh", "parser.hh", "bool_reader.hh")]
     os.makedirs(BUILD, exist_ok=True)
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps):
         subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wextra", "-fPIC", "-shared"] + srcs + ["-o", LIB], check=True)
@@ -36,13 +36,17 @@ def sim_lib():
     L.fsm_sim_set_pool_chunks.argtypes = [C.c_void_p, C.c_uint32]
     L.fsm_sim_last_chunks.argtypes = [C.c_void_p]
     L.fsm_sim_last_chunks.restype = C.c_uint32
+    L.fsm_sim_set_packed.argtypes = [C.c_void_p, C.c_int]
+    L.fsm_sim_last_words.argtypes = [C.c_void_p]
+    L.fsm_sim_last_words.restype = C.c_uint32
     return L
 
 
 class Sim:
-    def __init__(self, w, h):
+    def __init__(self, w, h, packed=False):
         self.L = sim_lib()
         self.h = self.L.fsm_sim_create(w, h)
+        self.L.fsm_sim_set_packed(self.h, int(packed))
         self.mbw, self.mbh = (w + 15) // 16, (h + 15) // 16
         n = self.mbw * self.mbh
         self.mb = np.zeros(n, dtype=capi.MB_INFO_DTYPE)
@@ -69,8 +73,8 @@ class Sim:
         return out
 
 
-def check_stream(w, h, frames):
-    host, sim = aa.Parser(w, h), Sim(w, h)
+def check_stream(w, h, frames, packed=False):
+    host, sim = aa.Parser(w, h), Sim(w, h, packed)
     for i, fr in enumerate(frames):
         hh, hmb, hcf = host.parse(fr)
         sh, smb, scf, steps = sim.frame(fr)
@@ -88,27 +92,34 @@ def check_stream(w, h, frames):
         assert steps != 0xFFFFFFFF          # (the step bound of the frame size was not hit)
 
 
+FORMATS = pytest.mark.parametrize("packed", [False, True], ids=["dense", "packed"])
+
+
+@FORMATS
 @pytest.mark.parametrize("name", sorted(GOLDEN))
-def test_device_algorithm_matches_host_parser_on_goldens(name):
-    check_stream(*golden_frames(name))
+def test_device_algorithm_matches_host_parser_on_goldens(name, packed):
+    check_stream(*golden_frames(name), packed=packed)
 
 
+@FORMATS
 @pytest.mark.parametrize("seed", list(range(200, 264)))       # (200..223 are the seeds the GPU runs too)
-def test_device_algorithm_matches_host_parser_on_synthetic_feature_streams(seed):
+def test_device_algorithm_matches_host_parser_on_synthetic_feature_streams(seed, packed):
     import vp8_synth
     sizes = [(96, 80), (33, 17), (64, 64), (175, 143), (16, 16), (200, 48), (320, 176), (48, 256)]
     w, h = sizes[seed % len(sizes)]
-    check_stream(w, h, vp8_synth.feature_stream(w, h, seed, 8).frames)
+    check_stream(w, h, vp8_synth.feature_stream(w, h, seed, 8).frames, packed=packed)
 
 
+@FORMATS
 @pytest.mark.parametrize("name", ["qcif_q30_lf24", "w200_q40_lf63s7", "qcif_allkey_q20"])
-def test_device_algorithm_matches_host_parser_on_truncated_frames(name):
+def test_device_algorithm_matches_host_parser_on_truncated_frames(name, packed):
     from test_parser_vs_oracle import truncated
     w, h, frames = golden_frames(name)
-    check_stream(w, h, truncated(frames))
+    check_stream(w, h, truncated(frames), packed=packed)
 
 
-def test_device_algorithm_on_long_runs_of_skipped_macroblocks():
+@FORMATS
+def test_device_algorithm_on_long_runs_of_skipped_macroblocks(packed):
     """A token lane learns about macroblocks through a 64-entry flag ring topped up every 64 steps; skipped macroblocks take no
     steps, so long runs of them outrun the ring and the lane has to wait for it (tok::macroblock_boundary)."""
     import vp8_synth
@@ -117,13 +128,14 @@ def test_device_algorithm_on_long_runs_of_skipped_macroblocks():
         s.frame(key=True, q_index=30, skip_prob=3, density=density, skip_rate=1.0, intra_bpred=0.2)
         for k in range(3):
             s.frame(key=False, q_index=30, skip_prob=2 + k, density=density, skip_rate=1.0, log2_parts=k % 3, lf_level=8)
-        check_stream(w, h, s.frames)
+        check_stream(w, h, s.frames, packed=packed)
 
 
-def test_device_algorithm_on_extreme_geometries():
+@FORMATS
+def test_device_algorithm_on_extreme_geometries(packed):
     import vp8_synth
     for w, h, seed in ((16, 4096, 901), (4096, 16, 902), (24, 1000, 903), (2000, 32, 904)):
-        check_stream(w, h, vp8_synth.feature_stream(w, h, seed, 3).frames)
+        check_stream(w, h, vp8_synth.feature_stream(w, h, seed, 3).frames, packed=packed)
 
 
 def test_bool_decoder_hand_over_between_window_widths():
@@ -136,12 +148,13 @@ def test_bool_decoder_hand_over_between_window_widths():
         assert L.fsm_sim_handover_check(data, size, min(8 * size + 40, 1500), 64) == 0, size
 
 
-def test_device_algorithm_on_a_1080p_bench_stream():
+@FORMATS
+def test_device_algorithm_on_a_1080p_bench_stream(packed):
     """A stream of the benchmark workload (the reference encoder's output at 1920x1080)."""
     import workload
     if not workload.have_reference_tools():
         pytest.skip("oracle/_ref (stream generator) not built")
-    check_stream(*aa.read_ivf(workload.make_stream("1080p_inter_lf", 3, 105)))
+    check_stream(*aa.read_ivf(workload.make_stream("1080p_inter_lf", 3, 105)), packed=packed)
 
 
 def test_coefficient_pool_runs_dry_and_the_frame_is_handed_back():
