@@ -559,6 +559,12 @@ def main():
             dt_host = time.perf_counter() - t0
             small[str(n)] = {"mb_per_s": round(n * F * mbs_per_frame / dt, 1), "ms_per_step": round(dt * 1e3, 2),
                              "route": "host workers, one per stream (aa_submit_frames, few streams)" if host_routed else "GPU token lanes"}
+            # the figure above is empty pipeline -> empty pipeline over `reps` steps (it pays for the first key-frame chain); between
+            # fill and drain: the mean interval of the hand-overs after the first one of the timed run
+            done = p.done_t[-reps:]
+            if len(done) == reps and reps > 1 and done[-1] > done[0]:
+                small[str(n)]["between_fill_and_drain_mb_per_s"] = round(n * F * mbs_per_frame * (reps - 1) / (done[-1] - done[0]), 1)
+                small[str(n)]["steps_timed"] = reps
             small.setdefault("1_host_parser", {"mb_per_s": round(F * mbs_per_frame / dt_host, 1), "ms_per_frame": round(dt_host / F * 1e3, 2),
                                                "note": "aa_stream_decode: serial BoolDecoder on one host core, frame by frame (Decoder::get_frame_output)"})
             del p, d1
