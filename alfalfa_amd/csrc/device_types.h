@@ -88,7 +88,7 @@ int launch_segment_fixup( const ParseJob * jobs, const aa_seg_stream * streams, 
 // token workers (tok_fsm.hh, parse_kernels.hip): lanes that take frames from a queue in HBM
 void token_worker_shape( uint32_t lane_bytes, int n_cus, int * lanes_out, uint32_t * lds_out, int * wgs_per_cu_out );
 int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap & heap, uint32_t * exited, const uint32_t * retire, uint32_t gen, uint32_t spread,
-                          unsigned long long * prof, unsigned long long linger_ticks, int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, bool packed, void * stream );
+                          unsigned long long * prof, unsigned long long linger_ticks, int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, bool packed, uint32_t mp_hint, void * stream );
 // packed coefficients of n frames -> their dense arrays (k_dense_index + k_expand_coeffs); heap = the coefficient heap's base,
 // jobs = host memory the device can read, jobs_hbm = room for a copy of them in HBM
 int launch_expand_coeffs( const int16_t * heap, const aa_expand_job * jobs, aa_expand_job * jobs_hbm, int n, unsigned max_mbs, void * stream );

@@ -47,11 +47,16 @@ __global__ __launch_bounds__( 64 ) void k_parse_mb_headers( const ParseJob * job
   const unsigned words_per_row = ( mbw + 63 ) / 64;
   uint32_t intra = 0, split = 0;
   unsigned mi = 0;
+  // (one lane per partition: a second copy of the flags, every partition's rows back to back -- aa::mp_flag_index, with
+  // everything it reads out of the job held in registers: the loop must not wait for HBM)
+  const uint32_t mp_stride = J.mp_stride, mp_base = J.flags_padded, nparts = fp.nparts;
   for ( unsigned row = 0; row < mbh; row++ ) {
     unsigned long long word = 0;
+    const uint32_t mp_row = mp_stride ? mp_base + ( row % nparts ) * mp_stride + ( row / nparts ) * mbw : 0u;
     for ( unsigned col = 0; col < mbw; col++, mi++ ) {
       const uint8_t flags = aa::parse_mb_header( bd, fp, J.mbs, mi, col, row, static_cast<uint8_t *>( nullptr ) );
       J.mbflags[mi] = flags;
+      if ( mp_stride ) J.mbflags[mp_row + col] = flags;
       if ( !( flags & AA_MB_INTER ) ) { intra++; word |= 1ull << ( col & 63 ); }
       else if ( J.mbs[mi].y_mode == aa::SPLITMV ) split = 1;
       if ( ( col & 63 ) == 63 || col + 1 == mbw ) { J.intra_rows[row * words_per_row + ( col >> 6 )] = word; word = 0; }
@@ -94,6 +99,7 @@ struct WorkerArgs {
   unsigned long long linger_ticks;        // a workgroup without work stays this long (100 MHz ticks) before it leaves
   int lanes;
   uint32_t lane_bytes;
+  uint32_t mp_hint;                       // one lane per partition: most partitions a frame in flight has (a wave leaves that many lanes per ticket)
 };
 
 // up to `want` tickets for this wave (called by ONE lane): -> first ticket in *base, how many as the result; 0 = the queue is
@@ -121,8 +127,16 @@ __device__ inline uint32_t queue_take( aa::TokQueue * q, uint32_t want, uint32_t
   }
 }
 
-// PK: the coefficients are stored packed (tok_fsm.hh); a context runs one of the two instantiations for all its frames
-template <bool PK>
+// position of the n-th set bit of `mask` (n < popcount)
+__device__ inline int nth_set_bit( unsigned long long mask, uint32_t n )
+{
+  for ( uint32_t k = 0; k < n; k++ ) mask &= mask - 1ull;
+  return __ffsll( static_cast<long long>( mask ) ) - 1;
+}
+
+// PK: the coefficients are stored packed (tok_fsm.hh); MP: frames with several DCT partitions may get a lane per partition.  A
+// context runs one instantiation for all its frames.
+template <bool PK, bool MP>
 __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t smem[];
@@ -157,7 +171,12 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
         if ( lane == first ) {
           // (the retire word lives in host memory: a read over the bus -- every 8th look is often enough)
           if ( ( looks++ & 7u ) == 0 && __hip_atomic_load( a.retire, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM ) >= a.gen ) got = 0xFFFFFFFFu;
-          else got = queue_take( a.q, static_cast<uint32_t>( __popcll( idle_mask ) ), a.spread, &base );
+          else {
+            // (one lane per partition: leave lanes for the partitions of the frames drawn -- what is left over draws again next period)
+            uint32_t want = static_cast<uint32_t>( __popcll( idle_mask ) );
+            if constexpr ( MP ) want = want / a.mp_hint > 1u ? want / a.mp_hint : 1u;
+            got = queue_take( a.q, want, a.spread, &base );
+          }
         }
         base = __shfl( base, first ); got = __shfl( got, first );
         if ( got == 0xFFFFFFFFu ) { retired = true; got = 0; }
@@ -167,8 +186,37 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
           // the slot, the job, the compressed frame, the header kernel's flags: written by other agents / other XCDs, and
           // this CU may hold stale lines of the recycled memory they live in
           __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "agent" );
-          if ( mine ) {
-            const aa::ParseJob * job = reinterpret_cast<const aa::ParseJob *>( AA_AT_LOAD( &a.slots[( base + rank ) & a.q->mask] ) );
+          const aa::ParseJob * job = nullptr;
+          if ( mine ) job = reinterpret_cast<const aa::ParseJob *>( AA_AT_LOAD( &a.slots[( base + rank ) & a.q->mask] ) );
+          if constexpr ( MP ) {
+            // Ticket t (t = 0 .. got - 1, held by the idle lane of rank t) is a frame of P_t partitions.  In ticket order, a frame
+            // gets P_t lanes if the wave has that many idle lanes to spare beyond one per ticket, else it runs on one lane as ever.
+            // Lanes are dealt out in rank order: the frame's partition p goes to the (start + p)-th lane handed out.
+            const uint32_t n_idle = static_cast<uint32_t>( __popcll( idle_mask ) );
+            uint32_t my_p = 0;
+            if ( mine ) my_p = job->nmb && job->mp_stride ? job->fp.nparts : 1u;
+            uint32_t spare = n_idle - got, start = 0;
+            const aa::ParseJob * my_job = nullptr;
+            uint32_t my_part = 0, my_n = 1, my_owner = 0;
+            for ( uint32_t t = 0; t < got; t++ ) {
+              const int lt = nth_set_bit( idle_mask, t );                      // the lane that holds ticket t
+              const uint32_t P = static_cast<uint32_t>( __shfl( static_cast<int>( my_p ), lt ) );
+              const unsigned long long jp = static_cast<unsigned long long>( __shfl( static_cast<long long>( reinterpret_cast<uintptr_t>( job ) ), lt ) );
+              const uint32_t n = ( P > 1u && P - 1u <= spare ) ? P : 1u;
+              spare -= n - 1u;
+              if ( idle && rank >= start && rank < start + n ) {
+                my_job = reinterpret_cast<const aa::ParseJob *>( static_cast<uintptr_t>( jp ) );
+                my_part = rank - start; my_n = n;
+                if ( n > 1u ) my_owner = aa::tok::kTablesBytes + static_cast<uint32_t>( nth_set_bit( idle_mask, start + aa::tok::mp_owner_partition( my_job ) ) ) * a.lane_bytes;
+              }
+              start += n;
+            }
+            if ( my_job ) {
+              F = my_n > 1u ? aa::tok::frame_of_partition( my_job, my_part, my_owner ) : aa::tok::frame_of( my_job );
+              if ( my_job->nmb == 0 ) { L.rec = aa::tok::R_DONE; }                  // (never queued; belt and braces)
+              else aa::tok::begin_frame( L, smem, L.base, F );
+            }
+          } else if ( mine ) {
             F = aa::tok::frame_of( job );
             if ( F.nmb == 0 ) { L.rec = aa::tok::R_DONE; }                        // (never queued; belt and braces)
             else aa::tok::begin_frame( L, smem, L.base, F );
@@ -193,9 +241,9 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
     }
     idle_since = 0;
     const unsigned long long t_b = profiling ? wall_clock64() : 0ull;
-    if ( active ) aa::tok::top_up( L, smem, F );
+    if ( active ) aa::tok::top_up<MP>( L, smem, F );
     const unsigned long long t_c = profiling ? wall_clock64() : 0ull;
-    aa::tok::run_period<PK>( L, smem, F, a.heap, profiling ? prof : nullptr );
+    aa::tok::run_period<PK, MP>( L, smem, F, a.heap, profiling ? prof : nullptr );
     if ( profiling ) {
       const unsigned long long t_d = wall_clock64();
       prof[3] += t_b - t_a; prof[4] += t_c - t_b; prof[5] += t_d - t_c;
@@ -403,13 +451,20 @@ void token_worker_shape( uint32_t lane_bytes, int n_cus, int * lanes_out, uint32
 }
 
 int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap & heap, uint32_t * exited, const uint32_t * retire, uint32_t gen, uint32_t spread,
-                          unsigned long long * prof, unsigned long long linger_ticks, int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, bool packed, void * stream )
+                          unsigned long long * prof, unsigned long long linger_ticks, int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, bool packed, uint32_t mp_hint, void * stream )
 {
   if ( lanes < 1 || wgs < 1 ) return static_cast<int>( hipErrorInvalidValue );
   WorkerArgs a;
   a.q = q; a.slots = slots; a.heap = heap; a.exited = exited; a.retire = retire; a.gen = gen; a.spread = spread ? spread : 1u; a.prof = prof; a.linger_ticks = linger_ticks; a.lanes = lanes; a.lane_bytes = lane_bytes;
-  if ( packed ) hipLaunchKernelGGL( k_token_workers<true>, dim3( wgs ), dim3( 64 ), lds, static_cast<hipStream_t>( stream ), a );
-  else hipLaunchKernelGGL( k_token_workers<false>, dim3( wgs ), dim3( 64 ), lds, static_cast<hipStream_t>( stream ), a );
+  a.mp_hint = mp_hint ? mp_hint : 1u;
+  // (mp_hint != 0: the context allows a lane per partition)
+  if ( mp_hint ) {
+    if ( packed ) hipLaunchKernelGGL( ( k_token_workers<true, true> ), dim3( wgs ), dim3( 64 ), lds, static_cast<hipStream_t>( stream ), a );
+    else hipLaunchKernelGGL( ( k_token_workers<false, true> ), dim3( wgs ), dim3( 64 ), lds, static_cast<hipStream_t>( stream ), a );
+  } else {
+    if ( packed ) hipLaunchKernelGGL( ( k_token_workers<true, false> ), dim3( wgs ), dim3( 64 ), lds, static_cast<hipStream_t>( stream ), a );
+    else hipLaunchKernelGGL( ( k_token_workers<false, false> ), dim3( wgs ), dim3( 64 ), lds, static_cast<hipStream_t>( stream ), a );
+  }
   return static_cast<int>( hipGetLastError() );
 }
 

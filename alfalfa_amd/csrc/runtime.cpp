@@ -188,6 +188,10 @@ struct aa_ctx {
     // coefficients; frames are expanded into a transient dense array when they are handed to reconstruction.  One format per
     // context, fixed when the first frame is submitted (ALFALFA_AMD_PACKED=1 / aa_ctx_set_packed_coefficients).
     bool packed = false;
+    // One lane per DCT partition (tok_fsm.hh): frames with 2 / 4 / 8 partitions may be decoded by as many lanes of one wave.
+    // Per context, fixed at the first submit (ALFALFA_AMD_LANE_PER_PARTITION=1 / aa_ctx_set_lane_per_partition).
+    bool lane_per_partition = false;
+    uint32_t mp_hint = 1;                // most partitions a frame submitted so far had (workgroups leave that many lanes per ticket)
     double words_per_byte = 4.0;         // running estimate for packed frames: 16-bit words stored per compressed byte
     uint32_t seen_starving = 0;
     std::vector<const uint32_t *> pending_lists;   // chunk lists of released frames, not yet handed to k_pool_free_lists
@@ -626,9 +630,9 @@ void tok_free( aa_ctx * ctx )
   if ( T.prof_dev ) (void) hipFree( T.prof_dev );
   if ( T.retire_host ) (void) hipHostFree( T.retire_host );
   if ( T.mirror_host ) (void) hipHostFree( T.mirror_host );
-  const bool packed = T.packed;
+  const bool packed = T.packed, lpp = T.lane_per_partition;
   T = aa_ctx::Tok {};
-  T.packed = packed;
+  T.packed = packed; T.lane_per_partition = lpp;
 }
 
 // Launch worker workgroups if jobs are waiting and fewer workgroups are alive than the GPU holds (the mirror must be fresh).
@@ -668,7 +672,7 @@ aa_status tok_launch_workers( aa_ctx * ctx, hipEvent_t after )
   sl.gen++;
   if ( after ) HIP_TRY( hipStreamWaitEvent( sl.st, after, 0 ) );
   LaunchTimer timer( ctx, 4, sl.st );
-  if ( int e = aa::launch_token_workers( T.q, T.slots, heap_of( ctx ), T.exited_dev + g, T.retire_dev + g, sl.gen, static_cast<uint32_t>( T.cap_wgs ), T.prof_dev, T.linger_ticks, want, T.lanes, T.lane_bytes, T.lds, T.packed, sl.st ) )
+  if ( int e = aa::launch_token_workers( T.q, T.slots, heap_of( ctx ), T.exited_dev + g, T.retire_dev + g, sl.gen, static_cast<uint32_t>( T.cap_wgs ), T.prof_dev, T.linger_ticks, want, T.lanes, T.lane_bytes, T.lds, T.packed, T.lane_per_partition ? T.mp_hint : 0u, sl.st ) )
     return hip_fail( static_cast<hipError_t>( e ), "k_token_workers" );
   sl.launched += static_cast<uint32_t>( want );
   ctx->stats.worker_launches++; ctx->stats.worker_wgs += static_cast<uint64_t>( want );
@@ -1080,6 +1084,7 @@ aa_status aa_ctx_create( int device, aa_ctx ** out )
   for ( auto & e : ctx->parse_idle ) HIP_TRY( hipEventCreateWithFlags( &e, hipEventDisableTiming ) );
   if ( const char * e = std::getenv( "ALFALFA_AMD_SCHEDULE" ) ) ctx->schedule = std::string( e ) == "diagonal" ? 1 : 0;
   if ( const char * e = std::getenv( "ALFALFA_AMD_PACKED" ) ) ctx->tok.packed = atoi( e ) != 0;
+  if ( const char * e = std::getenv( "ALFALFA_AMD_LANE_PER_PARTITION" ) ) ctx->tok.lane_per_partition = atoi( e ) != 0;
   // The row-pipelined kernels keep every unit on one XCD (per-XCD ticket queues indexed by the hardware XCC_ID): find
   // out which XCC ids workgroups of this device really land on.  They must be 0..n-1, each reached by a modest grid.
   {
@@ -1209,6 +1214,7 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
   out->heap_used_bytes = static_cast<uint64_t>( std::max<int64_t>( 0, T.chunks_committed ) ) * kChunkBytesHeap;
   out->heap_is_virtual = T.vmm ? 1u : 0u;
   out->packed_coefficients = T.packed ? 1u : 0u;
+  out->lane_per_partition = T.lane_per_partition ? 1u : 0u;
   out->token_lanes_per_workgroup = static_cast<uint32_t>( T.lanes ); out->token_workgroups_capacity = static_cast<uint32_t>( T.cap_wgs );
   out->token_lane_lds_bytes = T.lane_bytes; out->token_workgroup_lds_bytes = T.lds;
   out->compute_units = static_cast<uint32_t>( T.n_cus );
@@ -1222,6 +1228,13 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
     const int32_t waiting = static_cast<int32_t>( static_cast<uint32_t>( T.jobs_enqueued ) - T.mirror_host->q_head );
     out->jobs_waiting = waiting > 0 ? static_cast<uint32_t>( waiting ) : 0u;
   }
+  return AA_OK;
+}
+aa_status aa_ctx_set_lane_per_partition( aa_ctx * ctx, int on )
+{
+  if ( !ctx ) return fail( AA_ERR_ARGUMENT, "null context" );
+  if ( ctx->tok.ready && ctx->tok.lane_per_partition != ( on != 0 ) ) return fail( AA_ERR_LOGIC, "aa_ctx_set_lane_per_partition: frames have been submitted to this context already" );
+  ctx->tok.lane_per_partition = on != 0;
   return AA_OK;
 }
 aa_status aa_ctx_set_packed_coefficients( aa_ctx * ctx, int on )
@@ -1485,8 +1498,12 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
   const size_t words_per_row = ( J.fp.mbw + 63 ) / 64;
   const size_t rows_bytes = align_up( words_per_row * J.fp.mbh * sizeof( unsigned long long ) );
   const uint32_t flags_padded = ( nmb + 15u ) & ~15u;
-  const size_t flags_bytes = align_up( flags_padded );
-  const size_t list_bytes = align_up( size_t( aa::chunk_list_entries( nmb ) ) * sizeof( uint32_t ) );
+  // one lane per partition: a second copy of the flags laid out partition by partition, a longer chunk list (tok_fsm.hh)
+  const bool mp = ctx->tok.lane_per_partition && J.fp.nparts > 1;
+  const uint32_t mp_stride = mp ? aa::mp_flag_stride( J.fp.mbw, J.fp.mbh, J.fp.nparts ) : 0u;
+  const size_t flags_bytes = align_up( size_t( flags_padded ) + size_t( J.fp.nparts ) * mp_stride );
+  const size_t list_bytes = align_up( size_t( aa::chunk_list_entries( nmb, mp ? J.fp.nparts : 1u ) ) * sizeof( uint32_t ) );
+  if ( mp ) ctx->tok.mp_hint = std::max<uint32_t>( ctx->tok.mp_hint, J.fp.nparts );
   const size_t pos_bytes = ctx->tok.packed ? align_up( size_t( nmb ) * sizeof( uint32_t ) ) : 0;
   rec.rec_bytes = mb_bytes + rows_bytes + flags_bytes + list_bytes + pos_bytes;
   rec.rec_block = b->dev + it.rec_off; rec.rec_in_arena = true;
@@ -1494,7 +1511,7 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
 
   J.data = b->dev + it.data_off;
   J.size = static_cast<uint32_t>( it.size ); J.data_padded = ( J.size + 15u ) & ~15u;
-  J.nmb = nmb; J.flags_padded = flags_padded;
+  J.nmb = nmb; J.flags_padded = flags_padded; J.mp_stride = mp_stride; J.mp_pad = 0;
   J.mbs = reinterpret_cast<aa_mb_info *>( blk );
   J.intra_rows = reinterpret_cast<unsigned long long *>( blk + mb_bytes );
   J.mbflags = blk + mb_bytes + rows_bytes;
@@ -1674,7 +1691,10 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
     const size_t words_per_row = ( s->parser.mb_width() + 63 ) / 64;
     items[i].rec_off = dev_arena;
     dev_arena += align_up( nmb * sizeof( aa_mb_info ) ) + align_up( words_per_row * s->parser.mb_height() * sizeof( unsigned long long ) )
-                 + align_up( ( nmb + 15u ) & ~size_t( 15 ) ) + align_up( size_t( aa::chunk_list_entries( static_cast<uint32_t>( nmb ) ) ) * sizeof( uint32_t ) )
+                 + ( ctx->tok.lane_per_partition      // (how many partitions a frame has is known after its pre-pass: room for 8)
+                       ? align_up( ( ( nmb + 15u ) & ~size_t( 15 ) ) + 8 * size_t( aa::mp_flag_stride( s->parser.mb_width(), s->parser.mb_height(), 8 ) ) )
+                         + align_up( size_t( aa::chunk_list_entries( static_cast<uint32_t>( nmb ), 8 ) ) * sizeof( uint32_t ) )
+                       : align_up( ( nmb + 15u ) & ~size_t( 15 ) ) + align_up( size_t( aa::chunk_list_entries( static_cast<uint32_t>( nmb ) ) ) * sizeof( uint32_t ) ) )
                  + ( ctx->tok.packed ? align_up( nmb * sizeof( uint32_t ) ) : 0 );
   }
   dev_arena = ( dev_arena + ( size_t( 16 ) << 20 ) - 1 ) & ~( ( size_t( 16 ) << 20 ) - 1 );
@@ -1841,7 +1861,7 @@ static aa_status resolve_summary( aa_stream * s, FrameRec & r )
     // chunks are returned, room is made (more heap if the memory limit allows it, else by letting everything else in flight
     // finish) and the frame goes to the queue again -- its macroblock headers are parsed already.
     ctx->stats.nomem_retries++;
-    const uint32_t worst = aa::chunk_list_entries( r.hdr.num_macroblocks );      // (what no frame of this size exceeds, in either storage format)
+    const uint32_t worst = aa::chunk_list_entries( r.hdr.num_macroblocks, T.lane_per_partition ? 8u : 1u );      // (what no frame of this size exceeds, in either storage format)
     {
       std::lock_guard<std::mutex> g( ctx->pool_mu );
       if ( !r.chunks_returned ) T.pending_lists.push_back( r.chunk_list );

@@ -46,6 +46,17 @@
 // the frame is handed to reconstruction (coeff_pack.hh, k_expand_coeffs), macroblock by macroblock, coeff_index being set
 // then.
 //
+// One lane per DCT partition (template parameter MP of the functions below: "capable of"; a frame uses it when its job says
+// so, ParseJob::mp_stride != 0).  Row r of a frame is coded in partition r % P (frame.cc:119-137), so a frame with P = 2, 4 or 8
+// partitions is P independent bit streams -- tied together only by the above-row non-zero flags a macroblock's contexts
+// need.  P lanes OF ONE WAVE take one partition each: lane p decodes rows p, p + P, ... as if they were a frame of their own
+// (its own sequence of macroblock flags: the header kernel lays them out partition by partition), all lanes read and write ONE
+// above-row array (in the slice of the lane that has the frame's last row -- it finishes last), and a lane starts macroblock
+// (r, c) only when the lane of row r - 1 has completed (r - 1, c): a progress word per lane in LDS, checked at the macroblock
+// boundary.  Rows then follow each other like a wavefront, one macroblock apart at best, and a key frame's chain is P times
+// shorter.  Chunks are drawn per lane, listed in the frame's one chunk list through a counter in LDS; the lane that finishes
+// last reports the frame.  A frame whose wave has fewer than P idle lanes when it is drawn runs on one lane as before.
+//
 // Who runs a frame.  Lanes are WORKERS (k_token_workers): a lane that has finished its frame takes the next ParseJob from a
 // queue in HBM (TokQueue) at once, so a wave does not wait for its longest lane and a launch not for its longest wave.
 #pragma once
@@ -120,7 +131,8 @@ constexpr uint32_t kChunkWords = kChunkBlocks * 16u;
 constexpr uint32_t kMbWords = 25u * 17u;
 // entries of a frame's chunk list ([0] = count): a chunk that is left behind holds at least 80 macroblocks' worth of dense
 // blocks ((2048 - 26 + 1) / 25) or 77 of packed words, whatever the content -- one bound for both formats
-AA_HD constexpr uint32_t chunk_list_entries( uint32_t nmb ) { return 2u + ( nmb + 75u ) / 76u; }
+// (lanes > 1: one lane per partition -- every lane leaves a partly filled chunk behind)
+AA_HD constexpr uint32_t chunk_list_entries( uint32_t nmb, uint32_t lanes = 1 ) { return 2u + ( nmb + 75u ) / 76u + 2u * ( lanes - 1u ); }
 
 // Jobs waiting for a token lane: slots[ticket & mask] = the ParseJob; tickets below `publish` are ready, `head` is the next
 // one to take.  Producers (k_enqueue_jobs) reserve a range, fill it, publish in order.  The host keeps fewer jobs in flight
@@ -144,11 +156,23 @@ struct alignas( 16 ) ParseJob {
   uint32_t nmb, flags_padded;   // flags_padded: multiple of 16, >= nmb
   aa_mb_info * mbs;
   uint32_t * chunk_list;        // [chunk_list_entries( nmb )]: [0] = how many coefficient chunks the frame took, then their numbers
+  uint32_t mp_stride;           // != 0: one lane per partition may be used; behind the flags in raster order (mbflags[0, flags_padded)) there is
+  uint32_t mp_pad;              //       then a second copy laid out partition by partition: partition p's rows back to back at
+                                //       mbflags + flags_padded + p * mp_stride (mp_stride: a multiple of 16; mp_flag_index)
   uint32_t * packed_pos;        // [nmb], packed storage only: where a macroblock's words start = ordinal of the chunk in chunk_list << 15 | word in the chunk
   unsigned long long * intra_rows;
   uint8_t * mbflags;            // [flags_padded]: INTER | HAS_Y2 | SKIP of every macroblock, header kernel -> token kernel
   FrameSummary * summary;
 };
+
+// where the header pass puts the second copy of the flags byte of macroblock (col, row), if the job asks for one (mp_stride != 0)
+AA_HD inline uint32_t mp_flag_index( const ParseJob & J, uint32_t row, uint32_t col )
+{
+  const uint32_t P = J.fp.nparts;
+  return J.flags_padded + ( row % P ) * J.mp_stride + ( row / P ) * J.fp.mbw + col;
+}
+// bytes of a job's flags: raster copy + (mp) one padded run per partition; stride for a frame of mbw x mbh with P partitions
+AA_HD constexpr uint32_t mp_flag_stride( uint32_t mbw, uint32_t mbh, uint32_t P ) { return ( ( ( mbh + P - 1u ) / P ) * mbw + 15u ) & ~15u; }
 
 namespace tok {
 
@@ -195,7 +219,8 @@ constexpr uint8_t kXtabInit[27] = { 159, 165, 145, 173, 148, 140, 176, 155, 140,
 // 37..46  the sign, one node per token kind: the record knows the magnitude to add (DCT_1..4: the literal; dct_catN: its
 //         base, the extra bits having been shifted into Lane::mag) and the context the token leaves behind
 // A lane's state is the ADDRESS of its node's record (8 * node); values >= R_MBDONE mean "not decoding".
-enum : uint32_t { kNodes = 47, R_MBDONE = 0x1000, R_MB = 0x1001, R_DONE = 0x1002 };
+enum : uint32_t { kNodes = 47, R_MBDONE = 0x1000, R_MB = 0x1001, R_DONE = 0x1002,
+                  R_PARK = 0x1003 };      // one lane per partition: through, but its slice holds what lanes still running share
 // half of a node record = what a decoded 0 / 1 at that node means:
 //   [0,9) address of the next node's record   [9,14) index of the next node's probability   [14] ... in the current row (else in kXtab)
 //   [15] shift the bit into the magnitude   [16] on to the next coefficient position   [17] emit the coefficient   [18] end of block
@@ -278,6 +303,9 @@ struct Frame {
   AA_GLOBAL uint32_t * packed_pos;
   uint32_t data_padded, flags_padded, nmb, mbw, nparts;
   uint32_t max_steps;           // no frame of this size can take more steps: a lane that gets there stops (never a hung GPU)
+  // one lane per partition (mp_P > 1; then nmb / mbflags / flags_padded are this lane's rows only):
+  uint32_t mp_P, mp_p;          // lanes of the frame, this lane's partition
+  uint32_t mp_owner;            // LDS offset of the slice that holds what the frame's lanes share (above-row flags, MpShared)
 };
 AA_HD inline Frame frame_of( const ParseJob * job )
 {
@@ -290,8 +318,34 @@ AA_HD inline Frame frame_of( const ParseJob * job )
   const uint64_t bound = static_cast<uint64_t>( job->nmb ) * ( 25u * 16u * 23u + 4u ) + 4096u;
   F.max_steps = bound > 0xFFFFFFF0ull ? 0xFFFFFFF0u : static_cast<uint32_t>( bound );
   F.data_padded = job->data_padded; F.flags_padded = job->flags_padded; F.nmb = job->nmb; F.mbw = job->fp.mbw; F.nparts = job->fp.nparts;
+  F.mp_P = 1; F.mp_p = 0; F.mp_owner = 0;
   return F;
 }
+// ... as lane `p` of the frame's P = nparts lanes sees it: its rows p, p + P, ... are its frame
+AA_HD inline Frame frame_of_partition( const ParseJob * job, uint32_t p, uint32_t owner_base )
+{
+  Frame F = frame_of( job );
+  const uint32_t P = job->fp.nparts, mbh = job->fp.mbh;
+  const uint32_t rows = mbh > p ? ( mbh - p + P - 1u ) / P : 0u;
+  F.mbflags = (const AA_GLOBAL uint8_t *) job->mbflags + job->flags_padded + p * job->mp_stride;
+  F.nmb = rows * F.mbw;
+  F.flags_padded = job->mp_stride;
+  F.mp_P = P; F.mp_p = p; F.mp_owner = owner_base;
+  return F;
+}
+// the partition whose lane finishes last (it has the frame's last row): its slice holds what the lanes share
+AA_HD inline uint32_t mp_owner_partition( const ParseJob * job ) { return ( job->fp.mbh - 1u ) % job->fp.nparts; }
+
+// What the lanes of a frame share (one lane per partition), in the owner's slice where a single lane keeps its saved partition
+// decoders (part_off): all zero at the start except `left`.
+struct MpShared {
+  uint32_t prog[8];             // [p]: macroblocks lane p has completed (in ITS sequence: whole rows * mbw + columns of the current one)
+  uint32_t nchunks;             // chunks in the frame's list so far
+  uint32_t left;                // lanes that have not finished
+  uint32_t blocks, words, steps;// sums over the lanes that have finished
+  uint32_t status;              // != TOK_OK: a lane gave up (no memory, step bound): the others stop at their next macroblock boundary
+};
+static_assert( sizeof( MpShared ) <= 128, "MpShared lives in the partition save area" );
 
 struct Chunk16 { uint32_t w[4]; };
 
@@ -350,6 +404,8 @@ struct Lane {
   AA_GLOBAL int16_t * hdr;        // the mask word of the block in progress (written when the block ends non-zero)
   uint32_t zzmask;                // zigzag positions of the block in progress that hold a coefficient
   uint32_t words;                 // words used in the chunks left behind
+  uint32_t mi_real;               // one lane per partition: index of the current macroblock's record (mi counts this lane's macroblocks)
+  uint32_t chunk_ord;             // ordinal, in the frame's chunk list, of the chunk being filled
   // position
   uint32_t mi, col, row, part;
   uint32_t steps;
@@ -428,9 +484,10 @@ AA_HD inline void switch_partition( Lane & L, uint8_t * smem, const Frame & J, u
 }
 
 // ---- every kPeriod steps, all lanes together: land the chunks requested a period ago, request the next ---------------
+template <bool MP = false>
 AA_HD inline void top_up( Lane & L, uint8_t * smem, const Frame & J )
 {
-  if ( L.rec == R_DONE ) return;
+  if ( L.rec == R_DONE || ( MP && L.rec == R_PARK ) ) return;
   if ( L.pend_wpos == L.wpos ) {
     for ( uint32_t k = 0; k < kChunks; k++ )
       lds_store16( smem, L.base + kStream + ( ( L.wpos + 16 * k ) & ( kRing - 1 ) ), mask_past_end( L.pend[k], L.wpos + 16 * k, L.rend ) );
@@ -465,6 +522,10 @@ AA_HD inline void top_up( Lane & L, uint8_t * smem, const Frame & J )
 // ---- block / macroblock transitions ----------------------------------------------------------------------------------
 #if defined( __HIP_DEVICE_COMPILE__ )
 #define AA_ANY( x ) ( __builtin_amdgcn_ballot_w64( x ) != 0 )        // wave-uniform: does any lane ...
+// (lanes of one wave add to the same LDS word in the same instruction: an LDS atomic, not a read-modify-write)
+#define AA_LDS_ADD( smem, off, v ) __hip_atomic_fetch_add( aa::tok::lds_at<uint32_t>( ( smem ), ( off ) ), ( v ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP )
+// (a word another lane of the wave writes: read it from LDS every time, never out of a register)
+#define AA_LDS_LOAD( smem, off ) __hip_atomic_load( aa::tok::lds_at<uint32_t>( ( smem ), ( off ) ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP )
 #define AA_MUL24( a, b ) __umul24( ( a ), ( b ) )
 #define AA_UBFE( v, off, width ) __builtin_amdgcn_ubfe( ( v ), ( off ), ( width ) )
 // The workgroup's dynamic LDS starts at LDS address 0 (the kernel has no static LDS), so an offset into smem IS the LDS
@@ -475,6 +536,8 @@ template <class T> __device__ inline __attribute__( ( address_space( 3 ) ) ) T *
 }
 #else
 #define AA_ANY( x ) ( x )
+#define AA_LDS_ADD( smem, off, v ) aa::aa_host_add( aa::tok::lds_at<uint32_t>( ( smem ), ( off ) ), ( v ) )
+#define AA_LDS_LOAD( smem, off ) ( *aa::tok::lds_at<uint32_t>( ( smem ), ( off ) ) )
 #define AA_MUL24( a, b ) ( ( a ) * ( b ) )
 #define AA_UBFE( v, off, width ) ( ( ( v ) >> ( off ) ) & ( ( 1u << ( width ) ) - 1u ) )
 template <class T> inline T * lds_at( uint8_t * smem, uint32_t off ) { return reinterpret_cast<T *>( smem + off ); }
@@ -539,26 +602,83 @@ AA_HD inline void finish_frame( Lane & L, const Frame & J, const Heap & H, uint3
   L.rec = R_DONE;
 }
 
+// One lane per partition: this lane is through with its rows (or gives up: status != TOK_OK, which the other lanes of the frame
+// see at their next macroblock boundary).  Its counts go to the frame's sums; the lane that finishes LAST reports the frame.
+template <bool PK>
+AA_HD inline void finish_partition( Lane & L, uint8_t * smem, const Frame & J, const Heap & H, uint32_t status )
+{
+  const uint32_t sh = J.mp_owner + part_off( J.mbw );
+  if ( status != TOK_OK ) *lds_at<uint32_t>( smem, sh + offsetof( MpShared, status ) ) = status;
+  uint32_t words = 0;
+  if constexpr ( PK ) words = L.words + ( L.nchunks ? static_cast<uint32_t>( L.hdr - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) ) : 0u );
+  AA_LDS_ADD( smem, sh + offsetof( MpShared, blocks ), L.coeff_blocks );
+  AA_LDS_ADD( smem, sh + offsetof( MpShared, words ), words );
+  AA_LDS_ADD( smem, sh + offsetof( MpShared, steps ), L.steps );
+  const uint32_t left = AA_LDS_ADD( smem, sh + offsetof( MpShared, left ), 0xFFFFFFFFu );
+  // (the owner finishes last when all goes well -- it has the last row; when lanes give up it may not: then it stays, parked,
+  // until the others are through with what its slice holds)
+  L.rec = ( left != 1u && L.base == J.mp_owner ) ? static_cast<uint32_t>( R_PARK ) : static_cast<uint32_t>( R_DONE );
+  if ( left != 1u ) return;
+  // the last one: every lane's sums are in (their adds were issued before their decrement)
+  const MpShared fin = *lds_at<const MpShared>( smem, sh );
+  J.chunk_list[0] = fin.nchunks;
+  AA_GLOBAL FrameSummary * sum = (AA_GLOBAL FrameSummary *) J.job->summary;
+  sum->num_coeff_blocks = fin.blocks;
+  sum->packed_words = PK ? fin.words : 0u;
+  sum->steps = fin.steps;
+  sum->num_chunks = fin.nchunks;
+  sum->status = fin.status;
+#if defined( __HIP_DEVICE_COMPILE__ )
+  __builtin_amdgcn_fence( __ATOMIC_RELEASE, "" );               // (this lane's release covers its wave-mates' stores too: the
+  asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );            //  counters are the wave's)
+  __hip_atomic_store( &sum->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+#else
+  sum->done = 1u;
+#endif
+}
+
 constexpr unsigned long long kMemWaitTicks = 200000000ull;      // 2 s of the 100 MHz clock: then the frame is handed back (TOK_NO_MEMORY)
 
-template <bool PK>
+template <bool PK, bool MP = false>
 AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J, const Heap & H )
 {
-  uint16_t * const above = reinterpret_cast<uint16_t *>( smem + L.base + kAbove );
-  if ( L.rec == R_MBDONE ) { L.mi++; L.col++; L.rec = R_MB; }
+  const bool mp = MP && J.mp_P > 1;                         // this frame has one lane per partition
+  uint16_t * const above = reinterpret_cast<uint16_t *>( smem + ( mp ? J.mp_owner : L.base ) + kAbove );
+  const uint32_t shared = J.mp_owner + part_off( J.mbw );   // (mp) MpShared
+  if constexpr ( MP ) if ( L.rec == R_PARK ) {
+    if ( AA_LDS_LOAD( smem, shared + offsetof( MpShared, left ) ) == 0u ) L.rec = R_DONE;
+    return;
+  }
+  if ( L.rec == R_MBDONE ) {
+    L.mi++; L.col++; L.rec = R_MB;
+    if constexpr ( MP ) { L.mi_real++; if ( mp ) *lds_at<uint32_t>( smem, shared + 4 * J.mp_p ) = L.mi; }       // completed: the row below may follow
+  }
   if ( L.steps > J.max_steps ) {             // cannot happen for any input; if it does the frame is reported, not hung on
-    finish_frame<PK>( L, J, H, TOK_STEP_BOUND );
+    if ( mp ) finish_partition<PK>( L, smem, J, H, TOK_STEP_BOUND );
+    else finish_frame<PK>( L, J, H, TOK_STEP_BOUND );
     return;
   }
   for ( ;; ) {
+    if constexpr ( MP ) if ( mp && AA_LDS_LOAD( smem, shared + offsetof( MpShared, status ) ) != TOK_OK ) {
+      finish_partition<PK>( L, smem, J, H, TOK_OK );        // another lane of the frame gave up (its status stands): so does this one
+      return;
+    }
     if ( L.mi == J.nmb ) {
-      finish_frame<PK>( L, J, H, TOK_OK );
+      if ( mp ) finish_partition<PK>( L, smem, J, H, TOK_OK );
+      else finish_frame<PK>( L, J, H, TOK_OK );
       return;
     }
     if ( L.mi >= L.mwpos ) return;                          // flags not here yet (only a long run of skipped macroblocks gets ahead of the ring)
     if ( L.col == J.mbw ) {
       L.col = 0; L.row++; L.ctxbits = 0;
-      if ( J.nparts > 1 ) switch_partition( L, smem, J, L.row % J.nparts );
+      if constexpr ( MP ) if ( mp ) L.mi_real += ( J.mp_P - 1u ) * J.mbw;      // this lane's next row is P rows further down
+      if ( !mp && J.nparts > 1 ) switch_partition( L, smem, J, L.row % J.nparts );
+    }
+    if constexpr ( MP ) if ( mp && ( J.mp_p | L.row ) != 0 ) {
+      // (r, c) needs the flags (r - 1, c) left behind: row r - 1 is the previous partition's -- its L.row-th row, or, for
+      // partition 0, the last partition's (L.row - 1)-th
+      const uint32_t q = J.mp_p ? J.mp_p - 1u : J.mp_P - 1u, k = J.mp_p ? L.row : L.row - 1u;
+      if ( AA_LDS_LOAD( smem, shared + 4 * q ) < k * J.mbw + L.col + 1u ) return;     // not there yet: ask again at the next pass
     }
     const uint32_t flags = smem[L.base + kMeta + ( L.mi & ( kMetaRing - 1 ) )];
     const uint32_t has_y2 = flags & AA_MB_HAS_Y2;
@@ -574,11 +694,17 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
           // handed back unfinished and the host runs it again when memory has been released.
           const unsigned long long now = AA_NOW();
           if ( !L.mem_since ) { L.mem_since = now | 1ull; AA_AT_ADD( &H.pool->starving, 1u ); }
-          else if ( now - L.mem_since > kMemWaitTicks ) finish_frame<PK>( L, J, H, TOK_NO_MEMORY );
+          else if ( now - L.mem_since > kMemWaitTicks ) { if ( mp ) finish_partition<PK>( L, smem, J, H, TOK_NO_MEMORY ); else finish_frame<PK>( L, J, H, TOK_NO_MEMORY ); }
           return;
         }
         L.mem_since = 0;
-        J.chunk_list[1 + L.nchunks] = c;
+        if ( mp ) {
+          L.chunk_ord = AA_LDS_ADD( smem, shared + offsetof( MpShared, nchunks ), 1u );
+          J.chunk_list[1 + L.chunk_ord] = c;
+        } else {
+          J.chunk_list[1 + L.nchunks] = c;
+          if constexpr ( MP ) L.chunk_ord = L.nchunks;
+        }
         L.nchunks++;
         L.blk_index = c * kChunkBlocks;
         if constexpr ( PK ) {
@@ -591,7 +717,7 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
         }
       }
       if constexpr ( PK ) {
-        L.mb_first = ( ( L.nchunks - 1u ) << 15 ) | static_cast<uint32_t>( L.hdr - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) );
+        L.mb_first = ( ( MP ? L.chunk_ord : L.nchunks - 1u ) << 15 ) | static_cast<uint32_t>( L.hdr - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) );
         L.blk = L.hdr + 1; L.zzmask = 0;
       } else L.mb_first = L.blk_index;
       L.flags = flags; L.nz_mask = 0;
@@ -602,19 +728,21 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
     }
     L.ctxbits &= has_y2 ? 0u : 0x01000100u;                 // a non-coded Y2 leaves its chain untouched (frame.cc:255-269)
     above[L.col] = static_cast<uint16_t>( L.ctxbits );
-    if constexpr ( PK ) store_mb_packed( J, L.mi, 0, 0, flags | ( has_y2 ? AA_MB_LF_SKIP_INNER : 0u ) );
-    else store_mb( J, L.mi, 0, L.blk_index, flags | ( has_y2 ? AA_MB_LF_SKIP_INNER : 0u ) );
+    const uint32_t mi_rec = MP ? L.mi_real : L.mi;
+    if constexpr ( PK ) store_mb_packed( J, mi_rec, 0, 0, flags | ( has_y2 ? AA_MB_LF_SKIP_INNER : 0u ) );
+    else store_mb( J, mi_rec, 0, L.blk_index, flags | ( has_y2 ? AA_MB_LF_SKIP_INNER : 0u ) );
     L.mi++; L.col++;
+    if constexpr ( MP ) { L.mi_real++; if ( mp ) *lds_at<uint32_t>( smem, shared + 4 * J.mp_p ) = L.mi; }
   }
 }
 
-AA_HD inline bool at_boundary( const Lane & L ) { return L.rec == R_MBDONE || L.rec == R_MB; }
+template <bool MP = false> AA_HD inline bool at_boundary( const Lane & L ) { return L.rec == R_MBDONE || L.rec == R_MB || ( MP && L.rec == R_PARK ); }
 
 // ---- one step: decode one bool (lanes with a node to decode; the others sit it out) -------------------------------------
 // Straight-line code: what the bit means comes out of the node's record as bit fields and is applied with arithmetic;
 // the only predicated regions are the stores.  A lone wave gets one issue slot every 4 cycles whatever the instruction, so
 // every instruction saved here is 4 cycles per bool.
-template <bool PK>
+template <bool PK, bool MP = false>
 AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
 {
   if ( L.rec < R_MBDONE ) {
@@ -682,11 +810,11 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
         }
         const bool mbdone = L.blkaddr == kBlockTabOff + 8 * 25;
         if ( mbdone ) {                           // the macroblock is complete: its record, its column's flags
-          *lds_at<uint16_t>( smem, L.base + kAbove + 2 * L.col ) = static_cast<uint16_t>( ctxbits );
+          *lds_at<uint16_t>( smem, ( MP && J.mp_P > 1 ? J.mp_owner : L.base ) + kAbove + 2 * L.col ) = static_cast<uint16_t>( ctxbits );
           uint32_t flags = L.flags;
           flags |= L.nz_mask ? AA_MB_HAS_NONZERO : ( ( flags & AA_MB_HAS_Y2 ) ? AA_MB_LF_SKIP_INNER : 0u );
-          if constexpr ( PK ) store_mb_packed( J, L.mi, L.nz_mask, L.mb_first, flags );
-          else store_mb( J, L.mi, L.nz_mask, L.mb_first, flags );
+          if constexpr ( PK ) store_mb_packed( J, MP ? L.mi_real : L.mi, L.nz_mask, L.mb_first, flags );
+          else store_mb( J, MP ? L.mi_real : L.mi, L.nz_mask, L.mb_first, flags );
         }
         // the block after it (never a Y2)
         const uint32_t a = nextblk.x & 255u, l = ( nextblk.x >> 8 ) & 255u, uv = ( nextblk.x >> 16 ) & 255u;
@@ -707,21 +835,21 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
 
 // One period of a wave: kPeriod steps, leaving the hot loop whenever a lane has reached a macroblock boundary.
 // `prof` (diagnostics, may be null): [0] += clock ticks spent in boundary passes, [1] += boundary passes, [2] += steps of the wave
-template <bool PK>
+template <bool PK, bool MP = false>
 AA_HD inline void run_period( Lane & L, uint8_t * smem, const Frame & J, const Heap & H, unsigned long long * prof = nullptr )
 {
   uint32_t it = 0;
   while ( it < kPeriod ) {
-    if ( AA_ANY( at_boundary( L ) ) ) {
+    if ( AA_ANY( at_boundary<MP>( L ) ) ) {
       const unsigned long long tb = prof ? AA_NOW() : 0ull;
-      if ( at_boundary( L ) ) macroblock_boundary<PK>( L, smem, J, H );
+      if ( at_boundary<MP>( L ) ) macroblock_boundary<PK, MP>( L, smem, J, H );
       if ( prof ) { prof[0] += AA_NOW() - tb; prof[1]++; }
       it++;                                                 // (a lane waiting for flags must not spin the period away)
       if ( !AA_ANY( L.rec < R_MBDONE ) ) break;             // nobody has anything to decode
     }
     // leave the hot loop when a lane has completed a macroblock (asked by ALL lanes, outside the predicated step: wave-uniform)
     const uint32_t it0 = it;
-    do { step<PK>( L, smem, J ); it++; } while ( it < kPeriod && !AA_ANY( L.rec == R_MBDONE ) );
+    do { step<PK, MP>( L, smem, J ); it++; } while ( it < kPeriod && !AA_ANY( L.rec == R_MBDONE ) );
     if ( prof ) prof[2] += it - it0;
   }
   if ( L.rec != R_DONE ) L.steps += it;                     // (an upper bound: the iterations a lane sat out count too)
@@ -760,7 +888,17 @@ AA_HD inline void begin_frame( Lane & L, uint8_t * smem, uint32_t base, const Fr
   L.blkaddr = kBlockTabOff;
   L.blk = nullptr; L.blk_index = 0; L.blk_left = 0; L.nchunks = 0; L.mem_since = 0;     // the first coded macroblock takes the first chunk
   L.hdr = nullptr; L.zzmask = 0; L.words = 0;
-  start_partition( L, smem, J, 0 );
+  L.mi_real = 0; L.chunk_ord = 0;
+  if ( J.mp_P > 1 ) {
+    // one lane per partition: this lane's first row is row mp_p; the owner's slice holds what the lanes share
+    L.mi_real = J.mp_p * J.mbw;
+    if ( base == J.mp_owner ) {
+      MpShared z {};
+      z.left = J.mp_P;
+      *reinterpret_cast<MpShared *>( lds + part_off( J.mbw ) ) = z;
+    }
+  }
+  start_partition( L, smem, J, J.mp_P > 1 ? J.mp_p : 0u );
   // flag ring: macroblocks [0, kMetaRing)
   for ( uint32_t k = 0; k < kMetaRing / 16; k++ ) {
     Chunk16 c; c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;

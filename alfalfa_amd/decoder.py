@@ -119,6 +119,11 @@ class Context:
         a frame is reconstructed) instead of dense blocks.  Before the context's first submit_frames only."""
         capi.check(self.L.aa_ctx_set_packed_coefficients(self.h, int(bool(on))))
 
+    def set_lane_per_partition(self, on=True):
+        """Frames with several DCT partitions may be entropy-decoded by one token lane per partition (lanes of one wave).  Before
+        the context's first submit_frames only.  Simulated on the host; not yet run on a GPU."""
+        capi.check(self.L.aa_ctx_set_lane_per_partition(self.h, int(bool(on))))
+
     def info(self):
         """What the context holds right now (aa_ctx_info): memory by kind, token-worker shape and occupancy."""
         st = capi.CtxInfo()

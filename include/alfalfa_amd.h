@@ -189,7 +189,7 @@ typedef struct aa_ctx_info {
    * starting frames [4] ring top-ups [5] periods (steps + boundary passes) [6] lane-periods that had a frame [7] periods */
   uint64_t token_profile[8];
   uint32_t packed_coefficients;      /* 1: device-parsed frames store packed coefficients (aa_ctx_set_packed_coefficients) */
-  uint32_t reserved0;
+  uint32_t lane_per_partition;       /* 1: frames with several DCT partitions may get a token lane per partition (aa_ctx_set_lane_per_partition) */
 } aa_ctx_info;
 aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out );
 /* How the device parser stores a frame's coefficients until the frame is reconstructed.  0 (default): dense, 32 bytes per
@@ -199,6 +199,13 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out );
  * the context's first aa_submit_frames call (AA_ERR_LOGIC afterwards); the environment variable ALFALFA_AMD_PACKED=1 makes
  * packed the default. */
 aa_status aa_ctx_set_packed_coefficients( aa_ctx * ctx, int on );
+/* One token lane per DCT partition.  A frame with 2, 4 or 8 partitions (frame.cc:119-137: macroblock row r is coded in
+ * partition r % P) is then decoded by that many lanes of one wave -- rows handed from lane to lane through the above-row
+ * flags in LDS --, whenever the wave that draws it has the lanes idle; its entropy-decode latency falls towards 1 / P of the
+ * single-lane figure.  Single-partition frames, records and rasters are unaffected.  Per context, before its first
+ * aa_submit_frames call (AA_ERR_LOGIC afterwards); ALFALFA_AMD_LANE_PER_PARTITION=1 makes it the default.  Off by default:
+ * simulated on the host lane by lane and wave by wave (tests/test_wave_sim.py), not yet run on a GPU. */
+aa_status aa_ctx_set_lane_per_partition( aa_ctx * ctx, int on );
 /* hipStream_t handles as opaque pointers (to order foreign work, e.g. an RCCL broadcast, against ours) */
 void * aa_ctx_compute_stream( aa_ctx * ctx );
 void * aa_ctx_copy_stream( aa_ctx * ctx );

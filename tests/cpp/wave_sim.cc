@@ -36,6 +36,7 @@ struct Job {
   aa_frame_header hdr;
   uint32_t nmb = 0;
   int attempts = 0;
+  bool collected = false;
   std::vector<void *> owned;
   Job() { std::memset( &J, 0, sizeof J ); std::memset( &sum, 0, sizeof sum ); std::memset( &hdr, 0, sizeof hdr ); }
   ~Job() { for ( void * p : owned ) free( p ); }
@@ -49,7 +50,7 @@ struct Stream {
 };
 
 // header pre-pass (the product's Parser::parse_header), k_parse_mb_headers' loop, k_segment_fixup's loop: as in fsm_sim.cc
-int prepare( Stream & S, const uint8_t * data, size_t size, bool packed, Job & B )
+int prepare( Stream & S, const uint8_t * data, size_t size, bool packed, bool mp, Job & B )
 {
   aa::ParseJob & J = B.J;
   try { S.parser.parse_header( data, size, B.hdr, J.fp ); }
@@ -61,9 +62,11 @@ int prepare( Stream & S, const uint8_t * data, size_t size, bool packed, Job & B
   std::memcpy( dev_data, data, size );
   J.data = dev_data;
   J.nmb = nmb; J.flags_padded = ( nmb + 15 ) & ~15u;
-  J.mbflags = B.buf<uint8_t>( J.flags_padded );
+  // one lane per partition allowed: a second copy of the flags, partition by partition (as the runtime lays it out)
+  J.mp_stride = mp && J.fp.nparts > 1 ? aa::mp_flag_stride( J.fp.mbw, J.fp.mbh, J.fp.nparts ) : 0u;
+  J.mbflags = B.buf<uint8_t>( J.flags_padded + size_t( J.fp.nparts ) * J.mp_stride );
   J.mbs = B.buf<aa_mb_info>( nmb * sizeof( aa_mb_info ) );
-  J.chunk_list = B.buf<uint32_t>( size_t( aa::chunk_list_entries( nmb ) ) * 4 );
+  J.chunk_list = B.buf<uint32_t>( size_t( aa::chunk_list_entries( nmb, J.mp_stride ? J.fp.nparts : 1u ) ) * 4 );
   J.packed_pos = packed ? B.buf<uint32_t>( size_t( nmb ) * 4 ) : nullptr;
   const unsigned words_per_row = ( J.fp.mbw + 63 ) / 64;
   J.intra_rows = B.buf<unsigned long long>( size_t( words_per_row ) * J.fp.mbh * 8 );
@@ -77,6 +80,7 @@ int prepare( Stream & S, const uint8_t * data, size_t size, bool packed, Job & B
     for ( unsigned col = 0; col < J.fp.mbw; col++, mi++ ) {
       const uint8_t flags = aa::parse_mb_header( bd, J.fp, J.mbs, mi, col, row, static_cast<uint8_t *>( nullptr ) );
       J.mbflags[mi] = flags;
+      if ( J.mp_stride ) J.mbflags[aa::mp_flag_index( J, row, col )] = flags;
       if ( !( flags & AA_MB_INTER ) ) { intra++; word |= 1ull << ( col & 63 ); }
       else if ( J.mbs[mi].y_mode == aa::SPLITMV ) split = 1;
       if ( ( col & 63 ) == 63 || col + 1 == J.fp.mbw ) { J.intra_rows[row * words_per_row + ( col >> 6 )] = word; word = 0; }
@@ -120,7 +124,7 @@ bool collect( const Job & B, const aa::Heap & H, bool packed, aa_mb_info * mbs, 
   return running == B.sum.num_coeff_blocks;
 }
 
-template <bool PK>
+template <bool PK, bool MP>
 void wave_period( std::vector<aa::tok::Lane> & L, std::vector<aa::tok::Frame> & F, const std::vector<int> & job_of, uint8_t * smem, const aa::Heap & H,
                   uint64_t * boundary_passes )
 {
@@ -130,14 +134,14 @@ void wave_period( std::vector<aa::tok::Lane> & L, std::vector<aa::tok::Frame> & 
   // run_period, written out over the lanes of the wave (AA_ANY = a ballot over them)
   uint32_t it = 0;
   while ( it < kPeriod ) {
-    if ( any( []( const Lane & l ) { return at_boundary( l ); } ) ) {
-      for ( size_t k = 0; k < n; k++ ) if ( job_of[k] >= 0 && at_boundary( L[k] ) ) macroblock_boundary<PK>( L[k], smem, F[k], H );
+    if ( any( []( const Lane & l ) { return at_boundary<MP>( l ); } ) ) {
+      for ( size_t k = 0; k < n; k++ ) if ( job_of[k] >= 0 && at_boundary<MP>( L[k] ) ) macroblock_boundary<PK, MP>( L[k], smem, F[k], H );
       ( *boundary_passes )++;
       it++;
       if ( !any( []( const Lane & l ) { return l.rec < R_MBDONE; } ) ) break;
     }
     do {
-      for ( size_t k = 0; k < n; k++ ) if ( job_of[k] >= 0 ) step<PK>( L[k], smem, F[k] );
+      for ( size_t k = 0; k < n; k++ ) if ( job_of[k] >= 0 ) step<PK, MP>( L[k], smem, F[k] );
       it++;
     } while ( it < kPeriod && !any( []( const Lane & l ) { return l.rec == R_MBDONE; } ) );
   }
@@ -156,7 +160,7 @@ extern "C" {
 // hdr_out [frames]; stats: [0] periods [1] boundary passes [2] frames handed back for lack of memory [3] peak chunks out
 // [4] lanes that were busy in the busiest period.  -> 0 ok; 1..: a frame's pre-pass failed; 100: a check failed; 101: stuck
 int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_stream, const uint8_t * const * data, const size_t * sizes,
-                  int lanes, uint32_t pool_chunks, int packed, uint32_t seed, int burst, int burst_gap,
+                  int lanes, uint32_t pool_chunks, int packed, int mp, uint32_t seed, int burst, int burst_gap,
                   aa_frame_header * hdr_out, aa_mb_info * mbs_out, int16_t * coeffs_out, uint64_t * stats )
 {
   using namespace aa::tok;
@@ -171,7 +175,7 @@ int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_
       first_job[s] = f;
       for ( int k = 0; k < frames_per_stream[s]; k++, f++ ) {
         jobs.emplace_back( new Job );
-        if ( const int rc = prepare( *streams[s], data[f], sizes[f], packed != 0, *jobs.back() ) ) return rc > 0 ? rc : -rc;
+        if ( const int rc = prepare( *streams[s], data[f], sizes[f], packed != 0, mp != 0, *jobs.back() ) ) return rc > 0 ? rc : -rc;
         multi = multi || jobs.back()->J.fp.nparts > 1;
       }
     }
@@ -193,7 +197,7 @@ int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_
     }
   }
   // the heap and its pool
-  const uint32_t worst = aa::chunk_list_entries( nmb ) - 1u;
+  const uint32_t worst = aa::chunk_list_entries( nmb, mp ? 8u : 1u ) - 1u;
   const uint32_t heap_chunks = pool_chunks ? pool_chunks : worst * static_cast<uint32_t>( std::min( n_jobs, lanes ) + 2 );
   int16_t * heap_mem = static_cast<int16_t *>( aligned( size_t( heap_chunks ) * aa::kChunkBlocks * 32 ) );
   uint32_t ring_entries = 1; while ( ring_entries < heap_chunks ) ring_entries <<= 1;
@@ -222,7 +226,7 @@ int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_
   std::deque<int> queue;
   size_t published = 0;
   int done = 0, bad = 0;
-  uint64_t periods = 0, boundary_passes = 0, handed_back = 0, peak_out = 0, peak_busy = 0, idle_periods = 0;
+  uint64_t periods = 0, boundary_passes = 0, handed_back = 0, peak_out = 0, peak_busy = 0, idle_periods = 0, mp_frames = 0, parked = 0;
   auto out_index = [&]( int j ) { return static_cast<size_t>( j ); };
   while ( done < n_jobs ) {
     // jobs arrive in bursts
@@ -232,36 +236,57 @@ int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_
     for ( int k = 0; k < lanes && !queue.empty(); k++ ) {
       if ( job_of[k] >= 0 ) continue;
       const int j = queue.front(); queue.pop_front();
-      job_of[k] = j;
       jobs[j]->attempts++;
+      const uint32_t P = jobs[j]->J.mp_stride ? jobs[j]->J.fp.nparts : 1u;
+      std::vector<int> idle;
+      for ( int q = k; q < lanes && idle.size() < P; q++ ) if ( job_of[q] < 0 ) idle.push_back( q );
+      if ( P > 1 && idle.size() == P ) {
+        // one lane per partition: P idle lanes of the wave, partition p on the p-th of them; what they share lives in the slice
+        // of the lane that has the frame's last row
+        const uint32_t owner = L[idle[mp_owner_partition( &jobs[j]->J )]].base;
+        for ( uint32_t p = 0; p < P; p++ ) {
+          const int q = idle[p];
+          job_of[q] = j;
+          F[q] = frame_of_partition( &jobs[j]->J, p, owner );
+          begin_frame( L[q], smem, L[q].base, F[q] );
+        }
+        mp_frames++;
+        continue;
+      }
+      job_of[k] = j;
       F[k] = frame_of( &jobs[j]->J );
       begin_frame( L[k], smem, L[k].base, F[k] );
     }
     uint64_t busy = 0;
-    for ( int k = 0; k < lanes; k++ ) if ( job_of[k] >= 0 ) { top_up( L[k], smem, F[k] ); busy++; }
+    for ( int k = 0; k < lanes; k++ ) if ( job_of[k] >= 0 ) { if ( mp ) top_up<true>( L[k], smem, F[k] ); else top_up<false>( L[k], smem, F[k] ); busy++; }
     peak_busy = std::max( peak_busy, busy );
     if ( !busy ) { if ( ++idle_periods > 1000 ) { free( heap_mem ); return 101; } periods++; continue; }
     idle_periods = 0;
-    if ( packed ) wave_period<true>( L, F, job_of, smem, H, &boundary_passes );
-    else wave_period<false>( L, F, job_of, smem, H, &boundary_passes );
+    if ( mp ) { if ( packed ) wave_period<true, true>( L, F, job_of, smem, H, &boundary_passes ); else wave_period<false, true>( L, F, job_of, smem, H, &boundary_passes ); }
+    else { if ( packed ) wave_period<true, false>( L, F, job_of, smem, H, &boundary_passes ); else wave_period<false, false>( L, F, job_of, smem, H, &boundary_passes ); }
     periods++;
     {
       const int64_t out_now = static_cast<int64_t>( heap_chunks ) - pool.avail;
       peak_out = std::max<uint64_t>( peak_out, out_now > 0 ? static_cast<uint64_t>( out_now ) : 0u );
     }
+    for ( int k = 0; k < lanes; k++ ) if ( job_of[k] >= 0 && L[k].rec == R_PARK ) parked++;
     // frames that are through: what the host does when it sees `done`
     for ( int k = 0; k < lanes; k++ ) {
       if ( job_of[k] < 0 || L[k].rec != R_DONE ) continue;
       const int j = job_of[k];
       Job & B = *jobs[j];
       job_of[k] = -1;
+      if ( F[k].mp_P > 1 ) {                          // one lane per partition: the frame is through when its LAST lane is
+        if ( !B.sum.done || B.collected ) continue;
+        B.collected = true;
+      }
       if ( !B.sum.done || B.J.chunk_list[0] != B.sum.num_chunks ) { bad = 1; done++; continue; }
       if ( B.sum.status == aa::TOK_NO_MEMORY ) {
         // handed back: its chunks return to the pool, the frame goes to the queue again (resolve_summary)
         pool_push( H, B.J.chunk_list + 1, 0, B.sum.num_chunks );
         handed_back++;
         if ( B.attempts > 64 ) { free( heap_mem ); return 101; }
-        B.sum.done = 0; B.sum.status = 0; B.sum.num_chunks = 0;
+        B.sum.done = 0; B.sum.status = 0; B.sum.num_chunks = 0; B.collected = false;
         queue.push_back( j );
         continue;
       }
@@ -279,7 +304,7 @@ int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_
     if ( periods > ( 1ull << 32 ) ) { free( heap_mem ); return 101; }
   }
   if ( pool.avail != static_cast<int32_t>( heap_chunks ) ) bad = 1;            // every chunk came back, once
-  if ( stats ) { stats[0] = periods; stats[1] = boundary_passes; stats[2] = handed_back; stats[3] = peak_out; stats[4] = peak_busy; }
+  if ( stats ) { stats[0] = periods; stats[1] = boundary_passes; stats[2] = handed_back; stats[3] = peak_out; stats[4] = peak_busy; stats[5] = mp_frames; stats[6] = parked; }
   free( heap_mem );
   return bad ? 100 : 0;
 }

@@ -24,7 +24,9 @@ def sim_lib():
     deps = srcs + [os.path.join(CSRC, f) for f in ("tok_fsm.hh", "coeff_pack.hh", "parse_common.hh", "parser.hh", "bool_reader.hh")]
     os.makedirs(BUILD, exist_ok=True)
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps):
-        subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wextra", "-fPIC", "-shared"] + srcs + ["-o", LIB], check=True)
+        tmp = "%s.%d.tmp" % (LIB, os.getpid())             # (pytest-xdist workers may build at the same time: rename is atomic)
+        subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wextra", "-fPIC", "-shared"] + srcs + ["-o", tmp], check=True)
+        os.replace(tmp, LIB)
     L = C.CDLL(LIB)
     L.fsm_sim_create.restype = C.c_void_p
     L.fsm_sim_create.argtypes = [C.c_uint16, C.c_uint16]
