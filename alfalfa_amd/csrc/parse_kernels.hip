@@ -189,30 +189,19 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
           const aa::ParseJob * job = nullptr;
           if ( mine ) job = reinterpret_cast<const aa::ParseJob *>( AA_AT_LOAD( &a.slots[( base + rank ) & a.q->mask] ) );
           if constexpr ( MP ) {
-            // Ticket t (t = 0 .. got - 1, held by the idle lane of rank t) is a frame of P_t partitions.  In ticket order, a frame
-            // gets P_t lanes if the wave has that many idle lanes to spare beyond one per ticket, else it runs on one lane as ever.
-            // Lanes are dealt out in rank order: the frame's partition p goes to the (start + p)-th lane handed out.
+            // the tickets' frames get their lanes (tok::mp_deal): a lane per partition where the wave has them idle
             const uint32_t n_idle = static_cast<uint32_t>( __popcll( idle_mask ) );
-            uint32_t my_p = 0;
-            if ( mine ) my_p = job->nmb && job->mp_stride ? job->fp.nparts : 1u;
-            uint32_t spare = n_idle - got, start = 0;
-            const aa::ParseJob * my_job = nullptr;
-            uint32_t my_part = 0, my_n = 1, my_owner = 0;
-            for ( uint32_t t = 0; t < got; t++ ) {
-              const int lt = nth_set_bit( idle_mask, t );                      // the lane that holds ticket t
-              const uint32_t P = static_cast<uint32_t>( __shfl( static_cast<int>( my_p ), lt ) );
-              const unsigned long long jp = static_cast<unsigned long long>( __shfl( static_cast<long long>( reinterpret_cast<uintptr_t>( job ) ), lt ) );
-              const uint32_t n = ( P > 1u && P - 1u <= spare ) ? P : 1u;
-              spare -= n - 1u;
-              if ( idle && rank >= start && rank < start + n ) {
-                my_job = reinterpret_cast<const aa::ParseJob *>( static_cast<uintptr_t>( jp ) );
-                my_part = rank - start; my_n = n;
-                if ( n > 1u ) my_owner = aa::tok::kTablesBytes + static_cast<uint32_t>( nth_set_bit( idle_mask, start + aa::tok::mp_owner_partition( my_job ) ) ) * a.lane_bytes;
-              }
-              start += n;
-            }
-            if ( my_job ) {
-              F = my_n > 1u ? aa::tok::frame_of_partition( my_job, my_part, my_owner ) : aa::tok::frame_of( my_job );
+            const int my_parts = mine ? static_cast<int>( job->nmb && job->mp_stride ? job->fp.nparts : 1u ) : 1;
+            const aa::tok::MpDeal d = aa::tok::mp_deal( n_idle, got, rank, [&]( uint32_t t ) {
+              return static_cast<uint32_t>( __shfl( my_parts, nth_set_bit( idle_mask, t ) ) ); } );      // (t is wave-uniform: every lane takes part)
+            // the job of my ticket is in the registers of the lane that holds the ticket (rank d.ticket)
+            const long long jp = __shfl( static_cast<long long>( reinterpret_cast<uintptr_t>( job ) ), nth_set_bit( idle_mask, d.ticket ) );
+            if ( idle && d.any ) {
+              const aa::ParseJob * my_job = reinterpret_cast<const aa::ParseJob *>( static_cast<uintptr_t>( jp ) );
+              if ( d.n > 1u ) {
+                const int owner_lane = nth_set_bit( idle_mask, d.start + aa::tok::mp_owner_partition( my_job ) );
+                F = aa::tok::frame_of_partition( my_job, d.part, aa::tok::kTablesBytes + static_cast<uint32_t>( owner_lane ) * a.lane_bytes );
+              } else F = aa::tok::frame_of( my_job );
               if ( my_job->nmb == 0 ) { L.rec = aa::tok::R_DONE; }                  // (never queued; belt and braces)
               else aa::tok::begin_frame( L, smem, L.base, F );
             }

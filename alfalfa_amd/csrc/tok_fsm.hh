@@ -336,6 +336,27 @@ AA_HD inline Frame frame_of_partition( const ParseJob * job, uint32_t p, uint32_
 // the partition whose lane finishes last (it has the frame's last row): its slice holds what the lanes share
 AA_HD inline uint32_t mp_owner_partition( const ParseJob * job ) { return ( job->fp.mbh - 1u ) % job->fp.nparts; }
 
+// How a wave deals its idle lanes out to the tickets it has just drawn (one lane per partition): ticket t = 0 .. got - 1 is a
+// frame of parts_of( t ) partitions.  In ticket order, a frame gets a lane per partition if the wave has that many idle lanes to
+// spare beyond one per ticket, else one lane as ever; lanes go out in rank order (rank = position among the wave's idle lanes).
+// -> what the idle lane of rank `rank` does: any = false: nothing (it stays idle); else partition `part` of ticket `ticket`,
+// whose n lanes are the ranks start .. start + n - 1.  Every lane of the wave evaluates this with the same n_idle / got / parts.
+struct MpDeal { uint32_t ticket, part, n, start; bool any; };
+template <class PartsOf>
+AA_HD inline MpDeal mp_deal( uint32_t n_idle, uint32_t got, uint32_t rank, PartsOf parts_of )
+{
+  MpDeal d { 0, 0, 1, 0, false };
+  uint32_t spare = n_idle - got, start = 0;
+  for ( uint32_t t = 0; t < got; t++ ) {
+    const uint32_t P = parts_of( t );
+    const uint32_t n = ( P > 1u && P - 1u <= spare ) ? P : 1u;
+    spare -= n - 1u;
+    if ( rank >= start && rank < start + n ) { d.ticket = t; d.part = rank - start; d.n = n; d.start = start; d.any = true; }
+    start += n;
+  }
+  return d;
+}
+
 // What the lanes of a frame share (one lane per partition), in the owner's slice where a single lane keeps its saved partition
 // decoders (part_off): all zero at the start except `left`.
 struct MpShared {

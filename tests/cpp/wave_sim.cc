@@ -160,7 +160,7 @@ extern "C" {
 // hdr_out [frames]; stats: [0] periods [1] boundary passes [2] frames handed back for lack of memory [3] peak chunks out
 // [4] lanes that were busy in the busiest period.  -> 0 ok; 1..: a frame's pre-pass failed; 100: a check failed; 101: stuck
 int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_stream, const uint8_t * const * data, const size_t * sizes,
-                  int lanes, uint32_t pool_chunks, int packed, int mp, uint32_t seed, int burst, int burst_gap,
+                  int lanes, uint32_t pool_chunks, int packed, int mp, int mp_hint, uint32_t seed, int burst, int burst_gap,
                   aa_frame_header * hdr_out, aa_mb_info * mbs_out, int16_t * coeffs_out, uint64_t * stats )
 {
   using namespace aa::tok;
@@ -233,29 +233,30 @@ int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_
     if ( published < order.size() && ( periods % static_cast<uint64_t>( std::max( 1, burst_gap ) ) == 0 || queue.empty() ) )
       for ( int b = 0; b < std::max( 1, burst ) && published < order.size(); b++ ) queue.push_back( order[published++] );
     // idle lanes take the next jobs (queue_take: all idle lanes of the wave at once, first come first served)
-    for ( int k = 0; k < lanes && !queue.empty(); k++ ) {
-      if ( job_of[k] >= 0 ) continue;
-      const int j = queue.front(); queue.pop_front();
-      jobs[j]->attempts++;
-      const uint32_t P = jobs[j]->J.mp_stride ? jobs[j]->J.fp.nparts : 1u;
+    {
+      // k_token_workers' take: the wave asks for as many tickets as it has idle lanes (mp: idle / hint, so that lanes are left for
+      // partitions), then deals its idle lanes out to the tickets' frames (tok::mp_deal, the device's own statements)
       std::vector<int> idle;
-      for ( int q = k; q < lanes && idle.size() < P; q++ ) if ( job_of[q] < 0 ) idle.push_back( q );
-      if ( P > 1 && idle.size() == P ) {
-        // one lane per partition: P idle lanes of the wave, partition p on the p-th of them; what they share lives in the slice
-        // of the lane that has the frame's last row
-        const uint32_t owner = L[idle[mp_owner_partition( &jobs[j]->J )]].base;
-        for ( uint32_t p = 0; p < P; p++ ) {
-          const int q = idle[p];
-          job_of[q] = j;
-          F[q] = frame_of_partition( &jobs[j]->J, p, owner );
-          begin_frame( L[q], smem, L[q].base, F[q] );
-        }
-        mp_frames++;
-        continue;
+      for ( int k = 0; k < lanes; k++ ) if ( job_of[k] < 0 ) idle.push_back( k );
+      uint32_t want = static_cast<uint32_t>( idle.size() );
+      if ( mp && want ) want = std::max( 1u, want / static_cast<uint32_t>( std::max( 1, mp_hint ) ) );
+      const uint32_t got = std::min<uint32_t>( want, static_cast<uint32_t>( queue.size() ) );
+      std::vector<int> ticket( queue.begin(), queue.begin() + got );
+      queue.erase( queue.begin(), queue.begin() + got );
+      for ( uint32_t t = 0; t < got; t++ ) jobs[ticket[t]]->attempts++;
+      auto parts_of = [&]( uint32_t t ) { const aa::ParseJob & J = jobs[ticket[t]]->J; return J.nmb && J.mp_stride ? uint32_t( J.fp.nparts ) : 1u; };
+      for ( uint32_t rank = 0; rank < idle.size() && got; rank++ ) {
+        const MpDeal d = mp ? mp_deal( static_cast<uint32_t>( idle.size() ), got, rank, parts_of )
+                            : MpDeal { rank, 0, 1, rank, rank < got };
+        if ( !d.any ) continue;
+        const int q = idle[rank], j = ticket[d.ticket];
+        job_of[q] = j;
+        if ( d.n > 1 ) {
+          F[q] = frame_of_partition( &jobs[j]->J, d.part, L[idle[d.start + mp_owner_partition( &jobs[j]->J )]].base );
+          if ( d.part == 0 ) mp_frames++;
+        } else F[q] = frame_of( &jobs[j]->J );
+        begin_frame( L[q], smem, L[q].base, F[q] );
       }
-      job_of[k] = j;
-      F[k] = frame_of( &jobs[j]->J );
-      begin_frame( L[k], smem, L[k].base, F[k] );
     }
     uint64_t busy = 0;
     for ( int k = 0; k < lanes; k++ ) if ( job_of[k] >= 0 ) { if ( mp ) top_up<true>( L[k], smem, F[k] ); else top_up<false>( L[k], smem, F[k] ); busy++; }
@@ -307,6 +308,16 @@ int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_
   if ( stats ) { stats[0] = periods; stats[1] = boundary_passes; stats[2] = handed_back; stats[3] = peak_out; stats[4] = peak_busy; stats[5] = mp_frames; stats[6] = parked; }
   free( heap_mem );
   return bad ? 100 : 0;
+}
+
+// tok::mp_deal for every rank of a wave with n_idle idle lanes that drew `got` tickets of parts[t] partitions each:
+// out[rank] = { any, ticket, part, n, start }
+void wave_sim_deal( uint32_t n_idle, uint32_t got, const uint32_t * parts, uint32_t * out )
+{
+  for ( uint32_t rank = 0; rank < n_idle; rank++ ) {
+    const aa::tok::MpDeal d = aa::tok::mp_deal( n_idle, got, rank, [&]( uint32_t t ) { return parts[t]; } );
+    out[5 * rank + 0] = d.any; out[5 * rank + 1] = d.ticket; out[5 * rank + 2] = d.part; out[5 * rank + 3] = d.n; out[5 * rank + 4] = d.start;
+  }
 }
 
 } // extern "C"

@@ -30,12 +30,13 @@ def wave_lib():
         os.replace(tmp, LIB)
     L = C.CDLL(LIB)
     L.wave_sim_run.argtypes = [C.c_uint16, C.c_uint16, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t),
-                               C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int,
+                               C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int,
                                C.POINTER(capi.FrameHeader), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.wave_sim_deal.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     return L
 
 
-def run_wave(w, h, streams, lanes, pool_chunks=0, packed=False, seed=1, burst=1000, burst_gap=1, mp=False):
+def run_wave(w, h, streams, lanes, pool_chunks=0, packed=False, seed=1, burst=1000, burst_gap=1, mp=False, mp_hint=4):
     """streams: list of lists of frames (bytes) of one size -> stats; asserts every frame's records equal the host parser's"""
     L = wave_lib()
     flat = [fr for st in streams for fr in st]
@@ -48,7 +49,7 @@ def run_wave(w, h, streams, lanes, pool_chunks=0, packed=False, seed=1, burst=10
     mbs = np.zeros(n * nmb, dtype=capi.MB_INFO_DTYPE)
     cfs = np.zeros((n, 25 * nmb, 16), dtype=np.int16)
     stats = (C.c_uint64 * 8)()
-    rc = L.wave_sim_run(w, h, len(streams), counts, data, sizes, lanes, pool_chunks, int(packed), int(mp), seed, burst, burst_gap,
+    rc = L.wave_sim_run(w, h, len(streams), counts, data, sizes, lanes, pool_chunks, int(packed), int(mp), mp_hint, seed, burst, burst_gap,
                         hdrs, mbs.ctypes.data, cfs.ctypes.data, stats)
     assert rc == 0, rc
     k = 0
@@ -165,3 +166,36 @@ def test_one_lane_per_partition_with_a_scarce_pool(packed):
     assert plenty["handed_back"] == 0 and plenty["frames_with_a_lane_per_partition"] > 0
     scarce = run_wave(w, h, streams, 16, pool_chunks=6, packed=packed, seed=5, mp=True)
     assert scarce["handed_back"] > 0 and scarce["frames_with_a_lane_per_partition"] > 0
+
+
+def test_how_a_wave_deals_its_idle_lanes_out():
+    """tok::mp_deal, the statements every lane of a wave evaluates after a draw: for any number of idle lanes, tickets and
+    partition counts -- every ticket gets lanes (one, or one per partition), no lane serves two, lanes go out in rank order,
+    a frame is split only if ALL its partitions get a lane, and a frame early in the draw is not starved by a later one"""
+    import random
+    L = wave_lib()
+    rng = random.Random(11)
+    for _ in range(3000):
+        n_idle = rng.randint(1, 64)
+        got = rng.randint(1, n_idle)
+        parts = [rng.choice([1, 1, 2, 4, 8]) for _ in range(got)]
+        out = (C.c_uint32 * (5 * n_idle))()
+        L.wave_sim_deal(n_idle, got, (C.c_uint32 * got)(*parts), out)
+        deal = [tuple(out[5 * r:5 * r + 5]) for r in range(n_idle)]
+        lanes_of = {}
+        for r, (any_, t, p, n, start) in enumerate(deal):
+            if not any_:
+                continue
+            assert t < got and n in (1, parts[t]) and p < n and start + p == r
+            lanes_of.setdefault(t, []).append((p, n, start))
+        assert sorted(lanes_of) == list(range(got))                       # every ticket is served
+        spare, start = n_idle - got, 0
+        for t in range(got):
+            ps = sorted(lanes_of[t])
+            n = ps[0][1]
+            assert [p for p, _, _ in ps] == list(range(n)) and all(s == start for _, _, s in ps)
+            want_split = parts[t] > 1 and parts[t] - 1 <= spare           # first come, first served
+            assert n == (parts[t] if want_split else 1)
+            spare -= n - 1
+            start += n
+        assert start <= n_idle
