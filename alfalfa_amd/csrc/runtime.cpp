@@ -1503,7 +1503,7 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
   const uint32_t mp_stride = mp ? aa::mp_flag_stride( J.fp.mbw, J.fp.mbh, J.fp.nparts ) : 0u;
   const size_t flags_bytes = align_up( size_t( flags_padded ) + size_t( J.fp.nparts ) * mp_stride );
   const size_t list_bytes = align_up( size_t( aa::chunk_list_entries( nmb, mp ? J.fp.nparts : 1u ) ) * sizeof( uint32_t ) );
-  if ( mp ) ctx->tok.mp_hint = std::max<uint32_t>( ctx->tok.mp_hint, J.fp.nparts );
+
   const size_t pos_bytes = ctx->tok.packed ? align_up( size_t( nmb ) * sizeof( uint32_t ) ) : 0;
   rec.rec_bytes = mb_bytes + rows_bytes + flags_bytes + list_bytes + pos_bytes;
   rec.rec_block = b->dev + it.rec_off; rec.rec_in_arena = true;
@@ -1758,6 +1758,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   for ( int i = 0; i < n; i++ ) b->items[i] = { items[i].s, items[i].frame_index, items[i].status == AA_OK };
   b->head_bytes = jobs_bytes + dframes_bytes;
   b->max_mbw = max_mbw; b->max_nparts = max_nparts;
+  if ( ctx->tok.lane_per_partition ) ctx->tok.mp_hint = std::max<uint32_t>( ctx->tok.mp_hint, static_cast<uint32_t>( max_nparts ) );   // (workgroups launched from now on leave that many lanes per ticket)
   // From here on the frames that were appended point at the batch.  If anything below fails they are given back one by one
   // (the last one frees the batch): no frame is left with a dangling batch, nothing leaks; the frames themselves stay in
   // their streams as frames whose records are gone (decoding them reports that).
