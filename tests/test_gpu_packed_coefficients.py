@@ -53,4 +53,7 @@ def test_the_format_is_fixed_once_frames_were_submitted(packed_ctx, gpu_ctx):
         packed_ctx.set_packed_coefficients(False)
     assert e.value.kind == "LogicError" or "submitted" in str(e.value)
     packed_ctx.set_packed_coefficients(True)                 # (saying what already holds is fine)
+    packed_ctx.decode_batch([d], [0])
+    from conftest import GOLDEN, sha256
+    assert sha256(d.raster_bytes(0)) == GOLDEN["qcif_q30"]["raster_sha256"][0]
     assert gpu_ctx.info()["packed_coefficients"] == 0         # the session's shared context stores dense blocks
