@@ -158,7 +158,8 @@ extern "C" {
 // when the wave has run `burst_gap` periods.  pool_chunks: chunks the pool holds in all (0: plenty).
 // Outputs, frame by frame in stream-major order: mbs_out [frames * nmb], coeffs_out [frames * (25 * nmb) * 16],
 // hdr_out [frames]; stats: [0] periods [1] boundary passes [2] frames handed back for lack of memory [3] peak chunks out
-// [4] lanes that were busy in the busiest period.  -> 0 ok; 1..: a frame's pre-pass failed; 100: a check failed; 101: stuck
+// [4] lanes that were busy in the busiest period.  -> 0 ok; 1..: a frame's pre-pass failed; 100: a check failed; 101: jobs are
+// missing although no lane is busy; 102: a frame was handed back more than 64 times; 103: too many periods
 int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_stream, const uint8_t * const * data, const size_t * sizes,
                   int lanes, uint32_t pool_chunks, int packed, int mp, int mp_hint, uint32_t seed, int burst, int burst_gap,
                   aa_frame_header * hdr_out, aa_mb_info * mbs_out, int16_t * coeffs_out, uint64_t * stats )
@@ -223,12 +224,22 @@ int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_
     L[k].rec = R_DONE; L[k].pend_wpos = L[k].pend_mwpos = kNoPend; L[k].steps = 0;
     L[k].base = kTablesBytes + static_cast<uint32_t>( k ) * lane_bytes;
   }
-  std::deque<int> queue;
+  std::deque<int> queue, held;
   size_t published = 0;
   int done = 0, bad = 0;
   uint64_t periods = 0, boundary_passes = 0, handed_back = 0, peak_out = 0, peak_busy = 0, idle_periods = 0, mp_frames = 0, parked = 0;
   auto out_index = [&]( int j ) { return static_cast<size_t>( j ); };
   while ( done < n_jobs ) {
+    // frames that were handed back go to the queue again one at a time, when the pool has what such a frame may take (the
+    // runtime waits for exactly that before it runs a frame again: resolve_summary)
+    if ( !held.empty() ) {
+      const aa::ParseJob & HJ = jobs[held.front()]->J;
+      const int32_t need = static_cast<int32_t>( aa::chunk_list_entries( HJ.nmb, HJ.mp_stride ? HJ.fp.nparts : 1u ) ) - 1;
+      bool running = false;
+      for ( int k = 0; k < lanes; k++ ) if ( job_of[k] >= 0 ) running = true;
+      if ( pool.avail >= std::min<int32_t>( need, static_cast<int32_t>( heap_chunks ) ) ) { queue.push_back( held.front() ); held.pop_front(); }
+      else if ( !running && queue.empty() && published == order.size() ) { free( heap_mem ); return 102; }       // nothing left that could give chunks back
+    }
     // jobs arrive in bursts
     if ( published < order.size() && ( periods % static_cast<uint64_t>( std::max( 1, burst_gap ) ) == 0 || queue.empty() ) )
       for ( int b = 0; b < std::max( 1, burst ) && published < order.size(); b++ ) queue.push_back( order[published++] );
@@ -286,9 +297,9 @@ int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_
         // handed back: its chunks return to the pool, the frame goes to the queue again (resolve_summary)
         pool_push( H, B.J.chunk_list + 1, 0, B.sum.num_chunks );
         handed_back++;
-        if ( B.attempts > 64 ) { free( heap_mem ); return 101; }
+        if ( B.attempts > 64 ) { free( heap_mem ); return 102; }
         B.sum.done = 0; B.sum.status = 0; B.sum.num_chunks = 0; B.collected = false;
-        queue.push_back( j );
+        held.push_back( j );          // (resolve_summary: run again when the pool holds what the frame may need)
         continue;
       }
       if ( B.sum.status != aa::TOK_OK ) { bad = 1; done++; continue; }
@@ -302,7 +313,7 @@ int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_
       pool_push( H, B.J.chunk_list + 1, 0, B.sum.num_chunks );      // released: the chunks go back (k_pool_free_lists)
       done++;
     }
-    if ( periods > ( 1ull << 32 ) ) { free( heap_mem ); return 101; }
+    if ( periods > ( 1ull << 32 ) ) { free( heap_mem ); return 103; }
   }
   if ( pool.avail != static_cast<int32_t>( heap_chunks ) ) bad = 1;            // every chunk came back, once
   if ( stats ) { stats[0] = periods; stats[1] = boundary_passes; stats[2] = handed_back; stats[3] = peak_out; stats[4] = peak_busy; stats[5] = mp_frames; stats[6] = parked; }
