@@ -61,7 +61,7 @@ class CtxInfo(C.Structure):
         (n, C.c_uint32) for n in ("heap_is_virtual", "token_lanes_per_workgroup", "token_workgroups_capacity", "token_workgroups_alive",
                                   "token_lane_lds_bytes", "token_workgroup_lds_bytes", "jobs_waiting", "compute_units")] + [
         ("heap_free_chunks", C.c_int32), ("lanes_starved", C.c_uint32), ("token_profile", C.c_uint64 * 8),
-        ("packed_coefficients", C.c_uint32), ("lane_per_partition", C.c_uint32)]
+        ("packed_coefficients", C.c_uint32), ("lane_per_partition", C.c_uint32), ("clock_mhz", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class AlfalfaError(RuntimeError):
@@ -114,6 +114,7 @@ SYMBOLS = [
     ("aa_stream_download", C.c_int, [_P, C.c_int, _P, _P, _P]),
     ("aa_pinned_alloc", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]), ("aa_pinned_free", None, [_P]),
     ("aa_stream_download_async", C.c_int, [_P, C.c_int, _P, _P, _P]), ("aa_stream_download_wait", C.c_int, [_P]),
+    ("aa_download_batch_async", C.c_int, [_P, C.POINTER(_P), C.c_int, C.POINTER(C.c_int), _P, C.c_size_t]), ("aa_ctx_download_wait", C.c_int, [_P]),
     ("aa_stream_raster_device", C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     ("aa_stream_references", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("aa_stream_reference_slots", C.c_int, [_P, C.POINTER(C.c_int)]),

@@ -31,6 +31,12 @@ struct aa_raster_binding {
   const uint8_t * ref[3][3];     // last, golden, altref
 };
 
+// One raster on its way out (aa_download_batch_async): `bytes` from `src` into piece i of the staging area
+struct aa_gather_job {
+  const uint8_t * src;
+  size_t bytes;
+};
+
 // One device-parsed frame whose coefficients are stored packed (tok_fsm.hh), as it is handed to reconstruction: the expansion
 // pass writes its dense blocks and the macroblocks' coeff_index, and points the job at the dense array.
 struct aa_expand_job {
@@ -111,6 +117,8 @@ int launch_loopfilter_rows4( const aa_frame_list & list, int n_groups, int mbh_m
 // out16[x] += number of workgroups (of `blocks`) that ran on XCD x
 int launch_probe_xcds( int * out16, int blocks, void * stream );
 int launch_bind_rasters( const aa_raster_binding * b, int n, void * stream );
+// raster i (jobs[i]) -> staging + i * stride, one launch for the lot
+int launch_gather_rasters( const aa_gather_job * jobs, int n, uint8_t * staging, size_t stride, size_t max_bytes, void * stream );
 // per-window SSIM terms of two planes (stride = width; width a multiple of 8): (height/4 - 1) x (width/4 - 1) floats
 // dst = src with lf_level := byte `segment_id` of `levels` (records are 80 bytes, 16-byte aligned)
 int launch_lf_relevel( const aa_mb_info * src, aa_mb_info * dst, unsigned nmb, uint32_t levels, void * stream );

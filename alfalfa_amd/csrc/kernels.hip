@@ -15,6 +15,7 @@
 // issue and the raster-order dependency wavefront, HBM traffic stays near the algorithmic bytes.  Batches of independent
 // frames (streams / GOPs) fill the chip.  The row-pipelined kernels are XCD-affine (see take_ticket).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstddef>
 
 #include <cstdlib>
@@ -1495,6 +1496,19 @@ __global__ void k_bind_rasters( const aa_raster_binding * b, int n )
   for ( int r = 1; r < 4; r++ ) for ( int p = 0; p < 3; p++ ) f->ref[r][p] = b[i].ref[r - 1][p];
 }
 
+// Delivery of shown frames (aa_download_batch_async): raster i (three padded planes, contiguous in its pool piece) -> piece i of one
+// staging area, so that ONE copy takes a whole frame index of a batch to the host instead of three per stream.  blockIdx.y =
+// raster, 16 bytes per thread and iteration, whole-line accesses.
+__global__ __launch_bounds__( 256 ) void k_gather_rasters( const aa_gather_job * jobs, uint8_t * staging, size_t stride )
+{
+  const aa_gather_job J = jobs[blockIdx.y];
+  const uint4 * src = reinterpret_cast<const uint4 *>( J.src );
+  uint4 * dst = reinterpret_cast<uint4 *>( staging + stride * blockIdx.y );
+  const size_t n16 = J.bytes >> 4;
+  for ( size_t i = size_t( blockIdx.x ) * 256 + threadIdx.x; i < n16; i += size_t( gridDim.x ) * 256 ) dst[i] = src[i];
+  if ( blockIdx.x == 0 && threadIdx.x < ( J.bytes & 15 ) ) staging[stride * blockIdx.y + ( n16 << 4 ) + threadIdx.x] = J.src[( n16 << 4 ) + threadIdx.x];
+}
+
 } // namespace
 
 // ---- SSIM windows of the encoder's loop-filter search (util/ssim.cc:57-71 -> libx264 pixel_ssim_wxh) -------
@@ -1552,6 +1566,17 @@ int launch_ssim_windows( const uint8_t * a, const uint8_t * b, int width, int he
   if ( w4 < 2 || h4 < 2 ) return static_cast<int>( hipErrorInvalidValue );
   hipLaunchKernelGGL( k_ssim_windows, dim3( ( w4 - 1 + 255 ) / 256, h4 - 1 ), dim3( 256 ), 0, static_cast<hipStream_t>( stream ), a, b, width, w4, h4, out );
   return static_cast<int>( hipGetLastError() );
+}
+
+int launch_gather_rasters( const aa_gather_job * jobs, int n, uint8_t * staging, size_t stride, size_t max_bytes, void * stream )
+{
+  const unsigned per = static_cast<unsigned>( std::min<size_t>( 64, std::max<size_t>( 1, max_bytes / ( 256 * 16 * 4 ) ) ) );
+  for ( int base = 0; base < n; base += 32768 ) {
+    const int cnt = std::min( 32768, n - base );
+    hipLaunchKernelGGL( k_gather_rasters, dim3( per, cnt ), dim3( 256 ), 0, static_cast<hipStream_t>( stream ), jobs + base, staging + stride * base, stride );
+    if ( hipError_t e = hipGetLastError() ) return static_cast<int>( e );
+  }
+  return 0;
 }
 
 int launch_bind_rasters( const aa_raster_binding * b, int n, void * stream )

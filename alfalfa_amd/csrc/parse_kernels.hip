@@ -153,6 +153,7 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
   uint32_t backoff = 0;
   unsigned long long idle_since = 0;      // the wave has had no frame since (0: it has one)
   uint32_t looks = 0;
+  bool retiring = false;                  // sticky: once the host has told this grid to retire, its waves take no more jobs
   // diagnostics: where a wave's time goes (100 MHz ticks): [0] boundary passes [1] their number [2] steps [3] looking for / starting
   // frames [4] ring top-ups [5] periods (hot loops + boundary passes) [6] lane-periods with a frame [7] periods
   unsigned long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -161,8 +162,8 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
     const unsigned long long t_a = profiling ? wall_clock64() : 0ull;
     const bool idle = is_lane && L.rec == aa::tok::R_DONE;
     const unsigned long long idle_mask = __ballot( idle );
-    bool looked = false, retired = false;
-    if ( idle_mask ) {
+    bool looked = false;
+    if ( idle_mask && !retiring ) {
       if ( backoff ) backoff--;
       else {
         looked = true;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
           }
         }
         base = __shfl( base, first ); got = __shfl( got, first );
-        if ( got == 0xFFFFFFFFu ) { retired = true; got = 0; }
+        if ( got == 0xFFFFFFFFu ) { retiring = true; got = 0; }
         const uint32_t rank = static_cast<uint32_t>( __popcll( idle_mask & ( ( 1ull << lane ) - 1ull ) ) );
         const bool mine = idle && rank < got;
         if ( got ) {
@@ -215,7 +216,7 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
     }
     const bool active = is_lane && L.rec != aa::tok::R_DONE;
     if ( !__any( active ) ) {
-      if ( retired ) break;
+      if ( retiring ) break;              // (the lanes' frames are through: the stream this grid holds is the host's again)
       if ( looked ) {
         // No lane has a frame and the queue is empty.  The wave does not leave at once: the host hands frames over in bursts,
         // and a grid whose waves left in the gap between two bursts would have to be launched again -- on a worker stream that a
@@ -237,6 +238,11 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
       const unsigned long long t_d = wall_clock64();
       prof[3] += t_b - t_a; prof[4] += t_c - t_b; prof[5] += t_d - t_c;
       prof[6] += static_cast<unsigned long long>( __popcll( __ballot( active ) ) ); prof[7]++;
+      // (waves stay for as long as there is work: the sums go out every 1024 periods, not only when the wave leaves)
+      if ( ( prof[7] & 1023ull ) == 0 ) {
+        if ( lane == 0 ) for ( int k = 0; k < 8; k++ ) __hip_atomic_fetch_add( &a.prof[k], prof[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        for ( int k = 0; k < 8; k++ ) prof[k] = 0;
+      }
     }
   }
   if ( lane == 0 ) {
@@ -294,8 +300,8 @@ __global__ __launch_bounds__( 256 ) void k_expand_coeffs( const int16_t * heap, 
   }
 }
 
-// jobs[order[i]] -> the queue, in this order (longest chains first).  Frames the host pre-pass rejected (nmb == 0) go in too:
-// the lane that draws one drops it.
+// jobs[order[i]] -> the queue, in this order (longest chains first).  `order` lists live frames only: a ticket is a pointer into
+// the batch arena, and nobody waits for the lane of a rejected or released frame before the arena is recycled.
 __global__ __launch_bounds__( 64 ) void k_enqueue_jobs( aa::TokQueue * q, unsigned long long * slots, const ParseJob * jobs, const uint32_t * order, int n )
 {
   __shared__ uint32_t s_base;

@@ -83,6 +83,8 @@ struct Batch {
   bool patch_jobs = false;                   // the jobs in HBM lack the coefficient pointers (two-phase form)
   size_t head_bytes = 0;                     // parse jobs + reconstruction job records at the start of the arena
   const uint32_t * launch_order_dev = nullptr;
+  uint32_t * launch_order_host = nullptr;    // ... in the pinned half: the LIVE items only, longest chains first
+  int n_order = 0;                           // entries of the launch order (frames the pre-pass rejected are not in it)
   int max_mbw = 0, max_nparts = 1;
   hipStream_t ps = nullptr;
   int parse_stream_index = 0;
@@ -149,6 +151,10 @@ struct aa_ctx {
   struct ExpandBuf { aa_expand_job * host = nullptr, * dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
   ExpandBuf expand_bufs[kBindBufs];
   int next_expand_buf = 0;
+  // the raster list of a batched download (aa_download_batch_async), read by k_gather_rasters over the bus
+  struct GatherBuf { aa_gather_job * host = nullptr, * dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
+  GatherBuf gather_bufs[kBindBufs];
+  int next_gather_buf = 0;
   // A parse batch holds its stream for as long as its longest chain (seconds for a key frame): a batch queued behind another
   // one on the same stream starts that much later.  Hence one stream per batch that can be in flight, and a batch goes to a
   // stream that has nothing queued (pick_parse_stream).
@@ -186,8 +192,9 @@ struct aa_ctx {
     double blocks_per_byte = 1.0;        // running estimate: coefficient blocks a frame stores per byte of its compressed size (never more than 25 per macroblock)
     // Packed coefficient storage (tok_fsm.hh): the lanes write a mask word + the non-zero coefficients of a block instead of 16
     // coefficients; frames are expanded into a transient dense array when they are handed to reconstruction.  One format per
-    // context, fixed when the first frame is submitted (ALFALFA_AMD_PACKED=1 / aa_ctx_set_packed_coefficients).
-    bool packed = false;
+    // context, fixed when the first frame is submitted.  The default since round 4 (ALFALFA_AMD_PACKED=0 /
+    // aa_ctx_set_packed_coefficients( ctx, 0 ): dense blocks).
+    bool packed = true;
     // One lane per DCT partition (tok_fsm.hh): frames with 2 / 4 / 8 partitions may be decoded by as many lanes of one wave.
     // Per context, fixed at the first submit (ALFALFA_AMD_LANE_PER_PARTITION=1 / aa_ctx_set_lane_per_partition).
     bool lane_per_partition = false;
@@ -239,6 +246,7 @@ struct aa_ctx {
                                           // (aa_ctx_create: 7/8 of what was free; aa_ctx_set_memory_limit)
   size_t pinned_bytes = 0;                // pinned host memory the context has taken (arenas, staging chunks, binding buffers)
   std::map<size_t, std::vector<uint8_t *>> dev_free;
+  std::mutex blank_mu;
   std::map<size_t, uint8_t *> blank;    // References( width, height ): one all-zero raster per raster size, shared by every new decoder (never written)
   uint8_t * boundary = nullptr; // loop filter: hand-off lines between macroblock rows (transient within a launch)
   size_t boundary_bytes = 0;
@@ -751,7 +759,14 @@ aa_status tok_set_lane_bytes( aa_ctx * ctx, uint32_t need )
   if ( need <= T.lane_bytes ) return AA_OK;
   if ( T.lane_bytes ) {
     if ( aa_status st = tok_quiesce( ctx ) ) return st;
+    // the grids that linger (idle waves stay for `linger`) are told to leave now: nobody should wait that long for them
+    for ( int g = 0; g < aa_ctx::Tok::kSlots; g++ ) {
+      auto & sl = T.slot[g];
+      __atomic_store_n( &T.retire_host[g], sl.gen, __ATOMIC_RELEASE );
+      sl.gen++;                                         // (the next grid of this slot is of a generation the word does not cover)
+    }
     for ( auto & sl : T.slot ) HIP_TRY( hipStreamSynchronize( sl.st ) );
+    for ( auto & sl : T.slot ) { sl.queued_behind_retiring = false; }
   }
   T.lane_bytes = ( need + 15u ) & ~15u;
   int per_cu = 0;
@@ -787,7 +802,9 @@ void release_records( aa_stream * s, FrameRec & f, bool deferred )
     // the coefficient chunks the frame took go back to the pool on the device, by a kernel that reads the list out of the
     // record block: the block itself is recycled only behind that kernel (always through an epoch, never at once)
     const bool has_chunks = parsed && f.chunk_list && !f.chunks_returned;
-    if ( has_chunks ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->tok.pending_lists.push_back( f.chunk_list ); }
+    // (the list is handed to k_pool_free_lists when the open epoch is closed: mark the epoch as used, or -- with every record
+    // block inside its batch arena, no deferred free of its own -- nothing would ever close it and the chunks would stay out)
+    if ( has_chunks ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->tok.pending_lists.push_back( f.chunk_list ); ctx->open_epoch_used = true; f.chunks_returned = true; }
     if ( !f.rec_in_arena ) dev_free( ctx, f.rec_block, f.rec_bytes, deferred || has_chunks );
     f.rec_block = nullptr; f.chunk_list = nullptr; f.packed_pos = nullptr;
     ctx->tok.chunks_committed -= f.est_chunks; f.est_chunks = 0;
@@ -1129,6 +1146,7 @@ static void ctx_free( aa_ctx * ctx )
   (void) hipEventDestroy( ctx->upload_done );
   for ( auto & bb : ctx->bind_bufs ) { if ( bb.host ) (void) hipHostFree( bb.host ); if ( bb.done ) (void) hipEventDestroy( bb.done ); }
   for ( auto & eb : ctx->expand_bufs ) { if ( eb.host ) (void) hipHostFree( eb.host ); if ( eb.done ) (void) hipEventDestroy( eb.done ); }
+  for ( auto & gb : ctx->gather_bufs ) { if ( gb.host ) (void) hipHostFree( gb.host ); if ( gb.done ) (void) hipEventDestroy( gb.done ); }
   if ( ctx->ws ) (void) hipFree( ctx->ws );
   if ( ctx->boundary ) (void) hipFree( ctx->boundary );
   tok_free( ctx );
@@ -1218,6 +1236,7 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
   out->token_lanes_per_workgroup = static_cast<uint32_t>( T.lanes ); out->token_workgroups_capacity = static_cast<uint32_t>( T.cap_wgs );
   out->token_lane_lds_bytes = T.lane_bytes; out->token_workgroup_lds_bytes = T.lds;
   out->compute_units = static_cast<uint32_t>( T.n_cus );
+  { int khz = 0; if ( hipDeviceGetAttribute( &khz, hipDeviceAttributeClockRate, ctx->device ) == hipSuccess ) out->clock_mhz = static_cast<uint32_t>( khz / 1000 ); else (void) hipGetLastError(); }
   if ( T.ready ) {
     if ( aa_status st = tok_refresh_mirror( ctx ) ) return st;
     out->heap_free_chunks = T.mirror_host->pool_avail; out->lanes_starved = T.mirror_host->pool_starving;
@@ -1296,11 +1315,15 @@ aa_status aa_stream_create( aa_ctx * ctx, uint16_t width, uint16_t height, aa_st
   // long before its first key frame is decoded (a chunk waiting in a pipeline) costs no raster.
   uint8_t * blank = nullptr;
   {
+    // (decoders are created from many threads at once; the raster is zero before anybody -- compute or copy stream -- can read it)
+    std::lock_guard<std::mutex> g( ctx->blank_mu );
     auto it = ctx->blank.find( s->slot_bytes );
     if ( it != ctx->blank.end() ) blank = it->second;
     else {
       if ( aa_status st = dev_alloc( ctx, s->slot_bytes, &blank ) ) return st;
-      if ( hipError_t e = hipMemsetAsync( blank, 0, s->slot_bytes, ctx->compute ) ) { dev_free( ctx, blank, s->slot_bytes ); return hip_fail( e, "hipMemsetAsync (blank reference raster)" ); }
+      hipError_t e = hipMemsetAsync( blank, 0, s->slot_bytes, ctx->compute );
+      if ( e == hipSuccess ) e = hipStreamSynchronize( ctx->compute );
+      if ( e != hipSuccess ) { dev_free( ctx, blank, s->slot_bytes ); return hip_fail( e, "hipMemsetAsync (blank reference raster)" ); }
       ctx->blank[s->slot_bytes] = blank;
     }
   }
@@ -1578,9 +1601,19 @@ aa_status launch_tokens_of( aa_ctx * ctx, Batch * b )
   if ( aa_status st = tok_grow_heap( ctx, static_cast<size_t>( std::max<int64_t>( 0, T.chunks_committed ) ) * kChunkBytesHeap ) ) return st;
   hipStream_t ps = b->ps;
   if ( b->patch_jobs && dropped ) HIP_TRY( hipMemcpyAsync( b->dev, b->host, b->head_bytes, hipMemcpyHostToDevice, ps ) );     // (behind the header kernel on its stream)
-  if ( int e = aa::launch_enqueue_jobs( T.q, T.slots, reinterpret_cast<const aa::ParseJob *>( b->dev ), b->launch_order_dev, b->n, ps ) )
-    return hip_fail( static_cast<hipError_t>( e ), "k_enqueue_jobs" );
-  T.jobs_enqueued += static_cast<uint64_t>( b->n );
+  if ( dropped ) {
+    // frames released between the two phases of a two-phase submit get no ticket: release_records waits only for frames that
+    // were handed to the queue, so a ticket nobody waits for could be drawn after the arena has been recycled
+    int keep = 0;
+    for ( int k = 0; k < b->n_order; k++ ) if ( b->items[b->launch_order_host[k]].live ) b->launch_order_host[keep++] = b->launch_order_host[k];
+    b->n_order = keep;
+    if ( keep ) HIP_TRY( hipMemcpyAsync( const_cast<uint32_t *>( b->launch_order_dev ), b->launch_order_host, size_t( keep ) * sizeof( uint32_t ), hipMemcpyHostToDevice, ps ) );
+  }
+  if ( b->n_order > 0 ) {
+    if ( int e = aa::launch_enqueue_jobs( T.q, T.slots, reinterpret_cast<const aa::ParseJob *>( b->dev ), b->launch_order_dev, b->n_order, ps ) )
+      return hip_fail( static_cast<hipError_t>( e ), "k_enqueue_jobs" );
+    T.jobs_enqueued += static_cast<uint64_t>( b->n_order );
+  }
   HIP_TRY( hipEventRecord( b->hdr_done, ps ) );
   HIP_TRY( hipEventRecord( ctx->parse_idle[b->parse_stream_index], ps ) );
   return tok_service( ctx, b->hdr_done );
@@ -1808,9 +1841,12 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
 
   // launch order: longest chains first (the compressed size is the length of a token chain, near enough), so that the lanes
   // of a wave finish together and the long waves start first
+  // (only frames the pre-pass accepted: a ticket in the job queue is a pointer into this arena that a lane may follow long
+  // after the call -- a rejected frame has nobody who would wait for its lane before the arena is recycled)
   uint32_t * launch_order = seg_order + n;
-  for ( int i = 0; i < n; i++ ) launch_order[i] = static_cast<uint32_t>( i );
-  std::stable_sort( launch_order, launch_order + n, [&]( uint32_t a, uint32_t b ) { return items[a].size > items[b].size; } );
+  int n_order = 0;
+  for ( int i = 0; i < n; i++ ) if ( items[i].status == AA_OK ) launch_order[n_order++] = static_cast<uint32_t>( i );
+  std::stable_sort( launch_order, launch_order + n_order, [&]( uint32_t a, uint32_t b ) { return items[a].size > items[b].size; } );
   const uint32_t * launch_order_dev = reinterpret_cast<const uint32_t *>( raw->dev + ( reinterpret_cast<uint8_t *>( launch_order ) - raw->host ) );
 
   // ---- device half: arena to HBM on the copy stream, then the header kernels on one of the parse streams ----
@@ -1823,7 +1859,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   const aa::ParseJob * jobs_dev = reinterpret_cast<const aa::ParseJob *>( raw->dev );
   {
     LaunchTimer t( ctx, 3, ps );
-    if ( int e = aa::launch_parse_mb_headers( jobs_dev, launch_order_dev, n, ps ) ) return hip_fail( static_cast<hipError_t>( e ), "k_parse_mb_headers" );
+    if ( int e = aa::launch_parse_mb_headers( jobs_dev, launch_order_dev, n_order, ps ) ) return hip_fail( static_cast<hipError_t>( e ), "k_parse_mb_headers" );
   }
   if ( n_seg_streams ) {
     if ( ctx->last_seg_batch ) HIP_TRY( hipStreamWaitEvent( ps, ctx->last_seg_batch, 0 ) );
@@ -1834,7 +1870,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
     if ( !ctx->last_seg_batch ) HIP_TRY( hipEventCreateWithFlags( &ctx->last_seg_batch, hipEventDisableTiming ) );
     HIP_TRY( hipEventRecord( ctx->last_seg_batch, ps ) );
   }
-  raw->ps = ps; raw->launch_order_dev = launch_order_dev;
+  raw->ps = ps; raw->launch_order_dev = launch_order_dev; raw->launch_order_host = launch_order; raw->n_order = n_order;
   raw->tokens_pending = true; raw->patch_jobs = defer_tokens;
   HIP_TRY( hipEventRecord( raw->hdr_done, ps ) );  // (the header kernels; recorded again behind the hand-over to the job queue)
   HIP_TRY( hipEventRecord( ctx->parse_idle[pick], ps ) );
@@ -1865,12 +1901,12 @@ static aa_status resolve_summary( aa_stream * s, FrameRec & r )
     const uint32_t worst = aa::chunk_list_entries( r.hdr.num_macroblocks, T.lane_per_partition ? 8u : 1u );      // (what no frame of this size exceeds, in either storage format)
     {
       std::lock_guard<std::mutex> g( ctx->pool_mu );
-      if ( !r.chunks_returned ) T.pending_lists.push_back( r.chunk_list );
+      // (marked as returned at once: a call that fails below and is repeated must not push the list a second time)
+      if ( !r.chunks_returned ) { T.pending_lists.push_back( r.chunk_list ); r.chunks_returned = true; T.chunks_committed -= r.est_chunks; r.est_chunks = 0; }
       flush_chunk_frees( ctx );                     // (and the chunks of everything the caller has released since)
       if ( !T.pending_lists.empty() ) return fail( AA_ERR_HIP, "k_pool_free_lists could not be launched" );
     }
     HIP_TRY( hipStreamSynchronize( ctx->compute ) );
-    if ( !r.chunks_returned ) { r.chunks_returned = true; T.chunks_committed -= r.est_chunks; r.est_chunks = 0; }
     if ( aa_status st = tok_grow_heap( ctx, T.heap_mapped + static_cast<size_t>( worst ) * kChunkBytesHeap ) ) return st;
     if ( aa_status st = tok_refresh_mirror( ctx ) ) return st;
     if ( T.mirror_host->pool_avail < static_cast<int32_t>( worst ) ) {
@@ -2362,6 +2398,65 @@ aa_status aa_stream_download_wait( aa_stream * s )
   if ( aa_status st = set_device( s->ctx ) ) return st;
   HIP_TRY( hipStreamSynchronize( s->ctx->copy ) );
   return check_watchdog( s->ctx );
+}
+
+/* A whole frame index of a batch on its way out (frontend/vp8decode.cc:78-93, decode-bundle.cc:92-99 deliver every shown frame): the
+ * rasters of n decoded frames -- each three padded planes, contiguous in its pool piece -- are gathered by ONE kernel on the
+ * compute stream into one staging piece, and ONE copy on the copy stream takes them to dst + i * stride (pinned memory).  The
+ * per-plane form (aa_stream_download_async) costs 3 n copies of 0.5-2 MB: measured 16.8 GB/s over a link that does 50+. */
+aa_status aa_download_batch_async( aa_ctx * ctx, aa_stream * const * streams, int n, const int * frame_index, uint8_t * dst, size_t stride )
+{
+  if ( !ctx || !streams || !frame_index || !dst || n <= 0 ) return fail( AA_ERR_ARGUMENT, "aa_download_batch_async: bad argument" );
+  if ( aa_status st = set_device( ctx ) ) return st;
+  size_t max_bytes = 0;
+  for ( int i = 0; i < n; i++ ) {
+    const aa_stream * s = streams[i];
+    if ( !s || s->ctx != ctx ) return fail( AA_ERR_ARGUMENT, "aa_download_batch_async: stream belongs to another context" );
+    const int fi = frame_index[i];
+    if ( fi < 0 || fi >= static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_ARGUMENT, "aa_download_batch_async: bad frame index" );
+    const FrameRec & r = s->frames[fi];
+    if ( !r.handle_held ) return fail( AA_ERR_LOGIC, "aa_download_batch_async: frame was released" );
+    if ( fi >= s->next_submit || !r.placed ) return fail( AA_ERR_LOGIC, "aa_download_batch_async: frame not decoded yet" );
+    const size_t bytes = s->plane_bytes[0] + 2 * s->plane_bytes[1];
+    if ( bytes > stride ) return fail( AA_ERR_ARGUMENT, "aa_download_batch_async: stride smaller than a raster" );
+    max_bytes = std::max( max_bytes, bytes );
+  }
+  if ( stride & 15 ) return fail( AA_ERR_ARGUMENT, "aa_download_batch_async: stride must be a multiple of 16" );
+  aa_ctx::GatherBuf & gb = ctx->gather_bufs[ctx->next_gather_buf];
+  ctx->next_gather_buf = ( ctx->next_gather_buf + 1 ) % aa_ctx::kBindBufs;
+  if ( gb.busy ) { HIP_TRY( hipEventSynchronize( gb.done ) ); gb.busy = false; }
+  if ( gb.cap < static_cast<size_t>( n ) ) {
+    if ( gb.host ) (void) hipHostFree( gb.host );
+    gb.host = nullptr; gb.dev = nullptr; gb.cap = 0;
+    const size_t cap = std::max<size_t>( 512, size_t( n ) * 2 );
+    HIP_TRY( hipHostMalloc( reinterpret_cast<void **>( &gb.host ), cap * sizeof( aa_gather_job ), hipHostMallocDefault ) );
+    HIP_TRY( hipHostGetDevicePointer( reinterpret_cast<void **>( &gb.dev ), gb.host, 0 ) );
+    gb.cap = cap;
+  }
+  if ( !gb.done ) HIP_TRY( hipEventCreateWithFlags( &gb.done, hipEventDisableTiming ) );
+  for ( int i = 0; i < n; i++ ) {
+    aa_stream * s = streams[i];
+    gb.host[i].src = s->slots[s->frames[frame_index[i]].out_slot].dev;          // (Y, U, V back to back: slot_plane)
+    gb.host[i].bytes = s->plane_bytes[0] + 2 * s->plane_bytes[1];
+  }
+  const size_t total = stride * static_cast<size_t>( n );
+  uint8_t * staging = nullptr;
+  if ( aa_status st = dev_alloc( ctx, total, &staging ) ) return st;
+  // (the piece goes back behind the copy that reads it: the epoch that frees it waits for the copy stream as well)
+  struct Back { aa_ctx * c; uint8_t * p; size_t b; ~Back() { { std::lock_guard<std::mutex> g( c->pool_mu ); c->copy_reads_rasters = true; } dev_free( c, p, b, true ); } } back { ctx, staging, total };
+  if ( int e = aa::launch_gather_rasters( gb.dev, n, staging, stride, max_bytes, ctx->compute ) ) return hip_fail( static_cast<hipError_t>( e ), "k_gather_rasters" );
+  HIP_TRY( hipEventRecord( gb.done, ctx->compute ) );
+  gb.busy = true;
+  HIP_TRY( hipStreamWaitEvent( ctx->copy, gb.done, 0 ) );
+  HIP_TRY( hipMemcpyAsync( dst, staging, total, hipMemcpyDeviceToHost, ctx->copy ) );
+  return AA_OK;
+}
+aa_status aa_ctx_download_wait( aa_ctx * ctx )
+{
+  if ( !ctx ) return fail( AA_ERR_ARGUMENT, "null ctx" );
+  if ( aa_status st = set_device( ctx ) ) return st;
+  HIP_TRY( hipStreamSynchronize( ctx->copy ) );
+  return check_watchdog( ctx );
 }
 
 aa_status aa_stream_raster_device( aa_stream * s, int fi, void ** y, void ** u, void ** v )

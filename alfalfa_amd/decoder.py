@@ -185,6 +185,17 @@ class Context:
         capi.check(self.L.aa_launch_tokens(self.h, max_batches, C.byref(n)))
         return n.value
 
+    def download_batch_async(self, decoders, frame_indices, dst_ptr, stride):
+        """aa_download_batch_async: frame frame_indices[i] of decoders[i] -> dst_ptr + i * stride (pinned host memory), one gather
+        kernel + one copy for the lot; valid after download_wait() / sync()."""
+        n = len(decoders)
+        arr = (C.c_void_p * n)(*[d.h for d in decoders])
+        idx = (C.c_int * n)(*frame_indices)
+        capi.check(self.L.aa_download_batch_async(self.h, arr, n, idx, C.c_void_p(dst_ptr), stride))
+
+    def download_wait(self):
+        capi.check(self.L.aa_ctx_download_wait(self.h))
+
     def decode_batch(self, decoders, frame_indices):
         n = len(decoders)
         arr = (C.c_void_p * n)(*[d.h for d in decoders])

@@ -6,14 +6,14 @@ One "step" = one pass of the WHOLE hot path over one batch: S independent synthe
 filtered rasters in HBM:
     host    frame-header pre-pass (serial across the frames of a stream) + staging of the compressed bytes   [C++ workers]
     H2D     the compressed frames themselves (~36 B/macroblock instead of ~360 B of parsed records)
-    GPU     BoolDecoder entropy decode: macroblock headers + tokens, one lane per (stream, frame)   [k_parse_*]
+    GPU     BoolDecoder entropy decode: macroblock headers + tokens, one lane per (stream, frame)   [k_parse_*, k_token_workers]
     GPU     reconstruction + loop filter + reference update                                        [k_recon_*, k_loopfilter_*]
 Steps are pipelined: a frame's entropy decode is one serial chain on one GPU lane (seconds for a 1080p frame), so the rate
 comes from the number of chains in flight.  Key frames are handed to the GPU parser `--key-ahead` steps before their group
-is reconstructed, inter frames `--depth` steps before; frames are released as they are consumed, so memory is a ring.  The
-timed region runs K steps from an EMPTY pipeline to an EMPTY pipeline (it pays for filling and draining); `value` is that
-end-to-end rate, `steady_state` the rate between fill and drain.  The reconstruction-only rate with parsed records
-already resident in HBM (last round's number) is reported beside it as `device_half`.
+is reconstructed, inter frames `--depth` steps before -- as far as the HBM budget (`--hbm-gb`) holds what they store; frames
+are released as they are consumed, so memory is a ring.  The timed region runs K steps from an EMPTY pipeline to an EMPTY
+pipeline (it pays for filling and draining); `value` is that end-to-end rate, `steady_state` the rate between fill and drain.
+The LAST step of the timed region is the one whose rasters are compared with the reference decoder.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -31,9 +31,12 @@ import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
 
-# The pipeline runs 14 HIP streams side by side; HIP multiplexes streams over GPU_MAX_HW_QUEUES (default 4) hardware queues and
+# The pipeline runs 15 HIP streams side by side; HIP multiplexes streams over GPU_MAX_HW_QUEUES (default 4) hardware queues and
 # reads the variable when the runtime starts -- which, with torch.distributed, is before libalfalfa_amd.so is loaded.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# the worker waves account for their own time (a few clock reads per 32 decode steps): the entropy decode's own roof in the
+# bench line comes from these counters
+os.environ.setdefault("ALFALFA_AMD_TOKEN_PROFILE", "1")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -51,12 +54,16 @@ KERNEL_NAMES = {"recon_inter": "k_recon_inter4", "recon_split": "k_recon_inter",
 
 
 def pmc_traffic(config):
-    """HBM bytes per macroblock per kernel from the rocprofv3 PMC passes of THIS config (tools/profile_round.sh writes
-    profiles/pmc_traffic.json); None when that config was never profiled."""
+    """HBM bytes per macroblock per kernel from rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
+    tools/profile_summary.py): {"round": ..., config: {kernel key: bytes per macroblock}}.  Only figures measured on the kernels
+    of THIS round's tree are used (the file says which round measured them); else None."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(config)
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except (OSError, ValueError):
-        return None
+        return None, None
+    if d.get("round") != "r04":
+        return None, None
+    return d.get(config), d.get("source")
 
 
 def parse_args():
@@ -67,9 +74,9 @@ def parse_args():
     ap.add_argument("--config", default="1080p_inter_lf")
     ap.add_argument("--streams", type=int, default=480, help="independent streams per GPU")
     ap.add_argument("--frames", type=int, default=12, help="frames per stream per step")
-    ap.add_argument("--key-ahead", type=int, default=12, help="steps by which KEY frames are handed to the GPU parser ahead of reconstruction (clamped to what the HBM budget holds)")
-    ap.add_argument("--depth", type=int, default=8, help="steps by which inter frames are handed to the GPU parser ahead of reconstruction (clamped likewise)")
-    ap.add_argument("--hbm-gb", type=float, default=200.0, help="HBM the decoder context may use on each GPU (aa_ctx_set_memory_limit); the look-ahead is planned inside it")
+    ap.add_argument("--key-ahead", type=int, default=12, help="steps by which KEY frames are handed to the GPU parser ahead of reconstruction (bounded by what the HBM budget holds)")
+    ap.add_argument("--depth", type=int, default=8, help="steps by which inter frames are handed to the GPU parser ahead of reconstruction (bounded likewise)")
+    ap.add_argument("--hbm-gb", type=float, default=150.0, help="HBM the decoder context may use on each GPU (aa_ctx_set_memory_limit); the look-ahead is planned inside it")
     ap.add_argument("--header-ahead", type=int, default=0, help="steps by which the macroblock-header pass of inter frames runs ahead of their token pass (two-phase submit)")
     ap.add_argument("--threads", type=int, default=0, help="host workers of the header pre-pass (0: cores / local ranks)")
     ap.add_argument("--schedule", default="rows", choices=["rows", "diagonal"])
@@ -77,15 +84,329 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-device-half", action="store_true")
     ap.add_argument("--profile-timed", action="store_true", help="HIP-event timing of every kernel INSIDE the timed region too (diagnostics)")
-    ap.add_argument("--overcommit", type=float, default=1.2, help="frames are admitted while what those in flight are EXPECTED to store stays below this x the heap "
+    ap.add_argument("--overcommit", type=float, default=1.2, help="frames are admitted while what those in flight are EXPECTED to store stays below this x the room "
                     "(frames being parsed hold only part of it, and the oldest are released first; a lane that finds the pool empty waits)")
-    ap.add_argument("--packed", action="store_true", help="device-parsed frames store PACKED coefficients (aa_ctx_set_packed_coefficients: a mask word + the non-zero "
-                    "values per block, expanded on the device when a frame is reconstructed) instead of dense 32-byte blocks")
-    ap.add_argument("--deliver", action="store_true", help="every reconstructed frame is also DELIVERED: copied to pinned host memory (aa_stream_download_async, "
-                    "copy stream) while the next frames are decoded -- what vp8decode / xc-decode-bundle do with every shown frame; the timed region then includes PCIe")
+    ap.add_argument("--dense", action="store_true", help="device-parsed frames store DENSE 32-byte coefficient blocks (aa_ctx_set_packed_coefficients( 0 )) instead of the "
+                    "default packed form (a mask word + the non-zero values per block, expanded on the device when a frame is reconstructed)")
+    ap.add_argument("--packed", action="store_true", help="(the default since round 4; accepted for old command lines)")
+    ap.add_argument("--deliver", action="store_true", help="every reconstructed frame is also DELIVERED: copied to pinned host memory (aa_download_batch_async: one "
+                    "gather + one copy per frame index) while the next frames are decoded -- what vp8decode / xc-decode-bundle do with every shown frame; "
+                    "the timed region then includes PCIe")
     ap.add_argument("--trace-memory", action="store_true", help="print the context's memory books after every step of the timed region (stderr)")
     ap.add_argument("--small-batches", default="1,8,64", help="stream counts for the small-batch end-to-end figures ('' = skip)")
+    ap.add_argument("--secondary", default="720p_intra,720p_inter,1080p_inter_lf_subpel",
+                    help="other BASELINE configs measured end to end after the main run, a few steps each, parity checked in the run ('' = skip)")
+    ap.add_argument("--secondary-streams", type=int, default=96)
+    ap.add_argument("--secondary-steps", type=int, default=4)
     return ap.parse_args()
+
+
+class Pipeline:
+    """Group g = one group of pictures of every stream = S decoders created when its key frames are handed over (a new
+    Decoder per chunk, as xc-decode-bundle does) and dropped when its last frame has been reconstructed: a decoder waiting
+    for its turn holds no raster (its references point at the context's shared blank one).
+
+    A step's S groups of pictures are S independent decode jobs (ExCamera chunks: one Decoder each, xc-decode-bundle).  The
+    entropy decode of a frame is ONE serial chain on ONE GPU lane, so what matters is how many chains are in flight; and a key
+    frame's chain is ~2.6x longer than an inter frame's.  The scheduler therefore hands key frames to the GPU `key_ahead`
+    steps before their group is reconstructed and inter frames only `depth` steps before (they would otherwise sit in HBM
+    waiting for their key frame)."""
+
+    def __init__(self, env, stream_list, key_ahead, depth, header_ahead=0):
+        import alfalfa_amd as aa
+        self.aa, self.env = aa, env
+        self.ctx, self.F = env["ctx"], env["F"]
+        self.streams = stream_list
+        self.n = len(stream_list)
+        self.H = max(0, header_ahead)
+        self.inter_h = 0
+        self.K, self.D = max(1, key_ahead), max(1, min(depth, key_ahead))
+        self.groups = {}                                # g -> [Decoder]
+        self.kept = {}                                  # g -> [Decoder] whose frames were not released (the step that is verified)
+        self.keep_group = None                          # group whose distinct decoders keep every frame (verification of a TIMED step)
+        n, F = self.n, self.F
+        # argument blocks, reused: only the decoder handles change from group to group
+        self.key_arr = (aa.capi.FrameIn * n)(); self.key_out = (C.c_int * n)()
+        self.inter_arr = (aa.capi.FrameIn * (n * (F - 1)))(); self.inter_out = (C.c_int * (n * (F - 1)))()
+        for i, st in enumerate(stream_list):
+            self.key_arr[i].data, self.key_arr[i].size = st[0], len(st[0])
+            for k, fr in enumerate(st[1:]):             # stream-major: the inter frames of one stream are consecutive (a host worker takes a whole stream)
+                e = self.inter_arr[i * (F - 1) + k]
+                e.data, e.size = fr, len(fr)
+        self.keys = self.inters = self.decoded = 0      # groups handed to the GPU parser (key / inter frames), groups reconstructed
+        self.frames_submitted = 0
+        self.host_s = 0.0
+        self.t_launch = self.t_decode = self.t_release = 0.0      # host time in aa_launch_tokens / aa_decode_batch / releases
+        self.done_t = []
+        self.delivered_bytes = 0
+        self.refused = 0                                 # times a hand-over was put off because HBM had no room for it
+
+    def _deliver(self, ds, f):
+        """Frame f of every decoder of the group -> the pinned ring, behind its reconstruction, beside the next frame's: ONE
+        gather kernel + ONE copy for the whole frame index (aa_download_batch_async)."""
+        env = self.env
+        slab = env["deliver_ring"][f & 1]
+        self.ctx.download_wait()                    # the copy that used this half of the ring before is through (copy stream)
+        self.ctx.download_batch_async(ds, [f] * len(ds), slab, env["raster_bytes"])
+        self.delivered_bytes += len(ds) * env["raster_bytes"]
+
+    def _submit_keys(self, g):
+        t = time.perf_counter()
+        env = self.env
+        ds = self.groups[g] = [self.aa.Decoder(self.ctx, env["width"], env["height"]) for _ in range(self.n)]
+        for i, d in enumerate(ds):
+            self.key_arr[i].stream = d.h.value
+        self.ctx.submit_prepared((self.key_arr, self.key_out, None), env["threads"], False)
+        self.frames_submitted += self.n
+        self.host_s += time.perf_counter() - t
+
+    def _submit_inters(self, g, defer_tokens=False):
+        F = self.F
+        if F < 2:
+            return
+        t = time.perf_counter()
+        for i, d in enumerate(self.groups[g]):
+            h = d.h.value
+            for k in range(F - 1):
+                self.inter_arr[i * (F - 1) + k].stream = h
+        self.ctx.submit_prepared((self.inter_arr, self.inter_out, None), self.env["threads"], defer_tokens)
+        self.frames_submitted += self.n * (F - 1)
+        self.host_s += time.perf_counter() - t
+
+    def decode(self, release=True):
+        g = self.decoded
+        ds = self.groups[g]
+        F, ctx, env = self.F, self.ctx, self.env
+        keep = set(env["distinct"]) if (g == self.keep_group and release) else ()
+        for f in range(F):
+            t = time.perf_counter()
+            ctx.decode_batch(ds, [f] * self.n)
+            t1 = time.perf_counter(); self.t_decode += t1 - t
+            if env.get("deliver_ring") and release:
+                self._deliver(ds, f)
+                t1 = time.perf_counter()
+            if release:             # this frame is consumed: its records go back to the pool once the kernels queued so far
+                for i, d in enumerate(ds):        # have run, its raster when nothing refers to it any more (RasterHandle semantics)
+                    if i not in keep:
+                        d.release_before(f + 1)
+                self.t_release += time.perf_counter() - t1
+        if release:
+            t1 = time.perf_counter()
+            if keep:
+                self.kept[g] = ds
+            del self.groups[g], ds  # the chunk is done: its decoders go (nothing waits for the GPU here)
+            self.t_release += time.perf_counter() - t1
+        self.decoded += 1
+        self.done_t.append(time.perf_counter())
+        if env["args"].trace_memory:
+            i = ctx.info()
+            print("step %d: pool %.1f GB (free %.1f, pending %.1f) heap mapped %.1f used %.1f GB free chunks %d starved %d alive wgs %d waiting %d refused %d"
+                  % (self.decoded, i["pool_bytes"] / 1e9, i["pool_free_bytes"] / 1e9, i["pool_pending_bytes"] / 1e9, i["heap_mapped_bytes"] / 1e9,
+                     i["heap_used_bytes"] / 1e9, i["heap_free_chunks"], i["lanes_starved"], i["token_workgroups_alive"], i["jobs_waiting"], self.refused), file=sys.stderr, flush=True)
+
+    def _room(self, nframes, coeff_bytes, arena_bytes):
+        """Is there room in HBM for `nframes` more frames in flight?  Both halves of the context's memory count: the POOL (batch
+        arenas with the compressed frames and the macroblock records, rasters, the transient dense blocks of a reconstruction
+        call) and the coefficient HEAP (frames in flight are on the context's books with what they are expected to store, parsed
+        ones with what they took).  The pool's live pieces + this hand-over's arena + what the next reconstruction calls need,
+        plus the heap's expected content (over-committed: frames being parsed hold only part of what they will, and the oldest
+        are released first) must fit the limit.  Never refuses when nothing is in flight: waiting would free nothing."""
+        if self.keys == self.decoded:
+            return True
+        env = self.env
+        i = self.ctx.info()
+        pool_live = i["pool_bytes"] - i["pool_free_bytes"]
+        heap_after = i["heap_used_bytes"] + coeff_bytes
+        heap_cap = i["heap_limit_bytes"] or i["memory_limit_bytes"]
+        ok = (heap_after <= env["args"].overcommit * heap_cap and
+              pool_live + arena_bytes + env["recon_reserve"] + heap_after / env["args"].overcommit <= i["memory_limit_bytes"])
+        if not ok:
+            self.refused += 1
+        return ok
+
+    def run(self, steps):
+        """`steps` whole steps, from an empty pipeline to an empty pipeline.  Frames go to the GPU parser in the order they
+        are needed, as far ahead as the look-ahead says AND the HBM budget holds: key frames up to K steps before their
+        group is reconstructed (their chains are the long ones), inter frames up to D steps."""
+        env, F = self.env, self.F
+        target = self.decoded + steps
+        while self.decoded < target:
+            while True:
+                can_inter = self.inter_h < min(target, self.decoded + self.D + self.H, self.keys)
+                can_key = self.keys < min(target, self.decoded + self.K)
+                # the group about to be reconstructed comes first; otherwise key frames lead (K - D steps ahead of the inter frames)
+                if can_inter and (self.inter_h == self.decoded or not can_key or self.keys - self.inter_h > self.K - self.D):
+                    if self.inter_h != self.decoded and not self._room(self.n * (F - 1), self.n * (F - 1) * env["inter_coeff_bytes"], self.n * (F - 1) * env["inter_arena_bytes"]):
+                        break
+                    self._submit_inters(self.inter_h, defer_tokens=self.H > 0); self.inter_h += 1
+                    if self.H == 0:
+                        self.inters += 1
+                elif can_key:
+                    if not self._room(self.n, self.n * env["key_coeff_bytes"], self.n * env["key_arena_bytes"]):
+                        break
+                    self._submit_keys(self.keys); self.keys += 1
+                elif self.H > 0 and self.inters < min(target, self.decoded + self.D, self.inter_h):
+                    t = time.perf_counter()
+                    self.ctx.launch_tokens(1); self.inters += 1
+                    self.t_launch += time.perf_counter() - t
+                else:
+                    break
+            self.decode()
+
+
+def calibrate(env, streams):
+    """What ONE lone chain costs, and what frames of this content really store:
+    (a) a key frame parsed with nothing else on the GPU: its wall time / its decode steps = the latency of one step of one
+        lane, the unit of the entropy decode's own roof (lanes / step latency);
+    (b) coefficient blocks (and packed words) per key / inter frame of a few streams -> bytes a frame in flight holds."""
+    import alfalfa_amd as aa
+    ctx, F, width, height, threads = env["ctx"], env["F"], env["width"], env["height"], env["threads"]
+    S = len(streams)
+    mbs_per_frame = env["mbs_per_frame"]
+    cal = [aa.Decoder(ctx, width, height) for _ in range(min(4, S))]
+    ctx.kernel_stats(reset=True)
+    t0 = time.perf_counter()
+    ctx.submit_frames([(cal[0], streams[0][0])], threads, route="device")
+    key_hdr = cal[0].frame_header(0)                     # waits for the parse
+    t_lone_key = time.perf_counter() - t0
+    lone_stats = ctx.kernel_stats(reset=True)
+    lone_steps = lone_stats["token_steps"]
+    ctx.submit_frames([(d, st[0]) for d, st in zip(cal[1:], streams[1:])] + [(d, fr) for d, st in zip(cal, streams) for fr in st[1:]], threads, route="device")
+    key_blocks = max([key_hdr["num_coeff_blocks"]] + [d.frame_header(0)["num_coeff_blocks"] for d in cal[1:]])
+    inter_blocks = max(d.frame_header(f)["num_coeff_blocks"] for d in cal for f in range(1, F)) if F > 1 else key_blocks
+    ctx.sync()
+    rest = ctx.kernel_stats(reset=True)
+    env["step_latency_us"] = t_lone_key / max(1, lone_steps) * 1e6
+    env["lone_key_s"] = t_lone_key
+    packed = bool(ctx.info()["packed_coefficients"])
+    key_bpb = inter_bpb = 32.0
+    if packed:
+        # bytes a stored block takes, key and inter frames apart (a key frame's blocks are nearly full, an inter frame's hold 2-4 values)
+        key_bpb = 2.0 * lone_stats["packed_words"] / max(1, lone_stats["packed_blocks"])
+        rest_keys = len(cal) - 1
+        inter_words = rest["packed_words"] - rest_keys * lone_stats["packed_words"]
+        inter_blks = rest["packed_blocks"] - rest_keys * lone_stats["packed_blocks"]
+        inter_bpb = 2.0 * inter_words / inter_blks if inter_blks > 0 and inter_words > 0 else key_bpb
+    del cal
+    # per frame in flight: the coefficient heap (its blocks + the partly filled last chunk) and the pool (macroblock records, flags,
+    # chunk list, packed positions, the compressed frame -- device half of the batch arena)
+    comp = env["compressed_bytes"] / max(1, S * F)
+    rec = mbs_per_frame * (80 + 1 + (4 if packed else 0)) + 8192
+    env["key_coeff_bytes"], env["inter_coeff_bytes"] = int(key_blocks * key_bpb + 65536), int(inter_blocks * inter_bpb + 65536)
+    env["key_arena_bytes"], env["inter_arena_bytes"] = int(rec + 1.1 * comp), int(rec + 1.1 * comp)
+    env["packed_storage"] = {"key_frame_bytes_per_block": round(key_bpb, 2), "inter_frame_bytes_per_block": round(inter_bpb, 2), "dense_bytes_per_block": 32} if packed else None
+    env["planned"] = {"key_frame_heap_bytes": env["key_coeff_bytes"], "inter_frame_heap_bytes": env["inter_coeff_bytes"], "frame_pool_bytes": env["key_arena_bytes"],
+                      "key_blocks_per_mb": round(key_blocks / mbs_per_frame, 2), "inter_blocks_per_mb": round(inter_blocks / mbs_per_frame, 2)}
+    # what the reconstruction calls of the next steps take from the pool while frames wait: ~3 rasters per stream in flight
+    # (output + references being replaced) and two calls' transient dense blocks
+    env["recon_reserve"] = int(S * (3 * env["raster_bytes"] + 2 * (inter_blocks * 32 if packed else 0)))
+
+
+def token_profile_delta(before, after, clock_mhz):
+    """The worker waves' own time accounting (k_token_workers, ALFALFA_AMD_TOKEN_PROFILE): 100 MHz ticks summed over the waves."""
+    d8 = [a - b for a, b in zip(after, before)]
+    tot = d8[3] + d8[4] + d8[5]
+    if not d8[7] or tot <= 0:
+        return None
+    us_step = (d8[5] - d8[0]) / max(1, d8[2]) / 100.0
+    return {"wave_seconds": round(tot / 1e8, 2), "frac_steps": round((d8[5] - d8[0]) / tot, 3), "frac_boundary_passes": round(d8[0] / tot, 3),
+            "frac_top_up": round(d8[4] / tot, 3), "frac_take_and_begin": round(d8[3] / tot, 3),
+            "us_per_wave_step": round(us_step, 4), "cycles_per_wave_step_at_%d_mhz" % clock_mhz: round(us_step * clock_mhz),
+            "us_per_boundary_pass": round(d8[0] / max(1, d8[1]) / 100.0, 3), "wave_steps": d8[2], "boundary_passes": d8[1],
+            "lanes_with_frame_per_period": round(d8[6] / max(1, d8[7]), 2), "steps_per_period": round(d8[2] / max(1, d8[7]), 2),
+            "note": "time of the worker waves while they held frames (waves that linger without work are asleep and not counted)"}
+
+
+def verify_against_reference(env, decoders_by_index, paths, frames_to_check):
+    """Rasters of decoders (index in the stream list -> Decoder, every frame still held) against the REFERENCE decoder run here
+    (oracle/_ref/ref_decode): SHA-256 of the three padded planes.  -> dict, or None when the reference binary is not there."""
+    import workload
+    ref_decode = os.path.join(ROOT, "oracle", "_ref", "ref_decode")
+    if not os.path.exists(ref_decode):
+        return None
+    F = env["F"]
+
+    def ref_hashes(i):
+        raw = os.path.join(workload.cache_dir(), "bench_verify_%d_%d.raw" % (os.getpid(), i))
+        subprocess.run([ref_decode, paths[i], raw], check=True, stdout=subprocess.DEVNULL)
+        with open(raw, "rb") as fh:
+            ref = fh.read()
+        os.unlink(raw)
+        fs = len(ref) // F
+        return i, [hashlib.sha256(ref[f * fs:(f + 1) * fs]).digest() for f in frames_to_check]
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+        refs = list(ex.map(ref_hashes, sorted(decoders_by_index)))
+    bad = [(i, f) for i, hs in refs for f, hsh in zip(frames_to_check, hs)
+           if hashlib.sha256(decoders_by_index[i].raster_bytes(f)).digest() != hsh]
+    if bad:
+        raise SystemExit("PARITY FAILURE (%s): HIP output differs from the reference decoder on (stream, frame) %r" % (env["config"], bad[:8]))
+    return {"streams_checked": len(refs), "frames_per_stream": len(frames_to_check), "bit_exact": True}
+
+
+def make_env(args, ctx, config, S, F, rank, world, threads):
+    import alfalfa_amd as aa
+    import workload
+    from alfalfa_amd import sharding
+    width, height = workload.CONFIGS[config][:2]
+    # stream ids are disjoint across ranks; their CONTENT is drawn from a pool of synthetic videos so that the one-off
+    # generation cost (reference encoder, cached on disk) stays bounded on an 8-GPU node
+    synth = workload.CONFIGS[config][2] == "synth"       # (the pure-Python stream writer is slow: few distinct streams)
+    pool = 8 if synth else (120 if config == args.config else 24)
+    seeds = [100 + (g - 100) % pool for g in sharding.stream_ids(rank, world, S)]
+    t0 = time.time()
+    paths = workload.make_streams(config, F, seeds)
+    t_gen = time.time() - t0
+    streams = [aa.read_ivf(p)[2] for p in paths]
+    distinct = {}
+    for i, sd in enumerate(seeds):
+        distinct.setdefault(sd, i)
+    env = {"args": args, "ctx": ctx, "config": config, "width": width, "height": height, "F": F, "S": S, "threads": threads,
+           "seeds": seeds, "paths": paths, "streams": streams, "t_gen": t_gen, "distinct": sorted(distinct.values()),
+           "mbs_per_frame": ((width + 15) // 16) * ((height + 15) // 16),
+           "compressed_bytes": sum(len(fr) for st in streams for fr in st), "deliver_ring": None}
+    env["mbs_per_step"] = S * F * env["mbs_per_frame"]
+    probe = aa.Decoder(ctx, width, height)
+    env["plane_sizes"] = probe.plane_sizes()
+    env["raster_bytes"] = sum(env["plane_sizes"])
+    del probe
+    return env
+
+
+def run_secondary(args, ctx, config, rank, world, threads):
+    """A BASELINE config other than the headline one, end to end, a few steps from an empty pipeline to an empty pipeline, the last
+    step's rasters checked against the reference decoder in the run."""
+    F = 6 if config.endswith("_subpel") else args.frames
+    S = args.secondary_streams
+    env = make_env(args, ctx, config, S, F, rank, world, threads)
+    calibrate(env, env["streams"])
+    steps = args.secondary_steps
+    pipe = Pipeline(env, env["streams"], min(args.key_ahead, steps), min(args.depth, steps))
+    pipe.run(1)                              # (pools of this geometry reach their size)
+    ctx.sync()
+    pipe.keep_group = pipe.decoded + steps - 1
+    ctx.kernel_stats(reset=True)
+    t0 = time.perf_counter()
+    pipe.run(steps)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    st = ctx.kernel_stats(reset=True)
+    kept = pipe.kept.get(pipe.keep_group)
+    verified = None
+    if rank == 0 and not args.no_verify and kept:
+        verified = verify_against_reference(env, {i: kept[i] for i in env["distinct"]}, env["paths"], sorted({0, F // 2, F - 1}))
+    import workload
+    cfg = workload.CONFIGS[config]
+    out = {"value": round(S * F * env["mbs_per_frame"] * steps / dt, 1), "unit": "macroblocks/s", "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
+           "workload": "%d streams x %d frames of %dx%d (%s, y_ac_qi %d, loop filter %d), end to end, empty pipeline to empty pipeline"
+                       % (S, F, env["width"], env["height"], "all key frames" if config.endswith("_intra") else "1 key + %d inter" % (F - 1), cfg[3], cfg[4]),
+           "macroblocks_per_step": S * F * env["mbs_per_frame"], "compressed_bytes_per_mb": round(env["compressed_bytes"] / (S * F * env["mbs_per_frame"]), 2),
+           "lone_key_frame_parse_s": round(env["lone_key_s"], 4), "token_steps_per_mb": round(st["token_steps"] / max(1, st["parsed_macroblocks"]), 1),
+           "distinct_streams": len(env["distinct"]), "verified_bit_exact_vs_reference": verified, "stream_generation_s": round(env["t_gen"], 1)}
+    if len(pipe.done_t) > steps and steps > 1:
+        d = pipe.done_t[-steps:]
+        out["between_fill_and_drain_value"] = round(S * F * env["mbs_per_frame"] * (steps - 1) / (d[-1] - d[0]), 1)
+    del pipe, kept
+    return out
 
 
 def main():
@@ -98,37 +419,35 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dev_index = int(os.environ.get("AA_BENCH_DEVICE", local_rank))     # (a dry run of N ranks on ONE GPU: AA_BENCH_DEVICE=0)
+        torch.cuda.set_device(dev_index)
+        backend = os.environ.get("AA_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
+    dev_index = int(os.environ.get("AA_BENCH_DEVICE", local_rank))
 
     import alfalfa_amd as aa
     import workload
     from alfalfa_amd import sharding
 
-    width, height = workload.CONFIGS[args.config][:2]
     S, F = args.streams, args.frames
     # host workers of the header pre-pass: this rank's share of the cores (measured on the 256-core box: with the 32 workers an
     # 8-GPU node leaves a rank, a step's pre-pass + staging takes 27 ms and the end-to-end rate is within run-to-run noise of
     # the 256-worker rate)
     threads = args.threads or max(1, (os.cpu_count() or 1) // max(1, local_world))
-    # stream ids are disjoint across ranks; their CONTENT is drawn from a pool of 120 synthetic videos so that the one-off
-    # generation cost (reference encoder, cached on disk) stays bounded on an 8-GPU node
-    pool = 24 if workload.CONFIGS[args.config][2] == "synth" else 120     # (the pure-Python stream writer is slow)
-    seeds = [100 + (g - 100) % pool for g in sharding.stream_ids(rank, world, S)]
-    t0 = time.time()
-    paths = workload.make_streams(args.config, F, seeds)
-    t_gen = time.time() - t0
-    streams = [aa.read_ivf(p)[2] for p in paths]
-    mbs_per_frame = ((width + 15) // 16) * ((height + 15) // 16)
-    mbs_per_step = S * F * mbs_per_frame
-    compressed_bytes = sum(len(fr) for st in streams for fr in st)
 
-    ctx = aa.Context(local_rank)
+    ctx = aa.Context(dev_index)
     ctx.set_schedule(args.schedule)
     hbm_budget = min(args.hbm_gb * 1e9, 0.9 * ctx.memory()[0])
     ctx.set_memory_limit(int(hbm_budget))
-    if args.packed:
-        ctx.set_packed_coefficients(True)
+    if args.dense:
+        ctx.set_packed_coefficients(False)
+    env = make_env(args, ctx, args.config, S, F, rank, world, threads)
+    width, height, streams, paths, seeds = env["width"], env["height"], env["streams"], env["paths"], env["seeds"]
+    mbs_per_frame, mbs_per_step, compressed_bytes = env["mbs_per_frame"], env["mbs_per_step"], env["compressed_bytes"]
+    t_gen = env["t_gen"]
 
     def barrier():
         ctx.sync()
@@ -141,6 +460,7 @@ def main():
     handoff = None
     if dist is not None:
         import torch
+        tdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
         shared = aa.read_ivf(workload.make_stream(args.config, min(F, 4), 99))[2]
         cont = aa.Decoder(ctx, width, height)
         ysz, usz, vsz = cont.plane_sizes()
@@ -155,209 +475,48 @@ def main():
             blob = head.export_state()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dist.broadcast(planes, src=0)
+        if tdev == "cuda":
+            dist.broadcast(planes, src=0)
+        else:                                                   # (gloo dry run: through host memory)
+            hp = planes.cpu(); dist.broadcast(hp, src=0); planes.copy_(hp)
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
-        blob = sharding.broadcast_bytes(dist, blob, 0, device="cuda")
+        blob = sharding.broadcast_bytes(dist, blob, 0, device=tdev)
         cont.import_state(blob)
         cont.import_reference_device(base, base + ysz, base + ysz + usz)
         last = None
         for fr in shared[1:]:
             _, last = cont.get_frame_output(fr)
         digest = sharding.sha256(cont.raster_bytes(last))
-        agree = sharding.digests_agree(dist, digest, device="cuda")
+        agree = sharding.digests_agree(dist, digest, device=tdev)
         if rank == 0:
             straight = aa.Decoder(ctx, width, height)
             for fr in shared:
                 _, fi = straight.get_frame_output(fr)
             agree = agree and sharding.sha256(straight.raster_bytes(fi)) == digest
-        handoff = {"raster_bytes": ysz + usz + vsz, "state_bytes": len(blob), "broadcast_ms": round(t_bcast * 1e3, 3),
-                   "continuations_agree": bool(agree)}
+        handoff = {"raster_bytes": ysz + usz + vsz, "state_bytes": len(blob), "broadcast_ms": round(t_bcast * 1e3, 3), "backend": dist.get_backend(),
+                   "world_size": world, "continuations_agree": bool(agree)}
         if not agree:
             raise SystemExit("entry-state hand-off mismatch across ranks")
 
     # ---- the end-to-end pipeline ----
-    # A step's S groups of pictures are S independent decode jobs (ExCamera chunks: one Decoder each, xc-decode-bundle).  The
-    # entropy decode of a frame is ONE serial chain on ONE GPU lane, so what matters is how many chains are in flight; and a key
-    # frame's chain is ~2.6x longer than an inter frame's.  The scheduler therefore hands key frames to the GPU `key_ahead`
-    # steps before their group is reconstructed and inter frames only `depth` steps before (they would otherwise sit in HBM
-    # waiting for their key frame).  R = key_ahead decoder sets rotate, so that the key frame of group g + R can be submitted
-    # to a decoder whose group g is done.
-    class Pipeline:
-        """Group g = one group of pictures of every stream = S decoders created when its key frames are handed over (a new
-        Decoder per chunk, as xc-decode-bundle does) and dropped when its last frame has been reconstructed: a decoder waiting
-        for its turn holds no raster (its references point at the context's shared blank one)."""
-
-        def __init__(self, stream_list, key_ahead, depth, header_ahead=0):
-            self.streams = stream_list
-            self.n = len(stream_list)
-            self.H = max(0, header_ahead)
-            self.inter_h = 0
-            self.K, self.D = max(1, key_ahead), max(1, min(depth, key_ahead))
-            self.groups = {}                                # g -> [Decoder]
-            n = self.n
-            # argument blocks, reused: only the decoder handles change from group to group
-            self.key_arr = (aa.capi.FrameIn * n)(); self.key_out = (C.c_int * n)()
-            self.inter_arr = (aa.capi.FrameIn * (n * (F - 1)))(); self.inter_out = (C.c_int * (n * (F - 1)))()
-            for i, st in enumerate(stream_list):
-                self.key_arr[i].data, self.key_arr[i].size = st[0], len(st[0])
-                for k, fr in enumerate(st[1:]):             # stream-major: the inter frames of one stream are consecutive (a host worker takes a whole stream)
-                    e = self.inter_arr[i * (F - 1) + k]
-                    e.data, e.size = fr, len(fr)
-            self.keys = self.inters = self.decoded = 0      # groups handed to the GPU parser (key / inter frames), groups reconstructed
-            self.frames_submitted = 0
-            self.host_s = 0.0
-            self.t_launch = self.t_decode = self.t_release = 0.0      # host time in aa_launch_tokens / aa_decode_batch / releases
-            self.done_t = []
-            self.delivered_bytes = 0
-
-        def _deliver(self, ds, f):
-            """Frame f of every decoder of the group -> the pinned ring, behind its reconstruction, beside the next frame's."""
-            slab = deliver_ring[f & 1]
-            ds[0].download_wait()                       # the copies that used this part of the ring before are through (copy stream)
-            for i, d in enumerate(ds):
-                base = slab + i * raster_bytes
-                d.download_async(f, base, base + plane_sizes[0], base + plane_sizes[0] + plane_sizes[1])
-            self.delivered_bytes += len(ds) * raster_bytes
-
-        def _submit_keys(self, g):
-            t = time.perf_counter()
-            ds = self.groups[g] = [aa.Decoder(ctx, width, height) for _ in range(self.n)]
-            for i, d in enumerate(ds):
-                self.key_arr[i].stream = d.h.value
-            ctx.submit_prepared((self.key_arr, self.key_out, None), threads, False)
-            self.frames_submitted += self.n
-            self.host_s += time.perf_counter() - t
-
-        def _submit_inters(self, g, defer_tokens=False):
-            if F < 2:
-                return
-            t = time.perf_counter()
-            for i, d in enumerate(self.groups[g]):
-                h = d.h.value
-                for k in range(F - 1):
-                    self.inter_arr[i * (F - 1) + k].stream = h
-            ctx.submit_prepared((self.inter_arr, self.inter_out, None), threads, defer_tokens)
-            self.frames_submitted += self.n * (F - 1)
-            self.host_s += time.perf_counter() - t
-
-        def decode(self, release=True):
-            g = self.decoded
-            ds = self.groups[g]
-            for f in range(F):
-                t = time.perf_counter()
-                ctx.decode_batch(ds, [f] * self.n)
-                t1 = time.perf_counter(); self.t_decode += t1 - t
-                if deliver_ring and release:
-                    self._deliver(ds, f)
-                    t1 = time.perf_counter()
-                if release:             # this frame is consumed: its records go back to the pool once the kernels queued so far
-                    for d in ds:        # have run, its raster when nothing refers to it any more (RasterHandle semantics)
-                        d.release_before(f + 1)
-                    self.t_release += time.perf_counter() - t1
-            if release:
-                t1 = time.perf_counter()
-                del self.groups[g], ds  # the chunk is done: its decoders go (nothing waits for the GPU here)
-                self.t_release += time.perf_counter() - t1
-            self.decoded += 1
-            self.done_t.append(time.perf_counter())
-            if args.trace_memory:
-                i = ctx.info()
-                print("step %d: pool %.1f GB (free %.1f, pending %.1f) heap mapped %.1f used %.1f GB free chunks %d starved %d alive wgs %d waiting %d"
-                      % (self.decoded, i["pool_bytes"] / 1e9, i["pool_free_bytes"] / 1e9, i["pool_pending_bytes"] / 1e9, i["heap_mapped_bytes"] / 1e9,
-                         i["heap_used_bytes"] / 1e9, i["heap_free_chunks"], i["lanes_starved"], i["token_workgroups_alive"], i["jobs_waiting"]), file=sys.stderr, flush=True)
-
-        def _room(self, nbytes):
-            """Is there room in the coefficient heap for frames expected to store `nbytes`?  (Frames in flight are on the context's
-            books with what they are expected to take, parsed ones with what they took.)  Never refuses when nothing is in
-            flight: then waiting would not free anything."""
-            if self.keys == self.decoded:
-                return True
-            i = ctx.info()
-            cap = min(i["heap_limit_bytes"], i["memory_limit_bytes"] - i["pool_bytes"]) if i["heap_limit_bytes"] else i["memory_limit_bytes"] - i["pool_bytes"]
-            return i["heap_used_bytes"] + nbytes <= args.overcommit * cap
-
-        def run(self, steps):
-            """`steps` whole steps, from an empty pipeline to an empty pipeline.  Frames go to the GPU parser in the order they
-            are needed, as far ahead as the look-ahead says AND the HBM budget holds: key frames up to K steps before their
-            group is reconstructed (their chains are the long ones), inter frames up to D steps."""
-            target = self.decoded + steps
-            while self.decoded < target:
-                while True:
-                    can_inter = self.inter_h < min(target, self.decoded + self.D + self.H, self.keys)
-                    can_key = self.keys < min(target, self.decoded + self.K)
-                    # the group about to be reconstructed comes first; otherwise key frames lead (K - D steps ahead of the inter frames)
-                    if can_inter and (self.inter_h == self.decoded or not can_key or self.keys - self.inter_h > self.K - self.D):
-                        if not self._room(self.n * (F - 1) * inter_bytes):
-                            break
-                        self._submit_inters(self.inter_h, defer_tokens=self.H > 0); self.inter_h += 1
-                        if self.H == 0:
-                            self.inters += 1
-                    elif can_key:
-                        if not self._room(self.n * key_bytes):
-                            break
-                        self._submit_keys(self.keys); self.keys += 1
-                    elif self.H > 0 and self.inters < min(target, self.decoded + self.D, self.inter_h):
-                        t = time.perf_counter()
-                        ctx.launch_tokens(1); self.inters += 1
-                        self.t_launch += time.perf_counter() - t
-                    else:
-                        break
-                self.decode()
-
-    # ---- calibration: what ONE lone chain costs, and what frames of this content really store ----
-    # (a) a key frame parsed with nothing else on the GPU: its wall time / its decode steps = the latency of one step of one
-    #     lane, the unit of the entropy decode's own roof (lanes / step latency);
-    # (b) coefficient blocks per key / inter frame of a few streams -> bytes a frame in flight holds (records + the chunks its
-    #     lane drew: demand-sized, not 25 blocks per macroblock).
-    cal = [aa.Decoder(ctx, width, height) for _ in range(min(4, S))]
-    ctx.kernel_stats(reset=True)
-    t0 = time.perf_counter()
-    ctx.submit_frames([(cal[0], streams[0][0])], threads, route="device")
-    key_hdr = cal[0].frame_header(0)                     # waits for the parse
-    t_lone_key = time.perf_counter() - t0
-    lone_stats = ctx.kernel_stats(reset=True)
-    lone_steps = lone_stats["token_steps"]
-    ctx.submit_frames([(d, st[0]) for d, st in zip(cal[1:], streams[1:])] + [(d, fr) for d, st in zip(cal, streams) for fr in st[1:]], threads, route="device")
-    key_blocks = max([key_hdr["num_coeff_blocks"]] + [d.frame_header(0)["num_coeff_blocks"] for d in cal[1:]])
-    inter_blocks = max(d.frame_header(f)["num_coeff_blocks"] for d in cal for f in range(1, F)) if F > 1 else key_blocks
-    ctx.sync()
-    step_latency_us = t_lone_key / max(1, lone_steps) * 1e6
-    del cal
-    rec_fixed = mbs_per_frame * 84 + 4096 + 2 * 65536          # macroblock records + flags + lists; two partly filled 64-KB chunks
-    key_bytes, inter_bytes = rec_fixed + key_blocks * 32, rec_fixed + inter_blocks * 32
-    packed_storage = None
-    if args.packed:
-        # bytes a stored block takes, key and inter frames apart (a key frame's blocks are nearly full, an inter frame's hold 2-4 values)
-        rest = ctx.kernel_stats()
-        key_bpb = 2.0 * lone_stats["packed_words"] / max(1, lone_stats["packed_blocks"])
-        rest_keys = len(streams[1:min(4, S)])
-        inter_words = rest["packed_words"] - rest_keys * lone_stats["packed_words"]
-        inter_blks = rest["packed_blocks"] - rest_keys * lone_stats["packed_blocks"]
-        inter_bpb = 2.0 * inter_words / inter_blks if inter_blks > 0 and inter_words > 0 else key_bpb
-        key_bytes, inter_bytes = int(rec_fixed + mbs_per_frame * 4 + key_blocks * key_bpb), int(rec_fixed + mbs_per_frame * 4 + inter_blocks * inter_bpb)
-        packed_storage = {"key_frame_bytes_per_block": round(key_bpb, 2), "inter_frame_bytes_per_block": round(inter_bpb, 2), "dense_bytes_per_block": 32}
-    plane_sizes = aa.Decoder(ctx, width, height).plane_sizes()
-    raster_bytes = sum(plane_sizes)
-    deliver_ring = [ctx.pinned_alloc(S * raster_bytes) for _ in range(2)] if args.deliver else None
-    info0 = ctx.info()
-    budget = hbm_budget - 2e9                                   # (arenas of the compressed frames, row-kernel work space)
+    calibrate(env, streams)
+    step_latency_us = env["step_latency_us"]
+    plane_sizes, raster_bytes = env["plane_sizes"], env["raster_bytes"]
+    if args.deliver:
+        env["deliver_ring"] = [ctx.pinned_alloc(S * raster_bytes) for _ in range(2)]
     K, D = max(1, args.key_ahead), max(1, min(args.depth, args.key_ahead))
-
-    # HBM holds what is in flight: K + 1 groups of key frames, D + 0.6 groups of inter frames (frames being parsed hold part of
-    # what they will), the rasters the decoder sets refer to.  Clamp the look-ahead to what fits.
-    def need(k, d):
-        # frames being parsed hold part of what they will (on average half, for the ~chain latency), parsed ones all of it
-        return S * ((0.5 * k + 1.5) * key_bytes + (0.6 * d + 1.0) * (F - 1) * inter_bytes + 5 * raster_bytes
-                    + (k + d * (F - 1)) * compressed_bytes / (S * F) * 1.1
-                    + args.header_ahead * (F - 1) * (mbs_per_frame * 84 + compressed_bytes / (S * F)))
-    planned_need_gb = round(need(K, D) / 1e9, 1)         # (the look-ahead is bounded by K / D AND, at run time, by what the heap holds: _room)
-    pipe = Pipeline(streams, K, D, args.header_ahead)
+    # what the look-ahead would hold if memory were free (the run itself is bounded by Pipeline._room)
+    planned_need_gb = round(S * ((0.5 * K + 1.5) * (env["key_coeff_bytes"] + env["key_arena_bytes"]) + (0.6 * D + 1.0) * (F - 1) * (env["inter_coeff_bytes"] + env["inter_arena_bytes"])
+                                 + 5 * raster_bytes) / 1e9, 1)
+    pipe = Pipeline(env, streams, K, D, args.header_ahead)
     pipe.run(max(2, pipe.K // 2))       # priming (untimed, before the warm-up): the pools and the coefficient heap reach their working
     pipe.run(args.warmup)               # size, so that first-touch allocations (hipMalloc / hipMemMap / hipHostMalloc) are not what the steps measure
     barrier()
-    pipe.host_s = pipe.t_launch = pipe.t_decode = pipe.t_release = 0.0; pipe.done_t = []
+    pipe.host_s = pipe.t_launch = pipe.t_decode = pipe.t_release = 0.0; pipe.done_t = []; pipe.refused = 0
+    pipe.keep_group = pipe.decoded + args.steps - 1          # the last TIMED step keeps the frames of its distinct streams: they are what is verified
     ctx.kernel_stats(reset=True)
+    prof0 = ctx.info()["token_profile"]
     if args.profile_timed:
         ctx.profile(True)
     t0 = time.perf_counter()
@@ -368,10 +527,14 @@ def main():
     delivery = None
     if args.deliver:
         delivery = {"bytes_per_step": (pipe.delivered_bytes - delivered0) // args.steps, "gb_per_s": round((pipe.delivered_bytes - delivered0) / elapsed / 1e9, 2),
-                    "note": "every reconstructed frame copied to pinned host memory on the copy stream inside the timed region (3.13 MB per 1080p frame); `value` of THIS run includes it"}
+                    "copies_per_frame_index": 1,
+                    "note": "every reconstructed frame gathered into one staging piece and copied to pinned host memory on the copy stream inside the timed region "
+                            "(%.2f MB per frame); `value` of THIS run includes it" % (raster_bytes / 1e6)}
     hbm_free, hbm_total = ctx.memory()
     tstats = ctx.kernel_stats(reset=True); ctx.profile(False)
     info = ctx.info()
+    clock_mhz = info.get("clock_mhz") or 2400
+    token_profile = token_profile_delta(prof0, info["token_profile"], clock_mhz)
     timed_region = {"step_done_at_ms": [round((t - t0) * 1e3) for t in pipe.done_t],
                     "host_ms_per_step": {"submit": round(pipe.host_s / args.steps * 1e3, 1), "launch_tokens": round(pipe.t_launch / args.steps * 1e3, 1),
                                          "decode_batch_calls_incl_wait_for_parse": round(pipe.t_decode / args.steps * 1e3, 1),
@@ -381,23 +544,25 @@ def main():
                     "host_in_pool_allocator_ms_per_step": round(tstats["alloc_ms"] / args.steps, 2), "slab_mallocs": tstats["slab_mallocs"],
                     "heap_grows": tstats["heap_grows"], "frames_handed_back_for_lack_of_memory": tstats["nomem_retries"], "frames_evicted": tstats["frames_evicted"],
                     "worker_grids_launched": tstats["worker_launches"], "worker_workgroups_launched": tstats["worker_wgs"], "worker_grids_retired": tstats["worker_retires"],
-                    "pool_waits": tstats["pool_waits"], "pool_wait_ms_per_step": round(tstats["pool_wait_ms"] / args.steps, 2)}
+                    "pool_waits": tstats["pool_waits"], "pool_wait_ms_per_step": round(tstats["pool_wait_ms"] / args.steps, 2),
+                    "hand_overs_put_off_for_lack_of_room": pipe.refused, "frames_parsed_on_host_cores": tstats["host_routed_frames"]}
     # the entropy decode against ITS roof: a lane decodes one bool per step, a step takes what it takes (measured on a lone chain),
     # the GPU holds `lanes` chains -> lanes / step latency bools per second at best
     lanes_total = info["token_lanes_per_workgroup"] * info["token_workgroups_capacity"]
     bools = tstats["token_steps"]
     lanes_roof = {"lanes": lanes_total, "lanes_per_workgroup": info["token_lanes_per_workgroup"], "workgroups_per_cu": info["token_workgroups_capacity"] // max(1, info["compute_units"]),
+                  "live_lanes_of_64": round(info["token_lanes_per_workgroup"] / 64.0, 3),
                   "lane_lds_bytes": info["token_lane_lds_bytes"], "workgroup_lds_bytes": info["token_workgroup_lds_bytes"],
                   "step_latency_us_lone_chain": round(step_latency_us, 4),
                   "roof_bools_per_s": round(lanes_total / (step_latency_us * 1e-6)), "sustained_bools_per_s": round(bools / elapsed),
                   "frac": round(bools / elapsed / (lanes_total / (step_latency_us * 1e-6)), 4), "bools_per_step": round(bools / args.steps),
+                  "in_kernel_accounting": token_profile,
                   "note": "decode steps of the frames parsed in the timed region (an upper bound on bools) over the timed region's wall time; step latency = lone key frame submit->parsed / its steps"}
     memory = {"limit_gb": round(info["memory_limit_bytes"] / 1e9, 1), "pool_gb": round(info["pool_bytes"] / 1e9, 2), "coefficient_heap_mapped_gb": round(info["heap_mapped_bytes"] / 1e9, 2),
               "hbm_taken_by_the_context_gb": round((info["pool_bytes"] + (info["heap_mapped_bytes"] if info["heap_is_virtual"] else 0)) / 1e9, 2),
               "pinned_host_gb": round(info["pinned_host_bytes"] / 1e9, 2), "heap_is_virtual": bool(info["heap_is_virtual"]),
               "hbm_in_use_on_device_gb": round((hbm_total - hbm_free) / 1e9, 1),
-              "packed_storage": packed_storage,
-              "planned": {"key_frame_bytes": key_bytes, "inter_frame_bytes": inter_bytes, "key_blocks_per_mb": round(key_blocks / mbs_per_frame, 2), "inter_blocks_per_mb": round(inter_blocks / mbs_per_frame, 2)}}
+              "packed_storage": env["packed_storage"], "planned": env["planned"]}
     if args.profile_timed:
         timed_region["kernel_ms_per_step"] = {k: round(v / args.steps, 2) for k, v in tstats.items() if k.endswith("_ms") and "wait" not in k}
     host_submit_s = pipe.host_s / max(1, args.steps)
@@ -407,18 +572,31 @@ def main():
     per_rank = None
     if dist is not None:
         import torch
-        mine = torch.tensor([elapsed, pipe.host_s / max(1, args.steps), tstats["parse_wait_ms"] / max(1, args.steps) * 1e-3, float(threads)],
-                            dtype=torch.float64, device="cuda")
+        tdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        mine = torch.tensor([elapsed, pipe.host_s / max(1, args.steps), tstats["parse_wait_ms"] / max(1, args.steps) * 1e-3, float(threads),
+                             info["pool_bytes"] + (info["heap_mapped_bytes"] if info["heap_is_virtual"] else 0), info["pinned_host_bytes"]],
+                            dtype=torch.float64, device=tdev)
         every = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank = [{"rank": r, "elapsed_s": round(float(v[0]), 4), "host_prepass_and_staging_s_per_step": round(float(v[1]), 4),
-                     "host_waited_for_parse_s_per_step": round(float(v[2]), 4), "host_threads": int(v[3])} for r, v in enumerate(every)]
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+                     "host_waited_for_parse_s_per_step": round(float(v[2]), 4), "host_threads": int(v[3]),
+                     "hbm_gb": round(float(v[4]) / 1e9, 2), "pinned_host_gb": round(float(v[5]) / 1e9, 2)} for r, v in enumerate(every)]
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
     ms_per_step = elapsed / args.steps * 1e3
     value = world * mbs_per_step * args.steps / elapsed
+
+    # ---- bit-exactness against the REFERENCE decoder, on the output of a TIMED step: every distinct stream of the last step of the
+    # timed region, first / middle / last frame (the last one depends on all the others through the references) ----
+    verified = None
+    kept = pipe.kept.pop(pipe.keep_group, None)
+    if rank == 0 and not args.no_verify and kept:
+        verified = verify_against_reference(env, {i: kept[i] for i in env["distinct"]}, paths, sorted({0, F // 2, F - 1}))
+        if verified:
+            verified["what"] = "rasters written by the last step of the timed region"
+    del kept
 
     # ---- per-kernel timing of one more (un-pipelined) step: HIP events on the streams the kernels run on ----
     ctx.profile(True); ctx.kernel_stats(reset=True)
@@ -434,7 +612,7 @@ def main():
 
     # macroblocks of the profiled step by kind (the records are in HBM: ask them)
     split_mbs = whole_mbs = intra_mbs = 0
-    for i in sorted({sd: k for k, sd in enumerate(seeds)}.values()):        # one decoder per distinct stream, scaled up
+    for i in env["distinct"]:                                               # one decoder per distinct stream, scaled up
         mult = seeds.count(seeds[i])
         for f in range(F):
             _, mb, _ = verify_decs[i].read_records(verify_base + f)
@@ -443,11 +621,11 @@ def main():
             split_mbs += mult * sp; whole_mbs += mult * (int(inter.sum()) - sp); intra_mbs += mult * int((~inter).sum())
     launches_per_step = {"recon_inter": max(1, kstats["recon_inter_launches"]), "recon_split": max(1, kstats["recon_split_launches"]),
                          "recon_intra": max(1, kstats["recon_intra_launches"]),
-                         "loopfilter": max(1, kstats["loopfilter_launches"]), "parse_tokens": max(1, kstats["worker_launches"]),
-                         "parse_headers": max(1, kstats["parse_launches"])}
+                         "loopfilter": max(1, kstats["loopfilter_launches"]), "parse_headers": max(1, kstats["parse_launches"])}
     units = {"recon_inter": whole_mbs, "recon_split": split_mbs, "recon_intra": intra_mbs,
              "loopfilter": S * F * mbs_per_frame, "parse_tokens": S * F * mbs_per_frame, "parse_headers": S * F * mbs_per_frame}
-    traffic = pmc_traffic(args.config) or {}
+    traffic, traffic_source = pmc_traffic(args.config)
+    traffic = traffic or {}
 
     def roof(k):
         ms = kstats[k + "_ms"]
@@ -460,58 +638,35 @@ def main():
         return {"bound": "hbm", "kernel": KERNEL_NAMES[k], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None if tr is None else round(tr * units[k] / n),
                 "avg_launch_us": round(ms / n * 1e3, 3), "launches_per_step": n, "ms_per_step": round(ms, 3),
-                "algorithmic_bytes_per_launch": round(bytes_per_launch)}
-    roofs = {k: roof(k) for k in BYTES_PER_MB}
-    if roofs["parse_tokens"] is None and units["parse_tokens"]:
-        # the worker grids of the timed region were still there (they linger between bursts): no launch, no launch events.  What this
-        # step's frames cost the workers is then the wall time from their hand-over to the last lane's `done` -- ONE residency
-        bytes_per_launch = BYTES_PER_MB["parse_tokens"] * units["parse_tokens"]
-        achieved = bytes_per_launch / t_parse_alone / 1e9
-        tr = traffic.get("parse_tokens")
-        roofs["parse_tokens"] = {"bound": "hbm", "kernel": KERNEL_NAMES["parse_tokens"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None if tr is None else round(tr * units["parse_tokens"]),
-                                 "avg_launch_us": round(t_parse_alone * 1e6, 3), "launches_per_step": 1, "ms_per_step": round(t_parse_alone * 1e3, 3),
-                                 "algorithmic_bytes_per_launch": round(bytes_per_launch),
-                                 "duration_source": "host clock, hand-over -> parsed (the grid was resident before the step: no HIP events around a launch)"}
-        kstats["parse_tokens_ms"] = t_parse_alone * 1e3
-    dom = max((k for k in roofs if roofs[k]), key=lambda k: kstats[k + "_ms"])
-    roofline = dict(roofs[dom])
-    roofline["note"] = ("dominant kernel by time, from the un-pipelined profile step (its worker grids overlap: one for the key frames, one for the inter frames). "
-                        "k_token_workers is a latency-bound serial arithmetic decode per lane; HBM is the nominal roof the contract prices against, "
-                        "what binds it is lanes / step latency: see entropy_decode_roof")
-    roofline["sustained_in_timed_region"] = {"achieved": round(BYTES_PER_MB["parse_tokens"] * value / world / 1e9, 2), "unit": "GB/s",
-                                             "frac": round(BYTES_PER_MB["parse_tokens"] * value / world / (HBM_PEAK_GBS * 1e9), 5),
-                                             "note": "algorithmic bytes of the entropy decode (880 per macroblock) x the end-to-end rate: the workers are resident for the whole timed region"}
-    roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this config)" if traffic else None
+                "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                "measured": "one un-pipelined step after the timed region, HIP events on the kernel's stream, worker grids resident beside it"}
+    roofs = {k: roof(k) for k in BYTES_PER_MB if k != "parse_tokens"}
+    # k_token_workers is RESIDENT: its workgroups draw frames from a queue for as long as there is work, so there is no launch to
+    # put events around.  Its roofline is priced on the time it was resident for the work it did: the whole timed region (the
+    # driver's clock), during which it parsed `parsed_macroblocks` macroblocks.  One "launch" = one step's share of that.
+    tok_mbs = tstats["parsed_macroblocks"]
+    tok_bytes_per_step = BYTES_PER_MB["parse_tokens"] * tok_mbs / args.steps
+    tok_achieved = BYTES_PER_MB["parse_tokens"] * tok_mbs / elapsed / 1e9
+    tr = traffic.get("parse_tokens")
+    roofs["parse_tokens"] = {"bound": "hbm", "kernel": KERNEL_NAMES["parse_tokens"], "achieved": round(tok_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(tok_achieved / HBM_PEAK_GBS, 5), "traffic": None if tr is None else round(tr * tok_mbs / args.steps),
+                             "avg_launch_us": round(ms_per_step * 1e3, 3), "launches_per_step": 1, "ms_per_step": round(ms_per_step, 3),
+                             "algorithmic_bytes_per_launch": round(tok_bytes_per_step), "macroblocks_parsed_in_the_timed_region": tok_mbs,
+                             "duration_source": "resident kernel: the timed region's wall time / steps (its workgroups hold their CUs for the whole region); "
+                                                "HBM is the nominal roof the contract prices against -- what binds this kernel is VALU issue of one wave per SIMD "
+                                                "at live_lanes_of_64 lane use: entropy_decode_roof (lanes / step latency, in-kernel time accounting)"}
+    # the dominant kernel by GPU time in a step: the resident workers hold every CU for the whole step
+    roofline = dict(roofs["parse_tokens"])
+    roofline["entropy_decode_alone_ms"] = round(t_parse_alone * 1e3, 1)      # (the un-pipelined latency of one step's chains: a latency, not a duration of the pipelined run)
+    roofline["traffic_source"] = traffic_source
     roofline["path_frac_of_hbm_peak"] = round(value / world * PATH_BYTES_PER_MB / (HBM_PEAK_GBS * 1e9), 5)
 
-    # ---- bit-exactness against the REFERENCE decoder: every distinct stream of the batch, first / middle / last frame
-    # (the last one depends on all the others through the references) ----
-    verified = None
-    ref_decode = os.path.join(ROOT, "oracle", "_ref", "ref_decode")
-    if rank == 0 and not args.no_verify and os.path.exists(ref_decode):
-        distinct = {}
-        for i, sd in enumerate(seeds):
-            distinct.setdefault(sd, i)
-        check_frames = sorted({0, F // 2, F - 1})
+    # ---- bit-exactness of the profile step too (all three formats of evidence agree: timed step, profile step, pytest) ----
+    verified_profile_step = None
+    if rank == 0 and not args.no_verify:
+        verified_profile_step = verify_against_reference(env, {i: verify_decs[i] for i in env["distinct"][:24]}, paths, [F - 1])
 
-        def ref_hashes(i):
-            raw = os.path.join(workload.cache_dir(), "bench_verify_%d_%d.raw" % (os.getpid(), i))
-            subprocess.run([ref_decode, paths[i], raw], check=True, stdout=subprocess.DEVNULL)
-            with open(raw, "rb") as fh:
-                ref = fh.read()
-            os.unlink(raw)
-            fs = len(ref) // F
-            return i, [hashlib.sha256(ref[f * fs:(f + 1) * fs]).digest() for f in check_frames]
-        with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
-            refs = list(ex.map(ref_hashes, distinct.values()))
-        bad = [(i, f) for i, hs in refs for f, hsh in zip(check_frames, hs)
-               if hashlib.sha256(verify_decs[i].raster_bytes(verify_base + f)).digest() != hsh]
-        verified = {"streams_checked": len(refs), "frames_per_stream": len(check_frames), "bit_exact": not bad}
-        if bad:
-            raise SystemExit("PARITY FAILURE: HIP output differs from the reference decoder on (stream, frame) %r" % bad[:8])
-
-    # ---- device half alone (last round's metric): the step just parsed stays resident, reconstruction replayed ----
+    # ---- device half alone (round-1 metric): the step just parsed stays resident, reconstruction replayed ----
     device_half = None
     if not args.no_device_half:
         reps = max(2, min(args.steps, 5))
@@ -524,13 +679,23 @@ def main():
         for d in verify_decs:
             d.rewind_to(verify_base)
         replay(); ctx.sync()
+        ctx.profile(True); ctx.kernel_stats(reset=True)
         t0 = time.perf_counter()
         for _ in range(reps):
             replay()
         ctx.sync()
         dt = (time.perf_counter() - t0) / reps
-        device_half = {"value": round(mbs_per_step / dt, 1), "unit": "macroblocks/s", "ms_per_step": round(dt * 1e3, 3),
-                       "note": "reconstruction + loop filter only, parsed records resident in HBM (round-1 metric)"}
+        hs = ctx.kernel_stats(reset=True); ctx.profile(False)
+        alone = {}
+        for k in ("recon_inter", "recon_split", "recon_intra", "loopfilter"):
+            n = hs[k + "_launches"]
+            if n and units[k]:
+                ms = hs[k + "_ms"] / n
+                alone[k] = {"kernel": KERNEL_NAMES[k], "avg_launch_us": round(ms * 1e3, 1),
+                            "frac": round(BYTES_PER_MB[k] * units[k] / launches_per_step[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        device_half = {"value": round(mbs_per_step / dt, 1), "unit": "macroblocks/s", "ms_per_step": round(dt * 1e3, 3), "kernels_alone": alone,
+                       "note": "reconstruction + loop filter only, parsed records resident in HBM (round-1 metric); kernels_alone: the same kernels with idle worker grids "
+                               "(lingering waves are asleep), frac = algorithmic bytes / launch time / HBM peak"}
     pipe_K, pipe_D = pipe.K, pipe.D
     mbs_whole_run = (pipe.frames_submitted + min(4, S) * F) * mbs_per_frame       # (+ the calibration frames)
     del pipe, verify_decs
@@ -544,7 +709,7 @@ def main():
             # few streams are parsed by host workers (aa_submit_frames routes them): no chains of seconds to hide, so no deep
             # look-ahead either -- one group ahead keeps the GPU's reconstruction and the host's parse overlapped
             host_routed = n <= min(threads, 24)
-            p = Pipeline(streams[:n], 2 if host_routed else pipe_K, 2 if host_routed else pipe_D, 0 if host_routed else args.header_ahead)
+            p = Pipeline(env, streams[:n], 2 if host_routed else pipe_K, 2 if host_routed else pipe_D, 0 if host_routed else args.header_ahead)
             p.run(3); ctx.sync()
             reps = max(6, p.K)
             t0 = time.perf_counter()
@@ -568,6 +733,17 @@ def main():
             small.setdefault("1_host_parser", {"mb_per_s": round(F * mbs_per_frame / dt_host, 1), "ms_per_frame": round(dt_host / F * 1e3, 2),
                                                "note": "aa_stream_decode: serial BoolDecoder on one host core, frame by frame (Decoder::get_frame_output)"})
             del p, d1
+
+    # ---- the other BASELINE configs, end to end, parity checked in the run ----
+    secondary = {}
+    if args.secondary:
+        for cfg_name in [c for c in args.secondary.split(",") if c and c != args.config]:
+            try:
+                secondary[cfg_name] = run_secondary(args, ctx, cfg_name, rank, world, threads)
+            except SystemExit:
+                raise
+            except Exception as e:                      # (a secondary figure that cannot be had must not take the headline down with it)
+                secondary[cfg_name] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- host parser (the product's C++ BoolDecoder path used for single streams): rate per core ----
     pp = aa.Parser(width, height)
@@ -622,7 +798,7 @@ def main():
                        "compressed_bytes_per_mb": round(compressed_bytes / mbs_per_step, 2), "sharding": "streams, one shard per GPU, no data-path collective",
                        "schedule": args.schedule, "key_frames_ahead": pipe_K, "inter_frames_ahead": pipe_D, "inter_headers_ahead_of_tokens": args.header_ahead, "host_threads": threads,
                        "hbm_budget_gb": round(hbm_budget / 1e9, 1), "look_ahead_if_memory_were_free_gb": planned_need_gb, "hbm_taken_by_the_context_gb": memory["hbm_taken_by_the_context_gb"],
-                       "coefficient_storage": "packed" if args.packed else "dense"},
+                       "coefficient_storage": "packed" if info["packed_coefficients"] else "dense"},
             "memory": memory, "entropy_decode_roof": lanes_roof, "delivery": delivery, "macroblocks_parsed_whole_run": mbs_whole_run,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "kernels": roofs, "units_per_step": units, "launches_per_step": launches_per_step, "device_half": device_half,
@@ -631,9 +807,9 @@ def main():
             "stages": {"host_prepass_and_staging_s_per_step": round(host_submit_s, 4),
                        "entropy_decode_alone_s_per_step": round(t_parse_alone, 4),
                        "note": "entropy_decode_alone = one step's submit -> parse finished with nothing else on the GPU (a latency: the longest chain, a key frame)"},
-            "timed_region": timed_region, "per_rank": per_rank, "small_batches": small,
+            "timed_region": timed_region, "per_rank": per_rank, "small_batches": small, "secondary": secondary,
             "host": {"parser_mb_per_s_per_core": round(parser_only, 1), "stream_generation_s": round(t_gen, 1)},
-            "kernel_stats": kstats, "verified_bit_exact_vs_reference": verified, "entry_state_handoff": handoff,
+            "kernel_stats": kstats, "verified_bit_exact_vs_reference": verified, "verified_profile_step": verified_profile_step, "entry_state_handoff": handoff,
         }
     else:
         line = None

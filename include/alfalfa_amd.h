@@ -190,14 +190,16 @@ typedef struct aa_ctx_info {
   uint64_t token_profile[8];
   uint32_t packed_coefficients;      /* 1: device-parsed frames store packed coefficients (aa_ctx_set_packed_coefficients) */
   uint32_t lane_per_partition;       /* 1: frames with several DCT partitions may get a token lane per partition (aa_ctx_set_lane_per_partition) */
+  uint32_t clock_mhz;                /* the device's shader clock (hipDeviceAttributeClockRate) */
+  uint32_t reserved0;
 } aa_ctx_info;
 aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out );
-/* How the device parser stores a frame's coefficients until the frame is reconstructed.  0 (default): dense, 32 bytes per
- * non-zero 4x4 block.  1: packed -- one mask word + the block's non-zero coefficients (about a third of the memory on video
- * content, and fewer stores for the token lanes); aa_decode_batch expands the frames it is given into a transient dense array
- * on the device before reconstructing them.  Results are identical.  The choice is per context and can only be made before
- * the context's first aa_submit_frames call (AA_ERR_LOGIC afterwards); the environment variable ALFALFA_AMD_PACKED=1 makes
- * packed the default. */
+/* How the device parser stores a frame's coefficients until the frame is reconstructed.  1 (default): packed -- one mask word +
+ * the block's non-zero coefficients (about a third of the memory on video content, and fewer stores for the token lanes);
+ * aa_decode_batch expands the frames it is given into a transient dense array on the device before reconstructing them.
+ * 0: dense, 32 bytes per non-zero 4x4 block.  Results are identical.  The choice is per context and can only be made before
+ * the context's first aa_submit_frames call (AA_ERR_LOGIC afterwards); the environment variable ALFALFA_AMD_PACKED=0 makes
+ * dense the default of every context. */
 aa_status aa_ctx_set_packed_coefficients( aa_ctx * ctx, int on );
 /* One token lane per DCT partition.  A frame with 2, 4 or 8 partitions (frame.cc:119-137: macroblock row r is coded in
  * partition r % P) is then decoded by that many lanes of one wave -- rows handed from lane to lane through the above-row
@@ -298,6 +300,12 @@ aa_status aa_pinned_alloc( aa_ctx * ctx, size_t bytes, void ** out );
 void aa_pinned_free( void * p );
 aa_status aa_stream_download_async( aa_stream * s, int frame_index, uint8_t * y, uint8_t * u, uint8_t * v );
 aa_status aa_stream_download_wait( aa_stream * s );
+/* A whole batch at once -- what frontend/vp8decode.cc:78-93 / decode-bundle.cc:92-99 do with every shown frame, for n decoders in
+ * lock step: frame frame_index[i] of streams[i] -> dst + i * stride (pinned memory, aa_pinned_alloc; stride a multiple of 16 and at
+ * least a raster: Y, U, V planes back to back as VP8Raster pads them).  One gather kernel behind the reconstruction on the
+ * compute stream and ONE copy on the copy stream, instead of 3 n plane copies; valid after aa_ctx_download_wait / aa_ctx_sync. */
+aa_status aa_download_batch_async( aa_ctx * ctx, aa_stream * const * streams, int n, const int * frame_index, uint8_t * dst, size_t stride );
+aa_status aa_ctx_download_wait( aa_ctx * ctx );
 /* Device pointers of a frame's planes (valid while the frame's raster is alive). */
 aa_status aa_stream_raster_device( aa_stream * s, int frame_index, void ** y, void ** u, void ** v );
 /* References::last/golden/alternative after the most recently SUBMITTED frame: frame indices (-1 = initial blank). */

@@ -34,7 +34,12 @@ def sha256(b):
     return hashlib.sha256(b).hexdigest()
 
 
-@pytest.fixture(scope="session")
-def gpu_ctx():
+@pytest.fixture(scope="session", params=["packed", "dense"])
+def gpu_ctx(request):
+    """The session's shared context, once per coefficient storage format of the device parser: every -m gpu test that takes it
+    runs in both (packed is the product's default; dense is what host-parsed frames use and what reconstruction reads)."""
     import alfalfa_amd as aa
-    return aa.Context(0)   # raises NoDevice on a box without a GPU: -m gpu tests must not pass silently
+    ctx = aa.Context(0)    # raises NoDevice on a box without a GPU: -m gpu tests must not pass silently
+    ctx.set_packed_coefficients(request.param == "packed")
+    assert ctx.info()["packed_coefficients"] == (1 if request.param == "packed" else 0)
+    return ctx

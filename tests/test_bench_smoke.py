@@ -20,9 +20,16 @@ def test_bench_small(dist):
     if dist:
         env.update(AA_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cif_inter_lf", "--streams", "12", "--frames", "6", "--steps", "3",
-                        "--warmup", "1", "--key-ahead", "3", "--depth", "2", "--small-batches", "1,4"], env=env, capture_output=True, text=True, timeout=900)
+                        "--warmup", "1", "--key-ahead", "3", "--depth", "2", "--small-batches", "1,4", "--secondary-streams", "8", "--secondary-steps", "2",
+                        "--secondary", "" if dist else "cif_inter_lf_subpel"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
+    if not dist:
+        sec = line["secondary"]["cif_inter_lf_subpel"]
+        assert sec.get("value", 0) > 0 and sec["verified_bit_exact_vs_reference"]["bit_exact"] is True, sec
+    assert line["config"]["coefficient_storage"] == "packed"
+    assert line["verified_bit_exact_vs_reference"]["what"].startswith("rasters written by the last step of the timed region")
+    assert line["roofline"]["kernel"] == "k_token_workers" and line["roofline"]["ms_per_step"] <= line["ms_per_step"] * 1.0001
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
     assert line["value"] > 0 and line["n_gpus"] == 1 and line["steps"] == 3 and line["scaling"] == "weak" and line["dtype"] == "u8"
@@ -34,3 +41,38 @@ def test_bench_small(dist):
         assert line["entry_state_handoff"]["continuations_agree"] is True
     else:
         assert line["entry_state_handoff"] is None
+
+
+def test_two_ranks_on_one_gpu_hand_over_the_entry_state():
+    """The N > 1 path without an 8-GPU node: TWO ranks share GPU 0 (AA_BENCH_DEVICE=0), a real world_size-2 process group
+    broadcasts the entry raster + DecoderState from rank 0, both continuations are checked against a straight decode, and the
+    per-rank budget is what eight ranks on one node can have.  RCCL refuses two ranks on one device ("duplicate GPU") on some
+    builds: then the same run goes through gloo (host memory) and says so -- the product calls are the same either way."""
+    def run(backend, port):
+        env = dict(os.environ)
+        env.update(AA_BENCH_FORCE_DIST="1", AA_BENCH_DEVICE="0", AA_BENCH_BACKEND=backend)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cif_inter_lf", "--streams", "8", "--frames", "6", "--steps", "2", "--warmup", "1",
+               "--key-ahead", "2", "--depth", "2", "--small-batches", "", "--secondary", "", "--hbm-gb", "30", "--no-cpu-baseline", "--no-device-half"]
+        try:
+            return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300 if backend == "nccl" else 900)
+        except subprocess.TimeoutExpired as e:
+            return subprocess.CompletedProcess(cmd, 124, e.stdout or "", "timeout")
+    r = run("nccl", 29541)
+    backend = "nccl"
+    if r.returncode != 0:
+        r = run("gloo", 29543)
+        backend = "gloo"
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    h = line["entry_state_handoff"]
+    assert h["world_size"] == 2 and h["backend"] == backend and h["continuations_agree"] is True
+    ranks = line["per_rank"]
+    assert len(ranks) == 2
+    cores = os.cpu_count() or 1
+    for pr in ranks:
+        assert pr["hbm_gb"] <= 30.5                               # inside --hbm-gb (8 x 200 GB would not fit a node of 8 x 288: the default is 150)
+        assert pr["pinned_host_gb"] * 8 <= 256                    # locked host memory of eight ranks
+        assert pr["host_threads"] <= max(1, cores // 2)           # cores / local world size
+    print("two ranks on one GPU: backend", backend)

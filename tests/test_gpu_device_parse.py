@@ -259,15 +259,19 @@ def test_context_info_and_demand_sized_coefficient_storage(gpu_ctx):
     nmb = hdrs[0]["num_macroblocks"]
     used_chunks = info["heap_used_bytes"] // 65536
     assert used_chunks >= 3                                                     # (other tests' frames may be alive too)
-    assert sum(-(-hd["num_coeff_blocks"] // 2048) for hd in hdrs) <= used_chunks
+    if not info["packed_coefficients"]:
+        assert sum(-(-hd["num_coeff_blocks"] // 2048) for hd in hdrs) <= used_chunks
+    else:                                                                        # a mask word + at least one value per stored block
+        assert 2 * sum(hd["num_coeff_blocks"] for hd in hdrs) <= used_chunks * 32768
     assert max(hd["num_coeff_blocks"] for hd in hdrs) < 25 * nmb
     for i in range(3):
         gpu_ctx.decode_batch([dec], [i])
     assert sha256(dec.raster_bytes(2)) == GOLDEN["cif_q60_lf40s5"]["raster_sha256"][2]
 
 
+@pytest.mark.parametrize("packed", [True, False], ids=["packed", "dense"])
 @pytest.mark.parametrize("vmm", [True, False])
-def test_coefficient_heap_runs_out_and_frames_are_run_again(vmm, monkeypatch):
+def test_coefficient_heap_runs_out_and_frames_are_run_again(vmm, packed, monkeypatch):
     """A heap far too small for what is submitted (8 MB = 128 chunks, 60 CIF key frames want more): lanes wait, hand their frames
     back (TOK_NO_MEMORY), the runtime runs them again as memory comes back -- and says AA_ERR_NO_MEMORY (repeatable) when the
     caller has to release frames first.  Every raster still equals the reference's.  Both heap kinds: mapped on demand
@@ -277,6 +281,7 @@ def test_coefficient_heap_runs_out_and_frames_are_run_again(vmm, monkeypatch):
     if not vmm:
         monkeypatch.setenv("ALFALFA_AMD_NO_VMM", "1")
     ctx = aa.Context(0)
+    ctx.set_packed_coefficients(packed)
     name = "cif_q60_lf40s5"
     w, h, frames = golden_frames(name)
     decs = [aa.Decoder(ctx, w, h) for _ in range(60)]

@@ -230,3 +230,34 @@ def test_rasters_released_while_binding_are_not_recycled_inside_the_same_launch(
         for d in decs:
             d.release_before(f + 1)
         gpu_ctx.sync()
+
+
+def test_a_whole_frame_index_is_delivered_by_one_gather_and_one_copy(gpu_ctx):
+    """aa_download_batch_async: the rasters of n decoders in lock step -- of different sizes -- gathered on the device and copied to
+    pinned host memory in one piece; every raster byte for byte what aa_stream_download gives, and the reference's hash."""
+    import ctypes as C
+    names = ["qcif_q30_lf24", "cif_q60_lf40s5", "synth_175x143_s3", "w200_q40_lf63s7", "qcif_q30"]
+    streams = [golden_frames(n) for n in names]
+    nf = min(len(f) for _, _, f in streams)
+    decs = [aa.Decoder(gpu_ctx, w, h) for w, h, _ in streams]
+    sizes = [sum(d.plane_sizes()) for d in decs]
+    stride = (max(sizes) + 255) & ~255
+    ring = [gpu_ctx.pinned_alloc(stride * len(decs)) for _ in range(2)]
+    try:
+        for f in range(nf):
+            for d, (_, _, frames) in zip(decs, streams):
+                d.parse_frame(frames[f])
+            gpu_ctx.decode_batch(decs, [f] * len(decs))
+            gpu_ctx.download_batch_async(decs, [f] * len(decs), ring[f & 1], stride)      # (arrives while the next frame index is decoded)
+        gpu_ctx.download_wait()
+        for f in (nf - 2, nf - 1):
+            for i, (d, n) in enumerate(zip(decs, names)):
+                got = C.string_at(ring[f & 1] + i * stride, sizes[i])
+                assert got == d.raster_bytes(f), (n, f)
+                assert sha256(got) == GOLDEN[n]["raster_sha256"][f], (n, f)
+    finally:
+        gpu_ctx.sync()
+        for p in ring:
+            gpu_ctx.pinned_free(p)
+    with pytest.raises(aa.AlfalfaError):                    # a stride smaller than a raster is refused, nothing is written
+        gpu_ctx.download_batch_async(decs, [0] * len(decs), 0x1000, 16)

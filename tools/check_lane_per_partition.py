@@ -66,8 +66,7 @@ def main():
     for packed in (False, True):
         ctx = aa.Context(0)
         ctx.set_lane_per_partition(True)
-        if packed:
-            ctx.set_packed_coefficients(True)
+        ctx.set_packed_coefficients(packed)
         assert ctx.info()["lane_per_partition"] == 1
         for log2_parts in (1, 2, 3):
             for w, h in ((320, 240), (176, 48), (64, 16)):

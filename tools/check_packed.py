@@ -104,6 +104,7 @@ def main():
     print("ok lock step", flush=True)
     if "--big" in sys.argv:
         dense = aa.Context(0)
+        dense.set_packed_coefficients(False)
         n += big(ctx, dense, 6, 3)
         print("ok 1080p", flush=True)
     st = ctx.kernel_stats()

@@ -51,6 +51,9 @@ def make_stream(config, frames, seed):
     path = os.path.join(cache_dir(), key + ".ivf")
     if os.path.exists(path):
         return path
+    shipped = os.path.join(ROOT, "gpurun_in", "streams", key + ".ivf")     # (pre-generated here, travels with the snapshot: the pure-Python writer is slow)
+    if os.path.exists(shipped):
+        return shipped
     # several ranks of one node may ask for the same stream at the same time: the first takes a lock file, the others wait
     lock = path + ".lock"
     try:
@@ -111,7 +114,8 @@ def _generate(config, frames, seed, path, lock):
 def make_streams(config, frames, seeds, workers=None):
     workers = workers or min(len(seeds), os.cpu_count() or 1, 64)
     if CONFIGS[config][2] == "synth":       # pure-Python writer: processes, not threads; distinct seeds once each
-        todo = sorted({s for s in seeds if not os.path.exists(os.path.join(cache_dir(), "%s_f%d_s%d.ivf" % (config, frames, s)))})
+        todo = sorted({s for s in seeds if not os.path.exists(os.path.join(cache_dir(), "%s_f%d_s%d.ivf" % (config, frames, s)))
+                       and not os.path.exists(os.path.join(ROOT, "gpurun_in", "streams", "%s_f%d_s%d.ivf" % (config, frames, s)))})
         if todo:
             procs = []
             for s in todo:
