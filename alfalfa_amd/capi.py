@@ -61,7 +61,7 @@ class CtxInfo(C.Structure):
         (n, C.c_uint32) for n in ("heap_is_virtual", "token_lanes_per_workgroup", "token_workgroups_capacity", "token_workgroups_alive",
                                   "token_lane_lds_bytes", "token_workgroup_lds_bytes", "jobs_waiting", "compute_units")] + [
         ("heap_free_chunks", C.c_int32), ("lanes_starved", C.c_uint32), ("token_profile", C.c_uint64 * 8),
-        ("packed_coefficients", C.c_uint32), ("lane_per_partition", C.c_uint32), ("clock_mhz", C.c_uint32), ("reserved0", C.c_uint32)]
+        ("packed_coefficients", C.c_uint32), ("lane_per_partition", C.c_uint32), ("clock_mhz", C.c_uint32), ("host_share_ms", C.c_uint32), ("stream_concurrency", C.c_uint32), ("streams_needed", C.c_uint32)]
 
 
 class AlfalfaError(RuntimeError):
@@ -76,7 +76,7 @@ class AlfalfaError(RuntimeError):
 _P = C.c_void_p
 _U8P = C.POINTER(C.c_uint8)
 SYMBOLS = [
-    ("aa_last_error", C.c_char_p, []), ("aa_abi_version", C.c_int, []), ("aa_device_count", C.c_int, []),
+    ("aa_last_error", C.c_char_p, []), ("aa_abi_version", C.c_int, []), ("aa_runtime_prepare", C.c_int, []), ("aa_device_count", C.c_int, []),
     ("aa_parser_create", C.c_int, [C.c_uint16, C.c_uint16, C.POINTER(_P)]), ("aa_parser_destroy", None, [_P]),
     ("aa_parser_parse", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(FrameHeader), _P, _P]),
     ("aa_parser_get_probs", C.c_int, [_P, _U8P]), ("aa_parser_set_error_concealment", C.c_int, [_P, C.c_int]),
@@ -93,7 +93,7 @@ SYMBOLS = [
     ("aa_stream_export_raster", C.c_int, [_P, C.c_int, _P, _P, _P]),
     ("aa_ctx_create", C.c_int, [C.c_int, C.POINTER(_P)]), ("aa_ctx_destroy", None, [_P]), ("aa_ctx_sync", C.c_int, [_P]),
     ("aa_ctx_memory", C.c_int, [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
-    ("aa_ctx_set_memory_limit", C.c_int, [_P, C.c_size_t]), ("aa_ctx_set_packed_coefficients", C.c_int, [_P, C.c_int]), ("aa_ctx_set_lane_per_partition", C.c_int, [_P, C.c_int]), ("aa_ctx_get_info", C.c_int, [_P, C.POINTER(CtxInfo)]),
+    ("aa_ctx_set_memory_limit", C.c_int, [_P, C.c_size_t]), ("aa_ctx_set_packed_coefficients", C.c_int, [_P, C.c_int]), ("aa_ctx_set_host_share_ms", C.c_int, [_P, C.c_double]), ("aa_ctx_set_lane_per_partition", C.c_int, [_P, C.c_int]), ("aa_ctx_get_info", C.c_int, [_P, C.POINTER(CtxInfo)]),
     ("aa_ctx_set_schedule", C.c_int, [_P, C.c_int]), ("aa_ctx_clear_error", C.c_int, [_P]), ("aa_ctx_compute_stream", _P, [_P]), ("aa_ctx_copy_stream", _P, [_P]),
     ("aa_stream_create", C.c_int, [_P, C.c_uint16, C.c_uint16, C.POINTER(_P)]), ("aa_stream_destroy", None, [_P]),
     ("aa_stream_parse", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(FrameHeader)]),
@@ -149,6 +149,7 @@ def lib():
         for name, restype, argtypes in SYMBOLS:
             fn = getattr(L, name)          # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = restype, argtypes
+        L.aa_runtime_prepare()             # GPU_MAX_HW_QUEUES=16 unless the environment says otherwise: before this process's first HIP call, if it is ours
         _lib = L
     return _lib
 

@@ -116,6 +116,8 @@ int launch_recon_intra4( const aa_frame_list & list, int n_groups, int mbh_max, 
 int launch_loopfilter_rows4( const aa_frame_list & list, int n_groups, int mbh_max, int mbw_max, aa_sync_ws * ws, uint8_t * boundary, int n_xcd, void * stream );
 // out16[x] += number of workgroups (of `blocks`) that ran on XCD x
 int launch_probe_xcds( int * out16, int blocks, void * stream );
+// seen[slot] = how many of the n probe kernels (one per stream) had arrived when this one gave up waiting or all were there
+int launch_probe_concurrency( uint32_t * counter, uint32_t * seen, uint32_t n, unsigned long long timeout_ticks, int slot, void * stream );
 int launch_bind_rasters( const aa_raster_binding * b, int n, void * stream );
 // raster i (jobs[i]) -> staging + i * stride, one launch for the lot
 int launch_gather_rasters( const aa_gather_job * jobs, int n, uint8_t * staging, size_t stride, size_t max_bytes, void * stream );

@@ -1474,6 +1474,20 @@ __global__ void k_probe_xcds( int * out )
   if ( threadIdx.x == 0 ) atomicAdd( &out[xcc_id() & 15], 1 );
 }
 
+// How many of the context's HIP streams really run side by side?  One single-thread kernel per stream: each counts itself in and
+// waits until all n have arrived or `timeout` (100 MHz ticks) has passed, then says how many it saw.  Streams that share a
+// hardware queue run their kernels one after the other, so the kernels of the first round see only as many arrivals as there
+// are queues: the smallest figure is the concurrency (GPU_MAX_HW_QUEUES: 4 by default, this runtime wants 16).
+__global__ void k_probe_concurrency( uint32_t * counter, uint32_t * seen, uint32_t n, unsigned long long timeout, int slot )
+{
+  if ( threadIdx.x || blockIdx.x ) return;
+  __hip_atomic_fetch_add( counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  const unsigned long long t0 = wall_clock64();
+  uint32_t m;
+  while ( ( m = __hip_atomic_load( counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) < n && wall_clock64() - t0 < timeout ) __builtin_amdgcn_s_sleep( 32 );
+  seen[slot] = m;
+}
+
 // After a row-pipelined launch: every queue must have handed out all of its rows.  A queue whose XCD received no workgroup
 // (placement is not promised by HIP) would otherwise leave its units silently unprocessed.
 __global__ void k_check_tickets( aa_sync_ws * ws, const int n_groups, const int mbh_max, const int n_xcd )
@@ -1632,6 +1646,11 @@ int launch_recon_intra4( const aa_frame_list & list, int n_groups, int mbh_max, 
 {
   hipLaunchKernelGGL( k_recon_intra4, dim3( n_xcd * ( ( n_groups + n_xcd - 1 ) / n_xcd ) * mbh_max ), dim3( kLanes ), test_lds_pad(), static_cast<hipStream_t>( stream ), list, n_groups, mbh_max, ws, n_xcd );
   hipLaunchKernelGGL( k_check_tickets, dim3( 1 ), dim3( 64 ), 0, static_cast<hipStream_t>( stream ), ws, n_groups, mbh_max, n_xcd );
+  return static_cast<int>( hipGetLastError() );
+}
+int launch_probe_concurrency( uint32_t * counter, uint32_t * seen, uint32_t n, unsigned long long timeout_ticks, int slot, void * stream )
+{
+  hipLaunchKernelGGL( k_probe_concurrency, dim3( 1 ), dim3( 64 ), 0, static_cast<hipStream_t>( stream ), counter, seen, n, timeout_ticks, slot );
   return static_cast<int>( hipGetLastError() );
 }
 int launch_probe_xcds( int * out16, int blocks, void * stream )

@@ -42,8 +42,11 @@ thread_local std::string g_last_error;
 
 // The entropy-decode kernels are long (a chain per lane, seconds) and must run BESIDE reconstruction and beside each other.
 // HIP spreads streams over few hardware queues by default (4), and commands of one queue run in order: with more streams
-// than queues a decode launch can end up queued behind a parse kernel.  Ask for more queues before the runtime starts.
-struct RuntimeEnv { RuntimeEnv() { setenv( "GPU_MAX_HW_QUEUES", "16", 0 ); } } g_runtime_env;
+// than queues a decode launch can end up queued behind a parse kernel.  The number of queues is read from the environment
+// (GPU_MAX_HW_QUEUES) when the HIP runtime starts.  The library does not touch the host process's environment behind its back:
+// aa_runtime_prepare() -- called by the bindings before their first aa_ctx_create, or by the host program before ITS first HIP
+// call -- sets the variable if it is unset; a context then CHECKS how many of its streams really run side by side
+// (probe_stream_concurrency) and says so (aa_ctx_info::stream_concurrency, a clear error below 8).
 
 aa_status fail( aa_status code, const std::string & msg ) { g_last_error = msg; return code; }
 aa_status hip_fail( hipError_t e, const char * what )
@@ -79,6 +82,8 @@ struct Batch {
   // Two-phase form (AA_SUBMIT_DEFER_TOKENS): the macroblock-header kernel has been queued, the token kernel has not -- the
   // coefficient blocks (9/10 of a frame's records) are only allocated when it is (aa_launch_tokens, or the first call that
   // needs the frame's records).
+  bool host_parsed = false;                  // the frames were parsed by host workers (submit_host_batch): the arena holds their finished records,
+  bool upload_waited = false;                // hdr_done = its upload; the compute stream has been made to wait for it
   bool tokens_pending = false;
   bool patch_jobs = false;                   // the jobs in HBM lack the coefficient pointers (two-phase form)
   size_t head_bytes = 0;                     // parse jobs + reconstruction job records at the start of the arena
@@ -229,7 +234,9 @@ struct aa_ctx {
   // yet, and an event recorded now would sit in FRONT of them on the compute stream.
   int binding_depth = 0;
   bool copy_reads_rasters = false;      // aa_stream_download_async queued copies since the last epoch was closed
+  uint32_t stream_concurrency = 0, streams_needed = 0;    // probe_stream_concurrency (at the first submit)
   bool profile = false;
+  double host_share_ms = 50.0;   // aa_submit_frames: a big call's key frames are parsed by host workers while that is expected to take no longer (0: never)
   int schedule = 0;            // 0: row-pipelined persistent kernels (default), 1: one launch per 2:1 anti-diagonal
   int n_xcd = 1;               // XCDs workgroups land on (probed at creation); row kernels keep a unit on one XCD
   int xcd_share[AA_MAX_XCD] = {};
@@ -478,7 +485,10 @@ aa_status ensure_ws( aa_ctx * ctx, aa_sync_ws ** ws, size_t * have, int max_mbh 
   if ( *ws ) { (void) hipMemcpy( &err, &( *ws )->error, sizeof err, hipMemcpyDeviceToHost ); (void) hipFree( *ws ); }
   *ws = nullptr; *have = 0;
   HIP_TRY( hipMalloc( reinterpret_cast<void **>( ws ), need ) );
-  HIP_TRY( hipMemset( *ws, 0, need ) );
+  // (hipMemset of device memory is not ordered against the context's NON-BLOCKING streams: everything that prepares memory a
+  // kernel on one of them will use is either queued on that stream or followed by a device-wide wait)
+  HIP_TRY( hipMemsetAsync( *ws, 0, need, ctx->compute ) );
+  HIP_TRY( hipStreamSynchronize( ctx->compute ) );
   if ( err ) HIP_TRY( hipMemcpy( &( *ws )->error, &err, sizeof err, hipMemcpyHostToDevice ) );   // the error word is sticky
   *have = need;
   return AA_OK;
@@ -552,6 +562,39 @@ aa_status tok_grow_heap( aa_ctx * ctx, size_t want_mapped )
   return AA_OK;
 }
 
+// One tiny kernel per stream of the context, all waiting for each other (k_probe_concurrency): -> how many ran side by side
+aa_status probe_stream_concurrency( aa_ctx * ctx )
+{
+  auto & T = ctx->tok;
+  std::vector<hipStream_t> all { ctx->compute, ctx->copy, T.util };
+  for ( auto ps : ctx->parse_streams ) all.push_back( ps );
+  for ( auto & sl : T.slot ) all.push_back( sl.st );
+  const uint32_t n = static_cast<uint32_t>( all.size() );
+  uint32_t * d = nullptr;
+  HIP_TRY( hipMalloc( reinterpret_cast<void **>( &d ), sizeof( uint32_t ) * ( n + 1 ) ) );
+  HIP_TRY( hipMemset( d, 0, sizeof( uint32_t ) * ( n + 1 ) ) );
+  HIP_TRY( hipStreamSynchronize( nullptr ) );        // (the memset runs on the null stream and is not ordered against the non-blocking streams the probe runs on)
+  for ( uint32_t i = 0; i < n; i++ )
+    if ( int e = aa::launch_probe_concurrency( d, d + 1, n, 300000ull /* 3 ms */, static_cast<int>( i ), all[i] ) ) { (void) hipFree( d ); return hip_fail( static_cast<hipError_t>( e ), "k_probe_concurrency" ); }
+  for ( auto st : all ) HIP_TRY( hipStreamSynchronize( st ) );
+  std::vector<uint32_t> seen( n + 1 );
+  HIP_TRY( hipMemcpy( seen.data(), d, sizeof( uint32_t ) * ( n + 1 ), hipMemcpyDeviceToHost ) );
+  (void) hipFree( d );
+  uint32_t conc = n;
+  for ( uint32_t i = 0; i < n; i++ ) conc = std::min( conc, seen[1 + i] );
+  ctx->stream_concurrency = conc; ctx->streams_needed = n;
+  if ( conc < n ) {
+    const std::string msg = "alfalfa_amd: only " + std::to_string( conc ) + " of this context's " + std::to_string( n ) + " HIP streams run side by side (hardware queues): "
+                            "set GPU_MAX_HW_QUEUES=16 in the environment before the process initialises HIP (aa_runtime_prepare() does it when called first); "
+                            "long-running entropy-decode grids will otherwise hold up reconstruction kernels that share their queue";
+    const char * allow = std::getenv( "ALFALFA_AMD_ALLOW_FEW_QUEUES" );
+    if ( conc < 8 && !( allow && atoi( allow ) ) ) return fail( AA_ERR_LOGIC, msg + " (ALFALFA_AMD_ALLOW_FEW_QUEUES=1 to run anyway)" );
+    static std::atomic<bool> said { false };
+    if ( !said.exchange( true ) ) std::fprintf( stderr, "%s\n", msg.c_str() );
+  }
+  return AA_OK;
+}
+
 aa_status tok_init( aa_ctx * ctx )
 {
   auto & T = ctx->tok;
@@ -561,6 +604,7 @@ aa_status tok_init( aa_ctx * ctx )
   T.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
   HIP_TRY( hipStreamCreateWithFlags( &T.util, hipStreamNonBlocking ) );
   for ( auto & sl : T.slot ) HIP_TRY( hipStreamCreateWithPriority( &sl.st, hipStreamNonBlocking, ctx->prio_low ) );
+  if ( aa_status st = probe_stream_concurrency( ctx ) ) return st;
   // the job queue
   HIP_TRY( hipMalloc( reinterpret_cast<void **>( &T.q ), 256 ) );
   { aa::TokQueue hq {}; hq.mask = T.q_slots - 1; HIP_TRY( hipMemcpy( T.q, &hq, sizeof hq, hipMemcpyHostToDevice ) ); }
@@ -609,6 +653,7 @@ aa_status tok_init( aa_ctx * ctx )
   HIP_TRY( hipMemset( pr, 0, 256 + size_t( entries ) * 4 ) );
   T.pool = reinterpret_cast<aa::CoeffPool *>( pr ); T.ring = reinterpret_cast<uint32_t *>( pr + 256 );
   { aa::CoeffPool hp {}; hp.mask = entries - 1; HIP_TRY( hipMemcpy( T.pool, &hp, sizeof hp, hipMemcpyHostToDevice ) ); }
+  HIP_TRY( hipStreamSynchronize( nullptr ) );          // (every memset above -- null stream -- has landed before a kernel on a non-blocking stream looks)
   if ( !T.vmm ) {
     if ( int e = aa::launch_pool_push_range( heap_of( ctx ), 0, static_cast<uint32_t>( T.heap_va / kChunkBytesHeap ), T.util ) ) return hip_fail( static_cast<hipError_t>( e ), "k_pool_push_range" );
     T.heap_mapped = T.heap_va;
@@ -950,6 +995,13 @@ aa_status segmap_to_host( aa_stream * s )
 extern "C" {
 
 const char * aa_last_error( void ) { return g_last_error.c_str(); }
+int aa_runtime_prepare( void )
+{
+  // (overwrite = 0: a value the host program or its user chose stands)
+  const bool was_set = std::getenv( "GPU_MAX_HW_QUEUES" ) != nullptr;
+  setenv( "GPU_MAX_HW_QUEUES", "16", 0 );
+  return was_set ? 1 : 0;
+}
 int aa_abi_version( void ) { return AA_ABI_VERSION; }
 int aa_device_count( void ) { int n = 0; if ( hipGetDeviceCount( &n ) != hipSuccess ) return 0; return n; }
 
@@ -1102,12 +1154,15 @@ aa_status aa_ctx_create( int device, aa_ctx ** out )
   if ( const char * e = std::getenv( "ALFALFA_AMD_SCHEDULE" ) ) ctx->schedule = std::string( e ) == "diagonal" ? 1 : 0;
   if ( const char * e = std::getenv( "ALFALFA_AMD_PACKED" ) ) ctx->tok.packed = atoi( e ) != 0;
   if ( const char * e = std::getenv( "ALFALFA_AMD_LANE_PER_PARTITION" ) ) ctx->tok.lane_per_partition = atoi( e ) != 0;
+  if ( const char * e = std::getenv( "ALFALFA_AMD_HOST_SHARE_MS" ) ) ctx->host_share_ms = std::max( 0.0, atof( e ) );
   // The row-pipelined kernels keep every unit on one XCD (per-XCD ticket queues indexed by the hardware XCC_ID): find
   // out which XCC ids workgroups of this device really land on.  They must be 0..n-1, each reached by a modest grid.
   {
     int * d = nullptr; int h[AA_MAX_XCD] = {};
     HIP_TRY( hipMalloc( reinterpret_cast<void **>( &d ), sizeof h ) );
-    HIP_TRY( hipMemset( d, 0, sizeof h ) );
+    // (on the probe's own stream: a plain hipMemset is not ordered against a non-blocking stream, and under load -- other contexts'
+    // worker grids resident -- it was seen to land AFTER the probe kernel: "XCD probe kernel did not run")
+    HIP_TRY( hipMemsetAsync( d, 0, sizeof h, ctx->compute ) );
     const int e2 = aa::launch_probe_xcds( d, 2048, ctx->compute );
     if ( e2 ) { (void) hipFree( d ); return hip_fail( static_cast<hipError_t>( e2 ), "k_probe_xcds" ); }
     HIP_TRY( hipStreamSynchronize( ctx->compute ) );
@@ -1236,6 +1291,8 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
   out->token_lanes_per_workgroup = static_cast<uint32_t>( T.lanes ); out->token_workgroups_capacity = static_cast<uint32_t>( T.cap_wgs );
   out->token_lane_lds_bytes = T.lane_bytes; out->token_workgroup_lds_bytes = T.lds;
   out->compute_units = static_cast<uint32_t>( T.n_cus );
+  out->host_share_ms = static_cast<uint32_t>( ctx->host_share_ms + 0.5 );
+  out->stream_concurrency = ctx->stream_concurrency; out->streams_needed = ctx->streams_needed;
   { int khz = 0; if ( hipDeviceGetAttribute( &khz, hipDeviceAttributeClockRate, ctx->device ) == hipSuccess ) out->clock_mhz = static_cast<uint32_t>( khz / 1000 ); else (void) hipGetLastError(); }
   if ( T.ready ) {
     if ( aa_status st = tok_refresh_mirror( ctx ) ) return st;
@@ -1256,6 +1313,12 @@ aa_status aa_ctx_set_lane_per_partition( aa_ctx * ctx, int on )
   ctx->tok.lane_per_partition = on != 0;
   return AA_OK;
 }
+aa_status aa_ctx_set_host_share_ms( aa_ctx * ctx, double ms )
+{
+  if ( !ctx || !( ms >= 0 ) ) return fail( AA_ERR_ARGUMENT, "aa_ctx_set_host_share_ms: bad argument" );
+  ctx->host_share_ms = ms;
+  return AA_OK;
+}
 aa_status aa_ctx_set_packed_coefficients( aa_ctx * ctx, int on )
 {
   if ( !ctx ) return fail( AA_ERR_ARGUMENT, "null context" );
@@ -1270,7 +1333,7 @@ aa_status aa_ctx_clear_error( aa_ctx * ctx )
   if ( !ctx ) return fail( AA_ERR_ARGUMENT, "null ctx" );
   if ( aa_status st = set_device( ctx ) ) return st;
   HIP_TRY( hipStreamSynchronize( ctx->compute ) );
-  if ( ctx->ws ) HIP_TRY( hipMemset( ctx->ws, 0, AA_SYNC_WS_ZERO_FROM ) );
+  if ( ctx->ws ) { HIP_TRY( hipMemsetAsync( ctx->ws, 0, AA_SYNC_WS_ZERO_FROM, ctx->compute ) ); HIP_TRY( hipStreamSynchronize( ctx->compute ) ); }
   return AA_OK;
 }
 aa_status aa_ctx_set_schedule( aa_ctx * ctx, int schedule )
@@ -1620,6 +1683,119 @@ aa_status launch_tokens_of( aa_ctx * ctx, Batch * b )
 }
 } // namespace
 
+namespace {
+// Frames of a big call that are parsed on the HOST (the call's key frames: their chains are the long ones -- 2.4 s on a lane, 20 ms
+// on a core -- and a group cannot be reconstructed before its key frame is parsed).  Unlike aa_stream_parse, which stages a
+// frame in its stream's own chunk (64 MB of pinned + device memory per stream: fine for a player, not for 480 decoders that live
+// for one group of pictures), the frames of the call share ONE arena: every worker parses into a private, lazily committed
+// worst-case buffer (Parser::parse: the records aa_parser_parse produces), then the used parts are packed into a pinned arena of
+// exactly their size, mirrored by one device piece, uploaded by one copy on the copy stream.  frames[idx[k]], k < n_sel, in
+// stream order per stream.
+aa_status submit_host_batch( aa_ctx * ctx, const aa_frame_in * frames, const std::vector<int> & idx, std::vector<SubmitItem> & items, int threads )
+{
+  struct Tmp { std::unique_ptr<uint8_t[]> buf; size_t used = 0, mb_bytes = 0, rows_bytes = 0; aa_frame_header hdr; bool has_split = false; std::vector<uint8_t> diag; size_t off = 0; };
+  const int n = static_cast<int>( idx.size() );
+  std::vector<Tmp> tmp( n );
+  std::map<aa_stream *, std::vector<int>> by_stream;      // -> positions in idx
+  std::vector<aa_stream *> order;
+  for ( int k = 0; k < n; k++ ) {
+    auto & v = by_stream[frames[idx[k]].stream];
+    if ( v.empty() ) order.push_back( frames[idx[k]].stream );
+    v.push_back( k );
+  }
+  const size_t job_bytes = align_up( sizeof( aa_dev_frame ) );
+  std::atomic<size_t> next { 0 };
+  auto work = [&]() {
+    (void) hipSetDevice( ctx->device );
+    for ( ;; ) {
+      const size_t w = next.fetch_add( 1 );
+      if ( w >= order.size() ) return;
+      aa_stream * s = order[w];
+      bool broken = segmap_to_host( s ) != AA_OK;
+      for ( int k : by_stream[s] ) {
+        SubmitItem & it = items[idx[k]];
+        if ( broken ) { it.status = AA_ERR_LOGIC; it.error = "an earlier frame of this stream in the same call failed"; continue; }
+        Tmp & t = tmp[k];
+        const size_t nmb = size_t( s->parser.mb_width() ) * s->parser.mb_height();
+        const size_t words_per_row = ( s->parser.mb_width() + 63 ) / 64;
+        t.mb_bytes = align_up( nmb * sizeof( aa_mb_info ) );
+        t.rows_bytes = align_up( words_per_row * s->parser.mb_height() * sizeof( unsigned long long ) );
+        const size_t head = job_bytes + t.mb_bytes + t.rows_bytes;
+        t.buf.reset( new ( std::nothrow ) uint8_t[head + nmb * 25 * 32 + kAlign] );      // (pages are committed as they are written)
+        if ( !t.buf ) { it.status = AA_ERR_ARGUMENT; it.error = "out of memory"; broken = true; continue; }
+        aa_mb_info * mbs = reinterpret_cast<aa_mb_info *>( t.buf.get() + job_bytes );
+        unsigned long long * intra_rows = reinterpret_cast<unsigned long long *>( t.buf.get() + job_bytes + t.mb_bytes );
+        int16_t * coeffs = reinterpret_cast<int16_t *>( t.buf.get() + head );
+        try { s->parser.parse( it.data, it.size, t.hdr, mbs, coeffs ); }
+        catch ( const aa::ParseError & e ) { it.status = e.code; it.error = e.message; t.buf.reset(); broken = true; continue; }
+        const aa_frame_header & h = t.hdr;
+        const int mbw = h.mb_width, mbh = h.mb_height;
+        t.diag.assign( mbw + 2 * ( mbh - 1 ), 0 );
+        std::memset( intra_rows, 0, words_per_row * mbh * sizeof( unsigned long long ) );
+        if ( h.has_intra_mb )
+          for ( int r = 0; r < mbh; r++ ) for ( int col = 0; col < mbw; col++ )
+            if ( !( mbs[r * mbw + col].flags & AA_MB_INTER ) ) { t.diag[col + 2 * r] = 1; intra_rows[r * words_per_row + ( col >> 6 )] |= 1ull << ( col & 63 ); }
+        if ( !h.key_frame ) for ( size_t i = 0; i < nmb; i++ ) if ( mbs[i].y_mode == 9 /* SPLITMV */ ) { t.has_split = true; break; }
+        t.used = head + align_up( size_t( h.num_coeff_blocks ) * 32 );
+        it.status = AA_OK;
+      }
+    }
+  };
+  {
+    const int nt = std::max( 1, std::min<int>( { threads, static_cast<int>( order.size() ), 256 } ) );
+    if ( nt == 1 ) work();
+    else { std::vector<std::thread> pool; for ( int t = 0; t < nt; t++ ) pool.emplace_back( work ); for ( auto & t : pool ) t.join(); }
+  }
+  size_t total = 0; int ok = 0;
+  for ( int k = 0; k < n; k++ ) if ( tmp[k].buf ) { tmp[k].off = total; total += tmp[k].used; ok++; }
+  if ( !ok ) return AA_OK;                                  // (every frame failed: the items say why)
+  std::unique_ptr<Batch> b( new Batch );
+  b->host = pinned_get( ctx, total, &b->host_bytes );
+  if ( !b->host ) return fail( AA_ERR_HIP, "aa_submit_frames: pinned staging allocation failed" );
+  b->dev_bytes = total;
+  if ( aa_status st = dev_alloc( ctx, total, &b->dev ) ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); return st; }
+  {
+    // pack: every worker copies whole frames (a frame is a few MB)
+    std::atomic<int> nk { 0 };
+    auto copy = [&]() { for ( ;; ) { const int k = nk.fetch_add( 1 ); if ( k >= n ) return; if ( tmp[k].buf ) { std::memcpy( b->host + tmp[k].off, tmp[k].buf.get(), tmp[k].used ); tmp[k].buf.reset(); } } };
+    const int nt = std::max( 1, std::min<int>( { threads, n, 64 } ) );
+    if ( nt == 1 ) copy();
+    else { std::vector<std::thread> pool; for ( int t = 0; t < nt; t++ ) pool.emplace_back( copy ); for ( auto & t : pool ) t.join(); }
+  }
+  b->n = n; b->live = ok; b->host_parsed = true;
+  b->items.resize( n );
+  for ( aa_stream * s : order )
+    for ( int k : by_stream[s] ) {
+      SubmitItem & it = items[idx[k]];
+      b->items[k] = { s, -1, false };
+      if ( it.status != AA_OK ) continue;
+      Tmp & t = tmp[k];
+      FrameRec rec;
+      rec.hdr = t.hdr; rec.has_split = t.has_split; rec.intra_diagonals = std::move( t.diag );
+      aa_dev_frame * job = reinterpret_cast<aa_dev_frame *>( b->host + t.off );
+      fill_job( rec, job );
+      job->mbs = reinterpret_cast<const aa_mb_info *>( b->dev + t.off + job_bytes );
+      job->intra_rows = reinterpret_cast<const unsigned long long *>( b->dev + t.off + job_bytes + t.mb_bytes );
+      job->coeffs = reinterpret_cast<const int16_t *>( b->dev + t.off + job_bytes + t.mb_bytes + t.rows_bytes );
+      rec.host_job = job;
+      rec.dev_job = reinterpret_cast<const aa_dev_frame *>( b->dev + t.off );
+      rec.batch = b.get(); rec.batch_item = k;
+      it.frame_index = static_cast<int>( s->frames.size() );
+      b->items[k] = { s, it.frame_index, true };
+      s->frames.push_back( std::move( rec ) );
+    }
+  Batch * raw = b.release();
+  // (from here on the frames point at the batch: a failure gives them back one by one)
+  auto abandon = [&]() { const std::string keep = g_last_error; std::vector<Batch::Item> its = raw->items; for ( auto & it : its ) if ( it.live ) release_records( it.s, it.s->frames[it.frame], true ); g_last_error = keep; };
+  if ( hipError_t e = hipEventCreateWithFlags( &raw->hdr_done, hipEventDisableTiming ) ) { abandon(); return hip_fail( e, "hipEventCreate" ); }
+  hipError_t e = hipMemcpyAsync( raw->dev, raw->host, total, hipMemcpyHostToDevice, ctx->copy );
+  if ( e == hipSuccess ) e = hipEventRecord( raw->hdr_done, ctx->copy );
+  if ( e != hipSuccess ) { abandon(); return hip_fail( e, "upload of host-parsed frames" ); }
+  ctx->stats.host_routed_frames += static_cast<uint64_t>( ok );
+  return AA_OK;
+}
+} // namespace
+
 aa_status aa_launch_tokens( aa_ctx * ctx, int max_batches, int * launched_out )
 {
   if ( !ctx ) return fail( AA_ERR_ARGUMENT, "aa_launch_tokens: null context" );
@@ -1709,6 +1885,48 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
         if ( items[i].status != AA_OK && first_error == AA_OK ) { first_error = items[i].status; first_message = items[i].error; }
       }
       return first_error == AA_OK ? AA_OK : fail( first_error, first_message );
+    }
+    // ---- hybrid: a big call's KEY frames on the host's cores, the rest on the lanes ----
+    // A key frame's chain is the longest there is (2.4 s on a lane at 1080p, ~20 ms on a core) and nothing of its group can be
+    // reconstructed before it is parsed; a call's key frames are few (one per stream and group of pictures).  Streams whose
+    // frames in this call are all key frames go to host workers (submit_host_batch: one shared arena, one upload), biggest
+    // first, while the host part is expected to take no longer than `host_share_ms` on `nt` workers (a core parses ~24 MB of
+    // compressed key-frame data per second); everything else takes the device route below.
+    if ( !defer_tokens && !force_device && ctx->host_share_ms > 0 ) {
+      std::vector<std::pair<size_t, aa_stream *>> cand;
+      for ( aa_stream * s : stream_order ) {
+        size_t bytes = 0; bool all_key = true;
+        for ( int i : by_stream[s] ) { all_key = all_key && frames[i].size >= 10 && ( frames[i].data[0] & 1u ) == 0u; bytes += frames[i].size; }
+        if ( all_key ) cand.emplace_back( bytes, s );
+      }
+      std::stable_sort( cand.begin(), cand.end(), []( const auto & a, const auto & b ) { return a.first > b.first; } );
+      const double capacity_bytes = ctx->host_share_ms * nt * 24.0e3;
+      std::vector<char> on_host( n, 0 );
+      double taken = 0; int n_host = 0;
+      for ( auto & c : cand ) {
+        if ( taken + static_cast<double>( c.first ) > capacity_bytes ) break;
+        taken += static_cast<double>( c.first );
+        for ( int i : by_stream[c.second] ) { on_host[i] = 1; n_host++; }
+      }
+      if ( n_host ) {
+        std::vector<int> host_idx, dev_idx;
+        for ( int i = 0; i < n; i++ ) ( on_host[i] ? host_idx : dev_idx ).push_back( i );
+        aa_status first_error = AA_OK; std::string first_message;
+        if ( aa_status st = submit_host_batch( ctx, frames, host_idx, items, nt ) ) { first_error = st; first_message = g_last_error; }
+        for ( int i : host_idx ) {
+          if ( frame_index_out ) frame_index_out[i] = items[i].status == AA_OK ? items[i].frame_index : -1;
+          if ( items[i].status != AA_OK && first_error == AA_OK ) { first_error = items[i].status; first_message = items[i].error; }
+        }
+        if ( !dev_idx.empty() ) {
+          std::vector<aa_frame_in> sub( dev_idx.size() );
+          std::vector<int> sub_out( dev_idx.size(), -1 );
+          for ( size_t k = 0; k < dev_idx.size(); k++ ) sub[k] = frames[dev_idx[k]];
+          const aa_status st = aa_submit_frames_ex( ctx, sub.data(), static_cast<int>( sub.size() ), sub_out.data(), threads, flags | AA_SUBMIT_DEVICE );
+          if ( frame_index_out ) for ( size_t k = 0; k < dev_idx.size(); k++ ) frame_index_out[dev_idx[k]] = sub_out[k];
+          if ( st != AA_OK && first_error == AA_OK ) { first_error = st; first_message = g_last_error; }
+        }
+        return first_error == AA_OK ? AA_OK : fail( first_error, first_message );
+      }
     }
   }
 
@@ -1988,7 +2206,7 @@ aa_status aa_stream_read_records( aa_stream * s, int fi, aa_mb_info * mb_out, in
   if ( r.records_released ) return fail( AA_ERR_LOGIC, "aa_stream_read_records: frame records were released" );
   if ( aa_status st = resolve_summary( s, r ) ) return st;
   if ( aa_status st = aa_stream_upload( s ) ) return st;
-  HIP_TRY( hipStreamSynchronize( s->ctx->copy ) );
+  HIP_TRY( hipStreamSynchronize( s->ctx->copy ) );        // (also covers the arena of a host-parsed submit call: same stream)
   aa_dev_frame job;
   HIP_TRY( hipMemcpy( &job, r.dev_job, sizeof job, hipMemcpyDeviceToHost ) );
   if ( coeff_out && coeff_capacity_blocks < r.hdr.num_coeff_blocks ) return fail( AA_ERR_ARGUMENT, "aa_stream_read_records: coefficient buffer too small" );
@@ -2158,6 +2376,10 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
     if ( fi != s->next_submit ) return fail( AA_ERR_LOGIC, "aa_decode_batch: frames of a stream must be submitted in order" );
   }
   for ( int i = 0; i < n; i++ ) if ( aa_status st = aa_stream_upload( streams[i] ) ) return st;
+  for ( int i = 0; i < n; i++ ) {            // frames parsed by host workers of a submit call: their arena's upload (copy stream) comes first
+    Batch * hb = streams[i]->frames[frame_index[i]].batch;
+    if ( hb && hb->host_parsed && !hb->upload_waited ) { HIP_TRY( hipStreamWaitEvent( ctx->compute, hb->hdr_done, 0 ) ); hb->upload_waited = true; }
+  }
   // coefficient chunks of the frames released since the last call go back to the pool (behind the kernels that read them:
   // those were queued before the release)
   // ... and what was released since then gets its epoch now: reusable as soon as the kernels queued before this call have run

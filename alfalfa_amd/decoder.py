@@ -114,6 +114,10 @@ class Context:
         """HBM the context may take for its pools (default: 7/8 of what was free at creation)."""
         capi.check(self.L.aa_ctx_set_memory_limit(self.h, int(nbytes)))
 
+    def set_host_share_ms(self, ms):
+        """Key frames of big submit calls are parsed by host workers while that is expected to take no longer than `ms` (0: never)."""
+        capi.check(self.L.aa_ctx_set_host_share_ms(self.h, float(ms)))
+
     def set_packed_coefficients(self, on=True):
         """Device-parsed frames store packed coefficients (mask word + non-zero values per block; expanded on the device when
         a frame is reconstructed) instead of dense blocks.  Before the context's first submit_frames only."""

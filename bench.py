@@ -92,6 +92,10 @@ def parse_args():
     ap.add_argument("--deliver", action="store_true", help="every reconstructed frame is also DELIVERED: copied to pinned host memory (aa_download_batch_async: one "
                     "gather + one copy per frame index) while the next frames are decoded -- what vp8decode / xc-decode-bundle do with every shown frame; "
                     "the timed region then includes PCIe")
+    ap.add_argument("--host-share-ms", type=float, default=None, help="aa_ctx_set_host_share_ms: key frames of a hand-over are parsed by host workers while that is "
+                    "expected to take no longer than this on the rank's host threads (library default 50; 0: every frame on the GPU's token lanes)")
+    ap.add_argument("--lanes-only-steps", type=int, default=8, help="after the main run: this many steps with host_share_ms = 0 (every frame, key frames too, "
+                    "parsed by GPU lanes), reported as all_frames_on_gpu_lanes (0 = skip)")
     ap.add_argument("--trace-memory", action="store_true", help="print the context's memory books after every step of the timed region (stderr)")
     ap.add_argument("--small-batches", default="1,8,64", help="stream counts for the small-batch end-to-end figures ('' = skip)")
     ap.add_argument("--secondary", default="720p_intra,720p_inter,1080p_inter_lf_subpel",
@@ -121,6 +125,10 @@ class Pipeline:
         self.H = max(0, header_ahead)
         self.inter_h = 0
         self.K, self.D = max(1, key_ahead), max(1, min(depth, key_ahead))
+        if env.get("keys_on_host"):
+            # key frames are parsed by host workers inside the hand-over call (milliseconds, not a 2.4-s chain on a lane): nothing
+            # is gained by handing them over earlier than the inter frames that follow them
+            self.K = self.D
         self.groups = {}                                # g -> [Decoder]
         self.kept = {}                                  # g -> [Decoder] whose frames were not released (the step that is verified)
         self.keep_group = None                          # group whose distinct decoders keep every frame (verification of a TIMED step)
@@ -215,11 +223,15 @@ class Pipeline:
             return True
         env = self.env
         i = self.ctx.info()
-        pool_live = i["pool_bytes"] - i["pool_free_bytes"]
+        limit, oc = i["memory_limit_bytes"], env["args"].overcommit
+        # the pool never gives memory back to the device and the heap never unmaps: what the HEAP can still get is what the pool has
+        # not taken (pool_bytes, free lists included), what the POOL can still get is what the heap has not mapped
         heap_after = i["heap_used_bytes"] + coeff_bytes
-        heap_cap = i["heap_limit_bytes"] or i["memory_limit_bytes"]
-        ok = (heap_after <= env["args"].overcommit * heap_cap and
-              pool_live + arena_bytes + env["recon_reserve"] + heap_after / env["args"].overcommit <= i["memory_limit_bytes"])
+        heap_cap = min(i["heap_limit_bytes"] or limit, limit - i["pool_bytes"])
+        pool_live = i["pool_bytes"] - i["pool_free_bytes"]
+        pool_after = pool_live + arena_bytes + env["recon_reserve"]
+        pool_cap = limit - max(i["heap_mapped_bytes"], heap_after / oc)
+        ok = heap_after <= oc * heap_cap and pool_after <= pool_cap
         if not ok:
             self.refused += 1
         return ok
@@ -242,7 +254,11 @@ class Pipeline:
                     if self.H == 0:
                         self.inters += 1
                 elif can_key:
-                    if not self._room(self.n, self.n * env["key_coeff_bytes"], self.n * env["key_arena_bytes"]):
+                    if env.get("keys_on_host"):      # (dense records in a pool piece, nothing in the coefficient heap)
+                        fits = self._room(self.n, 0, self.n * (env["key_arena_bytes"] + env["key_dense_bytes"]))
+                    else:
+                        fits = self._room(self.n, self.n * env["key_coeff_bytes"], self.n * env["key_arena_bytes"])
+                    if not fits:
                         break
                     self._submit_keys(self.keys); self.keys += 1
                 elif self.H > 0 and self.inters < min(target, self.decoded + self.D, self.inter_h):
@@ -252,6 +268,14 @@ class Pipeline:
                 else:
                     break
             self.decode()
+
+
+T_START = time.time()
+
+
+def log(msg):
+    """Progress on stderr (a run that is cut off by a timeout still says how far it got)."""
+    print("[bench %7.1f s] %s" % (time.time() - T_START, msg), file=sys.stderr, flush=True)
 
 
 def calibrate(env, streams):
@@ -294,6 +318,10 @@ def calibrate(env, streams):
     rec = mbs_per_frame * (80 + 1 + (4 if packed else 0)) + 8192
     env["key_coeff_bytes"], env["inter_coeff_bytes"] = int(key_blocks * key_bpb + 65536), int(inter_blocks * inter_bpb + 65536)
     env["key_arena_bytes"], env["inter_arena_bytes"] = int(rec + 1.1 * comp), int(rec + 1.1 * comp)
+    env["key_dense_bytes"] = key_blocks * 32
+    # does a hand-over of S key frames fit the host share?  (aa_submit_frames: ~24 MB of compressed key-frame data per second and core)
+    hs = ctx.info()["host_share_ms"]
+    env["keys_on_host"] = bool(hs > 0 and S > min(threads, 24) and sum(len(st[0]) for st in streams) <= hs * threads * 24.0e3)
     env["packed_storage"] = {"key_frame_bytes_per_block": round(key_bpb, 2), "inter_frame_bytes_per_block": round(inter_bpb, 2), "dense_bytes_per_block": 32} if packed else None
     env["planned"] = {"key_frame_heap_bytes": env["key_coeff_bytes"], "inter_frame_heap_bytes": env["inter_coeff_bytes"], "frame_pool_bytes": env["key_arena_bytes"],
                       "key_blocks_per_mb": round(key_blocks / mbs_per_frame, 2), "inter_blocks_per_mb": round(inter_blocks / mbs_per_frame, 2)}
@@ -444,6 +472,8 @@ def main():
     ctx.set_memory_limit(int(hbm_budget))
     if args.dense:
         ctx.set_packed_coefficients(False)
+    if args.host_share_ms is not None:
+        ctx.set_host_share_ms(args.host_share_ms)
     env = make_env(args, ctx, args.config, S, F, rank, world, threads)
     width, height, streams, paths, seeds = env["width"], env["height"], env["streams"], env["paths"], env["seeds"]
     mbs_per_frame, mbs_per_step, compressed_bytes = env["mbs_per_frame"], env["mbs_per_step"], env["compressed_bytes"]
@@ -500,7 +530,9 @@ def main():
             raise SystemExit("entry-state hand-off mismatch across ranks")
 
     # ---- the end-to-end pipeline ----
+    log("streams ready (%d distinct, generated in %.1f s)" % (len(env["distinct"]), t_gen))
     calibrate(env, streams)
+    log("calibrated: lone key frame %.3f s, step %.4f us, keys on host: %s, planned %s" % (env["lone_key_s"], env["step_latency_us"], env["keys_on_host"], env["planned"]))
     step_latency_us = env["step_latency_us"]
     plane_sizes, raster_bytes = env["plane_sizes"], env["raster_bytes"]
     if args.deliver:
@@ -510,9 +542,11 @@ def main():
     planned_need_gb = round(S * ((0.5 * K + 1.5) * (env["key_coeff_bytes"] + env["key_arena_bytes"]) + (0.6 * D + 1.0) * (F - 1) * (env["inter_coeff_bytes"] + env["inter_arena_bytes"])
                                  + 5 * raster_bytes) / 1e9, 1)
     pipe = Pipeline(env, streams, K, D, args.header_ahead)
+    log("priming")
     pipe.run(max(2, pipe.K // 2))       # priming (untimed, before the warm-up): the pools and the coefficient heap reach their working
     pipe.run(args.warmup)               # size, so that first-touch allocations (hipMalloc / hipMemMap / hipHostMalloc) are not what the steps measure
     barrier()
+    log("warm-up done; timed region starts")
     pipe.host_s = pipe.t_launch = pipe.t_decode = pipe.t_release = 0.0; pipe.done_t = []; pipe.refused = 0
     pipe.keep_group = pipe.decoded + args.steps - 1          # the last TIMED step keeps the frames of its distinct streams: they are what is verified
     ctx.kernel_stats(reset=True)
@@ -524,6 +558,7 @@ def main():
     pipe.run(args.steps)
     ctx.sync()
     elapsed = time.perf_counter() - t0
+    log("timed region: %.3f s for %d steps, steps done at %s ms, hand-overs put off %d" % (elapsed, args.steps, [round((t - t0) * 1e3) for t in pipe.done_t], pipe.refused))
     delivery = None
     if args.deliver:
         delivery = {"bytes_per_step": (pipe.delivered_bytes - delivered0) // args.steps, "gb_per_s": round((pipe.delivered_bytes - delivered0) / elapsed / 1e9, 2),
@@ -598,6 +633,7 @@ def main():
             verified["what"] = "rasters written by the last step of the timed region"
     del kept
 
+    log("verified: %s" % (verified,))
     # ---- per-kernel timing of one more (un-pipelined) step: HIP events on the streams the kernels run on ----
     ctx.profile(True); ctx.kernel_stats(reset=True)
     g = pipe.decoded
@@ -700,6 +736,7 @@ def main():
     mbs_whole_run = (pipe.frames_submitted + min(4, S) * F) * mbs_per_frame       # (+ the calibration frames)
     del pipe, verify_decs
 
+    log("profile step and device half done")
     # ---- small batches: the reference's actual callers (one stream, one 8-chunk ExCamera bundle), end to end ----
     small = {}
     if rank == 0 and args.small_batches:
@@ -734,6 +771,7 @@ def main():
                                                "note": "aa_stream_decode: serial BoolDecoder on one host core, frame by frame (Decoder::get_frame_output)"})
             del p, d1
 
+    log("small batches done: %s" % ({k: v.get("mb_per_s") for k, v in small.items()},))
     # ---- the other BASELINE configs, end to end, parity checked in the run ----
     secondary = {}
     if args.secondary:
@@ -744,6 +782,27 @@ def main():
                 raise
             except Exception as e:                      # (a secondary figure that cannot be had must not take the headline down with it)
                 secondary[cfg_name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            log("secondary %s: %s" % (cfg_name, {k: secondary[cfg_name].get(k) for k in ("value", "ms_per_step", "error")}))
+
+    # ---- every frame on the GPU's token lanes (host_share_ms = 0): the same workload, key frames `--key-ahead` steps ahead ----
+    lanes_only = None
+    if args.lanes_only_steps > 0 and env.get("keys_on_host"):
+        share = ctx.info()["host_share_ms"]
+        ctx.set_host_share_ms(0)
+        env2 = dict(env); env2["keys_on_host"] = False; env2["deliver_ring"] = None
+        p = Pipeline(env2, streams, K, D, args.header_ahead)
+        ctx.sync(); ctx.kernel_stats(reset=True)
+        t0 = time.perf_counter()
+        p.run(args.lanes_only_steps); ctx.sync()
+        dt = time.perf_counter() - t0
+        st2 = ctx.kernel_stats(reset=True)
+        lanes_only = {"value": round(world * mbs_per_step * args.lanes_only_steps / dt, 1), "unit": "macroblocks/s", "steps": args.lanes_only_steps, "ms_per_step": round(dt / args.lanes_only_steps * 1e3, 2),
+                      "first_step_done_at_ms": round((p.done_t[0] - t0) * 1e3), "frames_parsed_on_host_cores": st2["host_routed_frames"],
+                      "note": "empty pipeline to empty pipeline like `value` (fewer steps: the fill weighs more); this rank only"}
+        if len(p.done_t) > 1:
+            lanes_only["between_fill_and_drain_value"] = round(world * mbs_per_step * (len(p.done_t) - 1) / (p.done_t[-1] - p.done_t[0]), 1)
+        ctx.set_host_share_ms(share)
+        del p
 
     # ---- host parser (the product's C++ BoolDecoder path used for single streams): rate per core ----
     pp = aa.Parser(width, height)
@@ -807,7 +866,11 @@ def main():
             "stages": {"host_prepass_and_staging_s_per_step": round(host_submit_s, 4),
                        "entropy_decode_alone_s_per_step": round(t_parse_alone, 4),
                        "note": "entropy_decode_alone = one step's submit -> parse finished with nothing else on the GPU (a latency: the longest chain, a key frame)"},
-            "timed_region": timed_region, "per_rank": per_rank, "small_batches": small, "secondary": secondary,
+            "timed_region": timed_region, "per_rank": per_rank, "small_batches": small, "secondary": secondary, "all_frames_on_gpu_lanes": lanes_only,
+            "host_share": {"host_share_ms": info["host_share_ms"], "key_frames_parsed_by_host_workers": bool(env.get("keys_on_host")), "host_threads": threads,
+                           "note": "aa_submit_frames parses a hand-over's KEY frames on host cores when that fits host_share_ms on the rank's threads (one per stream and group "
+                                   "of pictures: the long chains); inter frames -- 11 of 12 frames, ~80 % of the bools -- are always decoded by GPU lanes. "
+                                   "all_frames_on_gpu_lanes is the same workload with host_share_ms = 0"},
             "host": {"parser_mb_per_s_per_core": round(parser_only, 1), "stream_generation_s": round(t_gen, 1)},
             "kernel_stats": kstats, "verified_bit_exact_vs_reference": verified, "verified_profile_step": verified_profile_step, "entry_state_handoff": handoff,
         }

@@ -43,6 +43,12 @@ typedef enum aa_status {
 /* Message of the last failing call on this thread ("" if none). */
 const char * aa_last_error( void );
 int aa_abi_version( void );
+/* The HIP runtime reads GPU_MAX_HW_QUEUES when it starts; this library runs 15 HIP streams side by side (long-lived entropy-decode
+ * grids beside short reconstruction kernels) and wants 16 hardware queues (the default is 4).  Call this before the process makes
+ * its first HIP call -- the bindings call it before their first aa_ctx_create -- to set the variable if the environment does not
+ * (a value that is set stands).  -> 1 if it was set already, 0 if this call set it.  Nothing else of the host process is touched;
+ * a context checks what it really got (aa_ctx_info::stream_concurrency). */
+int aa_runtime_prepare( void );
 /* Number of visible HIP devices (0 when there is none; never fails). */
 int aa_device_count( void );
 
@@ -191,7 +197,9 @@ typedef struct aa_ctx_info {
   uint32_t packed_coefficients;      /* 1: device-parsed frames store packed coefficients (aa_ctx_set_packed_coefficients) */
   uint32_t lane_per_partition;       /* 1: frames with several DCT partitions may get a token lane per partition (aa_ctx_set_lane_per_partition) */
   uint32_t clock_mhz;                /* the device's shader clock (hipDeviceAttributeClockRate) */
-  uint32_t reserved0;
+  uint32_t host_share_ms;            /* aa_ctx_set_host_share_ms */
+  uint32_t stream_concurrency;       /* how many of the context's HIP streams were seen running side by side (probed at the first aa_submit_frames; 0: not yet) */
+  uint32_t streams_needed;           /* ... of how many (15): fewer means GPU_MAX_HW_QUEUES was not in effect, see aa_runtime_prepare */
 } aa_ctx_info;
 aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out );
 /* How the device parser stores a frame's coefficients until the frame is reconstructed.  1 (default): packed -- one mask word +
@@ -201,6 +209,13 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out );
  * the context's first aa_submit_frames call (AA_ERR_LOGIC afterwards); the environment variable ALFALFA_AMD_PACKED=0 makes
  * dense the default of every context. */
 aa_status aa_ctx_set_packed_coefficients( aa_ctx * ctx, int on );
+/* Key frames of big calls on the host's cores.  aa_submit_frames hands a call with many streams to the GPU's token lanes; a KEY
+ * frame's chain is the longest there is (seconds on a lane, ~20 ms on a core) and its group cannot be reconstructed before it
+ * is parsed, so the streams of such a call whose frames are all key frames are parsed by host workers instead (the same
+ * records, one shared arena, one upload) -- biggest first, while that is expected to take no longer than `ms` milliseconds
+ * on the call's `threads` workers.  Default 50 (environment: ALFALFA_AMD_HOST_SHARE_MS); 0: every frame of a big call goes to
+ * the lanes.  AA_SUBMIT_DEVICE overrides it per call. */
+aa_status aa_ctx_set_host_share_ms( aa_ctx * ctx, double ms );
 /* One token lane per DCT partition.  A frame with 2, 4 or 8 partitions (frame.cc:119-137: macroblock row r is coded in
  * partition r % P) is then decoded by that many lanes of one wave -- rows handed from lane to lane through the above-row
  * flags in LDS --, whenever the wave that draws it has the lanes idle; its entropy-decode latency falls towards 1 / P of the

@@ -282,7 +282,7 @@ class GpuContext
 {
   aa_ctx * ctx_ = nullptr;
 public:
-  explicit GpuContext( const int device ) { check( aa_ctx_create( device, &ctx_ ) ); }
+  explicit GpuContext( const int device ) { aa_runtime_prepare(); check( aa_ctx_create( device, &ctx_ ) ); }
   ~GpuContext() { aa_ctx_destroy( ctx_ ); }
   GpuContext( const GpuContext & ) = delete;
   GpuContext & operator=( const GpuContext & ) = delete;

@@ -46,7 +46,7 @@ def test_lanes_of_one_frame_give_up_together_when_the_pool_runs_dry(monkeypatch)
     import check_lane_per_partition as clp
     import vp8_oracle as vo
     monkeypatch.setenv("ALFALFA_AMD_HEAP_GROW_MB", "2")
-    monkeypatch.setenv("ALFALFA_AMD_HEAP_LIMIT_MB", "8")
+    monkeypatch.setenv("ALFALFA_AMD_HEAP_LIMIT_MB", "4")
     ctx = aa.Context(0)
     ctx.set_lane_per_partition(True)
     w, h = 352, 288
@@ -75,7 +75,7 @@ def test_lanes_of_one_frame_give_up_together_when_the_pool_runs_dry(monkeypatch)
         ctx.sync()
         assert progress, "a whole round of decode calls was refused although decoded frames had been released"
     assert all(n == 2 for n in nxt)
-    assert ctx.info()["heap_mapped_bytes"] <= 8 << 20
+    assert ctx.info()["heap_mapped_bytes"] <= 4 << 20
 
 
 def test_a_four_partition_1080p_key_frame_is_parsed_faster_by_four_lanes():
