@@ -236,7 +236,7 @@ struct aa_ctx {
   bool copy_reads_rasters = false;      // aa_stream_download_async queued copies since the last epoch was closed
   uint32_t stream_concurrency = 0, streams_needed = 0;    // probe_stream_concurrency (at the first submit)
   bool profile = false;
-  double host_share_ms = 50.0;   // aa_submit_frames: a big call's key frames are parsed by host workers while that is expected to take no longer (0: never)
+  double host_share_ms = 80.0;   // aa_submit_frames: a big call's key frames are parsed by host workers while that is expected to take no longer (0: never)
   int schedule = 0;            // 0: row-pipelined persistent kernels (default), 1: one launch per 2:1 anti-diagonal
   int n_xcd = 1;               // XCDs workgroups land on (probed at creation); row kernels keep a unit on one XCD
   int xcd_share[AA_MAX_XCD] = {};
@@ -253,6 +253,8 @@ struct aa_ctx {
                                           // (aa_ctx_create: 7/8 of what was free; aa_ctx_set_memory_limit)
   size_t pinned_bytes = 0;                // pinned host memory the context has taken (arenas, staging chunks, binding buffers)
   std::map<size_t, std::vector<uint8_t *>> dev_free;
+  std::mutex scratch_mu;                  // worst-case sized parse buffers of the host workers of aa_submit_frames (submit_host_batch), kept from call to call
+  std::vector<std::pair<std::unique_ptr<uint8_t[]>, size_t>> host_scratch;
   std::mutex blank_mu;
   std::map<size_t, uint8_t *> blank;    // References( width, height ): one all-zero raster per raster size, shared by every new decoder (never written)
   uint8_t * boundary = nullptr; // loop filter: hand-off lines between macroblock rows (transient within a launch)
@@ -587,8 +589,10 @@ aa_status probe_stream_concurrency( aa_ctx * ctx )
     const std::string msg = "alfalfa_amd: only " + std::to_string( conc ) + " of this context's " + std::to_string( n ) + " HIP streams run side by side (hardware queues): "
                             "set GPU_MAX_HW_QUEUES=16 in the environment before the process initialises HIP (aa_runtime_prepare() does it when called first); "
                             "long-running entropy-decode grids will otherwise hold up reconstruction kernels that share their queue";
-    const char * allow = std::getenv( "ALFALFA_AMD_ALLOW_FEW_QUEUES" );
-    if ( conc < 8 && !( allow && atoi( allow ) ) ) return fail( AA_ERR_LOGIC, msg + " (ALFALFA_AMD_ALLOW_FEW_QUEUES=1 to run anyway)" );
+    // (said, not refused: in a process with several contexts the streams of all of them share the hardware queues, and a probe
+    // kernel that lands behind another context's lingering worker grid also arrives late -- seen in the GPU test session: 7 of 15)
+    const char * strict = std::getenv( "ALFALFA_AMD_REQUIRE_QUEUES" );
+    if ( strict && atoi( strict ) ) return fail( AA_ERR_LOGIC, msg );
     static std::atomic<bool> said { false };
     if ( !said.exchange( true ) ) std::fprintf( stderr, "%s\n", msg.c_str() );
   }
@@ -1278,6 +1282,7 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
   auto & T = ctx->tok;
   {
     std::lock_guard<std::mutex> g( ctx->pool_mu );
+    collect_pending( ctx, false );        // (pieces whose release epoch has fired are free, not pending: a caller that plans by these figures should see that)
     out->memory_limit_bytes = ctx->pool_soft_limit; out->pool_bytes = ctx->pool_bytes; out->pinned_host_bytes = ctx->pinned_bytes;
     for ( auto & kv : ctx->dev_free ) out->pool_free_bytes += kv.first * kv.second.size();
     for ( auto & pf : ctx->pending_free ) out->pool_pending_bytes += pf.bytes;
@@ -1687,13 +1692,19 @@ namespace {
 // Frames of a big call that are parsed on the HOST (the call's key frames: their chains are the long ones -- 2.4 s on a lane, 20 ms
 // on a core -- and a group cannot be reconstructed before its key frame is parsed).  Unlike aa_stream_parse, which stages a
 // frame in its stream's own chunk (64 MB of pinned + device memory per stream: fine for a player, not for 480 decoders that live
-// for one group of pictures), the frames of the call share ONE arena: every worker parses into a private, lazily committed
-// worst-case buffer (Parser::parse: the records aa_parser_parse produces), then the used parts are packed into a pinned arena of
-// exactly their size, mirrored by one device piece, uploaded by one copy on the copy stream.  frames[idx[k]], k < n_sel, in
-// stream order per stream.
+// for one group of pictures), the frames of the call share ARENAS OF ONE SIZE (kHostArenaBytes of pinned memory mirrored by a
+// device piece: every arena a context ever asks for is found again in the free lists).  A worker parses a frame into a scratch
+// buffer of its own -- kept by the context from call to call: no fresh pages, no page-fault storm of 256 threads in one address
+// space -- with Parser::parse (the records aa_parser_parse produces), takes room for exactly what the frame came to in the
+// arena being filled (a new one when it is full) and copies it there; every arena is uploaded by one copy on the copy stream and
+// is one Batch (released when the last of its frames goes).  frames[idx[k]], in stream order per stream.
+constexpr size_t kHostArenaBytes = size_t( 256 ) << 20;
+
+struct HostArena { uint8_t * host = nullptr, * dev = nullptr; size_t host_bytes = 0, dev_bytes = 0, used = 0; std::vector<int> members; };
+
 aa_status submit_host_batch( aa_ctx * ctx, const aa_frame_in * frames, const std::vector<int> & idx, std::vector<SubmitItem> & items, int threads )
 {
-  struct Tmp { std::unique_ptr<uint8_t[]> buf; size_t used = 0, mb_bytes = 0, rows_bytes = 0; aa_frame_header hdr; bool has_split = false; std::vector<uint8_t> diag; size_t off = 0; };
+  struct Tmp { int arena = -1; size_t off = 0, used = 0, mb_bytes = 0, rows_bytes = 0; aa_frame_header hdr; bool has_split = false; std::vector<uint8_t> diag; };
   const int n = static_cast<int>( idx.size() );
   std::vector<Tmp> tmp( n );
   std::map<aa_stream *, std::vector<int>> by_stream;      // -> positions in idx
@@ -1704,12 +1715,39 @@ aa_status submit_host_batch( aa_ctx * ctx, const aa_frame_in * frames, const std
     v.push_back( k );
   }
   const size_t job_bytes = align_up( sizeof( aa_dev_frame ) );
+  std::vector<HostArena> arenas;
+  std::mutex arena_mu;
+  aa_status arena_error = AA_OK; std::string arena_message;
+  // room for `bytes` in the arena being filled -> (arena, offset); a frame bigger than an arena gets one of its own size
+  auto place = [&]( size_t bytes, int k, int * arena_out, size_t * off_out ) -> bool {
+    std::lock_guard<std::mutex> g( arena_mu );
+    if ( arena_error != AA_OK ) return false;
+    if ( arenas.empty() || arenas.back().used + bytes > arenas.back().dev_bytes ) {
+      HostArena a;
+      const size_t want = std::max( kHostArenaBytes, align_up( bytes ) );
+      a.host = pinned_get( ctx, want, &a.host_bytes );
+      if ( !a.host ) { arena_error = AA_ERR_HIP; arena_message = "aa_submit_frames: pinned staging allocation failed"; return false; }
+      a.dev_bytes = want;
+      if ( aa_status st = dev_alloc( ctx, want, &a.dev ) ) {
+        arena_error = st; arena_message = g_last_error;
+        std::lock_guard<std::mutex> g2( ctx->pool_mu ); ctx->pinned_pool.emplace_back( a.host, a.host_bytes );
+        return false;
+      }
+      arenas.push_back( a );
+    }
+    HostArena & a = arenas.back();
+    *arena_out = static_cast<int>( arenas.size() ) - 1; *off_out = a.used;
+    a.used += bytes; a.members.push_back( k );
+    return true;
+  };
+  auto arena_host_of = [&]( int a ) -> uint8_t * { std::lock_guard<std::mutex> g( arena_mu ); return arenas[a].host; };
   std::atomic<size_t> next { 0 };
   auto work = [&]() {
     (void) hipSetDevice( ctx->device );
+    std::unique_ptr<uint8_t[]> scratch; size_t scratch_bytes = 0;
     for ( ;; ) {
       const size_t w = next.fetch_add( 1 );
-      if ( w >= order.size() ) return;
+      if ( w >= order.size() ) break;
       aa_stream * s = order[w];
       bool broken = segmap_to_host( s ) != AA_OK;
       for ( int k : by_stream[s] ) {
@@ -1721,13 +1759,21 @@ aa_status submit_host_batch( aa_ctx * ctx, const aa_frame_in * frames, const std
         t.mb_bytes = align_up( nmb * sizeof( aa_mb_info ) );
         t.rows_bytes = align_up( words_per_row * s->parser.mb_height() * sizeof( unsigned long long ) );
         const size_t head = job_bytes + t.mb_bytes + t.rows_bytes;
-        t.buf.reset( new ( std::nothrow ) uint8_t[head + nmb * 25 * 32 + kAlign] );      // (pages are committed as they are written)
-        if ( !t.buf ) { it.status = AA_ERR_ARGUMENT; it.error = "out of memory"; broken = true; continue; }
-        aa_mb_info * mbs = reinterpret_cast<aa_mb_info *>( t.buf.get() + job_bytes );
-        unsigned long long * intra_rows = reinterpret_cast<unsigned long long *>( t.buf.get() + job_bytes + t.mb_bytes );
-        int16_t * coeffs = reinterpret_cast<int16_t *>( t.buf.get() + head );
+        const size_t worst = head + nmb * 25 * 32 + kAlign;
+        if ( scratch_bytes < worst ) {
+          scratch.reset(); scratch_bytes = 0;
+          { std::lock_guard<std::mutex> g( ctx->scratch_mu );
+            for ( size_t i = 0; i < ctx->host_scratch.size(); i++ ) if ( ctx->host_scratch[i].second >= worst ) {
+              scratch = std::move( ctx->host_scratch[i].first ); scratch_bytes = ctx->host_scratch[i].second;
+              ctx->host_scratch[i] = std::move( ctx->host_scratch.back() ); ctx->host_scratch.pop_back(); break; } }
+          if ( !scratch ) { scratch.reset( new ( std::nothrow ) uint8_t[worst] ); scratch_bytes = scratch ? worst : 0; }
+          if ( !scratch ) { it.status = AA_ERR_ARGUMENT; it.error = "out of memory"; broken = true; continue; }
+        }
+        aa_mb_info * mbs = reinterpret_cast<aa_mb_info *>( scratch.get() + job_bytes );
+        unsigned long long * intra_rows = reinterpret_cast<unsigned long long *>( scratch.get() + job_bytes + t.mb_bytes );
+        int16_t * coeffs = reinterpret_cast<int16_t *>( scratch.get() + head );
         try { s->parser.parse( it.data, it.size, t.hdr, mbs, coeffs ); }
-        catch ( const aa::ParseError & e ) { it.status = e.code; it.error = e.message; t.buf.reset(); broken = true; continue; }
+        catch ( const aa::ParseError & e ) { it.status = e.code; it.error = e.message; broken = true; continue; }
         const aa_frame_header & h = t.hdr;
         const int mbw = h.mb_width, mbh = h.mb_height;
         t.diag.assign( mbw + 2 * ( mbh - 1 ), 0 );
@@ -1737,62 +1783,79 @@ aa_status submit_host_batch( aa_ctx * ctx, const aa_frame_in * frames, const std
             if ( !( mbs[r * mbw + col].flags & AA_MB_INTER ) ) { t.diag[col + 2 * r] = 1; intra_rows[r * words_per_row + ( col >> 6 )] |= 1ull << ( col & 63 ); }
         if ( !h.key_frame ) for ( size_t i = 0; i < nmb; i++ ) if ( mbs[i].y_mode == 9 /* SPLITMV */ ) { t.has_split = true; break; }
         t.used = head + align_up( size_t( h.num_coeff_blocks ) * 32 );
+        if ( !place( t.used, k, &t.arena, &t.off ) ) { it.status = AA_ERR_HIP; it.error = "no room for the parsed frame"; t.arena = -1; broken = true; continue; }
+        std::memcpy( arena_host_of( t.arena ) + t.off + job_bytes, scratch.get() + job_bytes, t.used - job_bytes );     // (the job record is filled in below)
         it.status = AA_OK;
       }
     }
+    if ( scratch ) { std::lock_guard<std::mutex> g( ctx->scratch_mu ); ctx->host_scratch.emplace_back( std::move( scratch ), scratch_bytes ); }
   };
   {
     const int nt = std::max( 1, std::min<int>( { threads, static_cast<int>( order.size() ), 256 } ) );
     if ( nt == 1 ) work();
     else { std::vector<std::thread> pool; for ( int t = 0; t < nt; t++ ) pool.emplace_back( work ); for ( auto & t : pool ) t.join(); }
   }
-  size_t total = 0; int ok = 0;
-  for ( int k = 0; k < n; k++ ) if ( tmp[k].buf ) { tmp[k].off = total; total += tmp[k].used; ok++; }
-  if ( !ok ) return AA_OK;                                  // (every frame failed: the items say why)
-  std::unique_ptr<Batch> b( new Batch );
-  b->host = pinned_get( ctx, total, &b->host_bytes );
-  if ( !b->host ) return fail( AA_ERR_HIP, "aa_submit_frames: pinned staging allocation failed" );
-  b->dev_bytes = total;
-  if ( aa_status st = dev_alloc( ctx, total, &b->dev ) ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); return st; }
-  {
-    // pack: every worker copies whole frames (a frame is a few MB)
-    std::atomic<int> nk { 0 };
-    auto copy = [&]() { for ( ;; ) { const int k = nk.fetch_add( 1 ); if ( k >= n ) return; if ( tmp[k].buf ) { std::memcpy( b->host + tmp[k].off, tmp[k].buf.get(), tmp[k].used ); tmp[k].buf.reset(); } } };
-    const int nt = std::max( 1, std::min<int>( { threads, n, 64 } ) );
-    if ( nt == 1 ) copy();
-    else { std::vector<std::thread> pool; for ( int t = 0; t < nt; t++ ) pool.emplace_back( copy ); for ( auto & t : pool ) t.join(); }
-  }
-  b->n = n; b->live = ok; b->host_parsed = true;
-  b->items.resize( n );
-  for ( aa_stream * s : order )
-    for ( int k : by_stream[s] ) {
+  aa_status result = AA_OK;
+  if ( arena_error != AA_OK ) result = fail( arena_error, arena_message );
+  int total_ok = 0;
+  for ( size_t ai = 0; ai < arenas.size(); ai++ ) {
+    HostArena & a = arenas[ai];
+    std::unique_ptr<Batch> b( new Batch );
+    b->host = a.host; b->host_bytes = a.host_bytes; b->dev = a.dev; b->dev_bytes = a.dev_bytes;
+    b->n = static_cast<int>( a.members.size() ); b->host_parsed = true;
+    b->items.resize( b->n );
+    int ok = 0;
+    for ( int j = 0; j < b->n; j++ ) {
+      const int k = a.members[j];
       SubmitItem & it = items[idx[k]];
-      b->items[k] = { s, -1, false };
-      if ( it.status != AA_OK ) continue;
+      aa_stream * s = frames[idx[k]].stream;
+      b->items[j] = { s, -1, false };
+      if ( it.status != AA_OK || tmp[k].arena != static_cast<int>( ai ) ) continue;
+      ok++;
+    }
+    b->live = ok;
+    if ( !ok ) {          // (nothing of it is used: straight back)
+      { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( a.host, a.host_bytes ); }
+      dev_free( ctx, a.dev, a.dev_bytes );
+      continue;
+    }
+    Batch * raw = b.release();
+    // frames of a stream are appended in stream order: an arena's members are in placement order, which for one stream IS its order
+    for ( int j = 0; j < raw->n; j++ ) {
+      const int k = a.members[j];
+      SubmitItem & it = items[idx[k]];
+      if ( it.status != AA_OK || tmp[k].arena != static_cast<int>( ai ) ) continue;
+      aa_stream * s = frames[idx[k]].stream;
       Tmp & t = tmp[k];
       FrameRec rec;
       rec.hdr = t.hdr; rec.has_split = t.has_split; rec.intra_diagonals = std::move( t.diag );
-      aa_dev_frame * job = reinterpret_cast<aa_dev_frame *>( b->host + t.off );
+      aa_dev_frame * job = reinterpret_cast<aa_dev_frame *>( raw->host + t.off );
       fill_job( rec, job );
-      job->mbs = reinterpret_cast<const aa_mb_info *>( b->dev + t.off + job_bytes );
-      job->intra_rows = reinterpret_cast<const unsigned long long *>( b->dev + t.off + job_bytes + t.mb_bytes );
-      job->coeffs = reinterpret_cast<const int16_t *>( b->dev + t.off + job_bytes + t.mb_bytes + t.rows_bytes );
+      job->mbs = reinterpret_cast<const aa_mb_info *>( raw->dev + t.off + job_bytes );
+      job->intra_rows = reinterpret_cast<const unsigned long long *>( raw->dev + t.off + job_bytes + t.mb_bytes );
+      job->coeffs = reinterpret_cast<const int16_t *>( raw->dev + t.off + job_bytes + t.mb_bytes + t.rows_bytes );
       rec.host_job = job;
-      rec.dev_job = reinterpret_cast<const aa_dev_frame *>( b->dev + t.off );
-      rec.batch = b.get(); rec.batch_item = k;
+      rec.dev_job = reinterpret_cast<const aa_dev_frame *>( raw->dev + t.off );
+      rec.batch = raw; rec.batch_item = j;
       it.frame_index = static_cast<int>( s->frames.size() );
-      b->items[k] = { s, it.frame_index, true };
+      raw->items[j] = { s, it.frame_index, true };
       s->frames.push_back( std::move( rec ) );
     }
-  Batch * raw = b.release();
-  // (from here on the frames point at the batch: a failure gives them back one by one)
-  auto abandon = [&]() { const std::string keep = g_last_error; std::vector<Batch::Item> its = raw->items; for ( auto & it : its ) if ( it.live ) release_records( it.s, it.s->frames[it.frame], true ); g_last_error = keep; };
-  if ( hipError_t e = hipEventCreateWithFlags( &raw->hdr_done, hipEventDisableTiming ) ) { abandon(); return hip_fail( e, "hipEventCreate" ); }
-  hipError_t e = hipMemcpyAsync( raw->dev, raw->host, total, hipMemcpyHostToDevice, ctx->copy );
-  if ( e == hipSuccess ) e = hipEventRecord( raw->hdr_done, ctx->copy );
-  if ( e != hipSuccess ) { abandon(); return hip_fail( e, "upload of host-parsed frames" ); }
-  ctx->stats.host_routed_frames += static_cast<uint64_t>( ok );
-  return AA_OK;
+    // (from here on the frames point at the batch: a failure gives them back one by one)
+    auto abandon = [&]() { const std::string keep = g_last_error; std::vector<Batch::Item> its = raw->items; for ( auto & x : its ) if ( x.live ) release_records( x.s, x.s->frames[x.frame], true ); g_last_error = keep; };
+    hipError_t e = hipEventCreateWithFlags( &raw->hdr_done, hipEventDisableTiming );
+    if ( e == hipSuccess ) e = hipMemcpyAsync( raw->dev, raw->host, a.used, hipMemcpyHostToDevice, ctx->copy );
+    if ( e == hipSuccess ) e = hipEventRecord( raw->hdr_done, ctx->copy );
+    if ( e != hipSuccess ) {
+      for ( auto & x : raw->items ) if ( x.live ) { for ( int k2 : a.members ) if ( frames[idx[k2]].stream == x.s && items[idx[k2]].frame_index == x.frame ) { items[idx[k2]].status = AA_ERR_HIP; items[idx[k2]].error = "upload of host-parsed frames failed"; } }
+      abandon();
+      result = hip_fail( e, "upload of host-parsed frames" );
+      continue;
+    }
+    total_ok += ok;
+  }
+  ctx->stats.host_routed_frames += static_cast<uint64_t>( total_ok );
+  return result;
 }
 } // namespace
 

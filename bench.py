@@ -228,7 +228,8 @@ class Pipeline:
         # not taken (pool_bytes, free lists included), what the POOL can still get is what the heap has not mapped
         heap_after = i["heap_used_bytes"] + coeff_bytes
         heap_cap = min(i["heap_limit_bytes"] or limit, limit - i["pool_bytes"])
-        pool_live = i["pool_bytes"] - i["pool_free_bytes"]
+        # (pieces released and waiting for kernels already queued -- "pending" -- are free by the time new frames need the room)
+        pool_live = i["pool_bytes"] - i["pool_free_bytes"] - i["pool_pending_bytes"]
         pool_after = pool_live + arena_bytes + env["recon_reserve"]
         pool_cap = limit - max(i["heap_mapped_bytes"], heap_after / oc)
         ok = heap_after <= oc * heap_cap and pool_after <= pool_cap
@@ -321,7 +322,7 @@ def calibrate(env, streams):
     env["key_dense_bytes"] = key_blocks * 32
     # does a hand-over of S key frames fit the host share?  (aa_submit_frames: ~24 MB of compressed key-frame data per second and core)
     hs = ctx.info()["host_share_ms"]
-    env["keys_on_host"] = bool(hs > 0 and S > min(threads, 24) and sum(len(st[0]) for st in streams) <= hs * threads * 24.0e3)
+    env["keys_on_host"] = bool(hs > 0 and S > min(threads, 24) and 0.9 * sum(len(st[0]) for st in streams) <= hs * threads * 24.0e3)
     env["packed_storage"] = {"key_frame_bytes_per_block": round(key_bpb, 2), "inter_frame_bytes_per_block": round(inter_bpb, 2), "dense_bytes_per_block": 32} if packed else None
     env["planned"] = {"key_frame_heap_bytes": env["key_coeff_bytes"], "inter_frame_heap_bytes": env["inter_coeff_bytes"], "frame_pool_bytes": env["key_arena_bytes"],
                       "key_blocks_per_mb": round(key_blocks / mbs_per_frame, 2), "inter_blocks_per_mb": round(inter_blocks / mbs_per_frame, 2)}

@@ -213,7 +213,7 @@ aa_status aa_ctx_set_packed_coefficients( aa_ctx * ctx, int on );
  * frame's chain is the longest there is (seconds on a lane, ~20 ms on a core) and its group cannot be reconstructed before it
  * is parsed, so the streams of such a call whose frames are all key frames are parsed by host workers instead (the same
  * records, one shared arena, one upload) -- biggest first, while that is expected to take no longer than `ms` milliseconds
- * on the call's `threads` workers.  Default 50 (environment: ALFALFA_AMD_HOST_SHARE_MS); 0: every frame of a big call goes to
+ * on the call's `threads` workers.  Default 80 (environment: ALFALFA_AMD_HOST_SHARE_MS); 0: every frame of a big call goes to
  * the lanes.  AA_SUBMIT_DEVICE overrides it per call. */
 aa_status aa_ctx_set_host_share_ms( aa_ctx * ctx, double ms );
 /* One token lane per DCT partition.  A frame with 2, 4 or 8 partitions (frame.cc:119-137: macroblock row r is coded in

@@ -288,6 +288,8 @@ def test_coefficient_heap_runs_out_and_frames_are_run_again(vmm, packed, monkeyp
     decs = [aa.Decoder(ctx, w, h) for _ in range(60)]
     ctx.submit_frames([(d, frames[0]) for d in decs] + [(d, frames[1]) for d in decs])
     assert bool(ctx.info()["heap_is_virtual"]) == vmm
+    import time
+    time.sleep(2.5)         # (lanes that found the pool empty give up after 2 s: let them, whatever the order in which the frames are asked for below)
     # decode whatever can be decoded, release it at once (its chunks go back), come back to the frames that were refused
     nxt, refused = [0] * len(decs), 0
     for rnd in range(200):
@@ -441,4 +443,4 @@ def test_key_frames_of_big_calls_are_parsed_by_host_workers(gpu_ctx, monkeypatch
         gpu_ctx.decode_batch(off, [0] * 26)
         assert sha256(off[25].raster_bytes(0)) == GOLDEN["qcif_q30"]["raster_sha256"][0]
     finally:
-        gpu_ctx.set_host_share_ms(50)
+        gpu_ctx.set_host_share_ms(80)

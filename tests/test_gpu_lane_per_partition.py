@@ -53,6 +53,8 @@ def test_lanes_of_one_frame_give_up_together_when_the_pool_runs_dry(monkeypatch)
     frames = clp.partitioned_stream(w, h, 71, 2, frames=2, density=0.8)
     decs = [aa.Decoder(ctx, w, h) for _ in range(40)]
     ctx.submit_frames([(d, frames[0]) for d in decs] + [(d, frames[1]) for d in decs])
+    import time
+    time.sleep(2.5)                                          # (lanes that found the pool empty give up after 2 s)
     ora = vo.OracleDecoder(w, h)
     want = []
     for fr in frames:
