@@ -52,7 +52,9 @@ class KernelStats(C.Structure):
                 ("bind_wait_ms", C.c_double), ("alloc_ms", C.c_double), ("slab_mallocs", C.c_uint64),
                 ("token_steps", C.c_uint64), ("token_frames", C.c_uint64), ("worker_launches", C.c_uint64), ("worker_wgs", C.c_uint64),
                 ("worker_retires", C.c_uint64), ("heap_grows", C.c_uint64), ("heap_mapped_bytes", C.c_uint64), ("nomem_retries", C.c_uint64), ("frames_evicted", C.c_uint64), ("host_routed_frames", C.c_uint64),
-                ("expand_ms", C.c_double), ("expand_launches", C.c_uint64), ("packed_frames", C.c_uint64), ("packed_words", C.c_uint64), ("packed_blocks", C.c_uint64)]
+                ("expand_ms", C.c_double), ("expand_launches", C.c_uint64), ("packed_frames", C.c_uint64), ("packed_words", C.c_uint64), ("packed_blocks", C.c_uint64),
+                ("host_batch_ms", C.c_double), ("host_batch_parse_wall_ms", C.c_double), ("host_batch_parse_cpu_ms", C.c_double), ("host_batch_arena_ms", C.c_double),
+                ("pinned_allocs", C.c_uint64)]
 
 
 class CtxInfo(C.Structure):
@@ -61,7 +63,7 @@ class CtxInfo(C.Structure):
         (n, C.c_uint32) for n in ("heap_is_virtual", "token_lanes_per_workgroup", "token_workgroups_capacity", "token_workgroups_alive",
                                   "token_lane_lds_bytes", "token_workgroup_lds_bytes", "jobs_waiting", "compute_units")] + [
         ("heap_free_chunks", C.c_int32), ("lanes_starved", C.c_uint32), ("token_profile", C.c_uint64 * 8),
-        ("packed_coefficients", C.c_uint32), ("lane_per_partition", C.c_uint32), ("clock_mhz", C.c_uint32), ("host_share_ms", C.c_uint32), ("stream_concurrency", C.c_uint32), ("streams_needed", C.c_uint32)]
+        ("packed_coefficients", C.c_uint32), ("lane_per_partition", C.c_uint32), ("clock_mhz", C.c_uint32), ("host_share_ms", C.c_uint32), ("host_rate_kb_per_ms", C.c_uint32), ("reserved1", C.c_uint32), ("stream_concurrency", C.c_uint32), ("streams_needed", C.c_uint32)]
 
 
 class AlfalfaError(RuntimeError):

@@ -236,7 +236,10 @@ struct aa_ctx {
   bool copy_reads_rasters = false;      // aa_stream_download_async queued copies since the last epoch was closed
   uint32_t stream_concurrency = 0, streams_needed = 0;    // probe_stream_concurrency (at the first submit)
   bool profile = false;
-  double host_share_ms = 80.0;   // aa_submit_frames: a big call's key frames are parsed by host workers while that is expected to take no longer (0: never)
+  double host_share_ms = 80.0;
+  double host_rate = 0.0;        // compressed key-frame bytes the host workers get through per millisecond of a call (measured: an average over the
+                                 // calls so far; 0 until the first one -- then threads x 24 KB/ms is assumed).  Cores a process SEES and cores it
+                                 // GETS are different things under a CPU quota: round 4's box showed 256 and gave ~15   // aa_submit_frames: a big call's key frames are parsed by host workers while that is expected to take no longer (0: never)
   int schedule = 0;            // 0: row-pipelined persistent kernels (default), 1: one launch per 2:1 anti-diagonal
   int n_xcd = 1;               // XCDs workgroups land on (probed at creation); row kernels keep a unit on one XCD
   int xcd_share[AA_MAX_XCD] = {};
@@ -253,6 +256,17 @@ struct aa_ctx {
                                           // (aa_ctx_create: 7/8 of what was free; aa_ctx_set_memory_limit)
   size_t pinned_bytes = 0;                // pinned host memory the context has taken (arenas, staging chunks, binding buffers)
   std::map<size_t, std::vector<uint8_t *>> dev_free;
+  // Pieces whose every use -- by the old owner and by the next one -- is a kernel (or copy) queued on the COMPUTE stream: output
+  // rasters and the transient dense coefficient blocks of a reconstruction call.  Stream order alone makes them reusable the
+  // moment they are released (whatever still reads the old content was queued earlier on the same stream), so they do not wait
+  // for a release epoch: a step releases ~45 GB of them at 1080p x 480 streams (a raster per frame, a dense piece per call),
+  // which the epochs kept out of reach for one step -- 45 GB of pool that the coefficient heap could not have.  Only handed
+  // out by dev_alloc_compute.  (A raster that a plain aa_stream_download_async may still be reading on the COPY stream takes the
+  // epoch route: raster_download_pending.)
+  std::map<size_t, std::vector<uint8_t *>> compute_free;
+  size_t compute_free_bytes = 0;
+  hipEvent_t last_raster_download = nullptr;   // recorded on the copy stream behind the last aa_stream_download_async
+  bool raster_download_pending = false;
   std::mutex scratch_mu;                  // worst-case sized parse buffers of the host workers of aa_submit_frames (submit_host_batch), kept from call to call
   std::vector<std::pair<std::unique_ptr<uint8_t[]>, size_t>> host_scratch;
   std::mutex blank_mu;
@@ -407,11 +421,38 @@ void dev_free( aa_ctx * ctx, uint8_t * p, size_t bytes, bool deferred = false )
   if ( deferred ) { ctx->pending_free.push_back( { p, pool_size_class( bytes ), ctx->open_epoch } ); ctx->open_epoch_used = true; }
   else ctx->dev_free[pool_size_class( bytes )].push_back( p );
 }
+// A piece that only the compute stream ever touched (see aa_ctx::compute_free): reusable at once by dev_alloc_compute
+void dev_free_compute( aa_ctx * ctx, uint8_t * p, size_t bytes )
+{
+  if ( !p ) return;
+  {
+    std::lock_guard<std::mutex> g( ctx->pool_mu );
+    if ( ctx->raster_download_pending && ctx->last_raster_download && hipEventQuery( ctx->last_raster_download ) == hipSuccess ) ctx->raster_download_pending = false;
+    (void) hipGetLastError();
+    if ( !ctx->raster_download_pending ) {
+      const size_t cls = pool_size_class( bytes );
+      ctx->compute_free[cls].push_back( p ); ctx->compute_free_bytes += cls;
+      return;
+    }
+  }
+  dev_free( ctx, p, bytes, true );
+}
+// ... and an allocation whose first use is queued on the compute stream
+aa_status dev_alloc_compute( aa_ctx * ctx, size_t bytes, uint8_t ** out )
+{
+  {
+    const size_t cls = pool_size_class( bytes );
+    std::lock_guard<std::mutex> g( ctx->pool_mu );
+    auto it = ctx->compute_free.find( cls );
+    if ( it != ctx->compute_free.end() && !it->second.empty() ) { *out = it->second.back(); it->second.pop_back(); ctx->compute_free_bytes -= cls; return AA_OK; }
+  }
+  return dev_alloc( ctx, bytes, out );
+}
 
 aa_status alloc_slot( aa_stream * s, int * out )
 {
   uint8_t * piece = nullptr;
-  if ( aa_status st = dev_alloc( s->ctx, s->slot_bytes, &piece ) ) return st;
+  if ( aa_status st = dev_alloc_compute( s->ctx, s->slot_bytes, &piece ) ) return st;     // (written by kernels / copies queued on the compute stream)
   for ( size_t i = 0; i < s->slots.size(); i++ ) if ( !s->slots[i].dev ) { s->slots[i] = Slot(); s->slots[i].dev = piece; *out = static_cast<int>( i ); return AA_OK; }
   Slot sl; sl.dev = piece;
   *out = static_cast<int>( s->slots.size() );
@@ -423,7 +464,7 @@ void release( aa_stream * s, int slot )
 {
   if ( slot < 0 ) return;
   Slot & sl = s->slots[slot];
-  if ( --sl.refs == 0 ) { if ( !sl.shared ) dev_free( s->ctx, sl.dev, s->slot_bytes, true ); sl.dev = nullptr; sl.shared = false; }   // (kernels already queued may still read it)
+  if ( --sl.refs == 0 ) { if ( !sl.shared ) dev_free_compute( s->ctx, sl.dev, s->slot_bytes ); sl.dev = nullptr; sl.shared = false; }   // (kernels already queued may still read it: they are ahead of the next owner's on the compute stream)
 }
 void set_ref( aa_stream * s, int which, int slot, int frame )
 {
@@ -899,7 +940,7 @@ uint8_t * pinned_get( aa_ctx * ctx, size_t bytes, size_t * got )
   uint8_t * p = nullptr;
   if ( hipHostMalloc( reinterpret_cast<void **>( &p ), bytes, hipHostMallocDefault ) != hipSuccess ) return nullptr;
   *got = bytes;
-  { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_bytes += bytes; }
+  { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_bytes += bytes; ctx->stats.pinned_allocs++; }
   return p;
 }
 
@@ -1203,6 +1244,7 @@ static void ctx_free( aa_ctx * ctx )
   drain_profile( ctx );
   for ( auto e : ctx->free_events ) (void) hipEventDestroy( e );
   (void) hipEventDestroy( ctx->upload_done );
+  if ( ctx->last_raster_download ) (void) hipEventDestroy( ctx->last_raster_download );
   for ( auto & bb : ctx->bind_bufs ) { if ( bb.host ) (void) hipHostFree( bb.host ); if ( bb.done ) (void) hipEventDestroy( bb.done ); }
   for ( auto & eb : ctx->expand_bufs ) { if ( eb.host ) (void) hipHostFree( eb.host ); if ( eb.done ) (void) hipEventDestroy( eb.done ); }
   for ( auto & gb : ctx->gather_bufs ) { if ( gb.host ) (void) hipHostFree( gb.host ); if ( gb.done ) (void) hipEventDestroy( gb.done ); }
@@ -1287,6 +1329,7 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
     for ( auto & kv : ctx->dev_free ) out->pool_free_bytes += kv.first * kv.second.size();
     for ( auto & pf : ctx->pending_free ) out->pool_pending_bytes += pf.bytes;
     if ( ctx->cur_slab ) out->pool_free_bytes += kSlabBytes - ctx->slab_used;
+    out->pool_free_bytes += ctx->compute_free_bytes;
   }
   out->heap_mapped_bytes = T.heap_mapped; out->heap_limit_bytes = T.heap_va;
   out->heap_used_bytes = static_cast<uint64_t>( std::max<int64_t>( 0, T.chunks_committed ) ) * kChunkBytesHeap;
@@ -1297,6 +1340,7 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
   out->token_lane_lds_bytes = T.lane_bytes; out->token_workgroup_lds_bytes = T.lds;
   out->compute_units = static_cast<uint32_t>( T.n_cus );
   out->host_share_ms = static_cast<uint32_t>( ctx->host_share_ms + 0.5 );
+  out->host_rate_kb_per_ms = static_cast<uint32_t>( ctx->host_rate / 1e3 + 0.5 );
   out->stream_concurrency = ctx->stream_concurrency; out->streams_needed = ctx->streams_needed;
   { int khz = 0; if ( hipDeviceGetAttribute( &khz, hipDeviceAttributeClockRate, ctx->device ) == hipSuccess ) out->clock_mhz = static_cast<uint32_t>( khz / 1000 ); else (void) hipGetLastError(); }
   if ( T.ready ) {
@@ -1422,7 +1466,7 @@ void aa_stream_destroy( aa_stream * s )
     if ( c.host ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( c.host, c.pinned_bytes ); c.host = nullptr; }
     if ( c.dev ) { dev_free( ctx, c.dev, c.dev_bytes, true ); c.dev = nullptr; }
   }
-  for ( auto & sl : s->slots ) if ( sl.dev && !sl.shared ) dev_free( ctx, sl.dev, s->slot_bytes, true );
+  for ( auto & sl : s->slots ) if ( sl.dev && !sl.shared ) dev_free_compute( ctx, sl.dev, s->slot_bytes );
   dev_free( ctx, s->dev_segmap, size_t( s->parser.mb_width() ) * s->parser.mb_height(), true );
   delete s;
   if ( --ctx->refs == 0 ) ctx_free( ctx );
@@ -1706,6 +1750,8 @@ aa_status submit_host_batch( aa_ctx * ctx, const aa_frame_in * frames, const std
 {
   struct Tmp { int arena = -1; size_t off = 0, used = 0, mb_bytes = 0, rows_bytes = 0; aa_frame_header hdr; bool has_split = false; std::vector<uint8_t> diag; };
   const int n = static_cast<int>( idx.size() );
+  const double t_begin = now_ms();
+  std::atomic<long long> parse_us { 0 }, arena_us { 0 };
   std::vector<Tmp> tmp( n );
   std::map<aa_stream *, std::vector<int>> by_stream;      // -> positions in idx
   std::vector<aa_stream *> order;
@@ -1723,6 +1769,7 @@ aa_status submit_host_batch( aa_ctx * ctx, const aa_frame_in * frames, const std
     std::lock_guard<std::mutex> g( arena_mu );
     if ( arena_error != AA_OK ) return false;
     if ( arenas.empty() || arenas.back().used + bytes > arenas.back().dev_bytes ) {
+      struct Clock { std::atomic<long long> & a; double t0 = now_ms(); ~Clock() { a += static_cast<long long>( ( now_ms() - t0 ) * 1e3 ); } } clock { arena_us };
       HostArena a;
       const size_t want = std::max( kHostArenaBytes, align_up( bytes ) );
       a.host = pinned_get( ctx, want, &a.host_bytes );
@@ -1772,8 +1819,10 @@ aa_status submit_host_batch( aa_ctx * ctx, const aa_frame_in * frames, const std
         aa_mb_info * mbs = reinterpret_cast<aa_mb_info *>( scratch.get() + job_bytes );
         unsigned long long * intra_rows = reinterpret_cast<unsigned long long *>( scratch.get() + job_bytes + t.mb_bytes );
         int16_t * coeffs = reinterpret_cast<int16_t *>( scratch.get() + head );
+        const double t_parse = now_ms();
         try { s->parser.parse( it.data, it.size, t.hdr, mbs, coeffs ); }
         catch ( const aa::ParseError & e ) { it.status = e.code; it.error = e.message; broken = true; continue; }
+        parse_us += static_cast<long long>( ( now_ms() - t_parse ) * 1e3 );
         const aa_frame_header & h = t.hdr;
         const int mbw = h.mb_width, mbh = h.mb_height;
         t.diag.assign( mbw + 2 * ( mbh - 1 ), 0 );
@@ -1795,6 +1844,9 @@ aa_status submit_host_batch( aa_ctx * ctx, const aa_frame_in * frames, const std
     if ( nt == 1 ) work();
     else { std::vector<std::thread> pool; for ( int t = 0; t < nt; t++ ) pool.emplace_back( work ); for ( auto & t : pool ) t.join(); }
   }
+  ctx->stats.host_batch_parse_wall_ms += now_ms() - t_begin;
+  ctx->stats.host_batch_parse_cpu_ms += parse_us.load() / 1e3;
+  ctx->stats.host_batch_arena_ms += arena_us.load() / 1e3;
   aa_status result = AA_OK;
   if ( arena_error != AA_OK ) result = fail( arena_error, arena_message );
   int total_ok = 0;
@@ -1855,6 +1907,7 @@ aa_status submit_host_batch( aa_ctx * ctx, const aa_frame_in * frames, const std
     total_ok += ok;
   }
   ctx->stats.host_routed_frames += static_cast<uint64_t>( total_ok );
+  ctx->stats.host_batch_ms += now_ms() - t_begin;
   return result;
 }
 } // namespace
@@ -1963,7 +2016,8 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
         if ( all_key ) cand.emplace_back( bytes, s );
       }
       std::stable_sort( cand.begin(), cand.end(), []( const auto & a, const auto & b ) { return a.first > b.first; } );
-      const double capacity_bytes = ctx->host_share_ms * nt * 24.0e3;
+      const double rate = ctx->host_rate > 0 ? ctx->host_rate : nt * 24.0e3;      // bytes per millisecond of wall time
+      const double capacity_bytes = ctx->host_share_ms * rate;
       std::vector<char> on_host( n, 0 );
       double taken = 0; int n_host = 0;
       for ( auto & c : cand ) {
@@ -1975,7 +2029,13 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
         std::vector<int> host_idx, dev_idx;
         for ( int i = 0; i < n; i++ ) ( on_host[i] ? host_idx : dev_idx ).push_back( i );
         aa_status first_error = AA_OK; std::string first_message;
-        if ( aa_status st = submit_host_batch( ctx, frames, host_idx, items, nt ) ) { first_error = st; first_message = g_last_error; }
+        {
+          const double t0 = now_ms();
+          if ( aa_status st = submit_host_batch( ctx, frames, host_idx, items, nt ) ) { first_error = st; first_message = g_last_error; }
+          const double dt = std::max( 0.05, now_ms() - t0 );
+          const double measured = taken / dt;
+          ctx->host_rate = ctx->host_rate > 0 ? 0.5 * ctx->host_rate + 0.5 * measured : measured;
+        }
         for ( int i : host_idx ) {
           if ( frame_index_out ) frame_index_out[i] = items[i].status == AA_OK ? items[i].frame_index : -1;
           if ( items[i].status != AA_OK && first_error == AA_OK ) { first_error = items[i].status; first_message = items[i].error; }
@@ -2454,7 +2514,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
   }
   // Packed coefficient storage: the frames of this call that were parsed on the device get their dense blocks now -- one
   // transient piece for the call, written by k_expand_coeffs in front of the reconstruction kernels and given back behind them
-  struct Scratch { aa_ctx * c; uint8_t * p = nullptr; size_t bytes = 0; ~Scratch() { if ( p ) dev_free( c, p, bytes, true ); } } dense { ctx };
+  struct Scratch { aa_ctx * c; uint8_t * p = nullptr; size_t bytes = 0; ~Scratch() { if ( p ) dev_free_compute( c, p, bytes ); } } dense { ctx };
   std::vector<std::pair<int, size_t>> packed_frames;      // (index in the call, first block in the piece)
   size_t dense_off = 0;
   {
@@ -2473,7 +2533,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
       while ( cls < want ) cls <<= 1;
       if ( cls > ( size_t( 16 ) << 20 ) ) { const size_t step = std::max<size_t>( size_t( 16 ) << 20, cls / 8 ); cls = ( want + step - 1 ) / step * step; }
       dense.bytes = cls;
-      if ( aa_status st = dev_alloc( ctx, dense.bytes, &dense.p ) ) { dense.p = nullptr; return st; }
+      if ( aa_status st = dev_alloc_compute( ctx, dense.bytes, &dense.p ) ) { dense.p = nullptr; return st; }
     }
   }
   // rasters released while binding (old references, outputs nobody holds) must not be recycled before this call's kernels
@@ -2673,8 +2733,11 @@ aa_status aa_stream_download_async( aa_stream * s, int fi, uint8_t * y, uint8_t 
   ctx->free_events.push_back( e );
   uint8_t * dst[3] = { y, u, v };
   // the raster may be released before the copy has run: the epoch that frees it waits for the copy stream as well
-  { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->copy_reads_rasters = true; }
+  { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->copy_reads_rasters = true; ctx->raster_download_pending = true; }
   for ( int p = 0; p < 3; p++ ) if ( dst[p] ) HIP_TRY( hipMemcpyAsync( dst[p], slot_plane( s, r.out_slot, p ), s->plane_bytes[p], hipMemcpyDeviceToHost, ctx->copy ) );
+  // (rasters released from now on are recycled through an epoch until this copy is through: dev_free_compute)
+  if ( !ctx->last_raster_download ) HIP_TRY( hipEventCreateWithFlags( &ctx->last_raster_download, hipEventDisableTiming ) );
+  HIP_TRY( hipEventRecord( ctx->last_raster_download, ctx->copy ) );
   return AA_OK;
 }
 aa_status aa_stream_download_wait( aa_stream * s )

@@ -320,9 +320,22 @@ def calibrate(env, streams):
     env["key_coeff_bytes"], env["inter_coeff_bytes"] = int(key_blocks * key_bpb + 65536), int(inter_blocks * inter_bpb + 65536)
     env["key_arena_bytes"], env["inter_arena_bytes"] = int(rec + 1.1 * comp), int(rec + 1.1 * comp)
     env["key_dense_bytes"] = key_blocks * 32
-    # does a hand-over of S key frames fit the host share?  (aa_submit_frames: ~24 MB of compressed key-frame data per second and core)
+    # does a hand-over of S key frames fit the host share?  The library plans with what its host workers REALLY got through in the calls
+    # so far (cores a process sees and cores it gets differ under a CPU quota): give it one hand-over of key frames to measure on
     hs = ctx.info()["host_share_ms"]
-    env["keys_on_host"] = bool(hs > 0 and S > min(threads, 24) and 0.9 * sum(len(st[0]) for st in streams) <= hs * threads * 24.0e3)
+    env["keys_on_host"] = False
+    env["host_rate_kb_per_ms"] = 0
+    if hs > 0 and S > min(threads, 24):
+        for _ in range(2):
+            probe = [aa.Decoder(ctx, width, height) for _ in range(S)]
+            ctx.submit_frames([(d, st[0]) for d, st in zip(probe, streams)], threads)
+            for d in probe:
+                d.frame_header(0)
+            ctx.sync()
+            del probe
+        env["host_rate_kb_per_ms"] = ctx.info()["host_rate_kb_per_ms"]
+        env["keys_on_host"] = bool(0.9 * sum(len(st[0]) for st in streams) <= hs * env["host_rate_kb_per_ms"] * 1e3)
+    ctx.kernel_stats(reset=True)
     env["packed_storage"] = {"key_frame_bytes_per_block": round(key_bpb, 2), "inter_frame_bytes_per_block": round(inter_bpb, 2), "dense_bytes_per_block": 32} if packed else None
     env["planned"] = {"key_frame_heap_bytes": env["key_coeff_bytes"], "inter_frame_heap_bytes": env["inter_coeff_bytes"], "frame_pool_bytes": env["key_arena_bytes"],
                       "key_blocks_per_mb": round(key_blocks / mbs_per_frame, 2), "inter_blocks_per_mb": round(inter_blocks / mbs_per_frame, 2)}
@@ -544,7 +557,7 @@ def main():
                                  + 5 * raster_bytes) / 1e9, 1)
     pipe = Pipeline(env, streams, K, D, args.header_ahead)
     log("priming")
-    pipe.run(max(2, pipe.K // 2))       # priming (untimed, before the warm-up): the pools and the coefficient heap reach their working
+    pipe.run(max(2, pipe.D + 1))        # priming (untimed, before the warm-up): the pools and the coefficient heap reach their working
     pipe.run(args.warmup)               # size, so that first-touch allocations (hipMalloc / hipMemMap / hipHostMalloc) are not what the steps measure
     barrier()
     log("warm-up done; timed region starts")
@@ -869,6 +882,9 @@ def main():
                        "note": "entropy_decode_alone = one step's submit -> parse finished with nothing else on the GPU (a latency: the longest chain, a key frame)"},
             "timed_region": timed_region, "per_rank": per_rank, "small_batches": small, "secondary": secondary, "all_frames_on_gpu_lanes": lanes_only,
             "host_share": {"host_share_ms": info["host_share_ms"], "key_frames_parsed_by_host_workers": bool(env.get("keys_on_host")), "host_threads": threads,
+                           "host_rate_kb_per_ms_measured": info["host_rate_kb_per_ms"], "equivalent_cores_at_24_kb_per_ms": round(info["host_rate_kb_per_ms"] / 24.0, 1),
+                           "host_batch_ms_per_step": round(tstats["host_batch_ms"] / args.steps, 1), "host_batch_parse_cpu_ms_per_step": round(tstats["host_batch_parse_cpu_ms"] / args.steps, 1),
+                           "host_batch_arena_ms_per_step": round(tstats["host_batch_arena_ms"] / args.steps, 1), "pinned_allocations_in_timed_region": tstats["pinned_allocs"],
                            "note": "aa_submit_frames parses a hand-over's KEY frames on host cores when that fits host_share_ms on the rank's threads (one per stream and group "
                                    "of pictures: the long chains); inter frames -- 11 of 12 frames, ~80 % of the bools -- are always decoded by GPU lanes. "
                                    "all_frames_on_gpu_lanes is the same workload with host_share_ms = 0"},

@@ -198,6 +198,9 @@ typedef struct aa_ctx_info {
   uint32_t lane_per_partition;       /* 1: frames with several DCT partitions may get a token lane per partition (aa_ctx_set_lane_per_partition) */
   uint32_t clock_mhz;                /* the device's shader clock (hipDeviceAttributeClockRate) */
   uint32_t host_share_ms;            /* aa_ctx_set_host_share_ms */
+  uint32_t host_rate_kb_per_ms;      /* what the host workers really got through in the key-frame parts of the calls so far (KB of compressed data per ms of wall
+                                        time; 0: none yet).  The share of later calls is planned with it: visible cores and usable cores differ under a CPU quota */
+  uint32_t reserved1;
   uint32_t stream_concurrency;       /* how many of the context's HIP streams were seen running side by side (probed at the first aa_submit_frames; 0: not yet) */
   uint32_t streams_needed;           /* ... of how many (15): fewer means GPU_MAX_HW_QUEUES was not in effect, see aa_runtime_prepare */
 } aa_ctx_info;
@@ -422,6 +425,10 @@ typedef struct aa_kernel_stats {
   double expand_ms;         /* k_dense_index + k_expand_coeffs (profile on) */
   uint64_t expand_launches;
   uint64_t packed_frames, packed_words, packed_blocks;   /* frames stored packed, the 16-bit words they took, the dense blocks they stand for */
+  /* key frames of big calls parsed by host workers (aa_ctx_set_host_share_ms): wall time of that part of aa_submit_frames, of its
+   * parse phase (all workers), the workers' summed parse time (CPU seconds x 1000), time spent getting arenas, pinned allocations made */
+  double host_batch_ms, host_batch_parse_wall_ms, host_batch_parse_cpu_ms, host_batch_arena_ms;
+  uint64_t pinned_allocs;
 } aa_kernel_stats;
 aa_status aa_ctx_profile( aa_ctx * ctx, int enable );
 aa_status aa_ctx_kernel_stats( aa_ctx * ctx, aa_kernel_stats * out, int reset );

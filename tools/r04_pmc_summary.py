@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_r04/ (tools/r04_profile.sh) -> profiles/r04_kernel_trace.md, profiles/r04_token_workers_counters.md,
+profiles/r04_recon_counters.md and profiles/pmc_traffic.json ({"round": "r04", "source": ..., config: {kernel: HBM bytes per
+macroblock}} -- what bench.py reports as `traffic`).  HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes): on gfx950
+FETCH_SIZE counts 64 bytes per 128-byte request of a wide streaming read (MI355X_MICROARCH.md, HBM); raw and corrected figures
+are both printed.  python tools/r04_pmc_summary.py"""
+import collections
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import rocpd_pmc_summary  # noqa: E402
+import rocpd_summary  # noqa: E402
+
+D = os.path.join(ROOT, "gpurun_out", "prof_r04")
+KINDS = collections.OrderedDict([("k_recon_inter4", "recon_inter"), ("k_recon_inter(", "recon_split"), ("k_recon_intra4", "recon_intra"),
+                                 ("k_loopfilter_rows4", "loopfilter"), ("k_token_workers", "parse_tokens"), ("k_parse_mb_headers", "parse_headers"),
+                                 ("k_expand_coeffs", "expand"), ("k_dense_index", "dense_index")])
+ALG = {"recon_inter": 1648, "recon_split": 1648, "recon_intra": 1264, "loopfilter": 768, "parse_tokens": 880, "parse_headers": 80}
+
+
+def db_of(name):
+    for pat in (os.path.join(D, name + "_results.db"), os.path.join(D, "**", name + "_results.db")):
+        hits = glob.glob(pat, recursive=True)
+        if hits:
+            return hits[0]
+    return None
+
+
+def counters(name):
+    db = db_of(name)
+    if not db:
+        return {}
+    by = rocpd_pmc_summary.per_kernel(db, list(KINDS))
+    return {KINDS[k]: {pn: (sum(x[0] for x in v), len(v), sum(x[1] for x in v)) for pn, v in c.items()} for k, c in by.items()}
+
+
+def last_json(path):
+    try:
+        return json.loads([l for l in open(path) if l.startswith("{")][-1])
+    except (OSError, IndexError, ValueError):
+        return None
+
+
+def main():
+    out_traffic = {"round": "r04", "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round's tree (tools/r04_profile.sh, tools/r04_pmc_summary.py): "
+                                             "k_token_workers / k_parse_mb_headers from the entropy decode alone with ALFALFA_AMD_WORKER_LINGER_MS=0 (96 streams x 12 frames), "
+                                             "reconstruction kernels from a shallow bench pipeline; bytes = 2 x FETCH_SIZE + WRITE_SIZE per macroblock"}
+    cfg = "1080p_inter_lf"
+    traffic = {}
+    # ---- kernel trace of the bench command ----
+    kt = db_of("kt")
+    if kt:
+        bench = last_json(os.path.join(D, "kt.log")) or {}
+        out = ["# r04 -- rocprofv3 kernel trace of `bench.py --steps 8 --warmup 2` (default config otherwise: packed storage, key frames on host workers)\n",
+               "bench line of the traced run: value %s, ms_per_step %s, steady state %s\n" % (bench.get("value"), bench.get("ms_per_step"), (bench.get("steady_state") or {}).get("value")),
+               "k_token_workers is RESIDENT: a few grids live for the whole run (their `avg us` is a lifetime, their `union ms` the wall time during which workers held the GPU); "
+               "the reconstruction kernels are per-call launches whose average must agree with `kernels.*.avg_launch_us` of the bench line.\n",
+               rocpd_summary.summarise(kt), "",
+               "## bench.py's own HIP-event figures of the same run\n", "```",
+               json.dumps({k: (v and {"avg_launch_us": v["avg_launch_us"], "launches_per_step": v["launches_per_step"], "frac": v["frac"]}) for k, v in (bench.get("kernels") or {}).items()}, indent=1),
+               json.dumps({"entropy_decode_roof": bench.get("entropy_decode_roof")}, indent=1)[:3000], "```"]
+        open(os.path.join(ROOT, "profiles", "r04_kernel_trace.md"), "w").write("\n".join(out) + "\n")
+        print("wrote profiles/r04_kernel_trace.md")
+    # ---- token workers: counters of the entropy decode alone ----
+    f, w, sq = counters("tok_fetch"), counters("tok_write"), counters("tok_sq")
+    probe = last_json(os.path.join(D, "tok_fetch.log")) or {}
+    chains = probe.get("chains", 96 * 12)
+    mbs = chains * 8160
+    out = ["# r04 -- counters of the RESIDENT token workers (and the header kernel), entropy decode alone\n",
+           "    ALFALFA_AMD_WORKER_LINGER_MS=0 rocprofv3 --kernel-trace --pmc <set> -- python tools/parse_probe.py --streams 96 --frames 12 --reps 1\n",
+           "Counter-friendly mode: with a linger of 0 a worker wave leaves when it has no frame and the queue is empty, so every dispatch ends and the counter pass (which serialises "
+           "dispatches) sees whole grids.  %d chains = %d macroblocks, every frame on the lanes (key frames too).  probe line of the FETCH pass: %s\n" % (chains, mbs, json.dumps(probe)[:600]),
+           "## per kernel, summed over its dispatches\n", "```"]
+    for name, c in (("FETCH pass", f), ("WRITE pass", w), ("SQ pass", sq)):
+        for k, v in sorted(c.items()):
+            for pn, (tot, n, dur) in sorted(v.items()):
+                out.append("%-10s %-14s %-20s dispatches %3d  sum %.6g  per macroblock %.4g  sum of durations %.1f ms" % (name, k, pn, n, tot, tot / mbs, dur / 1e6))
+    out += ["```", "", "## HBM traffic per macroblock\n", "| kernel | FETCH_SIZE raw B/MB | WRITE_SIZE B/MB | corrected 2 x FETCH + WRITE | algorithmic (SURVEY 8d) | corrected / algorithmic |", "|---|---|---|---|---|---|"]
+    for k in ("parse_tokens", "parse_headers"):
+        if k in f and k in w and "FETCH_SIZE" in f[k] and "WRITE_SIZE" in w[k]:
+            fb, wb = f[k]["FETCH_SIZE"][0] * 1024 / mbs, w[k]["WRITE_SIZE"][0] * 1024 / mbs
+            traffic[k] = round(2 * fb + wb, 1)
+            out.append("| %s | %.1f | %.1f | %.1f | %d | %.2f |" % (k, fb, wb, 2 * fb + wb, ALG[k], (2 * fb + wb) / ALG[k]))
+    if "parse_tokens" in sq:
+        s = sq["parse_tokens"]
+        g = lambda n: s.get(n, (0, 0, 0))[0]  # noqa: E731
+        steps = probe.get("lane_steps") or 0
+        out += ["", "## Issue accounting of k_token_workers (what binds it: VALU issue of one wave per SIMD at 22 of 64 lanes)\n", "```",
+                "SQ_WAVES %.6g   SQ_WAVE_CYCLES %.6g   SQ_BUSY_CYCLES %.6g" % (g("SQ_WAVES"), g("SQ_WAVE_CYCLES"), g("SQ_BUSY_CYCLES")),
+                "SQ_INSTS_VALU %.6g   SQ_INSTS_SALU %.6g   SQ_INSTS_LDS %.6g   SQ_ACTIVE_INST_VALU %.6g   SQ_WAIT_INST_ANY %.6g" % (g("SQ_INSTS_VALU"), g("SQ_INSTS_SALU"), g("SQ_INSTS_LDS"), g("SQ_ACTIVE_INST_VALU"), g("SQ_WAIT_INST_ANY")),
+                "VALU instructions per wave cycle: %.4f   (a lone wave64 issues at most one VALU per 4 cycles: 0.25 = saturated)" % (g("SQ_INSTS_VALU") / max(1.0, g("SQ_WAVE_CYCLES"))),
+                "lane steps of the parsed frames (an upper bound on bools): %s -> VALU instructions per lane step %.2f, per WAVE step (22 lanes) ~%.0f" % (steps, g("SQ_INSTS_VALU") / max(1, steps), 22.0 * g("SQ_INSTS_VALU") / max(1, steps)),
+                "```"]
+    open(os.path.join(ROOT, "profiles", "r04_token_workers_counters.md"), "w").write("\n".join(out) + "\n")
+    print("wrote profiles/r04_token_workers_counters.md")
+    # ---- reconstruction kernels ----
+    f, w, sq = counters("rec_fetch"), counters("rec_write"), counters("rec_sq")
+    bf, bw = last_json(os.path.join(D, "rec_fetch.log")) or {}, last_json(os.path.join(D, "rec_write.log")) or {}
+    units, lps = bf.get("units_per_step") or {}, bf.get("launches_per_step") or {}
+    out = ["# r04 -- counters of the reconstruction kernels (shallow bench pipeline, 240 streams x 12 frames, worker linger 0)\n", "```"]
+    for name, c in (("FETCH pass", f), ("WRITE pass", w), ("SQ pass", sq)):
+        for k, v in sorted(c.items()):
+            for pn, (tot, n, dur) in sorted(v.items()):
+                out.append("%-10s %-14s %-20s launches %4d  avg %.6g  avg duration %.1f us" % (name, k, pn, n, tot / max(1, n), dur / max(1, n) / 1e3))
+    out += ["```", "", "## HBM traffic per macroblock\n", "| kernel | macroblocks/launch | FETCH_SIZE raw B/MB | WRITE_SIZE B/MB | corrected 2 x FETCH + WRITE | algorithmic | corrected / algorithmic |", "|---|---|---|---|---|---|---|"]
+    for k in ("recon_inter", "recon_split", "recon_intra", "loopfilter"):
+        if k in f and k in w and units.get(k) and lps.get(k) and "FETCH_SIZE" in f[k] and "WRITE_SIZE" in w[k]:
+            per_launch = units[k] / lps[k]
+            fb = f[k]["FETCH_SIZE"][0] * 1024 / (f[k]["FETCH_SIZE"][1] * per_launch)
+            wb = w[k]["WRITE_SIZE"][0] * 1024 / (w[k]["WRITE_SIZE"][1] * per_launch)
+            traffic[k] = round(2 * fb + wb, 1)
+            out.append("| %s | %.0f | %.1f | %.1f | %.1f | %d | %.2f |" % (k, per_launch, fb, wb, 2 * fb + wb, ALG[k], (2 * fb + wb) / ALG[k]))
+    open(os.path.join(ROOT, "profiles", "r04_recon_counters.md"), "w").write("\n".join(out) + "\n")
+    print("wrote profiles/r04_recon_counters.md")
+    if traffic:
+        out_traffic[cfg] = traffic
+        json.dump(out_traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+        print("wrote profiles/pmc_traffic.json", traffic)
+
+
+if __name__ == "__main__":
+    main()
