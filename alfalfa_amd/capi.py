@@ -78,7 +78,7 @@ class AlfalfaError(RuntimeError):
 _P = C.c_void_p
 _U8P = C.POINTER(C.c_uint8)
 SYMBOLS = [
-    ("aa_last_error", C.c_char_p, []), ("aa_abi_version", C.c_int, []), ("aa_runtime_prepare", C.c_int, []), ("aa_device_count", C.c_int, []),
+    ("aa_last_error", C.c_char_p, []), ("aa_abi_version", C.c_int, []), ("aa_runtime_prepare", C.c_int, []), ("aa_host_cpus", C.c_int, []), ("aa_device_count", C.c_int, []),
     ("aa_parser_create", C.c_int, [C.c_uint16, C.c_uint16, C.POINTER(_P)]), ("aa_parser_destroy", None, [_P]),
     ("aa_parser_parse", C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(FrameHeader), _P, _P]),
     ("aa_parser_get_probs", C.c_int, [_P, _U8P]), ("aa_parser_set_error_concealment", C.c_int, [_P, C.c_int]),

@@ -28,6 +28,7 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
 #include <unistd.h>
 
 #include "../../include/alfalfa_amd.h"
@@ -49,6 +50,45 @@ thread_local std::string g_last_error;
 // (probe_stream_concurrency) and says so (aa_ctx_info::stream_concurrency, a clear error below 8).
 
 aa_status fail( aa_status code, const std::string & msg ) { g_last_error = msg; return code; }
+
+// Cores this process can really use: what the OS shows (hardware_concurrency, the affinity mask) bounded by the cgroup CPU quota.
+// Round 4's GPU box shows 256 hardware threads under a quota of 16 CPUs (cpu.max = "1600000 100000"): 256 parser threads there get
+// through LESS than 32 do (tools/host_parallelism.py: 25x one thread at 16-64 threads, 22x at 256), and a plan that counts on 256
+// cores is off by 16x.
+int effective_cpus()
+{
+  static const int n = [] {
+    int cpus = static_cast<int>( std::thread::hardware_concurrency() );
+    if ( cpus < 1 ) cpus = 1;
+    cpu_set_t set;
+    if ( sched_getaffinity( 0, sizeof set, &set ) == 0 ) { const int a = CPU_COUNT( &set ); if ( a > 0 && a < cpus ) cpus = a; }
+    auto read_two = []( const char * path, double * a, double * b ) -> int {
+      FILE * f = std::fopen( path, "r" );
+      if ( !f ) return 0;
+      char first[64] = { 0 };
+      int got = std::fscanf( f, "%63s %lf", first, b );
+      std::fclose( f );
+      if ( got < 1 ) return 0;
+      if ( std::strcmp( first, "max" ) == 0 ) { *a = -1; return got; }
+      *a = atof( first );
+      return got;
+    };
+    double quota = -1, period = 100000;
+    if ( read_two( "/sys/fs/cgroup/cpu.max", &quota, &period ) < 1 ) {                 // cgroup v2; else v1
+      double q = -1, dummy = 0;
+      if ( read_two( "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &q, &dummy ) >= 1 ) { quota = q; double pp = 100000; if ( read_two( "/sys/fs/cgroup/cpu/cpu.cfs_period_us", &pp, &dummy ) >= 1 && pp > 0 ) period = pp; }
+    }
+    if ( quota > 0 && period > 0 ) { const int q = std::max( 1, static_cast<int>( quota / period + 0.5 ) ); if ( q < cpus ) cpus = q; }
+    return cpus;
+  }();
+  return n;
+}
+// host workers of one call: what the caller asked for (0: all), never more than twice the cores the process really gets
+int worker_threads( int asked )
+{
+  const int cap = std::max( 1, std::min( 256, 2 * effective_cpus() ) );
+  return std::max( 1, std::min( asked > 0 ? asked : cap, cap ) );
+}
 aa_status hip_fail( hipError_t e, const char * what )
 {
   return fail( e == hipErrorNoDevice || e == hipErrorInvalidDevice ? AA_ERR_NO_DEVICE : AA_ERR_HIP,
@@ -265,6 +305,10 @@ struct aa_ctx {
   // epoch route: raster_download_pending.)
   std::map<size_t, std::vector<uint8_t *>> compute_free;
   size_t compute_free_bytes = 0;
+  // ... released WHILE an aa_decode_batch call binds rasters (binding_depth > 0): the frame being bound still predicts from the
+  // reference it has just let go of, and its kernels are not queued yet -- such a piece must not become another frame's output of
+  // the same call.  It is held until the call's launches are queued (tests/test_gpu_parity.py::test_rasters_released_while_binding...).
+  std::vector<std::pair<uint8_t *, size_t>> compute_hold;
   hipEvent_t last_raster_download = nullptr;   // recorded on the copy stream behind the last aa_stream_download_async
   bool raster_download_pending = false;
   std::mutex scratch_mu;                  // worst-case sized parse buffers of the host workers of aa_submit_frames (submit_host_batch), kept from call to call
@@ -431,7 +475,8 @@ void dev_free_compute( aa_ctx * ctx, uint8_t * p, size_t bytes )
     (void) hipGetLastError();
     if ( !ctx->raster_download_pending ) {
       const size_t cls = pool_size_class( bytes );
-      ctx->compute_free[cls].push_back( p ); ctx->compute_free_bytes += cls;
+      if ( ctx->binding_depth > 0 ) ctx->compute_hold.emplace_back( p, cls );
+      else { ctx->compute_free[cls].push_back( p ); ctx->compute_free_bytes += cls; }
       return;
     }
   }
@@ -1040,6 +1085,7 @@ aa_status segmap_to_host( aa_stream * s )
 extern "C" {
 
 const char * aa_last_error( void ) { return g_last_error.c_str(); }
+int aa_host_cpus( void ) { return effective_cpus(); }
 int aa_runtime_prepare( void )
 {
   // (overwrite = 0: a value the host program or its user chose stands)
@@ -1330,6 +1376,7 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
     for ( auto & pf : ctx->pending_free ) out->pool_pending_bytes += pf.bytes;
     if ( ctx->cur_slab ) out->pool_free_bytes += kSlabBytes - ctx->slab_used;
     out->pool_free_bytes += ctx->compute_free_bytes;
+    for ( auto & h : ctx->compute_hold ) out->pool_pending_bytes += h.second;
   }
   out->heap_mapped_bytes = T.heap_mapped; out->heap_limit_bytes = T.heap_va;
   out->heap_used_bytes = static_cast<uint64_t>( std::max<int64_t>( 0, T.chunks_committed ) ) * kChunkBytesHeap;
@@ -1964,14 +2011,27 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   // each stream's frames are parsed by one host worker (Parser::parse, the same records) and uploaded.  Frames of one stream
   // are serial on a core, so what counts is streams per worker, not frames.
   {
-    int nt = threads > 0 ? threads : static_cast<int>( std::thread::hardware_concurrency() );
-    nt = std::max( 1, std::min( nt, 256 ) );
+    const int nt = worker_threads( threads );
     const char * route_env = std::getenv( "ALFALFA_AMD_ROUTE" );            // "device" / "host": tests and experiments; default: by size
     const bool force_device = ( flags & AA_SUBMIT_DEVICE ) || ( route_env && route_env[0] == 'd' );
     const bool force_host = ( flags & AA_SUBMIT_HOST ) || ( route_env && route_env[0] == 'h' );
     // measured (round 3, 1080p, 256-core host): 1 stream 0.67 M macroblocks/s on the host route vs 0.14 M on the GPU lanes, 8 streams
     // 4.8 M vs 2.4 M -- but 64 streams 9.8 M vs 14.9 M (64 workers do not scale on this host's memory system): the bound is 24
     const bool few = static_cast<int>( stream_order.size() ) <= std::min( nt, 24 );
+    if ( !defer_tokens && !force_device && force_host && !few ) {
+      // many streams, and the caller wants them parsed NOW (AA_SUBMIT_HOST: frames that are needed at once -- the key frames of the
+      // group a pipeline starts with: 35 ms on a core, 2.4 s as a chain on a lane): the shared-arena path, every frame of the call
+      std::vector<int> all( n );
+      for ( int i = 0; i < n; i++ ) all[i] = i;
+      // (streams in the order of their first frame; frames of a stream in call order: as the per-stream route below)
+      aa_status first_error = AA_OK; std::string first_message;
+      if ( aa_status st = submit_host_batch( ctx, frames, all, items, nt ) ) { first_error = st; first_message = g_last_error; }
+      for ( int i = 0; i < n; i++ ) {
+        if ( frame_index_out ) frame_index_out[i] = items[i].status == AA_OK ? items[i].frame_index : -1;
+        if ( items[i].status != AA_OK && first_error == AA_OK ) { first_error = items[i].status; first_message = items[i].error; }
+      }
+      return first_error == AA_OK ? AA_OK : fail( first_error, first_message );
+    }
     if ( !defer_tokens && !force_device && ( force_host || few ) ) {
       std::atomic<size_t> next { 0 };
       auto work = [&]() {
@@ -2103,8 +2163,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
         }
       }
     };
-    int nt = threads > 0 ? threads : static_cast<int>( std::thread::hardware_concurrency() );
-    nt = std::max( 1, std::min<int>( { nt, static_cast<int>( stream_order.size() ), 256 } ) );
+    const int nt = std::min<int>( worker_threads( threads ), static_cast<int>( stream_order.size() ) );
     if ( nt == 1 ) work();
     else {
       std::vector<std::thread> pool;
@@ -2540,7 +2599,12 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
   // are queued: no release epoch is closed until then
   struct BindGuard { aa_ctx * c;
                      explicit BindGuard( aa_ctx * x ) : c( x ) { std::lock_guard<std::mutex> g( c->pool_mu ); c->binding_depth++; }
-                     ~BindGuard() { std::lock_guard<std::mutex> g( c->pool_mu ); c->binding_depth--; } } bind_guard( ctx );
+                     ~BindGuard() {
+                       std::lock_guard<std::mutex> g( c->pool_mu );
+                       if ( --c->binding_depth == 0 ) {      // every launch of the call is queued (or the call failed before any): what it released may be handed out
+                         for ( auto & h : c->compute_hold ) { c->compute_free[h.second].push_back( h.first ); c->compute_free_bytes += h.second; }
+                         c->compute_hold.clear();
+                       } } } bind_guard( ctx );
   if ( aa_status st = bind_batch( ctx, streams, n, frame_index ) ) return st;
   if ( !packed_frames.empty() ) if ( aa_status st = expand_packed( ctx, streams, frame_index, packed_frames, dense.p, dense_off ) ) return st;
   // frames count as submitted only once every launch of the batch has been queued (a failed launch must not leave them

@@ -96,6 +96,8 @@ def parse_args():
                     "expected to take no longer than this on the rank's host threads (library default 50; 0: every frame on the GPU's token lanes)")
     ap.add_argument("--lanes-only-steps", type=int, default=8, help="after the main run: this many steps with host_share_ms = 0 (every frame, key frames too, "
                     "parsed by GPU lanes), reported as all_frames_on_gpu_lanes (0 = skip)")
+    ap.add_argument("--no-urgent-host", action="store_true", help="key frames of the group a pipeline STARTS with also take the default route (GPU lanes) instead of the "
+                    "host route (AA_SUBMIT_HOST); they are the ones whose chain latency is the fill of the pipeline")
     ap.add_argument("--trace-memory", action="store_true", help="print the context's memory books after every step of the timed region (stderr)")
     ap.add_argument("--small-batches", default="1,8,64", help="stream counts for the small-batch end-to-end figures ('' = skip)")
     ap.add_argument("--secondary", default="720p_intra,720p_inter,1080p_inter_lf_subpel",
@@ -148,6 +150,7 @@ class Pipeline:
         self.done_t = []
         self.delivered_bytes = 0
         self.refused = 0                                 # times a hand-over was put off because HBM had no room for it
+        self.urgent_groups = 0                           # groups whose key frames took the host route because they were needed at once
 
     def _deliver(self, ds, f):
         """Frame f of every decoder of the group -> the pinned ring, behind its reconstruction, beside the next frame's: ONE
@@ -158,13 +161,19 @@ class Pipeline:
         self.ctx.download_batch_async(ds, [f] * len(ds), slab, env["raster_bytes"])
         self.delivered_bytes += len(ds) * env["raster_bytes"]
 
-    def _submit_keys(self, g):
+    def _submit_keys(self, g, urgent=False):
+        """urgent: the group is the one the pipeline is about to reconstruct (it starts empty): its key frames are needed NOW, and a key
+        frame is 35 ms on a host core but a 2.4-s chain on a GPU lane -- such a hand-over asks for the host route (AA_SUBMIT_HOST: every
+        frame of the call parsed by host workers into shared arenas).  Key frames handed over steps ahead of their turn take the
+        library's default route (the lanes, but for the share the host can take within host_share_ms)."""
         t = time.perf_counter()
         env = self.env
         ds = self.groups[g] = [self.aa.Decoder(self.ctx, env["width"], env["height"]) for _ in range(self.n)]
         for i, d in enumerate(ds):
             self.key_arr[i].stream = d.h.value
-        self.ctx.submit_prepared((self.key_arr, self.key_out, None), env["threads"], False)
+        self.ctx.submit_prepared((self.key_arr, self.key_out, None), env["threads"], False, "host" if urgent and env.get("urgent_keys_on_host") else "auto")
+        if urgent and env.get("urgent_keys_on_host"):
+            self.urgent_groups += 1
         self.frames_submitted += self.n
         self.host_s += time.perf_counter() - t
 
@@ -261,7 +270,7 @@ class Pipeline:
                         fits = self._room(self.n, self.n * env["key_coeff_bytes"], self.n * env["key_arena_bytes"])
                     if not fits:
                         break
-                    self._submit_keys(self.keys); self.keys += 1
+                    self._submit_keys(self.keys, urgent=self.keys == self.decoded); self.keys += 1
                 elif self.H > 0 and self.inters < min(target, self.decoded + self.D, self.inter_h):
                     t = time.perf_counter()
                     self.ctx.launch_tokens(1); self.inters += 1
@@ -302,6 +311,7 @@ def calibrate(env, streams):
     ctx.sync()
     rest = ctx.kernel_stats(reset=True)
     env["step_latency_us"] = t_lone_key / max(1, lone_steps) * 1e6
+    env["urgent_keys_on_host"] = not env["args"].no_urgent_host and S > 24
     env["lone_key_s"] = t_lone_key
     packed = bool(ctx.info()["packed_coefficients"])
     key_bpb = inter_bpb = 32.0
@@ -478,7 +488,8 @@ def main():
     # host workers of the header pre-pass: this rank's share of the cores (measured on the 256-core box: with the 32 workers an
     # 8-GPU node leaves a rank, a step's pre-pass + staging takes 27 ms and the end-to-end rate is within run-to-run noise of
     # the 256-worker rate)
-    threads = args.threads or max(1, (os.cpu_count() or 1) // max(1, local_world))
+    host_cpus = aa.capi.lib().aa_host_cpus()                # (what the process can really use: the cgroup quota counts -- the round-4 box shows 256, grants 16)
+    threads = args.threads or max(1, min(os.cpu_count() or 1, 2 * host_cpus) // max(1, local_world))
 
     ctx = aa.Context(dev_index)
     ctx.set_schedule(args.schedule)
@@ -561,7 +572,7 @@ def main():
     pipe.run(args.warmup)               # size, so that first-touch allocations (hipMalloc / hipMemMap / hipHostMalloc) are not what the steps measure
     barrier()
     log("warm-up done; timed region starts")
-    pipe.host_s = pipe.t_launch = pipe.t_decode = pipe.t_release = 0.0; pipe.done_t = []; pipe.refused = 0
+    pipe.host_s = pipe.t_launch = pipe.t_decode = pipe.t_release = 0.0; pipe.done_t = []; pipe.refused = 0; pipe.urgent_groups = 0
     pipe.keep_group = pipe.decoded + args.steps - 1          # the last TIMED step keeps the frames of its distinct streams: they are what is verified
     ctx.kernel_stats(reset=True)
     prof0 = ctx.info()["token_profile"]
@@ -580,6 +591,7 @@ def main():
                     "note": "every reconstructed frame gathered into one staging piece and copied to pinned host memory on the copy stream inside the timed region "
                             "(%.2f MB per frame); `value` of THIS run includes it" % (raster_bytes / 1e6)}
     hbm_free, hbm_total = ctx.memory()
+    urgent_groups_timed = pipe.urgent_groups
     tstats = ctx.kernel_stats(reset=True); ctx.profile(False)
     info = ctx.info()
     clock_mhz = info.get("clock_mhz") or 2400
@@ -800,10 +812,10 @@ def main():
 
     # ---- every frame on the GPU's token lanes (host_share_ms = 0): the same workload, key frames `--key-ahead` steps ahead ----
     lanes_only = None
-    if args.lanes_only_steps > 0 and env.get("keys_on_host"):
+    if args.lanes_only_steps > 0 and (env.get("keys_on_host") or env.get("urgent_keys_on_host")):
         share = ctx.info()["host_share_ms"]
         ctx.set_host_share_ms(0)
-        env2 = dict(env); env2["keys_on_host"] = False; env2["deliver_ring"] = None
+        env2 = dict(env); env2["keys_on_host"] = False; env2["urgent_keys_on_host"] = False; env2["deliver_ring"] = None
         p = Pipeline(env2, streams, K, D, args.header_ahead)
         ctx.sync(); ctx.kernel_stats(reset=True)
         t0 = time.perf_counter()
@@ -881,7 +893,9 @@ def main():
                        "entropy_decode_alone_s_per_step": round(t_parse_alone, 4),
                        "note": "entropy_decode_alone = one step's submit -> parse finished with nothing else on the GPU (a latency: the longest chain, a key frame)"},
             "timed_region": timed_region, "per_rank": per_rank, "small_batches": small, "secondary": secondary, "all_frames_on_gpu_lanes": lanes_only,
-            "host_share": {"host_share_ms": info["host_share_ms"], "key_frames_parsed_by_host_workers": bool(env.get("keys_on_host")), "host_threads": threads,
+            "host_share": {"host_cpus_usable": host_cpus, "host_cpus_visible": os.cpu_count(), "urgent_key_frames_on_host": bool(env.get("urgent_keys_on_host")),
+                           "groups_whose_key_frames_took_the_host_route_in_the_timed_region": urgent_groups_timed,
+                           "host_share_ms": info["host_share_ms"], "key_frames_parsed_by_host_workers": bool(env.get("keys_on_host")), "host_threads": threads,
                            "host_rate_kb_per_ms_measured": info["host_rate_kb_per_ms"], "equivalent_cores_at_24_kb_per_ms": round(info["host_rate_kb_per_ms"] / 24.0, 1),
                            "host_batch_ms_per_step": round(tstats["host_batch_ms"] / args.steps, 1), "host_batch_parse_cpu_ms_per_step": round(tstats["host_batch_parse_cpu_ms"] / args.steps, 1),
                            "host_batch_arena_ms_per_step": round(tstats["host_batch_arena_ms"] / args.steps, 1), "pinned_allocations_in_timed_region": tstats["pinned_allocs"],

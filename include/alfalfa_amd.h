@@ -49,6 +49,9 @@ int aa_abi_version( void );
  * (a value that is set stands).  -> 1 if it was set already, 0 if this call set it.  Nothing else of the host process is touched;
  * a context checks what it really got (aa_ctx_info::stream_concurrency). */
 int aa_runtime_prepare( void );
+/* Cores this process can really use: hardware threads and affinity mask bounded by the cgroup CPU quota (a container may show 256
+ * and grant 16).  The host workers of aa_submit_frames are never more than twice this, whatever `threads` says. */
+int aa_host_cpus( void );
 /* Number of visible HIP devices (0 when there is none; never fails). */
 int aa_device_count( void );
 

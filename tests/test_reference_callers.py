@@ -14,7 +14,8 @@ from test_cpp_mirror import _write_ivf, y4m_payload
 
 REF = "/root/reference/src"
 BUILD = os.path.join(ROOT, "tests", "cpp", "_build", "ref_callers")
-CALLERS = {"decode-to-stdout": "tests/decode-to-stdout.cc", "vp8decode": "frontend/vp8decode.cc", "xc-decode-bundle": "frontend/decode-bundle.cc"}
+CALLERS = {"decode-to-stdout": "tests/decode-to-stdout.cc", "vp8decode": "frontend/vp8decode.cc", "xc-decode-bundle": "frontend/decode-bundle.cc",
+           "xc-dump": "frontend/xc-dump.cc"}
 
 
 def build_callers():
@@ -89,6 +90,31 @@ def test_reference_vp8decode_resumes_from_a_state_file_written_by_the_reference(
     full, tail = y4m_payload(open(whole, "rb").read(), name), y4m_payload(open(rest, "rb").read(), name)
     frame = len(full) // sum(GOLDEN[name]["shown"])
     assert tail == full[sum(GOLDEN[name]["shown"][:n]) * frame:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n", [("qcif_q30_lf24", 3), ("synth_175x143_s3", 2), ("synth_96x80_s1", 4), ("w200_q40_lf63s7", 5)])
+def test_reference_xc_dump_writes_the_state_file_the_reference_writes(tmp_path, name, n):
+    """frontend/xc-dump.cc (SURVEY 8b caller list), unmodified on the shim: two-step decode of the first n frames
+    (UncompressedChunk, parse_frame<KeyFrame|InterFrame>, decode_frame), then Decoder::serialize -- byte for byte the .state file
+    the reference decoder wrote after the same frames (tests/golden/*.state, made by oracle/_ref/ref_state)."""
+    exe = _need(build_callers(), "xc-dump")
+    out = str(tmp_path / "dump.state")
+    subprocess.run([exe, "-f", str(n - 1), os.path.join(GOLDEN_DIR, name + ".ivf"), out], check=True)
+    assert open(out, "rb").read() == open(os.path.join(GOLDEN_DIR, "%s_f%d.state" % (name, n)), "rb").read()
+    # ... and from that state on (xc-dump -S): the state after the rest of the stream equals a straight run's
+    from conftest import golden_frames
+    _, _, frames = golden_frames(name)
+    cont, a, b = str(tmp_path / "cont.ivf"), str(tmp_path / "a.state"), str(tmp_path / "b.state")
+    _write_ivf(cont, name, frames[n:])
+    import json
+    import struct
+    hashes = json.load(open(os.path.join(GOLDEN_DIR, "hash_golden.json")))
+    if name in hashes:
+        data = bytearray(open(cont, "rb").read()); struct.pack_into("<I", data, 28, hashes[name]["minihash"][n - 1]); open(cont, "wb").write(data)
+        subprocess.run([exe, "-S", out, cont, a], check=True)
+        subprocess.run([exe, os.path.join(GOLDEN_DIR, name + ".ivf"), b], check=True)
+        assert open(a, "rb").read() == open(b, "rb").read()
 
 
 @pytest.mark.gpu
