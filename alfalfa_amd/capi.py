@@ -142,7 +142,9 @@ def lib():
     global _lib
     if _lib is None:
         path = _build.LIB
-        if _build.stale():
+        if os.environ.get("ALFALFA_AMD_LIB"):              # (A/B runs of a differently built library; never set in production)
+            path = os.environ["ALFALFA_AMD_LIB"]
+        elif _build.stale():
             if os.path.exists(_build.HIPCC):
                 _build.build()
             elif not os.path.exists(path):

@@ -1196,7 +1196,10 @@ __global__ __launch_bounds__( kLanes ) void k_recon_inter4( const aa_frame_list 
 //     macroblock, to a BOUNDARY buffer; the workgroup of the next macroblock row reads that line as its rows -4..-1,
 //     finishes them with its top MB edge and stores them with its own strip.  Frame rows are therefore written by
 //     exactly one workgroup and cross-row hand-off costs one line per macroblock each way (+ a 4-byte-column fix-up).
-constexpr int kStripMbs = 8;                         // 8: whole 128-byte lines, 19 KB of LDS per wave (2 waves per SIMD); 4: half lines, 11 KB, 3 waves per SIMD -- measured: same speed, 1.35x the HBM traffic
+#ifndef AA_LF_STRIP_MBS
+#define AA_LF_STRIP_MBS 8
+#endif
+constexpr int kStripMbs = AA_LF_STRIP_MBS;                         // 8: whole 128-byte lines, 19 KB of LDS per wave (2 waves per SIMD); 4: half lines, 11 KB, 3 waves per SIMD -- measured: same speed, 1.35x the HBM traffic
 constexpr int kStripRow = 16 + 16 * kStripMbs;        // LDS row: 16 bytes of padding + the strip's luma columns (U | V halves for chroma rows)
 constexpr int kStripRpi = 16 / kStripMbs;             // pixel rows covered by one bulk load/store instruction (16 lanes = chunks x rows)
 static_assert( ( kStripRow / 16 ) % 2 == 1, "odd multiple of 16: consecutive rows start on different banks" );

@@ -252,6 +252,15 @@ class Pipeline:
         group is reconstructed (their chains are the long ones), inter frames up to D steps."""
         env, F = self.env, self.F
         target = self.decoded + steps
+        if env.get("urgent_keys_on_host") and self.keys == self.decoded and self.decoded < target:
+            # An EMPTY pipeline.  The key frames of the group it starts with take the host route (a blocking second of the host's
+            # cores); the later groups' key frames are 2.4-s chains on the lanes whatever happens -- so they are handed to the lanes
+            # FIRST (asynchronous), and are 2.7 s old when the first group has been reconstructed instead of just begun.
+            g0 = self.decoded
+            for g in range(g0 + 1, min(target, g0 + self.K)):
+                self._submit_keys(g)
+            self._submit_keys(g0, urgent=True)
+            self.keys = max(g0 + 1, min(target, g0 + self.K))
         while self.decoded < target:
             while True:
                 can_inter = self.inter_h < min(target, self.decoded + self.D + self.H, self.keys)

@@ -79,7 +79,10 @@ def main():
         for k, v in sorted(c.items()):
             for pn, (tot, n, dur) in sorted(v.items()):
                 out.append("%-10s %-14s %-20s dispatches %3d  sum %.6g  per macroblock %.4g  sum of durations %.1f ms" % (name, k, pn, n, tot, tot / mbs, dur / 1e6))
-    out += ["```", "", "## HBM traffic per macroblock\n", "| kernel | FETCH_SIZE raw B/MB | WRITE_SIZE B/MB | corrected 2 x FETCH + WRITE | algorithmic (SURVEY 8d) | corrected / algorithmic |", "|---|---|---|---|---|---|"]
+    out += ["```", "", "## HBM traffic per macroblock\n",
+            "(k_token_workers moves LESS than the survey's algorithmic 880 B/MB: it stores packed coefficients -- a mask word + the non-zero values of a block, ~130 B/MB on this "
+            "content -- where the survey's model has 800 B of dense blocks; the dense blocks are written later by k_expand_coeffs, in front of the reconstruction that reads them.)\n",
+            "| kernel | FETCH_SIZE raw B/MB | WRITE_SIZE B/MB | corrected 2 x FETCH + WRITE | algorithmic (SURVEY 8d) | corrected / algorithmic |", "|---|---|---|---|---|---|"]
     for k in ("parse_tokens", "parse_headers"):
         if k in f and k in w and "FETCH_SIZE" in f[k] and "WRITE_SIZE" in w[k]:
             fb, wb = f[k]["FETCH_SIZE"][0] * 1024 / mbs, w[k]["WRITE_SIZE"][0] * 1024 / mbs
@@ -93,7 +96,10 @@ def main():
                 "SQ_WAVES %.6g   SQ_WAVE_CYCLES %.6g   SQ_BUSY_CYCLES %.6g" % (g("SQ_WAVES"), g("SQ_WAVE_CYCLES"), g("SQ_BUSY_CYCLES")),
                 "SQ_INSTS_VALU %.6g   SQ_INSTS_SALU %.6g   SQ_INSTS_LDS %.6g   SQ_ACTIVE_INST_VALU %.6g   SQ_WAIT_INST_ANY %.6g" % (g("SQ_INSTS_VALU"), g("SQ_INSTS_SALU"), g("SQ_INSTS_LDS"), g("SQ_ACTIVE_INST_VALU"), g("SQ_WAIT_INST_ANY")),
                 "VALU instructions per wave cycle: %.4f   (a lone wave64 issues at most one VALU per 4 cycles: 0.25 = saturated)" % (g("SQ_INSTS_VALU") / max(1.0, g("SQ_WAVE_CYCLES"))),
-                "lane steps of the parsed frames (an upper bound on bools): %s -> VALU instructions per lane step %.2f, per WAVE step (22 lanes) ~%.0f" % (steps, g("SQ_INSTS_VALU") / max(1, steps), 22.0 * g("SQ_INSTS_VALU") / max(1, steps)),
+                "VALU instructions per wave cycle / 0.5 (CDNA4: a wave64 VALU instruction occupies its SIMD-32 for two cycles) = %.1f %% of what ONE wave can issue" % (100.0 * g("SQ_INSTS_VALU") / max(1.0, g("SQ_WAVE_CYCLES")) / 0.5),
+                "lane steps of the parsed frames (an upper bound on bools): %s.  This probe has 1152 chains on 1024 waves, i.e. about one live lane per wave, so wave steps ~ lane steps;" % steps,
+                "the SQ_* sums above are those of ONE of the 8 XCDs (the counters are collected per shader-engine group; FETCH/WRITE are chip-wide): x 8 -> %.0f VALU instructions per wave step" % (8.0 * g("SQ_INSTS_VALU") / max(1, steps)),
+                "(in-kernel accounting of the same kernel in the bench run: 0.30-0.335 us per wave step = 722-804 cycles at 2.4 GHz, 19 of 22 lanes holding a frame).",
                 "```"]
     open(os.path.join(ROOT, "profiles", "r04_token_workers_counters.md"), "w").write("\n".join(out) + "\n")
     print("wrote profiles/r04_token_workers_counters.md")
