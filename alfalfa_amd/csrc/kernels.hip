@@ -503,12 +503,14 @@ __global__ __launch_bounds__( kLanes ) void k_recon_intra( const aa_frame_list l
 //     block b -> XCD b % 8 every workgroup takes exactly one ticket).
 // Every spin is bounded; on expiry the kernel records an error code and carries on (the host reports AA_ERR_HIP).
 // Bound of a hand-off wait.  The wait cannot deadlock (see above) but the workgroup waited for may be slow: reconstruction
-// runs beside thousands of entropy-decode waves that hold their SIMDs for seconds.  The bound is a TIME (two seconds of the
-// 100 MHz clock: a row kernel lasts milliseconds, so this is three orders beyond any delay load can cause, and a broken
-// hand-off is reported in seconds, not after minutes of spinning -- round 3 bounded the number of polls at 2^26); it exists so
-// that a broken hand-off ends in an error, never in a hung GPU.  The clock is read once per 1024 polls.  A waiting wave steps
-// down from the issue priority its kernel runs at: the row it waits for is produced on the same CU as often as not.
+// runs beside thousands of entropy-decode waves that hold their SIMDs for seconds.  A wait gives up when it has lasted TWO SECONDS
+// of the 100 MHz clock AND the wave has polled four million times: a row kernel lasts milliseconds, so a broken hand-off is
+// reported in seconds (round 3 bounded the polls alone at 2^26: minutes).  Time alone is not a bound: the first version of this
+// round had only the clock and expired once in a 20-step run ("needed 12 saw 11") -- wall time also passes while the whole GPU is
+// held up (the host mapping another GiB into the coefficient heap, pinning an arena), polls do not.  The clock is read once per
+// 1024 polls.  (Lowering the waiting wave's issue priority was tried with it and dropped: no measured gain.)
 constexpr unsigned long long kMaxWaitTicks = 200000000ull;
+constexpr int kMinPolls = 1 << 22;
 __device__ __forceinline__ int xcc_id() { return static_cast<int>( __builtin_amdgcn_s_getreg( 20 | ( 0 << 6 ) | ( 3 << 11 ) ) ); }   // HW_REG_XCC_ID[3:0]
 
 __device__ __forceinline__ int take_ticket( aa_sync_ws * ws, const int xcc, int * slot, const int lane )
@@ -794,9 +796,7 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
     if ( row > 0 ) {
       int spins = 0;
       unsigned long long wait_t0 = 0;
-      bool waited = false;
       while ( !__all( !on || seen >= need ) ) {
-        if ( !waited ) { waited = true; __builtin_amdgcn_s_setprio( 0 ); }
         __builtin_amdgcn_s_sleep( 4 );
         if ( on && seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
         ++spins;
@@ -806,10 +806,10 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
           if ( xcc_id() != home_xcc ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 4 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( home_xcc << 16 ) | xcc_id(); } break; }
           const unsigned long long now = wall_clock64();
           if ( !wait_t0 ) wait_t0 = now;
-          else if ( now - wait_t0 > kMaxWaitTicks ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 1 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( need << 16 ) | ( seen & 0xFFFF ); } break; }
+          else if ( spins > kMinPolls && now - wait_t0 > kMaxWaitTicks ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 1 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( need << 16 ) | ( seen & 0xFFFF ); } break; }
         }
       }
-      if ( waited ) __builtin_amdgcn_s_setprio( 3 );
+
     }
     const int x0 = col * 16, cx0 = col * 8;
     if ( on ) {
@@ -1370,9 +1370,7 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
       if ( row > 0 ) {
         int spins = 0;
         unsigned long long wait_t0 = 0;
-        bool waited = false;
         while ( !__all( seen >= need ) && !( dbg & 16 ) ) {
-          if ( !waited ) { waited = true; __builtin_amdgcn_s_setprio( 0 ); }
           __builtin_amdgcn_s_sleep( 4 );
           if ( seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
           ++spins;
@@ -1383,10 +1381,10 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
             if ( xcc_id() != home_xcc ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 4 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( home_xcc << 16 ) | xcc_id(); } break; }
             const unsigned long long now = wall_clock64();
             if ( !wait_t0 ) wait_t0 = now;
-            else if ( now - wait_t0 > kMaxWaitTicks ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 2 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( need << 16 ) | ( seen & 0xFFFF ); } break; }
+            else if ( spins > kMinPolls && now - wait_t0 > kMaxWaitTicks ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 2 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( need << 16 ) | ( seen & 0xFFFF ); } break; }
           }
         }
-        if ( waited ) __builtin_amdgcn_s_setprio( 3 );
+  
         // rows -4..-1: the boundary line the row above left for this macroblock (sc1: bypass L1, served by the XCD's L2)
         if ( frame_on && l < 8 && !( dbg & 8 ) ) {
           const uint8_t * src = bnd_top + static_cast<size_t>( col ) * 128;

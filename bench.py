@@ -256,11 +256,13 @@ class Pipeline:
             # An EMPTY pipeline.  The key frames of the group it starts with take the host route (a blocking second of the host's
             # cores); the later groups' key frames are 2.4-s chains on the lanes whatever happens -- so they are handed to the lanes
             # FIRST (asynchronous), and are 2.7 s old when the first group has been reconstructed instead of just begun.
+            # (the next three groups only: a hand-over costs the host ~0.1 s, and every one of them delays the first group's second of host parsing)
             g0 = self.decoded
-            for g in range(g0 + 1, min(target, g0 + self.K)):
+            last = min(target, g0 + min(self.K, 4))
+            for g in range(g0 + 1, last):
                 self._submit_keys(g)
             self._submit_keys(g0, urgent=True)
-            self.keys = max(g0 + 1, min(target, g0 + self.K))
+            self.keys = max(g0 + 1, last)
         while self.decoded < target:
             while True:
                 can_inter = self.inter_h < min(target, self.decoded + self.D + self.H, self.keys)
