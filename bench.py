@@ -96,6 +96,7 @@ def parse_args():
                     "expected to take no longer than this on the rank's host threads (library default 50; 0: every frame on the GPU's token lanes)")
     ap.add_argument("--lanes-only-steps", type=int, default=8, help="after the main run: this many steps with host_share_ms = 0 (every frame, key frames too, "
                     "parsed by GPU lanes), reported as all_frames_on_gpu_lanes (0 = skip)")
+    ap.add_argument("--urgent-host", action="store_true", help="... take the host route whatever the host's measured rate says")
     ap.add_argument("--no-urgent-host", action="store_true", help="key frames of the group a pipeline STARTS with also take the default route (GPU lanes) instead of the "
                     "host route (AA_SUBMIT_HOST); they are the ones whose chain latency is the fill of the pipeline")
     ap.add_argument("--trace-memory", action="store_true", help="print the context's memory books after every step of the timed region (stderr)")
@@ -322,7 +323,7 @@ def calibrate(env, streams):
     ctx.sync()
     rest = ctx.kernel_stats(reset=True)
     env["step_latency_us"] = t_lone_key / max(1, lone_steps) * 1e6
-    env["urgent_keys_on_host"] = not env["args"].no_urgent_host and S > 24
+    env["urgent_keys_on_host"] = False            # (decided below, once the host's real rate is known)
     env["lone_key_s"] = t_lone_key
     packed = bool(ctx.info()["packed_coefficients"])
     key_bpb = inter_bpb = 32.0
@@ -355,7 +356,15 @@ def calibrate(env, streams):
             ctx.sync()
             del probe
         env["host_rate_kb_per_ms"] = ctx.info()["host_rate_kb_per_ms"]
-        env["keys_on_host"] = bool(0.9 * sum(len(st[0]) for st in streams) <= hs * env["host_rate_kb_per_ms"] * 1e3)
+        key_bytes_total = sum(len(st[0]) for st in streams)
+        env["keys_on_host"] = bool(0.9 * key_bytes_total <= hs * env["host_rate_kb_per_ms"] * 1e3)
+        # The key frames of the group a pipeline STARTS with on the host route (AA_SUBMIT_HOST): worth it when the host gets through them
+        # in well under a key-frame chain -- half a second --, because the call blocks the thread that feeds the pipeline.  Measured on a
+        # box that grants 16 CPUs (1.3 s for 480 key frames): first step at 3.0 s instead of 3.9, but the hand-overs behind it start 1.3 s
+        # late and the run as a whole is no faster (profiles/r04_bench_sessions.md).
+        est_ms = key_bytes_total / max(1.0, env["host_rate_kb_per_ms"] * 1e3)
+        env["urgent_keys_on_host"] = bool(not env["args"].no_urgent_host and (env["args"].urgent_host or est_ms <= 500.0))
+        env["urgent_host_estimate_ms"] = round(est_ms)
     ctx.kernel_stats(reset=True)
     env["packed_storage"] = {"key_frame_bytes_per_block": round(key_bpb, 2), "inter_frame_bytes_per_block": round(inter_bpb, 2), "dense_bytes_per_block": 32} if packed else None
     env["planned"] = {"key_frame_heap_bytes": env["key_coeff_bytes"], "inter_frame_heap_bytes": env["inter_coeff_bytes"], "frame_pool_bytes": env["key_arena_bytes"],
@@ -904,7 +913,7 @@ def main():
                        "entropy_decode_alone_s_per_step": round(t_parse_alone, 4),
                        "note": "entropy_decode_alone = one step's submit -> parse finished with nothing else on the GPU (a latency: the longest chain, a key frame)"},
             "timed_region": timed_region, "per_rank": per_rank, "small_batches": small, "secondary": secondary, "all_frames_on_gpu_lanes": lanes_only,
-            "host_share": {"host_cpus_usable": host_cpus, "host_cpus_visible": os.cpu_count(), "urgent_key_frames_on_host": bool(env.get("urgent_keys_on_host")),
+            "host_share": {"host_cpus_usable": host_cpus, "host_cpus_visible": os.cpu_count(), "urgent_key_frames_on_host": bool(env.get("urgent_keys_on_host")), "a_group_of_key_frames_on_the_host_route_would_take_ms": env.get("urgent_host_estimate_ms"),
                            "groups_whose_key_frames_took_the_host_route_in_the_timed_region": urgent_groups_timed,
                            "host_share_ms": info["host_share_ms"], "key_frames_parsed_by_host_workers": bool(env.get("keys_on_host")), "host_threads": threads,
                            "host_rate_kb_per_ms_measured": info["host_rate_kb_per_ms"], "equivalent_cores_at_24_kb_per_ms": round(info["host_rate_kb_per_ms"] / 24.0, 1),
