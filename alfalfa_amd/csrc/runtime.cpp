@@ -278,7 +278,7 @@ struct aa_ctx {
   bool profile = false;
   double host_share_ms = 80.0;
   double host_rate = 0.0;        // compressed key-frame bytes the host workers get through per millisecond of a call (measured: an average over the
-                                 // calls so far; 0 until the first one -- then threads x 24 KB/ms is assumed).  Cores a process SEES and cores it
+                                 // calls so far; 0 until the first one -- then usable cores x 24 KB/ms is assumed).  Cores a process SEES and cores it
                                  // GETS are different things under a CPU quota: round 4's box showed 256 and gave ~15   // aa_submit_frames: a big call's key frames are parsed by host workers while that is expected to take no longer (0: never)
   int schedule = 0;            // 0: row-pipelined persistent kernels (default), 1: one launch per 2:1 anti-diagonal
   int n_xcd = 1;               // XCDs workgroups land on (probed at creation); row kernels keep a unit on one XCD
@@ -2076,7 +2076,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
         if ( all_key ) cand.emplace_back( bytes, s );
       }
       std::stable_sort( cand.begin(), cand.end(), []( const auto & a, const auto & b ) { return a.first > b.first; } );
-      const double rate = ctx->host_rate > 0 ? ctx->host_rate : nt * 24.0e3;      // bytes per millisecond of wall time
+      const double rate = ctx->host_rate > 0 ? ctx->host_rate : effective_cpus() * 24.0e3;      // bytes per millisecond of wall time (until measured: 24 KB/ms per usable core)
       const double capacity_bytes = ctx->host_share_ms * rate;
       std::vector<char> on_host( n, 0 );
       double taken = 0, wanted = 0; int n_host = 0;

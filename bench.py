@@ -362,7 +362,9 @@ def calibrate(env, streams):
         # in well under a key-frame chain -- half a second --, because the call blocks the thread that feeds the pipeline.  Measured on a
         # box that grants 16 CPUs (1.3 s for 480 key frames): first step at 3.0 s instead of 3.9, but the hand-overs behind it start 1.3 s
         # late and the run as a whole is no faster (profiles/r04_bench_sessions.md).
-        est_ms = key_bytes_total / max(1.0, env["host_rate_kb_per_ms"] * 1e3)
+        # (no host batch yet -- the library did not find half of a hand-over's key frames inside its budget: its own assumption then, 24 KB/ms per usable core)
+        rate_kb_per_ms = env["host_rate_kb_per_ms"] or 24.0 * aa.capi.lib().aa_host_cpus()
+        est_ms = key_bytes_total / (rate_kb_per_ms * 1e3)
         env["urgent_keys_on_host"] = bool(not env["args"].no_urgent_host and (env["args"].urgent_host or est_ms <= 500.0))
         env["urgent_host_estimate_ms"] = round(est_ms)
     ctx.kernel_stats(reset=True)

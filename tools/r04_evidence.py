@@ -21,7 +21,14 @@ RUNS = [
     ("r04f_ab_strip4", "session 6 A/B: loop-filter strips of 4 macroblocks (11 KB of LDS per wave)", "r04_ab_lf_strip4.log"),
     ("r04f_ab_wgs3", "session 6 A/B: three worker workgroups per CU (27 lanes each)", "r04_ab_workers3.log"),
     ("r04f_ab_wgs3_strip4", "session 6 A/B: both", "r04_ab_workers3_lf_strip4.log"),
-    ("r04g_bench", "session 7: the round's final default run (the driver's command)", "r04_bench_default.log"),
+    ("r04g_bench", "session 7: default with the urgent host route (three later key groups to the lanes first)", "r04_bench_session7_urgent.log"),
+    ("r04g_bench_again", "session 7: the same again, no secondary figures (run-to-run spread)", None),
+    ("r04h_nourgent1", "session 8 (20 steps, no extras): no urgent host route, host share as measured (~43 key frames per call)", None),
+    ("r04h_urgent1", "session 8: urgent host route", None),
+    ("r04h_nourgent2", "session 8: no urgent host route, again", None),
+    ("r04h_urgent2", "session 8: urgent host route, again", None),
+    ("r04h_lanesonly", "session 8: no urgent host route, host share 0 (every frame on the lanes)", "r04_bench_lanes_only_150gb.log"),
+    ("r04i_bench", "session 9: **the round's final tree, the driver's command** (host share: half of a call's key frames or none -> none on this box; urgent route off: a group would take 0.7 s)", "r04_bench_default.log"),
 ]
 
 
@@ -56,7 +63,7 @@ def main():
                 shutil.copy(err, os.path.join(P, keep.replace(".log", ".stderr.log")))
     open(os.path.join(P, "r04_bench_sessions.md"), "w").write("\n".join(rows) + "\n")
     for src, dst in (("r04d_host_parallelism.log", "r04_host_parallelism.log"), ("r04g_gpu_tests.log", "r04_gpu_tests.log"), ("r04c_gpu_tests.log", "r04_gpu_tests_session3.log"),
-                     ("r04b_gpu_tests.log", "r04_gpu_tests_session2_lane_per_partition_latency.log")):
+                     ("r04b_gpu_tests.log", "r04_gpu_tests_session2_lane_per_partition_latency.log"), ("r04a_gpu_tests.log", "r04_gpu_tests_session1_xcd_probe_race.log")):
         if os.path.exists(os.path.join(G, src)):
             shutil.copy(os.path.join(G, src), os.path.join(P, dst))
     print(open(os.path.join(P, "r04_bench_sessions.md")).read())
