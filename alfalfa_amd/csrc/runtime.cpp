@@ -429,6 +429,12 @@ aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out )
     // The pool is about to grow.  Past the soft limit, pieces that were released but may still be read by queued kernels are
     // waited for instead (they come back as the compute stream advances): the pool must not creep up to the last byte of HBM.
     const size_t grow = big ? bytes : kSlabBytes;
+    if ( ctx->pool_bytes + ctx->tok.heap_mapped + grow > ctx->pool_soft_limit && !ctx->compute_free.empty() ) {
+      // Past the limit: what is parked for the compute stream's own reuse (rasters and dense transients of a geometry the caller may
+      // have left behind) goes back to the general lists -- through an epoch, since queued kernels may still read it.
+      for ( auto & kv : ctx->compute_free ) for ( uint8_t * p : kv.second ) ctx->pending_free.push_back( { p, kv.first, ctx->open_epoch } );
+      ctx->compute_free.clear(); ctx->compute_free_bytes = 0; ctx->open_epoch_used = true;
+    }
     if ( ctx->pool_bytes + ctx->tok.heap_mapped + grow > ctx->pool_soft_limit && !ctx->pending_free.empty() && soft_waits < 64 ) {
       const auto t0 = std::chrono::steady_clock::now();
       collect_pending( ctx, true );

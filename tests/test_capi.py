@@ -43,3 +43,25 @@ def test_device_half_fails_loudly_without_gpu():
     with pytest.raises(aa.AlfalfaError) as e:
         aa.Context(0)
     assert e.value.kind == "NoDevice"
+
+
+def test_host_cpus_is_what_the_process_can_use_and_prepare_sets_the_queue_count_once():
+    """aa_host_cpus: hardware threads, affinity mask and cgroup CPU quota together (the round-4 GPU box shows 256 and grants 16);
+    aa_runtime_prepare: GPU_MAX_HW_QUEUES unless the environment has it (the bindings call it when the library is loaded)."""
+    L = capi.lib()
+    n = L.aa_host_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1) and n <= len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if a == "max" else int(a) / int(b)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / p if q > 0 else None
+        except (OSError, ValueError):
+            pass
+    if quota:
+        assert n <= max(1, round(quota))
+    assert os.environ.get("GPU_MAX_HW_QUEUES")             # set when capi.lib() loaded the library (or by the caller before)
+    assert L.aa_runtime_prepare() == 1                     # it is set now: a value that is there stands
