@@ -590,7 +590,7 @@ def main():
                                  + 5 * raster_bytes) / 1e9, 1)
     pipe = Pipeline(env, streams, K, D, args.header_ahead)
     log("priming")
-    pipe.run(max(2, pipe.D + 1))        # priming (untimed, before the warm-up): the pools and the coefficient heap reach their working
+    pipe.run(max(2, pipe.K + 1))        # priming (K + 1 steps: the key-frame look-ahead reaches its full depth, as it does in the timed region) (untimed, before the warm-up): the pools and the coefficient heap reach their working
     pipe.run(args.warmup)               # size, so that first-touch allocations (hipMalloc / hipMemMap / hipHostMalloc) are not what the steps measure
     barrier()
     log("warm-up done; timed region starts")
