@@ -29,6 +29,8 @@ RUNS = [
     ("r04h_urgent2", "session 8: urgent host route, again", None),
     ("r04h_lanesonly", "session 8: no urgent host route, host share 0 (every frame on the lanes)", "r04_bench_lanes_only_150gb.log"),
     ("r04j_bench", "session 10: the same command once more on the final tree (run-to-run spread of the headline: 81-87 M)", "r04_bench_default_again.log"),
+    ("r04k_bench", "session 11 (no extras): final tree after the last pool change (parked pieces drained at the limit)", "r04_bench_final_tree_check.log"),
+    ("r04l_bench", "session 12 (no extras): priming K + 1 steps instead of D + 1 (heap_grows in the timed region 8 -> 3; the 1-s gap before the fourth step stays)", "r04_bench_final_tree_check2.log"),
     ("r04i_bench", "session 9: **the round's final tree, the driver's command** (host share: half of a call's key frames or none -> none on this box; urgent route off: a group would take 0.7 s)", "r04_bench_default.log"),
 ]
 
