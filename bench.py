@@ -347,7 +347,10 @@ def calibrate(env, streams):
     hs = ctx.info()["host_share_ms"]
     env["keys_on_host"] = False
     env["host_rate_kb_per_ms"] = 0
-    if hs > 0 and S > min(threads, 24):
+    key_bytes_total = sum(len(st[0]) for st in streams)
+    # (only where the library's own assumption -- 24 KB/ms per usable core -- lets the host take at least half of a hand-over: else it
+    # takes none, there is nothing to measure, and 2 x S key frames would go through the lanes for nothing)
+    if hs > 0 and S > min(threads, 24) and hs * 24.0e3 * aa.capi.lib().aa_host_cpus() >= 0.5 * key_bytes_total:
         for _ in range(2):
             probe = [aa.Decoder(ctx, width, height) for _ in range(S)]
             ctx.submit_frames([(d, st[0]) for d, st in zip(probe, streams)], threads)
@@ -356,17 +359,16 @@ def calibrate(env, streams):
             ctx.sync()
             del probe
         env["host_rate_kb_per_ms"] = ctx.info()["host_rate_kb_per_ms"]
-        key_bytes_total = sum(len(st[0]) for st in streams)
         env["keys_on_host"] = bool(0.9 * key_bytes_total <= hs * env["host_rate_kb_per_ms"] * 1e3)
-        # The key frames of the group a pipeline STARTS with on the host route (AA_SUBMIT_HOST): worth it when the host gets through them
-        # in well under a key-frame chain -- half a second --, because the call blocks the thread that feeds the pipeline.  Measured on a
-        # box that grants 16 CPUs (1.3 s for 480 key frames): first step at 3.0 s instead of 3.9, but the hand-overs behind it start 1.3 s
-        # late and the run as a whole is no faster (profiles/r04_bench_sessions.md).
-        # (no host batch yet -- the library did not find half of a hand-over's key frames inside its budget: its own assumption then, 24 KB/ms per usable core)
-        rate_kb_per_ms = env["host_rate_kb_per_ms"] or 24.0 * aa.capi.lib().aa_host_cpus()
-        est_ms = key_bytes_total / (rate_kb_per_ms * 1e3)
-        env["urgent_keys_on_host"] = bool(not env["args"].no_urgent_host and (env["args"].urgent_host or est_ms <= 500.0))
-        env["urgent_host_estimate_ms"] = round(est_ms)
+    # The key frames of the group a pipeline STARTS with on the host route (AA_SUBMIT_HOST): worth it when the host gets through them
+    # in well under a key-frame chain -- half a second --, because the call blocks the thread that feeds the pipeline.  Measured on a
+    # box that grants 16 CPUs (1.3 s for 480 key frames): first step at 3.0 s instead of 3.9, but the hand-overs behind it start 1.3 s
+    # late and the run as a whole is no faster (profiles/r04_bench_sessions.md).
+    # (no host batch measured: the library's own assumption then, 24 KB/ms per usable core)
+    rate_kb_per_ms = env["host_rate_kb_per_ms"] or 24.0 * aa.capi.lib().aa_host_cpus()
+    est_ms = key_bytes_total / (rate_kb_per_ms * 1e3)
+    env["urgent_keys_on_host"] = bool(S > 24 and not env["args"].no_urgent_host and (env["args"].urgent_host or est_ms <= 500.0))
+    env["urgent_host_estimate_ms"] = round(est_ms)
     ctx.kernel_stats(reset=True)
     env["packed_storage"] = {"key_frame_bytes_per_block": round(key_bpb, 2), "inter_frame_bytes_per_block": round(inter_bpb, 2), "dense_bytes_per_block": 32} if packed else None
     env["planned"] = {"key_frame_heap_bytes": env["key_coeff_bytes"], "inter_frame_heap_bytes": env["inter_coeff_bytes"], "frame_pool_bytes": env["key_arena_bytes"],

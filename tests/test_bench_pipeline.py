@@ -129,3 +129,47 @@ def test_an_empty_pipeline_takes_the_host_route_for_the_group_it_starts_with(ben
     assert [s[2] for s in submits[:5]] == ["auto", "auto", "auto", "host", "auto"] and submits[4][1] == 8
     assert p.urgent_groups == 1 and p.decoded == 5 and ctx.in_flight == 0
     assert sum(1 for s in submits if s[2] == "host") == 1
+
+
+def test_calibration_runs_against_a_fake_context(bench, monkeypatch):
+    """calibrate(): the lone key frame, the frames' sizes, the host-share probe (skipped where the host cannot take half of a hand-over) and the
+    urgent-route decision -- every statement executed once on the CPU, so that a typo cannot wait for the GPU box to be found."""
+    import alfalfa_amd as aa
+
+    class Ctx(FakeCtx):
+        def __init__(self):
+            super().__init__(limit=10 ** 12)
+            self.calls = 0
+
+        def submit_frames(self, pairs, threads=0, defer_tokens=False, route="auto"):
+            self.calls += 1
+            return list(range(len(pairs)))
+
+        def kernel_stats(self, reset=False):
+            return {"token_steps": 1000, "packed_words": 4000, "packed_blocks": 400, "host_batch_ms": 0.0}
+
+        def sync(self):
+            pass
+
+        def info(self):
+            d = super().info()
+            d.update(host_share_ms=80, packed_coefficients=1, host_rate_kb_per_ms=600)
+            return d
+
+    def frame_header(self, i):
+        return {"num_coeff_blocks": 500}
+    monkeypatch.setattr(aa.Decoder, "frame_header", frame_header, raising=False)
+    args = types.SimpleNamespace(no_urgent_host=False, urgent_host=False)
+    for S, key_size in ((40, 2000), (40, 2_000_000), (8, 2000)):
+        ctx = Ctx()
+        streams = [[b"k" * key_size] + [b"i" * 100] * 2 for _ in range(S)]
+        env = {"ctx": ctx, "F": 3, "width": 64, "height": 64, "threads": 4, "mbs_per_frame": 16, "compressed_bytes": sum(len(f) for st in streams for f in st),
+               "raster_bytes": 64 * 64 * 3 // 2, "args": args}
+        bench.calibrate(env, streams)
+        assert env["key_coeff_bytes"] > 0 and env["inter_coeff_bytes"] > 0 and env["recon_reserve"] > 0 and env["step_latency_us"] > 0
+        assert env["packed_storage"]["dense_bytes_per_block"] == 32
+        cpus = aa.capi.lib().aa_host_cpus()
+        probed = S > min(env["threads"], 24) and 80 * 24.0e3 * cpus >= 0.5 * S * key_size      # (a call with few streams takes the per-stream host route anyway)
+        assert ctx.calls == 2 + (2 if probed else 0)
+        assert env["keys_on_host"] == (probed and 0.9 * S * key_size <= 80 * 600e3)
+        assert isinstance(env["urgent_keys_on_host"], bool) and (S > 24 or not env["urgent_keys_on_host"])
