@@ -53,6 +53,9 @@ KERNEL_NAMES = {"recon_inter": "k_recon_inter4", "recon_split": "k_recon_inter",
                 "parse_tokens": "k_token_workers", "parse_headers": "k_parse_mb_headers"}
 
 
+TRAFFIC_SOURCES = {}         # kernel key -> where its traffic figure was measured (profiles/pmc_traffic.json "per_kernel_source")
+
+
 def pmc_traffic(config):
     """HBM bytes per macroblock per kernel from rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
     tools/profile_summary.py): {"round": ..., config: {kernel key: bytes per macroblock}}.  Only figures measured on the kernels
@@ -63,6 +66,8 @@ def pmc_traffic(config):
         return None, None
     if d.get("round") != "r04":
         return None, None
+    global TRAFFIC_SOURCES
+    TRAFFIC_SOURCES = d.get("per_kernel_source") or {}
     return d.get(config), d.get("source")
 
 
@@ -724,7 +729,7 @@ def main():
         return {"bound": "hbm", "kernel": KERNEL_NAMES[k], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None if tr is None else round(tr * units[k] / n),
                 "avg_launch_us": round(ms / n * 1e3, 3), "launches_per_step": n, "ms_per_step": round(ms, 3),
-                "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                "algorithmic_bytes_per_launch": round(bytes_per_launch), "traffic_source": TRAFFIC_SOURCES.get(k) if tr is not None else None,
                 "measured": "one un-pipelined step after the timed region, HIP events on the kernel's stream, worker grids resident beside it"}
     roofs = {k: roof(k) for k in BYTES_PER_MB if k != "parse_tokens"}
     # k_token_workers is RESIDENT: its workgroups draw frames from a queue for as long as there is work, so there is no launch to
@@ -744,7 +749,7 @@ def main():
     # the dominant kernel by GPU time in a step: the resident workers hold every CU for the whole step
     roofline = dict(roofs["parse_tokens"])
     roofline["entropy_decode_alone_ms"] = round(t_parse_alone * 1e3, 1)      # (the un-pipelined latency of one step's chains: a latency, not a duration of the pipelined run)
-    roofline["traffic_source"] = traffic_source
+    roofline["traffic_source"] = TRAFFIC_SOURCES.get("parse_tokens") or traffic_source
     roofline["path_frac_of_hbm_peak"] = round(value / world * PATH_BYTES_PER_MB / (HBM_PEAK_GBS * 1e9), 5)
 
     # ---- bit-exactness of the profile step too (all three formats of evidence agree: timed step, profile step, pytest) ----
