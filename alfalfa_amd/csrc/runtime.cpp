@@ -1850,7 +1850,7 @@ aa_status submit_host_batch( aa_ctx * ctx, const aa_frame_in * frames, const std
       if ( w >= order.size() ) break;
       aa_stream * s = order[w];
       bool broken = segmap_to_host( s ) != AA_OK;
-      for ( int k : by_stream[s] ) {
+      for ( int k : by_stream.at( s ) ) {      // (read-only from the workers)
         SubmitItem & it = items[idx[k]];
         if ( broken ) { it.status = AA_ERR_LOGIC; it.error = "an earlier frame of this stream in the same call failed"; continue; }
         Tmp & t = tmp[k];
