@@ -441,8 +441,17 @@ void token_worker_shape( uint32_t lane_bytes, int n_cus, int * lanes_out, uint32
     lanes = sh.lanes; lds = sh.lds;
   }
   (void) n_cus;
+  // Experiment: ALFALFA_AMD_LDS_EXACT=1 makes a workgroup ask for what its lanes need and no more -- with
+  // ALFALFA_AMD_MAX_LANES=20 that leaves the reconstruction kernels 40 KB per CU instead of 27 -- and ALFALFA_AMD_WGS_CAP_PER_CU bounds
+  // the workgroups the host launches per CU (the LDS request then no longer keeps a fifth one out; the hardware spreads them evenly
+  // as a rule, not as a promise).  Off by default: not measured yet.
+  static const bool lds_exact = env_u32( "ALFALFA_AMD_LDS_EXACT", 0u ) != 0u;
+  static const uint32_t wgs_cap = env_u32( "ALFALFA_AMD_WGS_CAP_PER_CU", 0u );
+  if ( lds_exact && lanes > 0 ) lds = ( ( tok::kTablesBytes + static_cast<uint32_t>( lanes ) * lane_bytes + kLdsGranule - 1u ) / kLdsGranule ) * kLdsGranule;
   *lanes_out = lanes; *lds_out = lds;
-  *wgs_per_cu_out = lds ? static_cast<int>( kLdsPerCu / lds ) : 0;
+  int per_cu = lds ? static_cast<int>( kLdsPerCu / lds ) : 0;
+  if ( wgs_cap && per_cu > static_cast<int>( wgs_cap ) ) per_cu = static_cast<int>( wgs_cap );
+  *wgs_per_cu_out = per_cu;
 }
 
 int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap & heap, uint32_t * exited, const uint32_t * retire, uint32_t gen, uint32_t spread,
