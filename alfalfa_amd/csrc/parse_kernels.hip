@@ -204,12 +204,12 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
                 F = aa::tok::frame_of_partition( my_job, d.part, aa::tok::kTablesBytes + static_cast<uint32_t>( owner_lane ) * a.lane_bytes );
               } else F = aa::tok::frame_of( my_job );
               if ( my_job->nmb == 0 ) { L.rec = aa::tok::R_DONE; }                  // (never queued; belt and braces)
-              else aa::tok::begin_frame( L, smem, L.base, F );
+              else aa::tok::begin_frame<MP>( L, smem, L.base, F );
             }
           } else if ( mine ) {
             F = aa::tok::frame_of( job );
             if ( F.nmb == 0 ) { L.rec = aa::tok::R_DONE; }                        // (never queued; belt and braces)
-            else aa::tok::begin_frame( L, smem, L.base, F );
+            else aa::tok::begin_frame<MP>( L, smem, L.base, F );
           }
         } else backoff = 3;               // nothing there: the busy lanes of this wave should not pay for a look every period
       }

@@ -196,6 +196,15 @@ struct aa_ctx {
   struct ExpandBuf { aa_expand_job * host = nullptr, * dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
   ExpandBuf expand_bufs[kBindBufs];
   int next_expand_buf = 0;
+  // The dense blocks themselves: TWO transient arrays used in turn by the calls that have packed frames.  The expansion kernels of
+  // call N run on the utility stream, not in front of the call's reconstruction kernels on the compute stream: they need nothing
+  // of call N - 1 (whose kernels the compute stream is still working through when the host issues call N), only the array -- which
+  // call N - 2 was the last to read.  `used` is recorded on the compute stream behind the launches of the call that used the
+  // array; `filled` on the utility stream behind its expansion kernels.  (Round 4 had the expansion on the compute stream: 12 x
+  // 2.3 ms of a step's serial chain.)
+  struct DenseBuf { uint8_t * p = nullptr; size_t bytes = 0; hipEvent_t used = nullptr, filled = nullptr; bool in_use = false; };
+  DenseBuf dense_bufs[2];
+  int next_dense_buf = 0;
   // the raster list of a batched download (aa_download_batch_async), read by k_gather_rasters over the bus
   struct GatherBuf { aa_gather_job * host = nullptr, * dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
   GatherBuf gather_bufs[kBindBufs];
@@ -1299,6 +1308,7 @@ static void ctx_free( aa_ctx * ctx )
   if ( ctx->last_raster_download ) (void) hipEventDestroy( ctx->last_raster_download );
   for ( auto & bb : ctx->bind_bufs ) { if ( bb.host ) (void) hipHostFree( bb.host ); if ( bb.done ) (void) hipEventDestroy( bb.done ); }
   for ( auto & eb : ctx->expand_bufs ) { if ( eb.host ) (void) hipHostFree( eb.host ); if ( eb.done ) (void) hipEventDestroy( eb.done ); }
+  for ( auto & db : ctx->dense_bufs ) { if ( db.used ) (void) hipEventDestroy( db.used ); if ( db.filled ) (void) hipEventDestroy( db.filled ); db.p = nullptr; }   // (the arrays are pool pieces: freed with the slabs)
   for ( auto & gb : ctx->gather_bufs ) { if ( gb.host ) (void) hipHostFree( gb.host ); if ( gb.done ) (void) hipEventDestroy( gb.done ); }
   if ( ctx->ws ) (void) hipFree( ctx->ws );
   if ( ctx->boundary ) (void) hipFree( ctx->boundary );
@@ -2218,7 +2228,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
     }
   } abandon { ctx, b.release() };
   Batch * const raw = abandon.b;
-  if ( aa_status st = tok_set_lane_bytes( ctx, aa::tok::lane_lds_bytes( static_cast<uint32_t>( max_mbw ), max_nparts > 1 ) ) ) return st;
+  if ( aa_status st = tok_set_lane_bytes( ctx, aa::tok::lane_lds_bytes( static_cast<uint32_t>( max_mbw ), max_nparts > 1, ctx->tok.lane_per_partition ) ) ) return st;
 
   // ---- segment-map pass lists (only streams that use segmentation in this batch) ----
   aa_seg_stream * seg_streams = reinterpret_cast<aa_seg_stream *>( raw->host + jobs_bytes + dframes_bytes + sums_bytes );
@@ -2513,7 +2523,8 @@ aa_status launch_lf_rows( aa_ctx * ctx, std::vector<std::pair<uint32_t, const aa
 namespace {
 // k_dense_index + k_expand_coeffs for the packed frames of a reconstruction submission (on the compute stream, in front of its
 // reconstruction kernels): every frame's dense blocks into its part of `dense`, its macroblocks' coeff_index, its job's pointer.
-aa_status expand_packed( aa_ctx * ctx, aa_stream * const * streams, const int * frame_index, const std::vector<std::pair<int, size_t>> & frames, uint8_t * piece, size_t dense_off )
+aa_status expand_packed( aa_ctx * ctx, aa_stream * const * streams, const int * frame_index, const std::vector<std::pair<int, size_t>> & frames, uint8_t * piece, size_t dense_off,
+                         hipStream_t on )
 {
   uint8_t * dense = piece + dense_off;
   aa_ctx::ExpandBuf & eb = ctx->expand_bufs[ctx->next_expand_buf];
@@ -2541,11 +2552,11 @@ aa_status expand_packed( aa_ctx * ctx, aa_stream * const * streams, const int * 
   }
   const int16_t * heap = reinterpret_cast<const int16_t *>( ctx->tok.heap );
   for ( size_t base = 0; base < frames.size(); base += 32768 ) {          // (grid.y)
-    LaunchTimer t( ctx, 6 );
+    LaunchTimer t( ctx, 6, on );
     const int cnt = static_cast<int>( std::min<size_t>( 32768, frames.size() - base ) );
-    if ( int e = aa::launch_expand_coeffs( heap, eb.dev + base, reinterpret_cast<aa_expand_job *>( piece ) + base, cnt, max_mbs, ctx->compute ) ) return hip_fail( static_cast<hipError_t>( e ), "k_expand_coeffs" );
+    if ( int e = aa::launch_expand_coeffs( heap, eb.dev + base, reinterpret_cast<aa_expand_job *>( piece ) + base, cnt, max_mbs, on ) ) return hip_fail( static_cast<hipError_t>( e ), "k_expand_coeffs" );
   }
-  HIP_TRY( hipEventRecord( eb.done, ctx->compute ) );
+  HIP_TRY( hipEventRecord( eb.done, on ) );
   eb.busy = true;
   return AA_OK;
 }
@@ -2585,14 +2596,16 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
   }
   // Packed coefficient storage: the frames of this call that were parsed on the device get their dense blocks now -- one
   // transient piece for the call, written by k_expand_coeffs in front of the reconstruction kernels and given back behind them
-  struct Scratch { aa_ctx * c; uint8_t * p = nullptr; size_t bytes = 0; ~Scratch() { if ( p ) dev_free_compute( c, p, bytes ); } } dense { ctx };
+  aa_ctx::DenseBuf * dense = nullptr;
   std::vector<std::pair<int, size_t>> packed_frames;      // (index in the call, first block in the piece)
   size_t dense_off = 0;
+  bool decoded_before = false;     // a frame of the call has been reconstructed before (replays, the loop-filter search): its job record is re-pointed
   {
     size_t blocks = 0;
     for ( int i = 0; i < n; i++ ) {
       const FrameRec & r = streams[i]->frames[frame_index[i]];
       if ( !r.packed_pos ) continue;
+      decoded_before = decoded_before || r.placed;
       packed_frames.emplace_back( i, blocks );
       blocks += ( size_t( r.hdr.num_coeff_blocks ) + 7 ) & ~size_t( 7 );        // (every frame's array 256-byte aligned)
     }
@@ -2603,8 +2616,15 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
       size_t want = dense_off + std::max<size_t>( blocks, 8 ) * 32, cls = size_t( 64 ) << 10;
       while ( cls < want ) cls <<= 1;
       if ( cls > ( size_t( 16 ) << 20 ) ) { const size_t step = std::max<size_t>( size_t( 16 ) << 20, cls / 8 ); cls = ( want + step - 1 ) / step * step; }
-      dense.bytes = cls;
-      if ( aa_status st = dev_alloc_compute( ctx, dense.bytes, &dense.p ) ) { dense.p = nullptr; return st; }
+      dense = &ctx->dense_bufs[ctx->next_dense_buf];
+      ctx->next_dense_buf ^= 1;
+      if ( dense->bytes < cls ) {
+        // (the array grows: whoever still reads the old one was queued on the compute stream -- the deferred free waits for it)
+        if ( dense->p ) { dev_free( ctx, dense->p, dense->bytes, true ); dense->p = nullptr; dense->bytes = 0; dense->in_use = false; }
+        if ( aa_status st = dev_alloc( ctx, cls, &dense->p ) ) { dense->p = nullptr; return st; }
+        dense->bytes = cls;
+      }
+      if ( !dense->used ) { HIP_TRY( hipEventCreateWithFlags( &dense->used, hipEventDisableTiming ) ); HIP_TRY( hipEventCreateWithFlags( &dense->filled, hipEventDisableTiming ) ); }
     }
   }
   // rasters released while binding (old references, outputs nobody holds) must not be recycled before this call's kernels
@@ -2618,7 +2638,21 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
                          c->compute_hold.clear();
                        } } } bind_guard( ctx );
   if ( aa_status st = bind_batch( ctx, streams, n, frame_index ) ) return st;
-  if ( !packed_frames.empty() ) if ( aa_status st = expand_packed( ctx, streams, frame_index, packed_frames, dense.p, dense_off ) ) return st;
+  if ( !packed_frames.empty() ) {
+    // the expansion runs on the utility stream, behind the kernels that last read the array (two calls ago) -- or, when a frame
+    // of the call is being reconstructed again, behind everything queued so far: kernels of its earlier run may still follow
+    // its job record to the array it pointed at then
+    static const bool on_compute = [] { const char * e = std::getenv( "ALFALFA_AMD_EXPAND_ON_COMPUTE" ); return e && atoi( e ) != 0; }();      // (A/B runs: round 4's placement)
+    hipStream_t es = ( ctx->tok.util && !on_compute ) ? ctx->tok.util : ctx->compute;
+    if ( es != ctx->compute ) {
+      if ( decoded_before ) { HIP_TRY( hipEventRecord( dense->filled, ctx->compute ) ); HIP_TRY( hipStreamWaitEvent( es, dense->filled, 0 ) ); }
+      else if ( dense->in_use ) HIP_TRY( hipStreamWaitEvent( es, dense->used, 0 ) );
+    }
+    if ( aa_status st = expand_packed( ctx, streams, frame_index, packed_frames, dense->p, dense_off, es ) ) return st;
+    if ( es != ctx->compute ) { HIP_TRY( hipEventRecord( dense->filled, es ) ); HIP_TRY( hipStreamWaitEvent( ctx->compute, dense->filled, 0 ) ); }
+  }
+  // ... and whatever the call queues on the compute stream from here on reads the array: `used` is recorded when the call is over
+  struct DenseUsed { aa_ctx * c; aa_ctx::DenseBuf * d; ~DenseUsed() { if ( d ) { (void) hipEventRecord( d->used, c->compute ); d->in_use = true; } } } dense_used { ctx, dense };
   // frames count as submitted only once every launch of the batch has been queued (a failed launch must not leave them
   // looking decoded)
   struct Advance { aa_stream * const * streams; int n; bool ok = false; ~Advance() { if ( ok ) for ( int i = 0; i < n; i++ ) streams[i]->next_submit++; } } advance { streams, n };

@@ -197,13 +197,28 @@ constexpr uint32_t kXtab = 720;           // extra-bit probabilities of the six 
 constexpr uint32_t kSignX = 26;           // index of the sign's probability in that table
 constexpr uint32_t kTablesBytes = 768;    // first lane slice
 // offsets relative to a lane's slice:
-constexpr uint32_t kProbs = 0;            // [4][8][3][11] token probabilities
-constexpr uint32_t kStream = 1056;        // stream ring
+constexpr uint32_t kStream = 0;           // stream ring (16-byte aligned: filled 16 bytes at a time)
 constexpr uint32_t kMeta = kStream + kRing;
-constexpr uint32_t kAbove = kMeta + kMetaRing;  // uint16 per macroblock column: the above-row non-zero flags
+// Token probabilities: THREE of the frame's four 264-byte type planes ([8][3][11] each), not the whole [4][8][3][11] table.  The
+// order of block types inside a macroblock is fixed (macroblock.cc:475-502): Y2, 16 x Y_AFTER_Y2, 8 x UV -- or, for a macroblock
+// without a Y2 block (B_PRED, SPLITMV), 16 x Y_WITHOUT_Y2, 8 x UV.  A macroblock therefore reads ONE of the two Y planes, and which
+// one is known from its flags byte when it starts: the slice keeps the Y2 and UV planes for the whole frame and one Y plane
+// (Lane::ykind), replaced from the job's table in HBM at the macroblock boundary where the kind changes (the slow path; inter
+// frames are nearly all-Y2, the reference encoder's key frames all-B_PRED; a frame that mixes the kinds pays one 264-byte read
+// per change).  264 bytes less per lane = 5 more chains per wave at 1080p.
+constexpr uint32_t kPlaneBytes = 264;
+constexpr uint32_t kPlaneY = kMeta + kMetaRing;     // Y_AFTER_Y2 or Y_WITHOUT_Y2
+constexpr uint32_t kPlaneUV = kPlaneY + kPlaneBytes;
+constexpr uint32_t kPlaneY2 = kPlaneUV + kPlaneBytes;
+constexpr uint32_t kAbove = kPlaneY2 + kPlaneBytes; // the above-row non-zero flags, 9 bits per macroblock column:
+//   a lane of its own (SH = false): one BYTE per column (4 Y, 2 U, 2 V) followed by one BIT per column (Y2) -- 135 bytes at 1080p
+//   lanes of one frame sharing the array (one lane per partition, SH = true): uint16 per column -- two lanes may be in columns of
+//   the same byte of a bit array in the same instruction, and a read-modify-write would lose one of the bits
+static_assert( kPlaneY % 8 == 0 && kPlaneUV % 8 == 0 && kPlaneY2 % 8 == 0 && kPlaneY2 / 8 < 128, "plane offsets travel as bytes / 8 in the block table" );
+AA_HD constexpr uint32_t above_bytes( uint32_t mbw, bool shared ) { return shared ? 2u * mbw : mbw + ( mbw + 7u ) / 8u; }
 // then, only for frames with more than one token partition: 8 saved partition decoders x 16 bytes
-AA_HD constexpr uint32_t part_off( uint32_t mbw ) { return ( kAbove + 2 * mbw + 15 ) & ~15u; }
-AA_HD constexpr uint32_t lane_lds_bytes( uint32_t mbw, bool multi_partition ) { return part_off( mbw ) + ( multi_partition ? 128u : 0u ); }
+AA_HD constexpr uint32_t part_off( uint32_t mbw, bool shared ) { return ( kAbove + above_bytes( mbw, shared ) + 15 ) & ~15u; }
+AA_HD constexpr uint32_t lane_lds_bytes( uint32_t mbw, bool multi_partition, bool shared = false ) { return part_off( mbw, shared ) + ( multi_partition ? 128u : 0u ); }
 // (The flags were tried in HBM -- 240 bytes of LDS per lane at 1080p would buy 15 % more chains per CU --, the lane keeping the
 // eight columns it passes in registers.  Measured on MI355X, round 3: every use of those registers costs the wave an
 // s_waitcnt vmcnt(0), i.e. a drain of ALL its outstanding coefficient stores at every macroblock boundary of every lane;
@@ -220,7 +235,8 @@ constexpr uint8_t kXtabInit[27] = { 159, 165, 145, 173, 148, 140, 176, 155, 140,
 //         base, the extra bits having been shifted into Lane::mag) and the context the token leaves behind
 // A lane's state is the ADDRESS of its node's record (8 * node); values >= R_MBDONE mean "not decoding".
 enum : uint32_t { kNodes = 47, R_MBDONE = 0x1000, R_MB = 0x1001, R_DONE = 0x1002,
-                  R_PARK = 0x1003 };      // one lane per partition: through, but its slice holds what lanes still running share
+                  R_PARK = 0x1003,        // one lane per partition: through, but its slice holds what lanes still running share
+                  R_BEND = 0x1004 };      // the block in progress has ended: the lane waits for the wave's next block-end pass (tok::block_end)
 // half of a node record = what a decoded 0 / 1 at that node means:
 //   [0,9) address of the next node's record   [9,14) index of the next node's probability   [14] ... in the current row (else in kXtab)
 //   [15] shift the bit into the magnitude   [16] on to the next coefficient position   [17] emit the coefficient   [18] end of block
@@ -271,15 +287,18 @@ static_assert( sizeof( NodeTable ) <= kBlockTabOff, "node records must stay belo
 // ---- blocks ---------------------------------------------------------------------------------------------------------
 // parse order within a macroblock (macroblock.cc:480-500): 0 = Y2, 1..16 = Y, 17..20 = U, 21..24 = V.  Per block: where its
 // "above" / "left" non-zero flags live in Lane::ctxbits (above: bits 0-8 = 4 Y columns, 2 U, 2 V, Y2; left: bits 16-24),
-// the kind of probabilities it reads, its bit in nz_mask.
+// the plane of probabilities it reads (byte 2: offset of the plane in the lane's slice / 8, + kBlkIsY for a Y block, whose first
+// position depends on the macroblock having a Y2), its bit in nz_mask.  Word 1 = the two flag bits as a mask: the block's context
+// is the number of bits of ctxbits under it.
+constexpr uint32_t kBlkIsY = 128;
 struct BlockTable { V8 b[26]; };
 constexpr BlockTable make_blocks()
 {
   BlockTable t {};
   for ( uint32_t blk = 0; blk < 25; blk++ ) {
-    uint32_t a = 8, l = 8, sel = 2, bit = 24;                       // Y2
-    if ( blk >= 1 && blk <= 16 ) { const uint32_t b = blk - 1; a = b & 3; l = b >> 2; sel = 0; bit = b; }
-    else if ( blk >= 17 ) { const uint32_t k = blk - 17, pl = k >> 2; a = 4 + 2 * pl + ( k & 1 ); l = 4 + 2 * pl + ( ( k >> 1 ) & 1 ); sel = 1; bit = blk - 1; }
+    uint32_t a = 8, l = 8, sel = kPlaneY2 / 8, bit = 24;            // Y2
+    if ( blk >= 1 && blk <= 16 ) { const uint32_t b = blk - 1; a = b & 3; l = b >> 2; sel = kPlaneY / 8 + kBlkIsY; bit = b; }
+    else if ( blk >= 17 ) { const uint32_t k = blk - 17, pl = k >> 2; a = 4 + 2 * pl + ( k & 1 ); l = 4 + 2 * pl + ( ( k >> 1 ) & 1 ); sel = kPlaneUV / 8; bit = blk - 1; }
     t.b[blk] = { a | ( ( 16 + l ) << 8 ) | ( sel << 16 ) | ( bit << 24 ), ( 1u << a ) | ( 1u << ( 16 + l ) ) };
   }
   t.b[25] = { 0, 0 };
@@ -314,8 +333,9 @@ AA_HD inline Frame frame_of( const ParseJob * job )
   F.data = (const AA_GLOBAL uint8_t *) job->data; F.mbflags = (const AA_GLOBAL uint8_t *) job->mbflags;
   F.mbs = (AA_GLOBAL aa_mb_info *) job->mbs; F.chunk_list = (AA_GLOBAL uint32_t *) job->chunk_list;
   F.packed_pos = (AA_GLOBAL uint32_t *) job->packed_pos;
-  // per macroblock at most 25 blocks x 16 tokens x (11 tree nodes + 11 extra bits + sign), plus boundary steps
-  const uint64_t bound = static_cast<uint64_t>( job->nmb ) * ( 25u * 16u * 23u + 4u ) + 4096u;
+  // per macroblock at most 25 blocks x (16 tokens x (11 tree nodes + 11 extra bits + sign) + the wait for the block-end pass),
+  // plus boundary steps
+  const uint64_t bound = static_cast<uint64_t>( job->nmb ) * ( 25u * ( 16u * 23u + 8u ) + 8u ) + 4096u;
   F.max_steps = bound > 0xFFFFFFF0ull ? 0xFFFFFFF0u : static_cast<uint32_t>( bound );
   F.data_padded = job->data_padded; F.flags_padded = job->flags_padded; F.nmb = job->nmb; F.mbw = job->fp.mbw; F.nparts = job->fp.nparts;
   F.mp_P = 1; F.mp_p = 0; F.mp_owner = 0;
@@ -401,6 +421,7 @@ struct Lane {
   uint32_t value, range;
   int32_t sh;
   uint32_t rpos, rend;            // next stream byte to shift in / end of the partition (offsets into the frame)
+  uint32_t rawq;                  // ... and that byte, read from the ring as soon as rpos is known (AA_STEP_VARIANT & 2)
   uint32_t wpos;                  // stream ring holds [wpos - kRing, wpos)
   uint32_t mwpos;                 // flag ring holds macroblocks [mwpos - kMetaRing, mwpos)
   uint32_t pend_wpos, pend_mwpos; // what the chunks in flight are for (kNoPend: nothing in flight)
@@ -415,7 +436,8 @@ struct Lane {
   uint32_t nzsel, blkbit;
   // macroblock in progress
   uint32_t ctxbits;               // non-zero flags: above (this column) bits 0-8, left bits 16-24
-  uint32_t flags, nz_mask, mb_first, coeff_blocks, ytypeaddr, yfirst;
+  uint32_t flags, nz_mask, mb_first, coeff_blocks, yfirst;
+  uint32_t ykind;                 // which Y plane the slice holds (Y_AFTER_Y2 / Y_WITHOUT_Y2; kNoPlane: none yet)
   AA_GLOBAL int16_t * blk;        // the coefficient block being filled = Heap::base + 16 * blk_index (zeroed in advance)
   uint32_t blk_index;             // its index in the heap
   uint32_t blk_left;              // blocks left in the chunk being filled, the current one included (0: no chunk yet)
@@ -432,6 +454,7 @@ struct Lane {
   uint32_t steps;
 };
 constexpr uint32_t kNoPend = 0xFFFFFFFFu;
+constexpr uint32_t kNoPlane = 0xFFFFFFFFu;
 
 AA_HD inline void zero_slot( AA_GLOBAL int16_t * block )
 {
@@ -489,11 +512,13 @@ AA_HD inline void start_partition( Lane & L, uint8_t * smem, const Frame & J, ui
   uint32_t v = 0;
   for ( int k = 0; k < 4; k++ ) { v = ( v << 8 ) | smem[L.base + kStream + ( L.rpos & ( kRing - 1 ) )]; L.rpos++; }
   L.value = v; L.sh = -8; L.range = 255;
+  L.rawq = smem[L.base + kStream + ( L.rpos & ( kRing - 1 ) )];
 }
 
+template <bool SH = false>
 AA_HD inline void switch_partition( Lane & L, uint8_t * smem, const Frame & J, uint32_t p )
 {
-  const uint32_t save = L.base + part_off( J.mbw );
+  const uint32_t save = L.base + part_off( J.mbw, SH );
   uint32_t * s = reinterpret_cast<uint32_t *>( smem + save + 16 * L.part );
   s[0] = L.value; s[1] = L.range | ( static_cast<uint32_t>( L.sh + 64 ) << 8 ); s[2] = L.rpos; s[3] = 1;
   const uint32_t * t = reinterpret_cast<const uint32_t *>( smem + save + 16 * p );
@@ -502,6 +527,7 @@ AA_HD inline void switch_partition( Lane & L, uint8_t * smem, const Frame & J, u
   L.value = t[0]; L.range = t[1] & 255u; L.sh = static_cast<int32_t>( t[1] >> 8 ) - 64; L.rpos = t[2];
   L.rend = J.job->fp.part_off[p] + J.job->fp.part_size[p];
   prime_stream( L, smem, J );
+  L.rawq = smem[L.base + kStream + ( L.rpos & ( kRing - 1 ) )];
 }
 
 // ---- every kPeriod steps, all lanes together: land the chunks requested a period ago, request the next ---------------
@@ -548,7 +574,9 @@ AA_HD inline void top_up( Lane & L, uint8_t * smem, const Frame & J )
 // (a word another lane of the wave writes: read it from LDS every time, never out of a register)
 #define AA_LDS_LOAD( smem, off ) __hip_atomic_load( aa::tok::lds_at<uint32_t>( ( smem ), ( off ) ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP )
 #define AA_MUL24( a, b ) __umul24( ( a ), ( b ) )
+#define AA_POPC( v ) static_cast<uint32_t>( __builtin_popcount( v ) )
 #define AA_UBFE( v, off, width ) __builtin_amdgcn_ubfe( ( v ), ( off ), ( width ) )
+#define AA_BFI( m, a, b ) ( ( ( m ) & ( a ) ) | ( ~( m ) & ( b ) ) )       /* v_bfi_b32 */
 // The workgroup's dynamic LDS starts at LDS address 0 (the kernel has no static LDS), so an offset into smem IS the LDS
 // address: form the pointer from the number and spare the hot loop one "add the base symbol" per access.
 template <class T> __device__ inline __attribute__( ( address_space( 3 ) ) ) T * lds_at( uint8_t *, uint32_t off )
@@ -560,7 +588,9 @@ template <class T> __device__ inline __attribute__( ( address_space( 3 ) ) ) T *
 #define AA_LDS_ADD( smem, off, v ) aa::aa_host_add( aa::tok::lds_at<uint32_t>( ( smem ), ( off ) ), ( v ) )
 #define AA_LDS_LOAD( smem, off ) ( *aa::tok::lds_at<uint32_t>( ( smem ), ( off ) ) )
 #define AA_MUL24( a, b ) ( ( a ) * ( b ) )
+#define AA_POPC( v ) static_cast<uint32_t>( __builtin_popcount( v ) )
 #define AA_UBFE( v, off, width ) ( ( ( v ) >> ( off ) ) & ( ( 1u << ( width ) ) - 1u ) )
+#define AA_BFI( m, a, b ) ( ( ( m ) & ( a ) ) | ( ~( m ) & ( b ) ) )
 template <class T> inline T * lds_at( uint8_t * smem, uint32_t off ) { return reinterpret_cast<T *>( smem + off ); }
 #endif
 
@@ -585,13 +615,13 @@ AA_HD inline void store_mb_packed( const Frame & J, uint32_t mi, uint32_t nz_mas
 AA_HD inline void setup_block( Lane & L, const uint8_t * smem, uint32_t blk )
 {
   const V8 e = *reinterpret_cast<const V8 *>( smem + kBlockTabOff + 8 * blk );
-  const uint32_t a = e.x & 255u, l = ( e.x >> 8 ) & 255u, sel = ( e.x >> 16 ) & 255u;
+  const uint32_t sel = ( e.x >> 16 ) & 255u;
   L.blkaddr = kBlockTabOff + 8 * ( blk + 1 );
   L.nzsel = e.y;
   L.blkbit = 1u << ( e.x >> 24 );
-  const uint32_t ctx = ( ( L.ctxbits >> a ) & 1u ) + ( ( L.ctxbits >> l ) & 1u );
-  L.typeaddr = sel == 0 ? L.ytypeaddr : L.base + kProbs + ( sel == 1 ? UV : Y2 ) * 264u;
-  L.idx = sel == 0 ? L.yfirst : 0u;                         // Y blocks after a Y2 start at position 1 (tokens.cc:61)
+  const uint32_t ctx = AA_POPC( L.ctxbits & e.y );          // "above" flag + "left" flag
+  L.typeaddr = L.base + 8u * ( sel & ( kBlkIsY - 1u ) );
+  L.idx = ( sel & kBlkIsY ) ? L.yfirst : 0u;                // Y blocks after a Y2 start at position 1 (tokens.cc:61)
   L.rowaddr = L.typeaddr + L.idx * 33u + ctx * 11u;         // band of position 0 / 1 is 0 / 1
   L.rec = 0; L.paddr = L.rowaddr;
   L.nonzero = 0; L.mag = 0;
@@ -628,7 +658,7 @@ AA_HD inline void finish_frame( Lane & L, const Frame & J, const Heap & H, uint3
 template <bool PK>
 AA_HD inline void finish_partition( Lane & L, uint8_t * smem, const Frame & J, const Heap & H, uint32_t status )
 {
-  const uint32_t sh = J.mp_owner + part_off( J.mbw );
+  const uint32_t sh = J.mp_owner + part_off( J.mbw, true );
   if ( status != TOK_OK ) *lds_at<uint32_t>( smem, sh + offsetof( MpShared, status ) ) = status;
   uint32_t words = 0;
   if constexpr ( PK ) words = L.words + ( L.nchunks ? static_cast<uint32_t>( L.hdr - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) ) : 0u );
@@ -658,19 +688,50 @@ AA_HD inline void finish_partition( Lane & L, uint8_t * smem, const Frame & J, c
 #endif
 }
 
+// ---- the above-row non-zero flags of column `col` (9 bits: ctxbits bits 0-8); `abase` = address of the array -----------------
+template <bool SH>
+AA_HD inline uint32_t above_load( uint8_t * smem, uint32_t abase, uint32_t mbw, uint32_t col )
+{
+  if constexpr ( SH ) return *lds_at<const uint16_t>( smem, abase + 2u * col );
+  else {
+    const uint32_t yuv = *lds_at<const uint8_t>( smem, abase + col ), y2 = *lds_at<const uint8_t>( smem, abase + mbw + ( col >> 3 ) );
+    return yuv | ( ( ( y2 >> ( col & 7u ) ) & 1u ) << 8 );
+  }
+}
+template <bool SH>
+AA_HD inline void above_store( uint8_t * smem, uint32_t abase, uint32_t mbw, uint32_t col, uint32_t bits )
+{
+  if constexpr ( SH ) *lds_at<uint16_t>( smem, abase + 2u * col ) = static_cast<uint16_t>( bits );
+  else {
+    *lds_at<uint8_t>( smem, abase + col ) = static_cast<uint8_t>( bits );
+    const uint32_t at = abase + mbw + ( col >> 3 ), m = 1u << ( col & 7u );      // (this lane's own array: nobody else touches the byte)
+    const uint32_t old = *lds_at<const uint8_t>( smem, at );
+    *lds_at<uint8_t>( smem, at ) = static_cast<uint8_t>( ( bits & 0x100u ) ? old | m : old & ~m );
+  }
+}
+
+// plane `type` of the frame's token probabilities -> the slice's plane at `off` (66 words; the job's table is in HBM)
+AA_HD inline void load_plane( uint8_t * smem, uint32_t at, const Frame & J, uint32_t type )
+{
+  const AA_GLOBAL uint32_t * src = (const AA_GLOBAL uint32_t *) &J.job->fp.coeff_probs[type][0][0][0];
+  auto dst = lds_at<uint32_t>( smem, at );
+  for ( uint32_t k = 0; k < kPlaneBytes / 4; k++ ) dst[k] = src[k];
+}
+
 constexpr unsigned long long kMemWaitTicks = 200000000ull;      // 2 s of the 100 MHz clock: then the frame is handed back (TOK_NO_MEMORY)
 
 template <bool PK, bool MP = false>
 AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J, const Heap & H )
 {
   const bool mp = MP && J.mp_P > 1;                         // this frame has one lane per partition
-  uint16_t * const above = reinterpret_cast<uint16_t *>( smem + ( mp ? J.mp_owner : L.base ) + kAbove );
-  const uint32_t shared = J.mp_owner + part_off( J.mbw );   // (mp) MpShared
+  const uint32_t above = ( mp ? J.mp_owner : L.base ) + kAbove;
+  const uint32_t shared = J.mp_owner + part_off( J.mbw, true );   // (mp) MpShared
   if constexpr ( MP ) if ( L.rec == R_PARK ) {
     if ( AA_LDS_LOAD( smem, shared + offsetof( MpShared, left ) ) == 0u ) L.rec = R_DONE;
     return;
   }
   if ( L.rec == R_MBDONE ) {
+    above_store<MP>( smem, above, J.mbw, L.col, L.ctxbits );           // the column's flags as the macroblock leaves them
     L.mi++; L.col++; L.rec = R_MB;
     if constexpr ( MP ) { L.mi_real++; if ( mp ) *lds_at<uint32_t>( smem, shared + 4 * J.mp_p ) = L.mi; }       // completed: the row below may follow
   }
@@ -693,7 +754,7 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
     if ( L.col == J.mbw ) {
       L.col = 0; L.row++; L.ctxbits = 0;
       if constexpr ( MP ) if ( mp ) L.mi_real += ( J.mp_P - 1u ) * J.mbw;      // this lane's next row is P rows further down
-      if ( !mp && J.nparts > 1 ) switch_partition( L, smem, J, L.row % J.nparts );
+      if ( !mp && J.nparts > 1 ) switch_partition<MP>( L, smem, J, L.row % J.nparts );
     }
     if constexpr ( MP ) if ( mp && ( J.mp_p | L.row ) != 0 ) {
       // (r, c) needs the flags (r - 1, c) left behind: row r - 1 is the previous partition's -- its L.row-th row, or, for
@@ -703,7 +764,7 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
     }
     const uint32_t flags = smem[L.base + kMeta + ( L.mi & ( kMetaRing - 1 ) )];
     const uint32_t has_y2 = flags & AA_MB_HAS_Y2;
-    L.ctxbits = ( L.ctxbits & 0x01FF0000u ) | above[L.col];
+    L.ctxbits = ( L.ctxbits & 0x01FF0000u ) | above_load<MP>( smem, above, J.mbw, L.col );
     if ( !( flags & AA_MB_SKIP ) ) {
       // words of the chunk in use (packed storage; hdr = the next free word)
       const uint32_t used = PK && L.nchunks ? static_cast<uint32_t>( L.hdr - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) ) : 0u;
@@ -742,13 +803,14 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
         L.blk = L.hdr + 1; L.zzmask = 0;
       } else L.mb_first = L.blk_index;
       L.flags = flags; L.nz_mask = 0;
-      L.ytypeaddr = L.base + kProbs + ( has_y2 ? Y_AFTER_Y2 : Y_WITHOUT_Y2 ) * 264u;
+      const uint32_t kind = has_y2 ? Y_AFTER_Y2 : Y_WITHOUT_Y2;
+      if ( L.ykind != kind ) { load_plane( smem, L.base + kPlaneY, J, kind ); L.ykind = kind; }
       L.yfirst = has_y2 ? 1u : 0u;
       setup_block( L, smem, has_y2 ? 0u : 1u );
       return;
     }
     L.ctxbits &= has_y2 ? 0u : 0x01000100u;                 // a non-coded Y2 leaves its chain untouched (frame.cc:255-269)
-    above[L.col] = static_cast<uint16_t>( L.ctxbits );
+    above_store<MP>( smem, above, J.mbw, L.col, L.ctxbits );
     const uint32_t mi_rec = MP ? L.mi_real : L.mi;
     if constexpr ( PK ) store_mb_packed( J, mi_rec, 0, 0, flags | ( has_y2 ? AA_MB_LF_SKIP_INNER : 0u ) );
     else store_mb( J, mi_rec, 0, L.blk_index, flags | ( has_y2 ? AA_MB_LF_SKIP_INNER : 0u ) );
@@ -761,17 +823,35 @@ template <bool MP = false> AA_HD inline bool at_boundary( const Lane & L ) { ret
 
 // ---- one step: decode one bool (lanes with a node to decode; the others sit it out) -------------------------------------
 // Straight-line code: what the bit means comes out of the node's record as bit fields and is applied with arithmetic;
-// the only predicated regions are the stores.  A lone wave gets one issue slot every 4 cycles whatever the instruction, so
-// every instruction saved here is 4 cycles per bool.
+// the only predicated region is the coefficient store.  A lone wave gets one issue slot every 4 cycles whatever the
+// instruction -- vector, scalar, branch or wait -- so every instruction saved here is 4 cycles per bool.
+//
+// The END OF A BLOCK is not part of the step (it was, as a predicated region: ~55 issue slots that the wave paid whenever ANY of
+// its lanes was there -- four steps out of five at 22 lanes per wave).  A lane whose block has ended parks (R_BEND) and the wave
+// runs tok::block_end for all parked lanes every kBendEvery steps: the wave pays a quarter of those slots per step, a lane
+// waits (kBendEvery - 1) / 2 steps per block on average (a block is ~16 bools on inter frames, ~39 on key frames).
+#ifndef AA_STEP_VARIANT
+#define AA_STEP_VARIANT 0             /* build parameter (A/B runs of formulations of the step) */
+#endif
+#ifndef AA_BEND_EVERY
+#define AA_BEND_EVERY 4               /* build parameter (A/B runs): steps between block-end passes */
+#endif
+constexpr uint32_t kBendEvery = AA_BEND_EVERY;
+static_assert( kPeriod % kBendEvery == 0 && kBendEvery <= 8, "a period is a whole number of step groups; Frame::max_steps allows for 8" );
+
 template <bool PK, bool MP = false>
 AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
 {
+  (void) J;
   if ( L.rec < R_MBDONE ) {
     // the LDS reads of a step; all addresses were known at the end of the previous one
     const uint32_t prob = *lds_at<const uint8_t>( smem, L.paddr );
+#if AA_STEP_VARIANT & 2
+    const uint32_t raw = L.rawq;                  // (asked for a step ago)
+#else
     const uint32_t raw = *lds_at<const uint8_t>( smem, L.base + kStream + ( L.rpos & ( kRing - 1 ) ) );
+#endif
     const V8 rec = *lds_at<const V8>( smem, L.rec );
-    const V8 nextblk = *lds_at<const V8>( smem, L.blkaddr );
 
     // top the window up by one byte whenever one fits (sh >= 0): a decode shifts out at most 7 bits, so the 8 bits being
     // compared are always real and the refill is never on the critical path.  Mask arithmetic, no condition.
@@ -779,6 +859,9 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
     L.value |= ( raw << ( L.sh & 31 ) ) & room;
     L.sh -= static_cast<int32_t>( 8u & room );
     L.rpos -= room;
+#if AA_STEP_VARIANT & 2
+    L.rawq = *lds_at<const uint8_t>( smem, L.base + kStream + ( L.rpos & ( kRing - 1 ) ) );
+#endif
 
     // BoolDecoder::get (bool_decoder.hh:67-107)
     const uint32_t split = ( AA_MUL24( L.range - 1, prob ) + 256u ) >> 8;   // = 1 + (((range - 1) * prob) >> 8)
@@ -812,49 +895,59 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
     const uint32_t adv = AA_UBFE( h, 16, 1 );     // on to the next coefficient position?
     const uint32_t idx = L.idx + adv;
     const uint32_t band = static_cast<uint32_t>( kBandNib >> ( ( idx * 4 ) & 63 ) ) & 15u;
+#if AA_STEP_VARIANT & 1
+    // (a select by mask arithmetic: as a predicated region the wave pays a compare, two scalar instructions on the exec mask and
+    // the round trip between the vector and the scalar unit that goes with them)
+    const uint32_t rowaddr = AA_BFI( 0u - adv, L.typeaddr + band * 33u + AA_UBFE( h, 19, 5 ), L.rowaddr );
+#else
     const uint32_t rowaddr = adv ? L.typeaddr + band * 33u + AA_UBFE( h, 19, 5 ) : L.rowaddr;
+#endif
     const uint32_t paddr = ( ( h & H_ROWREL ) ? rowaddr : kXtab ) + AA_UBFE( h, 9, 5 );
     const bool bend = ( ( h & H_EOB ) | ( idx & 16u ) ) != 0;            // an EOB token, or position 16 reached
-    L.idx = idx; L.rowaddr = rowaddr; L.paddr = paddr; L.rec = h & 511u;
-
-    // ---- end of a block: a predicated region (exec mask; skipped when no lane of the wave is there), its results land
-    // in the lane's registers directly ----
-    {
-      if ( bend ) {
-        const bool nonzero = PK ? L.zzmask != 0 : L.nonzero != 0;
-        const uint32_t ctxbits = nonzero ? L.ctxbits | L.nzsel : L.ctxbits & ~L.nzsel;
-        if constexpr ( PK ) {
-          // the block's mask into the word kept for it; the word after its last value is kept for the next block
-          if ( nonzero ) { L.coeff_blocks++; *L.hdr = static_cast<int16_t>( L.zzmask ); L.hdr = L.blk; L.blk += 1; L.zzmask = 0; L.nz_mask |= L.blkbit; }
-        } else {
-          if ( nonzero ) { L.coeff_blocks++; L.blk += 16; L.blk_index++; L.blk_left--; zero_slot( L.blk ); L.nz_mask |= L.blkbit; }
-        }
-        const bool mbdone = L.blkaddr == kBlockTabOff + 8 * 25;
-        if ( mbdone ) {                           // the macroblock is complete: its record, its column's flags
-          *lds_at<uint16_t>( smem, ( MP && J.mp_P > 1 ? J.mp_owner : L.base ) + kAbove + 2 * L.col ) = static_cast<uint16_t>( ctxbits );
-          uint32_t flags = L.flags;
-          flags |= L.nz_mask ? AA_MB_HAS_NONZERO : ( ( flags & AA_MB_HAS_Y2 ) ? AA_MB_LF_SKIP_INNER : 0u );
-          if constexpr ( PK ) store_mb_packed( J, MP ? L.mi_real : L.mi, L.nz_mask, L.mb_first, flags );
-          else store_mb( J, MP ? L.mi_real : L.mi, L.nz_mask, L.mb_first, flags );
-        }
-        // the block after it (never a Y2)
-        const uint32_t a = nextblk.x & 255u, l = ( nextblk.x >> 8 ) & 255u, uv = ( nextblk.x >> 16 ) & 255u;
-        const uint32_t nctx = ( ( ctxbits >> a ) & 1u ) + ( ( ctxbits >> l ) & 1u );
-        L.typeaddr = uv ? L.base + kProbs + UV * 264u : L.ytypeaddr;
-        L.idx = uv ? 0u : L.yfirst;
-        L.rowaddr = L.paddr = L.typeaddr + L.idx * 33u + nctx * 11u;
-        L.ctxbits = ctxbits;
-        L.blkaddr += 8;
-        L.nzsel = nextblk.y;
-        L.blkbit = 1u << ( nextblk.x >> 24 );
-        L.nonzero = 0; L.mag = 0;
-        L.rec = mbdone ? static_cast<uint32_t>( R_MBDONE ) : 0u;
-      }
-    }
+    L.idx = idx; L.rowaddr = rowaddr; L.paddr = paddr;
+    L.rec = bend ? static_cast<uint32_t>( R_BEND ) : h & 511u;
   }
 }
 
-// One period of a wave: kPeriod steps, leaving the hot loop whenever a lane has reached a macroblock boundary.
+// ---- the end of a block, for the lanes that wait for it (R_BEND): the block's flags and mask word, the macroblock's record
+// if it was its last block, then the next block's contexts and first probability row ----
+template <bool PK, bool MP = false>
+AA_HD inline void block_end( Lane & L, uint8_t * smem, const Frame & J )
+{
+  if ( L.rec == R_BEND ) {
+    const V8 nextblk = *lds_at<const V8>( smem, L.blkaddr );
+    const bool nonzero = PK ? L.zzmask != 0 : L.nonzero != 0;
+    const uint32_t ctxbits = nonzero ? L.ctxbits | L.nzsel : L.ctxbits & ~L.nzsel;
+    if constexpr ( PK ) {
+      // the block's mask into the word kept for it; the word after its last value is kept for the next block
+      if ( nonzero ) { L.coeff_blocks++; *L.hdr = static_cast<int16_t>( L.zzmask ); L.hdr = L.blk; L.blk += 1; L.zzmask = 0; L.nz_mask |= L.blkbit; }
+    } else {
+      if ( nonzero ) { L.coeff_blocks++; L.blk += 16; L.blk_index++; L.blk_left--; zero_slot( L.blk ); L.nz_mask |= L.blkbit; }
+    }
+    const bool mbdone = L.blkaddr == kBlockTabOff + 8 * 25;
+    if ( mbdone ) {                           // the macroblock is complete: its record (its column's flags: at the boundary pass)
+      uint32_t flags = L.flags;
+      flags |= L.nz_mask ? AA_MB_HAS_NONZERO : ( ( flags & AA_MB_HAS_Y2 ) ? AA_MB_LF_SKIP_INNER : 0u );
+      if constexpr ( PK ) store_mb_packed( J, MP ? L.mi_real : L.mi, L.nz_mask, L.mb_first, flags );
+      else store_mb( J, MP ? L.mi_real : L.mi, L.nz_mask, L.mb_first, flags );
+    }
+    // the block after it (never a Y2)
+    const uint32_t sel = AA_UBFE( nextblk.x, 16, 8 );
+    const uint32_t nctx = AA_POPC( ctxbits & nextblk.y );
+    L.typeaddr = L.base + 8u * ( sel & ( kBlkIsY - 1u ) );
+    L.idx = ( sel >> 7 ) & L.yfirst;
+    L.rowaddr = L.paddr = L.typeaddr + L.idx * 33u + nctx * 11u;
+    L.ctxbits = ctxbits;
+    L.blkaddr += 8;
+    L.nzsel = nextblk.y;
+    L.blkbit = 1u << ( nextblk.x >> 24 );
+    L.nonzero = 0; L.mag = 0;
+    L.rec = mbdone ? static_cast<uint32_t>( R_MBDONE ) : 0u;
+  }
+}
+
+// One period of a wave: kPeriod steps in groups of kBendEvery, each group followed by the block-end pass if a lane waits for
+// one; the hot loop is left whenever a lane has reached a macroblock boundary (which only a block-end pass can bring about).
 // `prof` (diagnostics, may be null): [0] += clock ticks spent in boundary passes, [1] += boundary passes, [2] += steps of the wave
 template <bool PK, bool MP = false>
 AA_HD inline void run_period( Lane & L, uint8_t * smem, const Frame & J, const Heap & H, unsigned long long * prof = nullptr )
@@ -866,11 +959,15 @@ AA_HD inline void run_period( Lane & L, uint8_t * smem, const Frame & J, const H
       if ( at_boundary<MP>( L ) ) macroblock_boundary<PK, MP>( L, smem, J, H );
       if ( prof ) { prof[0] += AA_NOW() - tb; prof[1]++; }
       it++;                                                 // (a lane waiting for flags must not spin the period away)
-      if ( !AA_ANY( L.rec < R_MBDONE ) ) break;             // nobody has anything to decode
+      if ( !AA_ANY( L.rec < R_MBDONE ) ) break;             // nobody has anything to decode (no lane is at R_BEND out here)
     }
-    // leave the hot loop when a lane has completed a macroblock (asked by ALL lanes, outside the predicated step: wave-uniform)
     const uint32_t it0 = it;
-    do { step<PK, MP>( L, smem, J ); it++; } while ( it < kPeriod && !AA_ANY( L.rec == R_MBDONE ) );
+    do {
+      for ( uint32_t k = 0; k < kBendEvery; k++ ) step<PK, MP>( L, smem, J );
+      it += kBendEvery;
+      // (asked by ALL lanes, outside the predicated regions: wave-uniform)
+      if ( AA_ANY( L.rec == R_BEND ) ) block_end<PK, MP>( L, smem, J );
+    } while ( it < kPeriod && !AA_ANY( L.rec == R_MBDONE ) );
     if ( prof ) prof[2] += it - it0;
   }
   if ( L.rec != R_DONE ) L.steps += it;                     // (an upper bound: the iterations a lane sat out count too)
@@ -892,20 +989,24 @@ AA_HD inline uint32_t table_word( uint32_t k )
   return 0;
 }
 
+// SH: the layout of the above-row flags (tok::kAbove) -- that of the kernel the lane runs in: shared by the lanes of a frame
+// (one lane per partition, the MP instantiations) or the lane's own
+template <bool SH = false>
 AA_HD inline void begin_frame( Lane & L, uint8_t * smem, uint32_t base, const Frame & J )
 {
-  // lane LDS: probabilities, constants, zeroed above-row flags / partition save area
+  // lane LDS: the UV and Y2 probability planes (the Y plane: when the first coded macroblock says which), zeroed above-row
+  // flags / partition save area
   L.base = base;
   uint8_t * lds = smem + base;
-  const AA_GLOBAL uint32_t * src = (const AA_GLOBAL uint32_t *) &J.job->fp.coeff_probs[0][0][0][0];
-  uint32_t * dst = reinterpret_cast<uint32_t *>( lds + kProbs );
-  for ( uint32_t k = 0; k < 1056 / 4; k++ ) dst[k] = src[k];
-  if ( J.nparts > 1 ) for ( uint32_t k = 0; k < 128 / 4; k++ ) reinterpret_cast<uint32_t *>( lds + part_off( J.mbw ) )[k] = 0;
-  for ( uint32_t k = 0; k < J.mbw; k++ ) reinterpret_cast<uint16_t *>( lds + kAbove )[k] = 0;
+  load_plane( smem, base + kPlaneUV, J, UV );
+  load_plane( smem, base + kPlaneY2, J, Y2 );
+  L.ykind = kNoPlane;
+  if ( J.nparts > 1 ) for ( uint32_t k = 0; k < 128 / 4; k++ ) reinterpret_cast<uint32_t *>( lds + part_off( J.mbw, SH ) )[k] = 0;
+  for ( uint32_t k = 0; k < above_bytes( J.mbw, SH ); k++ ) lds[kAbove + k] = 0;
   L.mi = 0; L.col = 0; L.row = 0; L.ctxbits = 0; L.coeff_blocks = 0; L.steps = 0;
   L.flags = L.nz_mask = L.mb_first = L.yfirst = 0;
   L.idx = L.nonzero = L.nzsel = L.blkbit = L.mag = 0;
-  L.ytypeaddr = L.typeaddr = L.rowaddr = L.paddr = base;
+  L.typeaddr = L.rowaddr = L.paddr = base;
   L.blkaddr = kBlockTabOff;
   L.blk = nullptr; L.blk_index = 0; L.blk_left = 0; L.nchunks = 0; L.mem_since = 0;     // the first coded macroblock takes the first chunk
   L.hdr = nullptr; L.zzmask = 0; L.words = 0;
@@ -916,7 +1017,7 @@ AA_HD inline void begin_frame( Lane & L, uint8_t * smem, uint32_t base, const Fr
     if ( base == J.mp_owner ) {
       MpShared z {};
       z.left = J.mp_P;
-      *reinterpret_cast<MpShared *>( lds + part_off( J.mbw ) ) = z;
+      *reinterpret_cast<MpShared *>( lds + part_off( J.mbw, SH ) ) = z;
     }
   }
   start_partition( L, smem, J, J.mp_P > 1 ? J.mp_p : 0u );

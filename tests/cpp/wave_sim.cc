@@ -140,10 +140,16 @@ void wave_period( std::vector<aa::tok::Lane> & L, std::vector<aa::tok::Frame> & 
       it++;
       if ( !any( []( const Lane & l ) { return l.rec < R_MBDONE; } ) ) break;
     }
-    do {
-      for ( size_t k = 0; k < n; k++ ) if ( job_of[k] >= 0 ) step<PK, MP>( L[k], smem, F[k] );
-      it++;
-    } while ( it < kPeriod && !any( []( const Lane & l ) { return l.rec == R_MBDONE; } ) );
+    for ( ;; ) {
+      for ( uint32_t g = 0; g < kBendEvery; g++ )
+        for ( size_t k = 0; k < n; k++ ) if ( job_of[k] >= 0 ) step<PK, MP>( L[k], smem, F[k] );
+      it += kBendEvery;
+      if ( any( []( const Lane & l ) { return l.rec == R_BEND; } ) ) {
+        for ( size_t k = 0; k < n; k++ ) if ( job_of[k] >= 0 ) block_end<PK, MP>( L[k], smem, F[k] );
+        if ( any( []( const Lane & l ) { return l.rec == R_MBDONE; } ) ) break;
+      }
+      if ( it >= kPeriod ) break;
+    }
   }
   for ( size_t k = 0; k < n; k++ ) if ( job_of[k] >= 0 && L[k].rec != R_DONE ) L[k].steps += it;
 }
@@ -211,7 +217,7 @@ int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_
     for ( uint32_t k = 0; k < heap_chunks; k++ ) pool_push( H, nullptr, ( k * stride + 2u ) % heap_chunks, 1 );
   }
   // the workgroup's LDS: tables + one slice per lane
-  const uint32_t lane_bytes = lane_lds_bytes( mbw, multi );
+  const uint32_t lane_bytes = lane_lds_bytes( mbw, multi, mp );
   std::vector<uint8_t> store( kTablesBytes + size_t( lanes ) * lane_bytes + 16 );
   uint8_t * smem = reinterpret_cast<uint8_t *>( ( reinterpret_cast<uintptr_t>( store.data() ) + 15 ) & ~uintptr_t( 15 ) );
   std::memset( smem, 0xA5, kTablesBytes + size_t( lanes ) * lane_bytes );
@@ -266,7 +272,7 @@ int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_
           F[q] = frame_of_partition( &jobs[j]->J, d.part, L[idle[d.start + mp_owner_partition( &jobs[j]->J )]].base );
           if ( d.part == 0 ) mp_frames++;
         } else F[q] = frame_of( &jobs[j]->J );
-        begin_frame( L[q], smem, L[q].base, F[q] );
+        if ( mp ) begin_frame<true>( L[q], smem, L[q].base, F[q] ); else begin_frame<false>( L[q], smem, L[q].base, F[q] );
       }
     }
     uint64_t busy = 0;

@@ -25,7 +25,7 @@ def sim_lib():
     os.makedirs(BUILD, exist_ok=True)
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps):
         tmp = "%s.%d.tmp" % (LIB, os.getpid())             # (pytest-xdist workers may build at the same time: rename is atomic)
-        subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wextra", "-fPIC", "-shared"] + srcs + ["-o", tmp], check=True)
+        subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wextra", "-fPIC", "-shared"] + os.environ.get("AA_SIM_FLAGS", "").split() + srcs + ["-o", tmp], check=True)
         os.replace(tmp, LIB)
     L = C.CDLL(LIB)
     L.fsm_sim_create.restype = C.c_void_p

@@ -26,7 +26,7 @@ def wave_lib():
     os.makedirs(BUILD, exist_ok=True)
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps):
         tmp = "%s.%d.tmp" % (LIB, os.getpid())             # (pytest-xdist workers may build at the same time: rename is atomic)
-        subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wextra", "-fPIC", "-shared"] + srcs + ["-o", tmp], check=True)
+        subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wextra", "-fPIC", "-shared"] + os.environ.get("AA_SIM_FLAGS", "").split() + srcs + ["-o", tmp], check=True)
         os.replace(tmp, LIB)
     L = C.CDLL(LIB)
     L.wave_sim_run.argtypes = [C.c_uint16, C.c_uint16, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t),
