@@ -391,18 +391,21 @@ static int header_lanes() { const int v = parse_lanes_env(); return v ? v : 16; 
 // Token workgroups stay for as long as there is work, and what they leave of a CU -- LDS, registers -- is all the reconstruction
 // kernels (milliseconds each, on the high-priority stream) ever get.  The shape is therefore chosen for the reconstruction
 // kernels' sake as much as for the lanes':
-//   * `n` workgroups (waves) per CU, default 4 = ONE per SIMD: a worker wave holds 208 VGPRs, so a SIMD with one of them keeps
-//     304 free -- room for a loop-filter wave (256) or two intra waves; with two worker waves on a SIMD only k_recon_inter4 fits;
+//   * `n` workgroups (waves) per CU, default 3 (round 5; 4 = one per SIMD before): a worker wave holds ~215 VGPRs, so with three
+//     of them one SIMD of every CU is the reconstruction kernels' alone (all 512 registers: a loop-filter wave of 256 and more)
+//     and the other three keep ~300 free;
 //   * each workgroup asks for just over 1 / (n + 1) of the CU's LDS, so that an (n + 1)-th does not fit and n of them leave
-//     160 KB - n * request to the other kernels (n = 4: 30 KB, a loop-filter workgroup's 19 KB and an inter workgroup's 11 KB);
-//   * lanes per workgroup = what that request holds (26 at 1216 bytes per lane).  A step costs a wave the same whatever its
-//     width, but the rarer paths -- a block ended, a macroblock ended -- run whenever ANY lane needs them: wider waves step
-//     slower (measured in round 2: 16 lanes per wave with 6 waves per CU was the best shape when nothing else had to fit).
+//     160 KB - n * request to the other kernels (n = 3: 38.5 KB -- two loop-filter workgroups of 19 KB, or one and an inter
+//     workgroup's 11 KB; n = 4 left 30 KB);
+//   * lanes per workgroup = what that request holds: 37 at 1088 bytes per lane (1080p), 3 x 37 = 111 chains per CU where 4 x 29
+//     held 116.  A step costs a wave nearly the same whatever its width (the block-end pass is deferred and shared, tok_fsm.hh).
+//     Measured on MI355X, round 5 (profiles/r05_bench_sessions.md): 3 x 37 against 4 x 29 -- steady state 155 M against 140 M
+//     macroblocks/s, the host waits 126 ms per step for the compute stream instead of 180.
 // ALFALFA_AMD_WGS_PER_CU / ALFALFA_AMD_MAX_LANES: experiments.
 constexpr uint32_t kLdsPerCu = 160u * 1024u, kLdsGranule = 512u;
 static uint32_t env_u32( const char * name, uint32_t dflt ) { const char * e = getenv( name ); return e ? static_cast<uint32_t>( atoi( e ) ) : dflt; }
-static const uint32_t kWgsPerCu = std::max( 1u, std::min( 16u, env_u32( "ALFALFA_AMD_WGS_PER_CU", 4u ) ) );
-static const uint32_t kMaxLanes = std::max( 1u, std::min( 64u, env_u32( "ALFALFA_AMD_MAX_LANES", 32u ) ) );
+static const uint32_t kWgsPerCu = std::max( 1u, std::min( 16u, env_u32( "ALFALFA_AMD_WGS_PER_CU", 3u ) ) );
+static const uint32_t kMaxLanes = std::max( 1u, std::min( 64u, env_u32( "ALFALFA_AMD_MAX_LANES", 40u ) ) );
 struct TokenShape { int lanes; uint32_t lds; int per_cu; };
 static TokenShape token_launch_shape( uint32_t lane_bytes )
 {

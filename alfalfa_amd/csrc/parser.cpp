@@ -429,20 +429,22 @@ void Parser::parse_header_impl( const uint8_t * data, size_t size, aa_frame_head
   seg_map_reset_ = seg_reset;
 }
 
-void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa_mb_info * mbs, int16_t * coeff_out )
+// Everything of a frame behind its header: macroblock headers (first partition, `bd` continuing behind the frame header) and
+// tokens (DCT partitions), Frame::parse_macroblock_headers / parse_tokens (frame.cc:95-137).  Needs nothing of the stream's state
+// but what the header pre-pass put into `fp` -- and, for streams that use segmentation, the persistent segment map (`segmap`,
+// else null).  `above_nz`: scratch, 9 bytes per macroblock column.
+template <class BD>
+static void parse_body( BD & bd, const uint8_t * data, const FrameParams & fp, aa_mb_info * mbs, int16_t * coeff_out, uint8_t * segmap, uint8_t * above_nz,
+                        uint32_t & coeff_blocks_out, uint32_t & intra_mbs_out )
 {
-  FrameParams fp;
-  BoolReader bd;                 // the first partition's decoder continues right behind the frame header
-  parse_header_impl( data, size, hdr, fp, bd );
   const int nparts = fp.nparts;
   BoolReader parts[8];
   for ( int i = 0; i < nparts; i++ ) parts[i].reset( data + fp.part_off[i], fp.part_size[i] );
 
   // ---- macroblock headers + tokens ----
-  std::memset( above_nz_.data(), 0, above_nz_.size() );
+  const unsigned mbw = fp.mbw, mbh = fp.mbh;
+  std::memset( above_nz, 0, size_t( mbw ) * 9 );
   uint32_t coeff_blocks = 0, intra_mbs = 0;
-  const unsigned mbw = mbw_, mbh = mbh_;
-  uint8_t * segmap = seg_.enabled ? seg_.map.data() : nullptr;
 
   for ( unsigned row = 0; row < mbh; row++ ) {
     uint8_t left_nz[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -455,7 +457,7 @@ void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa
       if ( !( flags & AA_MB_INTER ) ) intra_mbs++;
 
       // ---- tokens: Macroblock::parse_tokens (macroblock.cc:475-502); storage order = parse order: Y2, Y0..15, U, V ----
-      uint8_t * anz = &above_nz_[static_cast<size_t>( col ) * 9];
+      uint8_t * anz = &above_nz[static_cast<size_t>( col ) * 9];
       mb.coeff_index = coeff_blocks;
       bool any = false;
       if ( skip ) {
@@ -495,9 +497,30 @@ void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa
       if ( has_y2 && !any ) mb.flags |= AA_MB_LF_SKIP_INNER;
     }
   }
+  coeff_blocks_out = coeff_blocks; intra_mbs_out = intra_mbs;
+}
+
+void Parser::parse( const uint8_t * data, size_t size, aa_frame_header & hdr, aa_mb_info * mbs, int16_t * coeff_out )
+{
+  FrameParams fp;
+  BoolReader bd;                 // the first partition's decoder continues right behind the frame header
+  parse_header_impl( data, size, hdr, fp, bd );
+  uint32_t coeff_blocks = 0, intra_mbs = 0;
+  parse_body( bd, data, fp, mbs, coeff_out, seg_.enabled ? seg_.map.data() : nullptr, above_nz_.data(), coeff_blocks, intra_mbs );
   hdr.num_coeff_blocks = coeff_blocks;
   hdr.num_intra_mbs = intra_mbs;
   hdr.has_intra_mb = intra_mbs != 0;
+}
+
+// ... from what the header pre-pass (Parser::parse_header) left in `fp`, the way a GPU lane takes a frame over: the first
+// partition's decoder resumed from the exported state.  For frames of streams WITHOUT segmentation (the persistent map is the
+// one piece of macroblock data that outlives a frame); any thread, no Parser.
+void parse_frame_body( const uint8_t * data, const FrameParams & fp, aa_mb_info * mbs, int16_t * coeff_out, uint8_t * above_nz, uint32_t * coeff_blocks, uint32_t * intra_mbs )
+{
+  BoolReader32 bd;
+  BoolState st; st.bitpos = fp.bd_bitpos; st.range = fp.bd_range; st.active = fp.bd_active;
+  bd.resume( data + fp.first_off, fp.first_size, st );
+  parse_body( bd, data, fp, mbs, coeff_out, nullptr, above_nz, *coeff_blocks, *intra_mbs );
 }
 
 } // namespace aa

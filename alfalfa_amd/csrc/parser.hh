@@ -117,4 +117,9 @@ private:
   std::vector<uint8_t> above_nz_;   // per MB column: 4 Y, 2 U, 2 V, 1 Y2
 };
 
+// A frame's macroblock headers and tokens from the header pre-pass's FrameParams alone (no Parser: any thread) -- what a GPU lane
+// does with a ParseJob, on a host core.  Streams without segmentation only (fp.seg_enabled == 0).  above_nz: 9 * fp.mbw bytes of
+// scratch; mbs: fp.mbw * fp.mbh records; coeff_out: worst case 25 * 16 int16 per macroblock.
+void parse_frame_body( const uint8_t * data, const FrameParams & fp, aa_mb_info * mbs, int16_t * coeff_out, uint8_t * above_nz, uint32_t * coeff_blocks, uint32_t * intra_mbs );
+
 } // namespace aa

@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -133,7 +135,9 @@ struct Batch {
   int max_mbw = 0, max_nparts = 1;
   hipStream_t ps = nullptr;
   int parse_stream_index = 0;
-  struct Item { aa_stream * s; int frame; bool live; };
+  // on_host: the frame was handed to a HOST LANE, not to the GPU's job queue (host_lane_run): its dense coefficient blocks are a
+  // pool piece of its own (host_dense: written by the worker before the frame's `done` word, read after it)
+  struct Item { aa_stream * s; int frame; bool live; bool on_host = false; size_t data_off = 0; uint8_t * host_dense = nullptr; size_t host_dense_bytes = 0; };
   std::vector<Item> items;                   // [n]; live: accepted and not released since
 };
 
@@ -202,6 +206,18 @@ struct aa_ctx {
   // call N - 2 was the last to read.  `used` is recorded on the compute stream behind the launches of the call that used the
   // array; `filled` on the utility stream behind its expansion kernels.  (Round 4 had the expansion on the compute stream: 12 x
   // 2.3 ms of a step's serial chain.)
+  // HOST LANES: host cores in the role of token lanes.  A frame handed to them (AA_SUBMIT_HOST on a call with many streams: the key
+  // frames a pipeline needs at once -- 35 ms on a core, 2 s as a chain on a GPU lane) has had its header pre-pass like every frame
+  // of the device route; a worker thread parses macroblock headers and tokens from the batch arena's pinned copy (aa::parse_frame_body),
+  // uploads the records to where the kernels expect them and then writes the SAME `done` word a GPU lane writes -- the submit call does
+  // not wait, and everything that waits for a frame's parse (aa_decode_batch, aa_stream_frame_header, release) waits for that word.
+  struct HostLanes {
+    struct Task { Batch * b; int item; };
+    std::mutex mu; std::condition_variable cv;
+    std::deque<Task> q;
+    std::vector<std::thread> threads;
+    bool stop = false;
+  } host_lanes;
   struct DenseBuf { uint8_t * p = nullptr; size_t bytes = 0; hipEvent_t used = nullptr, filled = nullptr; bool in_use = false; };
   DenseBuf dense_bufs[2];
   int next_dense_buf = 0;
@@ -333,6 +349,8 @@ struct aa_ctx {
   std::vector<Timed> pending;
   std::vector<hipEvent_t> free_events;
 };
+
+namespace { void host_lanes_start( aa_ctx * ctx ); void host_lanes_stop( aa_ctx * ctx ); }
 
 struct aa_stream {
   aa_ctx * ctx;
@@ -960,6 +978,10 @@ void release_records( aa_stream * s, FrameRec & f, bool deferred )
     ctx->tok.chunks_committed -= f.est_chunks; f.est_chunks = 0;
   }
   if ( Batch * b = f.batch ) {
+    if ( f.batch_item >= 0 && f.batch_item < static_cast<int>( b->items.size() ) ) {
+      Batch::Item & bi = b->items[f.batch_item];          // (a host lane's frame: its dense blocks; the wait above saw its `done` word)
+      if ( bi.host_dense ) { dev_free( ctx, bi.host_dense, bi.host_dense_bytes, true ); bi.host_dense = nullptr; }
+    }
     bool last;
     { std::lock_guard<std::mutex> g( ctx->pool_mu ); last = --b->live == 0; }
     if ( f.batch_item >= 0 && f.batch_item < static_cast<int>( b->items.size() ) ) b->items[f.batch_item].live = false;
@@ -1297,6 +1319,7 @@ static void ctx_free( aa_ctx * ctx )
 {
   (void) hipSetDevice( ctx->device );
   (void) tok_quiesce( ctx );
+  host_lanes_stop( ctx );
   (void) hipStreamSynchronize( ctx->compute ); (void) hipStreamSynchronize( ctx->copy );
   for ( auto ps : ctx->parse_streams ) if ( ps ) { (void) hipStreamSynchronize( ps ); (void) hipStreamDestroy( ps ); }
   for ( auto e : ctx->parse_idle ) if ( e ) (void) hipEventDestroy( e );
@@ -1677,10 +1700,11 @@ struct SubmitItem {
   aa_status status = AA_OK; std::string error;
   int frame_index = -1;
   bool seg_enabled = false, seg_reset = false;
+  bool on_host = false;     // goes to a host lane (aa_ctx::HostLanes), not to the GPU's job queue
 };
 
 // one frame of one stream: header pre-pass on the host, compressed bytes into the pinned arena, record block + raster slot
-aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_host, aa_dev_frame * dframes_host )
+aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_host, aa_dev_frame * dframes_host, bool want_host_lane )
 {
   aa_stream * s = it.s;
   aa_ctx * ctx = s->ctx;
@@ -1729,6 +1753,15 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
   rec.host_job = job;
   rec.dev_job = reinterpret_cast<const aa_dev_frame *>( b->dev + ( reinterpret_cast<uint8_t *>( job ) - b->host ) );
   rec.batch = b; rec.batch_item = item; rec.summary_pending = true;
+  if ( want_host_lane && !J.fp.seg_enabled ) {
+    // A host lane takes the frame (not one of a stream that uses segmentation: the persistent segment map is the one piece of
+    // macroblock data a frame inherits, and that stream's map lives on the device).  Its records are dense blocks in a piece of
+    // their own, like a host-parsed frame's: no chunk list, no packed words; and it counts as handed over from now on -- whoever
+    // releases it waits for the worker's `done` word.
+    it.on_host = true;
+    rec.packed_pos = nullptr; rec.chunk_list = nullptr;
+    rec.enqueued = true;
+  }
   it.frame_index = static_cast<int>( s->frames.size() );
   s->frames.push_back( std::move( rec ) );
   return AA_OK;
@@ -1757,6 +1790,7 @@ aa_status launch_tokens_of( aa_ctx * ctx, Batch * b )
     Batch::Item & it = b->items[i];
     if ( !it.live ) { if ( jobs_host[i].nmb ) { jobs_host[i].nmb = 0; dropped = true; } continue; }   // rejected by the pre-pass, or released since: the lane that draws it drops it
     FrameRec & r = it.s->frames[it.frame];
+    if ( it.on_host ) continue;                    // (a host lane's: no ticket, no chunks)
     r.enqueued = true;
     // what the frame is expected to store, in chunks: blocks per compressed byte as frames have turned out so far (the ratio
     // holds across key and inter frames and quantisers far better than blocks per macroblock), a margin, and the chunk its
@@ -1975,6 +2009,97 @@ aa_status submit_host_batch( aa_ctx * ctx, const aa_frame_in * frames, const std
 }
 } // namespace
 
+namespace {
+// ---- host lanes (aa_ctx::HostLanes) ----
+// One frame: macroblock headers + tokens from the arena's pinned copy (the header pre-pass left everything else in its ParseJob),
+// records to HBM where the frame's job record says they are, dense coefficient blocks to a pool piece of their own, then the
+// summary and -- last, behind the copies -- the `done` word.  Scratch buffers are the worker's own, kept from frame to frame.
+struct HostLaneScratch { std::vector<uint8_t> mbs, rows, above; std::vector<int16_t> coeffs; hipEvent_t ev = nullptr; };
+void host_lane_run( aa_ctx * ctx, Batch * b, int item, HostLaneScratch & S )
+{
+  const aa::ParseJob & J = reinterpret_cast<const aa::ParseJob *>( b->host )[item];
+  volatile aa::FrameSummary * sum = reinterpret_cast<volatile aa::FrameSummary *>( b->host + b->summaries_off ) + item;
+  Batch::Item & it = b->items[item];
+  const uint32_t mbw = J.fp.mbw, mbh = J.fp.mbh, nmb = mbw * mbh;
+  const size_t words_per_row = ( mbw + 63 ) / 64;
+  uint32_t status = aa::TOK_OK, blocks = 0, intra = 0, split = 0;
+  try {
+    S.mbs.resize( size_t( nmb ) * sizeof( aa_mb_info ) ); S.rows.resize( words_per_row * mbh * sizeof( unsigned long long ) );
+    S.above.resize( size_t( mbw ) * 9 ); S.coeffs.resize( size_t( nmb ) * 25 * 16 + 16 );
+  } catch ( const std::bad_alloc & ) { status = aa::TOK_HOST_FAILED; }
+  if ( status == aa::TOK_OK ) {
+    aa_mb_info * mbs = reinterpret_cast<aa_mb_info *>( S.mbs.data() );
+    unsigned long long * rows = reinterpret_cast<unsigned long long *>( S.rows.data() );
+    std::memset( static_cast<void *>( mbs ), 0, S.mbs.size() );
+    aa::parse_frame_body( b->host + it.data_off, J.fp, mbs, S.coeffs.data(), S.above.data(), &blocks, &intra );
+    std::memset( rows, 0, S.rows.size() );
+    for ( uint32_t r = 0; r < mbh; r++ ) for ( uint32_t c = 0; c < mbw; c++ ) {
+      const aa_mb_info & mb = mbs[r * mbw + c];
+      if ( !( mb.flags & AA_MB_INTER ) ) rows[r * words_per_row + ( c >> 6 )] |= 1ull << ( c & 63 );
+      else if ( mb.y_mode == aa::SPLITMV ) split = 1;
+    }
+    uint8_t * dense = nullptr;
+    const size_t dense_bytes = align_up( std::max<size_t>( size_t( blocks ) * 32, 32 ) );
+    hipError_t e = hipSuccess;
+    if ( dev_alloc( ctx, dense_bytes, &dense ) != AA_OK ) status = aa::TOK_HOST_FAILED;
+    else {
+      it.host_dense = dense; it.host_dense_bytes = dense_bytes;
+      // (the copy stream: the arena's upload -- which carries the job record as the pre-pass left it -- was queued there by the submit call)
+      e = hipMemcpyAsync( J.mbs, mbs, size_t( nmb ) * sizeof( aa_mb_info ), hipMemcpyHostToDevice, ctx->copy );
+      if ( e == hipSuccess ) e = hipMemcpyAsync( J.intra_rows, rows, words_per_row * mbh * sizeof( unsigned long long ), hipMemcpyHostToDevice, ctx->copy );
+      if ( e == hipSuccess && blocks ) e = hipMemcpyAsync( dense, S.coeffs.data(), size_t( blocks ) * 32, hipMemcpyHostToDevice, ctx->copy );
+      if ( e == hipSuccess ) {
+        // the frame's reconstruction job record (aa_dev_frame, in the arena behind the parse jobs): its blocks are here, not in the heap
+        uint8_t * job_dev = b->dev + align_up( size_t( b->n ) * sizeof( aa::ParseJob ) ) + size_t( item ) * sizeof( aa_dev_frame );
+        const int16_t * dense_ptr = reinterpret_cast<const int16_t *>( dense );
+        e = hipMemcpyAsync( job_dev + offsetof( aa_dev_frame, coeffs ), &dense_ptr, sizeof dense_ptr, hipMemcpyHostToDevice, ctx->copy );
+      }
+      if ( e == hipSuccess ) e = hipEventRecord( S.ev, ctx->copy );
+      if ( e == hipSuccess ) e = hipEventSynchronize( S.ev );
+      if ( e != hipSuccess ) status = aa::TOK_HOST_FAILED;
+    }
+  }
+  sum->num_coeff_blocks = blocks; sum->num_intra_mbs = intra; sum->has_split = split; sum->steps = 0; sum->num_chunks = 0; sum->packed_words = 0;
+  sum->status = status;
+  __atomic_thread_fence( __ATOMIC_RELEASE );
+  sum->done = 1u;
+}
+void host_lanes_main( aa_ctx * ctx )
+{
+  (void) hipSetDevice( ctx->device );
+  HostLaneScratch S;
+  (void) hipEventCreateWithFlags( &S.ev, hipEventDisableTiming );
+  auto & H = ctx->host_lanes;
+  for ( ;; ) {
+    aa_ctx::HostLanes::Task t;
+    {
+      std::unique_lock<std::mutex> g( H.mu );
+      H.cv.wait( g, [&] { return H.stop || !H.q.empty(); } );
+      if ( H.q.empty() ) break;                      // (stop: after the queue has been worked off -- somebody may wait for those frames)
+      t = H.q.front(); H.q.pop_front();
+    }
+    host_lane_run( ctx, t.b, t.item, S );
+  }
+  if ( S.ev ) (void) hipEventDestroy( S.ev );
+}
+void host_lanes_start( aa_ctx * ctx )
+{
+  auto & H = ctx->host_lanes;
+  if ( !H.threads.empty() ) return;
+  int nt = effective_cpus();
+  if ( const char * e = std::getenv( "ALFALFA_AMD_HOST_LANES" ) ) nt = std::max( 1, atoi( e ) );
+  for ( int t = 0; t < nt; t++ ) H.threads.emplace_back( host_lanes_main, ctx );
+}
+void host_lanes_stop( aa_ctx * ctx )
+{
+  auto & H = ctx->host_lanes;
+  { std::lock_guard<std::mutex> g( H.mu ); H.stop = true; }
+  H.cv.notify_all();
+  for ( auto & t : H.threads ) t.join();
+  H.threads.clear();
+}
+} // namespace
+
 aa_status aa_launch_tokens( aa_ctx * ctx, int max_batches, int * launched_out )
 {
   if ( !ctx ) return fail( AA_ERR_ARGUMENT, "aa_launch_tokens: null context" );
@@ -2020,6 +2145,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   for ( aa_stream * s : stream_order )
     if ( s->next_submit > static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_LOGIC, "aa_submit_frames: stream state is inconsistent" );
 
+  bool to_host_lanes = false;
   // ---- route: few chains -> the host's cores ----
   // A GPU lane decodes a bool in ~0.3 us, a host core in ~4 ns: one core is worth ~75 lanes, and a frame on a lane is a chain of
   // seconds whatever else the GPU does.  The GPU wins by holding 22 000 chains at once; a call with fewer streams than the host
@@ -2035,20 +2161,14 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
     // 4.8 M vs 2.4 M -- but 64 streams 9.8 M vs 14.9 M (64 workers do not scale on this host's memory system): the bound is 24
     const bool few = static_cast<int>( stream_order.size() ) <= std::min( nt, 24 );
     if ( !defer_tokens && !force_device && force_host && !few ) {
-      // many streams, and the caller wants them parsed NOW (AA_SUBMIT_HOST: frames that are needed at once -- the key frames of the
-      // group a pipeline starts with: 35 ms on a core, 2.4 s as a chain on a lane): the shared-arena path, every frame of the call
-      std::vector<int> all( n );
-      for ( int i = 0; i < n; i++ ) all[i] = i;
-      // (streams in the order of their first frame; frames of a stream in call order: as the per-stream route below)
-      aa_status first_error = AA_OK; std::string first_message;
-      if ( aa_status st = submit_host_batch( ctx, frames, all, items, nt ) ) { first_error = st; first_message = g_last_error; }
-      for ( int i = 0; i < n; i++ ) {
-        if ( frame_index_out ) frame_index_out[i] = items[i].status == AA_OK ? items[i].frame_index : -1;
-        if ( items[i].status != AA_OK && first_error == AA_OK ) { first_error = items[i].status; first_message = items[i].error; }
-      }
-      return first_error == AA_OK ? AA_OK : fail( first_error, first_message );
+      // many streams, and the caller wants them parsed by the host's cores (AA_SUBMIT_HOST: frames that are needed at once -- the key
+      // frames of the group a pipeline starts with: 35 ms on a core, 2 s as a chain on a lane): HOST LANES.  The frames take the
+      // device route below -- header pre-pass, arena, records in HBM -- but their tickets go to worker threads of the context, which
+      // finish them with the `done` word a GPU lane writes.  The call does not wait for them (round 4's version of this route did,
+      // ~1 s for a group's key frames, and the hand-overs behind it started that much later).
+      to_host_lanes = true;
     }
-    if ( !defer_tokens && !force_device && ( force_host || few ) ) {
+    if ( !defer_tokens && !force_device && !to_host_lanes && ( force_host || few ) ) {
       std::atomic<size_t> next { 0 };
       auto work = [&]() {
         for ( ;; ) {
@@ -2084,7 +2204,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
     // frames in this call are all key frames go to host workers (submit_host_batch: one shared arena, one upload), biggest
     // first, while the host part is expected to take no longer than `host_share_ms` on `nt` workers (a core parses ~24 MB of
     // compressed key-frame data per second); everything else takes the device route below.
-    if ( !defer_tokens && !force_device && ctx->host_share_ms > 0 ) {
+    if ( !defer_tokens && !force_device && !to_host_lanes && ctx->host_share_ms > 0 ) {
       std::vector<std::pair<size_t, aa_stream *>> cand;
       for ( aa_stream * s : stream_order ) {
         size_t bytes = 0; bool all_key = true;
@@ -2180,7 +2300,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
         for ( int i : by_stream[stream_order[k]] ) {
           SubmitItem & it = items[i];
           if ( broken ) { it.status = AA_ERR_LOGIC; it.error = "an earlier frame of this stream in the same call failed"; continue; }
-          it.status = submit_one( b.get(), it, i, jobs_host, dframes_host );
+          it.status = submit_one( b.get(), it, i, jobs_host, dframes_host, to_host_lanes );
           if ( it.status != AA_OK ) broken = true;
         }
       }
@@ -2210,7 +2330,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   }
   b->live = appended;
   b->items.resize( n );
-  for ( int i = 0; i < n; i++ ) b->items[i] = { items[i].s, items[i].frame_index, items[i].status == AA_OK };
+  for ( int i = 0; i < n; i++ ) { b->items[i] = { items[i].s, items[i].frame_index, items[i].status == AA_OK }; b->items[i].on_host = items[i].status == AA_OK && items[i].on_host; b->items[i].data_off = items[i].data_off; }
   b->head_bytes = jobs_bytes + dframes_bytes;
   b->max_mbw = max_mbw; b->max_nparts = max_nparts;
   if ( ctx->tok.lane_per_partition ) ctx->tok.mp_hint = std::max<uint32_t>( ctx->tok.mp_hint, static_cast<uint32_t>( max_nparts ) );   // (workgroups launched from now on leave that many lanes per ticket)
@@ -2222,6 +2342,10 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
     ~Abandon() {
       if ( !armed ) return;
       const std::string keep = g_last_error;
+      {                                                     // (host lanes' frames that no worker was given: nobody will write their `done` word)
+        volatile aa::FrameSummary * sums = reinterpret_cast<volatile aa::FrameSummary *>( b->host + b->summaries_off );
+        for ( size_t i = 0; i < b->items.size(); i++ ) if ( b->items[i].on_host ) { sums[i].status = aa::TOK_HOST_FAILED; sums[i].done = 1u; }
+      }
       std::vector<Batch::Item> its = b->items;              // (the batch dies with its last frame)
       for ( auto & it : its ) if ( it.live ) release_records( it.s, it.s->frames[it.frame], true );
       g_last_error = keep;
@@ -2267,7 +2391,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   // after the call -- a rejected frame has nobody who would wait for its lane before the arena is recycled)
   uint32_t * launch_order = seg_order + n;
   int n_order = 0;
-  for ( int i = 0; i < n; i++ ) if ( items[i].status == AA_OK ) launch_order[n_order++] = static_cast<uint32_t>( i );
+  for ( int i = 0; i < n; i++ ) if ( items[i].status == AA_OK && !items[i].on_host ) launch_order[n_order++] = static_cast<uint32_t>( i );      // (host lanes' frames: no ticket)
   std::stable_sort( launch_order, launch_order + n_order, [&]( uint32_t a, uint32_t b ) { return items[a].size > items[b].size; } );
   const uint32_t * launch_order_dev = reinterpret_cast<const uint32_t *>( raw->dev + ( reinterpret_cast<uint8_t *>( launch_order ) - raw->host ) );
 
@@ -2279,7 +2403,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   HIP_TRY( hipStreamWaitEvent( ps, up, 0 ) );
   ctx->free_events.push_back( up );
   const aa::ParseJob * jobs_dev = reinterpret_cast<const aa::ParseJob *>( raw->dev );
-  {
+  if ( n_order ) {
     LaunchTimer t( ctx, 3, ps );
     if ( int e = aa::launch_parse_mb_headers( jobs_dev, launch_order_dev, n_order, ps ) ) return hip_fail( static_cast<hipError_t>( e ), "k_parse_mb_headers" );
   }
@@ -2298,6 +2422,18 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   HIP_TRY( hipEventRecord( ctx->parse_idle[pick], ps ) );
   ctx->deferred.push_back( raw );
   abandon.armed = false;                           // the batch is on the books: from here on a failure leaves a consistent state
+  // the frames of the host lanes: behind the arena's upload on the copy stream (a worker patches its frame's job record there)
+  {
+    int n_host = 0;
+    for ( int i = 0; i < n; i++ ) if ( raw->items[i].on_host ) n_host++;
+    if ( n_host ) {
+      host_lanes_start( ctx );
+      { std::lock_guard<std::mutex> g( ctx->host_lanes.mu ); for ( int i = 0; i < n; i++ ) if ( raw->items[i].on_host ) ctx->host_lanes.q.push_back( { raw, i } ); }
+      ctx->host_lanes.cv.notify_all();
+      ctx->stats.host_routed_frames += static_cast<uint64_t>( n_host );
+      if ( std::find( ctx->tok.inflight.begin(), ctx->tok.inflight.end(), raw ) == ctx->tok.inflight.end() ) ctx->tok.inflight.push_back( raw );
+    }
+  }
   if ( !defer_tokens ) if ( aa_status st = launch_tokens_of( ctx, raw ) ) return st;
   if ( first_error != AA_OK ) return fail( first_error, first_message );
   return AA_OK;
@@ -2348,7 +2484,7 @@ static aa_status resolve_summary( aa_stream * s, FrameRec & r )
           if ( !vb->items[i].live ) continue;
           aa_stream * vs = vb->items[i].s;
           FrameRec & v = vs->frames[vb->items[i].frame];
-          if ( &v == &r || !v.enqueued || v.records_released || v.chunks_returned || !sums[i].done || vb->items[i].frame < vs->next_submit ) continue;
+          if ( &v == &r || vb->items[i].on_host || !v.enqueued || v.records_released || v.chunks_returned || !sums[i].done || vb->items[i].frame < vs->next_submit ) continue;     // (a host lane's frame holds no chunks)
           T.pending_lists.push_back( v.chunk_list );
           have += static_cast<int32_t>( sums[i].num_chunks );
           v.chunks_returned = true; v.summary_pending = true;
@@ -2375,6 +2511,7 @@ static aa_status resolve_summary( aa_stream * s, FrameRec & r )
     if ( std::find( T.inflight.begin(), T.inflight.end(), b ) == T.inflight.end() ) T.inflight.push_back( b );
     if ( aa_status st = tok_service( ctx ) ) return st;
   }
+  if ( sum->status == aa::TOK_HOST_FAILED ) return fail( AA_ERR_HIP, "host lane: the frame's records could not be placed in device memory" );
   if ( sum->status == aa::TOK_STEP_BOUND ) return fail( AA_ERR_HIP, "device parser: a token lane exceeded the step bound of its frame size (records are not valid)" );
   r.hdr.num_coeff_blocks = sum->num_coeff_blocks;
   r.hdr.num_intra_mbs = sum->num_intra_mbs;

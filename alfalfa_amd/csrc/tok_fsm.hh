@@ -91,7 +91,8 @@ struct FrameSummary {
   uint32_t done;                // 1: the token lane is through with this frame
   uint32_t packed_words;        // packed storage (see "Packed coefficients"): 16-bit words the frame's coefficients take; 0: stored dense
 };
-enum : uint32_t { TOK_OK = 0, TOK_STEP_BOUND = 1, TOK_NO_MEMORY = 2 };
+enum : uint32_t { TOK_OK = 0, TOK_STEP_BOUND = 1, TOK_NO_MEMORY = 2,
+                  TOK_HOST_FAILED = 3 };    // (written by a host lane -- runtime.cpp -- that could not place the frame's records)
 
 // ---- atomics: agent scope on the GPU (coherent across the XCDs' L2s); the host simulation runs one lane at a time ----
 #if defined( __HIP_DEVICE_COMPILE__ )
@@ -421,7 +422,6 @@ struct Lane {
   uint32_t value, range;
   int32_t sh;
   uint32_t rpos, rend;            // next stream byte to shift in / end of the partition (offsets into the frame)
-  uint32_t rawq;                  // ... and that byte, read from the ring as soon as rpos is known (AA_STEP_VARIANT & 2)
   uint32_t wpos;                  // stream ring holds [wpos - kRing, wpos)
   uint32_t mwpos;                 // flag ring holds macroblocks [mwpos - kMetaRing, mwpos)
   uint32_t pend_wpos, pend_mwpos; // what the chunks in flight are for (kNoPend: nothing in flight)
@@ -512,7 +512,6 @@ AA_HD inline void start_partition( Lane & L, uint8_t * smem, const Frame & J, ui
   uint32_t v = 0;
   for ( int k = 0; k < 4; k++ ) { v = ( v << 8 ) | smem[L.base + kStream + ( L.rpos & ( kRing - 1 ) )]; L.rpos++; }
   L.value = v; L.sh = -8; L.range = 255;
-  L.rawq = smem[L.base + kStream + ( L.rpos & ( kRing - 1 ) )];
 }
 
 template <bool SH = false>
@@ -527,7 +526,6 @@ AA_HD inline void switch_partition( Lane & L, uint8_t * smem, const Frame & J, u
   L.value = t[0]; L.range = t[1] & 255u; L.sh = static_cast<int32_t>( t[1] >> 8 ) - 64; L.rpos = t[2];
   L.rend = J.job->fp.part_off[p] + J.job->fp.part_size[p];
   prime_stream( L, smem, J );
-  L.rawq = smem[L.base + kStream + ( L.rpos & ( kRing - 1 ) )];
 }
 
 // ---- every kPeriod steps, all lanes together: land the chunks requested a period ago, request the next ---------------
@@ -830,9 +828,6 @@ template <bool MP = false> AA_HD inline bool at_boundary( const Lane & L ) { ret
 // its lanes was there -- four steps out of five at 22 lanes per wave).  A lane whose block has ended parks (R_BEND) and the wave
 // runs tok::block_end for all parked lanes every kBendEvery steps: the wave pays a quarter of those slots per step, a lane
 // waits (kBendEvery - 1) / 2 steps per block on average (a block is ~16 bools on inter frames, ~39 on key frames).
-#ifndef AA_STEP_VARIANT
-#define AA_STEP_VARIANT 0             /* build parameter (A/B runs of formulations of the step) */
-#endif
 #ifndef AA_BEND_EVERY
 #define AA_BEND_EVERY 4               /* build parameter (A/B runs): steps between block-end passes */
 #endif
@@ -846,11 +841,7 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
   if ( L.rec < R_MBDONE ) {
     // the LDS reads of a step; all addresses were known at the end of the previous one
     const uint32_t prob = *lds_at<const uint8_t>( smem, L.paddr );
-#if AA_STEP_VARIANT & 2
-    const uint32_t raw = L.rawq;                  // (asked for a step ago)
-#else
     const uint32_t raw = *lds_at<const uint8_t>( smem, L.base + kStream + ( L.rpos & ( kRing - 1 ) ) );
-#endif
     const V8 rec = *lds_at<const V8>( smem, L.rec );
 
     // top the window up by one byte whenever one fits (sh >= 0): a decode shifts out at most 7 bits, so the 8 bits being
@@ -859,9 +850,6 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
     L.value |= ( raw << ( L.sh & 31 ) ) & room;
     L.sh -= static_cast<int32_t>( 8u & room );
     L.rpos -= room;
-#if AA_STEP_VARIANT & 2
-    L.rawq = *lds_at<const uint8_t>( smem, L.base + kStream + ( L.rpos & ( kRing - 1 ) ) );
-#endif
 
     // BoolDecoder::get (bool_decoder.hh:67-107)
     const uint32_t split = ( AA_MUL24( L.range - 1, prob ) + 256u ) >> 8;   // = 1 + (((range - 1) * prob) >> 8)
@@ -895,13 +883,10 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
     const uint32_t adv = AA_UBFE( h, 16, 1 );     // on to the next coefficient position?
     const uint32_t idx = L.idx + adv;
     const uint32_t band = static_cast<uint32_t>( kBandNib >> ( ( idx * 4 ) & 63 ) ) & 15u;
-#if AA_STEP_VARIANT & 1
-    // (a select by mask arithmetic: as a predicated region the wave pays a compare, two scalar instructions on the exec mask and
-    // the round trip between the vector and the scalar unit that goes with them)
+    // (a select by mask arithmetic: written as a conditional the compiler makes it a predicated region -- a compare, two scalar
+    // instructions on the exec mask and the round trip between the vector and the scalar unit that goes with them; measured on
+    // MI355X: 4 % of a wave step.  Asking for the stream byte a step ahead, tried in the same session, bought nothing.)
     const uint32_t rowaddr = AA_BFI( 0u - adv, L.typeaddr + band * 33u + AA_UBFE( h, 19, 5 ), L.rowaddr );
-#else
-    const uint32_t rowaddr = adv ? L.typeaddr + band * 33u + AA_UBFE( h, 19, 5 ) : L.rowaddr;
-#endif
     const uint32_t paddr = ( ( h & H_ROWREL ) ? rowaddr : kXtab ) + AA_UBFE( h, 9, 5 );
     const bool bend = ( ( h & H_EOB ) | ( idx & 16u ) ) != 0;            // an EOB token, or position 16 reached
     L.idx = idx; L.rowaddr = rowaddr; L.paddr = paddr;

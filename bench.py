@@ -259,16 +259,11 @@ class Pipeline:
         env, F = self.env, self.F
         target = self.decoded + steps
         if env.get("urgent_keys_on_host") and self.keys == self.decoded and self.decoded < target:
-            # An EMPTY pipeline.  The key frames of the group it starts with take the host route (a blocking second of the host's
-            # cores); the later groups' key frames are 2.4-s chains on the lanes whatever happens -- so they are handed to the lanes
-            # FIRST (asynchronous), and are 2.7 s old when the first group has been reconstructed instead of just begun.
-            # (the next three groups only: a hand-over costs the host ~0.1 s, and every one of them delays the first group's second of host parsing)
-            g0 = self.decoded
-            last = min(target, g0 + min(self.K, 4))
-            for g in range(g0 + 1, last):
-                self._submit_keys(g)
-            self._submit_keys(g0, urgent=True)
-            self.keys = max(g0 + 1, last)
+            # An EMPTY pipeline.  The key frames of the group it starts with are needed at once and are the longest chains there are
+            # (2 s on a GPU lane, 35 ms on a host core): they go to the context's HOST LANES (AA_SUBMIT_HOST; the call does not wait
+            # for them).  The loop below then hands that group's inter frames and the later groups' key frames to the GPU lanes as ever.
+            self._submit_keys(self.decoded, urgent=True)
+            self.keys = self.decoded + 1
         while self.decoded < target:
             while True:
                 can_inter = self.inter_h < min(target, self.decoded + self.D + self.H, self.keys)
@@ -372,7 +367,10 @@ def calibrate(env, streams):
     # (no host batch measured: the library's own assumption then, 24 KB/ms per usable core)
     rate_kb_per_ms = env["host_rate_kb_per_ms"] or 24.0 * aa.capi.lib().aa_host_cpus()
     est_ms = key_bytes_total / (rate_kb_per_ms * 1e3)
-    env["urgent_keys_on_host"] = bool(S > 24 and not env["args"].no_urgent_host and (env["args"].urgent_host or est_ms <= 500.0))
+    # Round 5: that route no longer blocks (HOST LANES: the frames take the device route's pre-pass and arena, worker threads of the
+    # context finish them with the `done` word a GPU lane writes) -- the first group's key frames go to the host's cores whenever there
+    # are more streams than a small call has, while the lanes take that group's inter frames and the later groups' key frames.
+    env["urgent_keys_on_host"] = bool(S > 24 and not env["args"].no_urgent_host)
     env["urgent_host_estimate_ms"] = round(est_ms)
     ctx.kernel_stats(reset=True)
     env["packed_storage"] = {"key_frame_bytes_per_block": round(key_bpb, 2), "inter_frame_bytes_per_block": round(inter_bpb, 2), "dense_bytes_per_block": 32} if packed else None

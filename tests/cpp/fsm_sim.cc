@@ -199,6 +199,34 @@ int fsm_sim_handover_check( const uint8_t * data, size_t size, int n, int look )
   return bad;
 }
 
+// A host core in the role of a token lane (runtime.cpp, host lanes): Parser::parse_header + aa::parse_frame_body must produce the
+// records Parser::parse produces.  The frames of a stream one after the other (the handle keeps a second parser: header state only).
+// -> 0 equal, 1 records differ, 2 coefficient blocks differ, 3 counts differ, 4 not eligible (segmentation: not checked), 5 frame rejected by both parsers, 6 by one
+struct BodySim { aa::Parser full, hdr_only; BodySim( uint16_t w, uint16_t h ) : full( w, h ), hdr_only( w, h ) {} };
+void * fsm_sim_body_create( uint16_t w, uint16_t h ) { return new BodySim( w, h ); }
+void fsm_sim_body_destroy( void * p ) { delete static_cast<BodySim *>( p ); }
+int fsm_sim_body_frame( void * handle, const uint8_t * data, size_t size )
+{
+  BodySim & S = *static_cast<BodySim *>( handle );
+  const size_t nmb = size_t( S.full.mb_width() ) * S.full.mb_height();
+  std::vector<aa_mb_info> m1( nmb ), m2( nmb );
+  std::vector<int16_t> c1( nmb * 25 * 16 + 16 ), c2( nmb * 25 * 16 + 16 );
+  std::vector<uint8_t> above( size_t( S.full.mb_width() ) * 9 );
+  std::memset( static_cast<void *>( m1.data() ), 0, nmb * sizeof( aa_mb_info ) ); std::memset( static_cast<void *>( m2.data() ), 0, nmb * sizeof( aa_mb_info ) );
+  aa_frame_header h1, h2; aa::FrameParams fp;
+  int e1 = 0, e2 = 0;
+  try { S.full.parse( data, size, h1, m1.data(), c1.data() ); } catch ( const aa::ParseError & e ) { e1 = e.code; }
+  try { S.hdr_only.parse_header( data, size, h2, fp ); } catch ( const aa::ParseError & e ) { e2 = e.code; }
+  if ( e1 || e2 ) return e1 == e2 ? 5 : 6;        // rejected by both (the same way) / by one only
+  if ( fp.seg_enabled ) return 4;
+  uint32_t blocks = 0, intra = 0;
+  aa::parse_frame_body( data, fp, m2.data(), c2.data(), above.data(), &blocks, &intra );
+  if ( blocks != h1.num_coeff_blocks || intra != h1.num_intra_mbs ) return 3;
+  if ( std::memcmp( m1.data(), m2.data(), nmb * sizeof( aa_mb_info ) ) ) return 1;
+  if ( std::memcmp( c1.data(), c2.data(), size_t( blocks ) * 32 ) ) return 2;
+  return 0;
+}
+
 // the pool offers only `chunks` coefficient chunks to the next frames (0: plenty) -> a frame that needs more is handed back
 // with TOK_NO_MEMORY (fsm_sim_frame returns 202)
 void fsm_sim_set_pool_chunks( void * handle, uint32_t chunks ) { static_cast<Sim *>( handle )->pool_chunks = chunks; }

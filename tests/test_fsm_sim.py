@@ -41,6 +41,10 @@ def sim_lib():
     L.fsm_sim_set_packed.argtypes = [C.c_void_p, C.c_int]
     L.fsm_sim_last_words.argtypes = [C.c_void_p]
     L.fsm_sim_last_words.restype = C.c_uint32
+    L.fsm_sim_body_create.restype = C.c_void_p
+    L.fsm_sim_body_create.argtypes = [C.c_uint16, C.c_uint16]
+    L.fsm_sim_body_destroy.argtypes = [C.c_void_p]
+    L.fsm_sim_body_frame.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     return L
 
 
@@ -179,3 +183,36 @@ def test_coefficient_pool_runs_dry_and_the_frame_is_handed_back():
     sim3.L.fsm_sim_set_pool_chunks(sim3.h, took)
     h3, mb3, cf3, _ = sim3.frame(frames[0])
     assert h3 == hh and (cf3 == hcf.reshape(-1)).all()
+
+
+def body_check(w, h, frames):
+    """-> frames checked (streams that switch segmentation on are not eligible for host lanes from there on)"""
+    L = sim_lib()
+    hnd = L.fsm_sim_body_create(w, h)
+    checked = 0
+    try:
+        for i, fr in enumerate(frames):
+            rc = L.fsm_sim_body_frame(hnd, fr, len(fr))
+            assert rc in (0, 4, 5), (i, rc)
+            checked += rc == 0
+    finally:
+        L.fsm_sim_body_destroy(hnd)
+    return checked
+
+
+def test_host_lanes_parse_a_frame_from_its_header_prepass_alone():
+    """runtime.cpp's host lanes (AA_SUBMIT_HOST on a big call: host cores take frames the way GPU token lanes do) run
+    Parser::parse_header at submit time and aa::parse_frame_body on a worker thread: together they must give Parser::parse's
+    records -- goldens, the synthetic feature streams (multi-partition, SPLITMV, golden / altref), truncated frames."""
+    import vp8_synth
+    from test_parser_vs_oracle import truncated
+    total = 0
+    for name in sorted(GOLDEN):
+        w, h, frames = golden_frames(name)
+        total += body_check(w, h, frames)
+        total += body_check(w, h, truncated(frames))
+    sizes = [(96, 80), (33, 17), (64, 64), (175, 143), (16, 16), (200, 48), (320, 176), (48, 256)]
+    for seed in range(200, 232):
+        w, h = sizes[seed % len(sizes)]
+        total += body_check(w, h, vp8_synth.feature_stream(w, h, seed, 8).frames)
+    assert total >= 150, total

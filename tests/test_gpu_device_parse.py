@@ -444,3 +444,58 @@ def test_key_frames_of_big_calls_are_parsed_by_host_workers(gpu_ctx, monkeypatch
         assert sha256(off[25].raster_bytes(0)) == GOLDEN["qcif_q30"]["raster_sha256"][0]
     finally:
         gpu_ctx.set_host_share_ms(80)
+
+
+def test_host_lanes_take_a_big_calls_frames_without_blocking_it(gpu_ctx, monkeypatch):
+    """AA_SUBMIT_HOST on a call with many streams: HOST LANES.  The frames take the device route's pre-pass (frame indices at
+    once, inter frames of the same streams can follow immediately), worker threads of the context parse them the way a GPU lane
+    does and finish them with the same `done` word; records and rasters are those of the all-device route -- key frames and
+    inter frames, multi-partition frames, truncated frames; frames of a stream that uses segmentation stay on the GPU's lanes
+    (the persistent map lives there); a frame released before its worker got to it is waited for, not lost."""
+    import time
+    import vp8_synth
+    monkeypatch.delenv("ALFALFA_AMD_ROUTE", raising=False)
+    names = ["qcif_q30_lf24", "cif_q60_lf40s5", "synth_175x143_s3", "w200_q40_lf63s7", "qcif_q30", "qvga_q100"]
+    streams = [golden_frames(names[i % len(names)]) for i in range(36)]
+    nf = 3
+    hl = [aa.Decoder(gpu_ctx, w, h) for w, h, _ in streams]
+    dev = [aa.Decoder(gpu_ctx, w, h) for w, h, _ in streams]
+    before = gpu_ctx.kernel_stats()["host_routed_frames"]
+    t0 = time.perf_counter()
+    idx = gpu_ctx.submit_frames([(d, st[2][0]) for d, st in zip(hl, streams)], threads=8, route="host")
+    assert idx == [0] * 36
+    # the inter frames of the same streams at once, on the default route (the lanes): nothing waits for the key frames' parse
+    gpu_ctx.submit_frames([(d, st[2][f]) for d, st in zip(hl, streams) for f in (1, 2)], threads=8)
+    routed = gpu_ctx.kernel_stats()["host_routed_frames"] - before
+    # (streams of goldens that use segmentation -- cif_q60_lf40s5 and friends -- are not eligible; most are)
+    assert 12 <= routed <= 36, routed
+    gpu_ctx.submit_frames([(d, st[2][f]) for d, st in zip(dev, streams) for f in range(nf)], threads=8, route="device")
+    for i in range(36):
+        for f in range(nf):
+            assert_records_equal(hl[i].read_records(f), dev[i].read_records(f), "stream %d frame %d" % (i, f))
+    for f in range(nf):
+        gpu_ctx.decode_batch(hl, [f] * len(hl)); gpu_ctx.decode_batch(dev, [f] * len(dev))
+    for i in range(36):
+        want = GOLDEN[names[i % len(names)]]["raster_sha256"][nf - 1]
+        assert sha256(hl[i].raster_bytes(nf - 1)) == sha256(dev[i].raster_bytes(nf - 1)) == want, i
+    # whole feature streams (SPLITMV, golden / altref, 1-8 partitions; the segmentation seeds fall back to the lanes) through host lanes
+    sizes = [(96, 80), (33, 17), (64, 64), (175, 143), (16, 16), (200, 48), (320, 176), (48, 256)]
+    for seed in range(200, 212):
+        w, h = sizes[seed % len(sizes)]
+        frames = vp8_synth.feature_stream(w, h, seed, 6).frames
+        ds = [aa.Decoder(gpu_ctx, w, h) for _ in range(26)]
+        gpu_ctx.submit_frames([(d, fr) for d in ds for fr in frames], threads=8, route="host")
+        host = aa.Parser(w, h)
+        for f, fr in enumerate(frames):
+            want = host.parse(fr)
+            for d in (ds[0], ds[25]):
+                assert_records_equal(d.read_records(f), want, "seed %d frame %d" % (seed, f))
+    # released before the worker got to it (a decoder dropped right after the hand-over): the release waits for the `done` word
+    w, h, frames = golden_frames("qcif_q30")
+    ds = [aa.Decoder(gpu_ctx, w, h) for _ in range(40)]
+    gpu_ctx.submit_frames([(d, frames[0]) for d in ds], threads=4, route="host")
+    del ds
+    ds = [aa.Decoder(gpu_ctx, w, h) for _ in range(40)]
+    gpu_ctx.submit_frames([(d, frames[0]) for d in ds], threads=4, route="host")
+    gpu_ctx.decode_batch(ds, [0] * 40)
+    assert sha256(ds[39].raster_bytes(0)) == GOLDEN["qcif_q30"]["raster_sha256"][0]
