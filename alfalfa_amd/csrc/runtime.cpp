@@ -124,8 +124,6 @@ struct Batch {
   // Two-phase form (AA_SUBMIT_DEFER_TOKENS): the macroblock-header kernel has been queued, the token kernel has not -- the
   // coefficient blocks (9/10 of a frame's records) are only allocated when it is (aa_launch_tokens, or the first call that
   // needs the frame's records).
-  bool host_parsed = false;                  // the frames were parsed by host workers (submit_host_batch): the arena holds their finished records,
-  bool upload_waited = false;                // hdr_done = its upload; the compute stream has been made to wait for it
   bool tokens_pending = false;
   bool patch_jobs = false;                   // the jobs in HBM lack the coefficient pointers (two-phase form)
   size_t head_bytes = 0;                     // parse jobs + reconstruction job records at the start of the arena
@@ -217,6 +215,8 @@ struct aa_ctx {
     std::deque<Task> q;
     std::vector<std::thread> threads;
     bool stop = false;
+    // what the workers have really achieved (parse time only: no allocation, no upload) and what they have been given and not finished
+    std::atomic<uint64_t> parsed_bytes { 0 }, parse_us { 0 }, backlog_bytes { 0 };
   } host_lanes;
   struct DenseBuf { uint8_t * p = nullptr; size_t bytes = 0; hipEvent_t used = nullptr, filled = nullptr; bool in_use = false; };
   DenseBuf dense_bufs[2];
@@ -302,9 +302,7 @@ struct aa_ctx {
   uint32_t stream_concurrency = 0, streams_needed = 0;    // probe_stream_concurrency (at the first submit)
   bool profile = false;
   double host_share_ms = 80.0;
-  double host_rate = 0.0;        // compressed key-frame bytes the host workers get through per millisecond of a call (measured: an average over the
-                                 // calls so far; 0 until the first one -- then usable cores x 24 KB/ms is assumed).  Cores a process SEES and cores it
-                                 // GETS are different things under a CPU quota: round 4's box showed 256 and gave ~15   // aa_submit_frames: a big call's key frames are parsed by host workers while that is expected to take no longer (0: never)
+                                 // aa_submit_frames: a big call's key frames go to the host lanes while their backlog stays within this (0: never)
   int schedule = 0;            // 0: row-pipelined persistent kernels (default), 1: one launch per 2:1 anti-diagonal
   int n_xcd = 1;               // XCDs workgroups land on (probed at creation); row kernels keep a unit on one XCD
   int xcd_share[AA_MAX_XCD] = {};
@@ -336,8 +334,7 @@ struct aa_ctx {
   std::vector<std::pair<uint8_t *, size_t>> compute_hold;
   hipEvent_t last_raster_download = nullptr;   // recorded on the copy stream behind the last aa_stream_download_async
   bool raster_download_pending = false;
-  std::mutex scratch_mu;                  // worst-case sized parse buffers of the host workers of aa_submit_frames (submit_host_batch), kept from call to call
-  std::vector<std::pair<std::unique_ptr<uint8_t[]>, size_t>> host_scratch;
+  uint64_t downloads_queued = 0, downloads_recorded = 0;   // aa_stream_download_async calls begun / whose event has been recorded (under pool_mu)
   std::mutex blank_mu;
   std::map<size_t, uint8_t *> blank;    // References( width, height ): one all-zero raster per raster size, shared by every new decoder (never written)
   uint8_t * boundary = nullptr; // loop filter: hand-off lines between macroblock rows (transient within a launch)
@@ -350,7 +347,7 @@ struct aa_ctx {
   std::vector<hipEvent_t> free_events;
 };
 
-namespace { void host_lanes_start( aa_ctx * ctx ); void host_lanes_stop( aa_ctx * ctx ); }
+namespace { void host_lanes_start( aa_ctx * ctx ); void host_lanes_stop( aa_ctx * ctx ); double host_lanes_rate( aa_ctx * ctx ); }
 
 struct aa_stream {
   aa_ctx * ctx;
@@ -470,6 +467,12 @@ aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out )
       soft_waits++; attempt = 0;
       continue;
     }
+    // ... and a limit that limits: with nothing left to wait for, the allocation fails (repeatable: the caller releases frames or
+    // raises aa_ctx_set_memory_limit) rather than take the context past what it was told it may hold
+    if ( ctx->pool_bytes + ctx->tok.heap_mapped + grow > ctx->pool_soft_limit && ctx->pool_bytes > 0 )
+      return fail( AA_ERR_NO_MEMORY, "device pool: the context's memory limit (" + std::to_string( ctx->pool_soft_limit >> 20 ) + " MiB: pool "
+                                     + std::to_string( ctx->pool_bytes >> 20 ) + " + coefficient heap " + std::to_string( ctx->tok.heap_mapped >> 20 )
+                                     + ") does not allow another " + std::to_string( grow >> 20 ) + " MiB: release decoded frames or raise aa_ctx_set_memory_limit" );
     hipError_t e;
     uint8_t * piece = nullptr;
     e = hipMalloc( reinterpret_cast<void **>( &piece ), grow );
@@ -480,8 +483,13 @@ aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out )
       *out = piece;
       return AA_OK;
     }
-    // out of HBM: what was released but may still be read by queued kernels comes back once they have run
+    // out of HBM: what was released but may still be read by queued kernels comes back once they have run -- the pieces parked for
+    // the compute stream's own reuse included (another context or process may hold the rest of the HBM well below this one's limit)
     (void) hipGetLastError();
+    if ( !ctx->compute_free.empty() ) {
+      for ( auto & kv : ctx->compute_free ) for ( uint8_t * p : kv.second ) ctx->pending_free.push_back( { p, kv.first, ctx->open_epoch } );
+      ctx->compute_free.clear(); ctx->compute_free_bytes = 0; ctx->open_epoch_used = true;
+    }
     if ( attempt == 2 || ctx->pending_free.empty() ) return hip_fail( e, "hipMalloc (frame store)" );
     const auto t0 = std::chrono::steady_clock::now();
     collect_pending( ctx, true );
@@ -504,7 +512,8 @@ void dev_free_compute( aa_ctx * ctx, uint8_t * p, size_t bytes )
   if ( !p ) return;
   {
     std::lock_guard<std::mutex> g( ctx->pool_mu );
-    if ( ctx->raster_download_pending && ctx->last_raster_download && hipEventQuery( ctx->last_raster_download ) == hipSuccess ) ctx->raster_download_pending = false;
+    if ( ctx->raster_download_pending && ctx->last_raster_download && ctx->downloads_recorded == ctx->downloads_queued
+         && hipEventQuery( ctx->last_raster_download ) == hipSuccess ) ctx->raster_download_pending = false;
     (void) hipGetLastError();
     if ( !ctx->raster_download_pending ) {
       const size_t cls = pool_size_class( bytes );
@@ -664,7 +673,12 @@ aa_status tok_grow_heap( aa_ctx * ctx, size_t want_mapped )
   if ( !T.vmm ) return AA_OK;
   want_mapped = std::min( ( want_mapped + T.grow_bytes - 1 ) / T.grow_bytes * T.grow_bytes, T.heap_va );
   while ( T.heap_mapped < want_mapped ) {
-    { std::lock_guard<std::mutex> g( ctx->pool_mu ); if ( ctx->pool_bytes + T.heap_mapped + T.grow_bytes > ctx->pool_soft_limit ) break; }
+    // (the limit is the pool's too, and the heap never unmaps: a sixteenth of it stays out of the heap's reach, for the arenas and
+    // rasters of frames handed over after the heap has taken what it could -- round 4's driver run ended with heap + pool 2.4 GB
+    // over a limit the pool could only ask about, not keep)
+    { std::lock_guard<std::mutex> g( ctx->pool_mu );
+      const size_t reserve = ctx->pool_soft_limit == ~size_t( 0 ) ? 0 : ctx->pool_soft_limit / 16;
+      if ( ctx->pool_bytes + T.heap_mapped + T.grow_bytes + reserve > ctx->pool_soft_limit && T.heap_mapped >= T.grow_bytes ) break; }
     hipMemAllocationProp prop {};
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = ctx->device;
     hipMemGenericAllocationHandle_t h;
@@ -1426,7 +1440,7 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
   out->token_lane_lds_bytes = T.lane_bytes; out->token_workgroup_lds_bytes = T.lds;
   out->compute_units = static_cast<uint32_t>( T.n_cus );
   out->host_share_ms = static_cast<uint32_t>( ctx->host_share_ms + 0.5 );
-  out->host_rate_kb_per_ms = static_cast<uint32_t>( ctx->host_rate / 1e3 + 0.5 );
+  out->host_rate_kb_per_ms = ctx->host_lanes.parse_us.load() ? static_cast<uint32_t>( host_lanes_rate( ctx ) / 1e3 + 0.5 ) : 0u;
   out->stream_concurrency = ctx->stream_concurrency; out->streams_needed = ctx->streams_needed;
   { int khz = 0; if ( hipDeviceGetAttribute( &khz, hipDeviceAttributeClockRate, ctx->device ) == hipSuccess ) out->clock_mhz = static_cast<uint32_t>( khz / 1000 ); else (void) hipGetLastError(); }
   if ( T.ready ) {
@@ -1830,186 +1844,6 @@ aa_status launch_tokens_of( aa_ctx * ctx, Batch * b )
 } // namespace
 
 namespace {
-// Frames of a big call that are parsed on the HOST (the call's key frames: their chains are the long ones -- 2.4 s on a lane, 20 ms
-// on a core -- and a group cannot be reconstructed before its key frame is parsed).  Unlike aa_stream_parse, which stages a
-// frame in its stream's own chunk (64 MB of pinned + device memory per stream: fine for a player, not for 480 decoders that live
-// for one group of pictures), the frames of the call share ARENAS OF ONE SIZE (kHostArenaBytes of pinned memory mirrored by a
-// device piece: every arena a context ever asks for is found again in the free lists).  A worker parses a frame into a scratch
-// buffer of its own -- kept by the context from call to call: no fresh pages, no page-fault storm of 256 threads in one address
-// space -- with Parser::parse (the records aa_parser_parse produces), takes room for exactly what the frame came to in the
-// arena being filled (a new one when it is full) and copies it there; every arena is uploaded by one copy on the copy stream and
-// is one Batch (released when the last of its frames goes).  frames[idx[k]], in stream order per stream.
-constexpr size_t kHostArenaBytes = size_t( 256 ) << 20;
-
-struct HostArena { uint8_t * host = nullptr, * dev = nullptr; size_t host_bytes = 0, dev_bytes = 0, used = 0; std::vector<int> members; };
-
-aa_status submit_host_batch( aa_ctx * ctx, const aa_frame_in * frames, const std::vector<int> & idx, std::vector<SubmitItem> & items, int threads )
-{
-  struct Tmp { int arena = -1; size_t off = 0, used = 0, mb_bytes = 0, rows_bytes = 0; aa_frame_header hdr; bool has_split = false; std::vector<uint8_t> diag; };
-  const int n = static_cast<int>( idx.size() );
-  const double t_begin = now_ms();
-  std::atomic<long long> parse_us { 0 }, arena_us { 0 };
-  std::vector<Tmp> tmp( n );
-  std::map<aa_stream *, std::vector<int>> by_stream;      // -> positions in idx
-  std::vector<aa_stream *> order;
-  for ( int k = 0; k < n; k++ ) {
-    auto & v = by_stream[frames[idx[k]].stream];
-    if ( v.empty() ) order.push_back( frames[idx[k]].stream );
-    v.push_back( k );
-  }
-  const size_t job_bytes = align_up( sizeof( aa_dev_frame ) );
-  std::vector<HostArena> arenas;
-  std::mutex arena_mu;
-  aa_status arena_error = AA_OK; std::string arena_message;
-  // room for `bytes` in the arena being filled -> (arena, offset); a frame bigger than an arena gets one of its own size
-  auto place = [&]( size_t bytes, int k, int * arena_out, size_t * off_out ) -> bool {
-    std::lock_guard<std::mutex> g( arena_mu );
-    if ( arena_error != AA_OK ) return false;
-    if ( arenas.empty() || arenas.back().used + bytes > arenas.back().dev_bytes ) {
-      struct Clock { std::atomic<long long> & a; double t0 = now_ms(); ~Clock() { a += static_cast<long long>( ( now_ms() - t0 ) * 1e3 ); } } clock { arena_us };
-      HostArena a;
-      const size_t want = std::max( kHostArenaBytes, align_up( bytes ) );
-      a.host = pinned_get( ctx, want, &a.host_bytes );
-      if ( !a.host ) { arena_error = AA_ERR_HIP; arena_message = "aa_submit_frames: pinned staging allocation failed"; return false; }
-      a.dev_bytes = want;
-      if ( aa_status st = dev_alloc( ctx, want, &a.dev ) ) {
-        arena_error = st; arena_message = g_last_error;
-        std::lock_guard<std::mutex> g2( ctx->pool_mu ); ctx->pinned_pool.emplace_back( a.host, a.host_bytes );
-        return false;
-      }
-      arenas.push_back( a );
-    }
-    HostArena & a = arenas.back();
-    *arena_out = static_cast<int>( arenas.size() ) - 1; *off_out = a.used;
-    a.used += bytes; a.members.push_back( k );
-    return true;
-  };
-  auto arena_host_of = [&]( int a ) -> uint8_t * { std::lock_guard<std::mutex> g( arena_mu ); return arenas[a].host; };
-  std::atomic<size_t> next { 0 };
-  auto work = [&]() {
-    (void) hipSetDevice( ctx->device );
-    std::unique_ptr<uint8_t[]> scratch; size_t scratch_bytes = 0;
-    for ( ;; ) {
-      const size_t w = next.fetch_add( 1 );
-      if ( w >= order.size() ) break;
-      aa_stream * s = order[w];
-      bool broken = segmap_to_host( s ) != AA_OK;
-      for ( int k : by_stream.at( s ) ) {      // (read-only from the workers)
-        SubmitItem & it = items[idx[k]];
-        if ( broken ) { it.status = AA_ERR_LOGIC; it.error = "an earlier frame of this stream in the same call failed"; continue; }
-        Tmp & t = tmp[k];
-        const size_t nmb = size_t( s->parser.mb_width() ) * s->parser.mb_height();
-        const size_t words_per_row = ( s->parser.mb_width() + 63 ) / 64;
-        t.mb_bytes = align_up( nmb * sizeof( aa_mb_info ) );
-        t.rows_bytes = align_up( words_per_row * s->parser.mb_height() * sizeof( unsigned long long ) );
-        const size_t head = job_bytes + t.mb_bytes + t.rows_bytes;
-        const size_t worst = head + nmb * 25 * 32 + kAlign;
-        if ( scratch_bytes < worst ) {
-          scratch.reset(); scratch_bytes = 0;
-          { std::lock_guard<std::mutex> g( ctx->scratch_mu );
-            for ( size_t i = 0; i < ctx->host_scratch.size(); i++ ) if ( ctx->host_scratch[i].second >= worst ) {
-              scratch = std::move( ctx->host_scratch[i].first ); scratch_bytes = ctx->host_scratch[i].second;
-              ctx->host_scratch[i] = std::move( ctx->host_scratch.back() ); ctx->host_scratch.pop_back(); break; } }
-          if ( !scratch ) { scratch.reset( new ( std::nothrow ) uint8_t[worst] ); scratch_bytes = scratch ? worst : 0; }
-          if ( !scratch ) { it.status = AA_ERR_ARGUMENT; it.error = "out of memory"; broken = true; continue; }
-        }
-        aa_mb_info * mbs = reinterpret_cast<aa_mb_info *>( scratch.get() + job_bytes );
-        unsigned long long * intra_rows = reinterpret_cast<unsigned long long *>( scratch.get() + job_bytes + t.mb_bytes );
-        int16_t * coeffs = reinterpret_cast<int16_t *>( scratch.get() + head );
-        const double t_parse = now_ms();
-        try { s->parser.parse( it.data, it.size, t.hdr, mbs, coeffs ); }
-        catch ( const aa::ParseError & e ) { it.status = e.code; it.error = e.message; broken = true; continue; }
-        parse_us += static_cast<long long>( ( now_ms() - t_parse ) * 1e3 );
-        const aa_frame_header & h = t.hdr;
-        const int mbw = h.mb_width, mbh = h.mb_height;
-        t.diag.assign( mbw + 2 * ( mbh - 1 ), 0 );
-        std::memset( intra_rows, 0, words_per_row * mbh * sizeof( unsigned long long ) );
-        if ( h.has_intra_mb )
-          for ( int r = 0; r < mbh; r++ ) for ( int col = 0; col < mbw; col++ )
-            if ( !( mbs[r * mbw + col].flags & AA_MB_INTER ) ) { t.diag[col + 2 * r] = 1; intra_rows[r * words_per_row + ( col >> 6 )] |= 1ull << ( col & 63 ); }
-        if ( !h.key_frame ) for ( size_t i = 0; i < nmb; i++ ) if ( mbs[i].y_mode == 9 /* SPLITMV */ ) { t.has_split = true; break; }
-        t.used = head + align_up( size_t( h.num_coeff_blocks ) * 32 );
-        if ( !place( t.used, k, &t.arena, &t.off ) ) { it.status = AA_ERR_HIP; it.error = "no room for the parsed frame"; t.arena = -1; broken = true; continue; }
-        std::memcpy( arena_host_of( t.arena ) + t.off + job_bytes, scratch.get() + job_bytes, t.used - job_bytes );     // (the job record is filled in below)
-        it.status = AA_OK;
-      }
-    }
-    if ( scratch ) { std::lock_guard<std::mutex> g( ctx->scratch_mu ); ctx->host_scratch.emplace_back( std::move( scratch ), scratch_bytes ); }
-  };
-  {
-    const int nt = std::max( 1, std::min<int>( { threads, static_cast<int>( order.size() ), 256 } ) );
-    if ( nt == 1 ) work();
-    else { std::vector<std::thread> pool; for ( int t = 0; t < nt; t++ ) pool.emplace_back( work ); for ( auto & t : pool ) t.join(); }
-  }
-  ctx->stats.host_batch_parse_wall_ms += now_ms() - t_begin;
-  ctx->stats.host_batch_parse_cpu_ms += parse_us.load() / 1e3;
-  ctx->stats.host_batch_arena_ms += arena_us.load() / 1e3;
-  aa_status result = AA_OK;
-  if ( arena_error != AA_OK ) result = fail( arena_error, arena_message );
-  int total_ok = 0;
-  for ( size_t ai = 0; ai < arenas.size(); ai++ ) {
-    HostArena & a = arenas[ai];
-    std::unique_ptr<Batch> b( new Batch );
-    b->host = a.host; b->host_bytes = a.host_bytes; b->dev = a.dev; b->dev_bytes = a.dev_bytes;
-    b->n = static_cast<int>( a.members.size() ); b->host_parsed = true;
-    b->items.resize( b->n );
-    int ok = 0;
-    for ( int j = 0; j < b->n; j++ ) {
-      const int k = a.members[j];
-      SubmitItem & it = items[idx[k]];
-      aa_stream * s = frames[idx[k]].stream;
-      b->items[j] = { s, -1, false };
-      if ( it.status != AA_OK || tmp[k].arena != static_cast<int>( ai ) ) continue;
-      ok++;
-    }
-    b->live = ok;
-    if ( !ok ) {          // (nothing of it is used: straight back)
-      { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( a.host, a.host_bytes ); }
-      dev_free( ctx, a.dev, a.dev_bytes );
-      continue;
-    }
-    Batch * raw = b.release();
-    // frames of a stream are appended in stream order: an arena's members are in placement order, which for one stream IS its order
-    for ( int j = 0; j < raw->n; j++ ) {
-      const int k = a.members[j];
-      SubmitItem & it = items[idx[k]];
-      if ( it.status != AA_OK || tmp[k].arena != static_cast<int>( ai ) ) continue;
-      aa_stream * s = frames[idx[k]].stream;
-      Tmp & t = tmp[k];
-      FrameRec rec;
-      rec.hdr = t.hdr; rec.has_split = t.has_split; rec.intra_diagonals = std::move( t.diag );
-      aa_dev_frame * job = reinterpret_cast<aa_dev_frame *>( raw->host + t.off );
-      fill_job( rec, job );
-      job->mbs = reinterpret_cast<const aa_mb_info *>( raw->dev + t.off + job_bytes );
-      job->intra_rows = reinterpret_cast<const unsigned long long *>( raw->dev + t.off + job_bytes + t.mb_bytes );
-      job->coeffs = reinterpret_cast<const int16_t *>( raw->dev + t.off + job_bytes + t.mb_bytes + t.rows_bytes );
-      rec.host_job = job;
-      rec.dev_job = reinterpret_cast<const aa_dev_frame *>( raw->dev + t.off );
-      rec.batch = raw; rec.batch_item = j;
-      it.frame_index = static_cast<int>( s->frames.size() );
-      raw->items[j] = { s, it.frame_index, true };
-      s->frames.push_back( std::move( rec ) );
-    }
-    // (from here on the frames point at the batch: a failure gives them back one by one)
-    auto abandon = [&]() { const std::string keep = g_last_error; std::vector<Batch::Item> its = raw->items; for ( auto & x : its ) if ( x.live ) release_records( x.s, x.s->frames[x.frame], true ); g_last_error = keep; };
-    hipError_t e = hipEventCreateWithFlags( &raw->hdr_done, hipEventDisableTiming );
-    if ( e == hipSuccess ) e = hipMemcpyAsync( raw->dev, raw->host, a.used, hipMemcpyHostToDevice, ctx->copy );
-    if ( e == hipSuccess ) e = hipEventRecord( raw->hdr_done, ctx->copy );
-    if ( e != hipSuccess ) {
-      for ( auto & x : raw->items ) if ( x.live ) { for ( int k2 : a.members ) if ( frames[idx[k2]].stream == x.s && items[idx[k2]].frame_index == x.frame ) { items[idx[k2]].status = AA_ERR_HIP; items[idx[k2]].error = "upload of host-parsed frames failed"; } }
-      abandon();
-      result = hip_fail( e, "upload of host-parsed frames" );
-      continue;
-    }
-    total_ok += ok;
-  }
-  ctx->stats.host_routed_frames += static_cast<uint64_t>( total_ok );
-  ctx->stats.host_batch_ms += now_ms() - t_begin;
-  return result;
-}
-} // namespace
-
-namespace {
 // ---- host lanes (aa_ctx::HostLanes) ----
 // One frame: macroblock headers + tokens from the arena's pinned copy (the header pre-pass left everything else in its ParseJob),
 // records to HBM where the frame's job record says they are, dense coefficient blocks to a pool piece of their own, then the
@@ -2031,7 +1865,10 @@ void host_lane_run( aa_ctx * ctx, Batch * b, int item, HostLaneScratch & S )
     aa_mb_info * mbs = reinterpret_cast<aa_mb_info *>( S.mbs.data() );
     unsigned long long * rows = reinterpret_cast<unsigned long long *>( S.rows.data() );
     std::memset( static_cast<void *>( mbs ), 0, S.mbs.size() );
+    const double t_parse = now_ms();
     aa::parse_frame_body( b->host + it.data_off, J.fp, mbs, S.coeffs.data(), S.above.data(), &blocks, &intra );
+    ctx->host_lanes.parse_us += static_cast<uint64_t>( ( now_ms() - t_parse ) * 1e3 ); ctx->host_lanes.parsed_bytes += J.size;
+    ctx->stats.host_batch_parse_cpu_ms += now_ms() - t_parse;          // (a diagnostic sum: workers race on it, the atomics above are what the planning uses)
     std::memset( rows, 0, S.rows.size() );
     for ( uint32_t r = 0; r < mbh; r++ ) for ( uint32_t c = 0; c < mbw; c++ ) {
       const aa_mb_info & mb = mbs[r * mbw + c];
@@ -2061,6 +1898,7 @@ void host_lane_run( aa_ctx * ctx, Batch * b, int item, HostLaneScratch & S )
   }
   sum->num_coeff_blocks = blocks; sum->num_intra_mbs = intra; sum->has_split = split; sum->steps = 0; sum->num_chunks = 0; sum->packed_words = 0;
   sum->status = status;
+  ctx->host_lanes.backlog_bytes -= J.size;
   __atomic_thread_fence( __ATOMIC_RELEASE );
   sum->done = 1u;
 }
@@ -2089,6 +1927,17 @@ void host_lanes_start( aa_ctx * ctx )
   int nt = effective_cpus();
   if ( const char * e = std::getenv( "ALFALFA_AMD_HOST_LANES" ) ) nt = std::max( 1, atoi( e ) );
   for ( int t = 0; t < nt; t++ ) H.threads.emplace_back( host_lanes_main, ctx );
+}
+// compressed bytes the host lanes get through per millisecond, all workers together (measured on the frames parsed so far --
+// parse time only, so a cold first call's allocations do not depress it; before the first frame: 24 KB/ms per usable core)
+double host_lanes_rate( aa_ctx * ctx )
+{
+  auto & H = ctx->host_lanes;
+  int nt = static_cast<int>( H.threads.size() );
+  if ( !nt ) { nt = effective_cpus(); if ( const char * e = std::getenv( "ALFALFA_AMD_HOST_LANES" ) ) nt = std::max( 1, atoi( e ) ); }
+  const uint64_t us = H.parse_us.load(), bytes = H.parsed_bytes.load();
+  const double per_worker = us > 1000 ? static_cast<double>( bytes ) / static_cast<double>( us ) * 1e3 : 24.0e3;     // bytes per ms
+  return per_worker * std::min( nt, effective_cpus() );
 }
 void host_lanes_stop( aa_ctx * ctx )
 {
@@ -2146,6 +1995,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
     if ( s->next_submit > static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_LOGIC, "aa_submit_frames: stream state is inconsistent" );
 
   bool to_host_lanes = false;
+  std::vector<char> host_lane_wanted( n, 0 );     // [i]: frame i should go to a host lane (if it may: submit_one)
   // ---- route: few chains -> the host's cores ----
   // A GPU lane decodes a bool in ~0.3 us, a host core in ~4 ns: one core is worth ~75 lanes, and a frame on a lane is a chain of
   // seconds whatever else the GPU does.  The GPU wins by holding 22 000 chains at once; a call with fewer streams than the host
@@ -2199,11 +2049,13 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
       return first_error == AA_OK ? AA_OK : fail( first_error, first_message );
     }
     // ---- hybrid: a big call's KEY frames on the host's cores, the rest on the lanes ----
-    // A key frame's chain is the longest there is (2.4 s on a lane at 1080p, ~20 ms on a core) and nothing of its group can be
+    // A key frame's chain is the longest there is (2.2 s on a lane at 1080p, ~35 ms on a core) and nothing of its group can be
     // reconstructed before it is parsed; a call's key frames are few (one per stream and group of pictures).  Streams whose
-    // frames in this call are all key frames go to host workers (submit_host_batch: one shared arena, one upload), biggest
-    // first, while the host part is expected to take no longer than `host_share_ms` on `nt` workers (a core parses ~24 MB of
-    // compressed key-frame data per second); everything else takes the device route below.
+    // frames in this call are all key frames go to the HOST LANES, biggest first, while what the host lanes have been given and
+    // not finished stays within `host_share_ms` of their work (at the rate they have really achieved: bytes of compressed frames
+    // per millisecond of a worker's parse time x workers; until measured, 24 KB/ms per usable core); everything else takes the
+    // GPU's lanes.  Nothing here waits: round 4's version of this share parsed inside the call and was worth taking only when
+    // the host could have half of a call's key frames within the budget.
     if ( !defer_tokens && !force_device && !to_host_lanes && ctx->host_share_ms > 0 ) {
       std::vector<std::pair<size_t, aa_stream *>> cand;
       for ( aa_stream * s : stream_order ) {
@@ -2212,48 +2064,16 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
         if ( all_key ) cand.emplace_back( bytes, s );
       }
       std::stable_sort( cand.begin(), cand.end(), []( const auto & a, const auto & b ) { return a.first > b.first; } );
-      const double rate = ctx->host_rate > 0 ? ctx->host_rate : effective_cpus() * 24.0e3;      // bytes per millisecond of wall time (until measured: 24 KB/ms per usable core)
-      const double capacity_bytes = ctx->host_share_ms * rate;
-      std::vector<char> on_host( n, 0 );
-      double taken = 0, wanted = 0; int n_host = 0;
-      for ( auto & c : cand ) wanted += static_cast<double>( c.first );
-      // A share worth taking, or none: the host part BLOCKS the calling thread, and a caller that pipelines (hands the next frames over,
-      // issues reconstruction calls) pays for that with idle lanes.  Measured on a box that grants 16 CPUs: 49 of 480 key frames per
-      // call for 124 ms of blocking took the steady state from 172 M to 88-127 M macroblocks/s.  So the host takes the call's key
-      // frames when it can take at least half of them inside the budget, and otherwise leaves them all to the lanes.
-      if ( capacity_bytes >= 0.5 * wanted )
-        for ( auto & c : cand ) {
-          if ( taken + static_cast<double>( c.first ) > capacity_bytes ) break;
-          taken += static_cast<double>( c.first );
-          for ( int i : by_stream[c.second] ) { on_host[i] = 1; n_host++; }
-        }
-      if ( n_host ) {
-        std::vector<int> host_idx, dev_idx;
-        for ( int i = 0; i < n; i++ ) ( on_host[i] ? host_idx : dev_idx ).push_back( i );
-        aa_status first_error = AA_OK; std::string first_message;
-        {
-          const double t0 = now_ms();
-          if ( aa_status st = submit_host_batch( ctx, frames, host_idx, items, nt ) ) { first_error = st; first_message = g_last_error; }
-          const double dt = std::max( 0.05, now_ms() - t0 );
-          const double measured = taken / dt;
-          ctx->host_rate = ctx->host_rate > 0 ? 0.5 * ctx->host_rate + 0.5 * measured : measured;
-        }
-        for ( int i : host_idx ) {
-          if ( frame_index_out ) frame_index_out[i] = items[i].status == AA_OK ? items[i].frame_index : -1;
-          if ( items[i].status != AA_OK && first_error == AA_OK ) { first_error = items[i].status; first_message = items[i].error; }
-        }
-        if ( !dev_idx.empty() ) {
-          std::vector<aa_frame_in> sub( dev_idx.size() );
-          std::vector<int> sub_out( dev_idx.size(), -1 );
-          for ( size_t k = 0; k < dev_idx.size(); k++ ) sub[k] = frames[dev_idx[k]];
-          const aa_status st = aa_submit_frames_ex( ctx, sub.data(), static_cast<int>( sub.size() ), sub_out.data(), threads, flags | AA_SUBMIT_DEVICE );
-          if ( frame_index_out ) for ( size_t k = 0; k < dev_idx.size(); k++ ) frame_index_out[dev_idx[k]] = sub_out[k];
-          if ( st != AA_OK && first_error == AA_OK ) { first_error = st; first_message = g_last_error; }
-        }
-        return first_error == AA_OK ? AA_OK : fail( first_error, first_message );
+      const double capacity_bytes = ctx->host_share_ms * host_lanes_rate( ctx );
+      double taken = static_cast<double>( ctx->host_lanes.backlog_bytes.load() );
+      for ( auto & c : cand ) {
+        if ( taken + static_cast<double>( c.first ) > capacity_bytes ) break;
+        taken += static_cast<double>( c.first );
+        for ( int i : by_stream[c.second] ) host_lane_wanted[i] = 1;
       }
     }
   }
+  if ( to_host_lanes ) std::fill( host_lane_wanted.begin(), host_lane_wanted.end(), 1 );
 
   std::unique_ptr<Batch> b( new Batch );
   const size_t arena = ( off + ( size_t( 16 ) << 20 ) - 1 ) & ~( ( size_t( 16 ) << 20 ) - 1 );
@@ -2300,7 +2120,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
         for ( int i : by_stream[stream_order[k]] ) {
           SubmitItem & it = items[i];
           if ( broken ) { it.status = AA_ERR_LOGIC; it.error = "an earlier frame of this stream in the same call failed"; continue; }
-          it.status = submit_one( b.get(), it, i, jobs_host, dframes_host, to_host_lanes );
+          it.status = submit_one( b.get(), it, i, jobs_host, dframes_host, host_lane_wanted[i] != 0 );
           if ( it.status != AA_OK ) broken = true;
         }
       }
@@ -2428,7 +2248,8 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
     for ( int i = 0; i < n; i++ ) if ( raw->items[i].on_host ) n_host++;
     if ( n_host ) {
       host_lanes_start( ctx );
-      { std::lock_guard<std::mutex> g( ctx->host_lanes.mu ); for ( int i = 0; i < n; i++ ) if ( raw->items[i].on_host ) ctx->host_lanes.q.push_back( { raw, i } ); }
+      { std::lock_guard<std::mutex> g( ctx->host_lanes.mu );
+        for ( int i = 0; i < n; i++ ) if ( raw->items[i].on_host ) { ctx->host_lanes.backlog_bytes += items[i].size; ctx->host_lanes.q.push_back( { raw, i } ); } }
       ctx->host_lanes.cv.notify_all();
       ctx->stats.host_routed_frames += static_cast<uint64_t>( n_host );
       if ( std::find( ctx->tok.inflight.begin(), ctx->tok.inflight.end(), raw ) == ctx->tok.inflight.end() ) ctx->tok.inflight.push_back( raw );
@@ -2718,10 +2539,6 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
     if ( fi != s->next_submit ) return fail( AA_ERR_LOGIC, "aa_decode_batch: frames of a stream must be submitted in order" );
   }
   for ( int i = 0; i < n; i++ ) if ( aa_status st = aa_stream_upload( streams[i] ) ) return st;
-  for ( int i = 0; i < n; i++ ) {            // frames parsed by host workers of a submit call: their arena's upload (copy stream) comes first
-    Batch * hb = streams[i]->frames[frame_index[i]].batch;
-    if ( hb && hb->host_parsed && !hb->upload_waited ) { HIP_TRY( hipStreamWaitEvent( ctx->compute, hb->hdr_done, 0 ) ); hb->upload_waited = true; }
-  }
   // coefficient chunks of the frames released since the last call go back to the pool (behind the kernels that read them:
   // those were queued before the release)
   // ... and what was released since then gets its epoch now: reusable as soon as the kernels queued before this call have run
@@ -2980,11 +2797,19 @@ aa_status aa_stream_download_async( aa_stream * s, int fi, uint8_t * y, uint8_t 
   ctx->free_events.push_back( e );
   uint8_t * dst[3] = { y, u, v };
   // the raster may be released before the copy has run: the epoch that frees it waits for the copy stream as well
-  { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->copy_reads_rasters = true; ctx->raster_download_pending = true; }
+  // (the flag stays up until the event recorded behind THIS call's copies has fired: downloads are numbered, and a release on
+  // another thread that finds the event of an earlier download complete does not take the flag down while a later one is still
+  // between its copies and its event)
+  uint64_t my_download;
+  { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->copy_reads_rasters = true; ctx->raster_download_pending = true; my_download = ++ctx->downloads_queued; }
   for ( int p = 0; p < 3; p++ ) if ( dst[p] ) HIP_TRY( hipMemcpyAsync( dst[p], slot_plane( s, r.out_slot, p ), s->plane_bytes[p], hipMemcpyDeviceToHost, ctx->copy ) );
   // (rasters released from now on are recycled through an epoch until this copy is through: dev_free_compute)
-  if ( !ctx->last_raster_download ) HIP_TRY( hipEventCreateWithFlags( &ctx->last_raster_download, hipEventDisableTiming ) );
-  HIP_TRY( hipEventRecord( ctx->last_raster_download, ctx->copy ) );
+  {
+    std::lock_guard<std::mutex> g( ctx->pool_mu );
+    if ( !ctx->last_raster_download ) HIP_TRY( hipEventCreateWithFlags( &ctx->last_raster_download, hipEventDisableTiming ) );
+    HIP_TRY( hipEventRecord( ctx->last_raster_download, ctx->copy ) );
+    ctx->downloads_recorded = std::max( ctx->downloads_recorded, my_download );
+  }
   return AA_OK;
 }
 aa_status aa_stream_download_wait( aa_stream * s )

@@ -101,7 +101,9 @@ def parse_args():
                     "expected to take no longer than this on the rank's host threads (library default 50; 0: every frame on the GPU's token lanes)")
     ap.add_argument("--lanes-only-steps", type=int, default=8, help="after the main run: this many steps with host_share_ms = 0 (every frame, key frames too, "
                     "parsed by GPU lanes), reported as all_frames_on_gpu_lanes (0 = skip)")
-    ap.add_argument("--urgent-host", action="store_true", help="... take the host route whatever the host's measured rate says")
+    ap.add_argument("--urgent-host", action="store_true", help="(accepted for old command lines: the host lanes are the default for the groups a pipeline starts with)")
+    ap.add_argument("--urgent-groups", type=int, default=2, help="groups of pictures, counted from the one an EMPTY pipeline starts with, whose key frames go to the context's host lanes "
+                    "(AA_SUBMIT_HOST: host cores in the role of token lanes, the call does not wait)")
     ap.add_argument("--no-urgent-host", action="store_true", help="key frames of the group a pipeline STARTS with also take the default route (GPU lanes) instead of the "
                     "host route (AA_SUBMIT_HOST); they are the ones whose chain latency is the fill of the pipeline")
     ap.add_argument("--trace-memory", action="store_true", help="print the context's memory books after every step of the timed region (stderr)")
@@ -154,6 +156,7 @@ class Pipeline:
         self.host_s = 0.0
         self.t_launch = self.t_decode = self.t_release = 0.0      # host time in aa_launch_tokens / aa_decode_batch / releases
         self.done_t = []
+        self.step_series = None
         self.delivered_bytes = 0
         self.refused = 0                                 # times a hand-over was put off because HBM had no room for it
         self.urgent_groups = 0                           # groups whose key frames took the host route because they were needed at once
@@ -221,6 +224,10 @@ class Pipeline:
             self.t_release += time.perf_counter() - t1
         self.decoded += 1
         self.done_t.append(time.perf_counter())
+        if self.step_series is not None:          # what the host waited for, step by step (diagnostics of the timed region)
+            ks, i = ctx.kernel_stats(), ctx.info()
+            self.step_series.append((round(ks["parse_wait_ms"]), round(ks["bind_wait_ms"]), i["token_workgroups_alive"], i["jobs_waiting"],
+                                     round(i["heap_used_bytes"] / 1e9, 1), round((i["pool_bytes"] - i["pool_free_bytes"]) / 1e9, 1)))
         if env["args"].trace_memory:
             i = ctx.info()
             print("step %d: pool %.1f GB (free %.1f, pending %.1f) heap mapped %.1f used %.1f GB free chunks %d starved %d alive wgs %d waiting %d refused %d"
@@ -262,8 +269,13 @@ class Pipeline:
             # An EMPTY pipeline.  The key frames of the group it starts with are needed at once and are the longest chains there are
             # (2 s on a GPU lane, 35 ms on a host core): they go to the context's HOST LANES (AA_SUBMIT_HOST; the call does not wait
             # for them).  The loop below then hands that group's inter frames and the later groups' key frames to the GPU lanes as ever.
-            self._submit_keys(self.decoded, urgent=True)
-            self.keys = self.decoded + 1
+            # The SECOND group's too: the host's cores get through a group in ~1 s, a key frame handed to a GPU lane now is through in
+            # ~2.9 s (header kernel + a 2.2-s chain) -- the second group is ready at 2.1 s instead of 3, and from the third on the lanes'
+            # key frames arrive as fast as the host's would.
+            g0 = self.decoded
+            for g in range(g0, min(target, g0 + env["args"].urgent_groups)):
+                self._submit_keys(g, urgent=True)
+                self.keys = g + 1
         while self.decoded < target:
             while True:
                 can_inter = self.inter_h < min(target, self.decoded + self.D + self.H, self.keys)
@@ -600,6 +612,7 @@ def main():
     barrier()
     log("warm-up done; timed region starts")
     pipe.host_s = pipe.t_launch = pipe.t_decode = pipe.t_release = 0.0; pipe.done_t = []; pipe.refused = 0; pipe.urgent_groups = 0
+    pipe.step_series = []
     pipe.keep_group = pipe.decoded + args.steps - 1          # the last TIMED step keeps the frames of its distinct streams: they are what is verified
     ctx.kernel_stats(reset=True)
     prof0 = ctx.info()["token_profile"]
@@ -623,7 +636,11 @@ def main():
     info = ctx.info()
     clock_mhz = info.get("clock_mhz") or 2400
     token_profile = token_profile_delta(prof0, info["token_profile"], clock_mhz)
+    series = pipe.step_series or []
+    pipe.step_series = None
     timed_region = {"step_done_at_ms": [round((t - t0) * 1e3) for t in pipe.done_t],
+                    "per_step": {"what": "after each step: [host waited for parses so far ms, for the compute stream so far ms, worker workgroups alive, jobs waiting in the queue, "
+                                         "coefficient heap in use GB, pool in use GB]", "series": [list(x) for x in series]},
                     "host_ms_per_step": {"submit": round(pipe.host_s / args.steps * 1e3, 1), "launch_tokens": round(pipe.t_launch / args.steps * 1e3, 1),
                                          "decode_batch_calls_incl_wait_for_parse": round(pipe.t_decode / args.steps * 1e3, 1),
                                          "release": round(pipe.t_release / args.steps * 1e3, 1)},

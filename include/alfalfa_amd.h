@@ -26,7 +26,10 @@
 extern "C" {
 #endif
 
-#define AA_ABI_VERSION 3
+/* 4 (round 5): aa_ctx_info and aa_kernel_stats grew in round 4 (a caller built against version 3 passes smaller structs: check
+ * aa_abi_version() against the header you compiled with before calling aa_ctx_get_info / aa_ctx_kernel_stats), packed coefficient
+ * storage became the default, AA_SUBMIT_HOST on a big call no longer waits for the parse (host lanes), the memory limit is hard. */
+#define AA_ABI_VERSION 4
 
 typedef enum aa_status {
   AA_OK = 0,
@@ -174,7 +177,10 @@ aa_status aa_ctx_set_schedule( aa_ctx * ctx, int schedule );
  * After the caller has dealt with it (e.g. switched to AA_SCHEDULE_DIAGONAL), this clears the word. */
 aa_status aa_ctx_clear_error( aa_ctx * ctx );
 /* HBM the context may take for its pools (frame records, rasters, the coefficient heap of the device parser): by default 7/8 of
- * what was free when it was created; a caller that shares the GPU sets less.  Memory is taken as frames need it, up to this. */
+ * what was free when it was created; a caller that shares the GPU sets less.  Memory is taken as frames need it, up to this --
+ * and NOT beyond (round 5): pool + mapped coefficient heap never exceed it.  An allocation that would first waits for pieces
+ * released behind queued kernels; when none are left it fails with AA_ERR_NO_MEMORY (repeatable once frames have been released).
+ * The heap, which never unmaps, leaves a sixteenth of the limit to the pool. */
 aa_status aa_ctx_set_memory_limit( aa_ctx * ctx, size_t bytes );
 /* What the context holds right now (the memory budget of a deployment: one context per GPU, one process per GPU). */
 typedef struct aa_ctx_info {
@@ -201,8 +207,8 @@ typedef struct aa_ctx_info {
   uint32_t lane_per_partition;       /* 1: frames with several DCT partitions may get a token lane per partition (aa_ctx_set_lane_per_partition) */
   uint32_t clock_mhz;                /* the device's shader clock (hipDeviceAttributeClockRate) */
   uint32_t host_share_ms;            /* aa_ctx_set_host_share_ms */
-  uint32_t host_rate_kb_per_ms;      /* what the host workers really got through in the key-frame parts of the calls so far (KB of compressed data per ms of wall
-                                        time; 0: none yet).  The share of later calls is planned with it: visible cores and usable cores differ under a CPU quota */
+  uint32_t host_rate_kb_per_ms;      /* what the host lanes get through, all workers together (KB of compressed data per ms: measured on the frames they have parsed,
+                                        parse time only; 0: none yet).  The share of later calls is planned with it: visible cores and usable cores differ under a CPU quota */
   uint32_t reserved1;
   uint32_t stream_concurrency;       /* how many of the context's HIP streams were seen running side by side (probed at the first aa_submit_frames; 0: not yet) */
   uint32_t streams_needed;           /* ... of how many (15): fewer means GPU_MAX_HW_QUEUES was not in effect, see aa_runtime_prepare */
@@ -216,18 +222,18 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out );
  * dense the default of every context. */
 aa_status aa_ctx_set_packed_coefficients( aa_ctx * ctx, int on );
 /* Key frames of big calls on the host's cores.  aa_submit_frames hands a call with many streams to the GPU's token lanes; a KEY
- * frame's chain is the longest there is (seconds on a lane, ~20 ms on a core) and its group cannot be reconstructed before it
- * is parsed, so the streams of such a call whose frames are all key frames are parsed by host workers instead (the same
- * records, one shared arena, one upload) -- biggest first, while that is expected to take no longer than `ms` milliseconds
- * on the call's `threads` workers.  Default 80 (environment: ALFALFA_AMD_HOST_SHARE_MS); 0: every frame of a big call goes to
- * the lanes.  AA_SUBMIT_DEVICE overrides it per call. */
+ * frame's chain is the longest there is (seconds on a lane, ~35 ms on a core) and its group cannot be reconstructed before it
+ * is parsed, so the streams of such a call whose frames are all key frames go to the context's host lanes instead (see
+ * AA_SUBMIT_HOST: the same records, and the call does not wait) -- biggest first, while what the host lanes have been given and
+ * not finished stays within `ms` milliseconds of their work at the rate they have really achieved.  Default 80 (environment:
+ * ALFALFA_AMD_HOST_SHARE_MS); 0: every frame of a big call goes to the GPU's lanes.  AA_SUBMIT_DEVICE overrides it per call. */
 aa_status aa_ctx_set_host_share_ms( aa_ctx * ctx, double ms );
 /* One token lane per DCT partition.  A frame with 2, 4 or 8 partitions (frame.cc:119-137: macroblock row r is coded in
  * partition r % P) is then decoded by that many lanes of one wave -- rows handed from lane to lane through the above-row
  * flags in LDS --, whenever the wave that draws it has the lanes idle; its entropy-decode latency falls towards 1 / P of the
  * single-lane figure.  Single-partition frames, records and rasters are unaffected.  Per context, before its first
  * aa_submit_frames call (AA_ERR_LOGIC afterwards); ALFALFA_AMD_LANE_PER_PARTITION=1 makes it the default.  Off by default:
- * simulated on the host lane by lane and wave by wave (tests/test_wave_sim.py), not yet run on a GPU. */
+ * simulated on the host lane by lane and wave by wave (tests/test_wave_sim.py) and run on the GPU (tests/test_gpu_lane_per_partition.py). */
 aa_status aa_ctx_set_lane_per_partition( aa_ctx * ctx, int on );
 /* hipStream_t handles as opaque pointers (to order foreign work, e.g. an RCCL broadcast, against ours) */
 void * aa_ctx_compute_stream( aa_ctx * ctx );
@@ -283,7 +289,14 @@ aa_status aa_submit_frames( aa_ctx * ctx, const aa_frame_in * frames, int n, int
 /* Routing.  By default a call whose streams are fewer than the host workers it may use (and at most 24) is parsed on the HOST --
  * one worker per stream, Parser::parse, records uploaded: the same records, sooner, because a frame on a GPU lane is a chain of
  * seconds and one core is worth ~75 lanes (an 8-chunk bundle: 4x the rate of the GPU parser) -- and everything larger on the GPU.
- * AA_SUBMIT_DEVICE / AA_SUBMIT_HOST force one or the other (so does the environment variable ALFALFA_AMD_ROUTE=device|host). */
+ * AA_SUBMIT_DEVICE / AA_SUBMIT_HOST force one or the other (so does the environment variable ALFALFA_AMD_ROUTE=device|host).
+ * AA_SUBMIT_HOST on a call with MORE streams than that (frames that are needed at once: the key frames of the groups of pictures a
+ * pipeline starts with -- 35 ms on a core, 2 s as a chain on a GPU lane) hands the frames to the context's HOST LANES: they take the
+ * device route's header pre-pass and arena (frame indices at once; later frames of the same streams can be submitted immediately, on
+ * any route), worker threads of the context -- as many as aa_host_cpus() -- parse macroblock headers and tokens the way a GPU lane
+ * does and finish each frame with the same completion word.  THE CALL DOES NOT WAIT FOR THEM; aa_decode_batch,
+ * aa_stream_frame_header, aa_stream_read_records and the release calls do, frame by frame.  Frames of a stream that uses
+ * segmentation (its persistent map lives on the device) take the GPU's lanes all the same. */
 #define AA_SUBMIT_DEVICE 2u
 #define AA_SUBMIT_HOST 4u
 aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, int * frame_index_out, int threads, unsigned flags );
@@ -423,13 +436,13 @@ typedef struct aa_kernel_stats {
   uint64_t heap_mapped_bytes;
   uint64_t nomem_retries;   /* frames a lane handed back because the coefficient pool was empty, run again */
   uint64_t frames_evicted;  /* frames parsed ahead of their turn whose chunks were taken back for a frame needed now (parsed again later) */
-  uint64_t host_routed_frames; /* frames of aa_submit_frames calls that were parsed by host workers (few streams) */
+  uint64_t host_routed_frames; /* frames of aa_submit_frames calls that were parsed by host cores (few streams: one worker per stream; else host lanes) */
   /* packed coefficient storage (aa_ctx_set_packed_coefficients) */
   double expand_ms;         /* k_dense_index + k_expand_coeffs (profile on) */
   uint64_t expand_launches;
   uint64_t packed_frames, packed_words, packed_blocks;   /* frames stored packed, the 16-bit words they took, the dense blocks they stand for */
-  /* key frames of big calls parsed by host workers (aa_ctx_set_host_share_ms): wall time of that part of aa_submit_frames, of its
-   * parse phase (all workers), the workers' summed parse time (CPU seconds x 1000), time spent getting arenas, pinned allocations made */
+  /* host lanes: host_batch_parse_cpu_ms = the workers' summed parse time (CPU seconds x 1000; a diagnostic sum); host_batch_ms,
+   * host_batch_parse_wall_ms, host_batch_arena_ms: 0 since round 5 (nothing of a submit call waits for host parsing any more) */
   double host_batch_ms, host_batch_parse_wall_ms, host_batch_parse_cpu_ms, host_batch_arena_ms;
   uint64_t pinned_allocs;
 } aa_kernel_stats;

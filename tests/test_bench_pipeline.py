@@ -57,7 +57,7 @@ class FakeCtx:
 
 
 def make(bench, ctx, n_streams=4, F=3, K=4, D=2, urgent=False):
-    args = types.SimpleNamespace(trace_memory=False, overcommit=1.0)
+    args = types.SimpleNamespace(trace_memory=False, overcommit=1.0, urgent_groups=2)
     env = {"ctx": ctx, "F": F, "args": args, "width": 64, "height": 64, "threads": 1, "distinct": [0, 2], "recon_reserve": 0,
            "key_coeff_bytes": ctx.coeff, "inter_coeff_bytes": ctx.coeff, "key_arena_bytes": ctx.arena, "inter_arena_bytes": ctx.arena, "key_dense_bytes": 0,
            "urgent_keys_on_host": urgent, "deliver_ring": None}
@@ -125,10 +125,10 @@ def test_an_empty_pipeline_takes_the_host_route_for_the_group_it_starts_with(ben
     p = make(bench, ctx, K=6, D=2, urgent=True)
     p.run(5)
     submits = [e for e in ctx.log if e[0] == "submit"]
-    # three later groups' key frames to the lanes first, then the first group's on the host route, then its inter frames
-    assert [s[2] for s in submits[:5]] == ["auto", "auto", "auto", "host", "auto"] and submits[4][1] == 8
-    assert p.urgent_groups == 1 and p.decoded == 5 and ctx.in_flight == 0
-    assert sum(1 for s in submits if s[2] == "host") == 1
+    # the key frames of the first two groups to the host lanes (the call does not wait for them), then the first group's inter frames
+    assert [s[2] for s in submits[:3]] == ["host", "host", "auto"] and submits[2][1] == 8
+    assert p.urgent_groups == 2 and p.decoded == 5 and ctx.in_flight == 0
+    assert sum(1 for s in submits if s[2] == "host") == 2
 
 
 def test_calibration_runs_against_a_fake_context(bench, monkeypatch):
@@ -159,7 +159,7 @@ def test_calibration_runs_against_a_fake_context(bench, monkeypatch):
     def frame_header(self, i):
         return {"num_coeff_blocks": 500}
     monkeypatch.setattr(aa.Decoder, "frame_header", frame_header, raising=False)
-    args = types.SimpleNamespace(no_urgent_host=False, urgent_host=False)
+    args = types.SimpleNamespace(no_urgent_host=False, urgent_host=False, urgent_groups=2)
     for S, key_size in ((40, 2000), (40, 2_000_000), (8, 2000)):
         ctx = Ctx()
         streams = [[b"k" * key_size] + [b"i" * 100] * 2 for _ in range(S)]

@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(L, n), "missing export " + n
         assert n in bound, "ctypes binding lacks " + n
-    assert L.aa_abi_version() == 3
+    assert L.aa_abi_version() == 4
 
 
 def test_struct_layout_matches_header():
