@@ -437,7 +437,10 @@ inline size_t pool_size_class( size_t bytes )
   return ( bytes + step - 1 ) / step * step;
 }
 
-aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out )
+// `refusable`: the piece is for frames being HANDED OVER (a batch arena): such an allocation stops a thirty-second of the limit short
+// of it, so that what the caller needs to get frames OUT again -- rasters, the dense blocks of a reconstruction call -- still finds
+// room; a caller that pipelines treats AA_ERR_NO_MEMORY from aa_submit_frames as "not now" and reconstructs / releases first.
+aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out, bool refusable = false )
 {
   bytes = pool_size_class( bytes );
   std::lock_guard<std::mutex> g( ctx->pool_mu );
@@ -459,7 +462,8 @@ aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out )
       for ( auto & kv : ctx->compute_free ) for ( uint8_t * p : kv.second ) ctx->pending_free.push_back( { p, kv.first, ctx->open_epoch } );
       ctx->compute_free.clear(); ctx->compute_free_bytes = 0; ctx->open_epoch_used = true;
     }
-    if ( ctx->pool_bytes + ctx->tok.heap_mapped + grow > ctx->pool_soft_limit && !ctx->pending_free.empty() && soft_waits < 64 ) {
+    if ( ctx->pool_bytes + ctx->tok.heap_mapped + grow + ( refusable && ctx->pool_soft_limit != ~size_t( 0 ) ? ctx->pool_soft_limit / 32 : 0 ) > ctx->pool_soft_limit
+         && !ctx->pending_free.empty() && soft_waits < 64 ) {
       const auto t0 = std::chrono::steady_clock::now();
       collect_pending( ctx, true );
       ctx->stats.pool_waits++;
@@ -469,7 +473,8 @@ aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out )
     }
     // ... and a limit that limits: with nothing left to wait for, the allocation fails (repeatable: the caller releases frames or
     // raises aa_ctx_set_memory_limit) rather than take the context past what it was told it may hold
-    if ( ctx->pool_bytes + ctx->tok.heap_mapped + grow > ctx->pool_soft_limit && ctx->pool_bytes > 0 )
+    const size_t keep_back = ( refusable && ctx->pool_soft_limit != ~size_t( 0 ) ) ? ctx->pool_soft_limit / 32 : 0;
+    if ( ctx->pool_bytes + ctx->tok.heap_mapped + grow + keep_back > ctx->pool_soft_limit && ctx->pool_bytes > 0 )
       return fail( AA_ERR_NO_MEMORY, "device pool: the context's memory limit (" + std::to_string( ctx->pool_soft_limit >> 20 ) + " MiB: pool "
                                      + std::to_string( ctx->pool_bytes >> 20 ) + " + coefficient heap " + std::to_string( ctx->tok.heap_mapped >> 20 )
                                      + ") does not allow another " + std::to_string( grow >> 20 ) + " MiB: release decoded frames or raise aa_ctx_set_memory_limit" );
@@ -2097,7 +2102,7 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   b->host = pinned_get( ctx, arena, &b->host_bytes );
   if ( !b->host ) return fail( AA_ERR_HIP, "aa_submit_frames: pinned staging allocation failed" );
   b->dev_bytes = dev_arena;
-  if ( aa_status st = dev_alloc( ctx, dev_arena, &b->dev ) ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); return st; }
+  if ( aa_status st = dev_alloc( ctx, dev_arena, &b->dev, true ) ) { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); return st; }
   b->n = n; b->summaries_off = jobs_bytes + dframes_bytes;
   if ( hipError_t e = hipHostGetDevicePointer( reinterpret_cast<void **>( &b->host_dev ), b->host, 0 ) ) {
     { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->pinned_pool.emplace_back( b->host, b->host_bytes ); }

@@ -97,6 +97,7 @@ def parse_args():
     ap.add_argument("--deliver", action="store_true", help="every reconstructed frame is also DELIVERED: copied to pinned host memory (aa_download_batch_async: one "
                     "gather + one copy per frame index) while the next frames are decoded -- what vp8decode / xc-decode-bundle do with every shown frame; "
                     "the timed region then includes PCIe")
+    ap.add_argument("--deliver-steps", type=int, default=6, help="without --deliver: this many steps with every frame delivered AFTER the timed region, reported as `delivery` (0 = skip)")
     ap.add_argument("--host-share-ms", type=float, default=None, help="aa_ctx_set_host_share_ms: key frames of a hand-over are parsed by host workers while that is "
                     "expected to take no longer than this on the rank's host threads (library default 50; 0: every frame on the GPU's token lanes)")
     ap.add_argument("--lanes-only-steps", type=int, default=8, help="after the main run: this many steps with host_share_ms = 0 (every frame, key frames too, "
@@ -159,6 +160,7 @@ class Pipeline:
         self.step_series = None
         self.delivered_bytes = 0
         self.refused = 0                                 # times a hand-over was put off because HBM had no room for it
+        self.refused_by_the_library = 0                  # ... of which by aa_submit_frames itself (AA_ERR_NO_MEMORY at the context's limit)
         self.urgent_groups = 0                           # groups whose key frames took the host route because they were needed at once
 
     def _deliver(self, ds, f):
@@ -180,11 +182,22 @@ class Pipeline:
         ds = self.groups[g] = [self.aa.Decoder(self.ctx, env["width"], env["height"]) for _ in range(self.n)]
         for i, d in enumerate(ds):
             self.key_arr[i].stream = d.h.value
-        self.ctx.submit_prepared((self.key_arr, self.key_out, None), env["threads"], False, "host" if urgent and env.get("urgent_keys_on_host") else "auto")
+        try:
+            self.ctx.submit_prepared((self.key_arr, self.key_out, None), env["threads"], False, "host" if urgent and env.get("urgent_keys_on_host") else "auto")
+        except self.aa.AlfalfaError as e:
+            # the context's memory limit leaves no room for this hand-over's arena (a hard limit since round 5; the call appends
+            # nothing then and can be repeated): "not now" -- reconstruct and release first, like a hand-over _room() puts off
+            if e.kind != "NoMemory" or self.keys == self.decoded:
+                raise
+            del self.groups[g], ds
+            self.refused += 1; self.refused_by_the_library += 1
+            self.host_s += time.perf_counter() - t
+            return False
         if urgent and env.get("urgent_keys_on_host"):
             self.urgent_groups += 1
         self.frames_submitted += self.n
         self.host_s += time.perf_counter() - t
+        return True
 
     def _submit_inters(self, g, defer_tokens=False):
         F = self.F
@@ -195,9 +208,17 @@ class Pipeline:
             h = d.h.value
             for k in range(F - 1):
                 self.inter_arr[i * (F - 1) + k].stream = h
-        self.ctx.submit_prepared((self.inter_arr, self.inter_out, None), self.env["threads"], defer_tokens)
+        try:
+            self.ctx.submit_prepared((self.inter_arr, self.inter_out, None), self.env["threads"], defer_tokens)
+        except self.aa.AlfalfaError as e:
+            if e.kind != "NoMemory" or g == self.decoded:          # (the group about to be reconstructed must go: nothing would free memory otherwise)
+                raise
+            self.refused += 1; self.refused_by_the_library += 1
+            self.host_s += time.perf_counter() - t
+            return False
         self.frames_submitted += self.n * (F - 1)
         self.host_s += time.perf_counter() - t
+        return True
 
     def decode(self, release=True):
         g = self.decoded
@@ -284,7 +305,9 @@ class Pipeline:
                 if can_inter and (self.inter_h == self.decoded or not can_key or self.keys - self.inter_h > self.K - self.D):
                     if self.inter_h != self.decoded and not self._room(self.n * (F - 1), self.n * (F - 1) * env["inter_coeff_bytes"], self.n * (F - 1) * env["inter_arena_bytes"]):
                         break
-                    self._submit_inters(self.inter_h, defer_tokens=self.H > 0); self.inter_h += 1
+                    if self._submit_inters(self.inter_h, defer_tokens=self.H > 0) is False:
+                        break
+                    self.inter_h += 1
                     if self.H == 0:
                         self.inters += 1
                 elif can_key:
@@ -294,7 +317,9 @@ class Pipeline:
                         fits = self._room(self.n, self.n * env["key_coeff_bytes"], self.n * env["key_arena_bytes"])
                     if not fits:
                         break
-                    self._submit_keys(self.keys, urgent=self.keys == self.decoded); self.keys += 1
+                    if self._submit_keys(self.keys, urgent=self.keys == self.decoded) is False:
+                        break
+                    self.keys += 1
                 elif self.H > 0 and self.inters < min(target, self.decoded + self.D, self.inter_h):
                     t = time.perf_counter()
                     self.ctx.launch_tokens(1); self.inters += 1
@@ -497,7 +522,37 @@ def run_secondary(args, ctx, config, rank, world, threads):
         d = pipe.done_t[-steps:]
         out["between_fill_and_drain_value"] = round(S * F * env["mbs_per_frame"] * (steps - 1) / (d[-1] - d[0]), 1)
     del pipe, kept
+    # the reference CPU decoder on a stream of THIS config (north_star: 720p and 1080p "next to the reference CPU path"): a bounded
+    # sample, ~4 s of one core
+    ref_time = os.path.join(ROOT, "oracle", "_ref", "ref_time")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and os.path.exists(ref_time):
+        try:
+            reps = max(1, int(round(4.0 / (F * env["mbs_per_frame"] / 150000.0))))
+            r = json.loads(subprocess.run([ref_time, env["paths"][0], str(reps)], check=True, capture_output=True, text=True, timeout=120).stdout)
+            out["cpu_baseline"] = {"value": round(r["mb_per_s"], 1), "unit": "macroblocks/s", "cores": 1, "kind": "reference",
+                                   "sample": "the first stream of this config (%d frames %dx%d) decoded %d times by oracle/_ref/ref_time; reference built without x86 asm"
+                                             % (F, env["width"], env["height"], reps)}
+        except Exception as e:
+            out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
+
+
+def lane_per_partition_leg(args, config, rank, world, threads):
+    """The multi-partition config once more in a context of its own with ONE LANE PER DCT PARTITION (aa_ctx_set_lane_per_partition: a
+    per-context switch, off by default -- the shared above-row flags cost every frame of the context 128 bytes of LDS per lane and the
+    kernel 10 registers): the same streams, steps and check as the `secondary` figure beside it."""
+    import alfalfa_amd as aa
+    ctx2 = aa.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    ctx2.set_memory_limit(int(32e9))
+    ctx2.set_lane_per_partition(True)
+    try:
+        r = run_secondary(args, ctx2, config, rank, world, threads)
+        r["lane_per_partition"] = bool(ctx2.info()["lane_per_partition"])
+        r.pop("cpu_baseline", None)
+        return r
+    finally:
+        ctx2.sync()
+        del ctx2
 
 
 def main():
@@ -611,7 +666,7 @@ def main():
     pipe.run(args.warmup)               # size, so that first-touch allocations (hipMalloc / hipMemMap / hipHostMalloc) are not what the steps measure
     barrier()
     log("warm-up done; timed region starts")
-    pipe.host_s = pipe.t_launch = pipe.t_decode = pipe.t_release = 0.0; pipe.done_t = []; pipe.refused = 0; pipe.urgent_groups = 0
+    pipe.host_s = pipe.t_launch = pipe.t_decode = pipe.t_release = 0.0; pipe.done_t = []; pipe.refused = pipe.refused_by_the_library = 0; pipe.urgent_groups = 0
     pipe.step_series = []
     pipe.keep_group = pipe.decoded + args.steps - 1          # the last TIMED step keeps the frames of its distinct streams: they are what is verified
     ctx.kernel_stats(reset=True)
@@ -650,7 +705,8 @@ def main():
                     "heap_grows": tstats["heap_grows"], "frames_handed_back_for_lack_of_memory": tstats["nomem_retries"], "frames_evicted": tstats["frames_evicted"],
                     "worker_grids_launched": tstats["worker_launches"], "worker_workgroups_launched": tstats["worker_wgs"], "worker_grids_retired": tstats["worker_retires"],
                     "pool_waits": tstats["pool_waits"], "pool_wait_ms_per_step": round(tstats["pool_wait_ms"] / args.steps, 2),
-                    "hand_overs_put_off_for_lack_of_room": pipe.refused, "frames_parsed_on_host_cores": tstats["host_routed_frames"]}
+                    "hand_overs_put_off_for_lack_of_room": pipe.refused, "of_which_refused_by_the_library_at_its_memory_limit": pipe.refused_by_the_library,
+                    "frames_parsed_on_host_cores": tstats["host_routed_frames"]}
     # the entropy decode against ITS roof: a lane decodes one bool per step, a step takes what it takes (measured on a lone chain),
     # the GPU holds `lanes` chains -> lanes / step latency bools per second at best
     lanes_total = info["token_lanes_per_workgroup"] * info["token_workgroups_capacity"]
@@ -665,6 +721,7 @@ def main():
                   "note": "decode steps of the frames parsed in the timed region (an upper bound on bools) over the timed region's wall time; step latency = lone key frame submit->parsed / its steps"}
     memory = {"limit_gb": round(info["memory_limit_bytes"] / 1e9, 1), "pool_gb": round(info["pool_bytes"] / 1e9, 2), "coefficient_heap_mapped_gb": round(info["heap_mapped_bytes"] / 1e9, 2),
               "hbm_taken_by_the_context_gb": round((info["pool_bytes"] + (info["heap_mapped_bytes"] if info["heap_is_virtual"] else 0)) / 1e9, 2),
+              "inside_the_limit": bool(info["pool_bytes"] + (info["heap_mapped_bytes"] if info["heap_is_virtual"] else 0) <= info["memory_limit_bytes"]),
               "pinned_host_gb": round(info["pinned_host_bytes"] / 1e9, 2), "heap_is_virtual": bool(info["heap_is_virtual"]),
               "hbm_in_use_on_device_gb": round((hbm_total - hbm_free) / 1e9, 1),
               "packed_storage": env["packed_storage"], "planned": env["planned"]}
@@ -853,6 +910,14 @@ def main():
             except Exception as e:                      # (a secondary figure that cannot be had must not take the headline down with it)
                 secondary[cfg_name] = {"error": "%s: %s" % (type(e).__name__, e)}
             log("secondary %s: %s" % (cfg_name, {k: secondary[cfg_name].get(k) for k in ("value", "ms_per_step", "error")}))
+            if cfg_name.endswith("_subpel") and "error" not in secondary[cfg_name]:
+                try:
+                    secondary[cfg_name]["with_a_lane_per_partition"] = lane_per_partition_leg(args, cfg_name, rank, world, threads)
+                except SystemExit:
+                    raise
+                except Exception as e:
+                    secondary[cfg_name]["with_a_lane_per_partition"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                log("secondary %s with a lane per partition: %s" % (cfg_name, {k: secondary[cfg_name]["with_a_lane_per_partition"].get(k) for k in ("value", "ms_per_step", "error")}))
 
     # ---- every frame on the GPU's token lanes (host_share_ms = 0): the same workload, key frames `--key-ahead` steps ahead ----
     lanes_only = None
@@ -873,6 +938,29 @@ def main():
             lanes_only["between_fill_and_drain_value"] = round(world * mbs_per_step * (len(p.done_t) - 1) / (p.done_t[-1] - p.done_t[0]), 1)
         ctx.set_host_share_ms(share)
         del p
+
+    # ---- every frame DELIVERED (what vp8decode / xc-decode-bundle do with every shown frame): the same workload a few steps more,
+    # each reconstructed frame gathered and copied to pinned host memory beside the next frame's reconstruction ----
+    if delivery is None and args.deliver_steps > 0 and rank == 0:
+        try:
+            env3 = dict(env); env3["deliver_ring"] = [ctx.pinned_alloc(S * raster_bytes) for _ in range(2)]
+            p = Pipeline(env3, streams, K, D, args.header_ahead)
+            ctx.sync()
+            t0 = time.perf_counter()
+            p.run(args.deliver_steps); ctx.download_wait(); ctx.sync()
+            dt = time.perf_counter() - t0
+            delivery = {"leg": "a separate run of %d steps after the timed region (the headline `value` does not deliver); empty pipeline to empty pipeline" % args.deliver_steps,
+                        "value": round(mbs_per_step * args.deliver_steps / dt, 1), "unit": "macroblocks/s", "ms_per_step": round(dt / args.deliver_steps * 1e3, 2),
+                        "bytes_per_step": p.delivered_bytes // args.deliver_steps, "gb_per_s": round(p.delivered_bytes / dt / 1e9, 2), "copies_per_frame_index": 1,
+                        "first_step_done_at_ms": round((p.done_t[0] - t0) * 1e3)}
+            if len(p.done_t) > 1:
+                delivery["between_fill_and_drain_gb_per_s"] = round(p.delivered_bytes * (len(p.done_t) - 1) / len(p.done_t) / (p.done_t[-1] - p.done_t[0]) / 1e9, 2)
+            del p
+            for a_ in env3["deliver_ring"]:
+                ctx.pinned_free(a_)
+        except Exception as e:                          # (must not take the headline down)
+            delivery = {"error": "%s: %s" % (type(e).__name__, e)}
+        log("delivery leg: %s" % ({k: delivery.get(k) for k in ("value", "gb_per_s", "between_fill_and_drain_gb_per_s", "error")},))
 
     # ---- host parser (the product's C++ BoolDecoder path used for single streams): rate per core ----
     pp = aa.Parser(width, height)

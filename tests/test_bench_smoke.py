@@ -59,8 +59,9 @@ def test_two_ranks_on_one_gpu_hand_over_the_entry_state():
         except subprocess.TimeoutExpired as e:
             return subprocess.CompletedProcess(cmd, 124, e.stdout or "", "timeout")
     r = run("nccl", 29541)
-    backend = "nccl"
+    backend, nccl_said = "nccl", None
     if r.returncode != 0:
+        nccl_said = (r.stderr or "").strip().splitlines()[-3:]
         r = run("gloo", 29543)
         backend = "gloo"
     assert r.returncode == 0, r.stderr[-3000:]
@@ -75,4 +76,11 @@ def test_two_ranks_on_one_gpu_hand_over_the_entry_state():
         assert pr["hbm_gb"] <= 30.5                               # inside --hbm-gb (8 x 200 GB would not fit a node of 8 x 288: the default is 150)
         assert pr["pinned_host_gb"] * 8 <= 256                    # locked host memory of eight ranks
         assert pr["host_threads"] <= max(1, cores // 2)           # cores / local world size
-    print("two ranks on one GPU: backend", backend)
+    # which backend really carried the hand-off is part of the evidence: on the record, not only on stdout
+    record = {"backend": backend, "world_size": h["world_size"], "broadcast_ms": h.get("broadcast_ms"), "continuations_agree": h["continuations_agree"],
+              "ranks_on_one_gpu": True, "rccl_refused_two_ranks_on_one_device": nccl_said}
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "entry_state_handoff.json"), "w") as fh:
+        json.dump(record, fh, indent=1)
+    print("two ranks on one GPU:", json.dumps(record))

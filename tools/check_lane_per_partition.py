@@ -1,10 +1,8 @@
-"""One token lane per DCT partition (aa_ctx_set_lane_per_partition; tok_fsm.hh, template parameter MP) on a real MI355X.
-NOT YET RUN ON A GPU: the lanes' algorithm is checked on the host, lane by lane and wave by wave (tests/test_wave_sim.py); what
-only a GPU can say is whether the wave-level hand-out of lanes in k_token_workers is right and what a step costs with
-macroblock-boundary passes this frequent.  First thing to run next round:
+"""One token lane per DCT partition (aa_ctx_set_lane_per_partition; tok_fsm.hh, template parameter MP) on a real MI355X -- the
+stand-alone form of tests/test_gpu_lane_per_partition.py (run on the GPU since round 4: profiles/r04_gpu_tests_session2_lane_per_partition_latency.log).
 
     python tools/check_lane_per_partition.py            # parity: records vs the host parser, rasters vs the oracle
-    python tools/check_lane_per_partition.py --latency  # + a 1080p 4-partition key frame: parse latency vs one lane (bar: <= 0.35)
+    python tools/check_lane_per_partition.py --latency  # + a 1080p 4-partition key frame: parse latency vs one lane (measured 0.36)
 """
 import os
 import sys
