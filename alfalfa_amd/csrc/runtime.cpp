@@ -199,10 +199,10 @@ struct aa_ctx {
   ExpandBuf expand_bufs[kBindBufs];
   int next_expand_buf = 0;
   // The dense blocks themselves: TWO transient arrays used in turn by the calls that have packed frames.  The expansion kernels of
-  // call N run on the utility stream, not in front of the call's reconstruction kernels on the compute stream: they need nothing
+  // call N run on a stream of their own (Tok::expand), not in front of the call's reconstruction kernels on the compute stream: they need nothing
   // of call N - 1 (whose kernels the compute stream is still working through when the host issues call N), only the array -- which
   // call N - 2 was the last to read.  `used` is recorded on the compute stream behind the launches of the call that used the
-  // array; `filled` on the utility stream behind its expansion kernels.  (Round 4 had the expansion on the compute stream: 12 x
+  // array; `filled` on that stream behind its expansion kernels.  (Round 4 had the expansion on the compute stream: 12 x
   // 2.3 ms of a step's serial chain.)
   // HOST LANES: host cores in the role of token lanes.  A frame handed to them (AA_SUBMIT_HOST on a call with many streams: the key
   // frames a pipeline needs at once -- 35 ms on a core, 2 s as a chain on a GPU lane) has had its header pre-pass like every frame
@@ -231,7 +231,7 @@ struct aa_ctx {
   static constexpr int kMaxParseStreams = 20;
   // Hardware queues are few (16 asked for above) and a queue runs its commands in order: a stream that shares a queue with a
   // worker grid -- which stays for as long as there is work -- would not get a kernel started until that grid leaves.  So the
-  // context keeps to 15 streams: compute, copy, utility, 4 header-parse streams (short kernels now), 8 worker streams.
+  // context keeps to 16 streams: compute, copy, utility, expansion, 4 header-parse streams (short kernels now), 8 worker streams.
   int n_parse_streams = 4;
   std::vector<hipStream_t> parse_streams;
   std::vector<hipEvent_t> parse_idle;    // recorded behind the last operation queued on the stream
@@ -243,6 +243,9 @@ struct aa_ctx {
   struct Tok {
     bool ready = false;
     hipStream_t util = nullptr;          // mirror kernel, heap pushes: never behind anything long
+    hipStream_t expand = nullptr;        // k_dense_index / k_expand_coeffs of the NEXT reconstruction call (a stream of their own: they wait for events of the compute
+                                         // stream, and the host synchronises with `util` whenever it refreshes the counters -- on `util` they made every such look wait
+                                         // for the compute stream's backlog, 280 ms per step of the first round-5 runs)
     // job queue
     aa::TokQueue * q = nullptr;
     unsigned long long * slots = nullptr;
@@ -471,10 +474,13 @@ aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out, bool refusable 
       soft_waits++; attempt = 0;
       continue;
     }
-    // ... and a limit that limits: with nothing left to wait for, the allocation fails (repeatable: the caller releases frames or
-    // raises aa_ctx_set_memory_limit) rather than take the context past what it was told it may hold
-    const size_t keep_back = ( refusable && ctx->pool_soft_limit != ~size_t( 0 ) ) ? ctx->pool_soft_limit / 32 : 0;
-    if ( ctx->pool_bytes + ctx->tok.heap_mapped + grow + keep_back > ctx->pool_soft_limit && ctx->pool_bytes > 0 )
+    // ... and a limit that limits what the context ACCEPTS: with nothing left to wait for, the arena of a hand-over is refused
+    // (repeatable: the caller reconstructs and releases frames first, or raises aa_ctx_set_memory_limit) rather than take the
+    // context past what it was told it may hold.  What gets frames OUT again -- rasters, the dense blocks of a reconstruction call --
+    // is never refused: it lives on the thirty-second kept back from the hand-overs, and goes past the limit only when the caller
+    // holds more decoded frames at once than that covers (the pool does not re-split the free pieces of other sizes it holds).
+    const size_t keep_back = ctx->pool_soft_limit != ~size_t( 0 ) ? ctx->pool_soft_limit / 32 : 0;
+    if ( refusable && ctx->pool_bytes + ctx->tok.heap_mapped + grow + keep_back > ctx->pool_soft_limit && ctx->pool_bytes > 0 )
       return fail( AA_ERR_NO_MEMORY, "device pool: the context's memory limit (" + std::to_string( ctx->pool_soft_limit >> 20 ) + " MiB: pool "
                                      + std::to_string( ctx->pool_bytes >> 20 ) + " + coefficient heap " + std::to_string( ctx->tok.heap_mapped >> 20 )
                                      + ") does not allow another " + std::to_string( grow >> 20 ) + " MiB: release decoded frames or raise aa_ctx_set_memory_limit" );
@@ -706,7 +712,7 @@ aa_status tok_grow_heap( aa_ctx * ctx, size_t want_mapped )
 aa_status probe_stream_concurrency( aa_ctx * ctx )
 {
   auto & T = ctx->tok;
-  std::vector<hipStream_t> all { ctx->compute, ctx->copy, T.util };
+  std::vector<hipStream_t> all { ctx->compute, ctx->copy, T.util, T.expand };
   for ( auto ps : ctx->parse_streams ) all.push_back( ps );
   for ( auto & sl : T.slot ) all.push_back( sl.st );
   const uint32_t n = static_cast<uint32_t>( all.size() );
@@ -745,6 +751,7 @@ aa_status tok_init( aa_ctx * ctx )
   HIP_TRY( hipGetDeviceProperties( &prop, ctx->device ) );
   T.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
   HIP_TRY( hipStreamCreateWithFlags( &T.util, hipStreamNonBlocking ) );
+  { int lo = 0, hi = 0; (void) hipDeviceGetStreamPriorityRange( &lo, &hi ); HIP_TRY( hipStreamCreateWithPriority( &T.expand, hipStreamNonBlocking, hi ) ); }
   for ( auto & sl : T.slot ) HIP_TRY( hipStreamCreateWithPriority( &sl.st, hipStreamNonBlocking, ctx->prio_low ) );
   if ( aa_status st = probe_stream_concurrency( ctx ) ) return st;
   // the job queue
@@ -812,6 +819,7 @@ void tok_free( aa_ctx * ctx )
   if ( T.util ) { (void) hipStreamSynchronize( T.util ); }
   for ( auto & sl : T.slot ) if ( sl.st ) { (void) hipStreamSynchronize( sl.st ); (void) hipStreamDestroy( sl.st ); sl.st = nullptr; }
   if ( T.util ) { (void) hipStreamDestroy( T.util ); T.util = nullptr; }
+  if ( T.expand ) { (void) hipStreamSynchronize( T.expand ); (void) hipStreamDestroy( T.expand ); T.expand = nullptr; }
   if ( T.vmm ) {
     if ( T.heap_mapped ) (void) hipMemUnmap( T.heap, T.heap_mapped );
     for ( auto h : T.handles ) (void) hipMemRelease( h );
@@ -2598,11 +2606,11 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
                        } } } bind_guard( ctx );
   if ( aa_status st = bind_batch( ctx, streams, n, frame_index ) ) return st;
   if ( !packed_frames.empty() ) {
-    // the expansion runs on the utility stream, behind the kernels that last read the array (two calls ago) -- or, when a frame
+    // the expansion runs on a stream of its own, behind the kernels that last read the array (two calls ago) -- or, when a frame
     // of the call is being reconstructed again, behind everything queued so far: kernels of its earlier run may still follow
     // its job record to the array it pointed at then
     static const bool on_compute = [] { const char * e = std::getenv( "ALFALFA_AMD_EXPAND_ON_COMPUTE" ); return e && atoi( e ) != 0; }();      // (A/B runs: round 4's placement)
-    hipStream_t es = ( ctx->tok.util && !on_compute ) ? ctx->tok.util : ctx->compute;
+    hipStream_t es = ( ctx->tok.expand && !on_compute ) ? ctx->tok.expand : ctx->compute;
     if ( es != ctx->compute ) {
       if ( decoded_before ) { HIP_TRY( hipEventRecord( dense->filled, ctx->compute ) ); HIP_TRY( hipStreamWaitEvent( es, dense->filled, 0 ) ); }
       else if ( dense->in_use ) HIP_TRY( hipStreamWaitEvent( es, dense->used, 0 ) );

@@ -885,7 +885,10 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
     const uint32_t band = static_cast<uint32_t>( kBandNib >> ( ( idx * 4 ) & 63 ) ) & 15u;
     // (a select by mask arithmetic: written as a conditional the compiler makes it a predicated region -- a compare, two scalar
     // instructions on the exec mask and the round trip between the vector and the scalar unit that goes with them; measured on
-    // MI355X: 4 % of a wave step.  Asking for the stream byte a step ahead, tried in the same session, bought nothing.)
+    // MI355X: 4 % of a wave step.  Two other formulations measured and dropped: the stream byte asked for a step ahead (no change),
+    // and probability + node record + stream byte all asked for in the MIDDLE of the previous step, so that the renormalisation and
+    // the coefficient store run while they travel (0.247 against 0.236 us per wave step: the extra live registers and moves cost more
+    // than the LDS round trip they hide -- the step is bound by its ~70 dependent vector instructions, not by LDS latency).)
     const uint32_t rowaddr = AA_BFI( 0u - adv, L.typeaddr + band * 33u + AA_UBFE( h, 19, 5 ), L.rowaddr );
     const uint32_t paddr = ( ( h & H_ROWREL ) ? rowaddr : kXtab ) + AA_UBFE( h, 9, 5 );
     const bool bend = ( ( h & H_EOB ) | ( idx & 16u ) ) != 0;            // an EOB token, or position 16 reached

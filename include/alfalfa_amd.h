@@ -28,7 +28,7 @@ extern "C" {
 
 /* 4 (round 5): aa_ctx_info and aa_kernel_stats grew in round 4 (a caller built against version 3 passes smaller structs: check
  * aa_abi_version() against the header you compiled with before calling aa_ctx_get_info / aa_ctx_kernel_stats), packed coefficient
- * storage became the default, AA_SUBMIT_HOST on a big call no longer waits for the parse (host lanes), the memory limit is hard. */
+ * storage became the default, AA_SUBMIT_HOST on a big call no longer waits for the parse (host lanes), hand-overs are refused at the memory limit. */
 #define AA_ABI_VERSION 4
 
 typedef enum aa_status {
@@ -46,7 +46,7 @@ typedef enum aa_status {
 /* Message of the last failing call on this thread ("" if none). */
 const char * aa_last_error( void );
 int aa_abi_version( void );
-/* The HIP runtime reads GPU_MAX_HW_QUEUES when it starts; this library runs 15 HIP streams side by side (long-lived entropy-decode
+/* The HIP runtime reads GPU_MAX_HW_QUEUES when it starts; this library runs 16 HIP streams side by side (long-lived entropy-decode
  * grids beside short reconstruction kernels) and wants 16 hardware queues (the default is 4).  Call this before the process makes
  * its first HIP call -- the bindings call it before their first aa_ctx_create -- to set the variable if the environment does not
  * (a value that is set stands).  -> 1 if it was set already, 0 if this call set it.  Nothing else of the host process is touched;
@@ -177,10 +177,13 @@ aa_status aa_ctx_set_schedule( aa_ctx * ctx, int schedule );
  * After the caller has dealt with it (e.g. switched to AA_SCHEDULE_DIAGONAL), this clears the word. */
 aa_status aa_ctx_clear_error( aa_ctx * ctx );
 /* HBM the context may take for its pools (frame records, rasters, the coefficient heap of the device parser): by default 7/8 of
- * what was free when it was created; a caller that shares the GPU sets less.  Memory is taken as frames need it, up to this --
- * and NOT beyond (round 5): pool + mapped coefficient heap never exceed it.  An allocation that would first waits for pieces
- * released behind queued kernels; when none are left it fails with AA_ERR_NO_MEMORY (repeatable once frames have been released).
- * The heap, which never unmaps, leaves a sixteenth of the limit to the pool. */
+ * what was free when it was created; a caller that shares the GPU sets less.  Memory is taken as frames need it, up to this.
+ * Round 5: the limit bounds what the context ACCEPTS.  aa_submit_frames stops a thirty-second short of it: a hand-over whose
+ * arena would take pool + mapped coefficient heap beyond that first waits for pieces released behind queued kernels, and when
+ * none are left is refused with AA_ERR_NO_MEMORY (nothing is appended; repeatable once frames have been reconstructed and
+ * released) -- a pipelining caller treats that as "not now".  The coefficient heap, which never unmaps, leaves a sixteenth of
+ * the limit to the pool.  Reconstruction (rasters, transient dense blocks) is never refused: it lives on what is kept back, and
+ * goes past the limit only if the caller holds more decoded frames at once than that covers. */
 aa_status aa_ctx_set_memory_limit( aa_ctx * ctx, size_t bytes );
 /* What the context holds right now (the memory budget of a deployment: one context per GPU, one process per GPU). */
 typedef struct aa_ctx_info {
@@ -211,7 +214,7 @@ typedef struct aa_ctx_info {
                                         parse time only; 0: none yet).  The share of later calls is planned with it: visible cores and usable cores differ under a CPU quota */
   uint32_t reserved1;
   uint32_t stream_concurrency;       /* how many of the context's HIP streams were seen running side by side (probed at the first aa_submit_frames; 0: not yet) */
-  uint32_t streams_needed;           /* ... of how many (15): fewer means GPU_MAX_HW_QUEUES was not in effect, see aa_runtime_prepare */
+  uint32_t streams_needed;           /* ... of how many (16): fewer means GPU_MAX_HW_QUEUES was not in effect, see aa_runtime_prepare */
 } aa_ctx_info;
 aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out );
 /* How the device parser stores a frame's coefficients until the frame is reconstructed.  1 (default): packed -- one mask word +
