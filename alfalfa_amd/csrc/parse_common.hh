@@ -52,8 +52,11 @@ constexpr uint8_t kSplitCount[4] = { 2, 2, 4, 16 };
 // Everything the macroblock loop of one frame needs that is decided by the frame header and the persistent DecoderState
 // (decoder_state.hh:72-167).  Written by the host header pre-pass (Parser::parse_header); read by the host macroblock loop
 // or, unchanged, by the device parse kernels (one record per frame in HBM).  Plain data, no pointers.
-struct FrameParams {
-  uint8_t coeff_probs[4][8][3][11];      // this frame's token probabilities (first: 16-byte aligned in a ParseJob)
+//   CoeffProbs   the token probabilities: what the token lanes read (first: 16-byte aligned in a ParseJob)
+//   HeaderParams everything else: what the macroblock-HEADER parse reads -- 200 bytes, which the header kernel copies into LDS per
+//                lane (a field read from the job in HBM is a dependent global load in front of nearly every bool)
+struct CoeffProbs { uint8_t coeff_probs[4][8][3][11]; };
+struct HeaderParams {
   uint32_t first_off, first_size;        // first partition: byte range inside the frame (uncompressed_chunk.cc:117-130)
   uint32_t bd_bitpos;                    // boolean decoder hand-over at the first macroblock header (see BoolState)
   uint8_t bd_range, bd_active;
@@ -69,7 +72,38 @@ struct FrameParams {
   uint8_t y_mode_probs[4], uv_mode_probs[3], mv_probs[2][19];
   uint8_t pad[3];
 };
-static_assert( sizeof( FrameParams ) % 4 == 0, "FrameParams is copied as words" );
+struct FrameParams : CoeffProbs, HeaderParams {};
+static_assert( sizeof( FrameParams ) % 4 == 0 && sizeof( HeaderParams ) % 4 == 0 && sizeof( FrameParams ) == sizeof( CoeffProbs ) + sizeof( HeaderParams ),
+               "FrameParams / HeaderParams are copied as words" );
+
+// Every constant table the macroblock-header parse reads with a data-dependent index, as ONE blob: the header kernel copies it into
+// LDS once per workgroup (from the kernel's constant data each tree node and each probability was a dependent global load: two of
+// them in front of every bool); the host parser reads the static instance.
+struct HeaderTables {
+  int8_t kf_y_mode_tree[8], y_mode_tree[8], uv_mode_tree[6], b_mode_tree[18], small_mv_tree[14], mv_ref_tree[8], sub_mv_ref_tree[6], split_mv_tree[6], segment_id_tree[6];
+  uint8_t kf_y_mode_probs[4], kf_uv_mode_probs[3], b_mode_probs[9], mv_counts_to_probs[24], split_mv_probs[3], submv_ref_probs[15];
+  uint8_t split_layout[4][16], split_first[4][16], split_count[4];
+  uint8_t kf_b_mode_probs[900];          // [above mode][left mode][node]
+  uint8_t pad[2];
+};
+static_assert( sizeof( HeaderTables ) % 4 == 0, "HeaderTables is copied as words" );
+constexpr HeaderTables make_header_tables()
+{
+  HeaderTables t {};
+  for ( int i = 0; i < 8; i++ ) { t.kf_y_mode_tree[i] = kKfYModeTree[i]; t.y_mode_tree[i] = kYModeTree[i]; t.mv_ref_tree[i] = kMvRefTree[i]; }
+  for ( int i = 0; i < 6; i++ ) { t.uv_mode_tree[i] = kUvModeTree[i]; t.sub_mv_ref_tree[i] = kSubMvRefTree[i]; t.split_mv_tree[i] = kSplitMvTree[i]; t.segment_id_tree[i] = kSegmentIdTree[i]; }
+  for ( int i = 0; i < 18; i++ ) t.b_mode_tree[i] = kBModeTree[i];
+  for ( int i = 0; i < 14; i++ ) t.small_mv_tree[i] = kSmallMvTree[i];
+  for ( int i = 0; i < 4; i++ ) t.kf_y_mode_probs[i] = k_kf_y_mode_probs[i];
+  for ( int i = 0; i < 3; i++ ) { t.kf_uv_mode_probs[i] = k_kf_uv_mode_probs[i]; t.split_mv_probs[i] = k_split_mv_probs[i]; }
+  for ( int i = 0; i < 9; i++ ) t.b_mode_probs[i] = k_b_mode_probs[i];
+  for ( int i = 0; i < 24; i++ ) t.mv_counts_to_probs[i] = k_mv_counts_to_probs[i];
+  for ( int i = 0; i < 15; i++ ) t.submv_ref_probs[i] = k_submv_ref_probs[i];
+  for ( int i = 0; i < 4; i++ ) { t.split_count[i] = kSplitCount[i]; for ( int j = 0; j < 16; j++ ) { t.split_layout[i][j] = kSplitLayout[i][j]; t.split_first[i][j] = kSplitFirst[i][j]; } }
+  for ( int i = 0; i < 900; i++ ) t.kf_b_mode_probs[i] = k_kf_b_mode_probs[i];
+  return t;
+}
+constexpr HeaderTables kHeaderTables = make_header_tables();
 
 
 
@@ -89,6 +123,23 @@ class BoolReader32
   uint32_t value_ = 0;           // window, most significant bits first
   int count_ = 0;                // valid bits below the 8 being compared
   uint32_t range_ = 255;
+  uint32_t cache_ = 0;           // the bytes at pos_, pos_ + 1, ... of the aligned word they were read with (lowest byte first)
+  uint32_t cache_n_ = 0;         // how many of them: the stream is read a word at a time -- on the GPU every read is a trip to the L2
+
+  // the byte at pos_ (zero past the end), pos_ advanced.  The word read is the ALIGNED one the byte lies in: it never reaches into a
+  // page the byte itself is not on, whatever the alignment of the partition and wherever the buffer ends.
+  AA_HD inline uint32_t next_byte()
+  {
+    if ( cache_n_ == 0 ) {
+      const uintptr_t a = reinterpret_cast<uintptr_t>( base_ + pos_ );
+      const uint32_t skip = static_cast<uint32_t>( a & 3u );
+      cache_ = *reinterpret_cast<const uint32_t *>( a - skip ) >> ( 8u * skip );
+      cache_n_ = 4u - skip;
+    }
+    const uint32_t byte = pos_ < end_ ? ( cache_ & 0xFFu ) : 0u;
+    cache_ >>= 8; cache_n_--; pos_++;
+    return byte;
+  }
 
 public:
   AA_HD BoolReader32() {}
@@ -97,11 +148,11 @@ public:
     base_ = base; end_ = size; range_ = st.range;
     // raw bits from st.bitpos up to the next byte boundary + 16 go below the active byte; from there on whole bytes
     const uint32_t byte = st.bitpos >> 3, r = st.bitpos & 7;
+    pos_ = byte; cache_n_ = 0;
     uint32_t b = 0;
-    for ( int k = 0; k < 3; k++ ) b = ( b << 8 ) | ( byte + k < end_ ? base_[byte + k] : 0u );
+    for ( int k = 0; k < 3; k++ ) b = ( b << 8 ) | next_byte();
     value_ = ( static_cast<uint32_t>( st.active ) << 24 ) | ( ( b << r ) & 0xFFFFFFu );
     count_ = 24 - static_cast<int>( r );
-    pos_ = byte + 3;
   }
   AA_HD void reset( const uint8_t * base, uint32_t size )     // fresh partition: the first byte is the active byte
   {
@@ -112,9 +163,7 @@ public:
   {
     const uint32_t split = 1 + ( ( ( range_ - 1 ) * prob ) >> 8 );
     if ( count_ < 0 ) {                                         // one byte always fits: 8 + count_ < 8
-      const uint32_t byte = pos_ < end_ ? base_[pos_] : 0u;
-      pos_++;
-      value_ |= byte << ( 16 - count_ );
+      value_ |= next_byte() << ( 16 - count_ );
       count_ += 8;
     }
     const uint32_t bigsplit = split << 24;
@@ -148,7 +197,7 @@ AA_HD inline int clamp_int( int v, int lo, int hi ) { return v < lo ? lo : ( v >
 
 // MotionVector::read_component, macroblock.cc:198-229
 template <class BD>
-AA_HD inline int16_t read_mv_component( BD & bd, const uint8_t * p )
+AA_HD inline int16_t read_mv_component( BD & bd, const uint8_t * p, const HeaderTables & T )
 {
   enum { MV_IS_SHORT, SIGN, SHORT, BITS = SHORT + 8 - 1, MV_LONG_BITS = 10 };
   int x = 0;
@@ -157,7 +206,7 @@ AA_HD inline int16_t read_mv_component( BD & bd, const uint8_t * p )
     for ( int i = MV_LONG_BITS - 1; i > 3; i-- ) x += bd.get( p[BITS + i] ) << i;
     if ( !( x & 0xFFF0 ) || bd.get( p[BITS + 3] ) ) x += 8;
   } else {
-    x = bd.tree( kSmallMvTree, p + SHORT );
+    x = bd.tree( T.small_mv_tree, p + SHORT );
   }
   x <<= 1;
   if ( x && bd.get( p[SIGN] ) ) x = -x;
@@ -165,11 +214,11 @@ AA_HD inline int16_t read_mv_component( BD & bd, const uint8_t * p )
 }
 
 template <class BD>
-AA_HD inline Mv read_mv( BD & bd, const FrameParams & fp )
+AA_HD inline Mv read_mv( BD & bd, const HeaderParams & fp, const HeaderTables & T )
 {
   Mv m;
-  m.y = read_mv_component( bd, fp.mv_probs[0] );   // row first (macroblock.cc:283-287)
-  m.x = read_mv_component( bd, fp.mv_probs[1] );
+  m.y = read_mv_component( bd, fp.mv_probs[0], T );   // row first (macroblock.cc:283-287)
+  m.x = read_mv_component( bd, fp.mv_probs[1], T );
   return m;
 }
 
@@ -186,7 +235,7 @@ AA_HD inline Mv clamp_mv( Mv m, unsigned col, unsigned row, unsigned mbw, unsign
 }
 
 // Final loop-filter level of one macroblock: frame.cc:144-166, macroblock.cc:611-623, loopfilter.cc:59-79
-AA_HD inline uint8_t mb_lf_level( const FrameParams & fp, unsigned segment_id, unsigned ref_frame, unsigned y_mode )
+AA_HD inline uint8_t mb_lf_level( const HeaderParams & fp, unsigned segment_id, unsigned ref_frame, unsigned y_mode )
 {
   if ( !fp.loop_filter_level ) return 0;
   int level = fp.seg_level[segment_id];
@@ -202,7 +251,7 @@ AA_HD inline uint8_t mb_lf_level( const FrameParams & fp, unsigned segment_id, u
 
 // One macroblock of the segment-map pass that follows a device parse (frames of a stream in order): a frame that updates
 // the map publishes its ids, a frame that does not inherits them (and only now learns its loop-filter levels).
-AA_HD inline void segment_fixup( const FrameParams & fp, aa_mb_info & mb, uint8_t & map )
+AA_HD inline void segment_fixup( const HeaderParams & fp, aa_mb_info & mb, uint8_t & map )
 {
   if ( fp.seg_update_map ) map = mb.segment_id;
   else {
@@ -211,7 +260,7 @@ AA_HD inline void segment_fixup( const FrameParams & fp, aa_mb_info & mb, uint8_
   }
 }
 
-AA_HD inline bool mv_flipped( const FrameParams & fp, unsigned ref_frame )    // motion_vectors_flipped_, macroblock.cc:464-465
+AA_HD inline bool mv_flipped( const HeaderParams & fp, unsigned ref_frame )    // motion_vectors_flipped_, macroblock.cc:464-465
 {
   return ( ref_frame == GOLDEN_FRAME && fp.sign_bias_golden ) || ( ref_frame == ALTREF_FRAME && fp.sign_bias_alt );
 }
@@ -222,7 +271,7 @@ AA_HD inline bool mv_flipped( const FrameParams & fp, unsigned ref_frame )    //
 // afterwards (device parser: frames of one stream are parsed concurrently; see k_segment_fixup).
 // Returns the record's flags (INTER | HAS_Y2 | SKIP).
 template <class BD>
-AA_HD inline uint8_t parse_mb_header( BD & bd, const FrameParams & fp, aa_mb_info * mbs, unsigned mi, unsigned col, unsigned row,
+AA_HD inline uint8_t parse_mb_header( BD & bd, const HeaderParams & fp, const HeaderTables & T, aa_mb_info * mbs, unsigned mi, unsigned col, unsigned row,
                                       uint8_t * segmap )
 {
   const unsigned mbw = fp.mbw, mbh = fp.mbh;
@@ -237,7 +286,7 @@ AA_HD inline uint8_t parse_mb_header( BD & bd, const FrameParams & fp, aa_mb_inf
   unsigned segment_id = 0;
   if ( fp.seg_enabled ) {
     if ( fp.seg_update_map ) {
-      segment_id = static_cast<unsigned>( bd.tree( kSegmentIdTree, fp.seg_tree_probs ) );
+      segment_id = static_cast<unsigned>( bd.tree( T.segment_id_tree, fp.seg_tree_probs ) );
       if ( segmap ) segmap[mi] = static_cast<uint8_t>( segment_id );
     } else if ( segmap ) segment_id = segmap[mi];
   }
@@ -254,26 +303,35 @@ AA_HD inline uint8_t parse_mb_header( BD & bd, const FrameParams & fp, aa_mb_inf
 
   if ( !inter ) {
     // ---- intra modes: macroblock.cc:84-111 (key) / 354-376 (inter frame) ----
-    mb.y_mode = static_cast<uint8_t>( key ? bd.tree( kKfYModeTree, k_kf_y_mode_probs ) : bd.tree( kYModeTree, fp.y_mode_probs ) );
+    mb.y_mode = static_cast<uint8_t>( key ? bd.tree( T.kf_y_mode_tree, T.kf_y_mode_probs ) : bd.tree( T.y_mode_tree, fp.y_mode_probs ) );
     if ( mb.y_mode == B_PRED ) {
+      // (the sixteen modes in registers until all are known: read back out of the record they were a store -> load round trip
+      // through the L2 per sub-block on the GPU)
+      uint8_t bm[16];
+      uint8_t above4[4] = { B_DC_PRED, B_DC_PRED, B_DC_PRED, B_DC_PRED }, left4[4] = { B_DC_PRED, B_DC_PRED, B_DC_PRED, B_DC_PRED };
+      if ( key ) {
+        if ( row > 0 ) for ( int k = 0; k < 4; k++ ) above4[k] = mbs[mi - mbw].u.b_mode[12 + k];
+        if ( col > 0 ) for ( int k = 0; k < 4; k++ ) left4[k] = mbs[mi - 1].u.b_mode[4 * k + 3];
+      }
+#if defined( __HIP_DEVICE_COMPILE__ )
+#pragma unroll
+#endif
       for ( int b = 0; b < 16; b++ ) {
         if ( key ) {
-          int above_mode = B_DC_PRED, left_mode = B_DC_PRED;
-          if ( b >= 4 ) above_mode = mb.u.b_mode[b - 4];
-          else if ( row > 0 ) above_mode = mbs[mi - mbw].u.b_mode[b + 12];
-          if ( b & 3 ) left_mode = mb.u.b_mode[b - 1];
-          else if ( col > 0 ) left_mode = mbs[mi - 1].u.b_mode[b + 3];
-          mb.u.b_mode[b] = static_cast<uint8_t>( bd.tree( kBModeTree, k_kf_b_mode_probs + ( above_mode * 10 + left_mode ) * 9 ) );
+          const int above_mode = b >= 4 ? bm[b - 4] : above4[b];
+          const int left_mode = ( b & 3 ) ? bm[b - 1] : left4[b >> 2];
+          bm[b] = static_cast<uint8_t>( bd.tree( T.b_mode_tree, T.kf_b_mode_probs + ( above_mode * 10 + left_mode ) * 9 ) );
         } else {
-          mb.u.b_mode[b] = static_cast<uint8_t>( bd.tree( kBModeTree, k_b_mode_probs ) );
+          bm[b] = static_cast<uint8_t>( bd.tree( T.b_mode_tree, T.b_mode_probs ) );
         }
       }
+      for ( int b = 0; b < 16; b++ ) mb.u.b_mode[b] = bm[b];
     } else {
       constexpr uint8_t kImplied[4] = { B_DC_PRED, B_VE_PRED, B_HE_PRED, B_TM_PRED };   // macroblock.hh:134-143
       const uint8_t m = kImplied[mb.y_mode];
       for ( int b = 0; b < 16; b++ ) mb.u.b_mode[b] = m;
     }
-    mb.uv_mode = static_cast<uint8_t>( key ? bd.tree( kUvModeTree, k_kf_uv_mode_probs ) : bd.tree( kUvModeTree, fp.uv_mode_probs ) );
+    mb.uv_mode = static_cast<uint8_t>( key ? bd.tree( T.uv_mode_tree, T.kf_uv_mode_probs ) : bd.tree( T.uv_mode_tree, fp.uv_mode_probs ) );
   } else {
     // ---- inter modes: census (scorer.hh, macroblock.cc:143-181,301-312) then mode / MVs (:377-455) ----
     mb.flags |= AA_MB_INTER;
@@ -302,25 +360,25 @@ AA_HD inline uint8_t parse_mb_header( BD & bd, const FrameParams & fp, aa_mb_inf
       const Mv tm = cand[1]; cand[1] = cand[2]; cand[2] = tm;
     }
     if ( score[1] >= score[0] ) cand[0] = cand[1];
-    const uint8_t mode_probs[4] = { k_mv_counts_to_probs[score[0] * 4 + 0], k_mv_counts_to_probs[score[1] * 4 + 1],
-                                    k_mv_counts_to_probs[score[2] * 4 + 2], k_mv_counts_to_probs[split_score * 4 + 3] };
-    mb.y_mode = static_cast<uint8_t>( bd.tree( kMvRefTree, mode_probs ) );
+    const uint8_t mode_probs[4] = { T.mv_counts_to_probs[score[0] * 4 + 0], T.mv_counts_to_probs[score[1] * 4 + 1],
+                                    T.mv_counts_to_probs[score[2] * 4 + 2], T.mv_counts_to_probs[split_score * 4 + 3] };
+    mb.y_mode = static_cast<uint8_t>( bd.tree( T.mv_ref_tree, mode_probs ) );
     Mv base;
     switch ( mb.y_mode ) {
     case NEARESTMV: base = clamp_mv( cand[1], col, row, mbw, mbh ); break;
     case NEARMV: base = clamp_mv( cand[2], col, row, mbw, mbh ); break;
     case ZEROMV: break;
     case NEWMV: {
-      const Mv delta = read_mv( bd, fp );
+      const Mv delta = read_mv( bd, fp, T );
       const Mv best = clamp_mv( cand[0], col, row, mbw, mbh );
       base.x = static_cast<int16_t>( delta.x + best.x ); base.y = static_cast<int16_t>( delta.y + best.y );
       break; }
     default: {   // SPLITMV (the tree has no other leaf)
-      mb.split_partition = static_cast<uint8_t>( bd.tree( kSplitMvTree, k_split_mv_probs ) );
+      mb.split_partition = static_cast<uint8_t>( bd.tree( T.split_mv_tree, T.split_mv_probs ) );
       const Mv best = clamp_mv( cand[0], col, row, mbw, mbh );
-      const uint8_t * layout = kSplitLayout[mb.split_partition];
-      for ( int part = 0; part < kSplitCount[mb.split_partition]; part++ ) {
-        const int b = kSplitFirst[mb.split_partition][part];
+      const uint8_t * layout = T.split_layout[mb.split_partition];
+      for ( int part = 0; part < T.split_count[mb.split_partition]; part++ ) {
+        const int b = T.split_first[mb.split_partition][part];
         // YBlock::read_subblock_inter_prediction, macroblock.cc:231-281
         Mv lmv, amv;
         if ( b & 3 ) { lmv.x = mb.u.mv[b - 1][0]; lmv.y = mb.u.mv[b - 1][1]; }
@@ -332,11 +390,11 @@ AA_HD inline uint8_t parse_mb_header( BD & bd, const FrameParams & fp, aa_mb_inf
         else if ( amv.zero() ) ctx = 2;
         else if ( lmv.zero() ) ctx = 1;
         Mv m;
-        switch ( bd.tree( kSubMvRefTree, k_submv_ref_probs + ctx * 3 ) ) {
+        switch ( bd.tree( T.sub_mv_ref_tree, T.submv_ref_probs + ctx * 3 ) ) {
         case LEFT4X4: m = lmv; break;
         case ABOVE4X4: m = amv; break;
         case ZERO4X4: break;
-        default: { const Mv d = read_mv( bd, fp ); m.x = static_cast<int16_t>( d.x + best.x ); m.y = static_cast<int16_t>( d.y + best.y ); break; }   // NEW4X4
+        default: { const Mv d = read_mv( bd, fp, T ); m.x = static_cast<int16_t>( d.x + best.x ); m.y = static_cast<int16_t>( d.y + best.y ); break; }   // NEW4X4
         }
         for ( int k = 0; k < 16; k++ ) if ( layout[k] == part ) { mb.u.mv[k][0] = m.x; mb.u.mv[k][1] = m.y; }
       }

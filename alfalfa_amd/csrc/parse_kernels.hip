@@ -34,12 +34,27 @@ __global__ __launch_bounds__( 64 ) void k_parse_mb_headers( const ParseJob * job
 {
   __builtin_amdgcn_s_setprio( 2 );      // short chains the long token chains wait for: ahead of them at the issue arbiter
 
+  // Everything the parse reads with a data-dependent index lives in LDS: the constant trees and probability tables (one copy per
+  // workgroup) and the frame's own header parameters (one copy per lane).  Read out of the kernel's constant data and out of the job
+  // in HBM they were two dependent global loads in front of nearly every bool: 170 ms per hand-over of inter frames, half a second
+  // for key frames (16 tree decodes per B_PRED macroblock), on the path every frame's token lane waits for.
+  __shared__ aa::HeaderTables s_tables;
+  __shared__ aa::HeaderParams s_params[16];
   const int lane = threadIdx.x;
+  for ( uint32_t k = lane; k < sizeof( aa::HeaderTables ) / 4; k += 64 ) reinterpret_cast<uint32_t *>( &s_tables )[k] = reinterpret_cast<const uint32_t *>( &aa::kHeaderTables )[k];
   const int slot = blockIdx.x * lanes + lane;
-  if ( lane >= lanes || slot >= n ) return;
-  const ParseJob & J = jobs[order[slot]];
+  const bool mine = lane < lanes && lane < 16 && slot < n;
+  const ParseJob * Jp = mine ? &jobs[order[slot]] : nullptr;
+  if ( Jp ) {
+    const uint32_t * src = reinterpret_cast<const uint32_t *>( static_cast<const aa::HeaderParams *>( &Jp->fp ) );
+    for ( uint32_t k = 0; k < sizeof( aa::HeaderParams ) / 4; k++ ) reinterpret_cast<uint32_t *>( &s_params[lane] )[k] = src[k];
+  }
+  __syncthreads();
+  if ( !Jp ) return;
+  const ParseJob & J = *Jp;
   if ( J.nmb == 0 ) return;                      // a frame the host header pre-pass rejected
-  const aa::FrameParams & fp = J.fp;
+  const aa::HeaderParams & fp = s_params[lane];
+  const aa::HeaderTables & T = s_tables;
   aa::BoolReader32 bd;
   aa::BoolState st; st.bitpos = fp.bd_bitpos; st.range = fp.bd_range; st.active = fp.bd_active;
   bd.resume( J.data + fp.first_off, fp.first_size, st );
@@ -54,7 +69,7 @@ __global__ __launch_bounds__( 64 ) void k_parse_mb_headers( const ParseJob * job
     unsigned long long word = 0;
     const uint32_t mp_row = mp_stride ? mp_base + ( row % nparts ) * mp_stride + ( row / nparts ) * mbw : 0u;
     for ( unsigned col = 0; col < mbw; col++, mi++ ) {
-      const uint8_t flags = aa::parse_mb_header( bd, fp, J.mbs, mi, col, row, static_cast<uint8_t *>( nullptr ) );
+      const uint8_t flags = aa::parse_mb_header( bd, fp, T, J.mbs, mi, col, row, static_cast<uint8_t *>( nullptr ) );
       J.mbflags[mi] = flags;
       if ( mp_stride ) J.mbflags[mp_row + col] = flags;
       if ( !( flags & AA_MB_INTER ) ) { intra++; word |= 1ull << ( col & 63 ); }
@@ -386,7 +401,7 @@ static int parse_lanes_env()
   }();
   return lanes;
 }
-static int header_lanes() { const int v = parse_lanes_env(); return v ? v : 16; }
+static int header_lanes() { const int v = parse_lanes_env(); return v ? std::min( v, 16 ) : 16; }      // (k_parse_mb_headers keeps 16 lanes' parameters in LDS)
 
 // Token workgroups stay for as long as there is work, and what they leave of a CU -- LDS, registers -- is all the reconstruction
 // kernels (milliseconds each, on the high-priority stream) ever get.  The shape is therefore chosen for the reconstruction

@@ -452,7 +452,7 @@ static void parse_body( BD & bd, const uint8_t * data, const FrameParams & fp, a
     for ( unsigned col = 0; col < mbw; col++ ) {
       const unsigned mi = row * mbw + col;
       aa_mb_info & mb = mbs[mi];
-      const uint8_t flags = parse_mb_header( bd, fp, mbs, mi, col, row, segmap );
+      const uint8_t flags = parse_mb_header( bd, fp, kHeaderTables, mbs, mi, col, row, segmap );
       const bool skip = flags & AA_MB_SKIP, has_y2 = flags & AA_MB_HAS_Y2;
       if ( !( flags & AA_MB_INTER ) ) intra_mbs++;
 

@@ -479,8 +479,15 @@ aa_status dev_alloc( aa_ctx * ctx, size_t bytes, uint8_t ** out, bool refusable 
     // context past what it was told it may hold.  What gets frames OUT again -- rasters, the dense blocks of a reconstruction call --
     // is never refused: it lives on the thirty-second kept back from the hand-overs, and goes past the limit only when the caller
     // holds more decoded frames at once than that covers (the pool does not re-split the free pieces of other sizes it holds).
+    // (What counts is what the context HOLDS -- live pieces + mapped heap: the pool keeps freed pieces in per-size lists and does not
+    // re-split them, so after a change of geometry -- or of call sizes -- it may sit on gigabytes that fit nobody; refusing by what it
+    // has TAKEN would then refuse every hand-over for good.  In a run of one geometry the free lists are what the next hand-over is
+    // served from, and taken ~ held.)
     const size_t keep_back = ctx->pool_soft_limit != ~size_t( 0 ) ? ctx->pool_soft_limit / 32 : 0;
-    if ( refusable && ctx->pool_bytes + ctx->tok.heap_mapped + grow + keep_back > ctx->pool_soft_limit && ctx->pool_bytes > 0 )
+    size_t idle = ctx->compute_free_bytes + ( ctx->cur_slab ? kSlabBytes - ctx->slab_used : 0 );
+    for ( auto & kv : ctx->dev_free ) idle += kv.first * kv.second.size();
+    const size_t held = ctx->pool_bytes > idle ? ctx->pool_bytes - idle : 0;
+    if ( refusable && held + ctx->tok.heap_mapped + grow + keep_back > ctx->pool_soft_limit && ctx->pool_bytes > 0 )
       return fail( AA_ERR_NO_MEMORY, "device pool: the context's memory limit (" + std::to_string( ctx->pool_soft_limit >> 20 ) + " MiB: pool "
                                      + std::to_string( ctx->pool_bytes >> 20 ) + " + coefficient heap " + std::to_string( ctx->tok.heap_mapped >> 20 )
                                      + ") does not allow another " + std::to_string( grow >> 20 ) + " MiB: release decoded frames or raise aa_ctx_set_memory_limit" );

@@ -157,6 +157,7 @@ class Pipeline:
         self.host_s = 0.0
         self.t_launch = self.t_decode = self.t_release = 0.0      # host time in aa_launch_tokens / aa_decode_batch / releases
         self.done_t = []
+        self.t_room = 0.0                                # host time in aa_ctx_get_info (the planner's look at the books)
         self.step_series = None
         self.delivered_bytes = 0
         self.refused = 0                                 # times a hand-over was put off because HBM had no room for it
@@ -246,7 +247,9 @@ class Pipeline:
         self.decoded += 1
         self.done_t.append(time.perf_counter())
         if self.step_series is not None:          # what the host waited for, step by step (diagnostics of the timed region)
+            t_info = time.perf_counter()
             ks, i = ctx.kernel_stats(), ctx.info()
+            self.t_room += time.perf_counter() - t_info
             self.step_series.append((round(ks["parse_wait_ms"]), round(ks["bind_wait_ms"]), i["token_workgroups_alive"], i["jobs_waiting"],
                                      round(i["heap_used_bytes"] / 1e9, 1), round((i["pool_bytes"] - i["pool_free_bytes"]) / 1e9, 1)))
         if env["args"].trace_memory:
@@ -265,7 +268,9 @@ class Pipeline:
         if self.keys == self.decoded:
             return True
         env = self.env
+        t_info = time.perf_counter()
         i = self.ctx.info()
+        self.t_room += time.perf_counter() - t_info
         limit, oc = i["memory_limit_bytes"], env["args"].overcommit
         # the pool never gives memory back to the device and the heap never unmaps: what the HEAP can still get is what the pool has
         # not taken (pool_bytes, free lists included), what the POOL can still get is what the heap has not mapped
@@ -667,7 +672,7 @@ def main():
     barrier()
     log("warm-up done; timed region starts")
     pipe.host_s = pipe.t_launch = pipe.t_decode = pipe.t_release = 0.0; pipe.done_t = []; pipe.refused = pipe.refused_by_the_library = 0; pipe.urgent_groups = 0
-    pipe.step_series = []
+    pipe.step_series = []; pipe.t_room = 0.0
     pipe.keep_group = pipe.decoded + args.steps - 1          # the last TIMED step keeps the frames of its distinct streams: they are what is verified
     ctx.kernel_stats(reset=True)
     prof0 = ctx.info()["token_profile"]
@@ -693,7 +698,7 @@ def main():
     token_profile = token_profile_delta(prof0, info["token_profile"], clock_mhz)
     series = pipe.step_series or []
     pipe.step_series = None
-    timed_region = {"step_done_at_ms": [round((t - t0) * 1e3) for t in pipe.done_t],
+    timed_region = {"step_done_at_ms": [round((t - t0) * 1e3) for t in pipe.done_t], "host_ms_per_step_in_aa_ctx_get_info": round(pipe.t_room / args.steps * 1e3, 1),
                     "per_step": {"what": "after each step: [host waited for parses so far ms, for the compute stream so far ms, worker workgroups alive, jobs waiting in the queue, "
                                          "coefficient heap in use GB, pool in use GB]", "series": [list(x) for x in series]},
                     "host_ms_per_step": {"submit": round(pipe.host_s / args.steps * 1e3, 1), "launch_tokens": round(pipe.t_launch / args.steps * 1e3, 1),

@@ -79,7 +79,7 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
     for ( unsigned row = 0; row < J.fp.mbh; row++ ) {
       unsigned long long word = 0;
       for ( unsigned col = 0; col < J.fp.mbw; col++, mi++ ) {
-        const uint8_t flags = aa::parse_mb_header( bd, J.fp, J.mbs, mi, col, row, static_cast<uint8_t *>( nullptr ) );
+        const uint8_t flags = aa::parse_mb_header( bd, J.fp, aa::kHeaderTables, J.mbs, mi, col, row, static_cast<uint8_t *>( nullptr ) );
         J.mbflags[mi] = flags;
         if ( !( flags & AA_MB_INTER ) ) { intra++; word |= 1ull << ( col & 63 ); }
         else if ( J.mbs[mi].y_mode == aa::SPLITMV ) split = 1;

@@ -78,7 +78,7 @@ int prepare( Stream & S, const uint8_t * data, size_t size, bool packed, bool mp
   for ( unsigned row = 0; row < J.fp.mbh; row++ ) {
     unsigned long long word = 0;
     for ( unsigned col = 0; col < J.fp.mbw; col++, mi++ ) {
-      const uint8_t flags = aa::parse_mb_header( bd, J.fp, J.mbs, mi, col, row, static_cast<uint8_t *>( nullptr ) );
+      const uint8_t flags = aa::parse_mb_header( bd, J.fp, aa::kHeaderTables, J.mbs, mi, col, row, static_cast<uint8_t *>( nullptr ) );
       J.mbflags[mi] = flags;
       if ( J.mp_stride ) J.mbflags[aa::mp_flag_index( J, row, col )] = flags;
       if ( !( flags & AA_MB_INTER ) ) { intra++; word |= 1ull << ( col & 63 ); }
