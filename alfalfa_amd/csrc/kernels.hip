@@ -509,8 +509,11 @@ __global__ __launch_bounds__( kLanes ) void k_recon_intra( const aa_frame_list l
 // round had only the clock and expired once in a 20-step run ("needed 12 saw 11") -- wall time also passes while the whole GPU is
 // held up (the host mapping another GiB into the coefficient heap, pinning an arena), polls do not.  The clock is read once per
 // 1024 polls.  (Lowering the waiting wave's issue priority was tried with it and dropped: no measured gain.)
-constexpr unsigned long long kMaxWaitTicks = 200000000ull;
-constexpr int kMinPolls = 1 << 22;
+// Round 5: TEN seconds and 2^24 polls.  Two seconds were run out once more, in a priming pass (heap being mapped, arenas being pinned,
+// sixteen host-lane threads uploading from pageable memory -- since removed): the wait is a safety net against a broken hand-off, and
+// a net that tears under a slow but correct run costs a whole job.
+constexpr unsigned long long kMaxWaitTicks = 1000000000ull;
+constexpr int kMinPolls = 1 << 24;
 __device__ __forceinline__ int xcc_id() { return static_cast<int>( __builtin_amdgcn_s_getreg( 20 | ( 0 << 6 ) | ( 3 << 11 ) ) ); }   // HW_REG_XCC_ID[3:0]
 
 __device__ __forceinline__ int take_ticket( aa_sync_ws * ws, const int xcc, int * slot, const int lane )

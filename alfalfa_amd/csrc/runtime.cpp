@@ -285,6 +285,8 @@ struct aa_ctx {
     uint32_t * retire_host = nullptr, * retire_dev = nullptr;     // [AA_MAX_WORKER_GRIDS]: grids of generation <= this take no more jobs
     aa_tok_mirror * mirror_host = nullptr, * mirror_dev = nullptr;
     uint32_t mirror_seq = 0;
+    hipEvent_t mirror_ev = nullptr;      // tok_peek_mirror: behind the refresh that is under way
+    bool mirror_inflight = false;
     uint32_t lane_bytes = 0, lds = 0;
     int lanes = 0, cap_wgs = 0, n_cus = 0;
     unsigned long long linger_ticks = 200000000ull;    // 2 s at 100 MHz (ALFALFA_AMD_WORKER_LINGER_MS)
@@ -681,6 +683,33 @@ aa_status tok_refresh_mirror( aa_ctx * ctx )
   if ( int e = aa::launch_mirror_counters( T.q, T.pool, T.exited_dev, aa_ctx::Tok::kSlots, T.prof_dev, T.mirror_dev, T.mirror_seq, T.util ) )
     return hip_fail( static_cast<hipError_t>( e ), "k_mirror_counters" );
   HIP_TRY( hipStreamSynchronize( T.util ) );
+  T.mirror_inflight = false;
+  return AA_OK;
+}
+// ... for callers that only LOOK at the counters (aa_ctx_get_info: a pipelining caller plans by them several times per step): ask
+// for a refresh if none is under way, wait for it a few hundred microseconds at most, and otherwise make do with the last one.  On
+// an idle GPU the kernel is through in tens of microseconds; beside 700 resident worker workgroups and the reconstruction kernels
+// it was seen to take 50-100 ms to get its turn -- 295 ms per step of a caller that waited for it (round 5, profiles/r05_bench_sessions.md).
+aa_status tok_peek_mirror( aa_ctx * ctx )
+{
+  auto & T = ctx->tok;
+  if ( !T.mirror_ev ) HIP_TRY( hipEventCreateWithFlags( &T.mirror_ev, hipEventDisableTiming ) );
+  if ( !T.mirror_inflight ) {
+    T.mirror_seq++;
+    if ( int e = aa::launch_mirror_counters( T.q, T.pool, T.exited_dev, aa_ctx::Tok::kSlots, T.prof_dev, T.mirror_dev, T.mirror_seq, T.util ) )
+      return hip_fail( static_cast<hipError_t>( e ), "k_mirror_counters" );
+    HIP_TRY( hipEventRecord( T.mirror_ev, T.util ) );
+    T.mirror_inflight = true;
+  }
+  const double t0 = now_ms();
+  for ( ;; ) {
+    const hipError_t e = hipEventQuery( T.mirror_ev );
+    if ( e == hipSuccess ) { T.mirror_inflight = false; break; }
+    if ( e != hipErrorNotReady ) return hip_fail( e, "hipEventQuery (counters)" );
+    (void) hipGetLastError();
+    if ( now_ms() - t0 > 0.3 ) break;
+    usleep( 20 );
+  }
   return AA_OK;
 }
 
@@ -827,6 +856,7 @@ void tok_free( aa_ctx * ctx )
   for ( auto & sl : T.slot ) if ( sl.st ) { (void) hipStreamSynchronize( sl.st ); (void) hipStreamDestroy( sl.st ); sl.st = nullptr; }
   if ( T.util ) { (void) hipStreamDestroy( T.util ); T.util = nullptr; }
   if ( T.expand ) { (void) hipStreamSynchronize( T.expand ); (void) hipStreamDestroy( T.expand ); T.expand = nullptr; }
+  if ( T.mirror_ev ) { (void) hipEventDestroy( T.mirror_ev ); T.mirror_ev = nullptr; }
   if ( T.vmm ) {
     if ( T.heap_mapped ) (void) hipMemUnmap( T.heap, T.heap_mapped );
     for ( auto h : T.handles ) (void) hipMemRelease( h );
@@ -895,7 +925,7 @@ aa_status tok_service( aa_ctx * ctx, hipEvent_t after = nullptr )
 {
   auto & T = ctx->tok;
   if ( !T.ready ) return AA_OK;
-  if ( aa_status st = tok_refresh_mirror( ctx ) ) return st;
+  if ( aa_status st = tok_peek_mirror( ctx ) ) return st;       // (a look, not a wait: this runs inside every wait for a frame's parse)
   if ( T.mirror_host->pool_starving != T.seen_starving ) {
     T.seen_starving = T.mirror_host->pool_starving;
     if ( aa_status st = tok_grow_heap( ctx, T.heap_mapped + T.grow_bytes ) ) return st;
@@ -1464,7 +1494,7 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
   out->stream_concurrency = ctx->stream_concurrency; out->streams_needed = ctx->streams_needed;
   { int khz = 0; if ( hipDeviceGetAttribute( &khz, hipDeviceAttributeClockRate, ctx->device ) == hipSuccess ) out->clock_mhz = static_cast<uint32_t>( khz / 1000 ); else (void) hipGetLastError(); }
   if ( T.ready ) {
-    if ( aa_status st = tok_refresh_mirror( ctx ) ) return st;
+    if ( aa_status st = tok_peek_mirror( ctx ) ) return st;
     out->heap_free_chunks = T.mirror_host->pool_avail; out->lanes_starved = T.mirror_host->pool_starving;
     for ( int k = 0; k < 8; k++ ) out->token_profile[k] = T.mirror_host->prof[k];
     uint32_t alive = 0;
@@ -1868,7 +1898,21 @@ namespace {
 // One frame: macroblock headers + tokens from the arena's pinned copy (the header pre-pass left everything else in its ParseJob),
 // records to HBM where the frame's job record says they are, dense coefficient blocks to a pool piece of their own, then the
 // summary and -- last, behind the copies -- the `done` word.  Scratch buffers are the worker's own, kept from frame to frame.
-struct HostLaneScratch { std::vector<uint8_t> mbs, rows, above; std::vector<int16_t> coeffs; hipEvent_t ev = nullptr; };
+// (PINNED: a copy out of pageable memory makes the runtime pin and unpin pages under every transfer -- page-table updates that hold up
+// the whole GPU; with sixteen workers uploading 5-MB key frames that was enough to run a row kernel's bounded wait out during priming)
+struct HostLaneScratch {
+  uint8_t * pin = nullptr; size_t pin_bytes = 0;      // macroblock records | intra row masks | worst-case dense coefficient blocks
+  std::vector<uint8_t> above; hipEvent_t ev = nullptr;
+  bool fit( size_t bytes )
+  {
+    if ( bytes <= pin_bytes ) return true;
+    if ( pin ) (void) hipHostFree( pin );
+    pin = nullptr; pin_bytes = 0;
+    if ( hipHostMalloc( reinterpret_cast<void **>( &pin ), bytes, hipHostMallocDefault ) != hipSuccess ) { (void) hipGetLastError(); pin = nullptr; return false; }
+    pin_bytes = bytes;
+    return true;
+  }
+};
 void host_lane_run( aa_ctx * ctx, Batch * b, int item, HostLaneScratch & S )
 {
   const aa::ParseJob & J = reinterpret_cast<const aa::ParseJob *>( b->host )[item];
@@ -1877,19 +1921,19 @@ void host_lane_run( aa_ctx * ctx, Batch * b, int item, HostLaneScratch & S )
   const uint32_t mbw = J.fp.mbw, mbh = J.fp.mbh, nmb = mbw * mbh;
   const size_t words_per_row = ( mbw + 63 ) / 64;
   uint32_t status = aa::TOK_OK, blocks = 0, intra = 0, split = 0;
-  try {
-    S.mbs.resize( size_t( nmb ) * sizeof( aa_mb_info ) ); S.rows.resize( words_per_row * mbh * sizeof( unsigned long long ) );
-    S.above.resize( size_t( mbw ) * 9 ); S.coeffs.resize( size_t( nmb ) * 25 * 16 + 16 );
-  } catch ( const std::bad_alloc & ) { status = aa::TOK_HOST_FAILED; }
+  const size_t mbs_bytes = align_up( size_t( nmb ) * sizeof( aa_mb_info ) ), rows_bytes = align_up( words_per_row * mbh * sizeof( unsigned long long ) );
+  try { S.above.resize( size_t( mbw ) * 9 ); } catch ( const std::bad_alloc & ) { status = aa::TOK_HOST_FAILED; }
+  if ( status == aa::TOK_OK && !S.fit( mbs_bytes + rows_bytes + size_t( nmb ) * 25 * 32 + 256 ) ) status = aa::TOK_HOST_FAILED;
   if ( status == aa::TOK_OK ) {
-    aa_mb_info * mbs = reinterpret_cast<aa_mb_info *>( S.mbs.data() );
-    unsigned long long * rows = reinterpret_cast<unsigned long long *>( S.rows.data() );
-    std::memset( static_cast<void *>( mbs ), 0, S.mbs.size() );
+    aa_mb_info * mbs = reinterpret_cast<aa_mb_info *>( S.pin );
+    unsigned long long * rows = reinterpret_cast<unsigned long long *>( S.pin + mbs_bytes );
+    int16_t * coeffs = reinterpret_cast<int16_t *>( S.pin + mbs_bytes + rows_bytes );
+    std::memset( static_cast<void *>( mbs ), 0, size_t( nmb ) * sizeof( aa_mb_info ) );
     const double t_parse = now_ms();
-    aa::parse_frame_body( b->host + it.data_off, J.fp, mbs, S.coeffs.data(), S.above.data(), &blocks, &intra );
+    aa::parse_frame_body( b->host + it.data_off, J.fp, mbs, coeffs, S.above.data(), &blocks, &intra );
     ctx->host_lanes.parse_us += static_cast<uint64_t>( ( now_ms() - t_parse ) * 1e3 ); ctx->host_lanes.parsed_bytes += J.size;
     ctx->stats.host_batch_parse_cpu_ms += now_ms() - t_parse;          // (a diagnostic sum: workers race on it, the atomics above are what the planning uses)
-    std::memset( rows, 0, S.rows.size() );
+    std::memset( rows, 0, words_per_row * mbh * sizeof( unsigned long long ) );
     for ( uint32_t r = 0; r < mbh; r++ ) for ( uint32_t c = 0; c < mbw; c++ ) {
       const aa_mb_info & mb = mbs[r * mbw + c];
       if ( !( mb.flags & AA_MB_INTER ) ) rows[r * words_per_row + ( c >> 6 )] |= 1ull << ( c & 63 );
@@ -1904,12 +1948,13 @@ void host_lane_run( aa_ctx * ctx, Batch * b, int item, HostLaneScratch & S )
       // (the copy stream: the arena's upload -- which carries the job record as the pre-pass left it -- was queued there by the submit call)
       e = hipMemcpyAsync( J.mbs, mbs, size_t( nmb ) * sizeof( aa_mb_info ), hipMemcpyHostToDevice, ctx->copy );
       if ( e == hipSuccess ) e = hipMemcpyAsync( J.intra_rows, rows, words_per_row * mbh * sizeof( unsigned long long ), hipMemcpyHostToDevice, ctx->copy );
-      if ( e == hipSuccess && blocks ) e = hipMemcpyAsync( dense, S.coeffs.data(), size_t( blocks ) * 32, hipMemcpyHostToDevice, ctx->copy );
+      if ( e == hipSuccess && blocks ) e = hipMemcpyAsync( dense, coeffs, size_t( blocks ) * 32, hipMemcpyHostToDevice, ctx->copy );
       if ( e == hipSuccess ) {
         // the frame's reconstruction job record (aa_dev_frame, in the arena behind the parse jobs): its blocks are here, not in the heap
         uint8_t * job_dev = b->dev + align_up( size_t( b->n ) * sizeof( aa::ParseJob ) ) + size_t( item ) * sizeof( aa_dev_frame );
-        const int16_t * dense_ptr = reinterpret_cast<const int16_t *>( dense );
-        e = hipMemcpyAsync( job_dev + offsetof( aa_dev_frame, coeffs ), &dense_ptr, sizeof dense_ptr, hipMemcpyHostToDevice, ctx->copy );
+        const int16_t ** dense_ptr = reinterpret_cast<const int16_t **>( S.pin + S.pin_bytes - 16 );       // (pinned too: the last bytes of the scratch)
+        *dense_ptr = reinterpret_cast<const int16_t *>( dense );
+        e = hipMemcpyAsync( job_dev + offsetof( aa_dev_frame, coeffs ), dense_ptr, sizeof *dense_ptr, hipMemcpyHostToDevice, ctx->copy );
       }
       if ( e == hipSuccess ) e = hipEventRecord( S.ev, ctx->copy );
       if ( e == hipSuccess ) e = hipEventSynchronize( S.ev );
@@ -1939,6 +1984,7 @@ void host_lanes_main( aa_ctx * ctx )
     host_lane_run( ctx, t.b, t.item, S );
   }
   if ( S.ev ) (void) hipEventDestroy( S.ev );
+  if ( S.pin ) (void) hipHostFree( S.pin );
 }
 void host_lanes_start( aa_ctx * ctx )
 {
