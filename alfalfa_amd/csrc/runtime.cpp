@@ -31,6 +31,8 @@
 #include <vector>
 
 #include <sched.h>
+#include <sys/resource.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include "../../include/alfalfa_amd.h"
@@ -305,6 +307,7 @@ struct aa_ctx {
   int binding_depth = 0;
   bool copy_reads_rasters = false;      // aa_stream_download_async queued copies since the last epoch was closed
   uint32_t stream_concurrency = 0, streams_needed = 0;    // probe_stream_concurrency (at the first submit)
+  uint32_t clock_mhz = 0;                                 // hipDeviceAttributeClockRate, asked once
   bool profile = false;
   double host_share_ms = 80.0;
                                  // aa_submit_frames: a big call's key frames go to the host lanes while their backlog stays within this (0: never)
@@ -1492,7 +1495,10 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
   out->host_share_ms = static_cast<uint32_t>( ctx->host_share_ms + 0.5 );
   out->host_rate_kb_per_ms = ctx->host_lanes.parse_us.load() ? static_cast<uint32_t>( host_lanes_rate( ctx ) / 1e3 + 0.5 ) : 0u;
   out->stream_concurrency = ctx->stream_concurrency; out->streams_needed = ctx->streams_needed;
-  { int khz = 0; if ( hipDeviceGetAttribute( &khz, hipDeviceAttributeClockRate, ctx->device ) == hipSuccess ) out->clock_mhz = static_cast<uint32_t>( khz / 1000 ); else (void) hipGetLastError(); }
+  // (asked once: the attribute query goes to the driver and was seen to take ~100 ms beside a busy GPU -- three looks at the books per
+  // step of a pipelining caller were 300 ms of its step)
+  if ( !ctx->clock_mhz ) { int khz = 0; if ( hipDeviceGetAttribute( &khz, hipDeviceAttributeClockRate, ctx->device ) == hipSuccess ) ctx->clock_mhz = static_cast<uint32_t>( khz / 1000 ); else (void) hipGetLastError(); }
+  out->clock_mhz = ctx->clock_mhz;
   if ( T.ready ) {
     if ( aa_status st = tok_peek_mirror( ctx ) ) return st;
     out->heap_free_chunks = T.mirror_host->pool_avail; out->lanes_starved = T.mirror_host->pool_starving;
@@ -2177,8 +2183,14 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   // ---- host half, one worker per stream at a time (the header pre-pass is serial across the frames of a stream) ----
   {
     std::atomic<size_t> next { 0 };
+    // (while the host lanes have frames to parse -- frames somebody needs at once -- the pre-pass workers of later hand-overs step
+    // back: a thread may lower its own priority.  On a box that grants 16 CPUs the first group's key frames were seen to take 4 s
+    // instead of 1 when twenty hand-overs' worth of pre-pass threads and arena copies ran beside them.)
+    const int nt = std::min<int>( worker_threads( threads ), static_cast<int>( stream_order.size() ) );
+    const bool step_back = nt > 1 && ctx->host_lanes.backlog_bytes.load() > 0;          // (nt == 1: the caller's own thread does the work)
     auto work = [&]() {
       (void) hipSetDevice( ctx->device );
+      if ( step_back ) (void) setpriority( PRIO_PROCESS, static_cast<id_t>( syscall( SYS_gettid ) ), 10 );
       for ( ;; ) {
         const size_t k = next.fetch_add( 1 );
         if ( k >= stream_order.size() ) return;
@@ -2191,7 +2203,6 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
         }
       }
     };
-    const int nt = std::min<int>( worker_threads( threads ), static_cast<int>( stream_order.size() ) );
     if ( nt == 1 ) work();
     else {
       std::vector<std::thread> pool;

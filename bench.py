@@ -158,6 +158,7 @@ class Pipeline:
         self.t_launch = self.t_decode = self.t_release = 0.0      # host time in aa_launch_tokens / aa_decode_batch / releases
         self.done_t = []
         self.t_room = 0.0                                # host time in aa_ctx_get_info (the planner's look at the books)
+        self.t_decode_mark = 0.0
         self.step_series = None
         self.delivered_bytes = 0
         self.refused = 0                                 # times a hand-over was put off because HBM had no room for it
@@ -247,11 +248,15 @@ class Pipeline:
         self.decoded += 1
         self.done_t.append(time.perf_counter())
         if self.step_series is not None:          # what the host waited for, step by step (diagnostics of the timed region)
+            # (aa_ctx_get_info only: it looks at the books without waiting for the GPU.  aa_ctx_kernel_stats synchronises with the compute
+            # and parse streams -- called here, as the first version of this series did, it made every step wait for its own
+            # reconstruction: the "plateau" of 450 ms per step in the first round-5 sessions was this line)
             t_info = time.perf_counter()
-            ks, i = ctx.kernel_stats(), ctx.info()
+            i = ctx.info()
             self.t_room += time.perf_counter() - t_info
-            self.step_series.append((round(ks["parse_wait_ms"]), round(ks["bind_wait_ms"]), i["token_workgroups_alive"], i["jobs_waiting"],
+            self.step_series.append((round((self.t_decode - self.t_decode_mark) * 1e3), i["token_workgroups_alive"], i["jobs_waiting"],
                                      round(i["heap_used_bytes"] / 1e9, 1), round((i["pool_bytes"] - i["pool_free_bytes"]) / 1e9, 1)))
+            self.t_decode_mark = self.t_decode
         if env["args"].trace_memory:
             i = ctx.info()
             print("step %d: pool %.1f GB (free %.1f, pending %.1f) heap mapped %.1f used %.1f GB free chunks %d starved %d alive wgs %d waiting %d refused %d"
@@ -672,7 +677,7 @@ def main():
     barrier()
     log("warm-up done; timed region starts")
     pipe.host_s = pipe.t_launch = pipe.t_decode = pipe.t_release = 0.0; pipe.done_t = []; pipe.refused = pipe.refused_by_the_library = 0; pipe.urgent_groups = 0
-    pipe.step_series = []; pipe.t_room = 0.0
+    pipe.step_series = []; pipe.t_room = 0.0; pipe.t_decode_mark = 0.0
     pipe.keep_group = pipe.decoded + args.steps - 1          # the last TIMED step keeps the frames of its distinct streams: they are what is verified
     ctx.kernel_stats(reset=True)
     prof0 = ctx.info()["token_profile"]
@@ -699,8 +704,8 @@ def main():
     series = pipe.step_series or []
     pipe.step_series = None
     timed_region = {"step_done_at_ms": [round((t - t0) * 1e3) for t in pipe.done_t], "host_ms_per_step_in_aa_ctx_get_info": round(pipe.t_room / args.steps * 1e3, 1),
-                    "per_step": {"what": "after each step: [host waited for parses so far ms, for the compute stream so far ms, worker workgroups alive, jobs waiting in the queue, "
-                                         "coefficient heap in use GB, pool in use GB]", "series": [list(x) for x in series]},
+                    "per_step": {"what": "after each step: [ms of the step the host spent inside its aa_decode_batch calls (waits for parses and for binding buffers included), "
+                                         "worker workgroups alive, jobs waiting in the queue, coefficient heap in use GB, pool in use GB]", "series": [list(x) for x in series]},
                     "host_ms_per_step": {"submit": round(pipe.host_s / args.steps * 1e3, 1), "launch_tokens": round(pipe.t_launch / args.steps * 1e3, 1),
                                          "decode_batch_calls_incl_wait_for_parse": round(pipe.t_decode / args.steps * 1e3, 1),
                                          "release": round(pipe.t_release / args.steps * 1e3, 1)},
