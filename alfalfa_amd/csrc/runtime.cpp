@@ -1872,6 +1872,9 @@ aa_status launch_tokens_of( aa_ctx * ctx, Batch * b )
       const double blocks = std::min( 25.0 * jobs_host[i].nmb, T.blocks_per_byte * 1.15 * jobs_host[i].size );
       r.est_chunks = static_cast<uint32_t>( blocks / ( aa::kChunkBlocks - aa::kMbBlocks ) ) + 1u;
     }
+    // (one lane per partition: every lane of the frame fills a chunk of its own -- P - 1 more partly filled chunks than the words say;
+    // without them the heap was mapped for a quarter of what 4-partition frames take and their lanes sat out the 2-s memory wait)
+    if ( T.lane_per_partition && jobs_host[i].mp_stride && jobs_host[i].fp.nparts > 1 ) r.est_chunks += static_cast<uint32_t>( jobs_host[i].fp.nparts ) - 1u;
     T.chunks_committed += r.est_chunks;
     ctx->stats.parsed_macroblocks += jobs_host[i].nmb;
   }

@@ -527,7 +527,8 @@ def run_secondary(args, ctx, config, rank, world, threads):
                        % (S, F, env["width"], env["height"], "all key frames" if config.endswith("_intra") else "1 key + %d inter" % (F - 1), cfg[3], cfg[4]),
            "macroblocks_per_step": S * F * env["mbs_per_frame"], "compressed_bytes_per_mb": round(env["compressed_bytes"] / (S * F * env["mbs_per_frame"]), 2),
            "lone_key_frame_parse_s": round(env["lone_key_s"], 4), "token_steps_per_mb": round(st["token_steps"] / max(1, st["parsed_macroblocks"]), 1),
-           "distinct_streams": len(env["distinct"]), "verified_bit_exact_vs_reference": verified, "stream_generation_s": round(env["t_gen"], 1)}
+           "distinct_streams": len(env["distinct"]), "verified_bit_exact_vs_reference": verified, "stream_generation_s": round(env["t_gen"], 1),
+           "frames_handed_back_for_lack_of_memory": st["nomem_retries"], "heap_grows": st["heap_grows"], "host_waited_for_parse_ms_per_step": round(st["parse_wait_ms"] / steps, 1)}
     if len(pipe.done_t) > steps and steps > 1:
         d = pipe.done_t[-steps:]
         out["between_fill_and_drain_value"] = round(S * F * env["mbs_per_frame"] * (steps - 1) / (d[-1] - d[0]), 1)
@@ -598,7 +599,10 @@ def main():
     ctx = aa.Context(dev_index)
     ctx.set_schedule(args.schedule)
     hbm_budget = min(args.hbm_gb * 1e9, 0.9 * ctx.memory()[0])
-    ctx.set_memory_limit(int(hbm_budget))
+    # (the library refuses hand-overs by what the context HOLDS; what it has TAKEN from the device can sit a few hundred MB above that --
+    # free pieces of sizes nobody asks for again are not re-split -- so the limit it is given is the budget less 1 GB, and `memory` in the
+    # line checks the budget itself)
+    ctx.set_memory_limit(int(hbm_budget - 1e9))
     if args.dense:
         ctx.set_packed_coefficients(False)
     if args.host_share_ms is not None:
@@ -731,7 +735,7 @@ def main():
                   "note": "decode steps of the frames parsed in the timed region (an upper bound on bools) over the timed region's wall time; step latency = lone key frame submit->parsed / its steps"}
     memory = {"limit_gb": round(info["memory_limit_bytes"] / 1e9, 1), "pool_gb": round(info["pool_bytes"] / 1e9, 2), "coefficient_heap_mapped_gb": round(info["heap_mapped_bytes"] / 1e9, 2),
               "hbm_taken_by_the_context_gb": round((info["pool_bytes"] + (info["heap_mapped_bytes"] if info["heap_is_virtual"] else 0)) / 1e9, 2),
-              "inside_the_limit": bool(info["pool_bytes"] + (info["heap_mapped_bytes"] if info["heap_is_virtual"] else 0) <= info["memory_limit_bytes"]),
+              "inside_the_budget": bool(info["pool_bytes"] + (info["heap_mapped_bytes"] if info["heap_is_virtual"] else 0) <= hbm_budget), "budget_gb": round(hbm_budget / 1e9, 1),
               "pinned_host_gb": round(info["pinned_host_bytes"] / 1e9, 2), "heap_is_virtual": bool(info["heap_is_virtual"]),
               "hbm_in_use_on_device_gb": round((hbm_total - hbm_free) / 1e9, 1),
               "packed_storage": env["packed_storage"], "planned": env["planned"]}
