@@ -64,7 +64,7 @@ def pmc_traffic(config):
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except (OSError, ValueError):
         return None, None
-    if d.get("round") != "r04":
+    if d.get("round") != "r05":
         return None, None
     global TRAFFIC_SOURCES
     TRAFFIC_SOURCES = d.get("per_kernel_source") or {}
@@ -837,6 +837,17 @@ def main():
     roofline["entropy_decode_alone_ms"] = round(t_parse_alone * 1e3, 1)      # (the un-pipelined latency of one step's chains: a latency, not a duration of the pipelined run)
     roofline["traffic_source"] = TRAFFIC_SOURCES.get("parse_tokens") or traffic_source
     roofline["path_frac_of_hbm_peak"] = round(value / world * PATH_BYTES_PER_MB / (HBM_PEAK_GBS * 1e9), 5)
+    # what the whole path really moves per macroblock: every kernel's measured traffic (PMC passes: profiles/pmc_traffic.json) weighted by
+    # the macroblocks it touches in a step -- the two parse kernels, the expansion pass packed storage adds, reconstruction, loop filter
+    if traffic:
+        packed = bool(info.get("packed_coefficients"))
+        all_mbs = max(1, units["loopfilter"])
+        per_kernel = {"parse_tokens": all_mbs, "parse_headers": all_mbs, "expand": all_mbs if packed else 0, "dense_index": all_mbs if packed else 0,
+                      "recon_inter": units["recon_inter"] + units["recon_split"], "recon_intra": units["recon_intra"], "loopfilter": all_mbs}
+        if all(k in traffic for k in per_kernel if per_kernel[k]):
+            tb = sum(traffic[k] * n for k, n in per_kernel.items() if n) / all_mbs
+            roofline["path_traffic_bytes_per_mb"] = round(tb, 1)
+            roofline["path_traffic_over_algorithmic"] = round(tb / PATH_BYTES_PER_MB, 2)
 
     # ---- bit-exactness of the profile step too (all three formats of evidence agree: timed step, profile step, pytest) ----
     verified_profile_step = None
