@@ -63,7 +63,8 @@ class CtxInfo(C.Structure):
         (n, C.c_uint32) for n in ("heap_is_virtual", "token_lanes_per_workgroup", "token_workgroups_capacity", "token_workgroups_alive",
                                   "token_lane_lds_bytes", "token_workgroup_lds_bytes", "jobs_waiting", "compute_units")] + [
         ("heap_free_chunks", C.c_int32), ("lanes_starved", C.c_uint32), ("token_profile", C.c_uint64 * 8),
-        ("packed_coefficients", C.c_uint32), ("lane_per_partition", C.c_uint32), ("clock_mhz", C.c_uint32), ("host_share_ms", C.c_uint32), ("host_rate_kb_per_ms", C.c_uint32), ("reserved1", C.c_uint32), ("stream_concurrency", C.c_uint32), ("streams_needed", C.c_uint32)]
+        ("packed_coefficients", C.c_uint32), ("lane_per_partition", C.c_uint32), ("clock_mhz", C.c_uint32), ("host_share_ms", C.c_uint32), ("host_rate_kb_per_ms", C.c_uint32), ("reserved1", C.c_uint32), ("stream_concurrency", C.c_uint32), ("streams_needed", C.c_uint32),
+        ("host_waited_parse_ms", C.c_uint32), ("host_waited_compute_ms", C.c_uint32)]
 
 
 class AlfalfaError(RuntimeError):

@@ -51,7 +51,8 @@ thread_local std::string g_last_error;
 // (GPU_MAX_HW_QUEUES) when the HIP runtime starts.  The library does not touch the host process's environment behind its back:
 // aa_runtime_prepare() -- called by the bindings before their first aa_ctx_create, or by the host program before ITS first HIP
 // call -- sets the variable if it is unset; a context then CHECKS how many of its streams really run side by side
-// (probe_stream_concurrency) and says so (aa_ctx_info::stream_concurrency, a clear error below 8).
+// (probe_stream_concurrency) and says so: aa_ctx_info::stream_concurrency, a warning on stderr below 8 -- an error only with
+// ALFALFA_AMD_REQUIRE_QUEUES=1 (several contexts of one process share the queues and a probe can arrive late behind another's grid).
 
 aa_status fail( aa_status code, const std::string & msg ) { g_last_error = msg; return code; }
 
@@ -1495,6 +1496,7 @@ aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out )
   out->host_share_ms = static_cast<uint32_t>( ctx->host_share_ms + 0.5 );
   out->host_rate_kb_per_ms = ctx->host_lanes.parse_us.load() ? static_cast<uint32_t>( host_lanes_rate( ctx ) / 1e3 + 0.5 ) : 0u;
   out->stream_concurrency = ctx->stream_concurrency; out->streams_needed = ctx->streams_needed;
+  out->host_waited_parse_ms = static_cast<uint32_t>( ctx->stats.parse_wait_ms ); out->host_waited_compute_ms = static_cast<uint32_t>( ctx->stats.bind_wait_ms );
   // (asked once: the attribute query goes to the driver and was seen to take ~100 ms beside a busy GPU -- three looks at the books per
   // step of a pipelining caller were 300 ms of its step)
   if ( !ctx->clock_mhz ) { int khz = 0; if ( hipDeviceGetAttribute( &khz, hipDeviceAttributeClockRate, ctx->device ) == hipSuccess ) ctx->clock_mhz = static_cast<uint32_t>( khz / 1000 ); else (void) hipGetLastError(); }

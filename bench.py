@@ -99,7 +99,7 @@ def parse_args():
                     "the timed region then includes PCIe")
     ap.add_argument("--deliver-steps", type=int, default=6, help="without --deliver: this many steps with every frame delivered AFTER the timed region, reported as `delivery` (0 = skip)")
     ap.add_argument("--host-share-ms", type=float, default=None, help="aa_ctx_set_host_share_ms: key frames of a hand-over are parsed by host workers while that is "
-                    "expected to take no longer than this on the rank's host threads (library default 50; 0: every frame on the GPU's token lanes)")
+                    "expected to take no longer than this on the rank's host threads (library default 80; 0: every frame on the GPU's token lanes)")
     ap.add_argument("--lanes-only-steps", type=int, default=8, help="after the main run: this many steps with host_share_ms = 0 (every frame, key frames too, "
                     "parsed by GPU lanes), reported as all_frames_on_gpu_lanes (0 = skip)")
     ap.add_argument("--urgent-host", action="store_true", help="(accepted for old command lines: the host lanes are the default for the groups a pipeline starts with)")
@@ -255,8 +255,9 @@ class Pipeline:
             i = ctx.info()
             self.t_room += time.perf_counter() - t_info
             self.step_series.append((round((self.t_decode - self.t_decode_mark) * 1e3), i["token_workgroups_alive"], i["jobs_waiting"],
-                                     round(i["heap_used_bytes"] / 1e9, 1), round((i["pool_bytes"] - i["pool_free_bytes"]) / 1e9, 1)))
-            self.t_decode_mark = self.t_decode
+                                     round(i["heap_used_bytes"] / 1e9, 1), round((i["pool_bytes"] - i["pool_free_bytes"]) / 1e9, 1),
+                                     i["host_waited_parse_ms"] - self.wait_mark[0], i["host_waited_compute_ms"] - self.wait_mark[1]))
+            self.t_decode_mark = self.t_decode; self.wait_mark = (i["host_waited_parse_ms"], i["host_waited_compute_ms"])
         if env["args"].trace_memory:
             i = ctx.info()
             print("step %d: pool %.1f GB (free %.1f, pending %.1f) heap mapped %.1f used %.1f GB free chunks %d starved %d alive wgs %d waiting %d refused %d"
@@ -681,7 +682,7 @@ def main():
     barrier()
     log("warm-up done; timed region starts")
     pipe.host_s = pipe.t_launch = pipe.t_decode = pipe.t_release = 0.0; pipe.done_t = []; pipe.refused = pipe.refused_by_the_library = 0; pipe.urgent_groups = 0
-    pipe.step_series = []; pipe.t_room = 0.0; pipe.t_decode_mark = 0.0
+    pipe.step_series = []; pipe.t_room = 0.0; pipe.t_decode_mark = 0.0; pipe.wait_mark = (0, 0)
     pipe.keep_group = pipe.decoded + args.steps - 1          # the last TIMED step keeps the frames of its distinct streams: they are what is verified
     ctx.kernel_stats(reset=True)
     prof0 = ctx.info()["token_profile"]
@@ -709,7 +710,7 @@ def main():
     pipe.step_series = None
     timed_region = {"step_done_at_ms": [round((t - t0) * 1e3) for t in pipe.done_t], "host_ms_per_step_in_aa_ctx_get_info": round(pipe.t_room / args.steps * 1e3, 1),
                     "per_step": {"what": "after each step: [ms of the step the host spent inside its aa_decode_batch calls (waits for parses and for binding buffers included), "
-                                         "worker workgroups alive, jobs waiting in the queue, coefficient heap in use GB, pool in use GB]", "series": [list(x) for x in series]},
+                                         "worker workgroups alive, jobs waiting in the queue, coefficient heap in use GB, pool in use GB, ms of it waiting for the device parser, ms of it waiting for the compute stream]", "series": [list(x) for x in series]},
                     "host_ms_per_step": {"submit": round(pipe.host_s / args.steps * 1e3, 1), "launch_tokens": round(pipe.t_launch / args.steps * 1e3, 1),
                                          "decode_batch_calls_incl_wait_for_parse": round(pipe.t_decode / args.steps * 1e3, 1),
                                          "release": round(pipe.t_release / args.steps * 1e3, 1)},

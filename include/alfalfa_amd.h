@@ -215,6 +215,8 @@ typedef struct aa_ctx_info {
   uint32_t reserved1;
   uint32_t stream_concurrency;       /* how many of the context's HIP streams were seen running side by side (probed at the first aa_submit_frames; 0: not yet) */
   uint32_t streams_needed;           /* ... of how many (16): fewer means GPU_MAX_HW_QUEUES was not in effect, see aa_runtime_prepare */
+  uint32_t host_waited_parse_ms;     /* aa_decode_batch waiting for the device parser, since the last aa_ctx_kernel_stats reset (= its parse_wait_ms, without its synchronisation) */
+  uint32_t host_waited_compute_ms;   /* ... for a raster-binding buffer: the compute stream was 16 calls behind (= bind_wait_ms) */
 } aa_ctx_info;
 aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out );
 /* How the device parser stores a frame's coefficients until the frame is reconstructed.  1 (default): packed -- one mask word +
