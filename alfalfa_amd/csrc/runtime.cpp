@@ -292,7 +292,13 @@ struct aa_ctx {
     bool mirror_inflight = false;
     uint32_t lane_bytes = 0, lds = 0;
     int lanes = 0, cap_wgs = 0, n_cus = 0;
-    unsigned long long linger_ticks = 200000000ull;    // 2 s at 100 MHz (ALFALFA_AMD_WORKER_LINGER_MS)
+    // An idle wave stays this long before it leaves (100 MHz ticks; ALFALFA_AMD_WORKER_LINGER_MS).  100 ms: a wave that stays holds its
+    // workgroup's 41 KB of LDS and its SIMD's wave slot against the reconstruction kernels for nothing; a wave that left costs a grid
+    // launch when frames come again.  Measured on MI355X, round 5 (profiles/r05_bench_sessions.md, sessions 13/14, the driver's command):
+    // 2 s -> 97.6-103.1 M macroblocks/s; 200 ms -> 114.6; 100 ms -> 117.7; 50 ms -> 118.4; 20 ms -> 116.3 (5-7 grids, 1 700-2 400
+    // workgroups launched in the 20 steps instead of 1 grid of ~450) -- the drain above all: the last four steps take 0.6 s instead of 1.3
+    unsigned long long linger_ticks = 10000000ull;
+    bool pack_lanes = false;             // ALFALFA_AMD_PACK_LANES=1 (experiment): a wave takes as many frames of a long queue as it has idle lanes
   } tok;
   // Device pieces given back while kernels that read them may still be queued: they become reusable once an event recorded
   // on the compute stream after the release has fired ("epochs": one event per group of releases, recorded lazily).
@@ -804,6 +810,7 @@ aa_status tok_init( aa_ctx * ctx )
   HIP_TRY( hipMalloc( reinterpret_cast<void **>( &T.exited_dev ), sizeof( uint32_t ) * AA_MAX_WORKER_GRIDS ) );
   HIP_TRY( hipMemset( T.exited_dev, 0, sizeof( uint32_t ) * AA_MAX_WORKER_GRIDS ) );
   if ( const char * e = std::getenv( "ALFALFA_AMD_WORKER_LINGER_MS" ) ) T.linger_ticks = static_cast<unsigned long long>( std::max( 0, atoi( e ) ) ) * 100000ull;
+  if ( const char * e = std::getenv( "ALFALFA_AMD_PACK_LANES" ) ) T.pack_lanes = atoi( e ) != 0;
   if ( const char * e = std::getenv( "ALFALFA_AMD_TOKEN_PROFILE" ) ) if ( atoi( e ) ) {
     HIP_TRY( hipMalloc( reinterpret_cast<void **>( &T.prof_dev ), 64 ) );
     HIP_TRY( hipMemset( T.prof_dev, 0, 64 ) );
@@ -895,10 +902,10 @@ aa_status tok_launch_workers( aa_ctx * ctx, hipEvent_t after )
   }
   // as many workgroups as there are jobs waiting, up to what the GPU holds: when lanes are plentiful a frame gets a wave of its
   // own (a wave steps faster the fewer lanes it carries); grids already launched for these jobs -- started or not -- count
-  const int want = std::min( T.cap_wgs, queued ) - alive_total;
+  int want = std::min( T.cap_wgs, queued ) - alive_total;
   // ... and not in dribs and drabs: a grid takes a worker stream for as long as its last wave lives, so small top-ups use the
   // streams up.  Waves linger when the queue is empty; a top-up is for when a good part of the GPU's lanes is really gone.
-  if ( want <= 0 || ( alive_total > 0 && want * 4 < T.cap_wgs && want < queued ) ) return AA_OK;
+  if ( want <= 0 || ( alive_total > 0 && want * ( T.pack_lanes ? 8 : 4 ) < T.cap_wgs && want < queued ) ) return AA_OK;
   int g = -1;
   for ( int k = 0; k < aa_ctx::Tok::kSlots; k++ ) if ( alive[k] == 0 ) { g = k; break; }
   if ( g < 0 ) {
@@ -906,17 +913,24 @@ aa_status tok_launch_workers( aa_ctx * ctx, hipEvent_t after )
     // good): the smallest one retires -- its lanes finish the frames they have and take no more -- and the new grid queues behind it
     for ( int k = 0; k < aa_ctx::Tok::kSlots; k++ )
       if ( !T.slot[k].queued_behind_retiring && ( g < 0 || alive[k] < alive[g] ) ) g = k;
-    // (a retiring grid's lanes stop taking frames: that costs capacity until its last chain ends -- only worth it when half the GPU's lanes are gone)
-    if ( g < 0 || alive[g] * 4 > T.cap_wgs || alive_total * 2 > T.cap_wgs ) return AA_OK;
+    // (a retiring grid's lanes stop taking frames and the new grid starts when the old one's last chain has ended: that costs capacity
+    // for up to a key frame's chain -- worth it when half the GPU's lanes are gone, or when the grid that goes is small beside what
+    // comes.  Without the second case a long run whose waves leave after a short linger would end up with every worker stream held
+    // by a remnant and no way to top up before half the lanes are gone.)
+    if ( g < 0 ) return AA_OK;
+    const bool half_gone = alive[g] * 4 <= T.cap_wgs && alive_total * 2 <= T.cap_wgs;
+    const bool small_remnant = alive[g] * 2 <= want;
+    if ( !half_gone && !small_remnant ) return AA_OK;
     __atomic_store_n( &T.retire_host[g], T.slot[g].gen, __ATOMIC_RELEASE );
     T.slot[g].queued_behind_retiring = true; T.slot[g].retiring_until = T.slot[g].launched;
     ctx->stats.worker_retires++;
+    want = std::min( T.cap_wgs, want + alive[g] );       // (the remnant's workgroups are gone by the time this grid starts)
   }
   auto & sl = T.slot[g];
   sl.gen++;
   if ( after ) HIP_TRY( hipStreamWaitEvent( sl.st, after, 0 ) );
   LaunchTimer timer( ctx, 4, sl.st );
-  if ( int e = aa::launch_token_workers( T.q, T.slots, heap_of( ctx ), T.exited_dev + g, T.retire_dev + g, sl.gen, static_cast<uint32_t>( T.cap_wgs ), T.prof_dev, T.linger_ticks, want, T.lanes, T.lane_bytes, T.lds, T.packed, T.lane_per_partition ? T.mp_hint : 0u, sl.st ) )
+  if ( int e = aa::launch_token_workers( T.q, T.slots, heap_of( ctx ), T.exited_dev + g, T.retire_dev + g, sl.gen, static_cast<uint32_t>( T.cap_wgs ) | ( T.pack_lanes ? 0x80000000u : 0u ), T.prof_dev, T.linger_ticks, want, T.lanes, T.lane_bytes, T.lds, T.packed, T.lane_per_partition ? T.mp_hint : 0u, sl.st ) )
     return hip_fail( static_cast<hipError_t>( e ), "k_token_workers" );
   sl.launched += static_cast<uint32_t>( want );
   ctx->stats.worker_launches++; ctx->stats.worker_wgs += static_cast<uint64_t>( want );

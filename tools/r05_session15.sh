@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round 5, fifteenth GPU session: default linger now 100 ms; lanes packed into full waves (ALFALFA_AMD_PACK_LANES=1) against spread evenly;
+# a 5-ms linger over 24 steps as a stress of the top-up / retire path (every worker stream held by a remnant).
+set -u
+cd "$(dirname "$0")/.."
+R=$PWD; O=$R/gpurun_out/r05o; mkdir -p $O
+export ALFALFA_AMD_PARSE_TIMEOUT_S=120 ALFALFA_AMD_TOKEN_PROFILE=1
+line() { python - "$1" <<'PY'
+import json,sys
+try:
+    d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    e=d.get("entropy_decode_roof") or {}; a=e.get("in_kernel_accounting") or {}; t=d.get("timed_region") or {}
+    print({k:d.get(k) for k in ("value","ms_per_step")}, "steady", (d.get("steady_state") or {}).get("value"), "bools/s", e.get("sustained_bools_per_s"), "busy", a.get("lanes_with_frame_per_period"), "us/step", a.get("us_per_wave_step"), "waits parse/compute", t.get("host_waited_for_parse_ms_per_step"), t.get("host_waited_for_compute_stream_ms_per_step"), "bit-exact", (d.get("verified_bit_exact_vs_reference") or {}).get("bit_exact"))
+    print("   step_done", t.get("step_done_at_ms"))
+    print("   per_step", (t.get("per_step") or {}).get("series"))
+    print("   retired", t.get("worker_grids_retired"), "host", t.get("host_ms_per_step"), "host frames", t.get("frames_parsed_on_host_cores"), "grids/wgs", t.get("worker_grids_launched"), t.get("worker_workgroups_launched"), "threads", (d.get("config") or {}).get("host_threads"))
+except Exception as ex: print("no line", ex)
+PY
+}
+B="python bench.py --steps 20 --warmup 5 --secondary= --small-batches= --no-cpu-baseline --lanes-only-steps 0 --deliver-steps 0 --no-device-half"
+echo "== default (linger 100 ms)"; timeout 300 $B > $O/bench_default.log 2> $O/bench_default.err; echo rc=$?; line $O/bench_default.log; grep -i "Error" $O/bench_default.err | tail -2 | cut -c1-300
+echo "== packed lanes"; ALFALFA_AMD_PACK_LANES=1 timeout 300 $B > $O/bench_pack.log 2> $O/bench_pack.err; echo rc=$?; line $O/bench_pack.log; grep -i "Error" $O/bench_pack.err | tail -2 | cut -c1-300
+echo "== linger 5 ms, 28 steps"; ALFALFA_AMD_WORKER_LINGER_MS=5 timeout 300 $B --steps 28 > $O/bench_linger5.log 2> $O/bench_linger5.err; echo rc=$?; line $O/bench_linger5.log; grep -i "Error" $O/bench_linger5.err | tail -2 | cut -c1-300
