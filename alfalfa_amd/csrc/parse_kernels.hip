@@ -130,10 +130,7 @@ __device__ inline uint32_t queue_take( aa::TokQueue * q, uint32_t want, uint32_t
   for ( uint32_t tries = 0; ; tries++ ) {
     const uint32_t avail = AA_AT_LOAD( &q->publish ) - h;
     if ( static_cast<int32_t>( avail ) <= 0 ) return 0;
-    const uint32_t wgs = spread & 0x7FFFFFFFu;
-    // (bit 31, experiment: of a queue longer than the GPU has workgroups a wave takes all it can carry -- a step costs a wave nearly the
-    // same whatever its width since round 5, so full waves + waves that leave beat every wave five sixths full)
-    const uint32_t share = ( spread >> 31 ) && avail > wgs ? want : ( avail + wgs - 1u ) / wgs;
+    const uint32_t share = ( avail + spread - 1u ) / spread;
     const uint32_t n = want < share ? want : share;
     uint32_t expect = h;
     if ( __hip_atomic_compare_exchange_strong( &q->head, &expect, h + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) { *base = h; return n; }
@@ -480,7 +477,7 @@ int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap &
 {
   if ( lanes < 1 || wgs < 1 ) return static_cast<int>( hipErrorInvalidValue );
   WorkerArgs a;
-  a.q = q; a.slots = slots; a.heap = heap; a.exited = exited; a.retire = retire; a.gen = gen; a.spread = ( spread & 0x7FFFFFFFu ) ? spread : ( spread | 1u ); a.prof = prof; a.linger_ticks = linger_ticks; a.lanes = lanes; a.lane_bytes = lane_bytes;
+  a.q = q; a.slots = slots; a.heap = heap; a.exited = exited; a.retire = retire; a.gen = gen; a.spread = spread ? spread : 1u; a.prof = prof; a.linger_ticks = linger_ticks; a.lanes = lanes; a.lane_bytes = lane_bytes;
   a.mp_hint = mp_hint ? mp_hint : 1u;
   // (mp_hint != 0: the context allows a lane per partition)
   if ( mp_hint ) {

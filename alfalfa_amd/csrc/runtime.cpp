@@ -298,7 +298,7 @@ struct aa_ctx {
     // 2 s -> 97.6-103.1 M macroblocks/s; 200 ms -> 114.6; 100 ms -> 117.7; 50 ms -> 118.4; 20 ms -> 116.3 (5-7 grids, 1 700-2 400
     // workgroups launched in the 20 steps instead of 1 grid of ~450) -- the drain above all: the last four steps take 0.6 s instead of 1.3
     unsigned long long linger_ticks = 10000000ull;
-    bool pack_lanes = false;             // ALFALFA_AMD_PACK_LANES=1 (experiment): a wave takes as many frames of a long queue as it has idle lanes
+    int topup_div = 4;                   // a top-up grid is launched when jobs wait and at least cap_wgs / this many workgroups are gone (ALFALFA_AMD_TOPUP_DIV)
   } tok;
   // Device pieces given back while kernels that read them may still be queued: they become reusable once an event recorded
   // on the compute stream after the release has fired ("epochs": one event per group of releases, recorded lazily).
@@ -810,7 +810,7 @@ aa_status tok_init( aa_ctx * ctx )
   HIP_TRY( hipMalloc( reinterpret_cast<void **>( &T.exited_dev ), sizeof( uint32_t ) * AA_MAX_WORKER_GRIDS ) );
   HIP_TRY( hipMemset( T.exited_dev, 0, sizeof( uint32_t ) * AA_MAX_WORKER_GRIDS ) );
   if ( const char * e = std::getenv( "ALFALFA_AMD_WORKER_LINGER_MS" ) ) T.linger_ticks = static_cast<unsigned long long>( std::max( 0, atoi( e ) ) ) * 100000ull;
-  if ( const char * e = std::getenv( "ALFALFA_AMD_PACK_LANES" ) ) T.pack_lanes = atoi( e ) != 0;
+  if ( const char * e = std::getenv( "ALFALFA_AMD_TOPUP_DIV" ) ) T.topup_div = std::max( 1, std::min( 64, atoi( e ) ) );
   if ( const char * e = std::getenv( "ALFALFA_AMD_TOKEN_PROFILE" ) ) if ( atoi( e ) ) {
     HIP_TRY( hipMalloc( reinterpret_cast<void **>( &T.prof_dev ), 64 ) );
     HIP_TRY( hipMemset( T.prof_dev, 0, 64 ) );
@@ -905,7 +905,7 @@ aa_status tok_launch_workers( aa_ctx * ctx, hipEvent_t after )
   int want = std::min( T.cap_wgs, queued ) - alive_total;
   // ... and not in dribs and drabs: a grid takes a worker stream for as long as its last wave lives, so small top-ups use the
   // streams up.  Waves linger when the queue is empty; a top-up is for when a good part of the GPU's lanes is really gone.
-  if ( want <= 0 || ( alive_total > 0 && want * ( T.pack_lanes ? 8 : 4 ) < T.cap_wgs && want < queued ) ) return AA_OK;
+  if ( want <= 0 || ( alive_total > 0 && want * T.topup_div < T.cap_wgs && want < queued ) ) return AA_OK;
   int g = -1;
   for ( int k = 0; k < aa_ctx::Tok::kSlots; k++ ) if ( alive[k] == 0 ) { g = k; break; }
   if ( g < 0 ) {
@@ -930,7 +930,7 @@ aa_status tok_launch_workers( aa_ctx * ctx, hipEvent_t after )
   sl.gen++;
   if ( after ) HIP_TRY( hipStreamWaitEvent( sl.st, after, 0 ) );
   LaunchTimer timer( ctx, 4, sl.st );
-  if ( int e = aa::launch_token_workers( T.q, T.slots, heap_of( ctx ), T.exited_dev + g, T.retire_dev + g, sl.gen, static_cast<uint32_t>( T.cap_wgs ) | ( T.pack_lanes ? 0x80000000u : 0u ), T.prof_dev, T.linger_ticks, want, T.lanes, T.lane_bytes, T.lds, T.packed, T.lane_per_partition ? T.mp_hint : 0u, sl.st ) )
+  if ( int e = aa::launch_token_workers( T.q, T.slots, heap_of( ctx ), T.exited_dev + g, T.retire_dev + g, sl.gen, static_cast<uint32_t>( T.cap_wgs ), T.prof_dev, T.linger_ticks, want, T.lanes, T.lane_bytes, T.lds, T.packed, T.lane_per_partition ? T.mp_hint : 0u, sl.st ) )
     return hip_fail( static_cast<hipError_t>( e ), "k_token_workers" );
   sl.launched += static_cast<uint32_t>( want );
   ctx->stats.worker_launches++; ctx->stats.worker_wgs += static_cast<uint64_t>( want );
