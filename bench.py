@@ -817,7 +817,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None if tr is None else round(tr * units[k] / n),
                 "avg_launch_us": round(ms / n * 1e3, 3), "launches_per_step": n, "ms_per_step": round(ms, 3),
                 "algorithmic_bytes_per_launch": round(bytes_per_launch), "traffic_source": TRAFFIC_SOURCES.get(k) if tr is not None else None,
-                "measured": "one un-pipelined step after the timed region, HIP events on the kernel's stream, worker grids resident beside it"}
+                "measured": "one un-pipelined step after the timed region, HIP events on the kernel's stream; the step's frames are parsed before its reconstruction starts, so the worker waves beside it are idle or gone (they leave 100 ms after their last frame): the pipelined figures are in profiles/r05_kernel_trace.md"}
     roofs = {k: roof(k) for k in BYTES_PER_MB if k != "parse_tokens"}
     # k_token_workers is RESIDENT: its workgroups draw frames from a queue for as long as there is work, so there is no launch to
     # put events around.  Its roofline is priced on the time it was resident for the work it did: the whole timed region (the
