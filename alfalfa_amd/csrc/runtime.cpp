@@ -298,7 +298,11 @@ struct aa_ctx {
     // 2 s -> 97.6-103.1 M macroblocks/s; 200 ms -> 114.6; 100 ms -> 117.7; 50 ms -> 118.4; 20 ms -> 116.3 (5-7 grids, 1 700-2 400
     // workgroups launched in the 20 steps instead of 1 grid of ~450) -- the drain above all: the last four steps take 0.6 s instead of 1.3
     unsigned long long linger_ticks = 10000000ull;
-    int topup_div = 4;                   // a top-up grid is launched when jobs wait and at least cap_wgs / this many workgroups are gone (ALFALFA_AMD_TOPUP_DIV)
+    // A top-up grid is launched when jobs wait and at least cap_wgs / this many workgroups are gone (ALFALFA_AMD_TOPUP_DIV).  An eighth:
+    // with a quarter a 40-step run sat at 578 of 768 workgroups (just above the threshold) for twelve steps while the queue grew to
+    // 6 700 jobs, and its drain then waited 1.5 s for the chains that started late (session 17); over 20 steps a quarter and an eighth
+    // measure the same (117.8 M both, session 16), a sixteenth spends the worker streams on small grids.
+    int topup_div = 8;
   } tok;
   // Device pieces given back while kernels that read them may still be queued: they become reusable once an event recorded
   // on the compute stream after the release has fired ("epochs": one event per group of releases, recorded lazily).
