@@ -17,6 +17,6 @@ try:
 except Exception as ex: print("no line", ex)
 PY
 }
-timeout 120 python -m pytest tests/test_gpu_device_parse.py -m gpu -x -q > $O/gpu_tests_device_parse.log 2>&1; echo "tests rc=$?"; tail -2 $O/gpu_tests_device_parse.log
+timeout 240 python -m pytest tests/test_gpu_device_parse.py -m gpu -x -q > $O/gpu_tests_device_parse.log 2>&1; echo "tests rc=$?"; tail -2 $O/gpu_tests_device_parse.log
 echo "== the driver's command"; timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_default.log 2> $O/bench_default.err; echo rc=$?; line $O/bench_default.log; grep -i "Error" $O/bench_default.err | tail -2 | cut -c1-300
 echo "== 40 steps"; timeout 400 python bench.py --steps 40 --warmup 5 --secondary= --small-batches= --no-cpu-baseline --lanes-only-steps 0 --deliver-steps 0 --no-device-half > $O/bench_40.log 2> $O/bench_40.err; echo rc=$?; line $O/bench_40.log; grep -i "Error" $O/bench_40.err | tail -2 | cut -c1-300
