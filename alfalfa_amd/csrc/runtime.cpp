@@ -220,6 +220,7 @@ struct aa_ctx {
     bool stop = false;
     // what the workers have really achieved (parse time only: no allocation, no upload) and what they have been given and not finished
     std::atomic<uint64_t> parsed_bytes { 0 }, parse_us { 0 }, backlog_bytes { 0 };
+    uint64_t parse_us_mark = 0;          // parse_us at the last aa_ctx_kernel_stats reset
   } host_lanes;
   struct DenseBuf { uint8_t * p = nullptr; size_t bytes = 0; hipEvent_t used = nullptr, filled = nullptr; bool in_use = false; };
   DenseBuf dense_bufs[2];
@@ -1583,8 +1584,11 @@ aa_status aa_ctx_kernel_stats( aa_ctx * ctx, aa_kernel_stats * out, int reset )
   for ( auto ps : ctx->parse_streams ) HIP_TRY( hipStreamSynchronize( ps ) );
   drain_profile( ctx );
   ctx->stats.heap_mapped_bytes = ctx->tok.heap_mapped;
+  // (the host lanes' summed parse time comes from their atomic counter: the workers themselves never write to `stats`)
+  const uint64_t lanes_us = ctx->host_lanes.parse_us.load();
+  ctx->stats.host_batch_parse_cpu_ms = static_cast<double>( lanes_us - ctx->host_lanes.parse_us_mark ) / 1e3;
   *out = ctx->stats;
-  if ( reset ) ctx->stats = aa_kernel_stats {};
+  if ( reset ) { ctx->stats = aa_kernel_stats {}; ctx->host_lanes.parse_us_mark = lanes_us; }
   return AA_OK;
 }
 
@@ -1961,7 +1965,6 @@ void host_lane_run( aa_ctx * ctx, Batch * b, int item, HostLaneScratch & S )
     const double t_parse = now_ms();
     aa::parse_frame_body( b->host + it.data_off, J.fp, mbs, coeffs, S.above.data(), &blocks, &intra );
     ctx->host_lanes.parse_us += static_cast<uint64_t>( ( now_ms() - t_parse ) * 1e3 ); ctx->host_lanes.parsed_bytes += J.size;
-    ctx->stats.host_batch_parse_cpu_ms += now_ms() - t_parse;          // (a diagnostic sum: workers race on it, the atomics above are what the planning uses)
     std::memset( rows, 0, words_per_row * mbh * sizeof( unsigned long long ) );
     for ( uint32_t r = 0; r < mbh; r++ ) for ( uint32_t c = 0; c < mbw; c++ ) {
       const aa_mb_info & mb = mbs[r * mbw + c];
