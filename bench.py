@@ -305,7 +305,7 @@ class Pipeline:
             # ~2.9 s (header kernel + a 2.2-s chain) -- the second group is ready at 2.1 s instead of 3, and from the third on the lanes'
             # key frames arrive as fast as the host's would.
             g0 = self.decoded
-            for g in range(g0, min(target, g0 + env["args"].urgent_groups)):
+            for g in range(g0, min(target, g0 + env.get("urgent_groups", env["args"].urgent_groups))):
                 self._submit_keys(g, urgent=True)
                 self.keys = g + 1
         while self.decoded < target:
@@ -398,7 +398,8 @@ def calibrate(env, streams):
     key_bytes_total = sum(len(st[0]) for st in streams)
     # (only where the library's own assumption -- 24 KB/ms per usable core -- lets the host take at least half of a hand-over: else it
     # takes none, there is nothing to measure, and 2 x S key frames would go through the lanes for nothing)
-    if hs > 0 and S > min(threads, 24) and hs * 24.0e3 * aa.capi.lib().aa_host_cpus() >= 0.5 * key_bytes_total:
+    host_lanes = max(1, min(int(os.environ.get("ALFALFA_AMD_HOST_LANES") or 0) or aa.capi.lib().aa_host_cpus(), aa.capi.lib().aa_host_cpus()))      # (this rank's share: run())
+    if hs > 0 and S > min(threads, 24) and hs * 24.0e3 * host_lanes >= 0.5 * key_bytes_total:
         for _ in range(2):
             probe = [aa.Decoder(ctx, width, height) for _ in range(S)]
             ctx.submit_frames([(d, st[0]) for d, st in zip(probe, streams)], threads)
@@ -413,12 +414,15 @@ def calibrate(env, streams):
     # box that grants 16 CPUs (1.3 s for 480 key frames): first step at 3.0 s instead of 3.9, but the hand-overs behind it start 1.3 s
     # late and the run as a whole is no faster (profiles/r04_bench_sessions.md).
     # (no host batch measured: the library's own assumption then, 24 KB/ms per usable core)
-    rate_kb_per_ms = env["host_rate_kb_per_ms"] or 24.0 * aa.capi.lib().aa_host_cpus()
+    rate_kb_per_ms = env["host_rate_kb_per_ms"] or 24.0 * host_lanes
     est_ms = key_bytes_total / (rate_kb_per_ms * 1e3)
     # Round 5: that route no longer blocks (HOST LANES: the frames take the device route's pre-pass and arena, worker threads of the
     # context finish them with the `done` word a GPU lane writes) -- the first group's key frames go to the host's cores whenever there
     # are more streams than a small call has, while the lanes take that group's inter frames and the later groups' key frames.
-    env["urgent_keys_on_host"] = bool(S > 24 and not env["args"].no_urgent_host)
+    # How many groups: as many as the host lanes finish before the GPU lanes deliver their first key frames anyway (a key frame's
+    # chain beside a full GPU: ~2.8 s) -- two on a rank with 16 cores (1.0 s per group of 480), none on a rank that gets 2 of them.
+    env["urgent_groups"] = max(0, min(env["args"].urgent_groups, int(2800.0 / max(est_ms, 1.0))))
+    env["urgent_keys_on_host"] = bool(S > 24 and not env["args"].no_urgent_host and env["urgent_groups"] > 0)
     env["urgent_host_estimate_ms"] = round(est_ms)
     ctx.kernel_stats(reset=True)
     env["packed_storage"] = {"key_frame_bytes_per_block": round(key_bpb, 2), "inter_frame_bytes_per_block": round(inter_bpb, 2), "dense_bytes_per_block": 32} if packed else None
@@ -596,6 +600,11 @@ def main():
     # the 256-worker rate)
     host_cpus = aa.capi.lib().aa_host_cpus()                # (what the process can really use: the cgroup quota counts -- the round-4 box shows 256, grants 16)
     threads = args.threads or max(1, min(os.cpu_count() or 1, 2 * host_cpus) // max(1, local_world))
+    # ... and of the context's HOST LANES (worker threads that finish key frames on the host's cores): a rank gets its share of the
+    # granted CPUs, not all of them -- eight ranks with sixteen lanes each on a 16-CPU grant would plan with eight times the cores there
+    # are (the library sizes its lanes, and the rate it plans the host share with, from this variable; a value already set stands)
+    rank_cpus = max(1, host_cpus // max(1, local_world))
+    os.environ.setdefault("ALFALFA_AMD_HOST_LANES", str(rank_cpus))
 
     ctx = aa.Context(dev_index)
     ctx.set_schedule(args.schedule)
@@ -1051,7 +1060,7 @@ def main():
                        "entropy_decode_alone_s_per_step": round(t_parse_alone, 4),
                        "note": "entropy_decode_alone = one step's submit -> parse finished with nothing else on the GPU (a latency: the longest chain, a key frame)"},
             "timed_region": timed_region, "per_rank": per_rank, "small_batches": small, "secondary": secondary, "all_frames_on_gpu_lanes": lanes_only,
-            "host_share": {"host_cpus_usable": host_cpus, "host_cpus_visible": os.cpu_count(), "urgent_key_frames_on_host": bool(env.get("urgent_keys_on_host")), "a_group_of_key_frames_on_the_host_route_would_take_ms": env.get("urgent_host_estimate_ms"),
+            "host_share": {"host_cpus_usable": host_cpus, "host_cpus_visible": os.cpu_count(), "host_lanes_of_this_rank": int(os.environ.get("ALFALFA_AMD_HOST_LANES") or 0), "urgent_groups_planned": env.get("urgent_groups"), "urgent_key_frames_on_host": bool(env.get("urgent_keys_on_host")), "a_group_of_key_frames_on_the_host_route_would_take_ms": env.get("urgent_host_estimate_ms"),
                            "groups_whose_key_frames_took_the_host_route_in_the_timed_region": urgent_groups_timed,
                            "host_share_ms": info["host_share_ms"], "key_frames_parsed_by_host_workers": bool(env.get("keys_on_host")), "host_threads": threads,
                            "host_rate_kb_per_ms_measured": info["host_rate_kb_per_ms"], "equivalent_cores_at_24_kb_per_ms": round(info["host_rate_kb_per_ms"] / 24.0, 1),

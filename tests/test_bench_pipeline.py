@@ -173,3 +173,13 @@ def test_calibration_runs_against_a_fake_context(bench, monkeypatch):
         assert ctx.calls == 2 + (2 if probed else 0)
         assert env["keys_on_host"] == (probed and 0.9 * S * key_size <= 80 * 600e3)
         assert isinstance(env["urgent_keys_on_host"], bool) and (S > 24 or not env["urgent_keys_on_host"])
+        assert 0 <= env["urgent_groups"] <= 2 and (env["urgent_groups"] > 0 or not env["urgent_keys_on_host"])
+    # a rank that gets ONE of the host's cores (eight ranks on a small CPU grant): 40 key frames of 2 MB would take its lane 3.3 s --
+    # longer than the GPU lanes take for theirs -- so no group's key frames are planned for the host route
+    monkeypatch.setenv("ALFALFA_AMD_HOST_LANES", "1")
+    ctx = Ctx()
+    streams = [[b"k" * 2_000_000] + [b"i" * 100] * 2 for _ in range(40)]
+    env = {"ctx": ctx, "F": 3, "width": 64, "height": 64, "threads": 4, "mbs_per_frame": 16, "compressed_bytes": sum(len(f) for st in streams for f in st),
+           "raster_bytes": 64 * 64 * 3 // 2, "args": args}
+    bench.calibrate(env, streams)
+    assert ctx.calls == 2 and env["urgent_groups"] == 0 and env["urgent_keys_on_host"] is False and env["urgent_host_estimate_ms"] > 2800
