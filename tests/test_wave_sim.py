@@ -20,15 +20,18 @@ LIB = os.path.join(BUILD, "libwave_sim.so")
 CSRC = os.path.join(ROOT, "alfalfa_amd", "csrc")
 
 
-def wave_lib():
+def wave_lib(bend_every=None):
+    """bend_every: the period of the deferred block-end pass (tok_fsm.hh kBendEvery, the build's AA_BEND_EVERY; None = the product's 4)"""
     srcs = [os.path.join(ROOT, "tests", "cpp", "wave_sim.cc"), os.path.join(CSRC, "parser.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("tok_fsm.hh", "coeff_pack.hh", "parse_common.hh", "parser.hh", "bool_reader.hh")]
     os.makedirs(BUILD, exist_ok=True)
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps):
-        tmp = "%s.%d.tmp" % (LIB, os.getpid())             # (pytest-xdist workers may build at the same time: rename is atomic)
-        subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wextra", "-fPIC", "-shared"] + os.environ.get("AA_SIM_FLAGS", "").split() + srcs + ["-o", tmp], check=True)
-        os.replace(tmp, LIB)
-    L = C.CDLL(LIB)
+    lib = LIB if bend_every is None else LIB.replace(".so", "_bend%d.so" % bend_every)
+    flags = [] if bend_every is None else ["-DAA_BEND_EVERY=%d" % bend_every]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(d) for d in deps):
+        tmp = "%s.%d.tmp" % (lib, os.getpid())             # (pytest-xdist workers may build at the same time: rename is atomic)
+        subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wextra", "-fPIC", "-shared"] + flags + os.environ.get("AA_SIM_FLAGS", "").split() + srcs + ["-o", tmp], check=True)
+        os.replace(tmp, lib)
+    L = C.CDLL(lib)
     L.wave_sim_run.argtypes = [C.c_uint16, C.c_uint16, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t),
                                C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int,
                                C.POINTER(capi.FrameHeader), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
@@ -36,9 +39,9 @@ def wave_lib():
     return L
 
 
-def run_wave(w, h, streams, lanes, pool_chunks=0, packed=False, seed=1, burst=1000, burst_gap=1, mp=False, mp_hint=4):
+def run_wave(w, h, streams, lanes, pool_chunks=0, packed=False, seed=1, burst=1000, burst_gap=1, mp=False, mp_hint=4, bend_every=None):
     """streams: list of lists of frames (bytes) of one size -> stats; asserts every frame's records equal the host parser's"""
-    L = wave_lib()
+    L = wave_lib(bend_every)
     flat = [fr for st in streams for fr in st]
     n = len(flat)
     nmb = ((w + 15) // 16) * ((h + 15) // 16)
@@ -86,6 +89,22 @@ def test_a_wave_of_lanes_matches_the_host_parser(lanes, packed):
     st = run_wave(176, 144, qcif_streams(9), lanes, packed=packed, seed=lanes)
     assert st["peak_busy_lanes"] == min(lanes, sum(len(s) for s in qcif_streams(9)))
     assert st["boundary_passes"] > 0
+
+
+@FORMATS
+@pytest.mark.parametrize("bend_every", [1, 2, 8])
+def test_the_period_of_the_deferred_block_end_pass_does_not_change_a_record(bend_every, packed):
+    """Round 5: a lane whose block has ended parks (R_BEND) and the wave runs tok::block_end every kBendEvery steps (4 in the product:
+    measured best).  Parked lanes must lose nothing and gain nothing whatever the period: 1 (a pass after every step: the round-4
+    behaviour), 2 and 8 (the ends of the range the kernel was measured over) give the host parser's records byte for byte, with lanes
+    parked for different numbers of steps beside lanes in mid-token and lanes at a macroblock boundary."""
+    st = run_wave(176, 144, qcif_streams(6), 22, packed=packed, seed=40 + bend_every, bend_every=bend_every)
+    assert st["boundary_passes"] > 0
+    # (one lane per partition too: the lanes of a frame hand rows to each other while some of them are parked)
+    import vp8_synth  # noqa: F401
+    w, h = 176, 144
+    streams = [partitioned_stream(w, h, 900 + k, 1 + k % 3) for k in range(4)]
+    run_wave(w, h, streams, 16, packed=packed, seed=7, mp=True, mp_hint=4, bend_every=bend_every)
 
 
 @FORMATS
