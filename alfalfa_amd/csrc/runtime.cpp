@@ -2623,6 +2623,29 @@ aa_status expand_packed( aa_ctx * ctx, aa_stream * const * streams, const int * 
 }
 } // namespace
 
+namespace {
+// ALFALFA_AMD_DECODE_TIMING=1 (diagnostics, off by default): where the host's time inside aa_decode_batch goes, section by section, printed
+// to stderr when a context is destroyed.  (Round 5: the plateau's calls take 24 ms each with the counted waits at zero)
+struct DecodeTiming {
+  bool on = false; double ms[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; uint64_t calls = 0;
+  ~DecodeTiming()      // (the static below: at process exit)
+  {
+    if ( !on || !calls ) return;
+    static const char * const names[10] = { "checks", "stream uploads", "collect_pending", "resolve_summary (waits for the parser included)", "dense buffer",
+                                            "bind_batch (waits for a binding buffer included)", "expand_packed", "job lists", "inter launches", "intra + loop-filter launches" };
+    std::fprintf( stderr, "alfalfa_amd: aa_decode_batch host time over %llu calls, ms per call:", static_cast<unsigned long long>( calls ) );
+    for ( int k = 0; k < 10; k++ ) std::fprintf( stderr, " [%s] %.3f", names[k], ms[k] / static_cast<double>( calls ) );
+    std::fprintf( stderr, "\n" );
+  }
+};
+DecodeTiming * decode_timing() { static DecodeTiming d; static const bool init = [] { const char * e = std::getenv( "ALFALFA_AMD_DECODE_TIMING" ); d.on = e && atoi( e ) != 0; return true; }(); (void) init; return &d; }
+struct DecodeMark {
+  DecodeTiming & d; double t;
+  DecodeMark() : d( *decode_timing() ), t( d.on ? now_ms() : 0.0 ) { if ( d.on ) d.calls++; }
+  void lap( int k ) { if ( d.on ) { const double n = now_ms(); d.ms[k] += n - t; t = n; } }
+};
+} // namespace
+
 aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, const int * frame_index )
 {
   if ( !ctx || !streams || !frame_index || n <= 0 ) return fail( AA_ERR_ARGUMENT, "aa_decode_batch: bad argument" );
@@ -2634,6 +2657,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
   bool any_split = false;
   bool same_geometry = true;     // two-frames-per-wave loop filter needs equal macroblock dimensions in the batch
   uint64_t total_mbs = 0;
+  DecodeMark mk;
   for ( int i = 0; i < n; i++ ) {
     aa_stream * s = streams[i];
     if ( !s || s->ctx != ctx ) return fail( AA_ERR_ARGUMENT, "aa_decode_batch: stream belongs to another context" );
@@ -2641,16 +2665,20 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
     if ( fi < 0 || fi >= static_cast<int>( s->frames.size() ) ) return fail( AA_ERR_ARGUMENT, "aa_decode_batch: frame index out of range" );
     if ( fi != s->next_submit ) return fail( AA_ERR_LOGIC, "aa_decode_batch: frames of a stream must be submitted in order" );
   }
+  mk.lap( 0 );
   for ( int i = 0; i < n; i++ ) if ( aa_status st = aa_stream_upload( streams[i] ) ) return st;
+  mk.lap( 1 );
   // coefficient chunks of the frames released since the last call go back to the pool (behind the kernels that read them:
   // those were queued before the release)
   // ... and what was released since then gets its epoch now: reusable as soon as the kernels queued before this call have run
   // (not whenever some later allocation happens to miss its free list)
   { std::lock_guard<std::mutex> g( ctx->pool_mu ); collect_pending( ctx, false ); }
+  mk.lap( 2 );
   for ( int i = 0; i < n; i++ ) {
     if ( streams[i]->frames[frame_index[i]].records_released ) return fail( AA_ERR_LOGIC, "aa_decode_batch: frame records were released" );
     if ( aa_status st = resolve_summary( streams[i], streams[i]->frames[frame_index[i]] ) ) return st;
   }
+  mk.lap( 3 );
   // Packed coefficient storage: the frames of this call that were parsed on the device get their dense blocks now -- one
   // transient piece for the call, written by k_expand_coeffs in front of the reconstruction kernels and given back behind them
   aa_ctx::DenseBuf * dense = nullptr;
@@ -2694,7 +2722,9 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
                          for ( auto & h : c->compute_hold ) { c->compute_free[h.second].push_back( h.first ); c->compute_free_bytes += h.second; }
                          c->compute_hold.clear();
                        } } } bind_guard( ctx );
+  mk.lap( 4 );
   if ( aa_status st = bind_batch( ctx, streams, n, frame_index ) ) return st;
+  mk.lap( 5 );
   if ( !packed_frames.empty() ) {
     // the expansion runs on a stream of its own, behind the kernels that last read the array (two calls ago) -- or, when a frame
     // of the call is being reconstructed again, behind everything queued so far: kernels of its earlier run may still follow
@@ -2713,6 +2743,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
   // frames count as submitted only once every launch of the batch has been queued (a failed launch must not leave them
   // looking decoded)
   struct Advance { aa_stream * const * streams; int n; bool ok = false; ~Advance() { if ( ok ) for ( int i = 0; i < n; i++ ) streams[i]->next_submit++; } } advance { streams, n };
+  mk.lap( 6 );
   for ( int i = 0; i < n; i++ ) {
     aa_stream * s = streams[i];
     const FrameRec & r = s->frames[frame_index[i]];
@@ -2726,6 +2757,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
     total_mbs += h.num_macroblocks;
   }
   ctx->stats.macroblocks += total_mbs;
+  mk.lap( 7 );
 
   auto for_each_list = [&]( const std::vector<const aa_dev_frame *> & jobs, auto && fn ) -> int {
     for ( size_t base = 0; base < jobs.size(); base += AA_MAX_BATCH ) {
@@ -2753,6 +2785,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
       if ( aa_status st = check( e, "k_recon_inter" ) ) return st;
     }
   }
+  mk.lap( 8 );
   const int ndiag = max_mbw + 2 * ( max_mbh - 1 );
   if ( ctx->schedule == 0 ) {
     // 2+3. row-pipelined kernels: one launch each; macroblock rows are ordered in-launch (ticket + progress words)
@@ -2773,6 +2806,7 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
       for ( size_t i = 0; i < lf_jobs.size(); i++ ) keyed.emplace_back( lf_geometry[i], lf_jobs[i] );
       if ( aa_status st = launch_lf_rows( ctx, keyed, same_geometry, max_mbh, max_mbw ) ) return st;
     }
+    mk.lap( 9 );
     advance.ok = true;
     return AA_OK;
   }
