@@ -127,14 +127,19 @@ class BoolReader32
   uint32_t cache_n_ = 0;         // how many of them: the stream is read a word at a time -- on the GPU every read is a trip to the L2
 
   // the byte at pos_ (zero past the end), pos_ advanced.  The word read is the ALIGNED one the byte lies in: it never reaches into a
-  // page the byte itself is not on, whatever the alignment of the partition and wherever the buffer ends.
+  // page the byte itself is not on, whatever the alignment of the partition and wherever the buffer ends.  Memory is touched only
+  // while pos_ is INSIDE the partition: a truncated or crafted frame keeps the decoder consuming zeros for every macroblock header
+  // that follows (bool_decoder.hh:56-65), and a word read per four of those would walk hundreds of KB past the partition -- off the
+  // end of the pinned arena on the host-lane path.
   AA_HD inline uint32_t next_byte()
   {
     if ( cache_n_ == 0 ) {
-      const uintptr_t a = reinterpret_cast<uintptr_t>( base_ + pos_ );
-      const uint32_t skip = static_cast<uint32_t>( a & 3u );
-      cache_ = *reinterpret_cast<const uint32_t *>( a - skip ) >> ( 8u * skip );
-      cache_n_ = 4u - skip;
+      if ( pos_ < end_ ) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>( base_ + pos_ );
+        const uint32_t skip = static_cast<uint32_t>( a & 3u );
+        cache_ = *reinterpret_cast<const uint32_t *>( a - skip ) >> ( 8u * skip );
+        cache_n_ = 4u - skip;
+      } else { cache_ = 0; cache_n_ = 4u; }
     }
     const uint32_t byte = pos_ < end_ ? ( cache_ & 0xFFu ) : 0u;
     cache_ >>= 8; cache_n_--; pos_++;

@@ -4,6 +4,9 @@
 //   g++ -shared fsm_sim.cc ../../alfalfa_amd/csrc/parser.cpp
 // It follows parse_kernels.hip statement for statement: header pre-pass (Parser::parse_header, the real product code),
 // k_parse_mb_headers' loop, k_segment_fixup's loop, k_parse_tokens' loop.
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -225,6 +228,41 @@ int fsm_sim_body_frame( void * handle, const uint8_t * data, size_t size )
   if ( std::memcmp( m1.data(), m2.data(), nmb * sizeof( aa_mb_info ) ) ) return 1;
   if ( std::memcmp( c1.data(), c2.data(), size_t( blocks ) * 32 ) ) return 2;
   return 0;
+}
+
+// The same host-lane parse with the frame's bytes ending EXACTLY at an inaccessible page (the pinned arena's end, runtime.cpp):
+// a decoder that has run out of partition reads zeros (bool_decoder.hh:56-65) and must not touch memory for them.  Runs in a
+// forked child so that a stray read is a result, not a dead test process.
+// -> 0 parsed, 4 segmentation (not eligible), 5 rejected by the header pre-pass, 100 the child died (a read past the buffer), 101 could not set the check up
+int fsm_sim_body_guarded( uint16_t w, uint16_t h, const uint8_t * data, size_t size, int conceal )
+{
+  aa::Parser hdr_only( w, h );
+  hdr_only.set_error_concealment( conceal != 0 );
+  aa_frame_header hd; aa::FrameParams fp;
+  try { hdr_only.parse_header( data, size, hd, fp ); } catch ( const aa::ParseError & ) { return 5; }
+  if ( fp.seg_enabled ) return 4;
+  const size_t page = static_cast<size_t>( sysconf( _SC_PAGESIZE ) ), span = ( ( size + page - 1 ) / page + 1 ) * page;
+  uint8_t * region = static_cast<uint8_t *>( mmap( nullptr, span + page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0 ) );
+  if ( region == MAP_FAILED ) return 101;
+  if ( mprotect( region + span, page, PROT_NONE ) ) { munmap( region, span + page ); return 101; }
+  uint8_t * copy = region + span - size;                    // the frame's last byte is the last byte in front of the guard page
+  std::memcpy( copy, data, size );
+  int result = 101;
+  const pid_t pid = fork();
+  if ( pid == 0 ) {
+    const size_t nmb = size_t( hdr_only.mb_width() ) * hdr_only.mb_height();
+    std::vector<aa_mb_info> m( nmb );
+    std::vector<int16_t> c( nmb * 25 * 16 + 16 );
+    std::vector<uint8_t> above( size_t( hdr_only.mb_width() ) * 9 );
+    uint32_t blocks = 0, intra = 0;
+    aa::parse_frame_body( copy, fp, m.data(), c.data(), above.data(), &blocks, &intra );
+    _exit( 0 );
+  } else if ( pid > 0 ) {
+    int st = 0;
+    if ( waitpid( pid, &st, 0 ) == pid ) result = ( WIFEXITED( st ) && WEXITSTATUS( st ) == 0 ) ? 0 : 100;
+  }
+  munmap( region, span + page );
+  return result;
 }
 
 // the pool offers only `chunks` coefficient chunks to the next frames (0: plenty) -> a frame that needs more is handed back

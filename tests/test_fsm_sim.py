@@ -45,6 +45,7 @@ def sim_lib():
     L.fsm_sim_body_create.argtypes = [C.c_uint16, C.c_uint16]
     L.fsm_sim_body_destroy.argtypes = [C.c_void_p]
     L.fsm_sim_body_frame.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.fsm_sim_body_guarded.argtypes = [C.c_uint16, C.c_uint16, C.c_char_p, C.c_size_t, C.c_int]
     return L
 
 
@@ -216,3 +217,26 @@ def test_host_lanes_parse_a_frame_from_its_header_prepass_alone():
         w, h = sizes[seed % len(sizes)]
         total += body_check(w, h, vp8_synth.feature_stream(w, h, seed, 8).frames)
     assert total >= 150, total
+
+
+def test_a_decoder_that_has_run_out_of_partition_reads_no_memory():
+    """ADVICE round 5 (medium): BoolReader32::next_byte loaded the aligned word at its read position even when that position
+    was past the partition's end -- a frame cut inside its first partition (accepted with error concealment on) keeps the
+    header decoder consuming zeros for every macroblock that follows, and the loads walked off the end of the buffer: on the
+    host-lane path off the end of the pinned arena.  Here the frame's last byte is the last byte in front of an inaccessible
+    page; the parse runs in a forked child (100 = it died).  Frames cut inside the first partition, at its end, inside the DCT
+    partitions, and whole."""
+    L = sim_lib()
+    ran = 0
+    for name in ("qcif_q30_lf24", "qcif_allkey_q20", "w200_q40_lf63s7"):
+        w, h, frames = golden_frames(name)
+        for fr in frames[:3]:
+            tag = fr[0] | (fr[1] << 8) | (fr[2] << 16)
+            hdr = 3 if tag & 1 else 10
+            first = (tag >> 5) & 0x7FFFF
+            for cut, conceal in ((len(fr), 0), (hdr + first, 1), (hdr + first // 2, 1), (hdr + max(1, first // 8), 1), (hdr + first + 1, 0),
+                                 (hdr + first + (len(fr) - hdr - first) // 2, 0)):
+                rc = L.fsm_sim_body_guarded(w, h, fr[:cut], cut, conceal)
+                assert rc in (0, 4, 5), (name, cut, len(fr), rc)
+                ran += rc == 0
+    assert ran >= 30, ran
