@@ -160,11 +160,9 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
   __syncthreads();
   aa::tok::Lane L;
   aa::tok::Frame F {};
-  L.rec = aa::tok::R_DONE;
-  L.base = aa::tok::kTablesBytes + static_cast<uint32_t>( lane ) * a.lane_bytes;
-  L.pend_wpos = L.pend_mwpos = aa::tok::kNoPend;
-  L.steps = 0;
+  // (threads that are no token lanes run the steps too -- idle, at the addresses of lane 0: reads only)
   const bool is_lane = lane < a.lanes;
+  aa::tok::init_lane( L, aa::tok::ring_addr( is_lane ? lane : 0 ), aa::tok::slice_addr( is_lane ? lane : 0, a.lanes, a.lane_bytes ) );
   uint32_t backoff = 0;
   unsigned long long idle_since = 0;      // the wave has had no frame since (0: it has one)
   uint32_t looks = 0;
@@ -216,7 +214,7 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
               const aa::ParseJob * my_job = reinterpret_cast<const aa::ParseJob *>( static_cast<uintptr_t>( jp ) );
               if ( d.n > 1u ) {
                 const int owner_lane = nth_set_bit( idle_mask, d.start + aa::tok::mp_owner_partition( my_job ) );
-                F = aa::tok::frame_of_partition( my_job, d.part, aa::tok::kTablesBytes + static_cast<uint32_t>( owner_lane ) * a.lane_bytes );
+                F = aa::tok::frame_of_partition( my_job, d.part, aa::tok::slice_addr( owner_lane, a.lanes, a.lane_bytes ) );
               } else F = aa::tok::frame_of( my_job );
               if ( my_job->nmb == 0 ) { L.rec = aa::tok::R_DONE; }                  // (never queued; belt and braces)
               else aa::tok::begin_frame<MP>( L, smem, L.base, F );

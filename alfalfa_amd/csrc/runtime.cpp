@@ -847,6 +847,8 @@ aa_status tok_init( aa_ctx * ctx )
     HIP_TRY( hipMalloc( reinterpret_cast<void **>( &T.heap ), fixed ) );
     T.heap_va = fixed;
   }
+  // (the token lanes advance a pointer into a chunk with a 32-bit add: tok_fsm.hh bump_words)
+  if ( reinterpret_cast<uintptr_t>( T.heap ) & ( kChunkBytesHeap - 1 ) ) return fail( AA_ERR_HIP, "the coefficient heap's base is not aligned to a chunk (64 KB)" );
   uint32_t entries = 1;
   while ( size_t( entries ) * kChunkBytesHeap < T.heap_va ) entries <<= 1;
   uint8_t * pr = nullptr;
@@ -962,13 +964,16 @@ inline double parse_timeout_ms()
   return ms;
 }
 // the token lane's `done` word of one frame (pinned host memory the lane writes last)
+// (the `done` word is the writer's last store behind a release -- a GPU lane's system-scope fence, a host lane's thread fence: read
+// it with acquire, so that what the reader looks at next -- the summary's counts, host_dense -- is what the writer left)
+inline bool summary_done( volatile aa::FrameSummary * sum ) { return __atomic_load_n( const_cast<const uint32_t *>( &sum->done ), __ATOMIC_ACQUIRE ) != 0; }
 aa_status tok_wait_done( aa_ctx * ctx, volatile aa::FrameSummary * sum )
 {
-  if ( sum->done ) return AA_OK;
+  if ( summary_done( sum ) ) return AA_OK;
   const double t0 = now_ms();
   double last = t0 - 1e9;
   int spins = 0;
-  while ( !sum->done ) {
+  while ( !summary_done( sum ) ) {
     const double t = now_ms();
     if ( t - last > 2.0 ) { if ( aa_status st = tok_service( ctx ) ) return st; last = t; }
     if ( t - t0 > parse_timeout_ms() ) return fail( AA_ERR_HIP, "device parser: a frame handed to the token workers was not finished in time (ALFALFA_AMD_PARSE_TIMEOUT_S, default 300)" );
@@ -1052,6 +1057,14 @@ void release_records( aa_stream * s, FrameRec & f, bool deferred )
   // a token lane may still be writing this frame's records (callers release decoded frames: then this is over already)
   bool parsed = false;
   if ( f.enqueued && f.summary ) parsed = tok_wait_done( ctx, f.summary ) == AA_OK;
+  if ( !parsed && f.enqueued && f.summary && f.batch && f.batch_item >= 0 && f.batch_item < static_cast<int>( f.batch->items.size() ) && f.batch->items[f.batch_item].on_host ) {
+    // A HOST LANE's frame whose wait failed (the parse timeout, or a HIP error out of the service call): a worker thread may be
+    // inside host_lane_run for it right now -- reading the pinned arena, writing host_dense, queueing copies into the record
+    // block -- or have it in its queue.  Nothing of the batch may be freed under it (use-after-free, another
+    // batch's records silently overwritten).  A host lane ends every path with the `done` word, so wait for that word itself,
+    // without a bound and without the device.
+    while ( !summary_done( f.summary ) ) usleep( 200 );
+  }
   f.records_released = true;
   if ( f.rec_block ) {
     // the coefficient chunks the frame took go back to the pool on the device, by a kernel that reads the list out of the
@@ -2116,6 +2129,21 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
       // ~1 s for a group's key frames, and the hand-overs behind it started that much later).
       to_host_lanes = true;
     }
+    // Round 6: FRAME-PARALLEL parse of few streams.  A call that brings SEVERAL frames per stream (a player's look-ahead, an ExCamera
+    // bundle's chunks: player.cc:134-144, decode-bundle.cc:56-99) used to parse each stream's frames one after the other on one
+    // worker -- one stream = one core, whatever the box has -- and inside the call.  VP8 has no backward adaptation: once the header
+    // pre-pass (microseconds per frame, serial across a stream) has run, every frame body is an independent chain
+    // (decoder_state.hh:92-97,126-131), which is exactly what the host lanes take.  Such a call therefore goes the host lanes' way
+    // too: all its frames in parallel on the context's worker threads, the call returns at once, reconstruction waits for each
+    // frame's `done` word.  Not for streams that use segmentation (their persistent map lives with whoever parses them in order:
+    // the per-stream route below) and not for one-frame-per-stream calls (nothing to run in parallel; the caller waits anyway).
+    if ( !defer_tokens && !force_device && !force_host && few && !to_host_lanes && n > static_cast<int>( stream_order.size() ) ) {
+      const char * few_env = std::getenv( "ALFALFA_AMD_FEW_ROUTE" );
+      const bool per_stream = few_env && few_env[0] == 's';                // "streams": the round-3 route (A/B runs, tests)
+      bool seg = false;
+      for ( aa_stream * s : stream_order ) seg = seg || s->parser.segmentation().enabled || s->segmap_on_device;
+      if ( !per_stream && !seg ) to_host_lanes = true;
+    }
     if ( !defer_tokens && !force_device && !to_host_lanes && ( force_host || few ) ) {
       std::atomic<size_t> next { 0 };
       auto work = [&]() {
@@ -2937,16 +2965,21 @@ aa_status aa_stream_download_async( aa_stream * s, int fi, uint8_t * y, uint8_t 
   // (the flag stays up until the event recorded behind THIS call's copies has fired: downloads are numbered, and a release on
   // another thread that finds the event of an earlier download complete does not take the flag down while a later one is still
   // between its copies and its event)
-  uint64_t my_download;
-  { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->copy_reads_rasters = true; ctx->raster_download_pending = true; my_download = ++ctx->downloads_queued; }
+  { std::lock_guard<std::mutex> g( ctx->pool_mu ); ctx->copy_reads_rasters = true; ctx->raster_download_pending = true; ++ctx->downloads_queued; }
+  // Every exit -- the error exits of the HIP calls below too -- counts this download as recorded and leaves an event behind what it
+  // queued on the copy stream: a download that begun and never "recorded" would keep downloads_recorded != downloads_queued for
+  // the life of the context, and every raster released from then on would take the slow epoch route.
+  struct Recorded {
+    aa_ctx * ctx;
+    ~Recorded() {
+      std::lock_guard<std::mutex> g( ctx->pool_mu );
+      if ( !ctx->last_raster_download && hipEventCreateWithFlags( &ctx->last_raster_download, hipEventDisableTiming ) != hipSuccess ) { ctx->last_raster_download = nullptr; (void) hipGetLastError(); }
+      if ( ctx->last_raster_download && hipEventRecord( ctx->last_raster_download, ctx->copy ) != hipSuccess ) (void) hipGetLastError();
+      ++ctx->downloads_recorded;                         // (a count of finished calls: equal to downloads_queued when none is between its copies and its event)
+    }
+  } recorded { ctx };
   for ( int p = 0; p < 3; p++ ) if ( dst[p] ) HIP_TRY( hipMemcpyAsync( dst[p], slot_plane( s, r.out_slot, p ), s->plane_bytes[p], hipMemcpyDeviceToHost, ctx->copy ) );
   // (rasters released from now on are recycled through an epoch until this copy is through: dev_free_compute)
-  {
-    std::lock_guard<std::mutex> g( ctx->pool_mu );
-    if ( !ctx->last_raster_download ) HIP_TRY( hipEventCreateWithFlags( &ctx->last_raster_download, hipEventDisableTiming ) );
-    HIP_TRY( hipEventRecord( ctx->last_raster_download, ctx->copy ) );
-    ctx->downloads_recorded = std::max( ctx->downloads_recorded, my_download );
-  }
   return AA_OK;
 }
 aa_status aa_stream_download_wait( aa_stream * s )

@@ -190,16 +190,21 @@ constexpr uint32_t kMetaChunks = 1;       // 16-flag chunks fetched per top-up (
 static_assert( kRing >= 3 * kPeriod && 16 * kChunks == kPeriod && ( kRing & ( kRing - 1 ) ) == 0, "stream ring invariant" );
 
 // Workgroup LDS ("smem"; one flat buffer on the host): the node and block tables and the constant probabilities at offset
-// 0 -- so that a node record's address is a plain number a record can carry -- then one slice per lane.  The number of
-// chains a CU holds is what LDS is left (160 KB / slice), so a slice carries nothing that could be shared or left out.
-constexpr uint32_t kNodeTabOff = 0;       // node records, 8 bytes each (addresses < 512: 9 bits in a record)
-constexpr uint32_t kBlockTabOff = 512;    // block entries, 8 bytes each
-constexpr uint32_t kXtab = 720;           // extra-bit probabilities of the six categories, then the sign's 128 (absolute address)
+// 0 -- so that a node record's address is a plain number a record can carry --, then one 128-byte STREAM RING per lane (a region of
+// its own, 128-byte aligned: the step forms a ring address with one and-or), then one slice per lane.  The number of chains a CU
+// holds is what LDS is left (160 KB / (ring + slice)), so a slice carries nothing that could be shared or left out.
+constexpr uint32_t kNodeTabOff = 0;       // node records, 8 bytes each: 47 nodes (addresses < 512) ...
+constexpr uint32_t kBandTabOff = 384;     // band33[position 0..17]: 33 * coefficient band of a position (a multiple of 32: Lane::ia)
+constexpr uint32_t kXtab = 408;           // extra-bit probabilities of the six categories, then the sign's 128 (absolute address)
 constexpr uint32_t kSignX = 26;           // index of the sign's probability in that table
-constexpr uint32_t kTablesBytes = 768;    // first lane slice
+constexpr uint32_t kBlockTabOff = 440;    // block entries, 8 bytes each (26)
+constexpr uint32_t kIdleTabOff = 648;     // ... and 5 IDLE records (addresses >= 512: bit 9 says "this lane is not decoding")
+constexpr uint32_t kTablesBytes = 768;    // first stream ring (a multiple of 128)
+AA_HD constexpr uint32_t ring_addr( uint32_t lane ) { return kTablesBytes + lane * 128u; }
+// a lane's slice: behind the rings of all `lanes` lanes of the workgroup; lane_bytes = lane_lds_bytes() (ring included)
+AA_HD constexpr uint32_t slice_addr( uint32_t lane, uint32_t lanes, uint32_t lane_bytes ) { return kTablesBytes + lanes * 128u + lane * ( lane_bytes - 128u ); }
 // offsets relative to a lane's slice:
-constexpr uint32_t kStream = 0;           // stream ring (16-byte aligned: filled 16 bytes at a time)
-constexpr uint32_t kMeta = kStream + kRing;
+constexpr uint32_t kMeta = 0;             // flag ring (16-byte aligned: filled 16 bytes at a time)
 // Token probabilities: THREE of the frame's four 264-byte type planes ([8][3][11] each), not the whole [4][8][3][11] table.  The
 // order of block types inside a macroblock is fixed (macroblock.cc:475-502): Y2, 16 x Y_AFTER_Y2, 8 x UV -- or, for a macroblock
 // without a Y2 block (B_PRED, SPLITMV), 16 x Y_WITHOUT_Y2, 8 x UV.  A macroblock therefore reads ONE of the two Y planes, and which
@@ -219,7 +224,7 @@ static_assert( kPlaneY % 8 == 0 && kPlaneUV % 8 == 0 && kPlaneY2 % 8 == 0 && kPl
 AA_HD constexpr uint32_t above_bytes( uint32_t mbw, bool shared ) { return shared ? 2u * mbw : mbw + ( mbw + 7u ) / 8u; }
 // then, only for frames with more than one token partition: 8 saved partition decoders x 16 bytes
 AA_HD constexpr uint32_t part_off( uint32_t mbw, bool shared ) { return ( kAbove + above_bytes( mbw, shared ) + 15 ) & ~15u; }
-AA_HD constexpr uint32_t lane_lds_bytes( uint32_t mbw, bool multi_partition, bool shared = false ) { return part_off( mbw, shared ) + ( multi_partition ? 128u : 0u ); }
+AA_HD constexpr uint32_t lane_lds_bytes( uint32_t mbw, bool multi_partition, bool shared = false ) { return kRing + part_off( mbw, shared ) + ( multi_partition ? 128u : 0u ); }     // ring + slice
 // (The flags were tried in HBM -- 240 bytes of LDS per lane at 1080p would buy 15 % more chains per CU --, the lane keeping the
 // eight columns it passes in registers.  Measured on MI355X, round 3: every use of those registers costs the wave an
 // s_waitcnt vmcnt(0), i.e. a drain of ALL its outstanding coefficient stores at every macroblock boundary of every lane;
@@ -234,19 +239,29 @@ constexpr uint8_t kXtabInit[27] = { 159, 165, 145, 173, 148, 140, 176, 155, 140,
 // 11..36  extra bits: cat1 = 11, cat2 = 12-13, cat3 = 14-16, cat4 = 17-20, cat5 = 21-25, cat6 = 26-36 (node e reads kXtab[e-11])
 // 37..46  the sign, one node per token kind: the record knows the magnitude to add (DCT_1..4: the literal; dct_catN: its
 //         base, the extra bits having been shifted into Lane::mag) and the context the token leaves behind
-// A lane's state is the ADDRESS of its node's record (8 * node); values >= R_MBDONE mean "not decoding".
-enum : uint32_t { kNodes = 47, R_MBDONE = 0x1000, R_MB = 0x1001, R_DONE = 0x1002,
-                  R_PARK = 0x1003,        // one lane per partition: through, but its slice holds what lanes still running share
-                  R_BEND = 0x1004 };      // the block in progress has ended: the lane waits for the wave's next block-end pass (tok::block_end)
+// A lane's state is the ADDRESS of its node's record (8 * node).  A lane that is not decoding -- waiting for the block-end pass,
+// at a macroblock boundary, without a frame -- holds the address of an IDLE record instead, one per reason (R_*), and RUNS THE
+// STEP LIKE EVERYBODY ELSE (round 6; until then the step was a predicated region, paid for with a compare, an exec-mask save /
+// restore and two taken branches per step): an idle record leads back to itself and asks for nothing, and a lane whose record
+// address has bit 9 set decodes with probability 256 -- split = range, the bit is 0, range, value and shift do not move
+// (bool_decoder.hh:82-107 with split == range) -- so the step leaves an idle lane exactly as it found it, but for the stream
+// byte it may still shift into its window (which is what the next real step would have done first).
+enum : uint32_t { kNodes = 47, kIdleRecs = 5,
+                  R_MBDONE = kIdleTabOff, R_MB = kIdleTabOff + 8, R_DONE = kIdleTabOff + 16,
+                  R_PARK = kIdleTabOff + 24,      // one lane per partition: through, but its slice holds what lanes still running share
+                  R_BEND = kIdleTabOff + 32 };    // the block in progress has ended: the lane waits for the wave's next block-end pass (tok::block_end)
+static_assert( kIdleTabOff >= 512 && R_BEND + 8 <= kTablesBytes && kNodes * 8 <= kBandTabOff, "node addresses below 512, idle records from 512 on" );
 // half of a node record = what a decoded 0 / 1 at that node means:
-//   [0,9) address of the next node's record   [9,14) index of the next node's probability   [14] ... in the current row (else in kXtab)
-//   [15] shift the bit into the magnitude   [16] on to the next coefficient position   [17] emit the coefficient   [18] end of block
-//   [19,24) 11 * context the token leaves behind   [24,31) magnitude to add at emission
-constexpr uint32_t H_ROWREL = 1u << 14, H_XS = 1u << 15, H_ADV = 1u << 16, H_EMIT = 1u << 17, H_EOB = 1u << 18;
-constexpr uint32_t half( uint32_t next, uint32_t pk, uint32_t flags, uint32_t ctx = 0, uint32_t addv = 0 )
+//   [0,10) address of the next node's record (an EOB leads straight to R_BEND)   [10,15) index of the next node's probability
+//   [15] shift the bit into the magnitude   [16] on to the next coefficient position   [17] emit the coefficient
+//   [19,24) 11 * context the token leaves behind   [24,31) magnitude to add at emission   [31] ... probability in the current row (else in kXtab)
+constexpr uint32_t H_ROWREL = 1u << 31, H_XS = 1u << 15, H_ADV = 1u << 16, H_EMIT = 1u << 17;
+constexpr uint32_t kZeroX = 27;           // kXtab[27] = 0: what a record that reads no probability points at
+constexpr uint32_t half_at( uint32_t next_addr, uint32_t pk, uint32_t flags, uint32_t ctx = 0, uint32_t addv = 0 )
 {
-  return ( next * 8 ) | ( pk << 9 ) | flags | ( ( ctx * 11 ) << 19 ) | ( addv << 24 );
+  return next_addr | ( pk << 10 ) | flags | ( ( ctx * 11 ) << 19 ) | ( addv << 24 );
 }
+constexpr uint32_t half( uint32_t next, uint32_t pk, uint32_t flags, uint32_t ctx = 0, uint32_t addv = 0 ) { return half_at( next * 8, pk, flags, ctx, addv ); }
 constexpr uint32_t tree( uint32_t k ) { return half( k, k, H_ROWREL ); }                       // on to tree node k
 constexpr uint32_t sign_node( uint32_t addv )   // DCT_1..4 -> 37..40, dct_cat1..6 (bases 5,7,11,19,35,67) -> 41..46
 {
@@ -258,7 +273,7 @@ struct NodeTable { V8 n[kNodes]; };
 constexpr NodeTable make_nodes()
 {
   NodeTable t {};
-  t.n[0] = { half( 0, 0, H_EOB ), tree( 1 ) };
+  t.n[0] = { half_at( R_BEND, kZeroX, 0 ), tree( 1 ) };     // EOB: the block has ended
   t.n[1] = { half( 1, 1, H_ROWREL | H_ADV ), tree( 2 ) };   // a ZERO token: node 1 of the next position (no EOB check), context 0
   t.n[2] = { to_sign( 1 ), tree( 3 ) };
   t.n[3] = { tree( 4 ), tree( 6 ) };
@@ -283,7 +298,8 @@ constexpr NodeTable make_nodes()
   return t;
 }
 constexpr NodeTable kNodeTable = make_nodes();
-static_assert( sizeof( NodeTable ) <= kBlockTabOff, "node records must stay below the block table" );
+// idle record k (address kIdleTabOff + 8 k): both halves lead back to it, read no probability, ask for nothing
+constexpr uint32_t idle_half( uint32_t k ) { return half_at( kIdleTabOff + 8 * k, kZeroX, 0 ); }
 
 // ---- blocks ---------------------------------------------------------------------------------------------------------
 // parse order within a macroblock (macroblock.cc:480-500): 0 = Y2, 1..16 = Y, 17..20 = U, 21..24 = V.  Per block: where its
@@ -306,7 +322,8 @@ constexpr BlockTable make_blocks()
   return t;
 }
 constexpr BlockTable kBlockTable = make_blocks();
-static_assert( kBlockTabOff + sizeof( BlockTable ) <= kXtab && kXtab + 28 <= kTablesBytes, "tables overlap" );
+static_assert( kBandTabOff % 32 == 0 && kBandTabOff + 18 <= kXtab && kXtab + 28 <= kBlockTabOff && kBlockTabOff % 8 == 0 && kBlockTabOff + sizeof( BlockTable ) <= kIdleTabOff
+               && kTablesBytes % 128 == 0, "tables overlap" );
 
 constexpr uint64_t nib( std::initializer_list<unsigned> v ) { uint64_t r = 0; unsigned i = 0; for ( unsigned x : v ) r |= static_cast<uint64_t>( x ) << ( 4 * i++ ); return r; }
 constexpr uint64_t kZigzagNib = nib( { 0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15 } );
@@ -418,6 +435,7 @@ AA_HD inline Chunk16 mask_past_end( Chunk16 c, uint32_t at, uint32_t end )
 // All LDS addresses in a Lane are offsets into the workgroup's smem (the lane's slice starts at `base`).
 struct Lane {
   uint32_t base;                  // offset of this lane's slice
+  uint32_t sbase;                 // ... of its stream ring (128-byte aligned)
   // boolean decoder of the current partition: 32-bit window; sh = 16 - (valid bits below the 8 being compared)
   uint32_t value, range;
   int32_t sh;
@@ -427,10 +445,11 @@ struct Lane {
   uint32_t pend_wpos, pend_mwpos; // what the chunks in flight are for (kNoPend: nothing in flight)
   Chunk16 pend[kChunks], mpend[kMetaChunks];
   // token in progress
-  uint32_t rec;                   // address of the record of the node about to be decoded (>= R_MBDONE: not decoding)
+  uint32_t rec;                   // address of the record of the node about to be decoded (>= R_MBDONE: an idle record -- not decoding)
   uint32_t paddr;                 // address of its probability
   uint32_t rowaddr, typeaddr;     // addresses of the current probability row / of this block type's probabilities
-  uint32_t idx, mag, nonzero;
+  uint32_t ia;                    // kBandTabOff + coefficient position (a multiple of 32 + position: shifts and `& 16` see the position)
+  uint32_t mag, nonzero;
   // block in progress
   uint32_t blkaddr;               // address of the BlockTable entry of the block AFTER the current one
   uint32_t nzsel, blkbit;
@@ -496,7 +515,7 @@ AA_HD inline void prime_stream( Lane & L, uint8_t * smem, const Frame & J )
     const uint32_t at = base + 16 * k;
     Chunk16 c; c.w[0] = c.w[1] = c.w[2] = c.w[3] = 0;
     if ( at < J.data_padded ) c = load16( J.data + at );
-    lds_store16( smem, L.base + kStream + ( at & ( kRing - 1 ) ), mask_past_end( c, at, L.rend ) );
+    lds_store16( smem, L.sbase + ( at & ( kRing - 1 ) ), mask_past_end( c, at, L.rend ) );
   }
   L.wpos = base + kRing;
   L.pend_wpos = kNoPend;
@@ -510,7 +529,7 @@ AA_HD inline void start_partition( Lane & L, uint8_t * smem, const Frame & J, ui
   L.rend = J.job->fp.part_off[p] + J.job->fp.part_size[p];
   prime_stream( L, smem, J );
   uint32_t v = 0;
-  for ( int k = 0; k < 4; k++ ) { v = ( v << 8 ) | smem[L.base + kStream + ( L.rpos & ( kRing - 1 ) )]; L.rpos++; }
+  for ( int k = 0; k < 4; k++ ) { v = ( v << 8 ) | smem[L.sbase + ( L.rpos & ( kRing - 1 ) )]; L.rpos++; }
   L.value = v; L.sh = -8; L.range = 255;
 }
 
@@ -535,7 +554,7 @@ AA_HD inline void top_up( Lane & L, uint8_t * smem, const Frame & J )
   if ( L.rec == R_DONE || ( MP && L.rec == R_PARK ) ) return;
   if ( L.pend_wpos == L.wpos ) {
     for ( uint32_t k = 0; k < kChunks; k++ )
-      lds_store16( smem, L.base + kStream + ( ( L.wpos + 16 * k ) & ( kRing - 1 ) ), mask_past_end( L.pend[k], L.wpos + 16 * k, L.rend ) );
+      lds_store16( smem, L.sbase + ( ( L.wpos + 16 * k ) & ( kRing - 1 ) ), mask_past_end( L.pend[k], L.wpos + 16 * k, L.rend ) );
     L.wpos += 16 * kChunks;
   }
   if ( L.pend_mwpos == L.mwpos ) {
@@ -575,6 +594,8 @@ AA_HD inline void top_up( Lane & L, uint8_t * smem, const Frame & J )
 #define AA_POPC( v ) static_cast<uint32_t>( __builtin_popcount( v ) )
 #define AA_UBFE( v, off, width ) __builtin_amdgcn_ubfe( ( v ), ( off ), ( width ) )
 #define AA_BFI( m, a, b ) ( ( ( m ) & ( a ) ) | ( ~( m ) & ( b ) ) )       /* v_bfi_b32 */
+#define AA_SBFE( v, off, width ) __builtin_amdgcn_sbfe( static_cast<int>( v ), ( off ), ( width ) )      /* sign-extended field: a 1-bit field gives 0 / -1 */
+#define AA_CLZ( v ) __builtin_clz( v )                                      /* v_ffbh_u32: 32 for 0 on the GPU (idle lanes' garbage) */
 // The workgroup's dynamic LDS starts at LDS address 0 (the kernel has no static LDS), so an offset into smem IS the LDS
 // address: form the pointer from the number and spare the hot loop one "add the base symbol" per access.
 template <class T> __device__ inline __attribute__( ( address_space( 3 ) ) ) T * lds_at( uint8_t *, uint32_t off )
@@ -589,6 +610,8 @@ template <class T> __device__ inline __attribute__( ( address_space( 3 ) ) ) T *
 #define AA_POPC( v ) static_cast<uint32_t>( __builtin_popcount( v ) )
 #define AA_UBFE( v, off, width ) ( ( ( v ) >> ( off ) ) & ( ( 1u << ( width ) ) - 1u ) )
 #define AA_BFI( m, a, b ) ( ( ( m ) & ( a ) ) | ( ~( m ) & ( b ) ) )
+#define AA_SBFE( v, off, width ) ( static_cast<int32_t>( static_cast<uint32_t>( v ) << ( 32 - ( off ) - ( width ) ) ) >> ( 32 - ( width ) ) )
+#define AA_CLZ( v ) ( ( v ) ? __builtin_clz( v ) : 32 )
 template <class T> inline T * lds_at( uint8_t * smem, uint32_t off ) { return reinterpret_cast<T *>( smem + off ); }
 #endif
 
@@ -609,6 +632,19 @@ AA_HD inline void store_mb_packed( const Frame & J, uint32_t mi, uint32_t nz_mas
   J.packed_pos[mi] = pos;
 }
 
+// p + n words, n = 0 / 1, for a pointer into a coefficient chunk.  On the GPU a 32-bit add: a chunk is 64 KB and 64-KB aligned (the
+// runtime checks the heap's base), so the low half of the address never carries into the high half -- a 64-bit add is two
+// instructions on a path where every instruction is four cycles of every bool.
+AA_HD inline AA_GLOBAL int16_t * bump_words( AA_GLOBAL int16_t * p, uint32_t n )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+  const unsigned long long a = reinterpret_cast<unsigned long long>( p );
+  return reinterpret_cast<AA_GLOBAL int16_t *>( ( a & 0xFFFFFFFF00000000ull ) | static_cast<uint32_t>( static_cast<uint32_t>( a ) + 2u * n ) );
+#else
+  return p + n;
+#endif
+}
+
 // Make block `blk` of the macroblock the current one: contexts from the non-zero flags, first probability row.
 AA_HD inline void setup_block( Lane & L, const uint8_t * smem, uint32_t blk )
 {
@@ -619,8 +655,9 @@ AA_HD inline void setup_block( Lane & L, const uint8_t * smem, uint32_t blk )
   L.blkbit = 1u << ( e.x >> 24 );
   const uint32_t ctx = AA_POPC( L.ctxbits & e.y );          // "above" flag + "left" flag
   L.typeaddr = L.base + 8u * ( sel & ( kBlkIsY - 1u ) );
-  L.idx = ( sel & kBlkIsY ) ? L.yfirst : 0u;                // Y blocks after a Y2 start at position 1 (tokens.cc:61)
-  L.rowaddr = L.typeaddr + L.idx * 33u + ctx * 11u;         // band of position 0 / 1 is 0 / 1
+  const uint32_t idx = ( sel & kBlkIsY ) ? L.yfirst : 0u;   // Y blocks after a Y2 start at position 1 (tokens.cc:61)
+  L.ia = kBandTabOff + idx;
+  L.rowaddr = L.typeaddr + idx * 33u + ctx * 11u;           // band of position 0 / 1 is 0 / 1
   L.rec = 0; L.paddr = L.rowaddr;
   L.nonzero = 0; L.mag = 0;
 }
@@ -838,63 +875,65 @@ template <bool PK, bool MP = false>
 AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
 {
   (void) J;
-  if ( L.rec < R_MBDONE ) {
-    // the LDS reads of a step; all addresses were known at the end of the previous one
-    const uint32_t prob = *lds_at<const uint8_t>( smem, L.paddr );
-    const uint32_t raw = *lds_at<const uint8_t>( smem, L.base + kStream + ( L.rpos & ( kRing - 1 ) ) );
-    const V8 rec = *lds_at<const V8>( smem, L.rec );
+  // EVERY lane runs the step (idle lanes: see "nodes" above); no condition, no branch -- the one predicated instruction is the
+  // coefficient store.  The LDS reads of a step; all addresses were known at the end of the previous one
+  const uint32_t pbyte = *lds_at<const uint8_t>( smem, L.paddr );
+  const uint32_t raw = *lds_at<const uint8_t>( smem, L.sbase | ( L.rpos & ( kRing - 1 ) ) );
+  const V8 rec = *lds_at<const V8>( smem, L.rec );
+  const uint32_t nband = *lds_at<const uint8_t>( smem, L.ia + 1u );       // 33 * band of the NEXT position (the only one the row can move to)
 
-    // top the window up by one byte whenever one fits (sh >= 0): a decode shifts out at most 7 bits, so the 8 bits being
-    // compared are always real and the refill is never on the critical path.  Mask arithmetic, no condition.
-    const uint32_t room = ~static_cast<uint32_t>( L.sh >> 31 );
-    L.value |= ( raw << ( L.sh & 31 ) ) & room;
-    L.sh -= static_cast<int32_t>( 8u & room );
-    L.rpos -= room;
+  // ... and while they travel: the renormalisation the previous step left undone (bool_decoder.hh:94-105; a lane's decoder is
+  // normalised everywhere but between two steps -- the shift of an already normalised range is 0)
+  const int shift = AA_CLZ( L.range ) - 24;
+  L.range <<= ( shift & 31 );
+  L.value <<= ( shift & 31 );
+  L.sh += shift;
+  // top the window up by one byte whenever one fits (sh >= 0): a decode shifts out at most 7 bits, so the 8 bits being
+  // compared are always real and the refill is never on the critical path.  Mask arithmetic, no condition.
+  const uint32_t room = ~static_cast<uint32_t>( L.sh >> 31 );
+  L.value |= ( raw << ( L.sh & 31 ) ) & room;
+  L.sh -= static_cast<int32_t>( 8u & room );
+  L.rpos -= room;
+  const uint32_t tn = L.typeaddr + nband;       // (the row of the next position, but for the context the token leaves)
 
-    // BoolDecoder::get (bool_decoder.hh:67-107)
-    const uint32_t split = ( AA_MUL24( L.range - 1, prob ) + 256u ) >> 8;   // = 1 + (((range - 1) * prob) >> 8)
-    const uint32_t bigsplit = split << 24;
-    const bool bit = L.value >= bigsplit;
-    const uint32_t range = bit ? L.range - split : split;
-    const uint32_t value = bit ? L.value - bigsplit : L.value;
-    const int shift = __builtin_clz( range ) - 24;
-    L.range = range << shift;
-    L.value = value << shift;
-    L.sh += shift;
+  // an idle lane (record address >= 512) decodes with probability 256: split = range, nothing of its decoder moves
+  const uint32_t prob = L.rec >= 512u ? 256u : pbyte;
+  // BoolDecoder::get (bool_decoder.hh:67-107)
+  const uint32_t split = ( AA_MUL24( L.range - 1, prob ) + 256u ) >> 8;   // = 1 + (((range - 1) * prob) >> 8)
+  const uint32_t bigsplit = split << 24;
+  const bool bit = L.value >= bigsplit;
+  L.range = bit ? L.range - split : split;
+  L.value = bit ? L.value - bigsplit : L.value;
 
-    // what the node says this bit means
-    const uint32_t h = bit ? rec.y : rec.x;
-    const uint32_t xs = AA_UBFE( h, 15, 1 );
-    const uint32_t mag = ( L.mag << xs ) | ( ( bit ? 1u : 0u ) & xs );    // extra bits shift in; everything else leaves it alone
-    L.mag = mag;
-    if ( h & H_EMIT ) {                           // the sign: the token is complete (tokens.cc:126-133)
-      const int32_t m = static_cast<int32_t>( mag + AA_UBFE( h, 24, 7 ) );
-      if constexpr ( PK ) {                       // the next value of the block, its zigzag position into the mask
-        *L.blk = static_cast<int16_t>( bit ? -m : m );
-        L.blk += 1;
-        L.zzmask |= 1u << L.idx;
-        L.mag = 0;
-      } else {
-        const uint32_t zz = static_cast<uint32_t>( kZigzagNib >> ( L.idx * 4 ) ) & 15u;
-        L.blk[zz] = static_cast<int16_t>( bit ? -m : m );
-        L.mag = 0; L.nonzero = 1;
-      }
-    }
-    const uint32_t adv = AA_UBFE( h, 16, 1 );     // on to the next coefficient position?
-    const uint32_t idx = L.idx + adv;
-    const uint32_t band = static_cast<uint32_t>( kBandNib >> ( ( idx * 4 ) & 63 ) ) & 15u;
-    // (a select by mask arithmetic: written as a conditional the compiler makes it a predicated region -- a compare, two scalar
-    // instructions on the exec mask and the round trip between the vector and the scalar unit that goes with them; measured on
-    // MI355X: 4 % of a wave step.  Two other formulations measured and dropped: the stream byte asked for a step ahead (no change),
-    // and probability + node record + stream byte all asked for in the MIDDLE of the previous step, so that the renormalisation and
-    // the coefficient store run while they travel (0.247 against 0.236 us per wave step: the extra live registers and moves cost more
-    // than the LDS round trip they hide -- the step is bound by its ~70 dependent vector instructions, not by LDS latency).)
-    const uint32_t rowaddr = AA_BFI( 0u - adv, L.typeaddr + band * 33u + AA_UBFE( h, 19, 5 ), L.rowaddr );
-    const uint32_t paddr = ( ( h & H_ROWREL ) ? rowaddr : kXtab ) + AA_UBFE( h, 9, 5 );
-    const bool bend = ( ( h & H_EOB ) | ( idx & 16u ) ) != 0;            // an EOB token, or position 16 reached
-    L.idx = idx; L.rowaddr = rowaddr; L.paddr = paddr;
-    L.rec = bend ? static_cast<uint32_t>( R_BEND ) : h & 511u;
+  // what the node says this bit means
+  const uint32_t h = bit ? rec.y : rec.x;
+  // where the lane goes next -- first: the next step's LDS reads wait for these addresses.  Position 16 ends the block like an EOB
+  // (whose record half leads to R_BEND by itself)
+  const uint32_t adv = AA_UBFE( h, 16, 1 );     // on to the next coefficient position?
+  const uint32_t ia = L.ia + adv;
+  // (a select by mask arithmetic: written as a conditional the compiler makes it a predicated region -- measured on MI355X, round 5:
+  // 4 % of a wave step)
+  const uint32_t rowaddr = AA_BFI( 0u - adv, tn + AA_UBFE( h, 19, 5 ), L.rowaddr );
+  const uint32_t paddr = ( static_cast<int32_t>( h ) < 0 ? rowaddr : kXtab ) + AA_UBFE( h, 10, 5 );
+  const uint32_t nextrec = ( ia & 16u ) ? static_cast<uint32_t>( R_BEND ) : ( h & 1023u );
+  L.rowaddr = rowaddr; L.paddr = paddr; L.rec = nextrec;
+
+  const uint32_t xs = AA_UBFE( h, 15, 1 );
+  const uint32_t mag = ( L.mag << xs ) | ( ( bit ? 1u : 0u ) & xs );    // extra bits shift in; everything else leaves it alone
+  const uint32_t emit = AA_UBFE( h, 17, 1 );    // the sign: the token is complete (tokens.cc:126-133)
+  const int32_t m = static_cast<int32_t>( mag + AA_UBFE( h, 24, 7 ) );
+  const int16_t coeff = static_cast<int16_t>( bit ? -m : m );
+  if constexpr ( PK ) {                         // the next value of the block, its zigzag position into the mask
+    if ( emit ) *L.blk = coeff;
+    L.blk = bump_words( L.blk, emit );
+    L.zzmask |= emit << ( L.ia & 31u );
+  } else {
+    const uint32_t zz = static_cast<uint32_t>( kZigzagNib >> ( ( L.ia & 15u ) * 4 ) ) & 15u;
+    if ( emit ) L.blk[zz] = coeff;
+    L.nonzero |= emit;
   }
+  L.mag = emit ? 0u : mag;
+  L.ia = ia;
 }
 
 // ---- the end of a block, for the lanes that wait for it (R_BEND): the block's flags and mask word, the macroblock's record
@@ -923,8 +962,9 @@ AA_HD inline void block_end( Lane & L, uint8_t * smem, const Frame & J )
     const uint32_t sel = AA_UBFE( nextblk.x, 16, 8 );
     const uint32_t nctx = AA_POPC( ctxbits & nextblk.y );
     L.typeaddr = L.base + 8u * ( sel & ( kBlkIsY - 1u ) );
-    L.idx = ( sel >> 7 ) & L.yfirst;
-    L.rowaddr = L.paddr = L.typeaddr + L.idx * 33u + nctx * 11u;
+    const uint32_t idx = ( sel >> 7 ) & L.yfirst;
+    L.ia = kBandTabOff + idx;
+    L.rowaddr = L.paddr = L.typeaddr + idx * 33u + nctx * 11u;
     L.ctxbits = ctxbits;
     L.blkaddr += 8;
     L.nzsel = nextblk.y;
@@ -969,12 +1009,29 @@ AA_HD inline uint32_t table_word( uint32_t k )
   const uint32_t * b = reinterpret_cast<const uint32_t *>( &kBlockTable );
   if ( k < sizeof( NodeTable ) / 4 ) return n[k];
   if ( k >= kBlockTabOff / 4 && k < ( kBlockTabOff + sizeof( BlockTable ) ) / 4 ) return b[k - kBlockTabOff / 4];
+  if ( k >= kIdleTabOff / 4 && k < kIdleTabOff / 4 + 2 * kIdleRecs ) return idle_half( ( k - kIdleTabOff / 4 ) / 2 );
+  if ( k >= kBandTabOff / 4 && k < kBandTabOff / 4 + 5 ) {          // 33 * band of positions 0 .. 17 (16, 17: never read as a row)
+    uint32_t w = 0;
+    for ( uint32_t i = 0; i < 4; i++ ) { const uint32_t at = 4 * ( k - kBandTabOff / 4 ) + i; w |= ( at < 16 ? 33u * ( static_cast<uint32_t>( kBandNib >> ( 4 * at ) ) & 15u ) : 0u ) << ( 8 * i ); }
+    return w;
+  }
   if ( k >= kXtab / 4 && k < kXtab / 4 + 7 ) {
     uint32_t w = 0;
     for ( uint32_t i = 0; i < 4; i++ ) { const uint32_t at = 4 * ( k - kXtab / 4 ) + i; w |= ( at < 27 ? static_cast<uint32_t>( kXtabInit[at] ) : 0u ) << ( 8 * i ); }
     return w;
   }
   return 0;
+}
+
+// A lane before its first frame: idle (R_DONE), every address the step reads in range -- the step runs for idle lanes too
+AA_HD inline void init_lane( Lane & L, uint32_t sbase, uint32_t base )
+{
+  L.sbase = sbase; L.base = base;
+  L.rec = R_DONE; L.paddr = kXtab + kZeroX; L.ia = kBandTabOff; L.rowaddr = L.typeaddr = base;
+  L.value = 0; L.range = 255; L.sh = 0; L.rpos = 0; L.mag = 0; L.zzmask = 0; L.nonzero = 0;
+  L.blk = nullptr; L.hdr = nullptr;
+  L.pend_wpos = L.pend_mwpos = kNoPend;
+  L.steps = 0;
 }
 
 // SH: the layout of the above-row flags (tok::kAbove) -- that of the kernel the lane runs in: shared by the lanes of a frame
@@ -993,8 +1050,9 @@ AA_HD inline void begin_frame( Lane & L, uint8_t * smem, uint32_t base, const Fr
   for ( uint32_t k = 0; k < above_bytes( J.mbw, SH ); k++ ) lds[kAbove + k] = 0;
   L.mi = 0; L.col = 0; L.row = 0; L.ctxbits = 0; L.coeff_blocks = 0; L.steps = 0;
   L.flags = L.nz_mask = L.mb_first = L.yfirst = 0;
-  L.idx = L.nonzero = L.nzsel = L.blkbit = L.mag = 0;
-  L.typeaddr = L.rowaddr = L.paddr = base;
+  L.nonzero = L.nzsel = L.blkbit = L.mag = 0;
+  L.ia = kBandTabOff;
+  L.typeaddr = L.rowaddr = base; L.paddr = kXtab + kZeroX;
   L.blkaddr = kBlockTabOff;
   L.blk = nullptr; L.blk_index = 0; L.blk_left = 0; L.nchunks = 0; L.mem_since = 0;     // the first coded macroblock takes the first chunk
   L.hdr = nullptr; L.zzmask = 0; L.words = 0;

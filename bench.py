@@ -79,9 +79,9 @@ def parse_args():
     ap.add_argument("--config", default="1080p_inter_lf")
     ap.add_argument("--streams", type=int, default=480, help="independent streams per GPU")
     ap.add_argument("--frames", type=int, default=12, help="frames per stream per step")
-    ap.add_argument("--key-ahead", type=int, default=12, help="steps by which KEY frames are handed to the GPU parser ahead of reconstruction (bounded by what the HBM budget holds)")
+    ap.add_argument("--key-ahead", type=int, default=16, help="steps by which KEY frames are handed to the GPU parser ahead of reconstruction (bounded by what the HBM budget holds)")
     ap.add_argument("--depth", type=int, default=8, help="steps by which inter frames are handed to the GPU parser ahead of reconstruction (bounded likewise)")
-    ap.add_argument("--hbm-gb", type=float, default=150.0, help="HBM the decoder context may use on each GPU (aa_ctx_set_memory_limit); the look-ahead is planned inside it")
+    ap.add_argument("--hbm-gb", type=float, default=240.0, help="HBM the decoder context may use on each GPU (aa_ctx_set_memory_limit); the look-ahead is planned inside it")
     ap.add_argument("--header-ahead", type=int, default=0, help="steps by which the macroblock-header pass of inter frames runs ahead of their token pass (two-phase submit)")
     ap.add_argument("--threads", type=int, default=0, help="host workers of the header pre-pass (0: cores / local ranks)")
     ap.add_argument("--schedule", default="rows", choices=["rows", "diagonal"])
@@ -908,7 +908,10 @@ def main():
             # few streams are parsed by host workers (aa_submit_frames routes them): no chains of seconds to hide, so no deep
             # look-ahead either -- one group ahead keeps the GPU's reconstruction and the host's parse overlapped
             host_routed = n <= min(threads, 24)
-            p = Pipeline(env, streams[:n], 2 if host_routed else pipe_K, 2 if host_routed else pipe_D, 0 if host_routed else args.header_ahead)
+            # (round 6: such calls are parsed frame-parallel by the context's host lanes and return at once -- a deeper look-ahead
+            # keeps all the host's cores busy: AA_BENCH_SMALL_DEPTH groups ahead)
+            small_depth = int(os.environ.get("AA_BENCH_SMALL_DEPTH", "3"))
+            p = Pipeline(env, streams[:n], small_depth if host_routed else pipe_K, small_depth if host_routed else pipe_D, 0 if host_routed else args.header_ahead)
             p.run(3); ctx.sync()
             reps = max(6, p.K)
             t0 = time.perf_counter()
@@ -922,7 +925,7 @@ def main():
             ctx.sync()
             dt_host = time.perf_counter() - t0
             small[str(n)] = {"mb_per_s": round(n * F * mbs_per_frame / dt, 1), "ms_per_step": round(dt * 1e3, 2),
-                             "route": "host workers, one per stream (aa_submit_frames, few streams)" if host_routed else "GPU token lanes"}
+                             "route": "host lanes, frame-parallel (aa_submit_frames, few streams: header pre-pass in the call, every frame body on a worker thread)" if host_routed else "GPU token lanes"}
             # the figure above is empty pipeline -> empty pipeline over `reps` steps (it pays for the first key-frame chain); between
             # fill and drain: the mean interval of the hand-overs after the first one of the timed run
             done = p.done_t[-reps:]

@@ -106,8 +106,9 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
     aa::tok::Lane L;
     std::memset( &L, 0xA5, sizeof L );
     aa::tok::Frame F = aa::tok::frame_of( &J );
-    L.rec = aa::tok::R_DONE; L.pend_wpos = L.pend_mwpos = aa::tok::kNoPend;
-    aa::tok::begin_frame( L, smem, aa::tok::kTablesBytes, F );
+    const uint32_t lane_bytes = aa::tok::lane_lds_bytes( J.fp.mbw, J.fp.nparts > 1 );
+    aa::tok::init_lane( L, aa::tok::ring_addr( 0 ), aa::tok::slice_addr( 0, 1, lane_bytes ) );
+    aa::tok::begin_frame( L, smem, L.base, F );
     for ( ;; ) {
       aa::tok::top_up( L, smem, F );
       if ( L.rec == aa::tok::R_DONE ) break;

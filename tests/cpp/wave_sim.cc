@@ -142,7 +142,7 @@ void wave_period( std::vector<aa::tok::Lane> & L, std::vector<aa::tok::Frame> & 
     }
     for ( ;; ) {
       for ( uint32_t g = 0; g < kBendEvery; g++ )
-        for ( size_t k = 0; k < n; k++ ) if ( job_of[k] >= 0 ) step<PK, MP>( L[k], smem, F[k] );
+        for ( size_t k = 0; k < n; k++ ) step<PK, MP>( L[k], smem, F[k] );       // (every lane, with or without a frame: the step has no condition)
       it += kBendEvery;
       if ( any( []( const Lane & l ) { return l.rec == R_BEND; } ) ) {
         for ( size_t k = 0; k < n; k++ ) if ( job_of[k] >= 0 ) block_end<PK, MP>( L[k], smem, F[k] );
@@ -227,8 +227,7 @@ int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_
   std::vector<int> job_of( lanes, -1 );
   for ( int k = 0; k < lanes; k++ ) {
     std::memset( static_cast<void *>( &L[k] ), 0xA5, sizeof( Lane ) );
-    L[k].rec = R_DONE; L[k].pend_wpos = L[k].pend_mwpos = kNoPend; L[k].steps = 0;
-    L[k].base = kTablesBytes + static_cast<uint32_t>( k ) * lane_bytes;
+    init_lane( L[k], ring_addr( static_cast<uint32_t>( k ) ), slice_addr( static_cast<uint32_t>( k ), static_cast<uint32_t>( lanes ), lane_bytes ) );
   }
   std::deque<int> queue, held;
   size_t published = 0;

@@ -317,26 +317,57 @@ def test_coefficient_heap_runs_out_and_frames_are_run_again(vmm, packed, monkeyp
 
 
 def test_small_calls_are_routed_to_host_workers_and_give_the_same_records(gpu_ctx, monkeypatch):
-    """aa_submit_frames with few streams: every stream's frames are parsed by one host worker (Parser::parse) instead of a GPU
-    lane each -- same records, same rasters, counted in host_routed_frames; AA_SUBMIT_DEVICE forces the GPU parser."""
+    """aa_submit_frames with few streams: the frames are parsed by the host's cores instead of a GPU lane each -- same records,
+    same rasters, counted in host_routed_frames; AA_SUBMIT_DEVICE forces the GPU parser.  Two host routes (round 6): a call that
+    brings several frames per stream is parsed FRAME-PARALLEL by the context's host lanes (header pre-pass in the call, every
+    frame body an independent chain on a worker thread, the call does not wait); ALFALFA_AMD_FEW_ROUTE=streams keeps round 3's
+    route (one worker per stream, Parser::parse, inside the call), which is also what one-frame-per-stream calls and streams
+    that use segmentation take."""
     monkeypatch.delenv("ALFALFA_AMD_ROUTE", raising=False)
-    names = ["qcif_q30_lf24", "cif_q60_lf40s5", "synth_175x143_s3", "w200_q40_lf63s7"]
+    monkeypatch.delenv("ALFALFA_AMD_FEW_ROUTE", raising=False)
+    names = ["qcif_q30_lf24", "cif_q60_lf40s5", "synth_175x143_s3", "w200_q40_lf63s7", "qcif_allkey_q20"]
     streams = [golden_frames(n) for n in names]
     nf = min(len(f) for _, _, f in streams)
     before = gpu_ctx.kernel_stats()["host_routed_frames"]
     auto = [aa.Decoder(gpu_ctx, w, h) for w, h, _ in streams]
+    per_stream = [aa.Decoder(gpu_ctx, w, h) for w, h, _ in streams]
+    one_by_one = [aa.Decoder(gpu_ctx, w, h) for w, h, _ in streams]
     dev = [aa.Decoder(gpu_ctx, w, h) for w, h, _ in streams]
-    gpu_ctx.submit_frames([(auto[i], streams[i][2][f]) for i in range(len(names)) for f in range(nf)], threads=4)
+    gpu_ctx.submit_frames([(auto[i], streams[i][2][f]) for i in range(len(names)) for f in range(nf)], threads=8)
+    routed = gpu_ctx.kernel_stats()["host_routed_frames"] - before
+    # (a frame that switches segmentation on leaves the host lanes for a GPU lane, and so do the frames behind it: only the
+    # synthetic stream can)
+    assert (len(names) - 1) * nf <= routed <= len(names) * nf, routed
+    before = gpu_ctx.kernel_stats()["host_routed_frames"]
+    monkeypatch.setenv("ALFALFA_AMD_FEW_ROUTE", "streams")
+    gpu_ctx.submit_frames([(per_stream[i], streams[i][2][f]) for i in range(len(names)) for f in range(nf)], threads=8)
+    monkeypatch.delenv("ALFALFA_AMD_FEW_ROUTE")
     assert gpu_ctx.kernel_stats()["host_routed_frames"] == before + len(names) * nf
-    gpu_ctx.submit_frames([(dev[i], streams[i][2][f]) for i in range(len(names)) for f in range(nf)], threads=4, route="device")
-    assert gpu_ctx.kernel_stats()["host_routed_frames"] == before + len(names) * nf
+    for f in range(nf):                                   # one frame per stream and call: the per-stream route again
+        gpu_ctx.submit_frames([(one_by_one[i], streams[i][2][f]) for i in range(len(names))], threads=8)
+    assert gpu_ctx.kernel_stats()["host_routed_frames"] == before + 2 * len(names) * nf
+    before = gpu_ctx.kernel_stats()["host_routed_frames"]
+    gpu_ctx.submit_frames([(dev[i], streams[i][2][f]) for i in range(len(names)) for f in range(nf)], threads=8, route="device")
+    assert gpu_ctx.kernel_stats()["host_routed_frames"] == before
     for i, n in enumerate(names):
         for f in range(nf):
-            assert_records_equal(auto[i].read_records(f), dev[i].read_records(f), "%s frame %d" % (n, f))
+            want = dev[i].read_records(f)
+            assert_records_equal(auto[i].read_records(f), want, "%s frame %d (host lanes)" % (n, f))
+            assert_records_equal(per_stream[i].read_records(f), want, "%s frame %d (a worker per stream)" % (n, f))
+            assert_records_equal(one_by_one[i].read_records(f), want, "%s frame %d (frame by frame)" % (n, f))
     for f in range(nf):
-        gpu_ctx.decode_batch(auto, [f] * len(names)); gpu_ctx.decode_batch(dev, [f] * len(names))
+        for ds in (auto, per_stream, one_by_one, dev):
+            gpu_ctx.decode_batch(ds, [f] * len(names))
     for i, n in enumerate(names):
-        assert sha256(auto[i].raster_bytes(nf - 1)) == sha256(dev[i].raster_bytes(nf - 1)) == GOLDEN[n]["raster_sha256"][nf - 1], n
+        assert (sha256(auto[i].raster_bytes(nf - 1)) == sha256(per_stream[i].raster_bytes(nf - 1)) == sha256(one_by_one[i].raster_bytes(nf - 1))
+                == sha256(dev[i].raster_bytes(nf - 1)) == GOLDEN[n]["raster_sha256"][nf - 1]), n
+    # the frame-parallel route with a look-ahead that is released early: frames still on a worker are waited for, not freed under it
+    w, h, frames = golden_frames("cif_q60_lf40s5")
+    d = aa.Decoder(gpu_ctx, w, h)
+    gpu_ctx.submit_frames([(d, fr) for fr in frames], threads=8)
+    gpu_ctx.decode_batch([d], [0])
+    d.release_before(len(frames))
+    del d
     # a bitstream error stops ITS stream only, on the host route as on the device route
     w, h, frames = golden_frames("qcif_q30")
     a, b = aa.Decoder(gpu_ctx, w, h), aa.Decoder(gpu_ctx, w, h)
