@@ -19,7 +19,8 @@ struct aa_dev_frame {
   uint8_t loop_filter_level;   // header value (0: no filtering at all)
   uint8_t sharpness;
   uint8_t has_intra;
-  uint32_t pad;
+  uint32_t packed;             // 1: packed coefficient storage (coeff_pack.hh) -- coeffs = the coefficient heap's base and a macroblock's record
+                               // holds the offset of its words (reserved << 32 | coeff_index, in 16-bit words); 0: dense 16-coefficient blocks
 };
 
 // The raster planes of one frame job.  A job's records are final when the frame is parsed, but WHICH rasters it writes and
@@ -35,17 +36,6 @@ struct aa_raster_binding {
 struct aa_gather_job {
   const uint8_t * src;
   size_t bytes;
-};
-
-// One device-parsed frame whose coefficients are stored packed (tok_fsm.hh), as it is handed to reconstruction: the expansion
-// pass writes its dense blocks and the macroblocks' coeff_index, and points the job at the dense array.
-struct aa_expand_job {
-  aa_dev_frame * job;
-  aa_mb_info * mbs;
-  const uint32_t * packed_pos;   // [nmb]
-  const uint32_t * chunk_list;   // [0] = count, then chunk numbers
-  int16_t * dense;               // num_coeff_blocks * 16 coefficients
-  uint32_t nmb, num_coeff_blocks;
 };
 
 #define AA_MAX_XCD 16
@@ -95,9 +85,6 @@ int launch_segment_fixup( const ParseJob * jobs, const aa_seg_stream * streams, 
 void token_worker_shape( uint32_t lane_bytes, int n_cus, int * lanes_out, uint32_t * lds_out, int * wgs_per_cu_out );
 int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap & heap, uint32_t * exited, const uint32_t * retire, uint32_t gen, uint32_t spread,
                           unsigned long long * prof, unsigned long long linger_ticks, int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, bool packed, uint32_t mp_hint, void * stream );
-// packed coefficients of n frames -> their dense arrays (k_dense_index + k_expand_coeffs); heap = the coefficient heap's base,
-// jobs = host memory the device can read, jobs_hbm = room for a copy of them in HBM
-int launch_expand_coeffs( const int16_t * heap, const aa_expand_job * jobs, aa_expand_job * jobs_hbm, int n, unsigned max_mbs, void * stream );
 int launch_enqueue_jobs( TokQueue * q, unsigned long long * slots, const ParseJob * jobs, const uint32_t * order, int n, void * stream );
 int launch_pool_push_range( const Heap & heap, uint32_t first, uint32_t count, void * stream );
 int launch_pool_free_lists( const Heap & heap, const uint32_t * const * lists, int n, void * stream );

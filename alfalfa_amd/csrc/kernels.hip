@@ -22,6 +22,7 @@
 
 #include "device_types.h"
 #include "vp8_math.hh"
+#include "coeff_pack.hh"
 
 namespace aa {
 namespace {
@@ -49,13 +50,37 @@ __device__ void compute_residual( const aa_mb_info & mb, const aa_dev_frame & f,
   // storage order: Y2 (bit 24) first, then bit order
   if ( lane < 25 && ( ( mask >> lane ) & 1u ) ) L.map[lane == 24 ? 0 : __popc( mask & ( ( 1u << lane ) - 1u ) ) + static_cast<int>( mask >> 24 )] = static_cast<uint8_t>( lane );
   __syncthreads();
-  const int n = __popc( mask ) * 16;
-  const int16_t * src = f.coeffs + static_cast<size_t>( mb.coeff_index ) * 16;
   const uint16_t * q = f.quant[mb.segment_id & 3];
-  for ( int k = lane; k < n; k += kLanes ) {
-    const int blk = L.map[k >> 4], e = k & 15;
-    const int base = blk < 16 ? 0 : ( blk < 24 ? 4 : 2 );          // {y_dc,y_ac,y2_dc,y2_ac,uv_dc,uv_ac}
-    L.cf[blk][e] = static_cast<int16_t>( dequant( src[k], q[base + ( e ? 1 : 0 )] ) );
+  if ( f.packed ) {
+    // packed storage (coeff_pack.hh): 25 mask slots, then the values of the stored blocks in parse order.  Masks and the offsets
+    // of the blocks' values go through LDS (L.im is free until the first IDCT pass), then every lane fetches the coefficients of
+    // its raster positions one by one
+    const int16_t * const w = f.coeffs + ( static_cast<size_t>( mb.reserved ) << 32 | mb.coeff_index );
+    uint16_t * const scr = reinterpret_cast<uint16_t *>( &L.im[0][0] );          // [0, 25) masks, [32, 57) offsets
+    if ( lane < 25 ) scr[lane] = ( ( mask >> lane ) & 1u ) ? static_cast<uint16_t>( w[lane] ) : 0u;
+    __syncthreads();
+    if ( lane < 25 ) {
+      uint32_t off = pack::kMaskSlots;
+      if ( lane != 24 ) { off += __popc( scr[24] ); for ( int b = 0; b < lane; b++ ) off += __popc( scr[b] ); }
+      scr[32 + lane] = static_cast<uint16_t>( off );
+    }
+    __syncthreads();
+    for ( int k = lane; k < 25 * 16; k += kLanes ) {
+      const int blk = k >> 4, e = k & 15;
+      const uint32_t m = scr[blk], zz = pack::zigzag_of( e );
+      if ( ( m >> zz ) & 1u ) {
+        const int base = blk < 16 ? 0 : ( blk < 24 ? 4 : 2 );          // {y_dc,y_ac,y2_dc,y2_ac,uv_dc,uv_ac}
+        L.cf[blk][e] = static_cast<int16_t>( dequant( w[scr[32 + blk] + __popc( m & ( ( 1u << zz ) - 1u ) )], q[base + ( e ? 1 : 0 )] ) );
+      }
+    }
+  } else {
+    const int n = __popc( mask ) * 16;
+    const int16_t * src = f.coeffs + static_cast<size_t>( mb.coeff_index ) * 16;
+    for ( int k = lane; k < n; k += kLanes ) {
+      const int blk = L.map[k >> 4], e = k & 15;
+      const int base = blk < 16 ? 0 : ( blk < 24 ? 4 : 2 );          // {y_dc,y_ac,y2_dc,y2_ac,uv_dc,uv_ac}
+      L.cf[blk][e] = static_cast<int16_t>( dequant( src[k], q[base + ( e ? 1 : 0 )] ) );
+    }
   }
   __syncthreads();
   if ( mb.flags & AA_MB_HAS_Y2 ) {
@@ -674,16 +699,54 @@ __device__ __forceinline__ void idct_block_regs( const uint32_t ( &d )[8], const
 // 4x4 inverse DCTs in each lane's registers -- 16 luma blocks = 16 lanes, then 8 chroma blocks -- into S.res[block][row*4+col].
 // Macroblock::apply_walsh / DCTCoefficients::{dequantize,iwht,idct_add} (macroblock.cc:504-521, quantization.cc:95-126,
 // transform.cc:47-137).  Called by the whole wave (contains barriers).
+// inclusive prefix sum over the 16 lanes of a slot (a DPP row = 16 lanes: row_shr never crosses slots; lanes shifted in read 0)
+__device__ __forceinline__ int slot_scan16( int v )
+{
+  v += __builtin_amdgcn_update_dpp( 0, v, 0x111, 0xF, 0xF, true );
+  v += __builtin_amdgcn_update_dpp( 0, v, 0x112, 0xF, 0xF, true );
+  v += __builtin_amdgcn_update_dpp( 0, v, 0x114, 0xF, 0xF, true );
+  v += __builtin_amdgcn_update_dpp( 0, v, 0x118, 0xF, 0xF, true );
+  return v;
+}
+// A stored block of PACKED coefficient storage (coeff_pack.hh) -> the 16 coefficients in raster order, two per dword (what a dense
+// block holds): mask = the block's mask word, v = its first value.  One 2-byte load per coefficient that is there -- an inter
+// frame's stored block holds 2-3 --, none for positions no macroblock of the wave has a coefficient at.  Called by whole waves.
+__device__ __forceinline__ void load_packed_block( const uint32_t mask, const int16_t * const v, uint32_t ( &d )[8] )
+{
+#pragma unroll
+  for ( int j = 0; j < 16; j++ ) {
+    const uint32_t zz = static_cast<uint32_t>( pack::kInvZigzagNib >> ( 4 * j ) ) & 15u;         // (compile-time)
+    const bool there = ( mask >> zz ) & 1u;
+    if ( !__any( there ) ) continue;
+    uint32_t c = 0;
+    if ( there ) c = static_cast<uint16_t>( v[__popc( mask & ( ( 1u << zz ) - 1u ) )] );
+    d[j >> 1] |= c << ( 16 * ( j & 1 ) );
+  }
+}
+
+// `off_hi`: the record's `reserved` byte -- packed storage: bits 32-39 of the macroblock's word offset (coeff_index = bits 0-31)
 template <class Slot>
 __device__ __forceinline__ void residual_x4( Slot & S, const aa_dev_frame & f, const bool has_res, const bool has_y2, const uint32_t nz_mask,
-                                             const uint32_t coeff_index, const int segment, const int l )
+                                             const uint32_t coeff_index, const uint32_t off_hi, const int segment, const int l )
 {
   if ( __any( has_res ) ) {
-    const int16_t * const src = f.coeffs + static_cast<size_t>( coeff_index ) * 16;
+    const bool pk = f.packed != 0;            // (the same for the 16 lanes of a slot; slots of one wave may differ: k_recon_intra4)
+    const int16_t * const src = pk ? f.coeffs + ( static_cast<size_t>( off_hi ) << 32 | coeff_index ) : f.coeffs + static_cast<size_t>( coeff_index ) * 16;
     const uint16_t * const q = f.quant[segment];
     const bool y2_stored = has_y2 && ( ( nz_mask >> 24 ) & 1u );
+    // packed: where the values of the blocks start = behind the mask slots and the values of the blocks before them in parse order
+    // (Y2, then Y in raster order, then U, V)
+    uint32_t vbase = pack::kMaskSlots;
     if ( __any( y2_stored ) ) {
-      if ( y2_stored ) S.y2[l] = static_cast<int16_t>( dequant( src[l], q[l ? 3 : 2] ) );     // a stored Y2 block comes first
+      if ( y2_stored ) {
+        if ( pk ) {
+          const uint32_t m24 = static_cast<uint16_t>( src[24] );
+          const uint32_t zz = pack::zigzag_of( static_cast<uint32_t>( l ) );
+          const int c = ( ( m24 >> zz ) & 1u ) ? src[pack::kMaskSlots + __popc( m24 & ( ( 1u << zz ) - 1u ) )] : 0;
+          S.y2[l] = static_cast<int16_t>( dequant( c, q[l ? 3 : 2] ) );
+          vbase += __popc( m24 );
+        } else S.y2[l] = static_cast<int16_t>( dequant( src[l], q[l ? 3 : 2] ) );     // a stored Y2 block comes first
+      }
       __syncthreads();
       if ( y2_stored && l < 4 ) {
         const Quad v = iwht_pass1( S.y2[l], S.y2[l + 4], S.y2[l + 8], S.y2[l + 12] );
@@ -709,7 +772,12 @@ __device__ __forceinline__ void residual_x4( Slot & S, const aa_dev_frame & f, c
       if ( !__any( mine ) ) continue;
       if ( __any( stored ) ) {
         uint32_t d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        if ( stored ) {
+        // packed: this lane's mask, and -- a prefix sum over the slot's lanes -- where its values start
+        const uint32_t pmask = ( stored && pk ) ? static_cast<uint16_t>( src[blk] ) : 0u;
+        const int pcount = __popc( pmask ), pincl = slot_scan16( pcount );
+        if ( __any( stored && pk ) ) load_packed_block( pmask, src + vbase + ( pincl - pcount ), d );
+        vbase += static_cast<uint32_t>( __shfl( pincl, 15, 16 ) );           // (the chroma round: behind all the luma values)
+        if ( stored && !pk ) {
           const uint4 * p = reinterpret_cast<const uint4 *>( src + ( __popc( nz_mask & ( ( 1u << blk ) - 1u ) ) + static_cast<int>( nz_mask >> 24 ) ) * 16 );
           const uint4 a = p[0], b = p[1];
           d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
@@ -793,7 +861,7 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
     if ( on && row > 0 && seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
 
     // ---- residual: needs no neighbour, runs before the wait for the row above ----
-    residual_x4( S, f, has_res, has_y2, nz_mask, coeff_index, segment, l );
+    residual_x4( S, f, has_res, has_y2, nz_mask, coeff_index, hd.y >> 24, segment, l );
 
     // ---- wait for the row above, then stage the neighbours (sc1 loads: L1-bypassing, served by this XCD's L2) ----
     if ( row > 0 ) {
@@ -1042,7 +1110,7 @@ __device__ __forceinline__ void recon_inter4_body( const aa_dev_frame & f, const
   }
 
   // ---- residual ----
-  residual_x4( S, f, has_res, has_y2, nz_mask, coeff_index, segment, l );
+  residual_x4( S, f, has_res, has_y2, nz_mask, coeff_index, hd.y >> 24, segment, l );
 
   // ---- windows -> LDS ----
   {

@@ -264,55 +264,6 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
   }
 }
 
-// ---- packed coefficients -> dense blocks (coeff_pack.hh), for the frames of one reconstruction submission ----------------
-// coeff_index of every macroblock = blocks stored before it in the frame (the dense array holds the frame's blocks back to
-// back, as a host-parsed frame's does); one workgroup per frame walks the records 256 at a time.  Also points the frame's
-// reconstruction job at the dense array, and leaves a copy of the expansion job in HBM for k_expand_coeffs (`jobs` is host
-// memory read over the bus: once per frame here, not once per workgroup there).
-__global__ __launch_bounds__( 256 ) void k_dense_index( const aa_expand_job * jobs, aa_expand_job * jobs_hbm )
-{
-  const aa_expand_job J = jobs[blockIdx.x];
-  __shared__ uint32_t s_wave[4];
-  AA_GLOBAL aa_mb_info * mbs = (AA_GLOBAL aa_mb_info *) J.mbs;
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint32_t running = 0;
-  for ( uint32_t base = 0; base < J.nmb; base += 256 ) {
-    const uint32_t mb = base + threadIdx.x;
-    const uint32_t c = mb < J.nmb ? aa::pack::blocks_of( mbs[mb].nz_mask ) : 0u;
-    uint32_t v = c;                                        // inclusive scan over the wave
-    for ( uint32_t d = 1; d < 64; d <<= 1 ) { const uint32_t t = __shfl_up( v, d ); if ( lane >= d ) v += t; }
-    if ( lane == 63 ) s_wave[wave] = v;
-    __syncthreads();
-    uint32_t before = 0;
-    for ( uint32_t w = 0; w < wave; w++ ) before += s_wave[w];
-    const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    if ( mb < J.nmb ) mbs[mb].coeff_index = running + before + v - c;
-    running += total;
-    __syncthreads();
-  }
-  if ( threadIdx.x == 0 ) { J.job->coeffs = J.dense; jobs_hbm[blockIdx.x] = J; }
-}
-
-// 16 lanes per macroblock, lane j = raster position j of every stored block: one 32-byte row of the dense array per block and
-// group.  blockIdx.y = frame, blockIdx.x = 16 macroblocks.
-__global__ __launch_bounds__( 256 ) void k_expand_coeffs( const int16_t * heap, const aa_expand_job * jobs )
-{
-  const aa_expand_job J = jobs[blockIdx.y];
-  const uint32_t mb = blockIdx.x * 16u + ( threadIdx.x >> 4 ), j = threadIdx.x & 15u;
-  if ( mb >= J.nmb ) return;
-  const AA_GLOBAL aa_mb_info * mbs = (const AA_GLOBAL aa_mb_info *) J.mbs;
-  const uint32_t nz = mbs[mb].nz_mask, n = aa::pack::blocks_of( nz );
-  if ( !n ) return;
-  const uint32_t first = mbs[mb].coeff_index;
-  if ( first + n > J.num_coeff_blocks ) return;            // (records and summary disagree: never write past the array)
-  const AA_GLOBAL int16_t * w = (const AA_GLOBAL int16_t *) heap + aa::pack::word_offset( ( (const AA_GLOBAL uint32_t *) J.packed_pos )[mb], (const AA_GLOBAL uint32_t *) J.chunk_list );
-  AA_GLOBAL int16_t * d = (AA_GLOBAL int16_t *) J.dense + static_cast<size_t>( first ) * 16 + j;
-  for ( uint32_t b = 0; b < n; b++ ) {
-    d[16 * b] = aa::pack::value_at( w, j );
-    w += aa::pack::block_words( w );
-  }
-}
-
 // jobs[order[i]] -> the queue, in this order (longest chains first).  `order` lists live frames only: a ticket is a pointer into
 // the batch arena, and nobody waits for the lane of a rejected or released frame before the arena is recycled.
 __global__ __launch_bounds__( 64 ) void k_enqueue_jobs( aa::TokQueue * q, unsigned long long * slots, const ParseJob * jobs, const uint32_t * order, int n )
@@ -485,15 +436,6 @@ int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap &
     if ( packed ) hipLaunchKernelGGL( ( k_token_workers<true, false> ), dim3( wgs ), dim3( 64 ), lds, static_cast<hipStream_t>( stream ), a );
     else hipLaunchKernelGGL( ( k_token_workers<false, false> ), dim3( wgs ), dim3( 64 ), lds, static_cast<hipStream_t>( stream ), a );
   }
-  return static_cast<int>( hipGetLastError() );
-}
-
-int launch_expand_coeffs( const int16_t * heap, const aa_expand_job * jobs, aa_expand_job * jobs_hbm, int n, unsigned max_mbs, void * stream )
-{
-  if ( n < 1 ) return 0;
-  hipLaunchKernelGGL( k_dense_index, dim3( n ), dim3( 256 ), 0, static_cast<hipStream_t>( stream ), jobs, jobs_hbm );
-  if ( hipError_t e = hipGetLastError() ) return static_cast<int>( e );
-  hipLaunchKernelGGL( k_expand_coeffs, dim3( ( max_mbs + 15u ) / 16u, n ), dim3( 256 ), 0, static_cast<hipStream_t>( stream ), heap, static_cast<const aa_expand_job *>( jobs_hbm ) );
   return static_cast<int>( hipGetLastError() );
 }
 

@@ -196,17 +196,6 @@ struct aa_ctx {
   static constexpr int kBindBufs = 16;      // aa_decode_batch calls the host may run ahead of the compute stream
   BindBuf bind_bufs[kBindBufs];
   int next_bind_buf = 0;
-  // the expansion jobs of a reconstruction submission (packed coefficient storage), read by k_dense_index / k_expand_coeffs
-  // over the bus like the raster bindings
-  struct ExpandBuf { aa_expand_job * host = nullptr, * dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
-  ExpandBuf expand_bufs[kBindBufs];
-  int next_expand_buf = 0;
-  // The dense blocks themselves: TWO transient arrays used in turn by the calls that have packed frames.  The expansion kernels of
-  // call N run on a stream of their own (Tok::expand), not in front of the call's reconstruction kernels on the compute stream: they need nothing
-  // of call N - 1 (whose kernels the compute stream is still working through when the host issues call N), only the array -- which
-  // call N - 2 was the last to read.  `used` is recorded on the compute stream behind the launches of the call that used the
-  // array; `filled` on that stream behind its expansion kernels.  (Round 4 had the expansion on the compute stream: 12 x
-  // 2.3 ms of a step's serial chain.)
   // HOST LANES: host cores in the role of token lanes.  A frame handed to them (AA_SUBMIT_HOST on a call with many streams: the key
   // frames a pipeline needs at once -- 35 ms on a core, 2 s as a chain on a GPU lane) has had its header pre-pass like every frame
   // of the device route; a worker thread parses macroblock headers and tokens from the batch arena's pinned copy (aa::parse_frame_body),
@@ -222,9 +211,6 @@ struct aa_ctx {
     std::atomic<uint64_t> parsed_bytes { 0 }, parse_us { 0 }, backlog_bytes { 0 };
     uint64_t parse_us_mark = 0;          // parse_us at the last aa_ctx_kernel_stats reset
   } host_lanes;
-  struct DenseBuf { uint8_t * p = nullptr; size_t bytes = 0; hipEvent_t used = nullptr, filled = nullptr; bool in_use = false; };
-  DenseBuf dense_bufs[2];
-  int next_dense_buf = 0;
   // the raster list of a batched download (aa_download_batch_async), read by k_gather_rasters over the bus
   struct GatherBuf { aa_gather_job * host = nullptr, * dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
   GatherBuf gather_bufs[kBindBufs];
@@ -247,9 +233,10 @@ struct aa_ctx {
   struct Tok {
     bool ready = false;
     hipStream_t util = nullptr;          // mirror kernel, heap pushes: never behind anything long
-    hipStream_t expand = nullptr;        // k_dense_index / k_expand_coeffs of the NEXT reconstruction call (a stream of their own: they wait for events of the compute
-                                         // stream, and the host synchronises with `util` whenever it refreshes the counters -- on `util` they made every such look wait
-                                         // for the compute stream's backlog, 280 ms per step of the first round-5 runs)
+    hipStream_t host_up = nullptr;       // the HOST LANES' uploads (records, dense blocks, the job-record patch of a frame a host core parsed): a stream of their
+                                         // own since round 6 (the hardware queue the expansion kernels of rounds 4-5 had).  On the copy stream -- which is also the
+                                         // download stream, whose copies wait for compute-stream events -- a key frame's `done` word waited behind every queued
+                                         // raster download and the reconstruction backlog in front of it
     // job queue
     aa::TokQueue * q = nullptr;
     unsigned long long * slots = nullptr;
@@ -763,7 +750,7 @@ aa_status tok_grow_heap( aa_ctx * ctx, size_t want_mapped )
 aa_status probe_stream_concurrency( aa_ctx * ctx )
 {
   auto & T = ctx->tok;
-  std::vector<hipStream_t> all { ctx->compute, ctx->copy, T.util, T.expand };
+  std::vector<hipStream_t> all { ctx->compute, ctx->copy, T.util, T.host_up };
   for ( auto ps : ctx->parse_streams ) all.push_back( ps );
   for ( auto & sl : T.slot ) all.push_back( sl.st );
   const uint32_t n = static_cast<uint32_t>( all.size() );
@@ -802,7 +789,7 @@ aa_status tok_init( aa_ctx * ctx )
   HIP_TRY( hipGetDeviceProperties( &prop, ctx->device ) );
   T.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
   HIP_TRY( hipStreamCreateWithFlags( &T.util, hipStreamNonBlocking ) );
-  { int lo = 0, hi = 0; (void) hipDeviceGetStreamPriorityRange( &lo, &hi ); HIP_TRY( hipStreamCreateWithPriority( &T.expand, hipStreamNonBlocking, hi ) ); }
+  { int lo = 0, hi = 0; (void) hipDeviceGetStreamPriorityRange( &lo, &hi ); HIP_TRY( hipStreamCreateWithPriority( &T.host_up, hipStreamNonBlocking, hi ) ); }
   for ( auto & sl : T.slot ) HIP_TRY( hipStreamCreateWithPriority( &sl.st, hipStreamNonBlocking, ctx->prio_low ) );
   if ( aa_status st = probe_stream_concurrency( ctx ) ) return st;
   // the job queue
@@ -873,7 +860,7 @@ void tok_free( aa_ctx * ctx )
   if ( T.util ) { (void) hipStreamSynchronize( T.util ); }
   for ( auto & sl : T.slot ) if ( sl.st ) { (void) hipStreamSynchronize( sl.st ); (void) hipStreamDestroy( sl.st ); sl.st = nullptr; }
   if ( T.util ) { (void) hipStreamDestroy( T.util ); T.util = nullptr; }
-  if ( T.expand ) { (void) hipStreamSynchronize( T.expand ); (void) hipStreamDestroy( T.expand ); T.expand = nullptr; }
+  if ( T.host_up ) { (void) hipStreamSynchronize( T.host_up ); (void) hipStreamDestroy( T.host_up ); T.host_up = nullptr; }
   if ( T.mirror_ev ) { (void) hipEventDestroy( T.mirror_ev ); T.mirror_ev = nullptr; }
   if ( T.vmm ) {
     if ( T.heap_mapped ) (void) hipMemUnmap( T.heap, T.heap_mapped );
@@ -1430,8 +1417,6 @@ static void ctx_free( aa_ctx * ctx )
   (void) hipEventDestroy( ctx->upload_done );
   if ( ctx->last_raster_download ) (void) hipEventDestroy( ctx->last_raster_download );
   for ( auto & bb : ctx->bind_bufs ) { if ( bb.host ) (void) hipHostFree( bb.host ); if ( bb.done ) (void) hipEventDestroy( bb.done ); }
-  for ( auto & eb : ctx->expand_bufs ) { if ( eb.host ) (void) hipHostFree( eb.host ); if ( eb.done ) (void) hipEventDestroy( eb.done ); }
-  for ( auto & db : ctx->dense_bufs ) { if ( db.used ) (void) hipEventDestroy( db.used ); if ( db.filled ) (void) hipEventDestroy( db.filled ); db.p = nullptr; }   // (the arrays are pool pieces: freed with the slabs)
   for ( auto & gb : ctx->gather_bufs ) { if ( gb.host ) (void) hipHostFree( gb.host ); if ( gb.done ) (void) hipEventDestroy( gb.done ); }
   if ( ctx->ws ) (void) hipFree( ctx->ws );
   if ( ctx->boundary ) (void) hipFree( ctx->boundary );
@@ -1857,6 +1842,7 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
   fill_job( rec, job );
   job->mbs = J.mbs; job->intra_rows = J.intra_rows;
   job->coeffs = reinterpret_cast<const int16_t *>( ctx->tok.heap );     // coeff_index of a device-parsed macroblock = its first block's index in the heap
+  job->packed = ctx->tok.packed ? 1u : 0u;                              // ... packed storage: the 40-bit offset of its words (tok_fsm.hh store_mb_packed)
   rec.host_job = job;
   rec.dev_job = reinterpret_cast<const aa_dev_frame *>( b->dev + ( reinterpret_cast<uint8_t *>( job ) - b->host ) );
   rec.batch = b; rec.batch_item = item; rec.summary_pending = true;
@@ -1866,6 +1852,7 @@ aa_status submit_one( Batch * b, SubmitItem & it, int item, aa::ParseJob * jobs_
     // their own, like a host-parsed frame's: no chunk list, no packed words; and it counts as handed over from now on -- whoever
     // releases it waits for the worker's `done` word.
     it.on_host = true;
+    job->packed = 0;
     rec.packed_pos = nullptr; rec.chunk_list = nullptr;
     rec.enqueued = true;
   }
@@ -1967,6 +1954,8 @@ void host_lane_run( aa_ctx * ctx, Batch * b, int item, HostLaneScratch & S )
   const uint32_t mbw = J.fp.mbw, mbh = J.fp.mbh, nmb = mbw * mbh;
   const size_t words_per_row = ( mbw + 63 ) / 64;
   uint32_t status = aa::TOK_OK, blocks = 0, intra = 0, split = 0;
+  hipStream_t up = ctx->tok.host_up;              // (behind the arena's upload: the submit call made this stream wait for it)
+  if ( !S.ev ) status = aa::TOK_HOST_FAILED;      // (no event to wait for the uploads with: see host_lanes_main)
   const size_t mbs_bytes = align_up( size_t( nmb ) * sizeof( aa_mb_info ) ), rows_bytes = align_up( words_per_row * mbh * sizeof( unsigned long long ) );
   try { S.above.resize( size_t( mbw ) * 9 ); } catch ( const std::bad_alloc & ) { status = aa::TOK_HOST_FAILED; }
   if ( status == aa::TOK_OK && !S.fit( mbs_bytes + rows_bytes + size_t( nmb ) * 25 * 32 + 256 ) ) status = aa::TOK_HOST_FAILED;
@@ -1990,18 +1979,19 @@ void host_lane_run( aa_ctx * ctx, Batch * b, int item, HostLaneScratch & S )
     if ( dev_alloc( ctx, dense_bytes, &dense ) != AA_OK ) status = aa::TOK_HOST_FAILED;
     else {
       it.host_dense = dense; it.host_dense_bytes = dense_bytes;
-      // (the copy stream: the arena's upload -- which carries the job record as the pre-pass left it -- was queued there by the submit call)
-      e = hipMemcpyAsync( J.mbs, mbs, size_t( nmb ) * sizeof( aa_mb_info ), hipMemcpyHostToDevice, ctx->copy );
-      if ( e == hipSuccess ) e = hipMemcpyAsync( J.intra_rows, rows, words_per_row * mbh * sizeof( unsigned long long ), hipMemcpyHostToDevice, ctx->copy );
-      if ( e == hipSuccess && blocks ) e = hipMemcpyAsync( dense, coeffs, size_t( blocks ) * 32, hipMemcpyHostToDevice, ctx->copy );
+      // (the arena's upload -- which carries the job record as the pre-pass left it -- was queued on the copy stream by the submit call,
+      // which also made the host lanes' stream wait for it)
+      e = hipMemcpyAsync( J.mbs, mbs, size_t( nmb ) * sizeof( aa_mb_info ), hipMemcpyHostToDevice, up );
+      if ( e == hipSuccess ) e = hipMemcpyAsync( J.intra_rows, rows, words_per_row * mbh * sizeof( unsigned long long ), hipMemcpyHostToDevice, up );
+      if ( e == hipSuccess && blocks ) e = hipMemcpyAsync( dense, coeffs, size_t( blocks ) * 32, hipMemcpyHostToDevice, up );
       if ( e == hipSuccess ) {
         // the frame's reconstruction job record (aa_dev_frame, in the arena behind the parse jobs): its blocks are here, not in the heap
         uint8_t * job_dev = b->dev + align_up( size_t( b->n ) * sizeof( aa::ParseJob ) ) + size_t( item ) * sizeof( aa_dev_frame );
         const int16_t ** dense_ptr = reinterpret_cast<const int16_t **>( S.pin + S.pin_bytes - 16 );       // (pinned too: the last bytes of the scratch)
         *dense_ptr = reinterpret_cast<const int16_t *>( dense );
-        e = hipMemcpyAsync( job_dev + offsetof( aa_dev_frame, coeffs ), dense_ptr, sizeof *dense_ptr, hipMemcpyHostToDevice, ctx->copy );
+        e = hipMemcpyAsync( job_dev + offsetof( aa_dev_frame, coeffs ), dense_ptr, sizeof *dense_ptr, hipMemcpyHostToDevice, up );
       }
-      if ( e == hipSuccess ) e = hipEventRecord( S.ev, ctx->copy );
+      if ( e == hipSuccess ) e = hipEventRecord( S.ev, up );
       if ( e == hipSuccess ) e = hipEventSynchronize( S.ev );
       if ( e != hipSuccess ) status = aa::TOK_HOST_FAILED;
     }
@@ -2016,7 +2006,8 @@ void host_lanes_main( aa_ctx * ctx )
 {
   (void) hipSetDevice( ctx->device );
   HostLaneScratch S;
-  (void) hipEventCreateWithFlags( &S.ev, hipEventDisableTiming );
+  for ( int tries = 0; tries < 3 && !S.ev; tries++ )     // (without it the worker can only fail its frames: host_lane_run says TOK_HOST_FAILED)
+    if ( hipEventCreateWithFlags( &S.ev, hipEventDisableTiming ) != hipSuccess ) { (void) hipGetLastError(); S.ev = nullptr; usleep( 1000 ); }
   auto & H = ctx->host_lanes;
   for ( ;; ) {
     aa_ctx::HostLanes::Task t;
@@ -2352,6 +2343,8 @@ aa_status aa_submit_frames_ex( aa_ctx * ctx, const aa_frame_in * frames, int n, 
   hipEvent_t up = get_event( ctx );
   HIP_TRY( hipEventRecord( up, ctx->copy ) );
   HIP_TRY( hipStreamWaitEvent( ps, up, 0 ) );
+  { bool any_host = false; for ( int i = 0; i < n; i++ ) any_host = any_host || raw->items[i].on_host;
+    if ( any_host ) HIP_TRY( hipStreamWaitEvent( ctx->tok.host_up, up, 0 ) ); }      // (the host lanes patch job records the arena's upload carries)
   ctx->free_events.push_back( up );
   const aa::ParseJob * jobs_dev = reinterpret_cast<const aa::ParseJob *>( raw->dev );
   if ( n_order ) {
@@ -2534,15 +2527,19 @@ aa_status aa_stream_read_records( aa_stream * s, int fi, aa_mb_info * mb_out, in
         const uint32_t ord = pos[mi] >> 15, off = pos[mi] & ( aa::kChunkWords - 1u );
         if ( ord >= list[0] || running + nblk > r.hdr.num_coeff_blocks )
           return fail( AA_ERR_LOGIC, "aa_stream_read_records: a macroblock's coefficients lie outside the frame's chunks" );
-        // (a macroblock's words end inside its chunk -- the lane made sure of it; checked block by block all the same)
+        // (a macroblock's words end inside its chunk -- the lane made sure of it; checked all the same: the mask slots, then the
+        // values its masks announce)
         const int16_t * w = words[ord].data() + off, * end = words[ord].data() + aa::kChunkWords;
-        for ( uint32_t b = 0; b < nblk; b++ ) {
-          if ( w >= end || w + aa::pack::block_words( w ) > end ) return fail( AA_ERR_LOGIC, "aa_stream_read_records: packed coefficients run past their chunk" );
-          for ( uint32_t j = 0; j < 16; j++ ) coeff_out[( size_t( running ) + b ) * 16 + j] = aa::pack::value_at( w, j );
-          w += aa::pack::block_words( w );
-        }
+        if ( w + aa::pack::kMaskSlots > end ) return fail( AA_ERR_LOGIC, "aa_stream_read_records: packed coefficients run past their chunk" );
+        uint32_t values = 0;
+        for ( uint32_t b = 0; b < 25; b++ ) if ( ( mb.nz_mask >> b ) & 1u ) values += aa::pack::popc( static_cast<uint16_t>( w[b] ) );
+        if ( w + aa::pack::kMaskSlots + values > end ) return fail( AA_ERR_LOGIC, "aa_stream_read_records: packed coefficients run past their chunk" );
+        // (the record's own offset -- what the reconstruction kernels follow -- must name the same words)
+        if ( ( static_cast<unsigned long long>( mb.reserved ) << 32 | mb.coeff_index ) != static_cast<unsigned long long>( list[1 + ord] ) * aa::kChunkWords + off )
+          return fail( AA_ERR_LOGIC, "aa_stream_read_records: a macroblock's word offset disagrees with its place in the frame's chunks" );
+        aa::pack::expand_macroblock( w, mb.nz_mask, coeff_out + size_t( running ) * 16 );
       }
-      mb.coeff_index = running;
+      mb.coeff_index = running; mb.reserved = 0;
       running += nblk;
     }
     if ( running != r.hdr.num_coeff_blocks ) return fail( AA_ERR_LOGIC, "aa_stream_read_records: non-zero masks disagree with the parse summary" );
@@ -2610,48 +2607,6 @@ aa_status launch_lf_rows( aa_ctx * ctx, std::vector<std::pair<uint32_t, const aa
 } // namespace
 
 namespace {
-// k_dense_index + k_expand_coeffs for the packed frames of a reconstruction submission (on the compute stream, in front of its
-// reconstruction kernels): every frame's dense blocks into its part of `dense`, its macroblocks' coeff_index, its job's pointer.
-aa_status expand_packed( aa_ctx * ctx, aa_stream * const * streams, const int * frame_index, const std::vector<std::pair<int, size_t>> & frames, uint8_t * piece, size_t dense_off,
-                         hipStream_t on )
-{
-  uint8_t * dense = piece + dense_off;
-  aa_ctx::ExpandBuf & eb = ctx->expand_bufs[ctx->next_expand_buf];
-  ctx->next_expand_buf = ( ctx->next_expand_buf + 1 ) % aa_ctx::kBindBufs;
-  if ( eb.busy ) { HIP_TRY( hipEventSynchronize( eb.done ) ); eb.busy = false; }
-  if ( eb.cap < frames.size() ) {
-    if ( eb.host ) (void) hipHostFree( eb.host );
-    eb.host = nullptr; eb.dev = nullptr; eb.cap = 0;
-    const size_t cap = std::max<size_t>( 512, frames.size() * 2 );
-    HIP_TRY( hipHostMalloc( reinterpret_cast<void **>( &eb.host ), cap * sizeof( aa_expand_job ), hipHostMallocDefault ) );
-    HIP_TRY( hipHostGetDevicePointer( reinterpret_cast<void **>( &eb.dev ), eb.host, 0 ) );
-    eb.cap = cap;
-  }
-  if ( !eb.done ) HIP_TRY( hipEventCreateWithFlags( &eb.done, hipEventDisableTiming ) );
-  unsigned max_mbs = 0;
-  for ( size_t k = 0; k < frames.size(); k++ ) {
-    const FrameRec & r = streams[frames[k].first]->frames[frame_index[frames[k].first]];
-    aa_expand_job & e = eb.host[k];
-    e.job = const_cast<aa_dev_frame *>( r.dev_job );
-    e.mbs = r.dev_mbs;
-    e.packed_pos = r.packed_pos; e.chunk_list = r.chunk_list;
-    e.dense = reinterpret_cast<int16_t *>( dense ) + frames[k].second * 16;
-    e.nmb = r.hdr.num_macroblocks; e.num_coeff_blocks = r.hdr.num_coeff_blocks;
-    max_mbs = std::max<unsigned>( max_mbs, e.nmb );
-  }
-  const int16_t * heap = reinterpret_cast<const int16_t *>( ctx->tok.heap );
-  for ( size_t base = 0; base < frames.size(); base += 32768 ) {          // (grid.y)
-    LaunchTimer t( ctx, 6, on );
-    const int cnt = static_cast<int>( std::min<size_t>( 32768, frames.size() - base ) );
-    if ( int e = aa::launch_expand_coeffs( heap, eb.dev + base, reinterpret_cast<aa_expand_job *>( piece ) + base, cnt, max_mbs, on ) ) return hip_fail( static_cast<hipError_t>( e ), "k_expand_coeffs" );
-  }
-  HIP_TRY( hipEventRecord( eb.done, on ) );
-  eb.busy = true;
-  return AA_OK;
-}
-} // namespace
-
-namespace {
 // ALFALFA_AMD_DECODE_TIMING=1 (diagnostics, off by default): where the host's time inside aa_decode_batch goes, section by section, printed
 // to stderr when a context is destroyed.  (Round 5: the plateau's calls take 24 ms each with the counted waits at zero)
 struct DecodeTiming {
@@ -2707,39 +2662,9 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
     if ( aa_status st = resolve_summary( streams[i], streams[i]->frames[frame_index[i]] ) ) return st;
   }
   mk.lap( 3 );
-  // Packed coefficient storage: the frames of this call that were parsed on the device get their dense blocks now -- one
-  // transient piece for the call, written by k_expand_coeffs in front of the reconstruction kernels and given back behind them
-  aa_ctx::DenseBuf * dense = nullptr;
-  std::vector<std::pair<int, size_t>> packed_frames;      // (index in the call, first block in the piece)
-  size_t dense_off = 0;
-  bool decoded_before = false;     // a frame of the call has been reconstructed before (replays, the loop-filter search): its job record is re-pointed
-  {
-    size_t blocks = 0;
-    for ( int i = 0; i < n; i++ ) {
-      const FrameRec & r = streams[i]->frames[frame_index[i]];
-      if ( !r.packed_pos ) continue;
-      decoded_before = decoded_before || r.placed;
-      packed_frames.emplace_back( i, blocks );
-      blocks += ( size_t( r.hdr.num_coeff_blocks ) + 7 ) & ~size_t( 7 );        // (every frame's array 256-byte aligned)
-    }
-    if ( !packed_frames.empty() ) {
-      // [expansion jobs][dense blocks]; the pool recycles pieces by exact size, so the size is rounded to a few classes (a
-      // power of two up to 16 MiB, then an eighth of the next power of two)
-      dense_off = align_up( packed_frames.size() * sizeof( aa_expand_job ) );
-      size_t want = dense_off + std::max<size_t>( blocks, 8 ) * 32, cls = size_t( 64 ) << 10;
-      while ( cls < want ) cls <<= 1;
-      if ( cls > ( size_t( 16 ) << 20 ) ) { const size_t step = std::max<size_t>( size_t( 16 ) << 20, cls / 8 ); cls = ( want + step - 1 ) / step * step; }
-      dense = &ctx->dense_bufs[ctx->next_dense_buf];
-      ctx->next_dense_buf ^= 1;
-      if ( dense->bytes < cls ) {
-        // (the array grows: whoever still reads the old one was queued on the compute stream -- the deferred free waits for it)
-        if ( dense->p ) { dev_free( ctx, dense->p, dense->bytes, true ); dense->p = nullptr; dense->bytes = 0; dense->in_use = false; }
-        if ( aa_status st = dev_alloc( ctx, cls, &dense->p ) ) { dense->p = nullptr; return st; }
-        dense->bytes = cls;
-      }
-      if ( !dense->used ) { HIP_TRY( hipEventCreateWithFlags( &dense->used, hipEventDisableTiming ) ); HIP_TRY( hipEventCreateWithFlags( &dense->filled, hipEventDisableTiming ) ); }
-    }
-  }
+  // (packed coefficient storage: the reconstruction kernels read the packed words themselves -- kernels.hip, residual_x4 -- since
+  // round 6; rounds 3-5 expanded every frame of the call into a transient dense array here: k_dense_index + k_expand_coeffs, a
+  // quarter of the reconstruction's GPU time and 972 bytes of HBM traffic per macroblock)
   // rasters released while binding (old references, outputs nobody holds) must not be recycled before this call's kernels
   // are queued: no release epoch is closed until then
   struct BindGuard { aa_ctx * c;
@@ -2753,21 +2678,6 @@ aa_status aa_decode_batch( aa_ctx * ctx, aa_stream * const * streams, int n, con
   mk.lap( 4 );
   if ( aa_status st = bind_batch( ctx, streams, n, frame_index ) ) return st;
   mk.lap( 5 );
-  if ( !packed_frames.empty() ) {
-    // the expansion runs on a stream of its own, behind the kernels that last read the array (two calls ago) -- or, when a frame
-    // of the call is being reconstructed again, behind everything queued so far: kernels of its earlier run may still follow
-    // its job record to the array it pointed at then
-    static const bool on_compute = [] { const char * e = std::getenv( "ALFALFA_AMD_EXPAND_ON_COMPUTE" ); return e && atoi( e ) != 0; }();      // (A/B runs: round 4's placement)
-    hipStream_t es = ( ctx->tok.expand && !on_compute ) ? ctx->tok.expand : ctx->compute;
-    if ( es != ctx->compute ) {
-      if ( decoded_before ) { HIP_TRY( hipEventRecord( dense->filled, ctx->compute ) ); HIP_TRY( hipStreamWaitEvent( es, dense->filled, 0 ) ); }
-      else if ( dense->in_use ) HIP_TRY( hipStreamWaitEvent( es, dense->used, 0 ) );
-    }
-    if ( aa_status st = expand_packed( ctx, streams, frame_index, packed_frames, dense->p, dense_off, es ) ) return st;
-    if ( es != ctx->compute ) { HIP_TRY( hipEventRecord( dense->filled, es ) ); HIP_TRY( hipStreamWaitEvent( ctx->compute, dense->filled, 0 ) ); }
-  }
-  // ... and whatever the call queues on the compute stream from here on reads the array: `used` is recorded when the call is over
-  struct DenseUsed { aa_ctx * c; aa_ctx::DenseBuf * d; ~DenseUsed() { if ( d ) { (void) hipEventRecord( d->used, c->compute ); d->in_use = true; } } } dense_used { ctx, dense };
   // frames count as submitted only once every launch of the batch has been queued (a failed launch must not leave them
   // looking decoded)
   struct Advance { aa_stream * const * streams; int n; bool ok = false; ~Advance() { if ( ok ) for ( int i = 0; i < n; i++ ) streams[i]->next_submit++; } } advance { streams, n };

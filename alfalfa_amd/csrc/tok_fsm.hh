@@ -129,7 +129,8 @@ constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
 constexpr uint32_t kMbBlocks = 26;                    // what must be left in a chunk when a macroblock starts: 25 blocks + the pre-zeroed next one
 // Packed storage: a chunk is 32768 16-bit words, a macroblock takes at most 25 x (mask word + 16 values)
 constexpr uint32_t kChunkWords = kChunkBlocks * 16u;
-constexpr uint32_t kMbWords = 25u * 17u;
+constexpr uint32_t kMbMaskSlots = 25u;                // a macroblock's words start with one mask slot per block (coeff_pack.hh)
+constexpr uint32_t kMbWords = kMbMaskSlots + 25u * 16u;
 // entries of a frame's chunk list ([0] = count): a chunk that is left behind holds at least 80 macroblocks' worth of dense
 // blocks ((2048 - 26 + 1) / 25) or 77 of packed words, whatever the content -- one bound for both formats
 // (lanes > 1: one lane per partition -- every lane leaves a partly filled chunk behind)
@@ -453,6 +454,7 @@ struct Lane {
   // block in progress
   uint32_t blkaddr;               // address of the BlockTable entry of the block AFTER the current one
   uint32_t nzsel, blkbit;
+  uint32_t blkslot;               // number of the block in progress in nz_mask's numbering (packed storage: its mask slot)
   // macroblock in progress
   uint32_t ctxbits;               // non-zero flags: above (this column) bits 0-8, left bits 16-24
   uint32_t flags, nz_mask, mb_first, coeff_blocks, yfirst;
@@ -463,7 +465,7 @@ struct Lane {
   uint32_t nchunks;               // chunks taken so far
   unsigned long long mem_since;   // waiting for a chunk since (0: not waiting)
   // packed storage only (then blk = where the next coefficient value goes, blk_index = first block of the chunk being filled):
-  AA_GLOBAL int16_t * hdr;        // the mask word of the block in progress (written when the block ends non-zero)
+  AA_GLOBAL int16_t * hdr;        // the macroblock's first word = mask slot 0 (a block that ends non-zero writes its slot); blk = the next value
   uint32_t zzmask;                // zigzag positions of the block in progress that hold a coefficient
   uint32_t words;                 // words used in the chunks left behind
   uint32_t mi_real;               // one lane per partition: index of the current macroblock's record (mi counts this lane's macroblocks)
@@ -623,12 +625,16 @@ AA_HD inline void store_mb( const Frame & J, uint32_t mi, uint32_t nz_mask, uint
   mb->flags = static_cast<uint8_t>( flags );
 }
 
-// packed storage: coeff_index belongs to the expansion pass; where the macroblock's words start goes into packed_pos
-AA_HD inline void store_mb_packed( const Frame & J, uint32_t mi, uint32_t nz_mask, uint32_t pos, uint32_t flags )
+// packed storage: where the macroblock's words start -- as chunk ordinal + word in the chunk into packed_pos (the host's view: a
+// frame's chunks copied back), and as a 40-bit offset in 16-bit words from the heap's base into the record itself (coeff_index = the
+// low 32 bits, `reserved` = bits 32-39: what the reconstruction kernels follow -- one load, no chunk list)
+AA_HD inline void store_mb_packed( const Frame & J, uint32_t mi, uint32_t nz_mask, uint32_t pos, uint32_t flags, unsigned long long word_off = 0 )
 {
   AA_GLOBAL aa_mb_info * mb = J.mbs + mi;
   mb->nz_mask = nz_mask;
+  mb->coeff_index = static_cast<uint32_t>( word_off );
   mb->flags = static_cast<uint8_t>( flags );
+  mb->reserved = static_cast<uint8_t>( word_off >> 32 );
   J.packed_pos[mi] = pos;
 }
 
@@ -652,7 +658,8 @@ AA_HD inline void setup_block( Lane & L, const uint8_t * smem, uint32_t blk )
   const uint32_t sel = ( e.x >> 16 ) & 255u;
   L.blkaddr = kBlockTabOff + 8 * ( blk + 1 );
   L.nzsel = e.y;
-  L.blkbit = 1u << ( e.x >> 24 );
+  L.blkslot = e.x >> 24;
+  L.blkbit = 1u << L.blkslot;
   const uint32_t ctx = AA_POPC( L.ctxbits & e.y );          // "above" flag + "left" flag
   L.typeaddr = L.base + 8u * ( sel & ( kBlkIsY - 1u ) );
   const uint32_t idx = ( sel & kBlkIsY ) ? L.yfirst : 0u;   // Y blocks after a Y2 start at position 1 (tokens.cc:61)
@@ -673,7 +680,7 @@ AA_HD inline void finish_frame( Lane & L, const Frame & J, const Heap & H, uint3
   J.chunk_list[0] = L.nchunks;
   AA_GLOBAL FrameSummary * sum = (AA_GLOBAL FrameSummary *) J.job->summary;
   sum->num_coeff_blocks = L.coeff_blocks;
-  if constexpr ( PK ) sum->packed_words = L.words + ( L.nchunks ? static_cast<uint32_t>( L.hdr - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) ) : 0u );
+  if constexpr ( PK ) sum->packed_words = L.words + ( L.nchunks ? static_cast<uint32_t>( L.blk - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) ) : 0u );
   else sum->packed_words = 0;
   sum->steps = L.steps;
   sum->num_chunks = L.nchunks;
@@ -696,7 +703,7 @@ AA_HD inline void finish_partition( Lane & L, uint8_t * smem, const Frame & J, c
   const uint32_t sh = J.mp_owner + part_off( J.mbw, true );
   if ( status != TOK_OK ) *lds_at<uint32_t>( smem, sh + offsetof( MpShared, status ) ) = status;
   uint32_t words = 0;
-  if constexpr ( PK ) words = L.words + ( L.nchunks ? static_cast<uint32_t>( L.hdr - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) ) : 0u );
+  if constexpr ( PK ) words = L.words + ( L.nchunks ? static_cast<uint32_t>( L.blk - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) ) : 0u );
   AA_LDS_ADD( smem, sh + offsetof( MpShared, blocks ), L.coeff_blocks );
   AA_LDS_ADD( smem, sh + offsetof( MpShared, words ), words );
   AA_LDS_ADD( smem, sh + offsetof( MpShared, steps ), L.steps );
@@ -801,8 +808,8 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
     const uint32_t has_y2 = flags & AA_MB_HAS_Y2;
     L.ctxbits = ( L.ctxbits & 0x01FF0000u ) | above_load<MP>( smem, above, J.mbw, L.col );
     if ( !( flags & AA_MB_SKIP ) ) {
-      // words of the chunk in use (packed storage; hdr = the next free word)
-      const uint32_t used = PK && L.nchunks ? static_cast<uint32_t>( L.hdr - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) ) : 0u;
+      // words of the chunk in use (packed storage; between macroblocks blk = the next free word)
+      const uint32_t used = PK && L.nchunks ? static_cast<uint32_t>( L.blk - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) ) : 0u;
       if ( PK ? ( !L.nchunks || used + kMbWords > kChunkWords ) : L.blk_left < kMbBlocks ) {   // the chunk cannot take a whole macroblock: on to a new one
         const uint32_t c = pool_take( H );
         if ( c == kNoChunk ) {
@@ -826,7 +833,7 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
         L.blk_index = c * kChunkBlocks;
         if constexpr ( PK ) {
           L.words += used;
-          L.hdr = H.base + static_cast<size_t>( L.blk_index ) * 16;
+          L.blk = H.base + static_cast<size_t>( L.blk_index ) * 16;
         } else {
           L.blk = H.base + static_cast<size_t>( L.blk_index ) * 16;
           L.blk_left = kChunkBlocks;
@@ -834,8 +841,9 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
         }
       }
       if constexpr ( PK ) {
-        L.mb_first = ( ( MP ? L.chunk_ord : L.nchunks - 1u ) << 15 ) | static_cast<uint32_t>( L.hdr - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) );
-        L.blk = L.hdr + 1; L.zzmask = 0;
+        // the macroblock's words: kMaskSlots mask slots, then the values (coeff_pack.hh)
+        L.mb_first = ( ( MP ? L.chunk_ord : L.nchunks - 1u ) << 15 ) | static_cast<uint32_t>( L.blk - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) );
+        L.hdr = L.blk; L.blk = L.hdr + kMbMaskSlots; L.zzmask = 0;
       } else L.mb_first = L.blk_index;
       L.flags = flags; L.nz_mask = 0;
       const uint32_t kind = has_y2 ? Y_AFTER_Y2 : Y_WITHOUT_Y2;
@@ -939,15 +947,16 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
 // ---- the end of a block, for the lanes that wait for it (R_BEND): the block's flags and mask word, the macroblock's record
 // if it was its last block, then the next block's contexts and first probability row ----
 template <bool PK, bool MP = false>
-AA_HD inline void block_end( Lane & L, uint8_t * smem, const Frame & J )
+AA_HD inline void block_end( Lane & L, uint8_t * smem, const Frame & J, const Heap & H )
 {
+  (void) H;
   if ( L.rec == R_BEND ) {
     const V8 nextblk = *lds_at<const V8>( smem, L.blkaddr );
     const bool nonzero = PK ? L.zzmask != 0 : L.nonzero != 0;
     const uint32_t ctxbits = nonzero ? L.ctxbits | L.nzsel : L.ctxbits & ~L.nzsel;
     if constexpr ( PK ) {
-      // the block's mask into the word kept for it; the word after its last value is kept for the next block
-      if ( nonzero ) { L.coeff_blocks++; *L.hdr = static_cast<int16_t>( L.zzmask ); L.hdr = L.blk; L.blk += 1; L.zzmask = 0; L.nz_mask |= L.blkbit; }
+      // the block's mask into its slot at the head of the macroblock's words
+      if ( nonzero ) { L.coeff_blocks++; L.hdr[L.blkslot] = static_cast<int16_t>( L.zzmask ); L.zzmask = 0; L.nz_mask |= L.blkbit; }
     } else {
       if ( nonzero ) { L.coeff_blocks++; L.blk += 16; L.blk_index++; L.blk_left--; zero_slot( L.blk ); L.nz_mask |= L.blkbit; }
     }
@@ -955,8 +964,10 @@ AA_HD inline void block_end( Lane & L, uint8_t * smem, const Frame & J )
     if ( mbdone ) {                           // the macroblock is complete: its record (its column's flags: at the boundary pass)
       uint32_t flags = L.flags;
       flags |= L.nz_mask ? AA_MB_HAS_NONZERO : ( ( flags & AA_MB_HAS_Y2 ) ? AA_MB_LF_SKIP_INNER : 0u );
-      if constexpr ( PK ) store_mb_packed( J, MP ? L.mi_real : L.mi, L.nz_mask, L.mb_first, flags );
-      else store_mb( J, MP ? L.mi_real : L.mi, L.nz_mask, L.mb_first, flags );
+      if constexpr ( PK ) {
+        store_mb_packed( J, MP ? L.mi_real : L.mi, L.nz_mask, L.mb_first, flags, static_cast<unsigned long long>( L.hdr - H.base ) );
+        if ( !L.nz_mask ) L.blk = L.hdr;      // coded, and every block empty: the mask slots go back (the macroblock stores nothing)
+      } else store_mb( J, MP ? L.mi_real : L.mi, L.nz_mask, L.mb_first, flags );
     }
     // the block after it (never a Y2)
     const uint32_t sel = AA_UBFE( nextblk.x, 16, 8 );
@@ -968,7 +979,8 @@ AA_HD inline void block_end( Lane & L, uint8_t * smem, const Frame & J )
     L.ctxbits = ctxbits;
     L.blkaddr += 8;
     L.nzsel = nextblk.y;
-    L.blkbit = 1u << ( nextblk.x >> 24 );
+    L.blkslot = nextblk.x >> 24;
+    L.blkbit = 1u << L.blkslot;
     L.nonzero = 0; L.mag = 0;
     L.rec = mbdone ? static_cast<uint32_t>( R_MBDONE ) : 0u;
   }
@@ -994,7 +1006,7 @@ AA_HD inline void run_period( Lane & L, uint8_t * smem, const Frame & J, const H
       for ( uint32_t k = 0; k < kBendEvery; k++ ) step<PK, MP>( L, smem, J );
       it += kBendEvery;
       // (asked by ALL lanes, outside the predicated regions: wave-uniform)
-      if ( AA_ANY( L.rec == R_BEND ) ) block_end<PK, MP>( L, smem, J );
+      if ( AA_ANY( L.rec == R_BEND ) ) block_end<PK, MP>( L, smem, J, H );
     } while ( it < kPeriod && !AA_ANY( L.rec == R_MBDONE ) );
     if ( prof ) prof[2] += it - it0;
   }
@@ -1050,7 +1062,7 @@ AA_HD inline void begin_frame( Lane & L, uint8_t * smem, uint32_t base, const Fr
   for ( uint32_t k = 0; k < above_bytes( J.mbw, SH ); k++ ) lds[kAbove + k] = 0;
   L.mi = 0; L.col = 0; L.row = 0; L.ctxbits = 0; L.coeff_blocks = 0; L.steps = 0;
   L.flags = L.nz_mask = L.mb_first = L.yfirst = 0;
-  L.nonzero = L.nzsel = L.blkbit = L.mag = 0;
+  L.nonzero = L.nzsel = L.blkbit = L.blkslot = L.mag = 0;
   L.ia = kBandTabOff;
   L.typeaddr = L.rowaddr = base; L.paddr = kXtab + kZeroX;
   L.blkaddr = kBlockTabOff;

@@ -64,7 +64,7 @@ def pmc_traffic(config):
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except (OSError, ValueError):
         return None, None
-    if d.get("round") != "r05":
+    if d.get("round") != "r06":
         return None, None
     global TRAFFIC_SOURCES
     TRAFFIC_SOURCES = d.get("per_kernel_source") or {}
@@ -852,7 +852,8 @@ def main():
     if traffic:
         packed = bool(info.get("packed_coefficients"))
         all_mbs = max(1, units["loopfilter"])
-        per_kernel = {"parse_tokens": all_mbs, "parse_headers": all_mbs, "expand": all_mbs if packed else 0, "dense_index": all_mbs if packed else 0,
+        # (round 6: no expansion pass any more -- the reconstruction kernels read the packed words themselves)
+        per_kernel = {"parse_tokens": all_mbs, "parse_headers": all_mbs,
                       "recon_inter": units["recon_inter"] + units["recon_split"], "recon_intra": units["recon_intra"], "loopfilter": all_mbs}
         if all(k in traffic for k in per_kernel if per_kernel[k]):
             tb = sum(traffic[k] * n for k, n in per_kernel.items() if n) / all_mbs

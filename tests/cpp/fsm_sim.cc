@@ -135,16 +135,23 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
     uint32_t running = 0, words = 0;
     for ( uint32_t mi = 0; mi < nmb; mi++ ) {
       const uint32_t nblk = aa::pack::blocks_of( mbs[mi].nz_mask );
-      mbs[mi].coeff_index = running;
       if ( nblk ) {
         const uint32_t pos = J.packed_pos[mi], ord = pos >> 15, off = pos & ( aa::kChunkWords - 1u );
         if ( ord >= sum.num_chunks || running + nblk > sum.num_coeff_blocks ) { bad = 1; break; }
         const int16_t * w = heap_mem + aa::pack::word_offset( pos, J.chunk_list );
-        // 16 lanes, one raster position each, as the kernel does it
-        const int16_t * wb = w;
-        for ( uint32_t b = 0; b < nblk; b++ ) {
-          for ( uint32_t j = 0; j < 16; j++ ) coeffs[( size_t( running ) + b ) * 16 + j] = aa::pack::value_at( wb, j );
-          wb += aa::pack::block_words( wb );
+        // the record's own 40-bit word offset (what the reconstruction kernels follow) names the same place
+        if ( ( static_cast<unsigned long long>( mbs[mi].reserved ) << 32 | mbs[mi].coeff_index ) != static_cast<unsigned long long>( w - heap_mem ) ) bad = 1;
+        // as the reconstruction kernels read it: a block's mask from its slot, its values behind the values of the stored blocks
+        // before it in parse order (a prefix sum over the masks' populations), one raster position at a time
+        const int16_t * wb = w + aa::pack::kMaskSlots;
+        for ( uint32_t p = 0, b = 0; p < 25; p++ ) {
+          const uint32_t blk = aa::pack::parse_order_block( p );
+          if ( !( ( mbs[mi].nz_mask >> blk ) & 1u ) ) continue;
+          const uint32_t mask = static_cast<uint16_t>( w[blk] );
+          if ( !mask ) bad = 1;                               // a stored block holds a coefficient
+          for ( uint32_t j = 0; j < 16; j++ ) coeffs[( size_t( running ) + b ) * 16 + j] = aa::pack::value_at( mask, wb, j );
+          wb += aa::pack::popc( mask );
+          b++;
         }
         // ... and the host-side form (aa_stream_read_records) must say the same
         std::vector<int16_t> again( size_t( nblk ) * 16 );
@@ -153,6 +160,7 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
         if ( off + used > aa::kChunkWords ) bad = 1;          // a macroblock never straddles a chunk
         words += used;
       }
+      mbs[mi].coeff_index = running; mbs[mi].reserved = 0;      // the frame's own view, as aa_stream_read_records gives it
       running += nblk;
     }
     if ( running != sum.num_coeff_blocks ) bad = 1;

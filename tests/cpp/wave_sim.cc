@@ -118,7 +118,7 @@ bool collect( const Job & B, const aa::Heap & H, bool packed, aa_mb_info * mbs, 
         std::memcpy( coeffs + size_t( running ) * 16, H.base + size_t( mbs[mi].coeff_index ) * 16, size_t( nblk ) * 32 );
       }
     }
-    mbs[mi].coeff_index = running;
+    mbs[mi].coeff_index = running; mbs[mi].reserved = 0;
     running += nblk;
   }
   return running == B.sum.num_coeff_blocks;
@@ -145,7 +145,7 @@ void wave_period( std::vector<aa::tok::Lane> & L, std::vector<aa::tok::Frame> & 
         for ( size_t k = 0; k < n; k++ ) step<PK, MP>( L[k], smem, F[k] );       // (every lane, with or without a frame: the step has no condition)
       it += kBendEvery;
       if ( any( []( const Lane & l ) { return l.rec == R_BEND; } ) ) {
-        for ( size_t k = 0; k < n; k++ ) if ( job_of[k] >= 0 ) block_end<PK, MP>( L[k], smem, F[k] );
+        for ( size_t k = 0; k < n; k++ ) if ( job_of[k] >= 0 ) block_end<PK, MP>( L[k], smem, F[k], H );
         if ( any( []( const Lane & l ) { return l.rec == R_MBDONE; } ) ) break;
       }
       if ( it >= kPeriod ) break;

@@ -1,6 +1,6 @@
 """Packed coefficient storage (aa_ctx_set_packed_coefficients; tok_fsm.hh "Packed coefficients", coeff_pack.hh) on a real
-MI355X: a context whose token lanes store a mask word + the non-zero values of every block, expanded on the device
-(k_dense_index / k_expand_coeffs) when a frame is handed to reconstruction, must give byte for byte what the dense path gives --
+MI355X: a context whose token lanes store a mask word + the non-zero values of every block, read in that form by the
+reconstruction kernels (round 6; rounds 3-5 expanded them into a transient dense array first), must give byte for byte what the dense path gives --
 records against the host parser, rasters against the oracle and the committed reference hashes.  The statements are
 tools/check_packed.py's (also runnable on its own); the host-side simulation of the same lanes is tests/test_fsm_sim.py."""
 import os
@@ -34,12 +34,13 @@ def test_packed_records_and_rasters_match_host_parser_and_reference(packed_ctx, 
     import check_packed
     assert check_packed.one_stream(packed_ctx, name) > 0
     st = packed_ctx.kernel_stats()
-    assert st["packed_frames"] > 0 and 0 < st["packed_words"] < 17 * st["packed_blocks"]
+    # (a macroblock that stores blocks takes 25 mask slots + a word per coefficient: 41 words for a lone full block at worst)
+    assert st["packed_frames"] > 0 and 0 < st["packed_words"] <= 41 * st["packed_blocks"]
 
 
 def test_packed_and_host_parsed_frames_in_one_call_and_frames_decoded_twice(packed_ctx):
     """24 streams in lock step, every second one parsed on the host (dense records in the same reconstruction call), every
-    third step reconstructed twice (the dense blocks are transient: made again for the second pass)."""
+    third step reconstructed twice."""
     import check_packed
     assert check_packed.lock_step(packed_ctx, ["qcif_q30", "synth_96x80_s1", "w200_q40_lf63s7", "qvga_q100"], 6) > 0
 
