@@ -355,21 +355,25 @@ static int header_lanes() { const int v = parse_lanes_env(); return v ? std::min
 // Token workgroups stay for as long as there is work, and what they leave of a CU -- LDS, registers -- is all the reconstruction
 // kernels (milliseconds each, on the high-priority stream) ever get.  The shape is therefore chosen for the reconstruction
 // kernels' sake as much as for the lanes':
-//   * `n` workgroups (waves) per CU, default 3 (round 5; 4 = one per SIMD before): a worker wave holds ~215 VGPRs, so with three
-//     of them one SIMD of every CU is the reconstruction kernels' alone (all 512 registers: a loop-filter wave of 256 and more)
-//     and the other three keep ~300 free;
-//   * each workgroup asks for just over 1 / (n + 1) of the CU's LDS, so that an (n + 1)-th does not fit and n of them leave
-//     160 KB - n * request to the other kernels (n = 3: 38.5 KB -- two loop-filter workgroups of 19 KB, or one and an inter
-//     workgroup's 11 KB; n = 4 left 30 KB);
-//   * lanes per workgroup = what that request holds: 37 at 1088 bytes per lane (1080p), 3 x 37 = 111 chains per CU where 4 x 29
-//     held 116.  A step costs a wave nearly the same whatever its width (the block-end pass is deferred and shared, tok_fsm.hh).
-//     Measured on MI355X, round 5 (profiles/r05_bench_sessions.md): 3 x 37 against 4 x 29 -- steady state 155 M against 140 M
-//     macroblocks/s, the host waits 126 ms per step for the compute stream instead of 180.
-// ALFALFA_AMD_WGS_PER_CU / ALFALFA_AMD_MAX_LANES: experiments.
+//   * `n` workgroups (waves) per CU, default 3 (round 5; 4 = one per SIMD before): a worker wave holds ~245 VGPRs, so with three
+//     of them one SIMD of every CU is the reconstruction kernels' alone and the other three keep ~265 free (a loop-filter wave
+//     of 256 still fits);
+//   * ROUND 6: 30 lanes per workgroup and an LDS request of exactly what they need (33 792 B at 1080p), 3 x 256 workgroups launched.
+//     The branch-free step (tok_fsm.hh) made a wave step 24 % faster, and the plateau of the pipelined run became the
+//     reconstruction chain beside the workers -- whose pace is the number of its workgroups a CU holds, i.e. the LDS the workers
+//     leave: 3 x 37 lanes left 38.5 KB = TWO loop-filter workgroups (19 KB each) or three of k_recon_inter4 (11 KB); 3 x 30 lanes
+//     leave 58.6 KB = THREE loop-filter workgroups or five inter ones.  Measured on the driver's command, two runs per shape
+//     (profiles/r06_bench_sessions.md): 3 x 37 125.6 / 128.5 M macroblocks/s, 3 x 32 126.8 / 130.4 (52.5 KB: still two loop-filter
+//     workgroups), **3 x 30 136.4 / 135.0 / 138.8**, 3 x 27 136.1, 2 x 45 129.7 / 130.7, 2 x 48 134.4, 2 x 59 125.2.  Rounds 3-5
+//     padded the request to just over 1 / (n + 1) of the CU's LDS so that an (n + 1)-th workgroup could not land on a CU; with
+//     the exact request it could (4 x 33 KB fit), so the host launches no more than n per CU and leaves the placement to the
+//     dispatcher (which spreads workgroups by free resources).  A step costs a wave the same whatever its width, so lanes per
+//     workgroup trade token capacity (90 chains per CU now, 111 before) against the reconstruction's occupancy one for one.
+// ALFALFA_AMD_WGS_PER_CU / ALFALFA_AMD_MAX_LANES / ALFALFA_AMD_LDS_EXACT=0 (round 5's padded request) / ALFALFA_AMD_WGS_CAP_PER_CU: experiments.
 constexpr uint32_t kLdsPerCu = 160u * 1024u, kLdsGranule = 512u;
 static uint32_t env_u32( const char * name, uint32_t dflt ) { const char * e = getenv( name ); return e ? static_cast<uint32_t>( atoi( e ) ) : dflt; }
 static const uint32_t kWgsPerCu = std::max( 1u, std::min( 16u, env_u32( "ALFALFA_AMD_WGS_PER_CU", 3u ) ) );
-static const uint32_t kMaxLanes = std::max( 1u, std::min( 64u, env_u32( "ALFALFA_AMD_MAX_LANES", 40u ) ) );
+static const uint32_t kMaxLanes = std::max( 1u, std::min( 64u, env_u32( "ALFALFA_AMD_MAX_LANES", 30u ) ) );
 struct TokenShape { int lanes; uint32_t lds; int per_cu; };
 static TokenShape token_launch_shape( uint32_t lane_bytes )
 {
@@ -408,12 +412,10 @@ void token_worker_shape( uint32_t lane_bytes, int n_cus, int * lanes_out, uint32
     lanes = sh.lanes; lds = sh.lds;
   }
   (void) n_cus;
-  // Experiment: ALFALFA_AMD_LDS_EXACT=1 makes a workgroup ask for what its lanes need and no more -- with
-  // ALFALFA_AMD_MAX_LANES=20 that leaves the reconstruction kernels 40 KB per CU instead of 27 -- and ALFALFA_AMD_WGS_CAP_PER_CU bounds
-  // the workgroups the host launches per CU (the LDS request then no longer keeps a fifth one out; the hardware spreads them evenly
-  // as a rule, not as a promise).  Off by default: not measured yet.
-  static const bool lds_exact = env_u32( "ALFALFA_AMD_LDS_EXACT", 0u ) != 0u;
-  static const uint32_t wgs_cap = env_u32( "ALFALFA_AMD_WGS_CAP_PER_CU", 0u );
+  // (round 6 default: a workgroup asks for what its lanes need and no more, and the host launches kWgsPerCu workgroups per CU --
+  // see the note above token_launch_shape; ALFALFA_AMD_LDS_EXACT=0 brings back the padded request that keeps an (n + 1)-th out)
+  static const bool lds_exact = env_u32( "ALFALFA_AMD_LDS_EXACT", 1u ) != 0u;
+  static const uint32_t wgs_cap = env_u32( "ALFALFA_AMD_WGS_CAP_PER_CU", lds_exact && !parse_lanes_env() ? kWgsPerCu : 0u );
   if ( lds_exact && lanes > 0 ) lds = ( ( tok::kTablesBytes + static_cast<uint32_t>( lanes ) * lane_bytes + kLdsGranule - 1u ) / kLdsGranule ) * kLdsGranule;
   *lanes_out = lanes; *lds_out = lds;
   int per_cu = lds ? static_cast<int>( kLdsPerCu / lds ) : 0;

@@ -650,20 +650,27 @@ static void filter_edge( uint8_t * central, int step, int along, int count, int 
   }
 }
 
+/* SimpleLoopFilter / NormalLoopFilter ctors (loopfilter.cc:81-125): interior limit, macroblock-edge limit, sub-block-edge limit, hev threshold */
+static void filter_limits( int level, int sharpness, int key, int out[4] )
+{
+  int ilimit = level;
+  if ( sharpness ) {
+    ilimit >>= sharpness > 4 ? 2 : 1;
+    if ( ilimit > 9 - sharpness ) ilimit = 9 - sharpness;
+  }
+  if ( ilimit < 1 ) ilimit = 1;
+  int hevt = level >= 15;
+  if ( level >= 40 ) hevt++;
+  if ( level >= 20 && !key ) hevt++;
+  out[0] = ilimit; out[1] = ( ( level + 2 ) * 2 ) + ilimit; out[2] = ( level * 2 ) + ilimit; out[3] = hevt;
+}
 static void loopfilter_mb( vp8o_decoder * d, int col, int row, int level, int skip_subblock_edges ) /* loopfilter.cc:81-154 */
 {
   const frame_header * h = &d->hdr;
   level = level > 63 ? 63 : level;            /* clamp63; level > 0 already */
-  int ilimit = level;
-  if ( h->sharpness ) {
-    ilimit >>= h->sharpness > 4 ? 2 : 1;
-    if ( ilimit > 9 - h->sharpness ) ilimit = 9 - h->sharpness;
-  }
-  if ( ilimit < 1 ) ilimit = 1;
-  const int mb_limit = ( ( level + 2 ) * 2 ) + ilimit, sb_limit = ( level * 2 ) + ilimit;
-  int hevt = level >= 15;
-  if ( level >= 40 ) hevt++;
-  if ( level >= 20 && !h->key ) hevt++;
+  int lim[4];
+  filter_limits( level, h->sharpness, h->key, lim );
+  const int ilimit = lim[0], mb_limit = lim[1], sb_limit = lim[2], hevt = lim[3];
   for ( int pass = 0; pass < 4; pass++ ) {
     /* 0: left MB edge, 1: inner vertical edges, 2: top MB edge, 3: inner horizontal edges */
     if ( pass == 0 && col == 0 ) continue;
@@ -1022,3 +1029,45 @@ int vp8o_decode_frame( vp8o_decoder * d, const uint8_t * data, size_t size, int 
   if ( shown_out ) *shown_out = show;
   return VP8O_OK;
 }
+
+/* ---------------- single stages ----------------
+ * The arithmetic stages of the path one at a time, on caller-supplied numbers: what tests/test_gpu_stages.py compares the
+ * product's device functions with, stage by stage, so that a raster mismatch can be traced to a stage and not just to a
+ * macroblock.  Thin wrappers around the functions above (no restatement of their own). */
+void vp8o_stage_residual( const int16_t coeff[16], int dc_q, int ac_q, uint8_t pixels[16] ) /* dequantize + idct_add onto a 4x4 prediction */
+{
+  int16_t dq[16];
+  dequantize( coeff, (uint16_t) dc_q, (uint16_t) ac_q, dq );
+  idct_add( dq, pixels, 4 );
+}
+void vp8o_stage_iwht( const int16_t coeff[16], int dc_q, int ac_q, int16_t ydc[16] )          /* dequantize + iwht of a Y2 block */
+{
+  int16_t dq[16];
+  dequantize( coeff, (uint16_t) dc_q, (uint16_t) ac_q, dq );
+  iwht( dq, ydc );
+}
+/* intra prediction of the n x n block at (x0, y0) of `plane` (width pw), in place: n = 4 -> a sub-block mode (B_DC_PRED..), else a 16x16 / 8x8 mode */
+void vp8o_stage_predict( uint8_t * plane, int pw, int x0, int y0, int n, int mode )
+{
+  if ( n == 4 ) predict_4x4( plane, pw, x0, y0, mode );
+  else predict_big( plane, pw, x0, y0, n, mode );
+}
+/* one six-tap pass over six pixels (prediction.cc:645-653, 875-881): clamp255( ( sum + 64 ) >> 7 ) */
+int vp8o_stage_sixtap( const uint8_t p[6], int frac )
+{
+  int s = 64;
+  for ( int t = 0; t < 6; t++ ) s += p[t] * sixtap[frac][t];
+  return clamp255( s >> 7 );
+}
+/* both passes of an n x n block (inter_predict above) */
+void vp8o_stage_inter_predict( const uint8_t * ref, int w, int h, int x0, int y0, int n, int mvx, int mvy, uint8_t * dst, int stride )
+{
+  inter_predict( ref, w, h, x0, y0, n, mvx, mvy, dst, stride );
+}
+/* one position of one loop-filter edge: px[0..7] = p3 p2 p1 p0 q0 q1 q2 q3, in place */
+void vp8o_stage_filter_edge( uint8_t px[8], int is_mb_edge, int interior_limit, int edge_limit, int hev_threshold )
+{
+  filter_edge( px + 4, 1, 0, 1, is_mb_edge, interior_limit, edge_limit, hev_threshold );
+}
+/* the limits NormalLoopFilter derives from a level (loopfilter.cc:81-125): out = interior, mb edge, sub-block edge, hev threshold */
+void vp8o_stage_filter_limits( int level, int sharpness, int key_frame, int out[4] ) { filter_limits( level, sharpness, key_frame, out ); }

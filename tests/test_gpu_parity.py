@@ -64,18 +64,29 @@ def test_batched_lockstep_equals_single_stream(gpu_ctx):
 
 
 @pytest.mark.parametrize("seed", list(range(200, 224)))
-def test_hip_matches_oracle_on_synthetic_feature_streams(gpu_ctx, seed):
+def test_hip_matches_oracle_on_synthetic_feature_streams(gpu_ctx, seed, tmp_path):
     """SPLITMV / golden+altref / segmentation / multi-partition / LF deltas / hidden frames / far MVs / odd sizes."""
     import vp8_synth
     sizes = [(96, 80), (33, 17), (64, 64), (175, 143), (16, 16), (200, 48), (320, 176), (48, 256)]
     w, h = sizes[seed % len(sizes)]
     st = vp8_synth.feature_stream(w, h, seed, 8)
     dec, ora = aa.Decoder(gpu_ctx, w, h), vo.OracleDecoder(w, h)
+    # ... and against the REFERENCE decoder itself where it travelled with the snapshot (oracle/_ref/ref_decode, every frame's padded
+    # planes): the same seeds are oracle == reference on the CPU side too (tests/test_synth_streams.py GPU_SEEDS)
+    ref = None
+    if vo.ref_available():
+        ivf, raw = str(tmp_path / "s.ivf"), str(tmp_path / "s.raw")
+        vo.write_ivf(ivf, w, h, st.frames)
+        vo.ref_decode(ivf, raw)
+        ref = open(raw, "rb").read()
+    fs = dec.padded_width * dec.padded_height * 3 // 2
     for i, fr in enumerate(st.frames):
         shown, fi = dec.get_frame_output(fr)
         assert ora.decode(fr) == shown
         got, want = dec.raster_bytes(fi), ora.raster_bytes()
         assert got == want, "seed %d frame %d (%s): %s" % (seed, i, ora.frame_info(), first_diff(got, want, dec.padded_width, dec.padded_height))
+        if ref is not None:
+            assert got == ref[i * fs:(i + 1) * fs], "seed %d frame %d: HIP differs from the reference decoder" % (seed, i)
 
 
 def test_row_pipelined_schedule_under_load(gpu_ctx):

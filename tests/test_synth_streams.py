@@ -29,10 +29,23 @@ def check_intent(plans, om):
                 assert list(o["b_mode"]) == list(pl.b_modes)
 
 
-@pytest.mark.parametrize("seed", SEEDS)
-def test_synth_stream_cpu(seed, tmp_path):
+# the streams the GPU suite decodes (tests/test_gpu_parity.py::test_hip_matches_oracle_on_synthetic_feature_streams: same seeds,
+# sizes and frame counts): oracle == live reference on exactly those, so that HIP == oracle there is HIP == reference
+GPU_SIZES = [(96, 80), (33, 17), (64, 64), (175, 143), (16, 16), (200, 48), (320, 176), (48, 256)]
+GPU_SEEDS = list(range(200, 224))
+
+
+def stream_of(seed):
+    if seed >= 200:
+        w, h = GPU_SIZES[seed % len(GPU_SIZES)]
+        return w, h, vp8_synth.feature_stream(w, h, seed, 8)
     w, h = SIZES[seed % len(SIZES)]
-    st = vp8_synth.feature_stream(w, h, seed, 7)
+    return w, h, vp8_synth.feature_stream(w, h, seed, 7)
+
+
+@pytest.mark.parametrize("seed", SEEDS + GPU_SEEDS)
+def test_synth_stream_cpu(seed, tmp_path):
+    w, h, st = stream_of(seed)
     ref = None
     if vo.ref_available():
         path = str(tmp_path / "s.ivf"); vo.write_ivf(path, w, h, st.frames)
