@@ -959,14 +959,25 @@ __global__ __launch_bounds__( kLanes ) void k_recon_intra4( const aa_frame_list 
 //   * six-tap passes: luma and chroma tasks of a macroblock form ONE list (136 horizontal, 96 vertical) walked 16 at a
 //     time with per-lane source / taps / destination, so partially filled rounds are shared by all four macroblocks;
 //   * output: lane = pixel row (luma 16 B per lane, chroma 8 B per lane).
+// Round 6: what is never alive at the same time shares its bytes -- the prediction takes the place of the reference windows (which
+// the horizontal pass and the copies have read, into the transposed buffers and into registers, by the time it is written), the Y2
+// scratch of the residual stage that of the first-pass output.  2 320 instead of 2 776 bytes per slot: 9 344 B per workgroup, so that
+// SIX of them fit into the 58.6 KB of LDS the token workers leave of a CU where five of 11 200 B did (the kernel is latency bound:
+// beside the workers its pace is the number of its waves a CU holds).
 struct alignas( 16 ) Inter4Slot {
   alignas( 16 ) int16_t res[24][16];        // residual of block b at [row*4+col]
-  alignas( 16 ) uint8_t wy[21][24];         // luma reference window rows -2..18, 24 bytes from the aligned column
-  uint8_t wc[2][13][16];                    // chroma windows (directly follows wy: the staging loop treats both as one dword array)
-  alignas( 16 ) uint8_t ty[16][24];         // first-pass output, TRANSPOSED (column-major): the vertical pass also reads consecutive bytes
+  union {
+    struct {
+      alignas( 16 ) uint8_t wy[21][24];     // luma reference window rows -2..18, 24 bytes from the aligned column
+      uint8_t wc[2][13][16];                // chroma windows (directly follows wy: the staging loop treats both as one dword array)
+    };
+    alignas( 16 ) uint8_t pred[384];        // Y 16x16 | U 8x8 | V 8x8, row-major (born when the windows are dead)
+  };
+  union {
+    alignas( 16 ) uint8_t ty[16][24];       // first-pass output, TRANSPOSED (column-major): the vertical pass also reads consecutive bytes
+    alignas( 16 ) int16_t y2[32];           // (residual stage only)
+  };
   alignas( 16 ) uint8_t tc[2][8][16];
-  alignas( 16 ) uint8_t pred[384];          // Y 16x16 | U 8x8 | V 8x8, row-major
-  alignas( 16 ) int16_t y2[32];
 };
 struct alignas( 16 ) Inter4Lds { Inter4Slot slot[4]; uint32_t taps[16]; };
 static_assert( offsetof( Inter4Slot, wc ) == offsetof( Inter4Slot, wy ) + 21 * 24, "wy and wc must be contiguous" );
@@ -1064,22 +1075,6 @@ __device__ __forceinline__ void recon_inter4_body( const aa_dev_frame & f, const
   const bool luma_general = __any( on && ( ( mvx | mvy ) & 7 ) != 0 ), chroma_general = __any( on && ( ( cmx | cmy ) & 7 ) != 0 );
   const uint8_t * const wyb = &S.wy[0][0]; const uint8_t * const wcb = &S.wc[0][0][0];
   uint8_t * const tyb = &S.ty[0][0]; uint8_t * const tcb = &S.tc[0][0][0];
-  if ( !luma_general && on ) {          // lane = pixel row: bytes oy+2 .. oy+17 of window row l+2
-    const uint2 * rp = reinterpret_cast<const uint2 *>( wyb + ( l + 2 ) * 24 );
-    const uint2 a = rp[0], b = rp[1], c = rp[2];
-    const bool q = oy + 2 >= 4; const int sft = ( oy + 2 ) & 3;
-    const uint32_t e0 = q ? a.y : a.x, e1 = q ? b.x : a.y, e2 = q ? b.y : b.x, e3 = q ? c.x : b.y, e4 = q ? c.y : c.x;
-    *reinterpret_cast<uint4 *>( S.pred + l * 16 ) = make_uint4( __builtin_amdgcn_alignbyte( e1, e0, sft ), __builtin_amdgcn_alignbyte( e2, e1, sft ),
-                                                                __builtin_amdgcn_alignbyte( e3, e2, sft ), __builtin_amdgcn_alignbyte( e4, e3, sft ) );
-  }
-  if ( !chroma_general && on ) {        // lane = (plane, pixel row): bytes oc+2 .. oc+9 of window row r+2
-    const int pl = l >> 3, r = l & 7;
-    const uint2 * rp = reinterpret_cast<const uint2 *>( wcb + pl * 208 + ( r + 2 ) * 16 );
-    const uint2 a = rp[0], b = rp[1];
-    const bool q = oc + 2 >= 4; const int sft = ( oc + 2 ) & 3;
-    const uint32_t e0 = q ? a.y : a.x, e1 = q ? b.x : a.y, e2 = q ? b.y : b.x;
-    *reinterpret_cast<uint2 *>( S.pred + 256 + pl * 64 + r * 8 ) = make_uint2( __builtin_amdgcn_alignbyte( e1, e0, sft ), __builtin_amdgcn_alignbyte( e2, e1, sft ) );
-  }
   // ---- horizontal pass: 84 luma + 52 chroma tasks of four outputs; results to the transposed buffers t[column][row].
   //      Two unrolled task lists (instead of one 136-task loop) so that plane, strides and tap registers are compile-time ----
   if ( on && luma_general ) {
@@ -1110,7 +1105,28 @@ __device__ __forceinline__ void recon_inter4_body( const aa_dev_frame & f, const
       tb[0] = static_cast<uint8_t>( o4 ); tb[16] = static_cast<uint8_t>( o4 >> 8 ); tb[32] = static_cast<uint8_t>( o4 >> 16 ); tb[48] = static_cast<uint8_t>( o4 >> 24 );
     }
   }
+  // ---- planes that are copied: their window rows into registers now (the prediction shares the windows' bytes: nothing of it may be
+  //      written before every lane has read what it needs of the windows -- the horizontal pass above, the copies here) ----
+  uint4 copy_y = make_uint4( 0, 0, 0, 0 ); uint2 copy_c = make_uint2( 0, 0 );
+  if ( !luma_general && on ) {          // lane = pixel row: bytes oy+2 .. oy+17 of window row l+2
+    const uint2 * rp = reinterpret_cast<const uint2 *>( wyb + ( l + 2 ) * 24 );
+    const uint2 a = rp[0], b = rp[1], c = rp[2];
+    const bool q = oy + 2 >= 4; const int sft = ( oy + 2 ) & 3;
+    const uint32_t e0 = q ? a.y : a.x, e1 = q ? b.x : a.y, e2 = q ? b.y : b.x, e3 = q ? c.x : b.y, e4 = q ? c.y : c.x;
+    copy_y = make_uint4( __builtin_amdgcn_alignbyte( e1, e0, sft ), __builtin_amdgcn_alignbyte( e2, e1, sft ),
+                         __builtin_amdgcn_alignbyte( e3, e2, sft ), __builtin_amdgcn_alignbyte( e4, e3, sft ) );
+  }
+  if ( !chroma_general && on ) {        // lane = (plane, pixel row): bytes oc+2 .. oc+9 of window row r+2
+    const int pl = l >> 3, r = l & 7;
+    const uint2 * rp = reinterpret_cast<const uint2 *>( wcb + pl * 208 + ( r + 2 ) * 16 );
+    const uint2 a = rp[0], b = rp[1];
+    const bool q = oc + 2 >= 4; const int sft = ( oc + 2 ) & 3;
+    const uint32_t e0 = q ? a.y : a.x, e1 = q ? b.x : a.y, e2 = q ? b.y : b.x;
+    copy_c = make_uint2( __builtin_amdgcn_alignbyte( e1, e0, sft ), __builtin_amdgcn_alignbyte( e2, e1, sft ) );
+  }
   __syncthreads();
+  if ( !luma_general && on ) *reinterpret_cast<uint4 *>( S.pred + l * 16 ) = copy_y;
+  if ( !chroma_general && on ) *reinterpret_cast<uint2 *>( S.pred + 256 + ( l >> 3 ) * 64 + ( l & 7 ) * 8 ) = copy_c;
   // ---- vertical pass: 64 luma + 32 chroma tasks: (column c, row group i) -> rows 4i..4i+3 of column c ----
   if ( on && luma_general ) {
     const int frac = mvy & 7;

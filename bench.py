@@ -111,6 +111,8 @@ def parse_args():
     ap.add_argument("--small-batches", default="1,8,64", help="stream counts for the small-batch end-to-end figures ('' = skip)")
     ap.add_argument("--secondary", default="720p_intra,720p_inter,1080p_inter_lf_subpel",
                     help="other BASELINE configs measured end to end after the main run, a few steps each, parity checked in the run ('' = skip)")
+    ap.add_argument("--two-cpu-steps", type=int, default=8, help="rank 0 of a 1-GPU run: the same workload once more in a CHILD process confined to 2 CPUs (affinity, 2 host lanes, "
+                    "2 pre-pass threads) -- what a rank gets when eight share a 16-CPU grant -- this many steps, reported as per_rank_on_2_cpus (0 = skip)")
     ap.add_argument("--secondary-streams", type=int, default=96)
     ap.add_argument("--secondary-steps", type=int, default=4)
     return ap.parse_args()
@@ -571,8 +573,36 @@ def lane_per_partition_leg(args, config, rank, world, threads):
         del ctx2
 
 
+def two_cpu_leg(args):
+    """The headline workload in a child process that has TWO CPUs (sched_setaffinity: aa_host_cpus() then says 2, so the context gets 2
+    host lanes and the pre-pass 2 threads): the host budget of one rank when eight ranks share the 16 CPUs this pool's boxes grant
+    (the N = 1 headline leans on 16 CPUs that eight ranks will not have).  Run BEFORE this process takes its HBM."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.two_cpu_steps), "--warmup", "2", "--threads", "2", "--config", args.config,
+           "--streams", str(args.streams), "--frames", str(args.frames), "--key-ahead", str(args.key_ahead), "--depth", str(args.depth), "--hbm-gb", str(args.hbm_gb),
+           "--secondary=", "--small-batches=", "--no-cpu-baseline", "--no-verify", "--no-device-half", "--lanes-only-steps", "0", "--deliver-steps", "0", "--two-cpu-steps", "0"]
+    env = dict(os.environ)
+    env["AA_BENCH_CPUS"] = "2"; env["ALFALFA_AMD_HOST_LANES"] = "2"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "AA_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    except Exception as e:                          # (must not take the headline down)
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    t = d.get("timed_region") or {}
+    return {"value": d["value"], "unit": "macroblocks/s", "steps": d["steps"], "ms_per_step": d["ms_per_step"], "cpus": 2, "host_lanes": 2, "host_threads": 2,
+            "first_step_done_at_ms": (t.get("step_done_at_ms") or [None])[0], "between_fill_and_drain_value": (d.get("steady_state") or {}).get("value"),
+            "host_prepass_and_staging_ms_per_step": round((d.get("stages") or {}).get("host_prepass_and_staging_s_per_step", 0) * 1e3, 1),
+            "frames_parsed_on_host_cores": t.get("frames_parsed_on_host_cores"), "leg_wall_s": round(time.perf_counter() - t0, 1),
+            "note": "a child process of bench.py confined to 2 CPUs (empty pipeline to empty pipeline over fewer steps than `value`: the fill weighs more); "
+                    "not verified against the reference in the child (the parent's run is)"}
+
+
 def main():
     args = parse_args()
+    if os.environ.get("AA_BENCH_CPUS"):             # (the 2-CPU leg's child: before anything counts cores or starts threads)
+        os.sched_setaffinity(0, set(sorted(os.sched_getaffinity(0))[:int(os.environ["AA_BENCH_CPUS"])]))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0")); local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     dist = None
@@ -674,6 +704,10 @@ def main():
 
     # ---- the end-to-end pipeline ----
     log("streams ready (%d distinct, generated in %.1f s)" % (len(env["distinct"]), t_gen))
+    two_cpus = None
+    if rank == 0 and world == 1 and dist is None and args.two_cpu_steps > 0:
+        two_cpus = two_cpu_leg(args)                # (now: the streams are in the cache, and this process holds no HBM to speak of yet)
+        log("2-CPU leg: %s" % ({k: two_cpus.get(k) for k in ("value", "first_step_done_at_ms", "between_fill_and_drain_value", "leg_wall_s", "error")},))
     calibrate(env, streams)
     log("calibrated: lone key frame %.3f s, step %.4f us, keys on host: %s, planned %s" % (env["lone_key_s"], env["step_latency_us"], env["keys_on_host"], env["planned"]))
     step_latency_us = env["step_latency_us"]
@@ -1063,7 +1097,7 @@ def main():
             "stages": {"host_prepass_and_staging_s_per_step": round(host_submit_s, 4),
                        "entropy_decode_alone_s_per_step": round(t_parse_alone, 4),
                        "note": "entropy_decode_alone = one step's submit -> parse finished with nothing else on the GPU (a latency: the longest chain, a key frame)"},
-            "timed_region": timed_region, "per_rank": per_rank, "small_batches": small, "secondary": secondary, "all_frames_on_gpu_lanes": lanes_only,
+            "timed_region": timed_region, "per_rank": per_rank, "small_batches": small, "secondary": secondary, "all_frames_on_gpu_lanes": lanes_only, "per_rank_on_2_cpus": two_cpus,
             "host_share": {"host_cpus_usable": host_cpus, "host_cpus_visible": os.cpu_count(), "host_lanes_of_this_rank": int(os.environ.get("ALFALFA_AMD_HOST_LANES") or 0), "urgent_groups_planned": env.get("urgent_groups"), "urgent_key_frames_on_host": bool(env.get("urgent_keys_on_host")), "a_group_of_key_frames_on_the_host_route_would_take_ms": env.get("urgent_host_estimate_ms"),
                            "groups_whose_key_frames_took_the_host_route_in_the_timed_region": urgent_groups_timed,
                            "host_share_ms": info["host_share_ms"], "key_frames_parsed_by_host_workers": bool(env.get("keys_on_host")), "host_threads": threads,

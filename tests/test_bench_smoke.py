@@ -41,6 +41,8 @@ def test_bench_small(dist):
         assert line["entry_state_handoff"]["continuations_agree"] is True
     else:
         assert line["entry_state_handoff"] is None
+        two = line["per_rank_on_2_cpus"]             # the same workload in a child process confined to 2 CPUs
+        assert two.get("value", 0) > 0 and two["cpus"] == 2, two
 
 
 def test_two_ranks_on_one_gpu_hand_over_the_entry_state():
