@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libalfalfa_amd.so")
 SOURCES = ["parser.cpp", "runtime.cpp", "kernels.hip", "parse_kernels.hip"]
-HEADERS = ["parser.hh", "bool_reader.hh", "parse_common.hh", "tok_fsm.hh", "coeff_pack.hh", "recon_inl.hh", "vp8_tables.h", "vp8_math.hh", "device_types.h",
+HEADERS = ["parser.hh", "bool_reader.hh", "parse_common.hh", "tok_fsm.hh", "coeff_pack.hh", "recon_inl.hh", "runtime_types.inc", "runtime_pool.inc", "runtime_tokens.inc", "runtime_records.inc", "runtime_ctx.inc", "runtime_submit.inc", "runtime_decode.inc", "runtime_rasters.inc", "runtime_lf_search.inc", "vp8_tables.h", "vp8_math.hh", "device_types.h",
            os.path.join("..", "..", "include", "alfalfa_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]

@@ -163,6 +163,7 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
   // (threads that are no token lanes run the steps too -- idle, at the addresses of lane 0: reads only)
   const bool is_lane = lane < a.lanes;
   aa::tok::init_lane( L, aa::tok::ring_addr( is_lane ? lane : 0 ), aa::tok::slice_addr( is_lane ? lane : 0, a.lanes, a.lane_bytes ) );
+  aa::tok::preload( L, smem );              // (the tables are in LDS: an idle lane's record, probability, band)
   uint32_t backoff = 0;
   unsigned long long idle_since = 0;      // the wave has had no frame since (0: it has one)
   uint32_t looks = 0;
@@ -216,12 +217,12 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
                 const int owner_lane = nth_set_bit( idle_mask, d.start + aa::tok::mp_owner_partition( my_job ) );
                 F = aa::tok::frame_of_partition( my_job, d.part, aa::tok::slice_addr( owner_lane, a.lanes, a.lane_bytes ) );
               } else F = aa::tok::frame_of( my_job );
-              if ( my_job->nmb == 0 ) { L.rec = aa::tok::R_DONE; }                  // (never queued; belt and braces)
+              if ( my_job->nmb == 0 ) { L.rec = aa::tok::R_DONE; aa::tok::preload( L, smem ); }                  // (never queued; belt and braces)
               else aa::tok::begin_frame<MP>( L, smem, L.base, F );
             }
           } else if ( mine ) {
             F = aa::tok::frame_of( job );
-            if ( F.nmb == 0 ) { L.rec = aa::tok::R_DONE; }                        // (never queued; belt and braces)
+            if ( F.nmb == 0 ) { L.rec = aa::tok::R_DONE; aa::tok::preload( L, smem ); }                        // (never queued; belt and braces)
             else aa::tok::begin_frame<MP>( L, smem, L.base, F );
           }
         } else backoff = 3;               // nothing there: the busy lanes of this wave should not pay for a look every period

@@ -64,6 +64,10 @@
 
 #include "parse_common.hh"
 
+#ifndef AA_STEP_PRELOAD
+#define AA_STEP_PRELOAD 1             /* build parameter (A/B runs): the step's LDS reads are asked for at the end of the previous step (tok::preload) */
+#endif
+
 namespace aa {
 
 struct alignas( 16 ) V16 { uint32_t x, y, z, w; };   // one 16-byte memory transaction
@@ -447,6 +451,12 @@ struct Lane {
   Chunk16 pend[kChunks], mpend[kMetaChunks];
   // token in progress
   uint32_t rec;                   // address of the record of the node about to be decoded (>= R_MBDONE: an idle record -- not decoding)
+#if AA_STEP_PRELOAD
+  // what the next step reads from LDS, asked for ahead of time (tok::preload): the probability at paddr, the stream byte at rpos, the
+  // node record at rec, the band of the position after ia.  Whoever changes one of those four outside the step asks again.
+  uint32_t pre_prob, pre_raw, pre_band;
+  V8 pre_rec;
+#endif
   uint32_t paddr;                 // address of its probability
   uint32_t rowaddr, typeaddr;     // addresses of the current probability row / of this block type's probabilities
   uint32_t ia;                    // kBandTabOff + coefficient position (a multiple of 32 + position: shifts and `& 16` see the position)
@@ -638,6 +648,21 @@ AA_HD inline void store_mb_packed( const Frame & J, uint32_t mi, uint32_t nz_mas
   J.packed_pos[mi] = pos;
 }
 
+// The four LDS reads of a step (addresses all known when the previous step ends), asked for AHEAD of time -- at the end of the previous
+// step, in front of its coefficient store and bookkeeping, so that the round trip runs beside ~15 instructions instead of in front of
+// the step (a lone wave per SIMD has nobody else to hide it behind).  AA_STEP_PRELOAD=0: the step reads at its top (A/B builds).
+AA_HD inline void preload( Lane & L, uint8_t * smem )
+{
+#if AA_STEP_PRELOAD
+  L.pre_prob = *lds_at<const uint8_t>( smem, L.paddr );
+  L.pre_raw = *lds_at<const uint8_t>( smem, L.sbase | ( L.rpos & ( kRing - 1 ) ) );
+  L.pre_rec = *lds_at<const V8>( smem, L.rec );
+  L.pre_band = *lds_at<const uint8_t>( smem, L.ia + 1u );
+#else
+  (void) L; (void) smem;
+#endif
+}
+
 // p + n words, n = 0 / 1, for a pointer into a coefficient chunk.  On the GPU a 32-bit add: a chunk is 64 KB and 64-KB aligned (the
 // runtime checks the heap's base), so the low half of the address never carries into the high half -- a 64-bit add is two
 // instructions on a path where every instruction is four cycles of every bool.
@@ -763,7 +788,7 @@ AA_HD inline void load_plane( uint8_t * smem, uint32_t at, const Frame & J, uint
 constexpr unsigned long long kMemWaitTicks = 200000000ull;      // 2 s of the 100 MHz clock: then the frame is handed back (TOK_NO_MEMORY)
 
 template <bool PK, bool MP = false>
-AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J, const Heap & H )
+AA_HD inline void macroblock_boundary_body( Lane & L, uint8_t * smem, const Frame & J, const Heap & H )
 {
   const bool mp = MP && J.mp_P > 1;                         // this frame has one lane per partition
   const uint32_t above = ( mp ? J.mp_owner : L.base ) + kAbove;
@@ -862,6 +887,13 @@ AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J
   }
 }
 
+template <bool PK, bool MP = false>
+AA_HD inline void macroblock_boundary( Lane & L, uint8_t * smem, const Frame & J, const Heap & H )
+{
+  macroblock_boundary_body<PK, MP>( L, smem, J, H );
+  preload( L, smem );           // (wherever the lane stands now -- a block's first node, an idle record, another partition's bytes)
+}
+
 template <bool MP = false> AA_HD inline bool at_boundary( const Lane & L ) { return L.rec == R_MBDONE || L.rec == R_MB || ( MP && L.rec == R_PARK ); }
 
 // ---- one step: decode one bool (lanes with a node to decode; the others sit it out) -------------------------------------
@@ -885,10 +917,16 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
   (void) J;
   // EVERY lane runs the step (idle lanes: see "nodes" above); no condition, no branch -- the one predicated instruction is the
   // coefficient store.  The LDS reads of a step; all addresses were known at the end of the previous one
+#if AA_STEP_PRELOAD
+  const uint32_t pbyte = L.pre_prob, raw = L.pre_raw, nband = L.pre_band;   // (asked for when the previous step -- or whoever moved the lane since -- knew the addresses)
+  const V8 rec = L.pre_rec;
+#else
   const uint32_t pbyte = *lds_at<const uint8_t>( smem, L.paddr );
   const uint32_t raw = *lds_at<const uint8_t>( smem, L.sbase | ( L.rpos & ( kRing - 1 ) ) );
   const V8 rec = *lds_at<const V8>( smem, L.rec );
   const uint32_t nband = *lds_at<const uint8_t>( smem, L.ia + 1u );       // 33 * band of the NEXT position (the only one the row can move to)
+#endif
+  const uint32_t was_idle = L.rec;              // (the record this step decodes: L.rec moves on below)
 
   // ... and while they travel: the renormalisation the previous step left undone (bool_decoder.hh:94-105; a lane's decoder is
   // normalised everywhere but between two steps -- the shift of an already normalised range is 0)
@@ -905,7 +943,7 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
   const uint32_t tn = L.typeaddr + nband;       // (the row of the next position, but for the context the token leaves)
 
   // an idle lane (record address >= 512) decodes with probability 256: split = range, nothing of its decoder moves
-  const uint32_t prob = L.rec >= 512u ? 256u : pbyte;
+  const uint32_t prob = was_idle >= 512u ? 256u : pbyte;
   // BoolDecoder::get (bool_decoder.hh:67-107)
   const uint32_t split = ( AA_MUL24( L.range - 1, prob ) + 256u ) >> 8;   // = 1 + (((range - 1) * prob) >> 8)
   const uint32_t bigsplit = split << 24;
@@ -924,7 +962,9 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
   const uint32_t rowaddr = AA_BFI( 0u - adv, tn + AA_UBFE( h, 19, 5 ), L.rowaddr );
   const uint32_t paddr = ( static_cast<int32_t>( h ) < 0 ? rowaddr : kXtab ) + AA_UBFE( h, 10, 5 );
   const uint32_t nextrec = ( ia & 16u ) ? static_cast<uint32_t>( R_BEND ) : ( h & 1023u );
-  L.rowaddr = rowaddr; L.paddr = paddr; L.rec = nextrec;
+  const uint32_t pos = L.ia;                    // (the position of the token this step completes, if it does)
+  L.rowaddr = rowaddr; L.paddr = paddr; L.rec = nextrec; L.ia = ia;
+  preload( L, smem );                           // the next step's reads travel while this one stores its coefficient
 
   const uint32_t xs = AA_UBFE( h, 15, 1 );
   const uint32_t mag = ( L.mag << xs ) | ( ( bit ? 1u : 0u ) & xs );    // extra bits shift in; everything else leaves it alone
@@ -934,14 +974,13 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
   if constexpr ( PK ) {                         // the next value of the block, its zigzag position into the mask
     if ( emit ) *L.blk = coeff;
     L.blk = bump_words( L.blk, emit );
-    L.zzmask |= emit << ( L.ia & 31u );
+    L.zzmask |= emit << ( pos & 31u );
   } else {
-    const uint32_t zz = static_cast<uint32_t>( kZigzagNib >> ( ( L.ia & 15u ) * 4 ) ) & 15u;
+    const uint32_t zz = static_cast<uint32_t>( kZigzagNib >> ( ( pos & 15u ) * 4 ) ) & 15u;
     if ( emit ) L.blk[zz] = coeff;
     L.nonzero |= emit;
   }
   L.mag = emit ? 0u : mag;
-  L.ia = ia;
 }
 
 // ---- the end of a block, for the lanes that wait for it (R_BEND): the block's flags and mask word, the macroblock's record
@@ -983,6 +1022,7 @@ AA_HD inline void block_end( Lane & L, uint8_t * smem, const Frame & J, const He
     L.blkbit = 1u << L.blkslot;
     L.nonzero = 0; L.mag = 0;
     L.rec = mbdone ? static_cast<uint32_t>( R_MBDONE ) : 0u;
+    preload( L, smem );
   }
 }
 
@@ -1088,6 +1128,7 @@ AA_HD inline void begin_frame( Lane & L, uint8_t * smem, uint32_t base, const Fr
   L.mwpos = kMetaRing;
   L.pend_mwpos = kNoPend;
   L.rec = R_MB;
+  preload( L, smem );
 }
 
 } // namespace tok

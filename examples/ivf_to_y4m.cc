@@ -5,11 +5,14 @@
 //     -s   continue from a decoder state file in the reference's wire format (written by either implementation;
 //          the reference's minihash check of state against IVF header is the one thing not done)
 //     -o   output file; without it the stream is decoded and discarded (useful for timing)
+//     -l   look-ahead in frames (default 16; 0 = frame by frame, the reference's way): that many frames of the file are handed to the
+//          library at a time and their entropy decode runs frame-parallel on its host lanes (FilePlayer::set_look_ahead)
 //
 //   g++ -std=c++14 -O2 -Iinclude examples/ivf_to_y4m.cc -Lalfalfa_amd/lib -lalfalfa_amd -Wl,-rpath,$PWD/alfalfa_amd/lib
 #define ALFALFA_AMD_GLOBAL_NAMES
 #include "alfalfa_amd/alfalfa.hh"
 
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <string>
@@ -19,6 +22,7 @@ namespace {
 struct Options
 {
   std::string input, output, state;
+  unsigned int look_ahead = 16;
   bool ok = false;
 };
 
@@ -26,10 +30,11 @@ Options parse_command_line( int argc, char * argv[] )
 {
   Options o;
   for ( int i = 1; i < argc; i++ ) {
-    const bool takes_value = !std::strcmp( argv[i], "-s" ) || !std::strcmp( argv[i], "-o" );
+    const bool takes_value = !std::strcmp( argv[i], "-s" ) || !std::strcmp( argv[i], "-o" ) || !std::strcmp( argv[i], "-l" );
     if ( takes_value ) {
       if ( i + 1 >= argc ) return o;
-      ( argv[i][1] == 's' ? o.state : o.output ) = argv[i + 1];
+      if ( argv[i][1] == 'l' ) o.look_ahead = static_cast<unsigned int>( std::strtoul( argv[i + 1], nullptr, 10 ) );
+      else ( argv[i][1] == 's' ? o.state : o.output ) = argv[i + 1];
       i++;
     } else if ( argv[i][0] == '-' && argv[i][1] != '\0' ) {
       return o;                         // unknown switch
@@ -69,11 +74,12 @@ int main( int argc, char * argv[] )
 {
   const Options opt = parse_command_line( argc, argv );
   if ( !opt.ok ) {
-    std::cerr << "Usage: " << ( argc > 0 ? argv[0] : "ivf_to_y4m" ) << " [-s decoder_state] [-o y4m_output] input_file\n";
+    std::cerr << "Usage: " << ( argc > 0 ? argv[0] : "ivf_to_y4m" ) << " [-s decoder_state] [-o y4m_output] [-l look_ahead_frames] input_file\n";
     return EXIT_FAILURE;
   }
   try {
     Player player = open_player( opt );
+    player.set_look_ahead( opt.look_ahead );
     if ( opt.output.empty() ) {
       play( player, nullptr );
     } else {

@@ -762,6 +762,45 @@ public:
     for ( size_t i = 0; i < decoders.size(); i++ ) out.push_back( decoders[i]->adopt( index[i], shown[i] != 0 ) );
     return out;
   }
+  // LOOK-AHEAD of ONE stream (not in the reference, whose Player decodes frame by frame: player.cc:134-144).  hand_over() gives the next
+  // frames of this decoder's stream to the library in one call -- the header pre-pass runs in the call, every frame BODY is then an
+  // independent chain that the context's host lanes parse side by side (VP8 has no backward adaptation: decoder_state.hh:92-97) --
+  // and returns at once; decode_handed_over( k ) reconstructs the k-th of them (in order) and gives what get_frame_output gives.
+  // A frame the bitstream parser refuses is reported when ITS turn comes, as frame-by-frame decoding would (the frames in front of it
+  // decode; the ones behind it in the same call were not appended and are handed over again by the caller).
+  struct HandedOver { int index; aa_status status; std::string error; };
+  std::vector<HandedOver> hand_over( const std::vector<Chunk> & frames )
+  {
+    std::vector<aa_frame_in> in( frames.size() );
+    std::vector<int> index( frames.size(), -1 );
+    for ( size_t i = 0; i < frames.size(); i++ ) { in[i].stream = owner_->stream; in[i].data = frames[i].buffer(); in[i].size = frames[i].size(); }
+    const aa_status st = frames.empty() ? AA_OK : aa_submit_frames( owner_->ctx->get(), in.data(), static_cast<int>( in.size() ), index.data(), 0 );
+    const std::string msg = st == AA_OK ? std::string() : std::string( aa_last_error() );
+    std::vector<HandedOver> out;
+    bool failed = false;
+    for ( size_t i = 0; i < frames.size(); i++ ) {
+      if ( index[i] >= 0 && !failed ) { out.push_back( { index[i], AA_OK, std::string() } ); continue; }
+      if ( !failed ) { out.push_back( { -1, st == AA_OK ? AA_ERR_LOGIC : st, msg } ); failed = true; }      // the first refused frame carries the error;
+      else out.push_back( { -1, AA_ERR_LOGIC, std::string() } );                                           // the ones behind it were not looked at
+    }
+    return out;
+  }
+  std::pair<bool, RasterHandle> decode_handed_over( const HandedOver & f )
+  {
+    if ( f.status != AA_OK ) {
+      switch ( f.status ) {
+      case AA_ERR_INVALID: throw Invalid( f.error, 0 );
+      case AA_ERR_UNSUPPORTED: throw Unsupported( f.error, 0 );
+      case AA_ERR_OUT_OF_RANGE: throw std::out_of_range( f.error );
+      default: throw DeviceError( f.error );
+      }
+    }
+    aa_frame_header h;
+    check( aa_stream_frame_header( owner_->stream, f.index, &h ) );      // (waits for this frame's parse, not for the others')
+    aa_stream * one[1] = { owner_->stream };
+    check( aa_decode_batch( owner_->ctx->get(), one, 1, &f.index ) );
+    return adopt( f.index, h.show_frame != 0 );
+  }
   // The two-step form (decoder.hh:262-270, decoder.cc:83-118): decompress_frame reads the tag, parse_frame<KeyFrame|InterFrame> runs
   // DecoderState::parse_and_apply (the entropy decode, on a host core), decode_frame reconstructs + filters + updates the
   // references on the GPU.  A frame must be decoded before the next one is parsed into the same decoder (as every caller does).
@@ -892,6 +931,28 @@ class FilePlayer : public FramePlayer
   IVF file_;
   unsigned int frame_no_ = 0;
   std::string filename_;
+  // look-ahead (set_look_ahead; 0 = the reference's frame-by-frame decode): frames [window_first_, window_first_ + window_.size()) of the
+  // file have been handed over (Decoder::hand_over), frame_no_ is the next to reconstruct
+  unsigned int look_ahead_ = 0, window_first_ = 0;
+  std::vector<Decoder::HandedOver> window_;
+  Optional<RasterHandle> decode_next()
+  {
+    if ( look_ahead_ == 0 ) return decode( file_.frame( frame_no_++ ) );
+    if ( frame_no_ >= window_first_ + window_.size() || frame_no_ < window_first_ ) {
+      std::vector<Chunk> next;
+      for ( unsigned int k = frame_no_; k < file_.frame_count() && k < frame_no_ + look_ahead_; k++ ) next.push_back( file_.frame( k ) );
+      window_ = decoder_.hand_over( next );
+      window_first_ = frame_no_;
+    }
+    const Decoder::HandedOver f = window_[frame_no_ - window_first_];
+    frame_no_++;
+    if ( f.index < 0 && f.status == AA_ERR_LOGIC && f.error.empty() ) {   // behind a refused frame of its call: not looked at yet -- by itself, now
+      window_.clear();
+      return decode( file_.frame( frame_no_ - 1 ) );
+    }
+    const std::pair<bool, RasterHandle> out = decoder_.decode_handed_over( f );
+    return make_optional( out.first, out.second );
+  }
   FilePlayer( const std::string & filename, IVF && file )
     : FramePlayer( file.width(), file.height() ), file_( std::move( file ) ), filename_( filename )
   {
@@ -914,11 +975,14 @@ public:
   RasterHandle advance()                                  // player.cc:134-144
   {
     while ( !eof() ) {
-      Optional<RasterHandle> raster = decode( file_.frame( frame_no_++ ) );
+      Optional<RasterHandle> raster = decode_next();
       if ( raster.initialized() ) return raster.get();
     }
     throw Unsupported( "hidden frames at end of file" );
   }
+  // (not in the reference) hand the next `frames` frames of the file over at a time: their entropy decode runs frame-parallel on the
+  // library's host lanes while earlier frames are reconstructed; the output is what frame-by-frame decoding gives
+  void set_look_ahead( const unsigned int frames ) { look_ahead_ = frames; window_.clear(); }
   bool eof() const { return frame_no_ == file_.frame_count(); }
   unsigned int cur_frame_no() const { return frame_no_ - 1; }
   long unsigned int original_size() const { return file_.frame( cur_frame_no() ).size(); }

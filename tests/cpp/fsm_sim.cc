@@ -108,6 +108,7 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
     aa::tok::Frame F = aa::tok::frame_of( &J );
     const uint32_t lane_bytes = aa::tok::lane_lds_bytes( J.fp.mbw, J.fp.nparts > 1 );
     aa::tok::init_lane( L, aa::tok::ring_addr( 0 ), aa::tok::slice_addr( 0, 1, lane_bytes ) );
+    aa::tok::preload( L, smem );
     aa::tok::begin_frame( L, smem, L.base, F );
     for ( ;; ) {
       aa::tok::top_up( L, smem, F );

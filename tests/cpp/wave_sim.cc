@@ -228,6 +228,7 @@ int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_
   for ( int k = 0; k < lanes; k++ ) {
     std::memset( static_cast<void *>( &L[k] ), 0xA5, sizeof( Lane ) );
     init_lane( L[k], ring_addr( static_cast<uint32_t>( k ) ), slice_addr( static_cast<uint32_t>( k ), static_cast<uint32_t>( lanes ), lane_bytes ) );
+    preload( L[k], smem );
   }
   std::deque<int> queue, held;
   size_t published = 0;

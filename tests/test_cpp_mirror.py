@@ -76,12 +76,34 @@ def test_frontend_ports_build_and_fail_loudly_without_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("look_ahead", [0, 3, 16])
 @pytest.mark.parametrize("name", ["qcif_q30_lf24", "w200_q40_lf63s7", "synth_175x143_s3"])
-def test_ivf_to_y4m_matches_reference_dump(tmp_path, name):
-    """frontend/vp8decode.cc port: `-o out.y4m` = header + FRAME-delimited display rectangles of the shown frames."""
+def test_ivf_to_y4m_matches_reference_dump(tmp_path, name, look_ahead):
+    """frontend/vp8decode.cc port: `-o out.y4m` = header + FRAME-delimited display rectangles of the shown frames -- frame by frame
+    (-l 0: the reference's Player), and with the file handed over 3 / 16 frames at a time (FilePlayer::set_look_ahead: the frames'
+    entropy decode runs frame-parallel on the library's host lanes; the synthetic stream uses segmentation and hidden frames)."""
     out = tmp_path / "o.y4m"
-    subprocess.run([build_example("ivf_to_y4m"), "-o", str(out), os.path.join(GOLDEN_DIR, name + ".ivf")], check=True)
+    subprocess.run([build_example("ivf_to_y4m"), "-l", str(look_ahead), "-o", str(out), os.path.join(GOLDEN_DIR, name + ".ivf")], check=True)
     assert hashlib.sha1(y4m_payload(out.read_bytes(), name)).hexdigest() == GOLDEN[name]["display_sha1"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("look_ahead", [0, 4])
+def test_ivf_to_y4m_reports_a_refused_frame_when_its_turn_comes(tmp_path, look_ahead):
+    """A frame the bitstream parser refuses in the middle of a file: the frames in front of it are written, then the error -- the same
+    output and the same message with and without a look-ahead (the refused frame sits inside a hand-over of several)."""
+    from conftest import golden_frames
+    name = "qcif_q30_lf24"
+    _, _, frames = golden_frames(name)
+    bad = list(frames[:6])
+    bad[3] = bytes([bad[3][0] | 0x02]) + bad[3][1:]            # version 1: "unsupported bitstream" (uncompressed_chunk.cc:56-74)
+    path = str(tmp_path / "bad.ivf")
+    _write_ivf(path, name, bad)
+    out = tmp_path / "o.y4m"
+    r = subprocess.run([build_example("ivf_to_y4m"), "-l", str(look_ahead), "-o", str(out), path], capture_output=True, text=True)
+    assert r.returncode != 0 and "nsupported" in r.stderr, r.stderr
+    data = out.read_bytes()
+    assert data.count(b"FRAME\n") == 3, (look_ahead, data.count(b"FRAME\n"))
 
 
 @pytest.mark.gpu
