@@ -84,7 +84,10 @@ int launch_segment_fixup( const ParseJob * jobs, const aa_seg_stream * streams, 
 // token workers (tok_fsm.hh, parse_kernels.hip): lanes that take frames from a queue in HBM
 void token_worker_shape( uint32_t lane_bytes, int n_cus, int * lanes_out, uint32_t * lds_out, int * wgs_per_cu_out );
 int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap & heap, uint32_t * exited, const uint32_t * retire, uint32_t gen, uint32_t spread,
-                          unsigned long long * prof, unsigned long long linger_ticks, int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, bool packed, uint32_t mp_hint, void * stream );
+                          unsigned long long * prof, unsigned long long linger_ticks, int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, bool packed, uint32_t mp_hint, void * stream,
+                          uint32_t * cu_slots = nullptr, uint32_t cu_cap = 0 );
+// (cu_slots: AA_CU_SLOTS counters in HBM, zero at start -- worker workgroups resident per CU, for the per-CU admission of k_token_workers)
+#define AA_CU_SLOTS ( 16 * 256 )
 int launch_enqueue_jobs( TokQueue * q, unsigned long long * slots, const ParseJob * jobs, const uint32_t * order, int n, void * stream );
 int launch_pool_push_range( const Heap & heap, uint32_t first, uint32_t count, void * stream );
 int launch_pool_free_lists( const Heap & heap, const uint32_t * const * lists, int n, void * stream );

@@ -115,6 +115,14 @@ struct WorkerArgs {
   int lanes;
   uint32_t lane_bytes;
   uint32_t mp_hint;                       // one lane per partition: most partitions a frame in flight has (a wave leaves that many lanes per ticket)
+  // Per-CU admission (null: off).  The LDS request is exactly what a workgroup's lanes need, so a FOURTH worker workgroup fits a CU where
+  // the shape wants three -- the reconstruction kernels' pace beside the workers is the LDS the workers leave, and their row kernels'
+  // hand-off chains run at the pace of the CU with the least.  One grid spreads evenly; grids that overlap (top-ups, remnants) do not.
+  // A workgroup counts itself in on the CU it landed on (HW_ID: shader engine, array, CU; XCC_ID) and LEAVES AT ONCE when that CU has
+  // `cu_cap` already -- the host sees it among the exited and tops up, and the dispatcher, which fills the emptiest CUs first, puts the
+  // replacement elsewhere.
+  uint32_t * cu_slots;
+  uint32_t cu_cap;
 };
 
 // up to `want` tickets for this wave (called by ONE lane): -> first ticket in *base, how many as the result; 0 = the queue is
@@ -156,6 +164,19 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t smem[];
   const int lane = threadIdx.x;
+  uint32_t cu_slot = 0;
+  if ( a.cu_slots ) {
+    // HW_REG_HW_ID (4): CU_ID [11:8], SH_ID [12], SE_ID [15:13]; HW_REG_XCC_ID (20) [3:0]
+    const uint32_t hw = __builtin_amdgcn_s_getreg( 4 | ( 8 << 6 ) | ( 7 << 11 ) ), xcc = __builtin_amdgcn_s_getreg( 20 | ( 0 << 6 ) | ( 3 << 11 ) );
+    cu_slot = ( ( xcc & 15u ) << 8 ) | ( hw & 255u );
+    uint32_t before = 0;
+    if ( lane == 0 ) before = AA_AT_ADD( &a.cu_slots[cu_slot], 1u );
+    before = __shfl( before, 0 );
+    if ( before >= a.cu_cap ) {             // this CU has its share of worker workgroups: make room for the reconstruction kernels
+      if ( lane == 0 ) { AA_AT_ADD( &a.cu_slots[cu_slot], 0xFFFFFFFFu ); AA_AT_ADD( &a.cu_slots[AA_CU_SLOTS - 1], 1u ); AA_AT_ADD( a.exited, 1u ); }
+      return;
+    }
+  }
   for ( uint32_t k = lane; k < aa::tok::kTablesBytes / 4; k += 64 ) reinterpret_cast<uint32_t *>( smem )[k] = aa::tok::table_word( k );
   __syncthreads();
   aa::tok::Lane L;
@@ -261,6 +282,7 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
   }
   if ( lane == 0 ) {
     if ( profiling ) for ( int k = 0; k < 8; k++ ) __hip_atomic_fetch_add( &a.prof[k], prof[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    if ( a.cu_slots ) AA_AT_ADD( &a.cu_slots[cu_slot], 0xFFFFFFFFu );
     AA_AT_ADD( a.exited, 1u );
   }
 }
@@ -425,12 +447,14 @@ void token_worker_shape( uint32_t lane_bytes, int n_cus, int * lanes_out, uint32
 }
 
 int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap & heap, uint32_t * exited, const uint32_t * retire, uint32_t gen, uint32_t spread,
-                          unsigned long long * prof, unsigned long long linger_ticks, int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, bool packed, uint32_t mp_hint, void * stream )
+                          unsigned long long * prof, unsigned long long linger_ticks, int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, bool packed, uint32_t mp_hint, void * stream,
+                          uint32_t * cu_slots, uint32_t cu_cap )
 {
   if ( lanes < 1 || wgs < 1 ) return static_cast<int>( hipErrorInvalidValue );
   WorkerArgs a;
   a.q = q; a.slots = slots; a.heap = heap; a.exited = exited; a.retire = retire; a.gen = gen; a.spread = spread ? spread : 1u; a.prof = prof; a.linger_ticks = linger_ticks; a.lanes = lanes; a.lane_bytes = lane_bytes;
   a.mp_hint = mp_hint ? mp_hint : 1u;
+  a.cu_slots = cu_cap ? cu_slots : nullptr; a.cu_cap = cu_cap;
   // (mp_hint != 0: the context allows a lane per partition)
   if ( mp_hint ) {
     if ( packed ) hipLaunchKernelGGL( ( k_token_workers<true, true> ), dim3( wgs ), dim3( 64 ), lds, static_cast<hipStream_t>( stream ), a );
