@@ -117,7 +117,7 @@ SYMBOLS = [
     ("aa_stream_download", C.c_int, [_P, C.c_int, _P, _P, _P]),
     ("aa_pinned_alloc", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]), ("aa_pinned_free", None, [_P]),
     ("aa_stream_download_async", C.c_int, [_P, C.c_int, _P, _P, _P]), ("aa_stream_download_wait", C.c_int, [_P]),
-    ("aa_download_batch_async", C.c_int, [_P, C.POINTER(_P), C.c_int, C.POINTER(C.c_int), _P, C.c_size_t]), ("aa_ctx_download_wait", C.c_int, [_P]),
+    ("aa_download_batch_async", C.c_int, [_P, C.POINTER(_P), C.c_int, C.POINTER(C.c_int), _P, C.c_size_t]), ("aa_ctx_download_wait", C.c_int, [_P]), ("aa_ctx_download_wait_until", C.c_int, [_P, C.c_int]),
     ("aa_stream_raster_device", C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     ("aa_stream_references", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("aa_stream_reference_slots", C.c_int, [_P, C.POINTER(C.c_int)]),

@@ -40,14 +40,16 @@ struct aa_gather_job {
 
 #define AA_MAX_XCD 16
 
+#define AA_SYNC_WS_DUMP 132
 // In-launch ordering state of the row-pipelined kernels; zeroed (hipMemsetAsync) before every such launch.
 struct aa_sync_ws {
   int error;                   // != 0: a bounded spin expired (sticky; reported as AA_ERR_HIP by the host).  NOT zeroed per launch.
   int where[3];                // diagnostics of the FIRST expired wait: unit, row, need << 16 | seen
+  int dump[AA_SYNC_WS_DUMP];   // ... and what that wave saw when it gave up: progress[] of every row of its unit (128), then polls, clock ticks waited, rows
   int ticket[AA_MAX_XCD];      // per-XCD queue: next (unit,row) to hand out  -- zeroed from here on before every launch
   int progress[1];             // [unit in launch][mbh_max]: macroblock columns of that row that are final
 };
-#define AA_SYNC_WS_ZERO_FROM 16   // byte offset of `ticket`
+#define AA_SYNC_WS_ZERO_FROM ( 16 + 4 * AA_SYNC_WS_DUMP )   // byte offset of `ticket`
 
 #define AA_MAX_BATCH 480       // frames per launch and kind: kernel argument = 480 pointers (3840 B) passed by value (limit 4 KB)
 
@@ -87,7 +89,7 @@ int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap &
                           unsigned long long * prof, unsigned long long linger_ticks, int wgs, int lanes, uint32_t lane_bytes, uint32_t lds, bool packed, uint32_t mp_hint, void * stream,
                           uint32_t * cu_slots = nullptr, uint32_t cu_cap = 0 );
 // (cu_slots: AA_CU_SLOTS counters in HBM, zero at start -- worker workgroups resident per CU, for the per-CU admission of k_token_workers)
-#define AA_CU_SLOTS ( 16 * 256 )
+#define AA_CU_SLOTS ( 16 * 256 )       /* (the upper half, but for its last word, is the token lanes' store sink: 8 KB nobody reads) */
 int launch_enqueue_jobs( TokQueue * q, unsigned long long * slots, const ParseJob * jobs, const uint32_t * order, int n, void * stream );
 int launch_pool_push_range( const Heap & heap, uint32_t first, uint32_t count, void * stream );
 int launch_pool_free_lists( const Heap & heap, const uint32_t * const * lists, int n, void * stream );

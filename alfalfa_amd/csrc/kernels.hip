@@ -530,11 +530,28 @@ __global__ __launch_bounds__( kLanes ) void k_recon_intra( const aa_frame_list l
 // round had only the clock and expired once in a 20-step run ("needed 12 saw 11") -- wall time also passes while the whole GPU is
 // held up (the host mapping another GiB into the coefficient heap, pinning an arena), polls do not.  The clock is read once per
 // 1024 polls.  (Lowering the waiting wave's issue priority was tried with it and dropped: no measured gain.)
+// Round 6: SIXTY seconds (and 2^24 polls): ten were run out once in a priming pass of session 13 (1 run in ~60 of the round); the wave
+// that gives up now also leaves what it saw of its unit's rows (wait_expired).
 // Round 5: TEN seconds and 2^24 polls.  Two seconds were run out once more, in a priming pass (heap being mapped, arenas being pinned,
 // sixteen host-lane threads uploading from pageable memory -- since removed): the wait is a safety net against a broken hand-off, and
 // a net that tears under a slow but correct run costs a whole job.
-constexpr unsigned long long kMaxWaitTicks = 1000000000ull;
+constexpr unsigned long long kMaxWaitTicks = 6000000000ull;
 constexpr int kMinPolls = 1 << 24;
+// The first wave whose wait expires says where, and leaves what it sees of its unit's rows at that moment (the row that is not
+// moving while the row above it is far ahead, or done, is the one to look at)
+__device__ __noinline__ void wait_expired( aa_sync_ws * ws, const int code, const int group, const int row, const int need, const int seen, const int * progress, const int mbh,
+                                           const int spins, const unsigned long long waited )
+{
+  int won = 0;
+  if ( threadIdx.x == 0 ) won = atomicCAS( &ws->error, 0, code ) == 0;
+  if ( !__shfl( won, 0 ) ) return;
+  progress = reinterpret_cast<const int *>( static_cast<uintptr_t>( __shfl( static_cast<unsigned long long>( reinterpret_cast<uintptr_t>( progress ) ), 0 ) ) );   // (k_recon_intra4: a row array per frame of the wave -- lane 0's)
+  for ( int i = threadIdx.x; i < 128; i += 64 ) ws->dump[i] = i < mbh ? __hip_atomic_load( &progress[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) : -1;
+  if ( threadIdx.x == 0 ) {
+    ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( need << 16 ) | ( seen & 0xFFFF );
+    ws->dump[128] = spins; ws->dump[129] = static_cast<int>( waited / 100000ull ); ws->dump[130] = mbh;      // (ms)
+  }
+}
 __device__ __forceinline__ int xcc_id() { return static_cast<int>( __builtin_amdgcn_s_getreg( 20 | ( 0 << 6 ) | ( 3 << 11 ) ) ); }   // HW_REG_XCC_ID[3:0]
 
 __device__ __forceinline__ int take_ticket( aa_sync_ws * ws, const int xcc, int * slot, const int lane )
@@ -828,7 +845,7 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
           if ( xcc_id() != home_xcc ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 4 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( home_xcc << 16 ) | xcc_id(); } break; }
           const unsigned long long now = wall_clock64();
           if ( !wait_t0 ) wait_t0 = now;
-          else if ( spins > kMinPolls && now - wait_t0 > kMaxWaitTicks ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 1 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( need << 16 ) | ( seen & 0xFFFF ); } break; }
+          else if ( spins > kMinPolls && now - wait_t0 > kMaxWaitTicks ) { wait_expired( ws, 1, group, row, need, seen, progress, mbh_max, spins, now - wait_t0 ); break; }
         }
       }
 
@@ -1389,7 +1406,7 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
             if ( xcc_id() != home_xcc ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 4 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( home_xcc << 16 ) | xcc_id(); } break; }
             const unsigned long long now = wall_clock64();
             if ( !wait_t0 ) wait_t0 = now;
-            else if ( spins > kMinPolls && now - wait_t0 > kMaxWaitTicks ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 2 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( need << 16 ) | ( seen & 0xFFFF ); } break; }
+            else if ( spins > kMinPolls && now - wait_t0 > kMaxWaitTicks ) { wait_expired( ws, 2, group, row, need, seen, progress, mbh, spins, now - wait_t0 ); break; }
           }
         }
   

@@ -24,6 +24,10 @@
 #include "tok_fsm.hh"
 #include "coeff_pack.hh"
 
+#ifndef AA_WORKER_PRIO
+#define AA_WORKER_PRIO 0
+#endif
+
 namespace {
 
 using aa::ParseJob;
@@ -123,6 +127,7 @@ struct WorkerArgs {
   // replacement elsewhere.
   uint32_t * cu_slots;
   uint32_t cu_cap;
+  int16_t * sink;                         // 8 KB nobody reads: where a lane without a chunk stores (tok::step), a 64-byte line per workgroup (mod 64)
 };
 
 // up to `want` tickets for this wave (called by ONE lane): -> first ticket in *base, how many as the result; 0 = the queue is
@@ -164,6 +169,9 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
 {
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t smem[];
   const int lane = threadIdx.x;
+#if AA_WORKER_PRIO
+  __builtin_amdgcn_s_setprio( AA_WORKER_PRIO );     // (build parameter, A/B runs: the issue arbiter's priority of a worker wave; the reconstruction kernels run at 3)
+#endif
   uint32_t cu_slot = 0;
   if ( a.cu_slots ) {
     // HW_REG_HW_ID (4): CU_ID [11:8], SH_ID [12], SE_ID [15:13]; HW_REG_XCC_ID (20) [3:0]
@@ -183,7 +191,8 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
   aa::tok::Frame F {};
   // (threads that are no token lanes run the steps too -- idle, at the addresses of lane 0: reads only)
   const bool is_lane = lane < a.lanes;
-  aa::tok::init_lane( L, aa::tok::ring_addr( is_lane ? lane : 0 ), aa::tok::slice_addr( is_lane ? lane : 0, a.lanes, a.lane_bytes ) );
+  aa::tok::init_lane( L, aa::tok::ring_addr( is_lane ? lane : 0 ), aa::tok::slice_addr( is_lane ? lane : 0, a.lanes, a.lane_bytes ),
+                      (AA_GLOBAL int16_t *) ( a.sink + ( blockIdx.x & 63u ) * 32u + ( lane & 31 ) ) );
   aa::tok::preload( L, smem );              // (the tables are in LDS: an idle lane's record, probability, band)
   uint32_t backoff = 0;
   unsigned long long idle_since = 0;      // the wave has had no frame since (0: it has one)
@@ -455,6 +464,7 @@ int launch_token_workers( TokQueue * q, unsigned long long * slots, const Heap &
   a.q = q; a.slots = slots; a.heap = heap; a.exited = exited; a.retire = retire; a.gen = gen; a.spread = spread ? spread : 1u; a.prof = prof; a.linger_ticks = linger_ticks; a.lanes = lanes; a.lane_bytes = lane_bytes;
   a.mp_hint = mp_hint ? mp_hint : 1u;
   a.cu_slots = cu_cap ? cu_slots : nullptr; a.cu_cap = cu_cap;
+  a.sink = reinterpret_cast<int16_t *>( cu_slots + AA_CU_SLOTS / 2 );       // (the upper half of the counters' buffer: slots are < 2048)
   // (mp_hint != 0: the context allows a lane per partition)
   if ( mp_hint ) {
     if ( packed ) hipLaunchKernelGGL( ( k_token_workers<true, true> ), dim3( wgs ), dim3( 64 ), lds, static_cast<hipStream_t>( stream ), a );

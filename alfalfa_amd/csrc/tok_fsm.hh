@@ -64,6 +64,18 @@
 
 #include "parse_common.hh"
 
+#ifndef AA_STEP_UNROLL
+#define AA_STEP_UNROLL 1              /* build parameter (A/B runs): the kBendEvery steps of a group unrolled */
+#endif
+#ifndef AA_STEP_SCHED_BARRIER
+#define AA_STEP_SCHED_BARRIER 1       /* build parameter (A/B runs): a scheduling barrier between the load-independent and the load-dependent half of a step */
+#endif
+#ifndef AA_SLICE_SKEW
+#define AA_SLICE_SKEW 0               /* build parameter (A/B runs) */
+#endif
+#ifndef AA_STEP_STORE_ALWAYS
+#define AA_STEP_STORE_ALWAYS 1        /* build parameter (A/B runs): 0 = the coefficient store of a step under `if ( emit )` */
+#endif
 #ifndef AA_STEP_PRELOAD
 #define AA_STEP_PRELOAD 1             /* build parameter (A/B runs): the step's LDS reads are asked for at the end of the previous step (tok::preload) */
 #endif
@@ -229,7 +241,13 @@ static_assert( kPlaneY % 8 == 0 && kPlaneUV % 8 == 0 && kPlaneY2 % 8 == 0 && kPl
 AA_HD constexpr uint32_t above_bytes( uint32_t mbw, bool shared ) { return shared ? 2u * mbw : mbw + ( mbw + 7u ) / 8u; }
 // then, only for frames with more than one token partition: 8 saved partition decoders x 16 bytes
 AA_HD constexpr uint32_t part_off( uint32_t mbw, bool shared ) { return ( kAbove + above_bytes( mbw, shared ) + 15 ) & ~15u; }
-AA_HD constexpr uint32_t lane_lds_bytes( uint32_t mbw, bool multi_partition, bool shared = false ) { return kRing + part_off( mbw, shared ) + ( multi_partition ? 128u : 0u ); }     // ring + slice
+// (AA_SLICE_SKEW: a slice of an ODD number of 16-byte units -- consecutive lanes' slices then start 4 * odd banks apart (8 different bank
+// phases) instead of 0 / 16 banks: lanes that read the same probability of their frames hit the same bank 4 ways instead of 15)
+AA_HD constexpr uint32_t slice_skew( uint32_t slice ) { return AA_SLICE_SKEW && ( slice / 16u ) % 2u == 0u ? 16u : 0u; }
+AA_HD constexpr uint32_t lane_lds_bytes( uint32_t mbw, bool multi_partition, bool shared = false )     // ring + slice
+{
+  return kRing + part_off( mbw, shared ) + ( multi_partition ? 128u : 0u ) + slice_skew( part_off( mbw, shared ) + ( multi_partition ? 128u : 0u ) );
+}
 // (The flags were tried in HBM -- 240 bytes of LDS per lane at 1080p would buy 15 % more chains per CU --, the lane keeping the
 // eight columns it passes in registers.  Measured on MI355X, round 3: every use of those registers costs the wave an
 // s_waitcnt vmcnt(0), i.e. a drain of ALL its outstanding coefficient stores at every macroblock boundary of every lane;
@@ -475,6 +493,7 @@ struct Lane {
   uint32_t nchunks;               // chunks taken so far
   unsigned long long mem_since;   // waiting for a chunk since (0: not waiting)
   // packed storage only (then blk = where the next coefficient value goes, blk_index = first block of the chunk being filled):
+  AA_GLOBAL int16_t * sink;       // (packed) where blk points while the lane has no chunk: a word nobody reads (see step: the store is unconditional)
   AA_GLOBAL int16_t * hdr;        // the macroblock's first word = mask slot 0 (a block that ends non-zero writes its slot); blk = the next value
   uint32_t zzmask;                // zigzag positions of the block in progress that hold a coefficient
   uint32_t words;                 // words used in the chunks left behind
@@ -718,6 +737,7 @@ AA_HD inline void finish_frame( Lane & L, const Frame & J, const Heap & H, uint3
   sum->done = 1u;
 #endif
   L.rec = R_DONE;
+  L.blk = L.sink;                 // (the chunk is the frame's from here on: this lane's steps must not touch it any more)
 }
 
 // One lane per partition: this lane is through with its rows (or gives up: status != TOK_OK, which the other lanes of the frame
@@ -732,6 +752,7 @@ AA_HD inline void finish_partition( Lane & L, uint8_t * smem, const Frame & J, c
   AA_LDS_ADD( smem, sh + offsetof( MpShared, blocks ), L.coeff_blocks );
   AA_LDS_ADD( smem, sh + offsetof( MpShared, words ), words );
   AA_LDS_ADD( smem, sh + offsetof( MpShared, steps ), L.steps );
+  L.blk = L.sink;                 // (as in finish_frame)
   const uint32_t left = AA_LDS_ADD( smem, sh + offsetof( MpShared, left ), 0xFFFFFFFFu );
   // (the owner finishes last when all goes well -- it has the last row; when lanes give up it may not: then it stays, parked,
   // until the others are through with what its slice holds)
@@ -787,6 +808,11 @@ AA_HD inline void load_plane( uint8_t * smem, uint32_t at, const Frame & J, uint
 
 constexpr unsigned long long kMemWaitTicks = 200000000ull;      // 2 s of the 100 MHz clock: then the frame is handed back (TOK_NO_MEMORY)
 
+// The pass in PHASES (round 6): what a macroblock boundary decides -- wait, a coded macroblock to set up, the frame (or partition)
+// through, a partition switch -- is found by a loop that walks runs of skipped macroblocks and touches only the lane's position
+// (mi, col, row, the non-zero flags); what follows from the verdict is straight-line code behind the loop.  With the set-up inside
+// the loop (every exit a `return`) the compiler carried every field of the lane any exit writes through the loop's merge points:
+// ~85 register copies per pass, each an issue slot of the whole wave.
 template <bool PK, bool MP = false>
 AA_HD inline void macroblock_boundary_body( Lane & L, uint8_t * smem, const Frame & J, const Heap & H )
 {
@@ -802,81 +828,28 @@ AA_HD inline void macroblock_boundary_body( Lane & L, uint8_t * smem, const Fram
     L.mi++; L.col++; L.rec = R_MB;
     if constexpr ( MP ) { L.mi_real++; if ( mp ) *lds_at<uint32_t>( smem, shared + 4 * J.mp_p ) = L.mi; }       // completed: the row below may follow
   }
-  if ( L.steps > J.max_steps ) {             // cannot happen for any input; if it does the frame is reported, not hung on
-    if ( mp ) finish_partition<PK>( L, smem, J, H, TOK_STEP_BOUND );
-    else finish_frame<PK>( L, J, H, TOK_STEP_BOUND );
-    return;
-  }
-  for ( ;; ) {
-    if constexpr ( MP ) if ( mp && AA_LDS_LOAD( smem, shared + offsetof( MpShared, status ) ) != TOK_OK ) {
-      finish_partition<PK>( L, smem, J, H, TOK_OK );        // another lane of the frame gave up (its status stands): so does this one
-      return;
-    }
-    if ( L.mi == J.nmb ) {
-      if ( mp ) finish_partition<PK>( L, smem, J, H, TOK_OK );
-      else finish_frame<PK>( L, J, H, TOK_OK );
-      return;
-    }
-    if ( L.mi >= L.mwpos ) return;                          // flags not here yet (only a long run of skipped macroblocks gets ahead of the ring)
+  enum : uint32_t { V_WAIT = 0, V_CODED = 1, V_FINISH = 2, V_SWITCH = 3 };
+  uint32_t verdict = V_WAIT, flags = 0, status = TOK_OK;
+  if ( L.steps > J.max_steps ) { verdict = V_FINISH; status = TOK_STEP_BOUND; }      // cannot happen for any input; if it does the frame is reported, not hung on
+  else for ( ;; ) {
+    if constexpr ( MP ) if ( mp && AA_LDS_LOAD( smem, shared + offsetof( MpShared, status ) ) != TOK_OK ) { verdict = V_FINISH; break; }   // another lane of the frame gave up (its status stands): so does this one
+    if ( L.mi == J.nmb ) { verdict = V_FINISH; break; }
+    if ( L.mi >= L.mwpos ) break;                           // flags not here yet (only a long run of skipped macroblocks gets ahead of the ring)
     if ( L.col == J.mbw ) {
       L.col = 0; L.row++; L.ctxbits = 0;
       if constexpr ( MP ) if ( mp ) L.mi_real += ( J.mp_P - 1u ) * J.mbw;      // this lane's next row is P rows further down
-      if ( !mp && J.nparts > 1 ) switch_partition<MP>( L, smem, J, L.row % J.nparts );
+      if ( !mp && J.nparts > 1 ) { verdict = V_SWITCH; break; }               // (the pass after this one goes on from column 0)
     }
     if constexpr ( MP ) if ( mp && ( J.mp_p | L.row ) != 0 ) {
       // (r, c) needs the flags (r - 1, c) left behind: row r - 1 is the previous partition's -- its L.row-th row, or, for
       // partition 0, the last partition's (L.row - 1)-th
       const uint32_t q = J.mp_p ? J.mp_p - 1u : J.mp_P - 1u, k = J.mp_p ? L.row : L.row - 1u;
-      if ( AA_LDS_LOAD( smem, shared + 4 * q ) < k * J.mbw + L.col + 1u ) return;     // not there yet: ask again at the next pass
+      if ( AA_LDS_LOAD( smem, shared + 4 * q ) < k * J.mbw + L.col + 1u ) break;      // not there yet: ask again at the next pass
     }
-    const uint32_t flags = smem[L.base + kMeta + ( L.mi & ( kMetaRing - 1 ) )];
-    const uint32_t has_y2 = flags & AA_MB_HAS_Y2;
+    flags = smem[L.base + kMeta + ( L.mi & ( kMetaRing - 1 ) )];
     L.ctxbits = ( L.ctxbits & 0x01FF0000u ) | above_load<MP>( smem, above, J.mbw, L.col );
-    if ( !( flags & AA_MB_SKIP ) ) {
-      // words of the chunk in use (packed storage; between macroblocks blk = the next free word)
-      const uint32_t used = PK && L.nchunks ? static_cast<uint32_t>( L.blk - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) ) : 0u;
-      if ( PK ? ( !L.nchunks || used + kMbWords > kChunkWords ) : L.blk_left < kMbBlocks ) {   // the chunk cannot take a whole macroblock: on to a new one
-        const uint32_t c = pool_take( H );
-        if ( c == kNoChunk ) {
-          // nothing free right now: this lane sits the steps out and asks again at the next boundary pass (its wave-mates keep
-          // decoding).  The host maps more heap when it sees lanes starve; if nothing comes for kMemWaitTicks the frame is
-          // handed back unfinished and the host runs it again when memory has been released.
-          const unsigned long long now = AA_NOW();
-          if ( !L.mem_since ) { L.mem_since = now | 1ull; AA_AT_ADD( &H.pool->starving, 1u ); }
-          else if ( now - L.mem_since > kMemWaitTicks ) { if ( mp ) finish_partition<PK>( L, smem, J, H, TOK_NO_MEMORY ); else finish_frame<PK>( L, J, H, TOK_NO_MEMORY ); }
-          return;
-        }
-        L.mem_since = 0;
-        if ( mp ) {
-          L.chunk_ord = AA_LDS_ADD( smem, shared + offsetof( MpShared, nchunks ), 1u );
-          J.chunk_list[1 + L.chunk_ord] = c;
-        } else {
-          J.chunk_list[1 + L.nchunks] = c;
-          if constexpr ( MP ) L.chunk_ord = L.nchunks;
-        }
-        L.nchunks++;
-        L.blk_index = c * kChunkBlocks;
-        if constexpr ( PK ) {
-          L.words += used;
-          L.blk = H.base + static_cast<size_t>( L.blk_index ) * 16;
-        } else {
-          L.blk = H.base + static_cast<size_t>( L.blk_index ) * 16;
-          L.blk_left = kChunkBlocks;
-          zero_slot( L.blk );
-        }
-      }
-      if constexpr ( PK ) {
-        // the macroblock's words: kMaskSlots mask slots, then the values (coeff_pack.hh)
-        L.mb_first = ( ( MP ? L.chunk_ord : L.nchunks - 1u ) << 15 ) | static_cast<uint32_t>( L.blk - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) );
-        L.hdr = L.blk; L.blk = L.hdr + kMbMaskSlots; L.zzmask = 0;
-      } else L.mb_first = L.blk_index;
-      L.flags = flags; L.nz_mask = 0;
-      const uint32_t kind = has_y2 ? Y_AFTER_Y2 : Y_WITHOUT_Y2;
-      if ( L.ykind != kind ) { load_plane( smem, L.base + kPlaneY, J, kind ); L.ykind = kind; }
-      L.yfirst = has_y2 ? 1u : 0u;
-      setup_block( L, smem, has_y2 ? 0u : 1u );
-      return;
-    }
+    if ( !( flags & AA_MB_SKIP ) ) { verdict = V_CODED; break; }
+    const uint32_t has_y2 = flags & AA_MB_HAS_Y2;
     L.ctxbits &= has_y2 ? 0u : 0x01000100u;                 // a non-coded Y2 leaves its chain untouched (frame.cc:255-269)
     above_store<MP>( smem, above, J.mbw, L.col, L.ctxbits );
     const uint32_t mi_rec = MP ? L.mi_real : L.mi;
@@ -885,6 +858,58 @@ AA_HD inline void macroblock_boundary_body( Lane & L, uint8_t * smem, const Fram
     L.mi++; L.col++;
     if constexpr ( MP ) { L.mi_real++; if ( mp ) *lds_at<uint32_t>( smem, shared + 4 * J.mp_p ) = L.mi; }
   }
+  if ( verdict == V_WAIT ) return;
+  if ( verdict == V_SWITCH ) { switch_partition<MP>( L, smem, J, L.row % J.nparts ); return; }
+  if ( verdict == V_FINISH ) {
+    if ( mp ) finish_partition<PK>( L, smem, J, H, status );
+    else finish_frame<PK>( L, J, H, status );
+    return;
+  }
+  // ---- a coded macroblock ----
+  const uint32_t has_y2 = flags & AA_MB_HAS_Y2;
+  // words of the chunk in use (packed storage; between macroblocks blk = the next free word)
+  const uint32_t used = PK && L.nchunks ? static_cast<uint32_t>( L.blk - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) ) : 0u;
+  // (+ 1: blk -- one past the macroblock's last value when all 400 are there -- stays inside the lane's own chunk: the step stores at it)
+  if ( PK ? ( !L.nchunks || used + kMbWords + 1u > kChunkWords ) : L.blk_left < kMbBlocks ) {   // the chunk cannot take a whole macroblock: on to a new one
+    const uint32_t c = pool_take( H );
+    if ( c == kNoChunk ) {
+      // nothing free right now: this lane sits the steps out and asks again at the next boundary pass (its wave-mates keep
+      // decoding).  The host maps more heap when it sees lanes starve; if nothing comes for kMemWaitTicks the frame is
+      // handed back unfinished and the host runs it again when memory has been released.
+      const unsigned long long now = AA_NOW();
+      if ( !L.mem_since ) { L.mem_since = now | 1ull; AA_AT_ADD( &H.pool->starving, 1u ); }
+      else if ( now - L.mem_since > kMemWaitTicks ) { if ( mp ) finish_partition<PK>( L, smem, J, H, TOK_NO_MEMORY ); else finish_frame<PK>( L, J, H, TOK_NO_MEMORY ); }
+      return;
+    }
+    L.mem_since = 0;
+    if ( mp ) {
+      L.chunk_ord = AA_LDS_ADD( smem, shared + offsetof( MpShared, nchunks ), 1u );
+      J.chunk_list[1 + L.chunk_ord] = c;
+    } else {
+      J.chunk_list[1 + L.nchunks] = c;
+      if constexpr ( MP ) L.chunk_ord = L.nchunks;
+    }
+    L.nchunks++;
+    L.blk_index = c * kChunkBlocks;
+    if constexpr ( PK ) {
+      L.words += used;
+      L.blk = H.base + static_cast<size_t>( L.blk_index ) * 16;
+    } else {
+      L.blk = H.base + static_cast<size_t>( L.blk_index ) * 16;
+      L.blk_left = kChunkBlocks;
+      zero_slot( L.blk );
+    }
+  }
+  if constexpr ( PK ) {
+    // the macroblock's words: kMaskSlots mask slots, then the values (coeff_pack.hh)
+    L.mb_first = ( ( MP ? L.chunk_ord : L.nchunks - 1u ) << 15 ) | static_cast<uint32_t>( L.blk - ( H.base + static_cast<size_t>( L.blk_index ) * 16 ) );
+    L.hdr = L.blk; L.blk = L.hdr + kMbMaskSlots; L.zzmask = 0;
+  } else L.mb_first = L.blk_index;
+  L.flags = flags; L.nz_mask = 0;
+  const uint32_t kind = has_y2 ? Y_AFTER_Y2 : Y_WITHOUT_Y2;
+  if ( L.ykind != kind ) { load_plane( smem, L.base + kPlaneY, J, kind ); L.ykind = kind; }
+  L.yfirst = has_y2 ? 1u : 0u;
+  setup_block( L, smem, has_y2 ? 0u : 1u );
 }
 
 template <bool PK, bool MP = false>
@@ -934,6 +959,13 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
   L.range <<= ( shift & 31 );
   L.value <<= ( shift & 31 );
   L.sh += shift;
+#if AA_STEP_SCHED_BARRIER && defined( __HIP_DEVICE_COMPILE__ )
+  // Everything above this line -- the previous step's coefficient store and bookkeeping, this step's renormalisation -- needs none of the
+  // four values asked for by the previous step's preload(), everything below does: the scheduler keeps the two apart (left alone it has
+  // put the first wait 8 instructions behind the reads and the independent work behind the wait: a lone wave per SIMD then sits the
+  // LDS round trip out).
+  __builtin_amdgcn_sched_barrier( 0 );
+#endif
   // top the window up by one byte whenever one fits (sh >= 0): a decode shifts out at most 7 bits, so the 8 bits being
   // compared are always real and the refill is never on the critical path.  Mask arithmetic, no condition.
   const uint32_t room = ~static_cast<uint32_t>( L.sh >> 31 );
@@ -965,6 +997,9 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
   const uint32_t pos = L.ia;                    // (the position of the token this step completes, if it does)
   L.rowaddr = rowaddr; L.paddr = paddr; L.rec = nextrec; L.ia = ia;
   preload( L, smem );                           // the next step's reads travel while this one stores its coefficient
+#if AA_STEP_SCHED_BARRIER && defined( __HIP_DEVICE_COMPILE__ )
+  __builtin_amdgcn_sched_barrier( 0 );          // (... and nothing of what follows is done in front of them)
+#endif
 
   const uint32_t xs = AA_UBFE( h, 15, 1 );
   const uint32_t mag = ( L.mag << xs ) | ( ( bit ? 1u : 0u ) & xs );    // extra bits shift in; everything else leaves it alone
@@ -972,7 +1007,16 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
   const int32_t m = static_cast<int32_t>( mag + AA_UBFE( h, 24, 7 ) );
   const int16_t coeff = static_cast<int16_t>( bit ? -m : m );
   if constexpr ( PK ) {                         // the next value of the block, its zigzag position into the mask
+    // The store is UNCONDITIONAL: blk is the next free word of the lane's macroblock (or the lane's sink while it has no chunk), and a
+    // word there that no token completed is either overwritten by the token that does or never read (a reader takes popcount(mask)
+    // values).  As `if ( emit )` it was the step's one predicated region -- an exec-mask save, a branch and a restore that nearly every
+    // step of a wave of 30 lanes ran anyway, and a split of the step into basic blocks the scheduler could not move the LDS reads'
+    // waits across (measured, session 13: the same source scheduled with the waits 17 instructions earlier was 6 % slower).
+#if AA_STEP_STORE_ALWAYS
+    *L.blk = coeff;
+#else
     if ( emit ) *L.blk = coeff;
+#endif
     L.blk = bump_words( L.blk, emit );
     L.zzmask |= emit << ( pos & 31u );
   } else {
@@ -1043,6 +1087,9 @@ AA_HD inline void run_period( Lane & L, uint8_t * smem, const Frame & J, const H
     }
     const uint32_t it0 = it;
     do {
+#if AA_STEP_UNROLL
+#pragma unroll
+#endif
       for ( uint32_t k = 0; k < kBendEvery; k++ ) step<PK, MP>( L, smem, J );
       it += kBendEvery;
       // (asked by ALL lanes, outside the predicated regions: wave-uniform)
@@ -1076,12 +1123,13 @@ AA_HD inline uint32_t table_word( uint32_t k )
 }
 
 // A lane before its first frame: idle (R_DONE), every address the step reads in range -- the step runs for idle lanes too
-AA_HD inline void init_lane( Lane & L, uint32_t sbase, uint32_t base )
+AA_HD inline void init_lane( Lane & L, uint32_t sbase, uint32_t base, AA_GLOBAL int16_t * sink )
 {
+  L.sink = sink;
   L.sbase = sbase; L.base = base;
   L.rec = R_DONE; L.paddr = kXtab + kZeroX; L.ia = kBandTabOff; L.rowaddr = L.typeaddr = base;
   L.value = 0; L.range = 255; L.sh = 0; L.rpos = 0; L.mag = 0; L.zzmask = 0; L.nonzero = 0;
-  L.blk = nullptr; L.hdr = nullptr;
+  L.blk = sink; L.hdr = nullptr;
   L.pend_wpos = L.pend_mwpos = kNoPend;
   L.steps = 0;
 }
@@ -1106,7 +1154,7 @@ AA_HD inline void begin_frame( Lane & L, uint8_t * smem, uint32_t base, const Fr
   L.ia = kBandTabOff;
   L.typeaddr = L.rowaddr = base; L.paddr = kXtab + kZeroX;
   L.blkaddr = kBlockTabOff;
-  L.blk = nullptr; L.blk_index = 0; L.blk_left = 0; L.nchunks = 0; L.mem_since = 0;     // the first coded macroblock takes the first chunk
+  L.blk = L.sink; L.blk_index = 0; L.blk_left = 0; L.nchunks = 0; L.mem_since = 0;     // the first coded macroblock takes the first chunk
   L.hdr = nullptr; L.zzmask = 0; L.words = 0;
   L.mi_real = 0; L.chunk_ord = 0;
   if ( J.mp_P > 1 ) {

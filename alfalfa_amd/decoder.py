@@ -197,8 +197,13 @@ class Context:
         idx = (C.c_int * n)(*frame_indices)
         capi.check(self.L.aa_download_batch_async(self.h, arr, n, idx, C.c_void_p(dst_ptr), stride))
 
-    def download_wait(self):
-        capi.check(self.L.aa_ctx_download_wait(self.h))
+    def download_wait(self, max_in_flight=None):
+        """aa_ctx_download_wait: every batched download queued so far has arrived; with max_in_flight: only until at most that many are
+        still on their way (aa_ctx_download_wait_until: a ring of r destination buffers waits with r - 1 before it reuses one)."""
+        if max_in_flight is None:
+            capi.check(self.L.aa_ctx_download_wait(self.h))
+        else:
+            capi.check(self.L.aa_ctx_download_wait_until(self.h, int(max_in_flight)))
 
     def decode_batch(self, decoders, frame_indices):
         n = len(decoders)

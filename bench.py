@@ -49,6 +49,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 BYTES_PER_MB = {"recon_inter": 80 + 800 + 384 + 384, "recon_split": 80 + 800 + 384 + 384, "recon_intra": 80 + 800 + 384, "loopfilter": 768,
                 "parse_tokens": 80 + 800, "parse_headers": 80}
 PATH_BYTES_PER_MB = 2416       # inter + deblock, whole path
+DELIVER_RING = int(os.environ.get("AA_BENCH_DELIVER_RING") or 3)     # pinned slabs the delivered frames go to (one frame index of every stream each)
 KERNEL_NAMES = {"recon_inter": "k_recon_inter4", "recon_split": "k_recon_inter", "recon_intra": "k_recon_intra4", "loopfilter": "k_loopfilter_rows4",
                 "parse_tokens": "k_token_workers", "parse_headers": "k_parse_mb_headers"}
 
@@ -163,6 +164,7 @@ class Pipeline:
         self.t_decode_mark = 0.0
         self.step_series = None
         self.delivered_bytes = 0
+        self.deliveries = 0
         self.refused = 0                                 # times a hand-over was put off because HBM had no room for it
         self.refused_by_the_library = 0                  # ... of which by aa_submit_frames itself (AA_ERR_NO_MEMORY at the context's limit)
         self.urgent_groups = 0                           # groups whose key frames took the host route because they were needed at once
@@ -171,8 +173,9 @@ class Pipeline:
         """Frame f of every decoder of the group -> the pinned ring, behind its reconstruction, beside the next frame's: ONE
         gather kernel + ONE copy for the whole frame index (aa_download_batch_async)."""
         env = self.env
-        slab = env["deliver_ring"][f & 1]
-        self.ctx.download_wait()                    # the copy that used this half of the ring before is through (copy stream)
+        ring = env["deliver_ring"]
+        slab = ring[self.deliveries % len(ring)]; self.deliveries += 1
+        self.ctx.download_wait(len(ring) - 1)       # the copy that used this slab of the ring before is through (not the one queued a frame index ago)
         self.ctx.download_batch_async(ds, [f] * len(ds), slab, env["raster_bytes"])
         self.delivered_bytes += len(ds) * env["raster_bytes"]
 
@@ -713,7 +716,7 @@ def main():
     step_latency_us = env["step_latency_us"]
     plane_sizes, raster_bytes = env["plane_sizes"], env["raster_bytes"]
     if args.deliver:
-        env["deliver_ring"] = [ctx.pinned_alloc(S * raster_bytes) for _ in range(2)]
+        env["deliver_ring"] = [ctx.pinned_alloc(S * raster_bytes) for _ in range(DELIVER_RING)]
     K, D = max(1, args.key_ahead), max(1, min(args.depth, args.key_ahead))
     # what the look-ahead would hold if memory were free (the run itself is bounded by Pipeline._room)
     planned_need_gb = round(S * ((0.5 * K + 1.5) * (env["key_coeff_bytes"] + env["key_arena_bytes"]) + (0.6 * D + 1.0) * (F - 1) * (env["inter_coeff_bytes"] + env["inter_arena_bytes"])
@@ -1016,7 +1019,7 @@ def main():
     # each reconstructed frame gathered and copied to pinned host memory beside the next frame's reconstruction ----
     if delivery is None and args.deliver_steps > 0 and rank == 0:
         try:
-            env3 = dict(env); env3["deliver_ring"] = [ctx.pinned_alloc(S * raster_bytes) for _ in range(2)]
+            env3 = dict(env); env3["deliver_ring"] = [ctx.pinned_alloc(S * raster_bytes) for _ in range(DELIVER_RING)]
             p = Pipeline(env3, streams, K, D, args.header_ahead)
             ctx.sync()
             t0 = time.perf_counter()

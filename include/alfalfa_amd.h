@@ -345,6 +345,10 @@ aa_status aa_stream_download_wait( aa_stream * s );
  * compute stream and ONE copy on the copy stream, instead of 3 n plane copies; valid after aa_ctx_download_wait / aa_ctx_sync. */
 aa_status aa_download_batch_async( aa_ctx * ctx, aa_stream * const * streams, int n, const int * frame_index, uint8_t * dst, size_t stride );
 aa_status aa_ctx_download_wait( aa_ctx * ctx );
+/* ... or only until at most max_in_flight of the batches queued by aa_download_batch_async are still on their way (oldest first): a
+ * player that writes into a ring of r destination buffers calls this with r - 1 before it reuses one -- it waits for the copy that used
+ * the buffer, not for the one queued a moment ago (what vp8decode.cc's display loop gets from double-buffered rasters). */
+aa_status aa_ctx_download_wait_until( aa_ctx * ctx, int max_in_flight );
 /* Device pointers of a frame's planes (valid while the frame's raster is alive). */
 aa_status aa_stream_raster_device( aa_stream * s, int frame_index, void ** y, void ** u, void ** v );
 /* References::last/golden/alternative after the most recently SUBMITTED frame: frame indices (-1 = initial blank). */

@@ -19,6 +19,7 @@
 #include "../../alfalfa_amd/csrc/coeff_pack.hh"
 
 namespace {
+int16_t g_sink = 0;          // where a lane without a chunk stores (tok::step: the store is unconditional)
 struct Sim {
   aa::Parser parser;
   uint32_t pool_chunks = 0;        // coefficient chunks the pool offers per frame (0: plenty)
@@ -107,7 +108,7 @@ int fsm_sim_frame( void * handle, const uint8_t * data, size_t size, aa_frame_he
     std::memset( &L, 0xA5, sizeof L );
     aa::tok::Frame F = aa::tok::frame_of( &J );
     const uint32_t lane_bytes = aa::tok::lane_lds_bytes( J.fp.mbw, J.fp.nparts > 1 );
-    aa::tok::init_lane( L, aa::tok::ring_addr( 0 ), aa::tok::slice_addr( 0, 1, lane_bytes ) );
+    aa::tok::init_lane( L, aa::tok::ring_addr( 0 ), aa::tok::slice_addr( 0, 1, lane_bytes ), &g_sink );
     aa::tok::preload( L, smem );
     aa::tok::begin_frame( L, smem, L.base, F );
     for ( ;; ) {

@@ -20,6 +20,7 @@
 #include "../../alfalfa_amd/csrc/coeff_pack.hh"
 
 namespace {
+int16_t g_sink[64] = {};     // where lanes without a chunk store (tok::step: the store is unconditional)
 
 void * aligned( size_t bytes )
 {
@@ -227,7 +228,7 @@ int wave_sim_run( uint16_t w, uint16_t h, int n_streams, const int * frames_per_
   std::vector<int> job_of( lanes, -1 );
   for ( int k = 0; k < lanes; k++ ) {
     std::memset( static_cast<void *>( &L[k] ), 0xA5, sizeof( Lane ) );
-    init_lane( L[k], ring_addr( static_cast<uint32_t>( k ) ), slice_addr( static_cast<uint32_t>( k ), static_cast<uint32_t>( lanes ), lane_bytes ) );
+    init_lane( L[k], ring_addr( static_cast<uint32_t>( k ) ), slice_addr( static_cast<uint32_t>( k ), static_cast<uint32_t>( lanes ), lane_bytes ), &g_sink[k & 63] );
     preload( L[k], smem );
   }
   std::deque<int> queue, held;

@@ -272,3 +272,41 @@ def test_a_whole_frame_index_is_delivered_by_one_gather_and_one_copy(gpu_ctx):
             gpu_ctx.pinned_free(p)
     with pytest.raises(aa.AlfalfaError):                    # a stride smaller than a raster is refused, nothing is written
         gpu_ctx.download_batch_async(decs, [0] * len(decs), 0x1000, 16)
+
+
+def test_a_ring_of_destination_buffers_waits_for_the_copy_that_used_the_buffer(gpu_ctx):
+    """aa_ctx_download_wait_until(r - 1) in front of the reuse of one of r destination buffers: every frame index, checked as soon as
+    the call says its copy has arrived (i.e. r - 1 frame indices later), is the raster aa_stream_download gives."""
+    import ctypes as C
+    names = ["qcif_q30_lf24", "cif_q60_lf40s5", "qcif_q30"]
+    streams = [golden_frames(n) for n in names]
+    nf = min(len(f) for _, _, f in streams)
+    decs = [aa.Decoder(gpu_ctx, w, h) for w, h, _ in streams]
+    sizes = [sum(d.plane_sizes()) for d in decs]
+    stride = (max(sizes) + 255) & ~255
+    R = 3
+    ring = [gpu_ctx.pinned_alloc(stride * len(decs)) for _ in range(R)]
+    checked = 0
+
+    def check(f):
+        for i, (d, n) in enumerate(zip(decs, names)):
+            assert C.string_at(ring[f % R] + i * stride, sizes[i]) == d.raster_bytes(f), (n, f)
+    try:
+        for f in range(nf):
+            for d, (_, _, frames) in zip(decs, streams):
+                d.parse_frame(frames[f])
+            gpu_ctx.decode_batch(decs, [f] * len(decs))
+            gpu_ctx.download_wait(R - 1)            # the copy of frame index f - R (this slab's last user) is through
+            if f >= R:
+                check(f - R); checked += 1
+            gpu_ctx.download_batch_async(decs, [f] * len(decs), ring[f % R], stride)
+        gpu_ctx.download_wait(0)
+        for f in range(max(0, nf - R), nf):
+            check(f); checked += 1
+        assert checked == nf
+        with pytest.raises(aa.AlfalfaError):
+            gpu_ctx.download_wait(-1)
+    finally:
+        gpu_ctx.sync()
+        for p in ring:
+            gpu_ctx.pinned_free(p)
