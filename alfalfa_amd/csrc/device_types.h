@@ -40,12 +40,14 @@ struct aa_gather_job {
 
 #define AA_MAX_XCD 16
 
-#define AA_SYNC_WS_DUMP 132
+#define AA_SYNC_WS_DUMP 136
+#define AA_SYNC_WS_RESCUES 132
 // In-launch ordering state of the row-pipelined kernels; zeroed (hipMemsetAsync) before every such launch.
 struct aa_sync_ws {
   int error;                   // != 0: a bounded spin expired (sticky; reported as AA_ERR_HIP by the host).  NOT zeroed per launch.
   int where[3];                // diagnostics of the FIRST expired wait: unit, row, need << 16 | seen
-  int dump[AA_SYNC_WS_DUMP];   // ... and what that wave saw when it gave up: progress[] of every row of its unit (128), then polls, clock ticks waited, rows
+  int dump[AA_SYNC_WS_DUMP];   // ... and what that wave saw when it gave up: progress[] of every row of its unit (128), then polls, clock ticks waited, rows;
+                               // [AA_SYNC_WS_RESCUES .. +2]: waits that only the slow path's second look ended (see reread_progress), by which of its reads
   int ticket[AA_MAX_XCD];      // per-XCD queue: next (unit,row) to hand out  -- zeroed from here on before every launch
   int progress[1];             // [unit in launch][mbh_max]: macroblock columns of that row that are final
 };

@@ -537,6 +537,30 @@ __global__ __launch_bounds__( kLanes ) void k_recon_intra( const aa_frame_list l
 // a net that tears under a slow but correct run costs a whole job.
 constexpr unsigned long long kMaxWaitTicks = 6000000000ull;
 constexpr int kMinPolls = 1 << 24;
+// The slow path's second look at the row above (every 1024 polls, ~0.5 ms into a wait).  Session 16's dump of an expired wait showed the
+// row above COMPLETE (120 columns) while the waiting wave's polls -- one agent-scope load of one address for the whole wave -- had
+// returned "38" for sixty seconds ("needed N saw N - 1" every time such a wait has expired, rounds 5 and 6, always in a priming pass):
+// a hand-off that was written and never seen, not a workgroup that was not running.  Whatever held the stale value (the dump's own loads,
+// a microsecond later, from the same CU, were fresh), a second look that shares nothing with the first ends it: the caches invalidated
+// (buffer_inv sc1), the address per lane (a vector-addressed load, not the scalar-base form of the poll), system scope, and a
+// read-modify-write that the L2 itself executes.  progress only grows, so the larger value is the truth.  Counted (ws->dump[RESCUES..]):
+// how many waits ended this way, and by which read.
+__device__ __forceinline__ int reread_progress( aa_sync_ws * ws, const int * p, const int seen, const int need )
+{
+  int off = 0;
+  asm volatile( "" : "+v"( off ) );                       // (opaque: keeps the address in vector registers)
+  int * q = const_cast<int *>( p ) + off;
+  __builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "agent" );
+  const int a = __hip_atomic_load( q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+  const int b = __hip_atomic_fetch_or( q, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+  const int best = max( seen, max( a, b ) );
+  if ( seen < need && best >= need && ( threadIdx.x & 15 ) == 0 ) {
+    atomicAdd( &ws->dump[AA_SYNC_WS_RESCUES], 1 );
+    if ( a >= need ) atomicAdd( &ws->dump[AA_SYNC_WS_RESCUES + 1], 1 );
+    if ( b >= need ) atomicAdd( &ws->dump[AA_SYNC_WS_RESCUES + 2], 1 );
+  }
+  return best;
+}
 // The first wave whose wait expires says where, and leaves what it sees of its unit's rows at that moment (the row that is not
 // moving while the row above it is far ahead, or done, is the one to look at)
 __device__ __noinline__ void wait_expired( aa_sync_ws * ws, const int code, const int group, const int row, const int need, const int seen, const int * progress, const int mbh,
@@ -841,6 +865,7 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
         ++spins;
         if ( ( spins & 1023 ) == 0 ) {
           if ( __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
+          if ( on ) seen = reread_progress( ws, &progress[row - 1], seen, need );
           // the hand-off is only coherent inside the XCD the ticket was taken on: a wave that finds itself elsewhere says so
           if ( xcc_id() != home_xcc ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 4 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( home_xcc << 16 ) | xcc_id(); } break; }
           const unsigned long long now = wall_clock64();
@@ -1401,6 +1426,7 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
           ++spins;
           if ( ( spins & 1023 ) == 0 ) {
             if ( __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
+            seen = reread_progress( ws, &progress[row - 1], seen, need );
             // the hand-off is only coherent inside one XCD: a wave that finds itself on another one (context save / restore
             // under queue oversubscription) says so instead of waiting for the watchdog
             if ( xcc_id() != home_xcc ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 4 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( home_xcc << 16 ) | xcc_id(); } break; }

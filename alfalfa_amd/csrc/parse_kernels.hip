@@ -24,8 +24,13 @@
 #include "tok_fsm.hh"
 #include "coeff_pack.hh"
 
+// The issue arbiter's priority of a worker wave (s_setprio; the reconstruction kernels run at 3).  At 0-2 a reconstruction wave on the same
+// SIMD always issues first; at 3 the arbiter takes the OLDEST ready wave, which is the worker (resident for seconds): a wave step beside
+// the reconstruction kernels 0.216 -> 0.200 us, the reconstruction kernels ~20 % slower, end to end 141.5 -> 146.2 M macroblocks/s
+// (two runs each, profiles/r06_bench_sessions.md session 15; session 13: 141.5 -> 144.7).  The row kernels' hand-off chains still get the
+// issue slots the worker leaves -- it waits for LDS 45 % of the time.
 #ifndef AA_WORKER_PRIO
-#define AA_WORKER_PRIO 0
+#define AA_WORKER_PRIO 3
 #endif
 
 namespace {
@@ -170,7 +175,7 @@ __global__ __launch_bounds__( 64 ) void k_token_workers( const WorkerArgs a )
   extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t smem[];
   const int lane = threadIdx.x;
 #if AA_WORKER_PRIO
-  __builtin_amdgcn_s_setprio( AA_WORKER_PRIO );     // (build parameter, A/B runs: the issue arbiter's priority of a worker wave; the reconstruction kernels run at 3)
+  __builtin_amdgcn_s_setprio( AA_WORKER_PRIO );
 #endif
   uint32_t cu_slot = 0;
   if ( a.cu_slots ) {

@@ -74,7 +74,7 @@
 #define AA_SLICE_SKEW 0               /* build parameter (A/B runs) */
 #endif
 #ifndef AA_STEP_STORE_ALWAYS
-#define AA_STEP_STORE_ALWAYS 1        /* build parameter (A/B runs): 0 = the coefficient store of a step under `if ( emit )` */
+#define AA_STEP_STORE_ALWAYS 2        /* build parameter (A/B runs): 0 = the coefficient store of a step under `if ( emit )`, 1 = always at blk, 2 = at blk or at the sink */
 #endif
 #ifndef AA_STEP_PRELOAD
 #define AA_STEP_PRELOAD 1             /* build parameter (A/B runs): the step's LDS reads are asked for at the end of the previous step (tok::preload) */
@@ -1012,7 +1012,12 @@ AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
     // values).  As `if ( emit )` it was the step's one predicated region -- an exec-mask save, a branch and a restore that nearly every
     // step of a wave of 30 lanes ran anyway, and a split of the step into basic blocks the scheduler could not move the LDS reads'
     // waits across (measured, session 13: the same source scheduled with the waits 17 instructions earlier was 6 % slower).
-#if AA_STEP_STORE_ALWAYS
+#if AA_STEP_STORE_ALWAYS == 2
+    // (... at the lane's sink when no token was completed: with every lane of the wave storing at its own block the store touched 30
+    // cache lines a step instead of the ~6 of the lanes that have a value -- alone 8 % faster, beside the reconstruction kernels 5 %
+    // slower than the predicated store, session 14)
+    *( emit ? L.blk : L.sink ) = coeff;
+#elif AA_STEP_STORE_ALWAYS
     *L.blk = coeff;
 #else
     if ( emit ) *L.blk = coeff;

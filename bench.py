@@ -98,7 +98,7 @@ def parse_args():
     ap.add_argument("--deliver", action="store_true", help="every reconstructed frame is also DELIVERED: copied to pinned host memory (aa_download_batch_async: one "
                     "gather + one copy per frame index) while the next frames are decoded -- what vp8decode / xc-decode-bundle do with every shown frame; "
                     "the timed region then includes PCIe")
-    ap.add_argument("--deliver-steps", type=int, default=6, help="without --deliver: this many steps with every frame delivered AFTER the timed region, reported as `delivery` (0 = skip)")
+    ap.add_argument("--deliver-steps", type=int, default=12, help="without --deliver: this many steps with every frame delivered AFTER the timed region, reported as `delivery` (0 = skip)")
     ap.add_argument("--host-share-ms", type=float, default=None, help="aa_ctx_set_host_share_ms: key frames of a hand-over are parsed by host workers while that is "
                     "expected to take no longer than this on the rank's host threads (library default 80; 0: every frame on the GPU's token lanes)")
     ap.add_argument("--lanes-only-steps", type=int, default=8, help="after the main run: this many steps with host_share_ms = 0 (every frame, key frames too, "
@@ -762,7 +762,7 @@ def main():
                                          "release": round(pipe.t_release / args.steps * 1e3, 1)},
                     "host_waited_for_parse_ms_per_step": round(tstats["parse_wait_ms"] / args.steps, 2),
                     "host_waited_for_compute_stream_ms_per_step": round(tstats["bind_wait_ms"] / args.steps, 2),
-                    "host_in_pool_allocator_ms_per_step": round(tstats["alloc_ms"] / args.steps, 2), "slab_mallocs": tstats["slab_mallocs"],
+                    "host_in_pool_allocator_ms_per_step": round(tstats["alloc_ms"] / args.steps, 2), "slab_mallocs": tstats["slab_mallocs"], "row_handoff_rereads_since_context_creation": tstats["row_handoff_rereads"],
                     "heap_grows": tstats["heap_grows"], "frames_handed_back_for_lack_of_memory": tstats["nomem_retries"], "frames_evicted": tstats["frames_evicted"],
                     "worker_grids_launched": tstats["worker_launches"], "worker_workgroups_launched": tstats["worker_wgs"], "worker_grids_retired": tstats["worker_retires"],
                     "pool_waits": tstats["pool_waits"], "pool_wait_ms_per_step": round(tstats["pool_wait_ms"] / args.steps, 2),
@@ -1028,7 +1028,8 @@ def main():
             delivery = {"leg": "a separate run of %d steps after the timed region (the headline `value` does not deliver); empty pipeline to empty pipeline" % args.deliver_steps,
                         "value": round(mbs_per_step * args.deliver_steps / dt, 1), "unit": "macroblocks/s", "ms_per_step": round(dt / args.deliver_steps * 1e3, 2),
                         "bytes_per_step": p.delivered_bytes // args.deliver_steps, "gb_per_s": round(p.delivered_bytes / dt / 1e9, 2), "copies_per_frame_index": 1,
-                        "first_step_done_at_ms": round((p.done_t[0] - t0) * 1e3)}
+                        "destination_ring": DELIVER_RING, "first_step_done_at_ms": round((p.done_t[0] - t0) * 1e3),
+                        "note": "what the bus gives a lone 1.5-GB device -> pinned-host copy on such a box: 57 GB/s (tools/pcie_probe.py, profiles/r06_pcie_probe.json)"}
             if len(p.done_t) > 1:
                 delivery["between_fill_and_drain_gb_per_s"] = round(p.delivered_bytes * (len(p.done_t) - 1) / len(p.done_t) / (p.done_t[-1] - p.done_t[0]) / 1e9, 2)
             del p
