@@ -52,7 +52,7 @@ class KernelStats(C.Structure):
                 ("bind_wait_ms", C.c_double), ("alloc_ms", C.c_double), ("slab_mallocs", C.c_uint64),
                 ("token_steps", C.c_uint64), ("token_frames", C.c_uint64), ("worker_launches", C.c_uint64), ("worker_wgs", C.c_uint64),
                 ("worker_retires", C.c_uint64), ("heap_grows", C.c_uint64), ("heap_mapped_bytes", C.c_uint64), ("nomem_retries", C.c_uint64), ("frames_evicted", C.c_uint64), ("host_routed_frames", C.c_uint64),
-                ("expand_ms", C.c_double), ("row_handoff_rereads", C.c_uint64), ("packed_frames", C.c_uint64), ("packed_words", C.c_uint64), ("packed_blocks", C.c_uint64),
+                ("row_handoff_stale_polls", C.c_uint64), ("row_handoff_rereads", C.c_uint64), ("packed_frames", C.c_uint64), ("packed_words", C.c_uint64), ("packed_blocks", C.c_uint64),
                 ("host_batch_ms", C.c_double), ("host_batch_parse_wall_ms", C.c_double), ("host_batch_parse_cpu_ms", C.c_double), ("host_batch_arena_ms", C.c_double),
                 ("pinned_allocs", C.c_uint64)]
 

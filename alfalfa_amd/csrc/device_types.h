@@ -40,7 +40,7 @@ struct aa_gather_job {
 
 #define AA_MAX_XCD 16
 
-#define AA_SYNC_WS_DUMP 136
+#define AA_SYNC_WS_DUMP 140
 #define AA_SYNC_WS_RESCUES 132
 // In-launch ordering state of the row-pipelined kernels; zeroed (hipMemsetAsync) before every such launch.
 struct aa_sync_ws {

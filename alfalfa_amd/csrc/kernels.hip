@@ -545,7 +545,22 @@ constexpr int kMinPolls = 1 << 24;
 // (buffer_inv sc1), the address per lane (a vector-addressed load, not the scalar-base form of the poll), system scope, and a
 // read-modify-write that the L2 itself executes.  progress only grows, so the larger value is the truth.  Counted (ws->dump[RESCUES..]):
 // how many waits ended this way, and by which read.
-__device__ __forceinline__ int reread_progress( aa_sync_ws * ws, const int * p, const int seen, const int need )
+#ifndef AA_HANDOFF_POLL_FORM
+#define AA_HANDOFF_POLL_FORM 0        /* build parameter (A/B runs): 1 = the poll itself is a vector-addressed load */
+#endif
+#ifndef AA_HANDOFF_LOOK_EVERY
+#define AA_HANDOFF_LOOK_EVERY 1024    /* build parameter (A/B runs): polls between two second looks (a power of two) */
+#endif
+__device__ __forceinline__ int poll_progress( const int * p )
+{
+#if AA_HANDOFF_POLL_FORM
+  int off = 0;
+  asm volatile( "" : "+v"( off ) );
+  p += off;
+#endif
+  return __hip_atomic_load( p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+}
+__device__ __forceinline__ int reread_progress( aa_sync_ws * ws, const int * p, const int seen, const int need, const int kernel )
 {
   int off = 0;
   asm volatile( "" : "+v"( off ) );                       // (opaque: keeps the address in vector registers)
@@ -554,10 +569,16 @@ __device__ __forceinline__ int reread_progress( aa_sync_ws * ws, const int * p, 
   const int a = __hip_atomic_load( q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
   const int b = __hip_atomic_fetch_or( q, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
   const int best = max( seen, max( a, b ) );
-  if ( seen < need && best >= need && ( threadIdx.x & 15 ) == 0 ) {
-    atomicAdd( &ws->dump[AA_SYNC_WS_RESCUES], 1 );
-    if ( a >= need ) atomicAdd( &ws->dump[AA_SYNC_WS_RESCUES + 1], 1 );
-    if ( b >= need ) atomicAdd( &ws->dump[AA_SYNC_WS_RESCUES + 2], 1 );
+  if ( seen < need && best >= need ) {
+    // (... and the poll's own form once more, behind the reads that saw the value: still short of it = the poll was STALE, not early)
+    const int c = poll_progress( p );
+    if ( ( threadIdx.x & 63 ) == __builtin_ctzll( __ballot( 1 ) ) ) {       // one count per wave
+      atomicAdd( &ws->dump[AA_SYNC_WS_RESCUES], 1 );
+      if ( a >= need ) atomicAdd( &ws->dump[AA_SYNC_WS_RESCUES + 1], 1 );
+      if ( b >= need ) atomicAdd( &ws->dump[AA_SYNC_WS_RESCUES + 2], 1 );
+      if ( c < need ) atomicAdd( &ws->dump[AA_SYNC_WS_RESCUES + 3], 1 );
+      atomicAdd( &ws->dump[AA_SYNC_WS_RESCUES + 3 + kernel], 1 );          // (1: k_recon_intra4, 2: k_loopfilter_rows4)
+    }
   }
   return best;
 }
@@ -850,7 +871,7 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
     const bool has_res = on && ( flags & AA_MB_HAS_NONZERO );
     const bool has_y2 = has_res && ( flags & AA_MB_HAS_Y2 );
     const int need = min( col + 2, mbw );
-    if ( on && row > 0 && seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    if ( on && row > 0 && seen < need ) seen = poll_progress( &progress[row - 1] );
 
     // ---- residual: needs no neighbour, runs before the wait for the row above ----
     residual_x4( S, f, has_res, has_y2, nz_mask, coeff_index, hd.y >> 24, segment, l );
@@ -861,11 +882,11 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
       unsigned long long wait_t0 = 0;
       while ( !__all( !on || seen >= need ) ) {
         __builtin_amdgcn_s_sleep( 4 );
-        if ( on && seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+        if ( on && seen < need ) seen = poll_progress( &progress[row - 1] );
         ++spins;
+        if ( ( spins & ( AA_HANDOFF_LOOK_EVERY - 1 ) ) == 0 && on ) seen = reread_progress( ws, &progress[row - 1], seen, need, 1 );
         if ( ( spins & 1023 ) == 0 ) {
           if ( __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
-          if ( on ) seen = reread_progress( ws, &progress[row - 1], seen, need );
           // the hand-off is only coherent inside the XCD the ticket was taken on: a wave that finds itself elsewhere says so
           if ( xcc_id() != home_xcc ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 4 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( home_xcc << 16 ) | xcc_id(); } break; }
           const unsigned long long now = wall_clock64();
@@ -1379,7 +1400,7 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
       const int info_next = ( frame_on && more ) ? *reinterpret_cast<const uint16_t *>( &mbrow[col + 1].flags ) : 0;
       const int need = col + 1;           // boundary lines 0..col of the row above complete (the last one only at its row's end)
       // progress only grows: what an earlier poll saw stays valid, so a row that runs well behind the row above polls rarely
-      if ( row > 0 && seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+      if ( row > 0 && seen < need ) seen = poll_progress( &progress[row - 1] );
       const bool any_active = __any( active );
       if ( !__all( level == p_level ) ) { P = lf_params_pk( lf_params( active ? level : 1, sharp, key ) ); p_level = level; }     // levels rarely change along a row
       const pk2 g_on = active ? ~0u : 0u, g_in = ( active && inner ) ? ~0u : 0u, g_in23 = ( active && inner && luma ) ? ~0u : 0u;
@@ -1422,11 +1443,11 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
         unsigned long long wait_t0 = 0;
         while ( !__all( seen >= need ) && !( dbg & 16 ) ) {
           __builtin_amdgcn_s_sleep( 4 );
-          if ( seen < need ) seen = __hip_atomic_load( &progress[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+          if ( seen < need ) seen = poll_progress( &progress[row - 1] );
           ++spins;
+          if ( ( spins & ( AA_HANDOFF_LOOK_EVERY - 1 ) ) == 0 ) seen = reread_progress( ws, &progress[row - 1], seen, need, 2 );
           if ( ( spins & 1023 ) == 0 ) {
             if ( __hip_atomic_load( &ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT ) ) break;
-            seen = reread_progress( ws, &progress[row - 1], seen, need );
             // the hand-off is only coherent inside one XCD: a wave that finds itself on another one (context save / restore
             // under queue oversubscription) says so instead of waiting for the watchdog
             if ( xcc_id() != home_xcc ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 4 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( home_xcc << 16 ) | xcc_id(); } break; }

@@ -762,7 +762,7 @@ def main():
                                          "release": round(pipe.t_release / args.steps * 1e3, 1)},
                     "host_waited_for_parse_ms_per_step": round(tstats["parse_wait_ms"] / args.steps, 2),
                     "host_waited_for_compute_stream_ms_per_step": round(tstats["bind_wait_ms"] / args.steps, 2),
-                    "host_in_pool_allocator_ms_per_step": round(tstats["alloc_ms"] / args.steps, 2), "slab_mallocs": tstats["slab_mallocs"], "row_handoff_rereads_since_context_creation": tstats["row_handoff_rereads"],
+                    "host_in_pool_allocator_ms_per_step": round(tstats["alloc_ms"] / args.steps, 2), "slab_mallocs": tstats["slab_mallocs"], "row_handoff_rereads_since_context_creation": tstats["row_handoff_rereads"], "of_which_the_poll_repeated_was_still_stale": tstats["row_handoff_stale_polls"],
                     "heap_grows": tstats["heap_grows"], "frames_handed_back_for_lack_of_memory": tstats["nomem_retries"], "frames_evicted": tstats["frames_evicted"],
                     "worker_grids_launched": tstats["worker_launches"], "worker_workgroups_launched": tstats["worker_wgs"], "worker_grids_retired": tstats["worker_retires"],
                     "pool_waits": tstats["pool_waits"], "pool_wait_ms_per_step": round(tstats["pool_wait_ms"] / args.steps, 2),

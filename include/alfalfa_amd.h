@@ -447,9 +447,10 @@ typedef struct aa_kernel_stats {
   uint64_t frames_evicted;  /* frames parsed ahead of their turn whose chunks were taken back for a frame needed now (parsed again later) */
   uint64_t host_routed_frames; /* frames of aa_submit_frames calls that were parsed by host cores (few streams: one worker per stream; else host lanes) */
   /* packed coefficient storage (aa_ctx_set_packed_coefficients) */
-  double expand_ms;         /* (0 since round 6: the reconstruction kernels read the packed words themselves) */
+  /* (these two took the place of expand_ms / expand_launches: no expansion pass since round 6) */
+  uint64_t row_handoff_stale_polls; /* ... of row_handoff_rereads: waits whose poll, repeated BEHIND the reads that saw the value, still returned the old one */
   uint64_t row_handoff_rereads;   /* waits of the row-pipelined kernels for the row above that the slow path's second look ended (kernels.hip, reread_progress):
-                                     since the context was created, not reset; a count, not an error */
+                                     since the context was created, not reset; counts, not errors */
   uint64_t packed_frames, packed_words, packed_blocks;   /* frames stored packed, the 16-bit words they took, the dense blocks they stand for */
   /* host lanes: host_batch_parse_cpu_ms = the workers' summed parse time (CPU seconds x 1000; a diagnostic sum); host_batch_ms,
    * host_batch_parse_wall_ms, host_batch_arena_ms: 0 since round 5 (nothing of a submit call waits for host parsing any more) */

@@ -26,17 +26,21 @@ def main():
     failed = rescued_runs = rescues = 0
     for i in range(a.runs):
         t = time.time()
-        r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, ALFALFA_AMD_HANDOFF_REPORT="1"))
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         d = json.loads(line[-1]) if line else {}
         n = (d.get("timed_region") or {}).get("row_handoff_rereads_since_context_creation")
+        stale = (d.get("timed_region") or {}).get("of_which_the_poll_repeated_was_still_stale")
         ok = r.returncode == 0 and bool(d)
         failed += not ok
         if n:
             rescued_runs += 1; rescues += n
         err = "" if ok else (r.stderr.strip().splitlines() or ["?"])[-1][:600]
-        print("run %2d  rc %d  %5.1f s  value %6.1f M  bit-exact %s  rereads %s  %s" % (i, r.returncode, time.time() - t, d.get("value", 0) / 1e6,
-              (d.get("verified_bit_exact_vs_reference") or {}).get("bit_exact"), n, err), flush=True)
+        rep = [l for l in r.stderr.splitlines() if "row hand-off waits" in l]
+        if rep:
+            err = rep[-1][12:] + " " + err
+        print("run %2d  rc %d  %5.1f s  value %6.1f M  bit-exact %s  rereads %s (poll still stale: %s)  %s" % (i, r.returncode, time.time() - t, d.get("value", 0) / 1e6,
+              (d.get("verified_bit_exact_vs_reference") or {}).get("bit_exact"), n, stale, err), flush=True)
     print(json.dumps({"runs": a.runs, "failed": failed, "runs_with_rereads": rescued_runs, "rereads": rescues}))
 
 
