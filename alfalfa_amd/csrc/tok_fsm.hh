@@ -923,7 +923,7 @@ template <bool MP = false> AA_HD inline bool at_boundary( const Lane & L ) { ret
 
 // ---- one step: decode one bool (lanes with a node to decode; the others sit it out) -------------------------------------
 // Straight-line code: what the bit means comes out of the node's record as bit fields and is applied with arithmetic;
-// the only predicated region is the coefficient store.  A lone wave gets one issue slot every 4 cycles whatever the
+// nothing is predicated (the coefficient store was until round 6's session 14: see there).  A lone wave gets one issue slot every 4 cycles whatever the
 // instruction -- vector, scalar, branch or wait -- so every instruction saved here is 4 cycles per bool.
 //
 // The END OF A BLOCK is not part of the step (it was, as a predicated region: ~55 issue slots that the wave paid whenever ANY of
@@ -940,8 +940,8 @@ template <bool PK, bool MP = false>
 AA_HD inline void step( Lane & L, uint8_t * smem, const Frame & J )
 {
   (void) J;
-  // EVERY lane runs the step (idle lanes: see "nodes" above); no condition, no branch -- the one predicated instruction is the
-  // coefficient store.  The LDS reads of a step; all addresses were known at the end of the previous one
+  // EVERY lane runs the step (idle lanes: see "nodes" above); no condition, no branch, nothing predicated.  The LDS reads of a step;
+  // all addresses were known at the end of the previous one
 #if AA_STEP_PRELOAD
   const uint32_t pbyte = L.pre_prob, raw = L.pre_raw, nband = L.pre_band;   // (asked for when the previous step -- or whoever moved the lane since -- knew the addresses)
   const V8 rec = L.pre_rec;

@@ -219,9 +219,9 @@ typedef struct aa_ctx_info {
   uint32_t host_waited_compute_ms;   /* ... for a raster-binding buffer: the compute stream was 16 calls behind (= bind_wait_ms) */
 } aa_ctx_info;
 aa_status aa_ctx_get_info( aa_ctx * ctx, aa_ctx_info * out );
-/* How the device parser stores a frame's coefficients until the frame is reconstructed.  1 (default): packed -- one mask word +
- * the block's non-zero coefficients (about a third of the memory on video content, and fewer stores for the token lanes);
- * aa_decode_batch expands the frames it is given into a transient dense array on the device before reconstructing them.
+/* How the device parser stores a frame's coefficients until the frame is reconstructed.  1 (default): packed -- per macroblock 25
+ * mask slots + the non-zero coefficients in parse order (about a third of the memory on video content, and fewer stores for the
+ * token lanes); the reconstruction kernels read that form themselves (since round 6: no dense copy is made).
  * 0: dense, 32 bytes per non-zero 4x4 block.  Results are identical.  The choice is per context and can only be made before
  * the context's first aa_submit_frames call (AA_ERR_LOGIC afterwards); the environment variable ALFALFA_AMD_PACKED=0 makes
  * dense the default of every context. */
