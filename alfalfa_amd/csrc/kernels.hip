@@ -545,6 +545,14 @@ constexpr int kMinPolls = 1 << 24;
 // (buffer_inv sc1), the address per lane (a vector-addressed load, not the scalar-base form of the poll), system scope, and a
 // read-modify-write that the L2 itself executes.  progress only grows, so the larger value is the truth.  Counted (ws->dump[RESCUES..]):
 // how many waits ended this way, and by which read.
+#ifndef AA_HANDOFF_PUBLISH_AGENT
+#define AA_HANDOFF_PUBLISH_AGENT 0    /* build parameter (A/B runs): 1 = a row's progress word is stored with agent scope (sc1: written through), not workgroup scope */
+#endif
+#if AA_HANDOFF_PUBLISH_AGENT
+#define AA_PUBLISH_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#else
+#define AA_PUBLISH_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
 #ifndef AA_HANDOFF_POLL_FORM
 #define AA_HANDOFF_POLL_FORM 0        /* build parameter (A/B runs): 1 = the poll itself is a vector-addressed load */
 #endif
@@ -860,7 +868,7 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
     // has run out of intra macroblocks publishes the whole row at once -- it must not hold the rows below it back until
     // the OTHER three frames of the wave are through.
     asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-    if ( frame_on && l == 0 && ( on || !row_done ) ) __hip_atomic_store( &progress[row], on ? col : mbw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+    if ( frame_on && l == 0 && ( on || !row_done ) ) __hip_atomic_store( &progress[row], on ? col : mbw, __ATOMIC_RELAXED, AA_PUBLISH_SCOPE );
     row_done = row_done || !on;
 
     const aa_mb_info * const mb = f.mbs + static_cast<size_t>( row ) * mbw + col;
@@ -985,7 +993,7 @@ __device__ __forceinline__ void recon_intra4_row( const aa_frame_list & list, co
     __syncthreads();
   }
   asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-  if ( frame_on && l == 0 && !row_done ) __hip_atomic_store( &progress[row], mbw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+  if ( frame_on && l == 0 && !row_done ) __hip_atomic_store( &progress[row], mbw, __ATOMIC_RELAXED, AA_PUBLISH_SCOPE );
 }
 
 __global__ __launch_bounds__( kLanes ) void k_recon_intra4( const aa_frame_list list, const int n_groups, const int mbh_max, aa_sync_ws * ws, const int n_xcd )
@@ -1469,7 +1477,7 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
       // every boundary line up to macroblock col-1 is complete and has reached the L2 (the fix-up above drained behind the
       // wait for the row above): publish
       asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-      if ( lane == 0 && col > 0 ) __hip_atomic_store( &progress[row], col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+      if ( lane == 0 && col > 0 ) __hip_atomic_store( &progress[row], col, __ATOMIC_RELAXED, AA_PUBLISH_SCOPE );
       // the next strip's own rows: issued here so that no wait of THIS step covers them (vmcnt completes in order); they
       // have the rest of the strip to arrive
       if ( k == 0 && s + 1 < n_strips ) prefetch( s + 1 );
@@ -1529,7 +1537,7 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
     }
   }
   asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );       // the last macroblock's line has no right neighbour to wait for
-  if ( lane == 0 ) __hip_atomic_store( &progress[row], mbw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+  if ( lane == 0 ) __hip_atomic_store( &progress[row], mbw, __ATOMIC_RELAXED, AA_PUBLISH_SCOPE );
 }
 
 __device__ __forceinline__ void loopfilter_rows4_body( const aa_frame_list & list, const int n_groups, const int mbh_max, const int mbw_max, aa_sync_ws * ws, uint8_t * bnd,
