@@ -605,6 +605,12 @@ __device__ __noinline__ void wait_expired( aa_sync_ws * ws, const int code, cons
     ws->dump[128] = spins; ws->dump[129] = static_cast<int>( waited / 100000ull ); ws->dump[130] = mbh;      // (ms)
   }
 }
+// Test hooks riding in k_loopfilter_rows4's `dbg` argument (ALFALFA_AMD_LF_DEBUG, see lf_debug_bits): bit 5 = FAULT INJECTION -- row 1 of every
+// unit never publishes its progress, so row 2 waits until its wait expires (tests/test_gpu_parity.py: the error, its dump and that nothing
+// hangs); bits 8-15 = the wait's time bound in quarters of a second (0: kMaxWaitTicks), bits 16-20 = log2 of its poll bound (0: kMinPolls).
+__device__ __forceinline__ bool lf_fault_injected( const int dbg, const int row ) { return ( dbg & 32 ) && row == 1; }
+__device__ __forceinline__ unsigned long long lf_max_wait_ticks( const int dbg ) { const int q = ( dbg >> 8 ) & 255; return q ? static_cast<unsigned long long>( q ) * 25000000ull : kMaxWaitTicks; }
+__device__ __forceinline__ int lf_min_polls( const int dbg ) { const int e = ( dbg >> 16 ) & 31; return e ? 1 << e : kMinPolls; }
 __device__ __forceinline__ int xcc_id() { return static_cast<int>( __builtin_amdgcn_s_getreg( 20 | ( 0 << 6 ) | ( 3 << 11 ) ) ); }   // HW_REG_XCC_ID[3:0]
 
 __device__ __forceinline__ int take_ticket( aa_sync_ws * ws, const int xcc, int * slot, const int lane )
@@ -1461,7 +1467,7 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
             if ( xcc_id() != home_xcc ) { if ( lane == 0 && atomicCAS( &ws->error, 0, 4 ) == 0 ) { ws->where[0] = group; ws->where[1] = row; ws->where[2] = ( home_xcc << 16 ) | xcc_id(); } break; }
             const unsigned long long now = wall_clock64();
             if ( !wait_t0 ) wait_t0 = now;
-            else if ( spins > kMinPolls && now - wait_t0 > kMaxWaitTicks ) { wait_expired( ws, 2, group, row, need, seen, progress, mbh, spins, now - wait_t0 ); break; }
+            else if ( spins > lf_min_polls( dbg ) && now - wait_t0 > lf_max_wait_ticks( dbg ) ) { wait_expired( ws, 2, group, row, need, seen, progress, mbh, spins, now - wait_t0 ); break; }
           }
         }
   
@@ -1477,7 +1483,7 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
       // every boundary line up to macroblock col-1 is complete and has reached the L2 (the fix-up above drained behind the
       // wait for the row above): publish
       asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-      if ( lane == 0 && col > 0 ) __hip_atomic_store( &progress[row], col, __ATOMIC_RELAXED, AA_PUBLISH_SCOPE );
+      if ( lane == 0 && col > 0 && !lf_fault_injected( dbg, row ) ) __hip_atomic_store( &progress[row], col, __ATOMIC_RELAXED, AA_PUBLISH_SCOPE );
       // the next strip's own rows: issued here so that no wait of THIS step covers them (vmcnt completes in order); they
       // have the rest of the strip to arrive
       if ( k == 0 && s + 1 < n_strips ) prefetch( s + 1 );
@@ -1537,7 +1543,7 @@ __device__ __forceinline__ void loopfilter_strip_row( const aa_frame_list & list
     }
   }
   asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );       // the last macroblock's line has no right neighbour to wait for
-  if ( lane == 0 ) __hip_atomic_store( &progress[row], mbw, __ATOMIC_RELAXED, AA_PUBLISH_SCOPE );
+  if ( lane == 0 && !lf_fault_injected( dbg, row ) ) __hip_atomic_store( &progress[row], mbw, __ATOMIC_RELAXED, AA_PUBLISH_SCOPE );
 }
 
 __device__ __forceinline__ void loopfilter_rows4_body( const aa_frame_list & list, const int n_groups, const int mbh_max, const int mbw_max, aa_sync_ws * ws, uint8_t * bnd,
@@ -1720,6 +1726,7 @@ int launch_loopfilter_diagonal( const aa_frame_list & list, int n, int diagonal,
 }
 // Measurement hook (tools/row_kernel_probe.py): ALFALFA_AMD_LF_DEBUG=<bits> switches parts of the loop-filter row kernel
 // OFF (1 stores, 2 own-row loads, 4 filter arithmetic, 8 loads of the rows above, 16 waiting).  Output is then invalid.
+// Bit 5 and bits 8-20: fault injection and the waits' bounds for the test of the expired-wait path (lf_fault_injected).
 static int lf_debug_bits()
 {
   static const int bits = [] { const char * e = std::getenv( "ALFALFA_AMD_LF_DEBUG" ); return e ? std::atoi( e ) : 0; }();

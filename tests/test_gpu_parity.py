@@ -310,3 +310,40 @@ def test_a_ring_of_destination_buffers_waits_for_the_copy_that_used_the_buffer(g
         gpu_ctx.sync()
         for p in ring:
             gpu_ctx.pinned_free(p)
+
+
+def test_an_expired_row_kernel_wait_is_reported_with_what_the_waiting_wave_saw():
+    """Fault injection into the row kernels' in-launch hand-off (ALFALFA_AMD_LF_DEBUG bit 5: row 1 of every unit never publishes its
+    progress; bits 8-20: the wait's bounds brought down to a second and 2^16 polls): row 2 must give up -- not hang --, the call that
+    synchronises must fail with AA_ERR_HIP, and the message must carry what the waiting wave saw of its unit's rows (row 0 complete,
+    row 1 silent).  A process of its own: the hook is read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import alfalfa_amd as aa
+from conftest import golden_frames
+w, h, frames = golden_frames("qcif_q30_lf24")
+ctx = aa.Context(0)
+decs = [aa.Decoder(ctx, w, h) for _ in range(4)]
+try:
+    for f in range(2):
+        for d in decs:
+            d.parse_frame(frames[f])
+        ctx.decode_batch(decs, [f] * len(decs))
+    ctx.sync()
+    print("NO ERROR")
+except aa.AlfalfaError as e:
+    print("ERROR %s: %s" % (e.kind, e))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ALFALFA_AMD_LF_DEBUG=str(32 | (4 << 8) | (16 << 16)))
+    r = subprocess.run([sys.executable, "-c", code, root], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    out = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-800:]
+    assert out.startswith("ERROR HipError"), out
+    assert "k_loopfilter_rows4: a bounded wait for the macroblock row above expired" in out, out
+    import re
+    assert re.search(r"first at unit 0 row [2-8], needed 1 saw 0", out), out        # (rows 2 .. 8 all wait; whichever gives up first says so)
+    assert "columns done per row of that unit when it gave up: 11,0,0,0,0,0,0,0,0" in out, out
